@@ -1,0 +1,155 @@
+/*
+ * mgvcycle.h - C ABI of libmgvcycle.so, the MI355X (gfx950) multigrid-cycle library.
+ *
+ * Drop-in boundary for the hot path of JuliaInv/Multigrid.jl (reference @ v0.8.0):
+ *   recursiveCycle  src/Multigrid/MGcycle.jl:1-118      -> mg_cycle_*
+ *   relax           src/Multigrid/MGcycle.jl:122-136    -> fused inside mg_cycle_*
+ *   solveCoarsest   src/Multigrid/MGcycle.jl:138-181    -> fused inside mg_cycle_* (default branch l.177)
+ *   solveMG         src/Multigrid/SolveFuncs.jl:3-39    -> mg_solve_*
+ *   SpMatMul        src/Multigrid/SpMatMul.jl:4-26      -> mg_spmv_*
+ *   addVectors      src/Multigrid/SpMatMul.jl:29-37     -> fused into the SpMV epilogues
+ *   MGparam         src/Multigrid/MGdef.jl:91-116       -> mg_hierarchy (opaque) + mg_set_*
+ *   adjustMemoryForNumRHS  src/Multigrid/MGsetup.jl:166-223 -> mg_set_nrhs
+ *   replaceMatrixInHierarchy (numeric part) MGsetup.jl:226-270 -> mg_replace_values_FP64
+ *   clear!/destroyCoarsestLU  MGdef.jl:179-206          -> mg_destroy
+ *
+ * Calling convention follows the reference's own ccall idiom (src/Multigrid/parRelax.jl:61-64,
+ * deps/src/parRelax.h:7-43): sparse operators are passed exactly as Julia's SparseMatrixCSC holds
+ * them - colptr/rowval as 1-based Int64, nzval as Float64 - and the library subtracts 1; scalars are
+ * long long / double; symbols carry the _FP64_INT64 suffix.  Unlike the reference's void functions,
+ * every entry point returns an int status (MG_OK == 0) and mg_last_error() returns the message.
+ *
+ * The reference stores every operator TRANSPOSED (MGdef.jl:75-77), so the CSC arrays of AT are the
+ * CSR arrays of A: colptr = row pointers, rowval = column indices.  "n_rows" below is therefore
+ * length(colptr)-1 = size(AT,2) and "n_cols" is size(AT,1).
+ *
+ * Ownership: the caller owns every host array; the library copies the hierarchy to HBM inside
+ * mg_set_* / mg_finalize and retains no host pointer.  b is read-only, x is in/out in the caller's
+ * buffer (the in-place contract test/Multigrid/testGMG.jl:54-55 asserts).  A handle is not
+ * thread-safe (neither is MGparam: the F-cycle mutates it, MGcycle.jl:82-84).
+ */
+#ifndef MGVCYCLE_H
+#define MGVCYCLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mg_hierarchy mg_hierarchy;
+
+/* status codes */
+#define MG_OK 0
+#define MG_ERR_INVALID 1   /* bad argument / inconsistent hierarchy */
+#define MG_ERR_HIP 2       /* HIP runtime error (no device, out of memory, launch failure) */
+#define MG_ERR_STATE 3     /* call out of order (e.g. cycle before finalize) */
+#define MG_ERR_UNSUPPORTED 4
+
+/* operator selector for mg_set_operator / mg_spmv / mg_replace_values */
+#define MG_OP_A 0 /* As[level]  : n_l x n_l                                  */
+#define MG_OP_P 1 /* Ps[level]  : CSR of P, n_l rows  x n_{l+1} cols         */
+#define MG_OP_R 2 /* Rs[level]  : CSR of R, n_{l+1} rows x n_l cols          */
+
+/* kernel selector for mg_time_op_dev_FP64 / mg_profile_get */
+#define MG_K_SPMV 0     /* y = alpha*A*x + beta*y          (SpMatMul.jl:4-13)          */
+#define MG_K_RESIDUAL 1 /* r = b - A*x                     (MGcycle.jl:58-60 fused)    */
+#define MG_K_SMOOTH 2   /* x' = x + d.*(b - A*x)           (MGcycle.jl:128-131 fused)  */
+#define MG_K_RESTRICT 3 /* bc = R*r                        (MGcycle.jl:66)             */
+#define MG_K_PROLONG 4  /* x += P*xc                       (MGcycle.jl:90)             */
+#define MG_K_DSCALE 5   /* x = d.*b (first sweep from x=0) (MGcycle.jl:134)            */
+#define MG_K_COARSE 6   /* xc = LU \ bc                    (MGcycle.jl:177)            */
+#define MG_K_NORM 7     /* ||r||^2                         (SolveFuncs.jl:30)          */
+#define MG_K_COUNT 8
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+
+/* Allocate an empty hierarchy of `nlevels` levels (length(param.As)) on HIP device `device_id`,
+ * sized for `nrhs` right-hand sides.  Levels are 1-based in every call below, as in the reference. */
+int mg_create(long long nlevels, long long nrhs, long long device_id, mg_hierarchy** out);
+
+/* Upload one operator from Julia's CSC-of-the-transpose arrays (1-based Int64). */
+int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which,
+                               long long n_rows, long long n_cols,
+                               const long long* colptr, const long long* rowval, const double* nzval);
+
+/* relaxPrecs[level] (length n_level) and relaxPre(level)/relaxPost(level) evaluated by the host
+ * (they are Julia functions of the level, MGdef.jl:98-99). */
+int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long long n,
+                      long long relaxPre, long long relaxPost);
+
+/* cycleType: 'V', 'W' or 'F' (MGcycle.jl:78-85).  'K' is not on the device path yet. */
+int mg_set_cycle_type(mg_hierarchy* h, long long cycleType);
+
+/* Coarsest solve, default branch `z = param.LU\b` (MGcycle.jl:177): the host factors the coarsest
+ * operator (UMFPACK in the reference, MGsetup.jl:350) and hands over the explicit inverse,
+ * column-major n x n, applied on device as a dense product. */
+int mg_set_coarse_dense_inverse_FP64(mg_hierarchy* h, long long n, const double* Ainv_colmajor);
+
+/* Validate the hierarchy (shapes chain, every level complete), build the row-block partitions,
+ * allocate the per-level b/r/x scratch (CYCLEmem, MGdef.jl:56-60). */
+int mg_finalize(mg_hierarchy* h);
+
+/* adjustMemoryForNumRHS: re-size the scratch when the number of RHS columns changes. */
+int mg_set_nrhs(mg_hierarchy* h, long long nrhs);
+
+/* Replace the numerical values of an operator whose sparsity is unchanged (nnz must match). */
+int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which,
+                           const double* nzval, long long nnz);
+
+int mg_destroy(mg_hierarchy* h);
+
+/* ---- the hot path, host buffers (what the Julia glue ccalls) -------------------------------- */
+
+/* One cycle x <- recursiveCycle(param,b,x,1).  b, x: column-major n x nrhs (Julia Array{Float64}).
+ * x_is_zero: 1 = caller guarantees x==0 (preconditioner closure, SolveFuncs.jl:59), 0 = x!=0,
+ * -1 = decide like the reference does with norm(x)>0 (MGcycle.jl:29). */
+int mg_cycle_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
+                  long long x_is_zero);
+
+/* solveMG: cycles until ||b-Ax||_F/||r0||_F < tol or maxIter (SolveFuncs.jl:14-37).
+ * resvec (length maxIter+1, may be NULL) receives r0 and the residual norm after every cycle. */
+int mg_solve_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
+                  double tol, long long maxIter, long long* iters, double* resvec);
+
+/* target = beta*target + alpha*Op*x on one level (SpMatMul.jl:4-13); column-major host blocks. */
+int mg_spmv_FP64(mg_hierarchy* h, long long level, long long which, double alpha, const double* x,
+                 double beta, double* y, long long nrhs);
+
+/* ---- the hot path, device-resident buffers -------------------------------------------------- */
+/* Same semantics with b/x already in HBM (hipMalloc'd or torch tensors' data_ptr).  Blocks with
+ * nrhs>1 use the library's device layout: row-major [n][nrhs].  Work is enqueued on the library's
+ * stream; the call returns after the stream has drained (synchronous from the host's view). */
+int mg_cycle_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n,
+                      long long nrhs, long long x_is_zero);
+int mg_solve_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n,
+                      long long nrhs, double tol, long long maxIter, long long* iters,
+                      double* resvec);
+int mg_spmv_dev_FP64(mg_hierarchy* h, long long level, long long which, double alpha,
+                     const double* x_dev, double beta, double* y_dev, long long nrhs);
+/* Fused forms used inside the cycle, exposed for kernel-level parity tests:
+ *   MG_K_RESIDUAL: out = b - A*x ;  MG_K_SMOOTH: out = x + d.*(b - A*x)   (out must not alias x). */
+int mg_fused_dev_FP64(mg_hierarchy* h, long long level, long long kernel, const double* b_dev,
+                      const double* x_dev, double* out_dev, long long nrhs);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Launch kernel `kernel` of `level` `reps` times back to back on the library's stream between two
+ * HIP events and return the average duration in ms; *bytes receives the ALGORITHMIC bytes of one
+ * launch. */
+int mg_time_op_dev_FP64(mg_hierarchy* h, long long level, long long kernel, long long nrhs,
+                        long long reps, double* ms_avg, double* bytes);
+/* Per-kernel HIP-event accounting of everything the cycle launches (off by default). */
+int mg_profile_enable(mg_hierarchy* h, long long on);
+int mg_profile_get(mg_hierarchy* h, long long level, long long kernel, double* total_ms,
+                   long long* launches, double* bytes_per_launch);
+int mg_profile_reset(mg_hierarchy* h);
+/* Algorithmic HBM bytes of one full cycle (x0 = 0) with the current nrhs, DESIGN.md section 5. */
+int mg_cycle_bytes(mg_hierarchy* h, double* bytes);
+/* HBM bytes held by the hierarchy. */
+int mg_device_bytes(mg_hierarchy* h, double* bytes);
+
+const char* mg_last_error(void);
+const char* mg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGVCYCLE_H */

@@ -1,0 +1,17 @@
+"""multigrid.jl_amd - MI355X-native multigrid cycle behind the MGparam / MGsetup / solveMG surface
+of JuliaInv/Multigrid.jl.  Host side (this package): hierarchy setup on the CPU, as in the reference.
+Device side (csrc/): the cycle itself, hand-written HIP for gfx950, reached through the C ABI in
+include/mgvcycle.h.  Import as ``import multigrid_jl_amd`` (shim at the repo root: the directory
+name carries a dot).
+"""
+from .mgdef import (MGparam, getMGparam, hierarchyExists, destroyCoarsestLU, copySolver, clear_)
+from .mgsetup import (MGsetup, getRelaxPrec, getSPAIprec, adjustMemoryForNumRHS, replaceMatrixInHierarchy,
+                      transposeHierarchy, defineCoarsestAinv, multilevelOperatorConstructor,
+                      getMultilevelOperatorConstructor, galerkin)
+from .transfer_operators import getFWInterp, get1DFWInterp
+from .solve_funcs import solveMG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
+from .operators import (getRegularMesh, getNodalGradientMatrix, getNodalLaplacianMatrix,
+                        getNodalDivSigGradMatrix, poisson_shifted, anisotropic_divsiggrad, seeded_rhs)
+from . import device
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,341 @@
+// mg_kernels.hpp - hand-written gfx950 (CDNA4, wave64) kernels of the multigrid cycle.
+//
+// Every SpMV/SpMM on the reference's hot path is a row-parallel CSR gather product
+// (reference src/Multigrid/SpMatMul.jl:4-26; the arrays of the transposed CSC are the CSR arrays of A,
+// MGdef.jl:75-77).  All kernels here are HBM-bandwidth bound (0.13-0.65 flop/B): no MFMA.
+//
+// CSR-stream layout of one launch:
+//   * the host cuts the rows into "row blocks": consecutive rows whose non-zeros fit one LDS chunk
+//     (MG_CHUNK entries) - so a workgroup streams ONE contiguous nnz segment of val/colidx with
+//     16 B / 8 B per lane fully coalesced loads, independent of the row lengths;
+//   * products val*x[col] are staged in LDS; each row is then reduced from LDS (segmented reduction:
+//     1..64 lanes per row depending on how many rows the block holds) and the epilogue
+//     (axpby / residual / damped-Jacobi update) is fused, so the vectors are touched once;
+//   * blockIdx is remapped so that each XCD (private 4 MiB L2) walks one contiguous band of rows:
+//     the x gather window (3 grid planes for a 7-point stencil) then lives in that XCD's L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgk {
+
+constexpr int BLK = 256;            // threads per workgroup (4 waves)
+constexpr int ITEMS = 8;            // non-zeros per thread per chunk
+constexpr int CHUNK = BLK * ITEMS;  // 2048 non-zeros staged per workgroup (16 KiB of products)
+constexpr int MAXROWS = 256;        // rows per row block (one LDS row-pointer slot per thread)
+constexpr int PAIRS = ITEMS / 2;
+
+enum Mode { AXPBY = 0, RESID = 1, SMOOTH = 2 };
+
+struct CsrDev {
+  const int* rowptr;   // n_rows+1, 0-based
+  const int* colidx;   // nnz (+pad), 0-based
+  const double* val;   // nnz (+pad)
+  const int* blk_row;  // nblocks+1 row-block boundaries
+  int nblocks;
+  int n_rows;
+  int n_cols;
+};
+
+struct VecArgs {
+  const double* x;  // gathered vector           [n_cols][nrhs]
+  double* y;        // output                    [n_rows][nrhs]
+  const double* b;  // RESID / SMOOTH            [n_rows][nrhs]
+  const double* d;  // SMOOTH: relaxPrec          [n_rows]
+  double alpha;     // AXPBY
+  double beta;      // AXPBY
+  int nrhs;
+};
+
+// Each XCD gets a contiguous band of logical blocks (workgroups are dealt round-robin over the 8 XCDs:
+// MI355X_MICROARCH.md "Workgroup dispatch").  Bijective for every nb.  Placement only affects speed.
+__device__ __forceinline__ int xcd_band(int bid, int nb) {
+  const int q = nb >> 3, rem = nb & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return xcd * q + (xcd < rem ? xcd : rem) + idx;
+}
+
+template <int MODE>
+__device__ __forceinline__ double epilogue(const VecArgs& v, int row, double acc, double pb, double pd,
+                                           double px) {
+  if (MODE == AXPBY) return v.alpha * acc + pb;  // pb = beta*y[row] (0 when beta == 0)
+  if (MODE == RESID) return pb - acc;            // pb = b[row]
+  return px + pd * (pb - acc);                   // SMOOTH: x + d*(b - A x)
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR-stream SpMV, one right-hand side.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
+  __shared__ double prod[CHUNK];
+  __shared__ int srow[MAXROWS + 1];
+  __shared__ double red[BLK / 64];
+
+  const int tid = threadIdx.x;
+  const int bid = xcd_band(blockIdx.x, A.nblocks);
+  const int r0 = A.blk_row[bid];
+  const int r1 = A.blk_row[bid + 1];
+  const int nrows = r1 - r0;
+  const int k0 = A.rowptr[r0];
+  const int k1 = A.rowptr[r1];
+
+  if (nrows == 1 && (k1 - k0) > CHUNK - 2) {
+    // One row longer than a chunk: the whole workgroup strides over it.
+    double acc = 0.0;
+    for (int k = k0 + tid; k < k1; k += BLK) acc += A.val[k] * v.x[A.colidx[k]];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) s += red[w];
+      double pb = 0.0, pd = 0.0, px = 0.0;
+      if (MODE == AXPBY) pb = (v.beta != 0.0) ? v.beta * v.y[r0] : 0.0;
+      else pb = v.b[r0];
+      if (MODE == SMOOTH) { pd = v.d[r0]; px = v.x[r0]; }
+      v.y[r0] = epilogue<MODE>(v, r0, s, pb, pd, px);
+    }
+    return;
+  }
+
+  // lanes per row in the reduction phase: as many as the block's row count leaves room for
+  int sh = 0;
+  while (sh < 6 && (2 << sh) * nrows <= BLK) ++sh;
+  const int tpr = 1 << sh;
+  const int lrow = tid >> sh;
+  const int sub = tid & (tpr - 1);
+  const bool owner = (lrow < nrows) && (sub == 0);
+
+  // ---- issue every global load up front: matrix stream, row pointers, epilogue operands -------
+  const int base = k0 & ~1;  // 16-B aligned start of the value stream
+  double2 va[PAIRS];
+  int2 ca[PAIRS];
+#pragma unroll
+  for (int it = 0; it < PAIRS; ++it) {
+    const int idx = base + it * (2 * BLK) + 2 * tid;
+    if (idx < k1) {
+      va[it] = *reinterpret_cast<const double2*>(A.val + idx);
+      ca[it] = *reinterpret_cast<const int2*>(A.colidx + idx);
+    } else {
+      va[it] = make_double2(0.0, 0.0);
+      ca[it] = make_int2(0, 0);
+    }
+  }
+  if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
+  if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
+  double pb = 0.0, pd = 0.0, px = 0.0;
+  if (owner) {
+    const int row = r0 + lrow;
+    if (MODE == AXPBY) { if (v.beta != 0.0) pb = v.beta * v.y[row]; }
+    else pb = v.b[row];
+    if (MODE == SMOOTH) { pd = v.d[row]; px = v.x[row]; }
+  }
+  // ---- gather x and stage the products --------------------------------------------------------
+#pragma unroll
+  for (int it = 0; it < PAIRS; ++it) {
+    const int idx = base + it * (2 * BLK) + 2 * tid;
+    if (idx < k1) {
+      double2 p;
+      p.x = va[it].x * v.x[ca[it].x];
+      p.y = va[it].y * v.x[ca[it].y];
+      *reinterpret_cast<double2*>(&prod[it * (2 * BLK) + 2 * tid]) = p;
+    }
+  }
+  __syncthreads();
+  // ---- segmented reduction from LDS + fused epilogue -------------------------------------------
+  double acc = 0.0;
+  if (lrow < nrows) {
+    const int s = srow[lrow], e = srow[lrow + 1];
+    for (int k = s + sub; k < e; k += tpr) acc += prod[k];
+  }
+  for (int o = tpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (owner) v.y[r0 + lrow] = epilogue<MODE>(v, r0 + lrow, acc, pb, pd, px);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR-stream SpMM, nrhs > 1, vectors row-major [n][nrhs].
+// The nnz segment (values AND column indices) is staged in LDS with coalesced loads; then G lanes
+// (G = pow2 >= nrhs, <= 64) own one row x one RHS column each and walk the row from LDS (broadcast
+// reads); every x gather is one contiguous nrhs*8-byte segment.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int G) {
+  __shared__ double sval[CHUNK];
+  __shared__ int scol[CHUNK];
+  __shared__ int srow[MAXROWS + 1];
+
+  const int tid = threadIdx.x;
+  const int bid = xcd_band(blockIdx.x, A.nblocks);
+  const int r0 = A.blk_row[bid];
+  const int r1 = A.blk_row[bid + 1];
+  const int nrows = r1 - r0;
+  const int k0 = A.rowptr[r0];
+  const int k1 = A.rowptr[r1];
+  const int nrhs = v.nrhs;
+  const int grp = tid / G;
+  const int c = tid - grp * G;
+  const int ngrp = BLK / G;
+
+  const bool longrow = (nrows == 1 && (k1 - k0) > CHUNK - 2);
+  if (!longrow) {
+    const int base = k0 & ~1;
+#pragma unroll
+    for (int it = 0; it < PAIRS; ++it) {
+      const int idx = base + it * (2 * BLK) + 2 * tid;
+      if (idx < k1) {
+        *reinterpret_cast<double2*>(&sval[it * (2 * BLK) + 2 * tid]) =
+            *reinterpret_cast<const double2*>(A.val + idx);
+        *reinterpret_cast<int2*>(&scol[it * (2 * BLK) + 2 * tid]) =
+            *reinterpret_cast<const int2*>(A.colidx + idx);
+      }
+    }
+    if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
+    if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
+    __syncthreads();
+  }
+  for (int c0 = 0; c0 < nrhs; c0 += G) {
+    const int col = c0 + c;
+    const bool cact = col < nrhs;
+    for (int lr = grp; lr < nrows; lr += ngrp) {
+      const int row = r0 + lr;
+      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+      if (cact) {
+        if (!longrow) {
+          const int s = srow[lr], e = srow[lr + 1];
+          int k = s;
+          for (; k + 4 <= e; k += 4) {
+            const double x0 = v.x[(size_t)scol[k] * nrhs + col];
+            const double x1 = v.x[(size_t)scol[k + 1] * nrhs + col];
+            const double x2 = v.x[(size_t)scol[k + 2] * nrhs + col];
+            const double x3 = v.x[(size_t)scol[k + 3] * nrhs + col];
+            acc0 += sval[k] * x0;
+            acc1 += sval[k + 1] * x1;
+            acc2 += sval[k + 2] * x2;
+            acc3 += sval[k + 3] * x3;
+          }
+          for (; k < e; ++k) acc0 += sval[k] * v.x[(size_t)scol[k] * nrhs + col];
+        } else {
+          for (int k = k0; k < k1; ++k) acc0 += A.val[k] * v.x[(size_t)A.colidx[k] * nrhs + col];
+        }
+        const double acc = (acc0 + acc1) + (acc2 + acc3);
+        const size_t o = (size_t)row * nrhs + col;
+        double pb = 0.0, pd = 0.0, px = 0.0;
+        if (MODE == AXPBY) { if (v.beta != 0.0) pb = v.beta * v.y[o]; }
+        else pb = v.b[o];
+        if (MODE == SMOOTH) { pd = v.d[row]; px = v.x[o]; }
+        v.y[o] = epilogue<MODE>(v, row, acc, pb, pd, px);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Element-wise helpers (grid-stride, 16 B per lane where the length allows).
+// ------------------------------------------------------------------------------------------------
+// x[i][c] = d[i] * b[i][c] : first damped-Jacobi sweep from x = 0 (MGcycle.jl:134 with r = b).
+__global__ __launch_bounds__(BLK) void dscale_kernel(const double* __restrict__ d,
+                                                     const double* __restrict__ b,
+                                                     double* __restrict__ x, long long n, int nrhs) {
+  const long long total = n * nrhs;
+  const long long stride = (long long)gridDim.x * BLK;
+  if (nrhs == 1) {
+    const long long n2 = total >> 1;
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n2; i += stride) {
+      const double2 dd = reinterpret_cast<const double2*>(d)[i];
+      const double2 bb = reinterpret_cast<const double2*>(b)[i];
+      reinterpret_cast<double2*>(x)[i] = make_double2(dd.x * bb.x, dd.y * bb.y);
+    }
+    if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[total - 1] = d[total - 1] * b[total - 1];
+  } else {
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < total; i += stride)
+      x[i] = d[i / nrhs] * b[i];
+  }
+}
+
+__global__ __launch_bounds__(BLK) void fill_kernel(double* __restrict__ x, long long n, double val) {
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) x[i] = val;
+}
+
+// out[i*nrhs + c] = in[c*n + i]   (column-major host block -> row-major device block) and back.
+__global__ __launch_bounds__(BLK) void colmajor_to_rowmajor(const double* __restrict__ in,
+                                                            double* __restrict__ out, long long n,
+                                                            int nrhs) {
+  const long long total = n * nrhs;
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long o = (long long)blockIdx.x * BLK + threadIdx.x; o < total; o += stride) {
+    const long long i = o / nrhs;
+    const int c = (int)(o - i * nrhs);
+    out[o] = in[(long long)c * n + i];
+  }
+}
+__global__ __launch_bounds__(BLK) void rowmajor_to_colmajor(const double* __restrict__ in,
+                                                            double* __restrict__ out, long long n,
+                                                            int nrhs) {
+  const long long total = n * nrhs;
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long o = (long long)blockIdx.x * BLK + threadIdx.x; o < total; o += stride) {
+    const int c = (int)(o / n);
+    const long long i = o - (long long)c * n;
+    out[o] = in[i * nrhs + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum of squares, deterministic two-stage reduction (SolveFuncs.jl:15,20,30: Frobenius norm).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double acc, double* red) {
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < BLK / 64; ++w) s += red[w];
+  return s;  // valid in thread 0
+}
+
+__global__ __launch_bounds__(BLK) void sumsq_partial(const double* __restrict__ x, long long n,
+                                                     double* __restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const long long stride = (long long)gridDim.x * BLK;
+  double acc = 0.0;
+  const long long n2 = n >> 1;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n2; i += stride) {
+    const double2 t = reinterpret_cast<const double2*>(x)[i];
+    acc += t.x * t.x + t.y * t.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * x[n - 1];
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(BLK) void sum_final(const double* __restrict__ partial, int np,
+                                                 double* __restrict__ out) {
+  __shared__ double red[BLK / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < np; i += BLK) acc += partial[i];
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Coarsest solve x = Ainv * b with the explicit inverse (row-major n x n), MGcycle.jl:177.
+// One wavefront per (row, rhs column): coalesced sweep of the row of Ainv, shuffle reduction.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void dense_apply(const double* __restrict__ Ainv,
+                                                   const double* __restrict__ b,
+                                                   double* __restrict__ x, int n, int nrhs) {
+  const int wave = (int)(((long long)blockIdx.x * BLK + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (wave >= n * nrhs) return;  // wave-uniform
+  const int row = wave / nrhs;
+  const int c = wave - row * nrhs;
+  const double* a = Ainv + (size_t)row * n;
+  double acc = 0.0;
+  for (int j = lane; j < n; j += 64) acc += a[j] * b[(size_t)j * nrhs + c];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) x[(size_t)row * nrhs + c] = acc;
+}
+
+}  // namespace mgk

@@ -1,0 +1,977 @@
+// mgvcycle.hip - C ABI (include/mgvcycle.h) and level schedule of the MI355X multigrid cycle.
+//
+// Reference behaviour reproduced (JuliaInv/Multigrid.jl v0.8.0):
+//   recursiveCycle  src/Multigrid/MGcycle.jl:1-118   (operation order: SURVEY.md 3.2)
+//   relax           src/Multigrid/MGcycle.jl:122-136
+//   solveCoarsest   src/Multigrid/MGcycle.jl:138-181 (default branch, l.177)
+//   solveMG         src/Multigrid/SolveFuncs.jl:3-39
+// The hierarchy is resident in HBM; the host only sequences kernel launches on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mgvcycle.h"
+#include "mg_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(MG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                 \
+  } while (0)
+
+#define MG_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != MG_OK) return rc_; \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    n = count;
+    return MG_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+struct Csr {
+  bool set = false;
+  long long n_rows = 0, n_cols = 0, nnz = 0;
+  DevBuf<int> rowptr, colidx, blk_row;
+  DevBuf<double> val;
+  int nblocks = 0;
+  mgk::CsrDev dev() const {
+    mgk::CsrDev d;
+    d.rowptr = rowptr.p;
+    d.colidx = colidx.p;
+    d.val = val.p;
+    d.blk_row = blk_row.p;
+    d.nblocks = nblocks;
+    d.n_rows = (int)n_rows;
+    d.n_cols = (int)n_cols;
+    return d;
+  }
+  void release() {
+    rowptr.release();
+    colidx.release();
+    blk_row.release();
+    val.release();
+    set = false;
+  }
+  size_t bytes() const { return rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes(); }
+};
+
+struct Level {
+  Csr A, P, R;  // P, R: transfer to/from the next coarser level (unset on the coarsest)
+  DevBuf<double> d;
+  bool relax_set = false;
+  long long npre = 1, npost = 1;
+  long long n = 0;
+  // CYCLEmem (MGdef.jl:56-60) plus the Jacobi ping-pong partner of x
+  DevBuf<double> b, r, x0, x1;
+};
+
+struct ProfSlot {
+  double ms = 0.0;
+  long long launches = 0;
+  double bytes = 0.0;
+};
+
+}  // namespace
+
+struct mg_hierarchy {
+  int device = 0;
+  long long nlevels = 0;
+  long long nrhs = 1;
+  char cycle = 'V';
+  bool finalized = false;
+  std::vector<Level> lev;
+  DevBuf<double> Ainv;  // row-major n_c x n_c
+  long long n_coarse = 0;
+  bool coarse_set = false;
+  hipStream_t stream = nullptr;
+  // reductions
+  DevBuf<double> partial, scalar;
+  double* h_scalar = nullptr;  // pinned
+  int nred_blocks = 1024;
+  // staging for the host-pointer API
+  DevBuf<double> stage_b, stage_x, stage_t;
+  // fine-level operands of the last cycle/solve (used as inputs by mg_time_op_dev_FP64)
+  const double* last_b = nullptr;
+  double* last_x = nullptr;
+  // profiling
+  bool prof = false;
+  std::vector<ProfSlot> slots;  // [level][kernel]
+  struct Pending {
+    hipEvent_t a, b;
+    int level, kernel;
+    double bytes;
+  };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// algorithmic bytes: int32 indices + fp64 values, each vector element once
+// ---------------------------------------------------------------------------------------------
+double spmv_bytes(const Csr& M, long long nrhs, bool reads_y_or_b, bool smooth) {
+  double bts = 12.0 * (double)M.nnz + 4.0 * (double)(M.n_rows + 1);
+  bts += 8.0 * (double)nrhs * (double)(M.n_cols + M.n_rows);  // x read, y written
+  if (reads_y_or_b) bts += 8.0 * (double)nrhs * (double)M.n_rows;
+  if (smooth) bts += 8.0 * (double)M.n_rows;  // d; the x[row] term is the already-counted x read
+  return bts;
+}
+
+int grid_for(long long total) {
+  long long g = (total + mgk::BLK - 1) / mgk::BLK;
+  return (int)std::max<long long>(1, std::min<long long>(g, 2048));
+}
+
+// ---- profiling helpers --------------------------------------------------------------------------
+hipEvent_t get_event(mg_hierarchy* h) {
+  if (!h->ev_pool.empty()) {
+    hipEvent_t e = h->ev_pool.back();
+    h->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {
+  mg_hierarchy* h;
+  bool on;
+  mg_hierarchy::Pending p;
+  ProfScope(mg_hierarchy* h_, int level, int kernel, double bytes) : h(h_), on(h_->prof) {
+    if (!on) return;
+    p.a = get_event(h);
+    p.b = get_event(h);
+    p.level = level;
+    p.kernel = kernel;
+    p.bytes = bytes;
+    (void)hipEventRecord(p.a, h->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(p.b, h->stream);
+    h->pending.push_back(p);
+  }
+};
+
+void prof_collect(mg_hierarchy* h) {
+  for (auto& p : h->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ProfSlot& s = h->slots[(size_t)p.level * MG_K_COUNT + p.kernel];
+      s.ms += ms;
+      s.launches += 1;
+      s.bytes = p.bytes;
+    }
+    h->ev_pool.push_back(p.a);
+    h->ev_pool.push_back(p.b);
+  }
+  h->pending.clear();
+}
+
+// ---- kernel launchers ---------------------------------------------------------------------------
+int pow2_ge(long long v) {
+  int g = 1;
+  while (g < v && g < 64) g <<= 1;
+  return g;
+}
+
+template <int MODE>
+int launch_csr(mg_hierarchy* h, const Csr& M, const mgk::VecArgs& v) {
+  if (M.nblocks <= 0) return MG_OK;
+  if (v.nrhs == 1) {
+    hipLaunchKernelGGL(mgk::csr_stream_spmv<MODE>, dim3(M.nblocks), dim3(mgk::BLK), 0, h->stream,
+                       M.dev(), v);
+  } else {
+    hipLaunchKernelGGL(mgk::csr_stream_spmm<MODE>, dim3(M.nblocks), dim3(mgk::BLK), 0, h->stream,
+                       M.dev(), v, pow2_ge(v.nrhs));
+  }
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+
+// y = alpha*M*x + beta*y
+int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, const double* x,
+           double beta, double* y) {
+  mgk::VecArgs v{};
+  v.x = x;
+  v.y = y;
+  v.alpha = alpha;
+  v.beta = beta;
+  v.nrhs = (int)h->nrhs;
+  ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false));
+  return launch_csr<mgk::AXPBY>(h, M, v);
+}
+// out = b - A*x
+int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x,
+               double* out) {
+  mgk::VecArgs v{};
+  v.x = x;
+  v.y = out;
+  v.b = b;
+  v.nrhs = (int)h->nrhs;
+  ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, h->nrhs, true, false));
+  return launch_csr<mgk::RESID>(h, A, v);
+}
+// out = x + d.*(b - A*x)
+int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const double* b,
+             const double* x, double* out) {
+  mgk::VecArgs v{};
+  v.x = x;
+  v.y = out;
+  v.b = b;
+  v.d = d;
+  v.nrhs = (int)h->nrhs;
+  ProfScope ps(h, level, MG_K_SMOOTH, spmv_bytes(A, h->nrhs, true, true));
+  return launch_csr<mgk::SMOOTH>(h, A, v);
+}
+int k_dscale(mg_hierarchy* h, int level, const double* d, const double* b, double* x, long long n) {
+  ProfScope ps(h, level, MG_K_DSCALE, 8.0 * (double)n * (1.0 + 2.0 * (double)h->nrhs));
+  hipLaunchKernelGGL(mgk::dscale_kernel, dim3(grid_for(n * h->nrhs / 2 + 1)), dim3(mgk::BLK), 0,
+                     h->stream, d, b, x, n, (int)h->nrhs);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+int k_fill(mg_hierarchy* h, double* x, long long n, double val) {
+  hipLaunchKernelGGL(mgk::fill_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, x, n, val);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+int k_coarse(mg_hierarchy* h, int level, const double* b, double* x) {
+  const long long n = h->n_coarse;
+  ProfScope ps(h, level, MG_K_COARSE,
+               8.0 * ((double)n * (double)n + 2.0 * (double)n * (double)h->nrhs));
+  const long long waves = n * h->nrhs;
+  const long long blocks = (waves * 64 + mgk::BLK - 1) / mgk::BLK;
+  hipLaunchKernelGGL(mgk::dense_apply, dim3((unsigned)blocks), dim3(mgk::BLK), 0, h->stream,
+                     h->Ainv.p, b, x, (int)n, (int)h->nrhs);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+// sum of squares of x[0..len) -> h->scalar (device); no sync
+int k_sumsq(mg_hierarchy* h, const double* x, long long len) {
+  ProfScope ps(h, 0, MG_K_NORM, 8.0 * (double)len);
+  const int nb = std::min<long long>(h->nred_blocks, std::max<long long>(1, (len / 2 + mgk::BLK - 1) / mgk::BLK));
+  hipLaunchKernelGGL(mgk::sumsq_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, x, len,
+                     h->partial.p);
+  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb,
+                     h->scalar.p);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+// host value of sqrt(sum of squares); synchronises the stream
+int norm_sync(mg_hierarchy* h, const double* x, long long len, double* out) {
+  MG_TRY(k_sumsq(h, x, len));
+  HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *out = std::sqrt(*h->h_scalar);
+  return MG_OK;
+}
+
+// ---- the cycle ------------------------------------------------------------------------------------
+// Returns in *result the buffer (xa or xb) that holds the level's x after the cycle.
+// l is 0-based.  xa holds the incoming x when !x_zero; xb is the Jacobi ping-pong partner.
+int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero,
+                char ctype, double** result) {
+  const int nl = (int)h->nlevels;
+  if (l == nl - 1) {  // solveCoarsest (MGcycle.jl:13-18,67-69,177): x = LU \ b
+    MG_TRY(k_coarse(h, l, b, xa));
+    *result = xa;
+    return MG_OK;
+  }
+  Level& L = h->lev[l];
+  Level& C = h->lev[l + 1];
+  const long long len = L.n * h->nrhs;
+  double* cur = xa;
+  double* alt = xb;
+  // relax() always performs at least one update: `for i=1:numit-1 ... end; x .+= d.*r` (MGcycle.jl:127-134)
+  long long npre = std::max<long long>(1, L.npre);
+  const long long npost = std::max<long long>(1, L.npost);
+  // pre-smoothing (MGcycle.jl:26-31,54).  x == 0: r = b, so the first sweep is x = d.*b.
+  if (x_zero) {
+    MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
+    --npre;
+  }
+  for (long long s = 0; s < npre; ++s) {
+    MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
+    std::swap(cur, alt);
+  }
+  // r = b - A x ; bc = R r ; xc = 0 (MGcycle.jl:58-66)
+  MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
+  MG_TRY(k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, C.b.p));
+  double* xc = nullptr;
+  MG_TRY(cycle_level(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
+  if (l + 1 < nl - 1) {  // MGcycle.jl:78-85
+    if (ctype == 'W') {
+      double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
+      MG_TRY(cycle_level(h, l + 1, C.b.p, xc, other, false, 'W', &xc));
+    } else if (ctype == 'F') {
+      double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
+      MG_TRY(cycle_level(h, l + 1, C.b.p, xc, other, false, 'V', &xc));
+    }
+  }
+  // x += P xc (MGcycle.jl:90)
+  MG_TRY(k_spmv(h, l, MG_K_PROLONG, L.P, 1.0, xc, 1.0, cur));
+  // post-smoothing (MGcycle.jl:92-102)
+  for (long long s = 0; s < npost; ++s) {
+    MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
+    std::swap(cur, alt);
+  }
+  (void)len;
+  *result = cur;
+  return MG_OK;
+}
+
+int check_ready(mg_hierarchy* h, long long n, long long nrhs) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized: call mg_finalize first");
+  if (n != h->lev[0].n) return fail(MG_ERR_INVALID, "n=%lld does not match the fine level (%lld rows)", n, h->lev[0].n);
+  if (nrhs != h->nrhs)
+    return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld: call mg_set_nrhs (adjustMemoryForNumRHS)", nrhs, h->nrhs);
+  return MG_OK;
+}
+
+// one cycle on device buffers; result guaranteed to be in x on return (no sync)
+int cycle_dev(mg_hierarchy* h, const double* b, double* x, bool x_zero) {
+  double* res = nullptr;
+  h->last_b = b;
+  h->last_x = x;
+  MG_TRY(cycle_level(h, 0, b, x, h->lev[0].x1.p, x_zero, h->cycle, &res));
+  if (res != x)
+    HIP_TRY(hipMemcpyAsync(x, res, sizeof(double) * h->lev[0].n * h->nrhs, hipMemcpyDeviceToDevice, h->stream));
+  return MG_OK;
+}
+
+int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long maxIter,
+              long long* iters, double* resvec) {
+  Level& L = h->lev[0];
+  const long long len = L.n * h->nrhs;
+  double res = 0.0, res0 = 0.0, xn = 0.0;
+  h->last_b = b;
+  h->last_x = x;
+  // SolveFuncs.jl:14-22
+  MG_TRY(norm_sync(h, x, len, &xn));
+  bool x_zero = (xn == 0.0);
+  if (x_zero) {
+    MG_TRY(norm_sync(h, b, len, &res0));
+  } else {
+    MG_TRY(k_residual(h, 0, L.A, b, x, L.r.p));
+    MG_TRY(norm_sync(h, L.r.p, len, &res0));
+  }
+  res = res0;
+  if (resvec) resvec[0] = res0;
+  long long it = 0;
+  double* cur = x;
+  double* alt = L.x1.p;
+  for (long long count = 1; count <= maxIter; ++count) {
+    double* out = nullptr;
+    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out));
+    if (out != cur) std::swap(cur, alt);
+    x_zero = false;
+    MG_TRY(k_residual(h, 0, L.A, b, cur, L.r.p));  // SolveFuncs.jl:26-27
+    MG_TRY(norm_sync(h, L.r.p, len, &res));
+    ++it;
+    if (resvec) resvec[it] = res;
+    if (res / res0 < tol) break;  // SolveFuncs.jl:34-36
+  }
+  if (cur != x) {
+    HIP_TRY(hipMemcpyAsync(x, cur, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  if (iters) *iters = it;
+  return MG_OK;
+}
+
+// ---- host <-> device block transfer (column-major host <-> row-major device) --------------------
+int upload_block(mg_hierarchy* h, const double* host, double* dev, long long n, long long nrhs) {
+  const size_t bytes = sizeof(double) * (size_t)n * (size_t)nrhs;
+  if (nrhs == 1) {
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(h->stage_t.p, host, bytes, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(mgk::colmajor_to_rowmajor, dim3(grid_for(n * nrhs)), dim3(mgk::BLK), 0, h->stream,
+                       h->stage_t.p, dev, n, (int)nrhs);
+    HIP_TRY(hipGetLastError());
+  }
+  return MG_OK;
+}
+int download_block(mg_hierarchy* h, const double* dev, double* host, long long n, long long nrhs) {
+  const size_t bytes = sizeof(double) * (size_t)n * (size_t)nrhs;
+  if (nrhs == 1) {
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    hipLaunchKernelGGL(mgk::rowmajor_to_colmajor, dim3(grid_for(n * nrhs)), dim3(mgk::BLK), 0, h->stream,
+                       dev, h->stage_t.p, n, (int)nrhs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, h->stage_t.p, bytes, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return MG_OK;
+}
+
+int alloc_scratch(mg_hierarchy* h) {
+  const long long k = h->nrhs;
+  long long nmax = 0;
+  for (int l = 0; l < (int)h->nlevels; ++l) {
+    Level& L = h->lev[l];
+    const size_t len = (size_t)L.n * (size_t)k;
+    nmax = std::max(nmax, L.n);
+    MG_TRY(L.r.alloc(len));
+    MG_TRY(L.x1.alloc(len));
+    HIP_TRY(hipMemset(L.r.p, 0, L.r.bytes()));
+    HIP_TRY(hipMemset(L.x1.p, 0, L.x1.bytes()));
+    if (l > 0) {
+      MG_TRY(L.b.alloc(len));
+      MG_TRY(L.x0.alloc(len));
+      HIP_TRY(hipMemset(L.b.p, 0, L.b.bytes()));
+      HIP_TRY(hipMemset(L.x0.p, 0, L.x0.bytes()));
+    }
+  }
+  // host-pointer API staging (fine level) + transpose scratch (any level, for mg_spmv)
+  MG_TRY(h->stage_b.alloc((size_t)nmax * k));
+  MG_TRY(h->stage_x.alloc((size_t)nmax * k));
+  MG_TRY(h->stage_t.alloc((size_t)nmax * k));
+  HIP_TRY(hipMemset(h->stage_b.p, 0, h->stage_b.bytes()));
+  HIP_TRY(hipMemset(h->stage_x.p, 0, h->stage_x.bytes()));
+  HIP_TRY(hipMemset(h->stage_t.p, 0, h->stage_t.bytes()));
+  h->last_b = nullptr;
+  h->last_x = nullptr;
+  return MG_OK;
+}
+
+Csr* pick(mg_hierarchy* h, long long level, long long which) {
+  if (level < 1 || level > h->nlevels) return nullptr;
+  Level& L = h->lev[level - 1];
+  if (which == MG_OP_A) return &L.A;
+  if (which == MG_OP_P) return &L.P;
+  if (which == MG_OP_R) return &L.R;
+  return nullptr;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* mg_last_error(void) { return g_err.c_str(); }
+const char* mg_version(void) { return "mgvcycle 0.1 (gfx950, fp64, csr-stream)"; }
+
+int mg_create(long long nlevels, long long nrhs, long long device_id, mg_hierarchy** out) {
+  if (!out) return fail(MG_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (nlevels < 1 || nlevels > 64) return fail(MG_ERR_INVALID, "nlevels=%lld out of range [1,64]", nlevels);
+  if (nrhs < 1) return fail(MG_ERR_INVALID, "nrhs=%lld must be >= 1", nrhs);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
+  HIP_TRY(hipSetDevice((int)device_id));
+  mg_hierarchy* h = new mg_hierarchy();
+  h->device = (int)device_id;
+  h->nlevels = nlevels;
+  h->nrhs = nrhs;
+  h->lev.resize((size_t)nlevels);
+  h->slots.resize((size_t)nlevels * MG_K_COUNT);
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete h;
+    return fail(MG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  if (h->partial.alloc((size_t)h->nred_blocks) != MG_OK || h->scalar.alloc(1) != MG_OK ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), sizeof(double)) != hipSuccess) {
+    mg_destroy(h);
+    return fail(MG_ERR_HIP, "allocation of reduction scratch failed");
+  }
+  *out = h;
+  return MG_OK;
+}
+
+int mg_destroy(mg_hierarchy* h) {
+  if (!h) return MG_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  prof_collect(h);
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  for (auto& L : h->lev) {
+    L.A.release();
+    L.P.release();
+    L.R.release();
+    L.d.release();
+    L.b.release();
+    L.r.release();
+    L.x0.release();
+    L.x1.release();
+  }
+  h->Ainv.release();
+  h->partial.release();
+  h->scalar.release();
+  h->stage_b.release();
+  h->stage_x.release();
+  h->stage_t.release();
+  if (h->h_scalar) (void)hipHostFree(h->h_scalar);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return MG_OK;
+}
+
+int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which, long long n_rows,
+                               long long n_cols, const long long* colptr, const long long* rowval,
+                               const double* nzval) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  Csr* M = pick(h, level, which);
+  if (!M) return fail(MG_ERR_INVALID, "bad (level=%lld, which=%lld)", level, which);
+  if ((which == MG_OP_P || which == MG_OP_R) && level == h->nlevels)
+    return fail(MG_ERR_INVALID, "the coarsest level %lld has no transfer operators", level);
+  if (n_rows < 1 || n_cols < 1 || !colptr || !rowval || !nzval)
+    return fail(MG_ERR_INVALID, "empty operator or null array");
+  if (n_rows >= (1LL << 31) - 1 || n_cols >= (1LL << 31) - 1)
+    return fail(MG_ERR_UNSUPPORTED, "dimension exceeds int32 device indices");
+  if (colptr[0] != 1) return fail(MG_ERR_INVALID, "colptr[1] must be 1 (1-based Julia arrays expected)");
+  const long long nnz = colptr[n_rows] - 1;
+  if (nnz < 0 || nnz >= (1LL << 31) - 4096)
+    return fail(MG_ERR_UNSUPPORTED, "nnz=%lld does not fit int32 row pointers on device", nnz);
+  (void)hipSetDevice(h->device);
+  // validate + convert to 0-based int32 (the reference's C side does the -1 per access, parRelax.h:24-27)
+  std::vector<int> rp((size_t)n_rows + 1);
+  for (long long i = 0; i <= n_rows; ++i) {
+    const long long v = colptr[i] - 1;
+    if (v < 0 || v > nnz || (i > 0 && v < (long long)rp[(size_t)i - 1]))
+      return fail(MG_ERR_INVALID, "colptr is not a monotone 1-based pointer array at %lld", i);
+    rp[(size_t)i] = (int)v;
+  }
+  const size_t pad = 2 * mgk::BLK;  // loads of a trailing (idx, idx+1) pair stay in bounds
+  std::vector<int> ci((size_t)nnz + pad, 0);
+  for (long long k = 0; k < nnz; ++k) {
+    const long long c = rowval[k] - 1;
+    if (c < 0 || c >= n_cols) return fail(MG_ERR_INVALID, "rowval[%lld]=%lld outside 1..%lld", k + 1, rowval[k], n_cols);
+    ci[(size_t)k] = (int)c;
+  }
+  // row blocks: consecutive rows, <= MAXROWS rows and an (even-aligned) nnz span <= CHUNK
+  std::vector<int> blk;
+  blk.push_back(0);
+  long long r = 0;
+  while (r < n_rows) {
+    const long long base = rp[(size_t)r] & ~1LL;
+    long long e = r + 1;  // a block always holds at least one row (a longer row takes the long-row path)
+    while (e < n_rows && (e - r) < mgk::MAXROWS && (rp[(size_t)e + 1] - base) <= mgk::CHUNK) ++e;
+    blk.push_back((int)e);
+    r = e;
+  }
+  M->release();
+  M->n_rows = n_rows;
+  M->n_cols = n_cols;
+  M->nnz = nnz;
+  M->nblocks = (int)blk.size() - 1;
+  MG_TRY(M->rowptr.alloc(rp.size()));
+  MG_TRY(M->colidx.alloc(ci.size()));
+  MG_TRY(M->val.alloc((size_t)nnz + pad));
+  MG_TRY(M->blk_row.alloc(blk.size()));
+  HIP_TRY(hipMemcpy(M->rowptr.p, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->colidx.p, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(M->val.p, 0, ((size_t)nnz + pad) * sizeof(double)));
+  HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->blk_row.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+  M->set = true;
+  h->finalized = false;
+  return MG_OK;
+}
+
+int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long long n,
+                      long long relaxPre, long long relaxPost) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  if (!d || n < 1) return fail(MG_ERR_INVALID, "empty relaxPrec");
+  if (relaxPre < 0 || relaxPost < 0) return fail(MG_ERR_INVALID, "negative sweep count");
+  (void)hipSetDevice(h->device);
+  Level& L = h->lev[(size_t)level - 1];
+  MG_TRY(L.d.alloc((size_t)n));
+  HIP_TRY(hipMemcpy(L.d.p, d, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  L.relax_set = true;
+  L.npre = relaxPre;
+  L.npost = relaxPost;
+  h->finalized = false;
+  return MG_OK;
+}
+
+int mg_set_cycle_type(mg_hierarchy* h, long long cycleType) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (cycleType == 'K')
+    return fail(MG_ERR_UNSUPPORTED, "K-cycle (FGMRES recursion, MGcycle.jl:72-76) is not on the device path yet");
+  if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F')
+    return fail(MG_ERR_INVALID, "cycleType must be 'V', 'W' or 'F'");
+  h->cycle = (char)cycleType;
+  return MG_OK;
+}
+
+int mg_set_coarse_dense_inverse_FP64(mg_hierarchy* h, long long n, const double* Ainv) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (n < 1 || !Ainv) return fail(MG_ERR_INVALID, "empty coarse inverse");
+  if (n > 46000) return fail(MG_ERR_UNSUPPORTED, "dense coarse inverse of order %lld is too large", n);
+  (void)hipSetDevice(h->device);
+  // column-major -> row-major on the host (one-off, setup time)
+  std::vector<double> rm((size_t)n * (size_t)n);
+  for (long long j = 0; j < n; ++j)
+    for (long long i = 0; i < n; ++i) rm[(size_t)i * n + j] = Ainv[(size_t)j * n + i];
+  MG_TRY(h->Ainv.alloc(rm.size()));
+  HIP_TRY(hipMemcpy(h->Ainv.p, rm.data(), rm.size() * sizeof(double), hipMemcpyHostToDevice));
+  h->n_coarse = n;
+  h->coarse_set = true;
+  h->finalized = false;
+  return MG_OK;
+}
+
+int mg_finalize(mg_hierarchy* h) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  (void)hipSetDevice(h->device);
+  const int nl = (int)h->nlevels;
+  for (int l = 0; l < nl; ++l) {
+    Level& L = h->lev[l];
+    if (!L.A.set) return fail(MG_ERR_STATE, "As[%d] was not set", l + 1);
+    if (L.A.n_rows != L.A.n_cols) return fail(MG_ERR_INVALID, "As[%d] is not square", l + 1);
+    L.n = L.A.n_rows;
+    if (l < nl - 1) {
+      if (!L.P.set || !L.R.set) return fail(MG_ERR_STATE, "Ps[%d]/Rs[%d] were not set", l + 1, l + 1);
+      if (!L.relax_set) return fail(MG_ERR_STATE, "relaxPrecs[%d] was not set", l + 1);
+      if ((long long)L.d.n != L.n) return fail(MG_ERR_INVALID, "relaxPrecs[%d] has length %zu, expected %lld", l + 1, L.d.n, L.n);
+    }
+  }
+  for (int l = 0; l < nl - 1; ++l) {
+    Level& L = h->lev[l];
+    const long long nc = h->lev[l + 1].A.n_rows;
+    if (L.P.n_rows != L.n || L.P.n_cols != nc)
+      return fail(MG_ERR_INVALID, "Ps[%d] is %lldx%lld, expected %lldx%lld", l + 1, L.P.n_rows, L.P.n_cols, L.n, nc);
+    if (L.R.n_rows != nc || L.R.n_cols != L.n)
+      return fail(MG_ERR_INVALID, "Rs[%d] is %lldx%lld, expected %lldx%lld", l + 1, L.R.n_rows, L.R.n_cols, nc, L.n);
+  }
+  if (!h->coarse_set) return fail(MG_ERR_STATE, "the coarsest solve was not set");
+  if (h->n_coarse != h->lev[nl - 1].n)
+    return fail(MG_ERR_INVALID, "coarse inverse order %lld != coarsest level size %lld", h->n_coarse, h->lev[nl - 1].n);
+  MG_TRY(alloc_scratch(h));
+  h->finalized = true;
+  return MG_OK;
+}
+
+int mg_set_nrhs(mg_hierarchy* h, long long nrhs) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (nrhs < 1) return fail(MG_ERR_INVALID, "nrhs must be >= 1");
+  if (nrhs == h->nrhs) return MG_OK;
+  (void)hipSetDevice(h->device);
+  h->nrhs = nrhs;
+  if (h->finalized) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    MG_TRY(alloc_scratch(h));
+  }
+  return MG_OK;
+}
+
+int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, const double* nzval,
+                           long long nnz) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  Csr* M = pick(h, level, which);
+  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
+  if (nnz != M->nnz) return fail(MG_ERR_INVALID, "nnz=%lld differs from the stored pattern (%lld)", nnz, M->nnz);
+  (void)hipSetDevice(h->device);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+  return MG_OK;
+}
+
+// ---- device-resident hot path ---------------------------------------------------------------------
+int mg_cycle_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
+                      long long x_is_zero) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
+  (void)hipSetDevice(h->device);
+  bool xz = (x_is_zero == 1);
+  if (x_is_zero < 0) {  // norm(x)>0.0 decides (MGcycle.jl:29)
+    double xn = 0.0;
+    MG_TRY(norm_sync(h, x, n * nrhs, &xn));
+    xz = (xn == 0.0);
+  }
+  MG_TRY(cycle_dev(h, b, x, xz));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_solve_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
+                      double tol, long long maxIter, long long* iters, double* resvec) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
+  if (maxIter < 0) return fail(MG_ERR_INVALID, "maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(solve_dev(h, b, x, tol, maxIter, iters, resvec));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_spmv_dev_FP64(mg_hierarchy* h, long long level, long long which, double alpha,
+                     const double* x, double beta, double* y, long long nrhs) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  Csr* M = pick(h, level, which);
+  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
+  if (nrhs != h->nrhs) return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld", nrhs, h->nrhs);
+  if (!x || !y) return fail(MG_ERR_INVALID, "null vector");
+  if (x == y) return fail(MG_ERR_INVALID, "x and y must not alias");
+  (void)hipSetDevice(h->device);
+  MG_TRY(k_spmv(h, (int)level - 1, MG_K_SPMV, *M, alpha, x, beta, y));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_fused_dev_FP64(mg_hierarchy* h, long long level, long long kernel, const double* b,
+                      const double* x, double* out, long long nrhs) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  if (nrhs != h->nrhs) return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld", nrhs, h->nrhs);
+  if (!b || !x || !out || out == x) return fail(MG_ERR_INVALID, "null vector or out aliases x");
+  Level& L = h->lev[(size_t)level - 1];
+  (void)hipSetDevice(h->device);
+  if (kernel == MG_K_RESIDUAL) {
+    MG_TRY(k_residual(h, (int)level - 1, L.A, b, x, out));
+  } else if (kernel == MG_K_SMOOTH) {
+    if (!L.relax_set) return fail(MG_ERR_STATE, "relaxPrecs[%lld] was not set", level);
+    MG_TRY(k_smooth(h, (int)level - 1, L.A, L.d.p, b, x, out));
+  } else {
+    return fail(MG_ERR_INVALID, "kernel must be MG_K_RESIDUAL or MG_K_SMOOTH");
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  prof_collect(h);
+  return MG_OK;
+}
+
+// ---- host-buffer hot path (what the Julia glue ccalls) ------------------------------------------
+int mg_cycle_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
+                  long long x_is_zero) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
+  (void)hipSetDevice(h->device);
+  bool xz = (x_is_zero == 1);
+  if (x_is_zero < 0) {
+    xz = true;
+    const long long len = n * nrhs;
+    for (long long i = 0; i < len; ++i)
+      if (x[i] != 0.0) { xz = false; break; }
+  }
+  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
+  if (!xz) MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
+  MG_TRY(cycle_dev(h, h->stage_b.p, h->stage_x.p, xz));
+  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_solve_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
+                  double tol, long long maxIter, long long* iters, double* resvec) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
+  if (maxIter < 0) return fail(MG_ERR_INVALID, "maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
+  MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
+  MG_TRY(solve_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, resvec));
+  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_spmv_FP64(mg_hierarchy* h, long long level, long long which, double alpha, const double* x,
+                 double beta, double* y, long long nrhs) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  Csr* M = pick(h, level, which);
+  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
+  if (nrhs != h->nrhs) return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld", nrhs, h->nrhs);
+  if (!x || !y) return fail(MG_ERR_INVALID, "null vector");
+  (void)hipSetDevice(h->device);
+  MG_TRY(upload_block(h, x, h->stage_x.p, M->n_cols, nrhs));
+  if (beta != 0.0) MG_TRY(upload_block(h, y, h->stage_b.p, M->n_rows, nrhs));
+  MG_TRY(k_spmv(h, (int)level - 1, MG_K_SPMV, *M, alpha, h->stage_x.p, beta, h->stage_b.p));
+  MG_TRY(download_block(h, h->stage_b.p, y, M->n_rows, nrhs));
+  prof_collect(h);
+  return MG_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------------------
+int mg_time_op_dev_FP64(mg_hierarchy* h, long long level, long long kernel, long long nrhs,
+                        long long reps, double* ms_avg, double* bytes) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  if (nrhs != h->nrhs) return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld", nrhs, h->nrhs);
+  if (reps < 1 || !ms_avg) return fail(MG_ERR_INVALID, "reps < 1 or null output");
+  (void)hipSetDevice(h->device);
+  const int l = (int)level - 1;
+  Level& L = h->lev[(size_t)l];
+  const bool coarsest = (l == (int)h->nlevels - 1);
+  if (coarsest && kernel != MG_K_COARSE && kernel != MG_K_SPMV && kernel != MG_K_RESIDUAL)
+    return fail(MG_ERR_INVALID, "kernel %lld does not run on the coarsest level", kernel);
+  // operands: the level's own scratch (contents are whatever the last cycle left: finite values)
+  const double* bvec = (l == 0) ? (h->last_b ? h->last_b : h->stage_b.p) : L.b.p;
+  double* xa = (l == 0) ? (h->last_x ? h->last_x : h->stage_x.p) : L.x0.p;
+  double* xb = L.x1.p;
+  const bool was_prof = h->prof;
+  h->prof = false;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  double bts = 0.0;
+  int rc = MG_OK;
+  for (long long it = -2; it < reps && rc == MG_OK; ++it) {  // two untimed warm-up launches
+    if (it == 0) (void)hipEventRecord(e0, h->stream);
+    switch (kernel) {
+      case MG_K_SPMV:
+        rc = k_spmv(h, l, MG_K_SPMV, L.A, 1.0, xa, 0.0, L.r.p);
+        bts = spmv_bytes(L.A, nrhs, false, false);
+        break;
+      case MG_K_RESIDUAL:
+        rc = k_residual(h, l, L.A, bvec, xa, L.r.p);
+        bts = spmv_bytes(L.A, nrhs, true, false);
+        break;
+      case MG_K_SMOOTH:
+        rc = k_smooth(h, l, L.A, L.d.p, bvec, xa, xb);
+        bts = spmv_bytes(L.A, nrhs, true, true);
+        break;
+      case MG_K_RESTRICT:
+        rc = k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, h->lev[(size_t)l + 1].b.p);
+        bts = spmv_bytes(L.R, nrhs, false, false);
+        break;
+      case MG_K_PROLONG:
+        rc = k_spmv(h, l, MG_K_PROLONG, L.P, 0.0, h->lev[(size_t)l + 1].x0.p, 1.0, xb);
+        bts = spmv_bytes(L.P, nrhs, true, false);
+        break;
+      case MG_K_DSCALE:
+        rc = k_dscale(h, l, L.d.p, bvec, xb, L.n);
+        bts = 8.0 * (double)L.n * (1.0 + 2.0 * (double)nrhs);
+        break;
+      case MG_K_COARSE:
+        if (!coarsest) rc = fail(MG_ERR_INVALID, "MG_K_COARSE runs on the coarsest level only");
+        else rc = k_coarse(h, l, L.b.p, L.x0.p);
+        bts = 8.0 * ((double)L.n * (double)L.n + 2.0 * (double)L.n * (double)nrhs);
+        break;
+      case MG_K_NORM:
+        rc = k_sumsq(h, L.r.p, L.n * nrhs);
+        bts = 8.0 * (double)L.n * (double)nrhs;
+        break;
+      default:
+        rc = fail(MG_ERR_INVALID, "unknown kernel %lld", kernel);
+    }
+  }
+  if (rc == MG_OK) {
+    (void)hipEventRecord(e1, h->stream);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) rc = fail(MG_ERR_HIP, "event timing failed: %s", hipGetErrorString(e));
+    *ms_avg = (double)ms / (double)reps;
+    if (bytes) *bytes = bts;
+  }
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  h->prof = was_prof;
+  return rc;
+}
+
+int mg_profile_enable(mg_hierarchy* h, long long on) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  h->prof = (on != 0);
+  return MG_OK;
+}
+int mg_profile_reset(mg_hierarchy* h) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  for (auto& s : h->slots) s = ProfSlot();
+  return MG_OK;
+}
+int mg_profile_get(mg_hierarchy* h, long long level, long long kernel, double* total_ms,
+                   long long* launches, double* bytes_per_launch) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (level < 1 || level > h->nlevels || kernel < 0 || kernel >= MG_K_COUNT)
+    return fail(MG_ERR_INVALID, "bad (level=%lld, kernel=%lld)", level, kernel);
+  const ProfSlot& s = h->slots[(size_t)(level - 1) * MG_K_COUNT + (size_t)kernel];
+  if (total_ms) *total_ms = s.ms;
+  if (launches) *launches = s.launches;
+  if (bytes_per_launch) *bytes_per_launch = s.bytes;
+  return MG_OK;
+}
+
+int mg_cycle_bytes(mg_hierarchy* h, double* bytes) {
+  if (!h || !bytes) return fail(MG_ERR_INVALID, "null argument");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  // one V-cycle from x = 0 (SURVEY.md 8d "minimal-traffic fused model"); W/F revisit coarse levels
+  // and are accounted by the profile counters instead.
+  const long long k = h->nrhs;
+  double t = 0.0;
+  const int nl = (int)h->nlevels;
+  for (int l = 0; l < nl - 1; ++l) {
+    const Level& L = h->lev[(size_t)l];
+    const long long npre = std::max<long long>(1, L.npre), npost = std::max<long long>(1, L.npost);
+    t += 8.0 * (double)L.n * (1.0 + 2.0 * (double)k);                          // x = d.*b
+    t += (double)(npre - 1 + npost) * spmv_bytes(L.A, k, true, true);          // fused sweeps
+    t += spmv_bytes(L.A, k, true, false);                                      // residual
+    t += spmv_bytes(L.R, k, false, false);                                     // restriction
+    t += spmv_bytes(L.P, k, true, false);                                      // prolongation-add
+  }
+  const double nc = (double)h->n_coarse;
+  t += 8.0 * (nc * nc + 2.0 * nc * (double)k);
+  *bytes = t;
+  return MG_OK;
+}
+
+int mg_device_bytes(mg_hierarchy* h, double* bytes) {
+  if (!h || !bytes) return fail(MG_ERR_INVALID, "null argument");
+  double t = 0.0;
+  for (auto& L : h->lev)
+    t += (double)(L.A.bytes() + L.P.bytes() + L.R.bytes() + L.d.bytes() + L.b.bytes() + L.r.bytes() +
+                  L.x0.bytes() + L.x1.bytes());
+  t += (double)(h->Ainv.bytes() + h->stage_b.bytes() + h->stage_x.bytes() + h->stage_t.bytes());
+  *bytes = t;
+  return MG_OK;
+}
+
+}  // extern "C"

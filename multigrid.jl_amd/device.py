@@ -1,0 +1,289 @@
+"""ctypes binding of libmgvcycle.so (include/mgvcycle.h) and the device-side hierarchy handle.
+
+This is the Python stand-in for the Julia glue a maintainer would add: it passes
+the arrays exactly as Julia's ``SparseMatrixCSC`` holds them - 1-based Int64 ``colptr``/``rowval``,
+Float64 ``nzval`` - following the reference's ccall idiom (src/Multigrid/parRelax.jl:61-64).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, every entry point
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmgvcycle.so")
+
+MG_OP_A, MG_OP_P, MG_OP_R = 0, 1, 2
+(MG_K_SPMV, MG_K_RESIDUAL, MG_K_SMOOTH, MG_K_RESTRICT, MG_K_PROLONG, MG_K_DSCALE, MG_K_COARSE,
+ MG_K_NORM, MG_K_COUNT) = range(9)
+KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm"]
+
+_ll = C.c_longlong
+_dp = C.POINTER(C.c_double)
+_lp = C.POINTER(C.c_longlong)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); exactly the symbols include/mgvcycle.h declares
+SIGNATURES = {
+    "mg_create": (C.c_int, [_ll, _ll, _ll, C.POINTER(_vp)]),
+    "mg_set_operator_FP64_INT64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _lp, _lp, _dp]),
+    "mg_set_relax_FP64": (C.c_int, [_vp, _ll, _dp, _ll, _ll, _ll]),
+    "mg_set_cycle_type": (C.c_int, [_vp, _ll]),
+    "mg_set_coarse_dense_inverse_FP64": (C.c_int, [_vp, _ll, _dp]),
+    "mg_finalize": (C.c_int, [_vp]),
+    "mg_set_nrhs": (C.c_int, [_vp, _ll]),
+    "mg_replace_values_FP64": (C.c_int, [_vp, _ll, _ll, _dp, _ll]),
+    "mg_destroy": (C.c_int, [_vp]),
+    "mg_cycle_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, _ll]),
+    "mg_solve_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
+    "mg_spmv_FP64": (C.c_int, [_vp, _ll, _ll, C.c_double, _dp, C.c_double, _dp, _ll]),
+    "mg_cycle_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
+    "mg_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
+    "mg_spmv_dev_FP64": (C.c_int, [_vp, _ll, _ll, C.c_double, _vp, C.c_double, _vp, _ll]),
+    "mg_fused_dev_FP64": (C.c_int, [_vp, _ll, _ll, _vp, _vp, _vp, _ll]),
+    "mg_time_op_dev_FP64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _dp, _dp]),
+    "mg_profile_enable": (C.c_int, [_vp, _ll]),
+    "mg_profile_get": (C.c_int, [_vp, _ll, _ll, _dp, _lp, _dp]),
+    "mg_profile_reset": (C.c_int, [_vp]),
+    "mg_cycle_bytes": (C.c_int, [_vp, _dp]),
+    "mg_device_bytes": (C.c_int, [_vp, _dp]),
+    "mg_last_error": (C.c_char_p, []),
+    "mg_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class MGDeviceError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libmgvcycle.so and bind every symbol of the header.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MGDeviceError(
+            f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the multigrid cycle.")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export the symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int, what: str):
+    if rc != 0:
+        msg = lib.mg_last_error()
+        raise MGDeviceError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def _f64(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i64(a):
+    return a.ctypes.data_as(_lp)
+
+
+def _julia_arrays(M):
+    """scipy CSR -> the (colptr, rowval, nzval) triple Julia holds for the transposed CSC (1-based Int64)."""
+    colptr = np.ascontiguousarray(M.indptr, dtype=np.int64) + 1
+    rowval = np.ascontiguousarray(M.indices, dtype=np.int64) + 1
+    nzval = np.ascontiguousarray(M.data, dtype=np.float64)
+    return colptr, rowval, nzval
+
+
+def _ptr(t) -> int:
+    """Device address of a torch tensor / raw int."""
+    if isinstance(t, int):
+        return t
+    if hasattr(t, "data_ptr"):
+        if not t.is_cuda:
+            raise MGDeviceError("device API called with a CPU tensor")
+        if not t.is_contiguous():
+            raise MGDeviceError("device API needs contiguous tensors")
+        return int(t.data_ptr())
+    raise TypeError("expected a torch CUDA tensor or an integer device address")
+
+
+DENSE_COARSE_MAX = 16384
+
+
+class DeviceHierarchy:
+    """Owns one ``mg_hierarchy`` handle (HBM copy of As/Ps/Rs/relaxPrecs + coarse inverse)."""
+
+    def __init__(self, param, device_id: int = 0, nrhs: Optional[int] = None):
+        self.lib = load_library()
+        self.handle = _vp()
+        self.nlevels = len(param.As)
+        self.n = int(param.As[0].shape[0])
+        self.nrhs = int(nrhs if nrhs is not None else max(1, param.nrhs))
+        lib = self.lib
+        _check(lib, lib.mg_create(self.nlevels, self.nrhs, int(device_id), C.byref(self.handle)), "mg_create")
+        try:
+            self._upload(param)
+        except Exception:
+            self.close()
+            raise
+
+    # -- setup ------------------------------------------------------------------------------------
+    def _set_op(self, level, which, M):
+        colptr, rowval, nzval = _julia_arrays(M)
+        rc = self.lib.mg_set_operator_FP64_INT64(self.handle, level, which, M.shape[0], M.shape[1],
+                                                 _i64(colptr), _i64(rowval), _f64(nzval))
+        _check(self.lib, rc, f"mg_set_operator(level={level}, which={which})")
+
+    def _upload(self, param):
+        lib = self.lib
+        nl = self.nlevels
+        for l in range(1, nl + 1):
+            self._set_op(l, MG_OP_A, param.As[l - 1])
+            if l < nl:
+                self._set_op(l, MG_OP_P, param.Ps[l - 1])
+                self._set_op(l, MG_OP_R, param.Rs[l - 1])
+                d = np.ascontiguousarray(param.relaxPrecs[l - 1], dtype=np.float64)
+                _check(lib, lib.mg_set_relax_FP64(self.handle, l, _f64(d), d.size,
+                                                  int(param.relaxPre(l)), int(param.relaxPost(l))),
+                       f"mg_set_relax(level={l})")
+        _check(lib, lib.mg_set_cycle_type(self.handle, ord(param.cycleType)), "mg_set_cycle_type")
+        nc = int(param.As[-1].shape[0])
+        if nc > DENSE_COARSE_MAX:
+            raise MGDeviceError(
+                f"coarsest level has {nc} rows: the dense-inverse coarse solve is capped at {DENSE_COARSE_MAX}; "
+                "use more levels")
+        if param.LU is None:
+            raise MGDeviceError("param.LU is empty: run MGsetup / SA_AMGsetup first")
+        Ainv = np.asfortranarray(param.LU.solve(np.eye(nc)))        # LU \ I, column-major
+        _check(lib, lib.mg_set_coarse_dense_inverse_FP64(self.handle, nc, _f64(Ainv)), "mg_set_coarse_dense_inverse")
+        _check(lib, lib.mg_finalize(self.handle), "mg_finalize")
+
+    def set_nrhs(self, nrhs: int):
+        _check(self.lib, self.lib.mg_set_nrhs(self.handle, int(nrhs)), "mg_set_nrhs")
+        self.nrhs = int(nrhs)
+
+    def replace_values(self, level: int, which: int, M):
+        nz = np.ascontiguousarray(M.data, dtype=np.float64)
+        _check(self.lib, self.lib.mg_replace_values_FP64(self.handle, level, which, _f64(nz), nz.size),
+               "mg_replace_values")
+
+    def close(self):
+        if self.handle:
+            self.lib.mg_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-buffer hot path ------------------------------------------------------------------
+    @staticmethod
+    def _host_block(a, writable=False):
+        if not isinstance(a, np.ndarray) or a.dtype != np.float64:
+            raise TypeError("expected a float64 numpy array")
+        if a.ndim == 2 and a.shape[1] > 1 and not a.flags.f_contiguous:
+            raise ValueError("2-D blocks must be column-major (Julia layout): use np.asfortranarray")
+        if a.ndim == 1 and not a.flags.c_contiguous:
+            raise ValueError("vectors must be contiguous")
+        if writable and not a.flags.writeable:
+            raise ValueError("x must be writable (it is updated in place)")
+        return a
+
+    def cycle(self, b, x, x_is_zero: int = -1):
+        b = self._host_block(b)
+        x = self._host_block(x, True)
+        nrhs = 1 if b.ndim == 1 else b.shape[1]
+        _check(self.lib, self.lib.mg_cycle_FP64(self.handle, _f64(b), _f64(x), b.shape[0], nrhs, int(x_is_zero)),
+               "mg_cycle")
+        return x
+
+    def solve(self, b, x, tol: float, maxIter: int):
+        b = self._host_block(b)
+        x = self._host_block(x, True)
+        nrhs = 1 if b.ndim == 1 else b.shape[1]
+        iters = C.c_longlong(0)
+        resvec = np.zeros(int(maxIter) + 1)
+        _check(self.lib, self.lib.mg_solve_FP64(self.handle, _f64(b), _f64(x), b.shape[0], nrhs, float(tol),
+                                                int(maxIter), C.byref(iters), _f64(resvec)), "mg_solve")
+        return x, int(iters.value), resvec[: iters.value + 1]
+
+    def spmv(self, level: int, which: int, alpha: float, x, beta: float, y):
+        x = self._host_block(x)
+        y = self._host_block(y, True)
+        nrhs = 1 if x.ndim == 1 else x.shape[1]
+        _check(self.lib, self.lib.mg_spmv_FP64(self.handle, level, which, float(alpha), _f64(x), float(beta),
+                                               _f64(y), nrhs), "mg_spmv")
+        return y
+
+    # -- device-resident hot path (torch CUDA tensors, row-major [n][nrhs]) ---------------------
+    def cycle_dev(self, b, x, x_is_zero: int = -1, nrhs: Optional[int] = None):
+        nrhs = self.nrhs if nrhs is None else nrhs
+        _check(self.lib, self.lib.mg_cycle_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, nrhs, int(x_is_zero)),
+               "mg_cycle_dev")
+
+    def solve_dev(self, b, x, tol: float, maxIter: int, nrhs: Optional[int] = None):
+        nrhs = self.nrhs if nrhs is None else nrhs
+        iters = C.c_longlong(0)
+        resvec = np.zeros(int(maxIter) + 1)
+        _check(self.lib, self.lib.mg_solve_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, nrhs, float(tol),
+                                                    int(maxIter), C.byref(iters), _f64(resvec)), "mg_solve_dev")
+        return int(iters.value), resvec[: iters.value + 1]
+
+    def spmv_dev(self, level, which, alpha, x, beta, y, nrhs: Optional[int] = None):
+        nrhs = self.nrhs if nrhs is None else nrhs
+        _check(self.lib, self.lib.mg_spmv_dev_FP64(self.handle, level, which, float(alpha), _ptr(x), float(beta),
+                                                   _ptr(y), nrhs), "mg_spmv_dev")
+
+    def fused_dev(self, level, kernel, b, x, out, nrhs: Optional[int] = None):
+        nrhs = self.nrhs if nrhs is None else nrhs
+        _check(self.lib, self.lib.mg_fused_dev_FP64(self.handle, level, kernel, _ptr(b), _ptr(x), _ptr(out), nrhs),
+               "mg_fused_dev")
+
+    # -- measurement --------------------------------------------------------------------------------
+    def time_op(self, level: int, kernel: int, reps: int = 20):
+        ms = C.c_double(0.0)
+        bts = C.c_double(0.0)
+        _check(self.lib, self.lib.mg_time_op_dev_FP64(self.handle, level, kernel, self.nrhs, int(reps),
+                                                      C.byref(ms), C.byref(bts)), "mg_time_op_dev")
+        return ms.value, bts.value
+
+    def profile_enable(self, on: bool):
+        _check(self.lib, self.lib.mg_profile_enable(self.handle, 1 if on else 0), "mg_profile_enable")
+
+    def profile_reset(self):
+        _check(self.lib, self.lib.mg_profile_reset(self.handle), "mg_profile_reset")
+
+    def profile(self):
+        """{(level, kernel_name): (total_ms, launches, bytes_per_launch)} for every kernel that ran."""
+        out = {}
+        for l in range(1, self.nlevels + 1):
+            for k in range(MG_K_COUNT):
+                ms, n, bts = C.c_double(0), C.c_longlong(0), C.c_double(0)
+                _check(self.lib, self.lib.mg_profile_get(self.handle, l, k, C.byref(ms), C.byref(n), C.byref(bts)),
+                       "mg_profile_get")
+                if n.value:
+                    out[(l, KERNEL_NAMES[k])] = (ms.value, int(n.value), bts.value)
+        return out
+
+    def cycle_bytes(self) -> float:
+        v = C.c_double(0)
+        _check(self.lib, self.lib.mg_cycle_bytes(self.handle, C.byref(v)), "mg_cycle_bytes")
+        return v.value
+
+    def device_bytes(self) -> float:
+        v = C.c_double(0)
+        _check(self.lib, self.lib.mg_device_bytes(self.handle, C.byref(v)), "mg_device_bytes")
+        return v.value

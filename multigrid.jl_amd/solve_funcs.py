@@ -1,0 +1,74 @@
+"""Host-side mirror of the reference's cycle API: every call goes to the HIP library.
+
+Mirrors reference src/Multigrid/SolveFuncs.jl:3-39 (``solveMG``), MGcycle.jl:1-118 (``recursiveCycle``),
+SpMatMul.jl:4-26 (``SpMatMul``) and SolveFuncs.jl:43-63 (``getMultigridPreconditioner``).
+Same names, argument meaning and in-place contract; the arithmetic runs on the MI355X only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .device import DeviceHierarchy, MG_OP_A, MG_OP_P, MG_OP_R
+from .mgdef import MGparam, hierarchyExists
+from .mgsetup import adjustMemoryForNumRHS
+
+
+def _ncols(b):
+    return 1 if b.ndim == 1 else int(b.shape[1])
+
+
+def to_device(param: MGparam, device_id: int = 0) -> DeviceHierarchy:
+    """Upload the hierarchy (lifecycle hook at the end of MGsetup/SA_AMGsetup, MGsetup.jl:135-137)."""
+    if not hierarchyExists(param):
+        raise RuntimeError("The Hierarchy is empty - run a setup first.")
+    if param.device is None:
+        param.device = DeviceHierarchy(param, device_id=device_id, nrhs=max(1, param.nrhs))
+    return param.device
+
+
+def solveMG(param: MGparam, b: np.ndarray, x: np.ndarray, verbose: bool = False):
+    """``(x, param, iter) = solveMG(param,b,x,verbose)``: x is updated IN PLACE (testGMG.jl:54-55)."""
+    adjustMemoryForNumRHS(param, _ncols(b))
+    dev = to_device(param)
+    _, iters, resvec = dev.solve(b, x, param.relativeTol, param.maxOuterIter)
+    param.resvec = resvec
+    if verbose:
+        for c in range(1, iters + 1):
+            print(f"Cycle {c} done with relres: {resvec[c] / resvec[0]}. Convergence factor: {resvec[c] / resvec[c - 1]}")
+    return x, param, iters
+
+
+def recursiveCycle(param: MGparam, b: np.ndarray, x: np.ndarray, level: int = 1):
+    """One cycle from the finest level.  Only ``level == 1`` is an entry point of the device library."""
+    if level != 1:
+        raise ValueError("the device library owns the recursion: only level=1 can be entered from the host")
+    adjustMemoryForNumRHS(param, _ncols(b))
+    to_device(param).cycle(b, x, -1)
+    return x
+
+
+def getMultigridPreconditioner(param: MGparam, B: np.ndarray, verbose: bool = False):
+    """``M(b) = (z .= 0; recursiveCycle(param,b,z,1); z)`` (SolveFuncs.jl:59): x = 0 on entry."""
+    if not hierarchyExists(param):
+        print("You have to do a setup first.")
+    adjustMemoryForNumRHS(param, _ncols(B))
+    dev = to_device(param)
+    z = np.zeros_like(B, order="F")
+
+    def MMG(b):
+        z[...] = 0.0
+        dev.cycle(np.asfortranarray(b), z, 1)
+        return z
+
+    return MMG
+
+
+_WHICH = {"A": MG_OP_A, "P": MG_OP_P, "R": MG_OP_R}
+
+
+def SpMatMul(param: MGparam, level: int, which: str, x: np.ndarray, target: np.ndarray,
+             alpha: float = 1.0, beta: float = 0.0):
+    """``target = beta*target + alpha*Op*x`` (SpMatMul.jl:4-13) with Op = As/Ps/Rs[level] resident on device."""
+    adjustMemoryForNumRHS(param, _ncols(x))
+    to_device(param).spmv(level, _WHICH[which], alpha, x, beta, target)
+    return target

@@ -1,0 +1,275 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.  CPU restatement (numpy/scipy, fp64) of the multigrid cycle of
+JuliaInv/Multigrid.jl v0.8.0.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this; the product (multigrid.jl_amd/) never does.
+
+PARITY UNPINNED BY VALUE.  The reference path is Julia + the un-vendored Fortran package
+ParSpMatVec 0.1.1 (Manifest.toml:87-91); neither Julia nor gfortran exists in the build image and the
+reference's tests hold no golden vectors (every input is an unseeded rand, every assertion a residual
+threshold: test/Multigrid/testGMG.jl:49,55; testGMGRAPforPoisson.jl:30,40,78; testSAforDivSigGrad.jl:31,38,112).
+What pins this oracle instead (tests/test_oracle.py):
+  (i)   the reference's known-answer thresholds re-expressed with seeded inputs;
+  (ii)  independent formulations: dense two-grid error-propagation algebra on tiny grids;
+  (iii) SpMatMul's in-tree definition ``target = beta*target + alpha*A*x`` (SpMatMul.jl:5,9).
+
+Operators are scipy CSR matrices = the reference's transposed CSC arrays (MGdef.jl:75-77).
+Every function cites the reference lines it restates and keeps their operation order.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+# --------------------------------------------------------------------------------------------------
+# SpMatMul.jl
+# --------------------------------------------------------------------------------------------------
+def SpMatMul(alpha, A, x, beta, target):
+    """target = beta*target + alpha*A*x  (SpMatMul.jl:4-13; fallback mul!(target,adjoint(AT),x,alpha,beta), l.9).
+
+    scipy's csr_matvec accumulates each row sequentially in stored (sorted-column) order - the same
+    in-row order as a row-parallel CSR kernel.  Blocks (N x nrhs) are handled column by column.
+    """
+    Ax = A @ x
+    if beta == 0.0:
+        target[...] = alpha * Ax
+    else:
+        target[...] = beta * target + alpha * Ax
+    return target
+
+
+def SpMatMul2(A, x, target):
+    """alpha = 1, beta = 0 (SpMatMul.jl:16-26)."""
+    return SpMatMul(1.0, A, x, 0.0, target)
+
+
+def addVectors(alpha, x, target):
+    """target += alpha*x  (SpMatMul.jl:29-37, BLAS.axpy!)."""
+    target += alpha * x
+
+
+# --------------------------------------------------------------------------------------------------
+# MGcycle.jl
+# --------------------------------------------------------------------------------------------------
+def _dmul(d, r):
+    return d * r if r.ndim == 1 else d[:, None] * r
+
+
+def relax(A, r, x, b, d, numit):
+    """Damped Jacobi / SPAI-0 sweeps (MGcycle.jl:122-136).  r is left stale after the last sweep (l.124).
+    Note the loop runs numit-1 times and the final update is unconditional: numit=0 still updates once."""
+    for _ in range(1, numit):
+        x += _dmul(d, r)                         # x .+= d.*r            (l.129)
+        SpMatMul(-1.0, A, x, 0.0, r)             # r = -A x              (l.130)
+        addVectors(1.0, b, r)                    # r = r + b             (l.131)
+    x += _dmul(d, r)                             # (l.134)
+    return x
+
+
+def solveCoarsest(param, b, x):
+    """Default branch: z = param.LU \\ b ; x[:] = z  (MGcycle.jl:177-178)."""
+    x[...] = param.LU.solve(np.asarray(b))
+    return x
+
+
+class _Mem:
+    """CYCLEmem per level (MGdef.jl:56-60), sized by adjustMemoryForNumRHS (MGsetup.jl:166-223)."""
+
+    def __init__(self, param, nrhs):
+        self.b, self.r, self.x = [], [], []
+        for l, A in enumerate(param.As):
+            n = A.shape[0]
+            shp = (n,) if nrhs == 1 else (n, nrhs)
+            self.r.append(np.zeros(shp))
+            self.x.append(np.zeros(shp))
+            self.b.append(np.zeros(shp))
+        self.b[-1] = self.r[-1]                  # coarsest .b aliases .r (MGsetup.jl:217-218)
+
+
+def recursiveCycle(param, b, x, level, mem=None, cycleType=None):
+    """One cycle from `level` (1-based), operation order of MGcycle.jl:1-118."""
+    nrhs = 1 if b.ndim == 1 else b.shape[1]
+    if mem is None:
+        mem = _Mem(param, nrhs)
+    if cycleType is None:
+        cycleType = param.cycleType
+    As = param.As
+    nlevels = len(As)
+    if level == nlevels:                         # l.13-18
+        r = mem.r[level - 1]
+        r[...] = b
+        return solveCoarsest(param, r, x)
+    A = As[level - 1]
+    r = mem.r[level - 1]
+    r[...] = b                                   # l.26-28
+    if np.linalg.norm(x) > 0.0:                  # l.29-31
+        SpMatMul(-1.0, A, x, 1.0, r)
+    D = param.relaxPrecs[level - 1]
+    P = param.Ps[level - 1]
+    R = param.Rs[level - 1]
+    npresmth = param.relaxPre(level)
+    npostsmth = param.relaxPost(level)
+    x = relax(A, r, x, b, D, npresmth)           # l.54
+    SpMatMul(-1.0, A, x, 0.0, r)                 # l.58
+    addVectors(1.0, b, r)                        # l.60
+    xc = mem.x[level]
+    xc[...] = 0.0                                # l.63-64
+    bc = mem.b[level]
+    bc = SpMatMul2(R, r, bc)                     # l.66
+    if level == nlevels - 1:
+        xc = solveCoarsest(param, bc, xc)        # l.67-69
+    else:
+        if cycleType == "K":
+            raise NotImplementedError("K-cycle: SURVEY 8f-3")
+        xc = recursiveCycle(param, bc, xc, level + 1, mem, cycleType)          # l.78
+        if cycleType == "W":
+            xc = recursiveCycle(param, bc, xc, level + 1, mem, "W")            # l.79-80
+        elif cycleType == "F":
+            xc = recursiveCycle(param, bc, xc, level + 1, mem, "V")            # l.81-84
+    SpMatMul(1.0, P, xc, 1.0, x)                 # x += P xc             (l.90)
+    r[...] = b                                   # l.92
+    SpMatMul(-1.0, A, x, 1.0, r)                 # l.93
+    x = relax(A, r, x, b, D, npostsmth)          # l.102
+    return x
+
+
+# --------------------------------------------------------------------------------------------------
+# SolveFuncs.jl
+# --------------------------------------------------------------------------------------------------
+def solveMG(param, b, x, verbose=False, history=None):
+    """solveMG (SolveFuncs.jl:3-39).  Returns (x, param, iter); x updated in place.
+    `history` (list) receives [res_init, res after cycle 1, ...] and, if it is a dict, also x per cycle."""
+    nrhs = 1 if b.ndim == 1 else b.shape[1]
+    mem = _Mem(param, nrhs)
+    tol = param.relativeTol
+    maxIter = param.maxOuterIter
+    A = param.As[0]
+    r = mem.r[0]
+    r[...] = b
+    if np.linalg.norm(x) == 0:
+        res = np.linalg.norm(b)
+    else:
+        SpMatMul(-1.0, A, x, 1.0, r)
+        res = np.linalg.norm(r)
+    res_init = res
+    resvec = [res_init]
+    xs = []
+    it = 0
+    for count in range(1, maxIter + 1):
+        x = recursiveCycle(param, b, x, 1, mem)
+        SpMatMul(-1.0, A, x, 0.0, r)
+        addVectors(1.0, b, r)
+        it += 1
+        res_prev = res
+        res = np.linalg.norm(r)
+        resvec.append(res)
+        xs.append(x.copy())
+        if verbose:
+            print(f"Cycle {count} done with relres: {res / res_init}. Convergence factor: {res / res_prev}")
+        if res / res_init < tol:
+            break
+    if isinstance(history, list):
+        history.extend(resvec)
+    elif isinstance(history, dict):
+        history["resvec"] = np.array(resvec)
+        history["xs"] = xs
+    return x, param, it
+
+
+# --------------------------------------------------------------------------------------------------
+# Setup restated with explicit loops / dense algebra (small grids only): independent of the
+# vectorised host code in multigrid.jl_amd/mgsetup.py that it checks.
+# --------------------------------------------------------------------------------------------------
+def get1DFWInterp_dense(n_nodes, geometric=False):
+    """GeometricTransferOperators.jl:22-46, entry by entry."""
+    if n_nodes > 2:
+        T = np.zeros((n_nodes, n_nodes))
+        for i in range(n_nodes):
+            T[i, i] = 1.0
+            if i > 0:
+                T[i, i - 1] = 0.5
+            if i < n_nodes - 1:
+                T[i, i + 1] = 0.5
+        if n_nodes % 2 == 1:
+            P = T[:, 0::2]                                       # l.27-29
+        elif geometric:
+            P = np.eye(n_nodes)                                  # l.31-33
+        else:
+            cols = list(range(0, n_nodes, 2)) + [n_nodes - 1]    # l.35
+            P = T[:, cols].copy()
+            P[-2:, -2:] = np.eye(2)                              # l.36
+    else:
+        P = np.eye(n_nodes)                                      # l.41-43
+    return P, P.shape[1]
+
+
+def getFWInterp_dense(n_nodes, geometric=False):
+    """kron(P3, kron(P2, P1)) (GeometricTransferOperators.jl:5-20)."""
+    Ps = [get1DFWInterp_dense(int(k), geometric)[0] for k in n_nodes]
+    P = Ps[0]
+    for Pk in Ps[1:]:
+        P = np.kron(Pk, P)
+    return P, np.array([p.shape[1] for p in Ps])
+
+
+def getSPAIprec_dense(Adense):
+    """Q_i = diag_i / sum_j |AT[i,j]|^2, AT = A' (MGsetup.jl:359-362): column norms of A."""
+    AT = Adense.T
+    s = (AT ** 2).sum(axis=1)
+    return np.diag(AT) / s
+
+
+def getRelaxPrec_dense(Adense, relaxType, relaxParam):
+    """MGsetup.jl:142-149."""
+    if relaxType in ("Jac", "Jac-GMRES"):
+        return relaxParam / np.diag(Adense)
+    if relaxType == "SPAI":
+        return relaxParam * getSPAIprec_dense(Adense)
+    raise ValueError("Unknown relaxation type !!!!")
+
+
+class Hierarchy:
+    """Minimal MGparam stand-in the oracle cycle runs on."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def MGsetup_dense(Adense, n_cells, levels, relaxType, relaxParam, relaxPre, relaxPost, cycleType="V",
+                  relativeTol=1e-6, maxOuterIter=20):
+    """MGsetup (MGsetup.jl:7-138), FullWeighting + Galerkin, with dense matrices (tiny grids only)."""
+    n = np.asarray(n_cells, dtype=np.int64)
+    dim = n.size
+    As = [np.array(Adense, dtype=np.float64)]
+    Ps, Rs, relaxPrecs = [], [], []
+    for l in range(1, levels):
+        A = As[-1]
+        P, nc_nodes = getFWInterp_dense(n + 1, False)           # l.54
+        R = (0.5 ** dim) * P.T                                  # l.56-60
+        relaxPrecs.append(getRelaxPrec_dense(A, relaxType, relaxParam))   # l.76
+        if P.shape[0] == P.shape[1]:                            # l.84-92
+            break
+        Ps.append(P)
+        Rs.append(R)
+        As.append(R @ (A @ P))                                  # l.102
+        n = nc_nodes - 1
+    csr = lambda M: sp.csr_matrix(M)
+    pre = relaxPre if callable(relaxPre) else (lambda level: relaxPre)
+    post = relaxPost if callable(relaxPost) else (lambda level: relaxPost)
+    return Hierarchy(As=[csr(a) for a in As], Ps=[csr(p) for p in Ps], Rs=[csr(r) for r in Rs],
+                     relaxPrecs=relaxPrecs, LU=spla.splu(sp.csc_matrix(As[-1])), relaxPre=pre, relaxPost=post,
+                     cycleType=cycleType, relativeTol=relativeTol, maxOuterIter=maxOuterIter,
+                     dense_As=As, dense_Ps=Ps, dense_Rs=Rs)
+
+
+def two_grid_error_matrix(h: Hierarchy, nu1, nu2):
+    """Textbook two-grid error propagation  E = S^nu2 (I - P Ac^-1 R A) S^nu1,  S = I - diag(d) A.
+    Independent formulation used to check recursiveCycle on 2-level hierarchies."""
+    A = h.dense_As[0]
+    P = h.dense_Ps[0]
+    R = h.dense_Rs[0]
+    Ac = h.dense_As[1]
+    n = A.shape[0]
+    S = np.eye(n) - np.diag(h.relaxPrecs[0]) @ A
+    K = np.eye(n) - P @ np.linalg.solve(Ac, R @ A)
+    return np.linalg.matrix_power(S, nu2) @ K @ np.linalg.matrix_power(S, nu1)
