@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py - V-cycle DoF-updates/s + achieved HBM GB/s (BASELINE.json metric) on MI355X.
+
+A "step" is one iteration of the reference's solveMG loop (src/Multigrid/SolveFuncs.jl:24-37): one
+recursiveCycle from the finest level + the residual SpMV + the Frobenius norm.  The timed region is
+exactly K steps (mg_solve_dev_FP64 with maxIter=K, tol=0, x0=0 as SURVEY.md 8d prescribes) with the
+hierarchy, b and x resident in HBM.
+
+Workloads (BASELINE.json configs):
+  c2 (default)  3-D 7-pt Poisson 256^3 cells, GMG V(2,1) damped Jacobi w=0.8, 6 levels, fp64, nrhs=1
+  c5            same operator, 16 right-hand sides (block SpMM path)
+  c1            32^3 cells (CPU-plumbing size; parity case, not a bench line)
+Use --cells N to shrink the grid for quick checks (the JSON then names the reduced workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c5"])
+    ap.add_argument("--cells", type=int, default=0, help="override cells per dimension")
+    ap.add_argument("--levels", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cycles", type=int, default=0, help="cycles of the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def levels_for(cells):
+    """Coarsest grid 9^3 nodes: 32 -> 3, 256 -> 6, 512 -> 7."""
+    lv = 1
+    c = cells
+    while c > 8 and c % 2 == 0:
+        c //= 2
+        lv += 1
+    return lv
+
+
+def main():
+    args = parse()
+    import torch
+    import multigrid_jl_amd as mg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the multigrid cycle has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cells = args.cells or {"c1": 32, "c2": 256, "c5": 256}[args.workload]
+    nrhs = 16 if args.workload == "c5" else 1
+    levels = args.levels or levels_for(cells)
+    K, W = args.steps, args.warmup
+
+    # ---- host setup (CPU, as in the reference) ---------------------------------------------------
+    t0 = time.perf_counter()
+    A, mesh = mg.poisson_shifted([cells] * 3)
+    t_op = time.perf_counter() - t0
+    p = mg.getMGparam(np.float64, np.int64, levels, os.cpu_count() or 8, K, 0.0, "Jac", 0.8, 2, 1, "V",
+                      "NoMUMPS", 0.5, 0.0, "FullWeighting")
+    t0 = time.perf_counter()
+    mg.MGsetup(A, mesh, p, nrhs)
+    t_setup = time.perf_counter() - t0
+    b_host = mg.seeded_rhs(A, nrhs)
+    t0 = time.perf_counter()
+    h = mg.to_device(p, device_id=local_rank)
+    t_upload = time.perf_counter() - t0
+    n = A.shape[0]
+    log(f"[rank {rank}] {cells}^3 cells, N={n}, nnz={A.nnz}, levels={p.levels}, nrhs={nrhs}: operator {t_op:.1f}s, "
+        f"MGsetup {t_setup:.1f}s, upload {t_upload:.1f}s, HBM {h.device_bytes() / 1e9:.2f} GB")
+
+    # device-resident b / x (row-major [n][nrhs] is the library's block layout)
+    b = torch.from_numpy(np.ascontiguousarray(b_host)).to(dev)
+    x = torch.zeros_like(b)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up, then exactly K timed steps ------------------------------------------------------
+    if W > 0:
+        h.solve_dev(b, x, 0.0, W)
+    x.zero_()
+    barrier()
+    t0 = time.perf_counter()
+    iters, resvec = h.solve_dev(b, x, 0.0, K)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert iters == K
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    relres = float(resvec[-1] / resvec[0])
+    dof_per_s = world * n * nrhs * K / dt          # replicas when world > 1
+
+    # ---- per-kernel HIP-event accounting over the same K steps (separate, instrumented pass) -----
+    h.profile_reset()
+    h.profile_enable(True)
+    x.zero_()
+    torch.cuda.synchronize()
+    h.solve_dev(b, x, 0.0, K)
+    h.profile_enable(False)
+    prof = h.profile()
+    tot_ms = sum(v[0] for v in prof.values())
+    # dominant kernel: the fine-level fused smoother/residual SpMV (csr_stream_spmv/spmm on As[1])
+    dom = {}
+    for name in ("smooth", "residual"):
+        ms, cnt, bts = prof[(1, name)]
+        dom[name] = {"avg_ms": ms / cnt, "launches": cnt, "bytes": bts, "gbs": bts / (ms / cnt) / 1e6}
+    ms_s, cnt_s, bts_s = prof[(1, "smooth")]
+    achieved = bts_s / (ms_s / cnt_s) / 1e6        # GB/s
+    step_bytes = sum(v[2] * v[1] for v in prof.values()) / K            # algorithmic bytes per step (all launches)
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"{args.workload}_{cells}", {}).get("smooth_level1_bytes")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "csr_stream_spmv<SMOOTH> level 1" if nrhs == 1 else "csr_stream_spmm<SMOOTH> level 1",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": bts_s, "avg_launch_ms": round(ms_s / cnt_s, 5),
+                "launches": cnt_s,
+                "residual_level1": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in dom["residual"].items()},
+                "step_algorithmic_GB": round(step_bytes / 1e9, 4),
+                "step_hbm_gbs": round(step_bytes / (dt / K) / 1e9, 1),
+                "kernel_time_share": {f"L{l}:{k}": round(v[0] / tot_ms, 4) for (l, k), v in sorted(prof.items()) if v[0] / tot_ms > 0.01}}
+
+    # ---- CPU baseline: the C/OpenMP oracle ("port") on a bounded sample of the same workload ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle
+        cores = c_oracle.max_threads()
+        co = c_oracle.COracle(p, nrhs)
+        xc = np.zeros_like(b_host)
+        ncyc = args.cpu_cycles or (2 if cells >= 200 else 10)
+        if nrhs > 1:
+            ncyc = args.cpu_cycles or 1
+        co.solveMG(b_host, xc, 0.0, 1, cores)          # warm-up cycle
+        xc[...] = 0.0
+        t0 = time.perf_counter()
+        it, rv = co.solveMG(b_host, xc, 0.0, ncyc, cores)
+        tc = time.perf_counter() - t0
+        cpu = {"value": round(n * nrhs * it / tc, 1), "unit": "DoF-updates/s", "cores": cores, "kind": "port",
+               "sample": f"{it} solveMG steps of the same workload ({cells}^3 cells, nrhs={nrhs}) on the C/OpenMP oracle, "
+                         f"Int64 indices, unfused op sequence, {tc:.2f}s",
+               "relres_after_sample": float(rv[-1] / rv[0])}
+        # parity spot-check at full size: the oracle's residual history on its sample vs the device's
+        k = min(len(rv), len(resvec))
+        cpu["resvec_rel_diff_vs_gpu"] = float(np.abs(rv[:k] - resvec[:k]).max() / resvec[0])
+
+    if rank == 0:
+        out = {
+            "metric": "V-cycle DoF-updates/s", "value": round(dof_per_s, 1), "unit": "DoF-updates/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"3D 7-pt Poisson {cells}^3 cells ({n} nodal DoF), GMG V(2,1) damped-Jacobi w=0.8, "
+                                   f"{p.levels} levels, nrhs={nrhs}, fp64, solveMG step = cycle + residual + norm",
+                       "cells": cells, "levels": p.levels, "nrhs": nrhs, "N": n, "nnz": int(A.nnz),
+                       "parallelism": "1 process per GPU" if world == 1 else f"{world} independent replicas"},
+            "relres_after_steps": relres,
+            "setup_s": {"operator": round(t_op, 2), "MGsetup": round(t_setup, 2), "upload": round(t_upload, 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    mg.clear_(p)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

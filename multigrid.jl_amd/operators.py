@@ -68,8 +68,20 @@ def getNodalGradientMatrix(mesh: RegularMesh):
 
 
 def getNodalLaplacianMatrix(mesh: RegularMesh):
-    G = getNodalGradientMatrix(mesh)
-    return (G.T @ G).tocsr()
+    """G'G assembled as the Kronecker sum of the 1-D operators D_k'D_k (same matrix, much cheaper to build)."""
+    n, h = mesh.n, mesh.h
+    I = [sp.identity(int(k) + 1, format="csr") for k in n]
+    L = []
+    for k, hk in zip(n, h):
+        D = _ddx(int(k), float(hk))
+        L.append((D.T @ D).tocsr())
+    if mesh.dim == 2:
+        A = sp.kron(I[1], L[0], format="csr") + sp.kron(L[1], I[0], format="csr")
+    else:
+        A = _kron3(I[2], I[1], L[0]) + _kron3(I[2], L[1], I[0]) + _kron3(L[2], I[1], I[0])
+    A = A.tocsr()
+    A.sort_indices()
+    return A
 
 
 def getEdgeAverageMatrix(mesh: RegularMesh):
