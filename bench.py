@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cells", type=int, default=0, help="override cells per dimension")
     ap.add_argument("--levels", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed kernel launches before warm-up")
     ap.add_argument("--cpu-cycles", type=int, default=0, help="cycles of the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -102,7 +103,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- warm-up, then exactly K timed steps ------------------------------------------------------
+    # ---- pre-warm (untimed): ~0.5 s of the fine-level kernels so that clocks/power state and the HIP
+    # runtime's lazily grown pools settle before anything is timed (a one-off 70-80 ms stall was observed
+    # at a random point in the first tens of ms of GPU activity of a fresh process) ------------------
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < args.prewarm:
+        h.time_op(1, mg.device.MG_K_SMOOTH, 50)
+    # ---- W untimed warm-up steps, then exactly K timed steps ----------------------------------------
     if W > 0:
         h.solve_dev(b, x, 0.0, W)
     x.zero_()
