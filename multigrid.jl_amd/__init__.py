@@ -9,6 +9,7 @@ from .mgsetup import (MGsetup, getRelaxPrec, getSPAIprec, adjustMemoryForNumRHS,
                       transposeHierarchy, defineCoarsestAinv, multilevelOperatorConstructor,
                       getMultilevelOperatorConstructor, galerkin)
 from .transfer_operators import getFWInterp, get1DFWInterp
+from .sa_amg import (SA_AMGsetup, getAggregation, getStrengthMatrix, neighborhoodAggregationNew, aggrArray2P)
 from .solve_funcs import solveMG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
 from .operators import (getRegularMesh, getNodalGradientMatrix, getNodalLaplacianMatrix,
                         getNodalDivSigGradMatrix, poisson_shifted, anisotropic_divsiggrad, seeded_rhs)

@@ -27,6 +27,23 @@ constexpr int PAIRS = ITEMS / 2;
 
 enum Mode { AXPBY = 0, RESID = 1, SMOOTH = 2 };
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i2_t __attribute__((ext_vector_type(2)));
+// The matrix stream (values, column indices) is read exactly once per launch.  NT = non-temporal loads:
+// the stream then does not evict the gather window of the source vector from the XCD's L2.  Measured on
+// C2 (profiles/r01_nt_ab.md): +11..17 % on the transfer operators, -2 % on the 7-point A -> chosen
+// per operator by the host (Csr::nt).
+template <bool NT>
+__device__ __forceinline__ d2_t load_stream(const double* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(p));
+  return *reinterpret_cast<const d2_t*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ i2_t load_stream(const int* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const i2_t*>(p));
+  return *reinterpret_cast<const i2_t*>(p);
+}
+
 struct CsrDev {
   const int* rowptr;   // n_rows+1, 0-based
   const int* colidx;   // nnz (+pad), 0-based
@@ -66,7 +83,7 @@ __device__ __forceinline__ double epilogue(const VecArgs& v, int row, double acc
 // ------------------------------------------------------------------------------------------------
 // CSR-stream SpMV, one right-hand side.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool NT>
 __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
   __shared__ double prod[CHUNK];
   __shared__ int srow[MAXROWS + 1];
@@ -109,17 +126,17 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
 
   // ---- issue every global load up front: matrix stream, row pointers, epilogue operands -------
   const int base = k0 & ~1;  // 16-B aligned start of the value stream
-  double2 va[PAIRS];
-  int2 ca[PAIRS];
+  d2_t va[PAIRS];
+  i2_t ca[PAIRS];
 #pragma unroll
   for (int it = 0; it < PAIRS; ++it) {
     const int idx = base + it * (2 * BLK) + 2 * tid;
     if (idx < k1) {
-      va[it] = *reinterpret_cast<const double2*>(A.val + idx);
-      ca[it] = *reinterpret_cast<const int2*>(A.colidx + idx);
+      va[it] = load_stream<NT>(A.val + idx);
+      ca[it] = load_stream<NT>(A.colidx + idx);
     } else {
-      va[it] = make_double2(0.0, 0.0);
-      ca[it] = make_int2(0, 0);
+      va[it] = d2_t{0.0, 0.0};
+      ca[it] = i2_t{0, 0};
     }
   }
   if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
@@ -136,10 +153,10 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
   for (int it = 0; it < PAIRS; ++it) {
     const int idx = base + it * (2 * BLK) + 2 * tid;
     if (idx < k1) {
-      double2 p;
+      d2_t p;
       p.x = va[it].x * v.x[ca[it].x];
       p.y = va[it].y * v.x[ca[it].y];
-      *reinterpret_cast<double2*>(&prod[it * (2 * BLK) + 2 * tid]) = p;
+      *reinterpret_cast<d2_t*>(&prod[it * (2 * BLK) + 2 * tid]) = p;
     }
   }
   __syncthreads();
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
 // (G = pow2 >= nrhs, <= 64) own one row x one RHS column each and walk the row from LDS (broadcast
 // reads); every x gather is one contiguous nrhs*8-byte segment.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool NT>
 __global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int G) {
   __shared__ double sval[CHUNK];
   __shared__ int scol[CHUNK];
@@ -184,10 +201,8 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int 
     for (int it = 0; it < PAIRS; ++it) {
       const int idx = base + it * (2 * BLK) + 2 * tid;
       if (idx < k1) {
-        *reinterpret_cast<double2*>(&sval[it * (2 * BLK) + 2 * tid]) =
-            *reinterpret_cast<const double2*>(A.val + idx);
-        *reinterpret_cast<int2*>(&scol[it * (2 * BLK) + 2 * tid]) =
-            *reinterpret_cast<const int2*>(A.colidx + idx);
+        *reinterpret_cast<d2_t*>(&sval[it * (2 * BLK) + 2 * tid]) = load_stream<NT>(A.val + idx);
+        *reinterpret_cast<i2_t*>(&scol[it * (2 * BLK) + 2 * tid]) = load_stream<NT>(A.colidx + idx);
       }
     }
     if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
@@ -250,6 +265,30 @@ __global__ __launch_bounds__(BLK) void dscale_kernel(const double* __restrict__ 
   } else {
     for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < total; i += stride)
       x[i] = d[i / nrhs] * b[i];
+  }
+}
+
+// xout[i][c] = x[i][c] + d[i] * r[i][c] : a damped-Jacobi update from an already available residual
+// (MGcycle.jl:129/134 `x .+= d.*r`), used when r = b - A x is still valid from the previous step.
+__global__ __launch_bounds__(BLK) void xpdr_kernel(const double* __restrict__ x,
+                                                   const double* __restrict__ d,
+                                                   const double* __restrict__ r,
+                                                   double* __restrict__ xout, long long n, int nrhs) {
+  const long long total = n * nrhs;
+  const long long stride = (long long)gridDim.x * BLK;
+  if (nrhs == 1) {
+    const long long n2 = total >> 1;
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n2; i += stride) {
+      const double2 xx = reinterpret_cast<const double2*>(x)[i];
+      const double2 dd = reinterpret_cast<const double2*>(d)[i];
+      const double2 rr = reinterpret_cast<const double2*>(r)[i];
+      reinterpret_cast<double2*>(xout)[i] = make_double2(xx.x + dd.x * rr.x, xx.y + dd.y * rr.y);
+    }
+    if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+      xout[total - 1] = x[total - 1] + d[total - 1] * r[total - 1];
+  } else {
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < total; i += stride)
+      xout[i] = x[i] + d[i / nrhs] * r[i];
   }
 }
 

@@ -86,6 +86,7 @@ struct Csr {
   DevBuf<int> rowptr, colidx, blk_row;
   DevBuf<double> val;
   int nblocks = 0;
+  bool nt = false;  // non-temporal loads of the matrix stream (mg_kernels.hpp load_stream)
   mgk::CsrDev dev() const {
     mgk::CsrDev d;
     d.rowptr = rowptr.p;
@@ -232,12 +233,14 @@ int pow2_ge(long long v) {
 template <int MODE>
 int launch_csr(mg_hierarchy* h, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
+  const dim3 grid(M.nblocks), blk(mgk::BLK);
   if (v.nrhs == 1) {
-    hipLaunchKernelGGL(mgk::csr_stream_spmv<MODE>, dim3(M.nblocks), dim3(mgk::BLK), 0, h->stream,
-                       M.dev(), v);
+    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, h->stream, M.dev(), v);
+    else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, h->stream, M.dev(), v);
   } else {
-    hipLaunchKernelGGL(mgk::csr_stream_spmm<MODE>, dim3(M.nblocks), dim3(mgk::BLK), 0, h->stream,
-                       M.dev(), v, pow2_ge(v.nrhs));
+    const int G = pow2_ge(v.nrhs);
+    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, true>), grid, blk, 0, h->stream, M.dev(), v, G);
+    else hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, false>), grid, blk, 0, h->stream, M.dev(), v, G);
   }
   HIP_TRY(hipGetLastError());
   return MG_OK;
@@ -285,6 +288,15 @@ int k_dscale(mg_hierarchy* h, int level, const double* d, const double* b, doubl
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
+// xout = x + d.*r (first sweep when r = b - A x is already known)
+int k_xpdr(mg_hierarchy* h, int level, const double* x, const double* d, const double* r, double* xout,
+           long long n) {
+  ProfScope ps(h, level, MG_K_DSCALE, 8.0 * (double)n * (1.0 + 3.0 * (double)h->nrhs));
+  hipLaunchKernelGGL(mgk::xpdr_kernel, dim3(grid_for(n * h->nrhs / 2 + 1)), dim3(mgk::BLK), 0,
+                     h->stream, x, d, r, xout, n, (int)h->nrhs);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
 int k_fill(mg_hierarchy* h, double* x, long long n, double val) {
   hipLaunchKernelGGL(mgk::fill_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, x, n, val);
   HIP_TRY(hipGetLastError());
@@ -324,8 +336,10 @@ int norm_sync(mg_hierarchy* h, const double* x, long long len, double* out) {
 // ---- the cycle ------------------------------------------------------------------------------------
 // Returns in *result the buffer (xa or xb) that holds the level's x after the cycle.
 // l is 0-based.  xa holds the incoming x when !x_zero; xb is the Jacobi ping-pong partner.
+// r_valid: L.r already holds b - A*x for the incoming x (solveMG computed it for its stopping test,
+// SolveFuncs.jl:26-30, and recursiveCycle would recompute the same values, MGcycle.jl:26-31).
 int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero,
-                char ctype, double** result) {
+                char ctype, double** result, bool r_valid = false) {
   const int nl = (int)h->nlevels;
   if (l == nl - 1) {  // solveCoarsest (MGcycle.jl:13-18,67-69,177): x = LU \ b
     MG_TRY(k_coarse(h, l, b, xa));
@@ -343,6 +357,10 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   // pre-smoothing (MGcycle.jl:26-31,54).  x == 0: r = b, so the first sweep is x = d.*b.
   if (x_zero) {
     MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
+    --npre;
+  } else if (r_valid) {
+    MG_TRY(k_xpdr(h, l, cur, L.d.p, L.r.p, alt, L.n));
+    std::swap(cur, alt);
     --npre;
   }
   for (long long s = 0; s < npre; ++s) {
@@ -420,7 +438,8 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
   auto tprev = std::chrono::steady_clock::now();
   for (long long count = 1; count <= maxIter; ++count) {
     double* out = nullptr;
-    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out));
+    // from the second step on, L.r = b - A*x is the residual just computed for the stopping test
+    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero));
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
     MG_TRY(k_residual(h, 0, L.A, b, cur, L.r.p));  // SolveFuncs.jl:26-27
@@ -634,6 +653,11 @@ int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which
   HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(M->blk_row.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
   M->set = true;
+  // cache policy of the matrix stream: non-temporal once the operator is too large to stay in the
+  // 256 MiB Infinity Cache between two uses anyway (measured, profiles/r01_nt_ab.md: +2..17 % on the
+  // 685 MB..1.4 GB operators of C2, -5..25 % on the 89 MB ones); MG_NT=0/1 forces one policy
+  M->nt = (12.0 * (double)nnz > 128.0e6);
+  if (const char* e = std::getenv("MG_NT")) M->nt = (e[0] == '1');
   h->finalized = false;
   return MG_OK;
 }

@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmgvcycle.so")
+LIB_PATH = os.environ.get("MGVCYCLE_LIB") or os.path.join(_HERE, "csrc", "libmgvcycle.so")   # override: experiment builds
 
 MG_OP_A, MG_OP_P, MG_OP_R = 0, 1, 2
 (MG_K_SPMV, MG_K_RESIDUAL, MG_K_SMOOTH, MG_K_RESTRICT, MG_K_PROLONG, MG_K_DSCALE, MG_K_COARSE,

@@ -273,3 +273,152 @@ def two_grid_error_matrix(h: Hierarchy, nu1, nu2):
     S = np.eye(n) - np.diag(h.relaxPrecs[0]) @ A
     K = np.eye(n) - P @ np.linalg.solve(Ac, R @ A)
     return np.linalg.matrix_power(S, nu2) @ K @ np.linalg.matrix_power(S, nu1)
+
+
+# --------------------------------------------------------------------------------------------------
+# SA-AMG.jl restated with literal (1-based, pure-Python) loops - small cases only.
+# --------------------------------------------------------------------------------------------------
+def getStrengthMatrix_loops(A, theta):
+    """SA-AMG.jl:88-116 on the CSC arrays of AT (= CSR arrays of A), loop for loop.  Returns dense S + S'."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    n = A.shape[0]
+    colptr = A.indptr + 1
+    rowval = A.indices + 1
+    nzval = -A.data.copy()                                         # S = -AT
+    mm = 1e-16 * nzval.max()
+    for j in range(1, n + 1):
+        maxVal_j = mm
+        for g in range(colptr[j - 1], colptr[j]):
+            if nzval[g - 1] > maxVal_j:
+                maxVal_j = nzval[g - 1]
+        scal_k = 1.0 / maxVal_j
+        for g in range(colptr[j - 1], colptr[j]):
+            nzval[g - 1] *= scal_k
+        for g in range(colptr[j - 1], colptr[j]):
+            if rowval[g - 1] == j:
+                nzval[g - 1] = 1.0
+        for g in range(colptr[j - 1], colptr[j]):
+            if nzval[g - 1] < theta:
+                nzval[g - 1] = 0.0
+    S = np.zeros((n, n))
+    for j in range(1, n + 1):
+        for g in range(colptr[j - 1], colptr[j]):
+            S[rowval[g - 1] - 1, j - 1] = nzval[g - 1]
+    return S + S.T                                                 # Julia drops the zeros of the sum (note N3)
+
+
+def neighborhoodAggregationNew_loops(Sdense):
+    """SA-AMG.jl:119-211, literal, including the nested second loop of pass 3 (note N2).
+    Sdense: symmetric; its non-zeros are the stored entries."""
+    n = Sdense.shape[0]
+    cols = [np.nonzero(Sdense[:, k])[0] + 1 for k in range(n)]     # sorted row indices of column k (1-based)
+    tau = 3.0
+    aggr = [0] * (n + 1)
+    aux = [0.0] * (n + 1)
+    aux_count = [0] * (n + 1)
+    avg = sum(len(c) for c in cols) / n
+    for k in range(1, n + 1):
+        if len(cols[k - 1]) > tau * avg:
+            aux_count[k] = -1
+    for k in range(1, n + 1):
+        flag = False
+        if aux_count[k] == -1:
+            continue
+        for j in cols[k - 1]:
+            if aggr[j] != 0:
+                flag = True
+                break
+        if not flag:
+            for j in cols[k - 1]:
+                if aux_count[j] != -1:
+                    aggr[j] = k
+                    aux_count[k] += 1
+    for k in range(1, n + 1):
+        flag = False
+        if aux_count[k] != -1:
+            continue
+        aux_count[k] = 0
+        for j in cols[k - 1]:
+            if aggr[j] != 0:
+                flag = True
+                break
+        if not flag:
+            for j in cols[k - 1]:
+                aggr[j] = k
+                aux_count[k] += 1
+    for k in range(1, n + 1):
+        chosen_score = 0.0
+        chosen = 0
+        if aggr[k] == 0:
+            for j in cols[k - 1]:
+                if aggr[j] > 0:
+                    a = aggr[j]
+                    aux[a] += Sdense[j - 1, k - 1]
+                for j2 in cols[k - 1]:
+                    if aggr[j2] > 0:
+                        a = aggr[j2]
+                        if chosen_score < aux[a] / aux_count[a]:
+                            chosen_score = aux[a] / aux_count[a]
+                            chosen = a
+                            aux[a] = 0
+                aggr[k] = -chosen
+    for k in range(1, n + 1):
+        if aggr[k] < 0:
+            aggr[k] = -aggr[k]
+    return np.array(aggr[1:], dtype=np.int64)
+
+
+def aggrArray2P_loops(aggr):
+    """SA-AMG.jl:213-224."""
+    n = len(aggr)
+    fine2coarse = [0] * (n + 1)
+    cnt = 0
+    for i in range(1, n + 1):
+        if aggr[i - 1] == i:
+            cnt += 1
+            fine2coarse[i] = cnt
+    P = np.zeros((n, cnt))
+    for i in range(1, n + 1):
+        c = fine2coarse[aggr[i - 1]]
+        if c == 0:
+            raise RuntimeError("nodes without aggregates")
+        P[i - 1, c - 1] = 1.0
+    return P
+
+
+def SA_AMGsetup_dense(Adense, levels, relaxType, relaxParam, theta, relaxPre, relaxPost, cycleType="V",
+                      relativeTol=1e-6, maxOuterIter=20):
+    """SA_AMGsetup (SA-AMG.jl:8-76) in the reference's own transposed variables, dense."""
+    As = [np.array(Adense, dtype=np.float64)]
+    Ps, Rs, relaxPrecs = [], [], []
+    for l in range(1, levels):
+        A = As[-1]
+        AT = A.T
+        d = getRelaxPrec_dense(A, relaxType, relaxParam)               # l.28
+        n = A.shape[0]
+        if n <= 100:                                                   # l.79-81
+            break
+        S = getStrengthMatrix_loops(sp.csr_matrix(A), theta)
+        P0 = aggrArray2P_loops(neighborhoodAggregationNew_loops(S))    # n x Nc
+        P0T = P0.T                                                     # P0 = sparse(P0') (l.34)
+        if P0T.shape[0] == P0T.shape[1]:
+            break
+        relaxPrecs.append(d)
+        DAT = AT @ np.diag(d)                                          # l.44
+        rho = min(np.abs(DAT).sum(), np.abs(DAT).max())                # l.45, entry-wise norms (note N1)
+        PT = P0T - (1.33 / rho) * (P0T @ DAT)                          # l.46
+        RT = PT.T                                                      # l.47
+        Ps.append(PT.T)                                                # applied operator P  = PT'
+        Rs.append(RT.T)                                                # applied operator R  = RT'
+        Act = PT @ AT @ RT                                             # l.50
+        As.append(Act.T)
+    nc = As[-1].shape[0]
+    As[-1] = As[-1] + 1e-8 * np.abs(As[-1]).sum() * np.eye(nc)         # l.63
+    pre = relaxPre if callable(relaxPre) else (lambda level: relaxPre)
+    post = relaxPost if callable(relaxPost) else (lambda level: relaxPost)
+    csr = lambda M: sp.csr_matrix(M)
+    return Hierarchy(As=[csr(a) for a in As], Ps=[csr(p) for p in Ps], Rs=[csr(r) for r in Rs],
+                     relaxPrecs=relaxPrecs, LU=spla.splu(sp.csc_matrix(As[-1])), relaxPre=pre, relaxPost=post,
+                     cycleType=cycleType, relativeTol=relativeTol, maxOuterIter=maxOuterIter,
+                     dense_As=As, dense_Ps=Ps, dense_Rs=Rs)

@@ -24,6 +24,7 @@ x.zero_(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(10): h.cycle_dev(b, x, 1 if i == 0 else 0)
 print(f"cycle_dev x10: {(time.perf_counter()-t0)/10*1e3:.3f} ms/cycle", flush=True)
-for k in (mg.device.MG_K_SMOOTH, mg.device.MG_K_RESIDUAL, mg.device.MG_K_PROLONG, mg.device.MG_K_RESTRICT):
-    ms, bts = h.time_op(1, k, 20)
-    print(f"time_op kernel {k}: {ms:.4f} ms  {bts/ms/1e6:.0f} GB/s", flush=True)
+for lvl in (1, 2, 3):
+    for k in (mg.device.MG_K_SMOOTH, mg.device.MG_K_RESIDUAL, mg.device.MG_K_PROLONG, mg.device.MG_K_RESTRICT):
+        ms, bts = h.time_op(lvl, k, 20)
+        print(f"time_op L{lvl} {mg.device.KERNEL_NAMES[k]}: {ms:.4f} ms  {bts/ms/1e6:.0f} GB/s", flush=True)

@@ -155,7 +155,8 @@ def test_hip_path_reproduces_golden(mg, built, path):
     name = os.path.basename(path)[:-4]
     g = np.load(path)
     A, p, b = mk.build_case(name)
-    assert np.array_equal(b, g["b"])
+    assert np.allclose(b, g["b"], rtol=1e-12, atol=1e-15)      # regenerated RHS (last bits vary with the host BLAS)
+    b = np.asfortranarray(g["b"])                               # the fixture is the input
     x = np.zeros_like(b)
     _, _, it = mg.solveMG(p, b, x)
     assert it == int(g["iters"])

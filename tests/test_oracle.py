@@ -157,7 +157,8 @@ def test_oracle_reproduces_golden(mg, path):
         pytest.skip("fixture of another generator")
     g = np.load(path)
     A, p, b = mk.build_case(name)
-    assert np.array_equal(b, g["b"])
+    assert np.allclose(b, g["b"], rtol=1e-12, atol=1e-15)      # regenerated RHS (last bits vary with the host BLAS)
+    b = np.asfortranarray(g["b"])                               # the fixture is the input
     assert np.allclose(mk.fingerprint(p), g["fingerprint"], rtol=1e-12)
     x = np.zeros_like(b)
     hist = {}
