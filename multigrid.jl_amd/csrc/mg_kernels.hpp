@@ -19,10 +19,16 @@
 
 namespace mgk {
 
-constexpr int BLK = 256;            // threads per workgroup (4 waves)
-constexpr int ITEMS = 8;            // non-zeros per thread per chunk
+#ifndef MG_BLK
+#define MG_BLK 256
+#endif
+#ifndef MG_ITEMS
+#define MG_ITEMS 8
+#endif
+constexpr int BLK = MG_BLK;         // threads per workgroup (4 waves)
+constexpr int ITEMS = MG_ITEMS;     // non-zeros per thread per chunk
 constexpr int CHUNK = BLK * ITEMS;  // 2048 non-zeros staged per workgroup (16 KiB of products)
-constexpr int MAXROWS = 256;        // rows per row block (one LDS row-pointer slot per thread)
+constexpr int MAXROWS = BLK;        // rows per row block (one LDS row-pointer slot per thread)
 constexpr int PAIRS = ITEMS / 2;
 
 enum Mode { AXPBY = 0, RESID = 1, SMOOTH = 2 };
