@@ -146,6 +146,33 @@ int mg_cycle_bytes(mg_hierarchy* h, double* bytes);
 /* HBM bytes held by the hierarchy. */
 int mg_device_bytes(mg_hierarchy* h, double* bytes);
 
+/* ---- building blocks of the multi-GPU cycle ---------------------------------------------------- */
+/* One operator resident on its own (a rank's local rows of A, P or R with halo columns appended:
+ * rectangular), applied asynchronously on the caller's HIP stream (hipStream_t passed as void*).
+ * kernel: MG_K_SPMV/RESTRICT/PROLONG -> y = alpha*M*x + beta*y ; MG_K_RESIDUAL -> y = b - M*x ;
+ * MG_K_SMOOTH -> y = x + d.*(b - M*x).  Blocks are row-major [n][nrhs]. */
+typedef struct mg_operator mg_operator;
+int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_cols,
+                            const long long* colptr, const long long* rowval, const double* nzval,
+                            mg_operator** out);
+int mg_op_destroy(mg_operator* op);
+int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x_dev,
+                         double beta, double* y_dev, const double* b_dev, const double* d_dev,
+                         long long nrhs, void* stream);
+int mg_op_info(mg_operator* op, long long* n_rows, long long* n_cols, long long* nnz,
+               double* device_bytes);
+/* x = d.*b ; xout = x + d.*r ; out[0] = sum x^2 (workspace >= 1024 doubles) - asynchronous. */
+int mg_vec_dscale_dev_FP64(const double* d_dev, const double* b_dev, double* x_dev, long long n,
+                           long long nrhs, void* stream);
+int mg_vec_xpdr_dev_FP64(const double* x_dev, const double* d_dev, const double* r_dev,
+                         double* xout_dev, long long n, long long nrhs, void* stream);
+int mg_vec_sumsq_dev_FP64(const double* x_dev, long long len, double* workspace_dev, double* out_dev,
+                          void* stream);
+/* Make a hierarchy enqueue on the caller's stream; enqueue one cycle without waiting. */
+int mg_set_stream(mg_hierarchy* h, void* stream);
+int mg_cycle_async_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n,
+                            long long nrhs, long long x_is_zero);
+
 const char* mg_last_error(void);
 const char* mg_version(void);
 

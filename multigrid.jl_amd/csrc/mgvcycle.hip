@@ -137,6 +137,7 @@ struct mg_hierarchy {
   long long n_coarse = 0;
   bool coarse_set = false;
   hipStream_t stream = nullptr;
+  bool owns_stream = true;
   // reductions
   DevBuf<double> partial, scalar;
   double* h_scalar = nullptr;  // pinned
@@ -231,16 +232,16 @@ int pow2_ge(long long v) {
 }
 
 template <int MODE>
-int launch_csr(mg_hierarchy* h, const Csr& M, const mgk::VecArgs& v) {
+int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
   if (v.nrhs == 1) {
-    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, h->stream, M.dev(), v);
-    else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, h->stream, M.dev(), v);
+    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), v);
+    else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), v);
   } else {
     const int G = pow2_ge(v.nrhs);
-    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, true>), grid, blk, 0, h->stream, M.dev(), v, G);
-    else hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, false>), grid, blk, 0, h->stream, M.dev(), v, G);
+    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, true>), grid, blk, 0, stream, M.dev(), v, G);
+    else hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, false>), grid, blk, 0, stream, M.dev(), v, G);
   }
   HIP_TRY(hipGetLastError());
   return MG_OK;
@@ -256,7 +257,7 @@ int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, con
   v.beta = beta;
   v.nrhs = (int)h->nrhs;
   ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false));
-  return launch_csr<mgk::AXPBY>(h, M, v);
+  return launch_csr<mgk::AXPBY>(h->stream, M, v);
 }
 // out = b - A*x
 int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x,
@@ -267,7 +268,7 @@ int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const 
   v.b = b;
   v.nrhs = (int)h->nrhs;
   ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, h->nrhs, true, false));
-  return launch_csr<mgk::RESID>(h, A, v);
+  return launch_csr<mgk::RESID>(h->stream, A, v);
 }
 // out = x + d.*(b - A*x)
 int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const double* b,
@@ -279,7 +280,7 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
   v.d = d;
   v.nrhs = (int)h->nrhs;
   ProfScope ps(h, level, MG_K_SMOOTH, spmv_bytes(A, h->nrhs, true, true));
-  return launch_csr<mgk::SMOOTH>(h, A, v);
+  return launch_csr<mgk::SMOOTH>(h->stream, A, v);
 }
 int k_dscale(mg_hierarchy* h, int level, const double* d, const double* b, double* x, long long n) {
   ProfScope ps(h, level, MG_K_DSCALE, 8.0 * (double)n * (1.0 + 2.0 * (double)h->nrhs));
@@ -518,6 +519,67 @@ int alloc_scratch(mg_hierarchy* h) {
   return MG_OK;
 }
 
+// Validate Julia's (colptr,rowval,nzval) of the transposed CSC (1-based Int64), convert to 0-based int32
+// CSR (the reference's C side does the -1 per access, parRelax.h:24-27), cut the rows into row blocks
+// and upload.
+int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colptr,
+               const long long* rowval, const double* nzval) {
+  if (n_rows < 1 || n_cols < 1 || !colptr || !rowval || !nzval)
+    return fail(MG_ERR_INVALID, "empty operator or null array");
+  if (n_rows >= (1LL << 31) - 1 || n_cols >= (1LL << 31) - 1)
+    return fail(MG_ERR_UNSUPPORTED, "dimension exceeds int32 device indices");
+  if (colptr[0] != 1) return fail(MG_ERR_INVALID, "colptr[1] must be 1 (1-based Julia arrays expected)");
+  const long long nnz = colptr[n_rows] - 1;
+  if (nnz < 0 || nnz >= (1LL << 31) - 4096)
+    return fail(MG_ERR_UNSUPPORTED, "nnz=%lld does not fit int32 row pointers on device", nnz);
+  std::vector<int> rp((size_t)n_rows + 1);
+  for (long long i = 0; i <= n_rows; ++i) {
+    const long long v = colptr[i] - 1;
+    if (v < 0 || v > nnz || (i > 0 && v < (long long)rp[(size_t)i - 1]))
+      return fail(MG_ERR_INVALID, "colptr is not a monotone 1-based pointer array at %lld", i);
+    rp[(size_t)i] = (int)v;
+  }
+  const size_t pad = 2 * mgk::BLK;  // loads of a trailing (idx, idx+1) pair stay in bounds
+  std::vector<int> ci((size_t)nnz + pad, 0);
+  for (long long k = 0; k < nnz; ++k) {
+    const long long c = rowval[k] - 1;
+    if (c < 0 || c >= n_cols) return fail(MG_ERR_INVALID, "rowval[%lld]=%lld outside 1..%lld", k + 1, rowval[k], n_cols);
+    ci[(size_t)k] = (int)c;
+  }
+  // row blocks: consecutive rows, <= MAXROWS rows and an (even-aligned) nnz span <= CHUNK
+  std::vector<int> blk;
+  blk.push_back(0);
+  long long r = 0;
+  while (r < n_rows) {
+    const long long base = rp[(size_t)r] & ~1LL;
+    long long e = r + 1;  // a block always holds at least one row (a longer row takes the long-row path)
+    while (e < n_rows && (e - r) < mgk::MAXROWS && (rp[(size_t)e + 1] - base) <= mgk::CHUNK) ++e;
+    blk.push_back((int)e);
+    r = e;
+  }
+  M->release();
+  M->n_rows = n_rows;
+  M->n_cols = n_cols;
+  M->nnz = nnz;
+  M->nblocks = (int)blk.size() - 1;
+  MG_TRY(M->rowptr.alloc(rp.size()));
+  MG_TRY(M->colidx.alloc(ci.size()));
+  MG_TRY(M->val.alloc((size_t)nnz + pad));
+  MG_TRY(M->blk_row.alloc(blk.size()));
+  HIP_TRY(hipMemcpy(M->rowptr.p, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->colidx.p, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(M->val.p, 0, ((size_t)nnz + pad) * sizeof(double)));
+  HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->blk_row.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+  M->set = true;
+  // cache policy of the matrix stream: non-temporal once the operator is too large to stay in the
+  // 256 MiB Infinity Cache between two uses anyway (measured, profiles/r01_nt_ab.md: +2..17 % on the
+  // 685 MB..1.4 GB operators of C2, -5..25 % on the 89 MB ones); MG_NT=0/1 forces one policy
+  M->nt = (12.0 * (double)nnz > 128.0e6);
+  if (const char* e = std::getenv("MG_NT")) M->nt = (e[0] == '1');
+  return MG_OK;
+}
+
 Csr* pick(mg_hierarchy* h, long long level, long long which) {
   if (level < 1 || level > h->nlevels) return nullptr;
   Level& L = h->lev[level - 1];
@@ -590,7 +652,7 @@ int mg_destroy(mg_hierarchy* h) {
   h->stage_x.release();
   h->stage_t.release();
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MG_OK;
 }
@@ -603,61 +665,8 @@ int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which
   if (!M) return fail(MG_ERR_INVALID, "bad (level=%lld, which=%lld)", level, which);
   if ((which == MG_OP_P || which == MG_OP_R) && level == h->nlevels)
     return fail(MG_ERR_INVALID, "the coarsest level %lld has no transfer operators", level);
-  if (n_rows < 1 || n_cols < 1 || !colptr || !rowval || !nzval)
-    return fail(MG_ERR_INVALID, "empty operator or null array");
-  if (n_rows >= (1LL << 31) - 1 || n_cols >= (1LL << 31) - 1)
-    return fail(MG_ERR_UNSUPPORTED, "dimension exceeds int32 device indices");
-  if (colptr[0] != 1) return fail(MG_ERR_INVALID, "colptr[1] must be 1 (1-based Julia arrays expected)");
-  const long long nnz = colptr[n_rows] - 1;
-  if (nnz < 0 || nnz >= (1LL << 31) - 4096)
-    return fail(MG_ERR_UNSUPPORTED, "nnz=%lld does not fit int32 row pointers on device", nnz);
   (void)hipSetDevice(h->device);
-  // validate + convert to 0-based int32 (the reference's C side does the -1 per access, parRelax.h:24-27)
-  std::vector<int> rp((size_t)n_rows + 1);
-  for (long long i = 0; i <= n_rows; ++i) {
-    const long long v = colptr[i] - 1;
-    if (v < 0 || v > nnz || (i > 0 && v < (long long)rp[(size_t)i - 1]))
-      return fail(MG_ERR_INVALID, "colptr is not a monotone 1-based pointer array at %lld", i);
-    rp[(size_t)i] = (int)v;
-  }
-  const size_t pad = 2 * mgk::BLK;  // loads of a trailing (idx, idx+1) pair stay in bounds
-  std::vector<int> ci((size_t)nnz + pad, 0);
-  for (long long k = 0; k < nnz; ++k) {
-    const long long c = rowval[k] - 1;
-    if (c < 0 || c >= n_cols) return fail(MG_ERR_INVALID, "rowval[%lld]=%lld outside 1..%lld", k + 1, rowval[k], n_cols);
-    ci[(size_t)k] = (int)c;
-  }
-  // row blocks: consecutive rows, <= MAXROWS rows and an (even-aligned) nnz span <= CHUNK
-  std::vector<int> blk;
-  blk.push_back(0);
-  long long r = 0;
-  while (r < n_rows) {
-    const long long base = rp[(size_t)r] & ~1LL;
-    long long e = r + 1;  // a block always holds at least one row (a longer row takes the long-row path)
-    while (e < n_rows && (e - r) < mgk::MAXROWS && (rp[(size_t)e + 1] - base) <= mgk::CHUNK) ++e;
-    blk.push_back((int)e);
-    r = e;
-  }
-  M->release();
-  M->n_rows = n_rows;
-  M->n_cols = n_cols;
-  M->nnz = nnz;
-  M->nblocks = (int)blk.size() - 1;
-  MG_TRY(M->rowptr.alloc(rp.size()));
-  MG_TRY(M->colidx.alloc(ci.size()));
-  MG_TRY(M->val.alloc((size_t)nnz + pad));
-  MG_TRY(M->blk_row.alloc(blk.size()));
-  HIP_TRY(hipMemcpy(M->rowptr.p, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->colidx.p, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(M->val.p, 0, ((size_t)nnz + pad) * sizeof(double)));
-  HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->blk_row.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
-  M->set = true;
-  // cache policy of the matrix stream: non-temporal once the operator is too large to stay in the
-  // 256 MiB Infinity Cache between two uses anyway (measured, profiles/r01_nt_ab.md: +2..17 % on the
-  // 685 MB..1.4 GB operators of C2, -5..25 % on the 89 MB ones); MG_NT=0/1 forces one policy
-  M->nt = (12.0 * (double)nnz > 128.0e6);
-  if (const char* e = std::getenv("MG_NT")) M->nt = (e[0] == '1');
+  MG_TRY(upload_csr(M, n_rows, n_cols, colptr, rowval, nzval));
   h->finalized = false;
   return MG_OK;
 }
@@ -1017,6 +1026,130 @@ int mg_device_bytes(mg_hierarchy* h, double* bytes) {
   t += (double)(h->Ainv.bytes() + h->stage_b.bytes() + h->stage_x.bytes() + h->stage_t.bytes());
   *bytes = t;
   return MG_OK;
+}
+
+// ---- stand-alone operators and vector kernels (building blocks of the multi-GPU cycle) ------------
+struct mg_operator {
+  int device = 0;
+  Csr M;
+};
+
+int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_cols,
+                            const long long* colptr, const long long* rowval, const double* nzval,
+                            mg_operator** out) {
+  if (!out) return fail(MG_ERR_INVALID, "out is null");
+  *out = nullptr;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
+  HIP_TRY(hipSetDevice((int)device_id));
+  mg_operator* op = new mg_operator();
+  op->device = (int)device_id;
+  const int rc = upload_csr(&op->M, n_rows, n_cols, colptr, rowval, nzval);
+  if (rc != MG_OK) {
+    op->M.release();
+    delete op;
+    return rc;
+  }
+  *out = op;
+  return MG_OK;
+}
+
+int mg_op_destroy(mg_operator* op) {
+  if (!op) return MG_OK;
+  (void)hipSetDevice(op->device);
+  op->M.release();
+  delete op;
+  return MG_OK;
+}
+
+int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
+                         double* y, const double* b, const double* d, long long nrhs, void* stream) {
+  if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
+  if (!x || !y || nrhs < 1) return fail(MG_ERR_INVALID, "null vector or nrhs < 1");
+  if (kernel == MG_K_SMOOTH && y == x) return fail(MG_ERR_INVALID, "the Jacobi update must not alias x");
+  mgk::VecArgs v{};
+  v.x = x;
+  v.y = y;
+  v.b = b;
+  v.d = d;
+  v.alpha = alpha;
+  v.beta = beta;
+  v.nrhs = (int)nrhs;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (kernel) {
+    case MG_K_SPMV:
+    case MG_K_RESTRICT:
+    case MG_K_PROLONG:
+      return launch_csr<mgk::AXPBY>(s, op->M, v);
+    case MG_K_RESIDUAL:
+      if (!b) return fail(MG_ERR_INVALID, "residual needs b");
+      return launch_csr<mgk::RESID>(s, op->M, v);
+    case MG_K_SMOOTH:
+      if (!b || !d) return fail(MG_ERR_INVALID, "smoother needs b and d");
+      return launch_csr<mgk::SMOOTH>(s, op->M, v);
+    default:
+      return fail(MG_ERR_INVALID, "kernel %lld is not an operator kernel", kernel);
+  }
+}
+
+int mg_op_info(mg_operator* op, long long* n_rows, long long* n_cols, long long* nnz, double* device_bytes) {
+  if (!op) return fail(MG_ERR_INVALID, "null operator");
+  if (n_rows) *n_rows = op->M.n_rows;
+  if (n_cols) *n_cols = op->M.n_cols;
+  if (nnz) *nnz = op->M.nnz;
+  if (device_bytes) *device_bytes = (double)op->M.bytes();
+  return MG_OK;
+}
+
+int mg_vec_dscale_dev_FP64(const double* d, const double* b, double* x, long long n, long long nrhs, void* stream) {
+  if (!d || !b || !x || n < 1 || nrhs < 1) return fail(MG_ERR_INVALID, "bad vector arguments");
+  hipLaunchKernelGGL(mgk::dscale_kernel, dim3(grid_for(n * nrhs / 2 + 1)), dim3(mgk::BLK), 0,
+                     reinterpret_cast<hipStream_t>(stream), d, b, x, n, (int)nrhs);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+
+int mg_vec_xpdr_dev_FP64(const double* x, const double* d, const double* r, double* xout, long long n,
+                         long long nrhs, void* stream) {
+  if (!x || !d || !r || !xout || n < 1 || nrhs < 1) return fail(MG_ERR_INVALID, "bad vector arguments");
+  hipLaunchKernelGGL(mgk::xpdr_kernel, dim3(grid_for(n * nrhs / 2 + 1)), dim3(mgk::BLK), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, d, r, xout, n, (int)nrhs);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+
+// out[0] = sum_i x[i]^2 ; workspace: >= 1024 doubles
+int mg_vec_sumsq_dev_FP64(const double* x, long long len, double* workspace, double* out, void* stream) {
+  if (!x || !workspace || !out || len < 1) return fail(MG_ERR_INVALID, "bad vector arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = (int)std::min<long long>(1024, std::max<long long>(1, (len / 2 + mgk::BLK - 1) / mgk::BLK));
+  hipLaunchKernelGGL(mgk::sumsq_partial, dim3(nb), dim3(mgk::BLK), 0, s, x, len, workspace);
+  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, s, workspace, nb, out);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+
+// Run the hierarchy's kernels on the caller's stream (e.g. torch's current stream) instead of its own.
+int mg_set_stream(mg_hierarchy* h, void* stream) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  (void)hipSetDevice(h->device);
+  (void)spin_sync(h->stream);
+  if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  h->stream = reinterpret_cast<hipStream_t>(stream);
+  h->owns_stream = false;
+  return MG_OK;
+}
+
+// Enqueue one cycle and return without waiting (x_is_zero must be 0 or 1).
+int mg_cycle_async_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
+                            long long x_is_zero) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
+  if (x_is_zero != 0 && x_is_zero != 1) return fail(MG_ERR_INVALID, "x_is_zero must be 0 or 1 for the asynchronous cycle");
+  (void)hipSetDevice(h->device);
+  return cycle_dev(h, b, x, x_is_zero == 1);
 }
 
 }  // extern "C"

@@ -52,6 +52,15 @@ SIGNATURES = {
     "mg_profile_reset": (C.c_int, [_vp]),
     "mg_cycle_bytes": (C.c_int, [_vp, _dp]),
     "mg_device_bytes": (C.c_int, [_vp, _dp]),
+    "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
+    "mg_op_destroy": (C.c_int, [_vp]),
+    "mg_op_apply_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _vp]),
+    "mg_op_info": (C.c_int, [_vp, _lp, _lp, _lp, _dp]),
+    "mg_vec_dscale_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _vp]),
+    "mg_vec_xpdr_dev_FP64": (C.c_int, [_vp, _vp, _vp, _vp, _ll, _ll, _vp]),
+    "mg_vec_sumsq_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp]),
+    "mg_set_stream": (C.c_int, [_vp, _vp]),
+    "mg_cycle_async_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
     "mg_last_error": (C.c_char_p, []),
     "mg_version": (C.c_char_p, []),
 }
@@ -252,6 +261,15 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_fused_dev_FP64(self.handle, level, kernel, _ptr(b), _ptr(x), _ptr(out), nrhs),
                "mg_fused_dev")
 
+    def set_stream(self, stream: int):
+        """Enqueue on the caller's HIP stream (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        _check(self.lib, self.lib.mg_set_stream(self.handle, _vp(stream)), "mg_set_stream")
+
+    def cycle_async_dev(self, b, x, x_is_zero: int, nrhs: Optional[int] = None):
+        nrhs = self.nrhs if nrhs is None else nrhs
+        _check(self.lib, self.lib.mg_cycle_async_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, nrhs, int(x_is_zero)),
+               "mg_cycle_async_dev")
+
     # -- measurement --------------------------------------------------------------------------------
     def time_op(self, level: int, kernel: int, reps: int = 20):
         ms = C.c_double(0.0)
@@ -287,3 +305,55 @@ class DeviceHierarchy:
         v = C.c_double(0)
         _check(self.lib, self.lib.mg_device_bytes(self.handle, C.byref(v)), "mg_device_bytes")
         return v.value
+
+
+class DeviceOperator:
+    """One CSR operator resident in HBM on its own (``mg_operator``): the building block of the multi-GPU
+    cycle, where a rank holds its rows of A/P/R with halo columns appended.  Asynchronous on `stream`."""
+
+    def __init__(self, M, device_id: int = 0):
+        self.lib = load_library()
+        self.handle = _vp()
+        colptr, rowval, nzval = _julia_arrays(M)
+        if M.nnz == 0:                                   # keep the arrays non-empty for ctypes
+            rowval = np.zeros(1, dtype=np.int64)
+            nzval = np.zeros(1)
+        self.shape = M.shape
+        self.nnz = int(M.nnz)
+        _check(self.lib, self.lib.mg_op_create_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),
+                                                          _i64(rowval), _f64(nzval), C.byref(self.handle)),
+               "mg_op_create")
+
+    def apply(self, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, stream=0):
+        _check(self.lib, self.lib.mg_op_apply_dev_FP64(self.handle, int(kernel), float(alpha), _ptr(x), float(beta),
+                                                       _ptr(y), _ptr(b) if b is not None else None,
+                                                       _ptr(d) if d is not None else None, int(nrhs), _vp(stream)),
+               "mg_op_apply_dev")
+
+    def close(self):
+        if self.handle:
+            self.lib.mg_op_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def vec_dscale(d, b, x, n, nrhs=1, stream=0):
+    lib = load_library()
+    _check(lib, lib.mg_vec_dscale_dev_FP64(_ptr(d), _ptr(b), _ptr(x), int(n), int(nrhs), _vp(stream)), "mg_vec_dscale_dev")
+
+
+def vec_xpdr(x, d, r, xout, n, nrhs=1, stream=0):
+    lib = load_library()
+    _check(lib, lib.mg_vec_xpdr_dev_FP64(_ptr(x), _ptr(d), _ptr(r), _ptr(xout), int(n), int(nrhs), _vp(stream)),
+           "mg_vec_xpdr_dev")
+
+
+def vec_sumsq(x, length, workspace, out, stream=0):
+    lib = load_library()
+    _check(lib, lib.mg_vec_sumsq_dev_FP64(_ptr(x), int(length), _ptr(workspace), _ptr(out), _vp(stream)),
+           "mg_vec_sumsq_dev")

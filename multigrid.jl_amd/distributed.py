@@ -1,0 +1,509 @@
+"""Multi-GPU multigrid cycle: one process per GPU, the fine levels sharded by the reference's
+DomainDecomposition box rule, halo exchange per SpMV, coarse tail replicated.
+
+What is taken from the reference (src/DomainDecomposition/): only the PARTITION -
+``getOriginalBoundingBoxCells`` (DDIndices.jl:41-47: cellSize = div(nc,NumCells), the last box absorbs
+the remainder), the x-fastest nodal enumeration (DDIndices.jl:141-162) and the subdomain numbering
+``loc2cs`` (DDService.jl:27-36).  The Schwarz solver itself is a different algorithm and is out of
+scope; here every rank runs the SAME multigrid cycle as the single-GPU library (MGcycle.jl:1-118,
+SolveFuncs.jl:3-39) on its rows, so the iterates equal the single-GPU ones up to fp64 reassociation.
+
+Layout.  On level l a rank owns a set of rows (a box of nodes for GMG, a contiguous block for general
+CSR), renumbered locally 0..n_own-1.  Each local operator keeps its owned rows; column indices are
+renumbered [owned | halo grouped by owner rank, ascending global index], so the local source vector
+is [owned values | received halo] and ONE all_to_all_single per SpMV fills the halo tail in place.
+Levels at or below ``replicate_below`` rows are all-gathered and run replicated on every GPU by an
+ordinary single-GPU hierarchy (no further communication), re-entering the sharded path on the way up.
+
+PyTorch is plumbing only: device buffers, streams and ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI; "gloo" for the CPU tests).  All arithmetic runs in the HIP kernels of libmgvcycle.so through
+``HipBackend``; there is no CPU fallback in this module - the CPU tests inject their own checker backend.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import device as D
+from .mgdef import MGparam
+
+
+# ======================================================================================================
+# partition
+# ======================================================================================================
+def box_owner(n_nodes, numDomains) -> np.ndarray:
+    """Owner subdomain (0-based linear id, x-fastest as ``loc2cs``) of every node of a regular nodal grid.
+
+    Cells are split by ``getOriginalBoundingBoxCells`` (DDIndices.jl:41-47): cellSize = div(nc, NumCells),
+    box i holds cells (i-1)*cellSize+1 .. i*cellSize and the last box takes the remainder.  A node belongs to
+    the box of the cell on its upper side, the last node of a dimension to the last box - so every node has
+    exactly one owner and the interface nodes go to the upper box.
+    """
+    n_nodes = np.asarray(n_nodes, dtype=np.int64)
+    numDomains = np.asarray(numDomains, dtype=np.int64)
+    if n_nodes.size != numDomains.size:
+        raise ValueError("n_nodes and numDomains must have the same dimension")
+    idx1d = []
+    for k in range(n_nodes.size):
+        nc = int(n_nodes[k]) - 1
+        nd = int(numDomains[k])
+        if nd < 1 or nd > max(nc, 1):
+            raise ValueError(f"cannot split {nc} cells into {nd} boxes")
+        cs = max(nc // nd, 1)
+        idx1d.append(np.minimum(np.arange(n_nodes[k]) // cs, nd - 1))
+    if n_nodes.size == 2:
+        own = idx1d[0][None, :] + numDomains[0] * idx1d[1][:, None]
+    else:
+        own = (idx1d[0][None, None, :] + numDomains[0] * idx1d[1][None, :, None]
+               + numDomains[0] * numDomains[1] * idx1d[2][:, None, None])
+    return own.reshape(-1).astype(np.int32)          # C-order of (z,y,x) == x-fastest linear index
+
+
+def block_owner(n: int, nranks: int) -> np.ndarray:
+    """Contiguous row blocks (general CSR / SA-AMG: SURVEY.md 8e 'unstructured')."""
+    return np.minimum(np.arange(n, dtype=np.int64) * nranks // n, nranks - 1).astype(np.int32)
+
+
+def default_domains(nranks: int, dim: int):
+    """[2,2,2] for 8 GPUs (7 neighbours = the 7 xGMI peers), slabs [1,1,k] otherwise."""
+    if dim == 3:
+        table = {1: [1, 1, 1], 2: [1, 1, 2], 4: [1, 2, 2], 8: [2, 2, 2]}
+        return table.get(nranks, [1, 1, nranks])
+    table = {1: [1, 1], 2: [1, 2], 4: [2, 2]}
+    return table.get(nranks, [1, nranks])
+
+
+class Partition:
+    """Row ownership of one level: ``rows[r]`` = ascending global ids owned by rank r (= its local order)."""
+
+    def __init__(self, owner: np.ndarray, nranks: int):
+        self.owner = np.ascontiguousarray(owner, dtype=np.int32)
+        self.nranks = int(nranks)
+        n = self.owner.size
+        order = np.argsort(self.owner, kind="stable")
+        counts = np.bincount(self.owner, minlength=nranks)
+        if np.any(counts == 0):
+            raise ValueError("a rank owns no rows on a distributed level")
+        off = np.concatenate([[0], np.cumsum(counts)])
+        self.counts = counts
+        self.rows = [order[off[r]:off[r + 1]] for r in range(nranks)]
+        self.local_index = np.empty(n, dtype=np.int64)
+        self.local_index[order] = np.arange(n) - off[self.owner[order]]
+
+    def coarsen(self, P) -> "Partition":
+        """Owner of a coarse point = owner of the fine row carrying its largest interpolation weight
+        (for full weighting: the coincident fine node; for aggregation: a member of the aggregate)."""
+        Pc = sp.csc_matrix(P)
+        nc = Pc.shape[1]
+        owner_c = np.empty(nc, dtype=np.int32)
+        absd = np.abs(Pc.data)
+        # argmax per column (first maximum)
+        colmax = np.maximum.reduceat(absd, Pc.indptr[:-1])
+        col_of = np.repeat(np.arange(nc), np.diff(Pc.indptr))
+        ismax = absd == colmax[col_of]
+        first = np.full(nc, -1, dtype=np.int64)
+        pos = np.nonzero(ismax)[0][::-1]
+        first[col_of[pos]] = pos                       # the smallest position wins (reverse assignment)
+        owner_c[:] = self.owner[Pc.indices[first]]
+        return Partition(owner_c, self.nranks)
+
+
+@dataclass
+class HaloPlan:
+    n_own_src: int
+    n_halo: int
+    send_idx: np.ndarray          # local indices (into the owned part of the source vector) to send, grouped by peer
+    send_splits: List[int]
+    recv_splits: List[int]
+
+
+def localize(M, row_part: Partition, col_part: Optional[Partition], rank: int):
+    """Rows of M owned by `rank`, columns renumbered [owned | halo by (owner, global id)] + the halo plan.
+    ``col_part=None``: the source vector is replicated (coarse tail) - global column ids are kept."""
+    M = sp.csr_matrix(M)
+    rows = row_part.rows[rank]
+    Ml = M[rows, :].tocsr()
+    Ml.sort_indices()
+    if col_part is None:
+        return Ml, None
+    nr = row_part.nranks
+    cols = Ml.indices
+    cown = col_part.owner[cols]
+    mine = cown == rank
+    halo = np.unique(cols[~mine])
+    ho = col_part.owner[halo]
+    order = np.lexsort((halo, ho))
+    halo, ho = halo[order], ho[order]
+    n_own = int(col_part.counts[rank])
+    newcol = np.empty(cols.size, dtype=np.int64)
+    newcol[mine] = col_part.local_index[cols[mine]]
+    # position of each off-rank column in the (owner, id)-ordered halo list
+    key = ho.astype(np.int64) * M.shape[1] + halo
+    q = cown[~mine].astype(np.int64) * M.shape[1] + cols[~mine]
+    newcol[~mine] = n_own + np.searchsorted(key, q)
+    Mloc = sp.csr_matrix((Ml.data, newcol, Ml.indptr), shape=(rows.size, n_own + halo.size))
+    Mloc.sort_indices()
+    recv_splits = np.bincount(ho, minlength=nr).astype(int).tolist()
+    # what the peers need from me: columns I own that appear in THEIR rows (computed locally: every
+    # rank holds the global pattern in this round's host-setup design)
+    ro = np.repeat(row_part.owner, np.diff(M.indptr))
+    co = col_part.owner[M.indices]
+    sel = (co == rank) & (ro != rank)
+    dest = ro[sel].astype(np.int64)
+    gcol = M.indices[sel].astype(np.int64)
+    pairs = np.unique(dest * M.shape[1] + gcol)
+    dest_u = pairs // M.shape[1]
+    gcol_u = pairs - dest_u * M.shape[1]
+    send_idx = col_part.local_index[gcol_u]
+    send_splits = np.bincount(dest_u, minlength=nr).astype(int).tolist()
+    return Mloc, HaloPlan(n_own, int(halo.size), send_idx.astype(np.int64), send_splits, recv_splits)
+
+
+# ======================================================================================================
+# communication (torch.distributed plumbing)
+# ======================================================================================================
+class TorchComm:
+    """all_to_all_single / all_reduce / all_gather on a torch.distributed group.
+    ``stage_through_host`` moves device tensors through pinned host memory for backends that cannot take
+    device tensors (gloo): used to exercise the HIP path with 2 processes on ONE GPU."""
+
+    def __init__(self, group=None, stage_through_host: bool = False):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.stage = stage_through_host
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        if self.stage and out.is_cuda:
+            o = out.cpu()
+            self.dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def all_reduce_sum(self, t):
+        if self.stage and t.is_cuda:
+            c = t.cpu()
+            self.dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather(self, out, inp):
+        if self.stage and out.is_cuda:
+            o = out.cpu()
+            self.dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
+class SingleComm:
+    """World of one process (no communication)."""
+    rank, size = 0, 1
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        out.copy_(inp)
+
+    def all_reduce_sum(self, t):
+        return t
+
+    def all_gather(self, out, inp):
+        out.copy_(inp)
+
+
+# ======================================================================================================
+# local compute backend: the HIP library
+# ======================================================================================================
+class HipBackend:
+    """Local arithmetic of the distributed cycle = the single-GPU kernels of libmgvcycle.so, enqueued on
+    torch's current stream so that they order with the RCCL collectives torch issues."""
+
+    def __init__(self, device_id: int):
+        import torch
+        if not torch.cuda.is_available():
+            raise D.MGDeviceError("no GPU visible: the multigrid cycle has no CPU fallback")
+        self.torch = torch
+        self.device_id = int(device_id)
+        self.dev = torch.device("cuda", self.device_id)
+        torch.cuda.set_device(self.dev)
+        D.load_library()
+        self.ws = torch.zeros(1024, dtype=torch.float64, device=self.dev)
+        self.scalar = torch.zeros(1, dtype=torch.float64, device=self.dev)
+
+    def stream(self) -> int:
+        return int(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def zeros(self, *shape):
+        return self.torch.zeros(*shape, dtype=self.torch.float64, device=self.dev)
+
+    def from_numpy(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+
+    def index_tensor(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(self.dev)
+
+    def operator(self, M):
+        return D.DeviceOperator(M, self.device_id)
+
+    def apply(self, op, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1):
+        op.apply(kernel, x, y, b, d, alpha, beta, nrhs, self.stream())
+
+    def dscale(self, d, b, x, n, nrhs):
+        D.vec_dscale(d, b, x, n, nrhs, self.stream())
+
+    def xpdr(self, x, d, r, xout, n, nrhs):
+        D.vec_xpdr(x, d, r, xout, n, nrhs, self.stream())
+
+    def sumsq(self, x, length):
+        D.vec_sumsq(x, length, self.ws, self.scalar, self.stream())
+        return self.scalar
+
+    def index_select(self, src, idx, out):
+        self.torch.index_select(src, 0, idx, out=out)
+
+    def tail(self, sub: MGparam, nrhs: int):
+        h = D.DeviceHierarchy(sub, self.device_id, nrhs)
+        h.set_stream(self.stream())
+        return _HipTail(h)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.dev)
+
+
+class _HipTail:
+    def __init__(self, h):
+        self.h = h
+
+    def cycle(self, b, x, x_zero: bool, ctype: str):
+        D._check(self.h.lib, self.h.lib.mg_set_cycle_type(self.h.handle, ord(ctype)), "mg_set_cycle_type")
+        self.h.cycle_async_dev(b, x, 1 if x_zero else 0)
+
+
+# ======================================================================================================
+# the distributed hierarchy and cycle
+# ======================================================================================================
+class _Level:
+    pass
+
+
+def _sub_hierarchy(param: MGparam, start: int) -> MGparam:
+    """Levels start.. of `param` as a hierarchy of their own (the replicated coarse tail)."""
+    from .mgdef import getMGparam
+    sub = getMGparam(np.float64, np.int64, len(param.As) - start, param.numCores, param.maxOuterIter,
+                     param.relativeTol, param.relaxType, param.relaxParam,
+                     lambda level, _s=start: param.relaxPre(level + _s), lambda level, _s=start: param.relaxPost(level + _s),
+                     param.cycleType, param.coarseSolveType, param.strongConnParam, param.FilteringParam,
+                     param.transferOperatorType)
+    sub.As = param.As[start:]
+    sub.Ps = param.Ps[start:]
+    sub.Rs = param.Rs[start:]
+    sub.relaxPrecs = param.relaxPrecs[start:]
+    sub.LU = param.LU
+    sub.levels = len(sub.As)
+    return sub
+
+
+class DistributedHierarchy:
+    """The multi-GPU counterpart of ``DeviceHierarchy``: built by every rank from the (global) host
+    hierarchy ``param``; holds this rank's rows of the sharded levels plus the replicated tail."""
+
+    def __init__(self, param: MGparam, comm, backend, fine_owner: np.ndarray, nrhs: int = 1,
+                 replicate_below: int = 300_000):
+        self.comm = comm
+        self.be = backend
+        self.nrhs = int(nrhs)
+        self.cycleType = param.cycleType
+        rank, size = comm.rank, comm.size
+        nl = len(param.As)
+        if nl < 2:
+            raise ValueError("a distributed hierarchy needs at least two levels")
+        # which levels are sharded: the finest one always; then while the level is large enough
+        parts = [Partition(fine_owner, size)]
+        a = 1
+        while a < nl - 1 and param.As[a].shape[0] > replicate_below:
+            try:
+                parts.append(parts[-1].coarsen(param.Ps[a - 1]))
+            except ValueError:
+                break
+            a += 1
+        # the partition of the first replicated level is still needed (rows of R, gather of bc)
+        self.first_tail = a
+        self.nl = nl
+        part_tail = parts[-1].coarsen(param.Ps[a - 1])
+        self.parts = parts
+        self.part_tail = part_tail
+        self.levels: List[_Level] = []
+        be = backend
+        k = self.nrhs
+        for l in range(a):
+            L = _Level()
+            part = parts[l]
+            cpart = parts[l + 1] if l + 1 < a else part_tail
+            L.n_own = int(part.counts[rank])
+            L.n_global = int(param.As[l].shape[0])
+            A_loc, L.planA = localize(param.As[l], part, part, rank)
+            R_loc, L.planR = localize(param.Rs[l], cpart, part, rank)
+            if l + 1 < a:
+                P_loc, L.planP = localize(param.Ps[l], part, cpart, rank)       # gathers the sharded x_{l+1}
+            else:
+                P_loc, L.planP = localize(param.Ps[l], part, None, rank)        # gathers the replicated tail solution
+            L.A, L.R, L.P = be.operator(A_loc), be.operator(R_loc), be.operator(P_loc)
+            L.nnzA, L.nnzR, L.nnzP = A_loc.nnz, R_loc.nnz, P_loc.nnz
+            L.d = be.from_numpy(np.asarray(param.relaxPrecs[l])[part.rows[rank]])
+            L.npre = max(1, int(param.relaxPre(l + 1)))          # relax() always updates once (MGcycle.jl:127-134)
+            L.npost = max(1, int(param.relaxPost(l + 1)))
+            self.levels.append(L)
+        # vectors: capacity = owned + the largest halo any operator appends to that vector
+        for l, L in enumerate(self.levels):
+            halo_x = L.planA.n_halo
+            if l > 0 and self.levels[l - 1].planP is not None:
+                halo_x = max(halo_x, self.levels[l - 1].planP.n_halo)
+            L.cap_x = L.n_own + halo_x
+            L.cap_r = L.n_own + L.planR.n_halo
+            L.x0 = be.zeros(L.cap_x, k) if k > 1 else be.zeros(L.cap_x)
+            L.x1 = be.zeros(L.cap_x, k) if k > 1 else be.zeros(L.cap_x)
+            L.r = be.zeros(L.cap_r, k) if k > 1 else be.zeros(L.cap_r)
+            L.b = (be.zeros(L.n_own, k) if k > 1 else be.zeros(L.n_own)) if l > 0 else None
+            for plan in (L.planA, L.planR, L.planP):
+                if plan is not None:
+                    plan.send_idx_t = be.index_tensor(plan.send_idx)
+                    ns = int(plan.send_idx.size)
+                    plan.send_buf = be.zeros(max(ns, 1), k) if k > 1 else be.zeros(max(ns, 1))
+        # replicated tail
+        nt = int(param.As[a].shape[0])
+        self.n_tail = nt
+        self.tail = be.tail(_sub_hierarchy(param, a), k)
+        self.own_tail = int(part_tail.counts[rank])
+        self.max_tail = int(part_tail.counts.max())
+        self.bc_pad = be.zeros(self.max_tail, k) if k > 1 else be.zeros(self.max_tail)
+        self.bc_all = be.zeros(self.max_tail * size, k) if k > 1 else be.zeros(self.max_tail * size)
+        gather_index = part_tail.owner.astype(np.int64) * self.max_tail + part_tail.local_index
+        self.gather_index = be.index_tensor(gather_index)
+        self.b_tail = be.zeros(nt, k) if k > 1 else be.zeros(nt)
+        self.x_tail = be.zeros(nt, k) if k > 1 else be.zeros(nt)
+        self.rows_fine = parts[0].rows[rank]
+
+    # ---- helpers ---------------------------------------------------------------------------------------
+    def scatter_fine(self, v_global: np.ndarray):
+        """This rank's rows of a global fine-level vector/block (host) as a device tensor."""
+        return self.be.from_numpy(np.asarray(v_global)[self.rows_fine])
+
+    def exchange(self, plan: HaloPlan, buf):
+        """Fill the halo tail buf[n_own : n_own+n_halo] from the owners (one all_to_all_single)."""
+        if plan is None or self.comm.size == 1 or (plan.n_halo == 0 and plan.send_idx.size == 0):
+            return
+        ns = int(plan.send_idx.size)
+        send = plan.send_buf[:ns]
+        if ns:
+            self.be.index_select(buf, plan.send_idx_t, send)
+        recv = buf[plan.n_own_src: plan.n_own_src + plan.n_halo]
+        self.comm.all_to_all(recv, send, plan.recv_splits, plan.send_splits)
+
+    def norm(self, v, n_own):
+        """Global Frobenius norm of a sharded vector (SolveFuncs.jl:15,20,30): local sum of squares + all-reduce."""
+        s = self.be.sumsq(v, n_own * self.nrhs)
+        self.comm.all_reduce_sum(s)
+        return float(s.item()) ** 0.5
+
+    # ---- the cycle (mirror of csrc/mgvcycle.hip cycle_level; MGcycle.jl:1-118) ---------------------------
+    def _cycle(self, l, b, xa, xb, x_zero, ctype, r_valid=False):
+        be, k = self.be, self.nrhs
+        L = self.levels[l]
+        cur, alt = xa, xb
+        npre, npost = L.npre, L.npost
+        if x_zero:
+            be.dscale(L.d, b, cur, L.n_own, k)
+            npre -= 1
+        elif r_valid:
+            be.xpdr(cur, L.d, L.r, alt, L.n_own, k)
+            cur, alt = alt, cur
+            npre -= 1
+        for _ in range(npre):
+            self.exchange(L.planA, cur)
+            be.apply(L.A, D.MG_K_SMOOTH, cur, alt, b=b, d=L.d, nrhs=k)
+            cur, alt = alt, cur
+        self.exchange(L.planA, cur)
+        be.apply(L.A, D.MG_K_RESIDUAL, cur, L.r, b=b, nrhs=k)
+        self.exchange(L.planR, L.r)
+        if l + 1 < len(self.levels):
+            C = self.levels[l + 1]
+            be.apply(L.R, D.MG_K_RESTRICT, L.r, C.b, nrhs=k)
+            xc = self._cycle(l + 1, C.b, C.x0, C.x1, True, ctype)
+            if ctype in ("W", "F"):
+                other = C.x1 if xc is C.x0 else C.x0
+                xc = self._cycle(l + 1, C.b, xc, other, False, "W" if ctype == "W" else "V")
+            self.exchange(L.planP, xc)
+            be.apply(L.P, D.MG_K_PROLONG, xc, cur, alpha=1.0, beta=1.0, nrhs=k)
+        else:
+            # restrict into this rank's rows of the first replicated level, all-gather, run the tail replicated
+            be.apply(L.R, D.MG_K_RESTRICT, L.r, self.bc_pad, nrhs=k)
+            self.comm.all_gather(self.bc_all, self.bc_pad)
+            be.index_select(self.bc_all, self.gather_index, self.b_tail)
+            self.tail.cycle(self.b_tail, self.x_tail, True, ctype)
+            if self.first_tail < self.nl - 1 and ctype in ("W", "F"):       # second visit (MGcycle.jl:79-84)
+                self.tail.cycle(self.b_tail, self.x_tail, False, "W" if ctype == "W" else "V")
+            be.apply(L.P, D.MG_K_PROLONG, self.x_tail, cur, alpha=1.0, beta=1.0, nrhs=k)
+        for _ in range(npost):
+            self.exchange(L.planA, cur)
+            be.apply(L.A, D.MG_K_SMOOTH, cur, alt, b=b, d=L.d, nrhs=k)
+            cur, alt = alt, cur
+        return cur
+
+    # ---- public: cycle / solve on this rank's rows ---------------------------------------------------------
+    def cycle(self, b_loc, x_loc, x_is_zero: bool):
+        """One cycle; b_loc/x_loc hold this rank's fine rows (length n_own [x nrhs]); x_loc updated in place."""
+        L = self.levels[0]
+        L.x0[: L.n_own].copy_(x_loc)
+        res = self._cycle(0, b_loc, L.x0, L.x1, bool(x_is_zero), self.cycleType)
+        x_loc.copy_(res[: L.n_own])
+        return x_loc
+
+    def solve(self, b_loc, x_loc, tol: float, maxIter: int):
+        """solveMG (SolveFuncs.jl:3-39) on sharded vectors; returns (iters, resvec)."""
+        be, k = self.be, self.nrhs
+        L = self.levels[0]
+        cur, alt = L.x0, L.x1
+        cur[: L.n_own].copy_(x_loc)
+        xn = self.norm(cur, L.n_own)
+        x_zero = xn == 0.0
+        if x_zero:
+            res0 = self.norm(b_loc, L.n_own)
+        else:
+            self.exchange(L.planA, cur)
+            be.apply(L.A, D.MG_K_RESIDUAL, cur, L.r, b=b_loc, nrhs=k)
+            res0 = self.norm(L.r, L.n_own)
+        resvec = [res0]
+        it = 0
+        for count in range(1, maxIter + 1):
+            out = self._cycle(0, b_loc, cur, alt, x_zero, self.cycleType, r_valid=(count > 1 or not x_zero))
+            if out is not cur:
+                cur, alt = alt, cur
+            x_zero = False
+            self.exchange(L.planA, cur)
+            be.apply(L.A, D.MG_K_RESIDUAL, cur, L.r, b=b_loc, nrhs=k)
+            res = self.norm(L.r, L.n_own)
+            it += 1
+            resvec.append(res)
+            if res / res0 < tol:
+                break
+        x_loc.copy_(cur[: L.n_own])
+        return it, np.array(resvec)
+
+    def local_algorithmic_bytes(self):
+        """Per-rank algorithmic bytes of the sharded levels of one V-cycle from x=0."""
+        k = self.nrhs
+        t = 0.0
+        for L in self.levels:
+            n = L.n_own
+            sweep = 12.0 * L.nnzA + 4.0 * (n + 1) + 8.0 * k * (3 * n) + 8.0 * n
+            resid = 12.0 * L.nnzA + 4.0 * (n + 1) + 8.0 * k * (3 * n)
+            t += 8.0 * n * (1 + 2 * k) + (L.npre - 1 + L.npost) * sweep + resid
+            t += 12.0 * (L.nnzR + L.nnzP) + 8.0 * k * (3 * n)
+        return t

@@ -1,0 +1,179 @@
+"""Multi-GPU path (multigrid.jl_amd/distributed.py).
+
+CPU (-m "not gpu"): world_size-2 and -4 ``gloo`` runs with the test-only checker backend
+(tests/dist_cpu_backend.py): partition, halo plans, exchange, replicated tail and the cycle schedule must
+reproduce the oracle's single-process solveMG on the same seeded problem.
+GPU (-m gpu): the same schedule with the HIP kernels - world_size 1 in-process and world_size 2 as two
+processes sharing the one GPU of the box (gloo with host staging stands in for RCCL).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem(kind, nrhs, cyc):
+    import multigrid_jl_amd as mg
+    if kind == "gmg3d":
+        A, mesh = mg.poisson_shifted([16, 16, 16])
+        p = mg.getMGparam(np.float64, np.int64, 4, 8, 6, 1e-10, "Jac", 0.8, 2, 1, cyc, "NoMUMPS", 0.5, 0.0)
+        mg.MGsetup(A, mesh, p, nrhs)
+        nodes = mesh.n + 1
+    elif kind == "gmg2d":
+        A, mesh = mg.poisson_shifted([40, 24])
+        p = mg.getMGparam(np.float64, np.int64, 3, 8, 6, 1e-10, "SPAI", 1.0, 1, 1, cyc, "NoMUMPS", 0.5, 0.0)
+        mg.MGsetup(A, mesh, p, nrhs)
+        nodes = mesh.n + 1
+    else:  # "sa": general CSR, contiguous row blocks
+        A, _ = mg.anisotropic_divsiggrad([12, 12, 12], weights=(1, 0.5, 0.25))
+        p = mg.getMGparam(np.float64, np.int64, 4, 8, 6, 1e-10, "SPAI", 1.0, 1, 1, cyc, "Julia", 0.4)
+        mg.SA_AMGsetup(A, p, True, nrhs)
+        nodes = None
+    b = mg.seeded_rhs(A, nrhs)
+    return mg, A, p, b, nodes
+
+
+def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from multigrid_jl_amd import distributed as dd
+        mg, A, p, b, nodes = _problem(kind, nrhs, cyc)
+        if nodes is not None:
+            owner = dd.box_owner(nodes, dd.default_domains(world, len(nodes)))
+        else:
+            owner = dd.block_owner(A.shape[0], world)
+        if use_hip:
+            be = dd.HipBackend(0)
+            comm = dd.TorchComm(stage_through_host=True)
+        else:
+            from dist_cpu_backend import CpuCheckerBackend
+            be = CpuCheckerBackend()
+            comm = dd.TorchComm()
+        H = dd.DistributedHierarchy(p, comm, be, owner, nrhs, replicate_below=200)
+        assert len(H.levels) >= 2, "the test must exercise at least two sharded levels"
+        b_loc = H.scatter_fine(b)
+        x_loc = torch.zeros_like(b_loc)
+        it, resvec = H.solve(b_loc, x_loc, 1e-10, 6)
+        # one more single cycle from the non-zero x through the public cycle() entry
+        x2 = x_loc.clone()
+        H.cycle(b_loc, x2, False)
+        be.synchronize()
+        out = [None] * world
+        dist.all_gather_object(out, (H.rows_fine, x_loc.cpu().numpy(), x2.cpu().numpy()))
+        if rank == 0:
+            x = np.zeros_like(b)
+            xc = np.zeros_like(b)
+            for rows, xl, x2l in out:
+                x[rows] = xl
+                xc[rows] = x2l
+            q.put(("ok", it, resvec, x, xc))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+def _run(world, kind, nrhs, cyc, use_hip=False):
+    from oracle import mg_oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nrhs, cyc, use_hip, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    _, it, resvec, x, xc = res
+    mg, A, p, b, _ = _problem(kind, nrhs, cyc)
+    xo = np.zeros_like(b)
+    hist = {}
+    _, _, ito = orc.solveMG(p, b, xo, False, hist)
+    assert it == ito
+    assert np.abs(resvec - hist["resvec"]).max() / hist["resvec"][0] < 1e-10
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    xo2 = orc.recursiveCycle(p, b, xo.copy(), 1)
+    assert np.abs(xc - xo2).max() <= 1e-10 * np.abs(xo2).max()
+
+
+# ---- CPU: host logic --------------------------------------------------------------------------------------
+def test_box_owner_follows_dd_rule():
+    from multigrid_jl_amd import distributed as dd
+    own = dd.box_owner([9, 9], [2, 2]).reshape(9, 9)            # 8x8 cells -> cellSize 4
+    assert own[0, 0] == 0 and own[0, 3] == 0 and own[0, 4] == 1 and own[0, 8] == 1
+    assert own[4, 0] == 2 and own[8, 8] == 3                        # loc2cs: x fastest (DDService.jl:27-36)
+    own = dd.box_owner([8, 6], [3, 1])                              # 7 cells / 3 -> cellSize 2, last box takes the rest
+    assert np.array_equal(own[:8], [0, 0, 1, 1, 2, 2, 2, 2])
+    own3 = dd.box_owner([5, 5, 5], [2, 2, 2])
+    assert sorted(set(own3)) == list(range(8)) and own3.size == 125
+    assert dd.default_domains(8, 3) == [2, 2, 2] and dd.default_domains(2, 3) == [1, 1, 2]
+
+
+def test_halo_plan_reproduces_global_spmv():
+    """Without any process group: emulate the exchange of all ranks in one process."""
+    import multigrid_jl_amd as mg
+    from multigrid_jl_amd import distributed as dd
+    A, mesh = mg.poisson_shifted([10, 8, 6])
+    nr = 4
+    part = dd.Partition(dd.box_owner(mesh.n + 1, [1, 2, 2]), nr)
+    x = np.random.default_rng(0).standard_normal(A.shape[0])
+    y = A @ x
+    locs = [dd.localize(A, part, part, r) for r in range(nr)]
+    for r in range(nr):
+        Ml, plan = locs[r]
+        assert sum(plan.recv_splits) == plan.n_halo
+        halo = []
+        for q in range(nr):                                         # what q sends to r, in q's send order
+            Mq, pq = locs[q]
+            off = int(np.sum(pq.send_splits[:r]))
+            idx = pq.send_idx[off: off + pq.send_splits[r]]
+            assert len(idx) == plan.recv_splits[q]
+            halo.append(x[part.rows[q]][idx])
+        xl = np.concatenate([x[part.rows[r]]] + halo)
+        assert np.allclose(Ml @ xl, y[part.rows[r]], rtol=1e-14, atol=1e-14)
+
+
+def test_coarse_ownership_follows_coincident_node():
+    import multigrid_jl_amd as mg
+    from multigrid_jl_amd import distributed as dd
+    P, nc = mg.getFWInterp([9, 9, 9])
+    part = dd.Partition(dd.box_owner([9, 9, 9], [2, 2, 2]), 8)
+    cpart = part.coarsen(P)
+    fine = part.owner.reshape(9, 9, 9)[::2, ::2, ::2].reshape(-1)
+    assert np.array_equal(cpart.owner, fine)
+
+
+@pytest.mark.parametrize("world,kind,nrhs,cyc", [(2, "gmg3d", 1, "V"), (2, "gmg3d", 3, "W"), (4, "gmg3d", 1, "F"),
+                                                 (2, "gmg2d", 1, "V"), (2, "sa", 2, "V")])
+def test_gloo_distributed_solve_matches_oracle(built, world, kind, nrhs, cyc):
+    _run(world, kind, nrhs, cyc, use_hip=False)
+
+
+# ---- GPU: the HIP kernels under the same schedule ---------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,nrhs,cyc", [(1, "gmg3d", 1, "V"), (2, "gmg3d", 1, "V"), (2, "gmg3d", 4, "W"),
+                                                 (2, "sa", 1, "V")])
+def test_hip_distributed_solve_matches_oracle(built, world, kind, nrhs, cyc):
+    _run(world, kind, nrhs, cyc, use_hip=True)
