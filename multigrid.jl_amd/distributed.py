@@ -376,6 +376,10 @@ class DistributedHierarchy:
                     plan.send_idx_t = be.index_tensor(plan.send_idx)
                     ns = int(plan.send_idx.size)
                     plan.send_buf = be.zeros(max(ns, 1), k) if k > 1 else be.zeros(max(ns, 1))
+                    # a collective must be entered by every rank or by none: agree once, at setup
+                    flag = be.zeros(1)
+                    flag += float(ns + plan.n_halo)
+                    plan.active = size > 1 and float(comm.all_reduce_sum(flag).item()) > 0.0
         # replicated tail
         nt = int(param.As[a].shape[0])
         self.n_tail = nt
@@ -397,7 +401,7 @@ class DistributedHierarchy:
 
     def exchange(self, plan: HaloPlan, buf):
         """Fill the halo tail buf[n_own : n_own+n_halo] from the owners (one all_to_all_single)."""
-        if plan is None or self.comm.size == 1 or (plan.n_halo == 0 and plan.send_idx.size == 0):
+        if plan is None or not plan.active:
             return
         ns = int(plan.send_idx.size)
         send = plan.send_buf[:ns]
