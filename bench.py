@@ -252,8 +252,9 @@ def bench_distributed(args, mg, torch, dist, A, mesh, p, b_host, cells, nrhs, K,
         dist.barrier()
         torch.cuda.synchronize()
 
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < args.prewarm:
+    # pre-warm: a FIXED number of untimed cycles (a time-based loop would give the ranks different
+    # collective counts and deadlock)
+    for _ in range(20 if args.prewarm > 0 else 0):
         H.cycle(b, x, False)
     if W > 0:
         x.zero_()
