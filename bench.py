@@ -9,6 +9,7 @@ hierarchy, b and x resident in HBM.
 Workloads (BASELINE.json configs):
   c2 (default)  3-D 7-pt Poisson 256^3 cells, GMG V(2,1) damped Jacobi w=0.8, 6 levels, fp64, nrhs=1
   c5            same operator, 16 right-hand sides (block SpMM path)
+  c3            SA-AMG on anisotropic diffusion (edge weights 16:4:1 x log-normal sigma), general CSR, V(1,1) SPAI
   c1            32^3 cells (CPU-plumbing size; parity case, not a bench line)
 Use --cells N to shrink the grid for quick checks (the JSON then names the reduced workload).
 """
@@ -35,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--cells", type=int, default=0, help="override cells per dimension")
     ap.add_argument("--levels", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,22 +81,35 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cells = args.cells or {"c1": 32, "c2": 256, "c5": 256}[args.workload]
+    cells = args.cells or {"c1": 32, "c2": 256, "c3": 256, "c5": 256}[args.workload]
     nrhs = 16 if args.workload == "c5" else 1
     levels = args.levels or levels_for(cells)
     K, W = args.steps, args.warmup
 
     # ---- host setup (CPU, as in the reference) ---------------------------------------------------
     t0 = time.perf_counter()
-    A, mesh = mg.poisson_shifted([cells] * 3)
-    t_op = time.perf_counter() - t0
-    p = mg.getMGparam(np.float64, np.int64, levels, os.cpu_count() or 8, K, 0.0, "Jac", 0.8, 2, 1, "V",
-                      "NoMUMPS", 0.5, 0.0, "FullWeighting")
-    t0 = time.perf_counter()
-    mg.MGsetup(A, mesh, p, nrhs)
+    if args.workload == "c3":
+        A, mesh = mg.anisotropic_divsiggrad([cells] * 3, weights=(1.0, 0.25, 0.0625))
+        t_op = time.perf_counter() - t0
+        p = mg.getMGparam(np.float64, np.int64, args.levels or 14, os.cpu_count() or 8, K, 0.0, "SPAI", 1.0, 1, 1, "V",
+                          "Julia", 0.4, 0.0)
+        t0 = time.perf_counter()
+        mg.SA_AMGsetup(A, p, True, nrhs)
+        desc = (f"SA-AMG (theta=0.4, V(1,1) SPAI w=1) on anisotropic diffusion {cells}^3 cells, edge weights 16:4:1 x "
+                f"log-normal sigma, general CSR")
+    else:
+        A, mesh = mg.poisson_shifted([cells] * 3)
+        t_op = time.perf_counter() - t0
+        p = mg.getMGparam(np.float64, np.int64, levels, os.cpu_count() or 8, K, 0.0, "Jac", 0.8, 2, 1, "V",
+                          "NoMUMPS", 0.5, 0.0, "FullWeighting")
+        t0 = time.perf_counter()
+        mg.MGsetup(A, mesh, p, nrhs)
+        desc = f"3D 7-pt Poisson {cells}^3 cells, GMG V(2,1) damped-Jacobi w=0.8"
     t_setup = time.perf_counter() - t0
     b_host = mg.seeded_rhs(A, nrhs)
     if world > 1:
+        if args.workload == "c3":
+            raise SystemExit("c3 is a single-GPU workload (BASELINE.json configs[2])")
         return bench_distributed(args, mg, torch, dist, A, mesh, p, b_host, cells, nrhs, K, W, rank, world,
                                  local_rank, t_op, t_setup)
     t0 = time.perf_counter()
@@ -218,10 +232,11 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"3D 7-pt Poisson {cells}^3 cells ({n} nodal DoF), GMG V(2,1) damped-Jacobi w=0.8, "
-                                   f"{p.levels} levels, nrhs={nrhs}, fp64, solveMG step = cycle + residual + norm",
+            "config": {"workload": f"{desc} ({n} nodal DoF), {p.levels} levels, nrhs={nrhs}, fp64, "
+                                   f"solveMG step = cycle + residual + norm",
                        "cells": cells, "levels": p.levels, "nrhs": nrhs, "N": n, "nnz": int(A.nnz),
-                       "parallelism": "1 process per GPU" if world == 1 else f"{world} independent replicas"},
+                       "level_rows": [int(a.shape[0]) for a in p.As], "level_nnz": [int(a.nnz) for a in p.As],
+                       "parallelism": "1 process per GPU"},
             "relres_after_steps": relres,
             "setup_s": {"operator": round(t_op, 2), "MGsetup": round(t_setup, 2), "upload": round(t_upload, 2)},
             "roofline": roofline,

@@ -7,9 +7,14 @@
 // arrays of the (symmetric) strength matrix S, 1-based Int64.
 //
 //   mg_sa_aggregate_FP64_INT64  <->  neighborhoodAggregationNew, src/Multigrid/SA-AMG.jl:119-211
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
+#include <utility>
 #include <vector>
+
+#include <omp.h>
 
 extern "C" {
 
@@ -82,5 +87,98 @@ int mg_sa_aggregate_FP64_INT64(long long n, const long long* colptr, const long 
     if (aggr[k - 1] < 0) aggr[k - 1] = -aggr[k - 1];
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// C = A*B for CSR operands (0-based int64 pointers/indices, fp64 values), row-parallel Gustavson with a
+// per-row open-addressing hash accumulator; output rows have sorted column indices and keep entries
+// whose value cancels to zero (Julia's and scipy's sparse products keep them too).
+// Used for the Galerkin products Ps[l]*AT*Rs[l] (MGsetup.jl:102, SA-AMG.jl:50), which dominate the
+// reference's serial setup.  Two passes: spgemm_count fills C_ptr[i+1] = nnz of row i (caller prefix-sums),
+// spgemm_fill writes indices/values.
+// ------------------------------------------------------------------------------------------------
+namespace {
+inline std::size_t table_size(long long products, long long ncols) {
+  long long need = 2 * std::min(products, ncols) + 2;
+  std::size_t t = 16;
+  while ((long long)t < need) t <<= 1;
+  return t;
+}
+inline std::size_t hash_slot(long long key, std::size_t mask) {
+  return (std::size_t)((unsigned long long)key * 0x9E3779B97F4A7C15ull >> 20) & mask;
+}
+}  // namespace
+
+int mg_spgemm_count_INT64(long long n_rows, long long ncols_B, const long long* A_ptr, const long long* A_idx,
+                          const long long* B_ptr, const long long* B_idx, long long* C_ptr, long long nthreads) {
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+  C_ptr[0] = 0;
+#pragma omp parallel
+  {
+    std::vector<long long> keys;
+#pragma omp for schedule(dynamic, 64)
+    for (long long i = 0; i < n_rows; ++i) {
+      long long products = 0;
+      for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) products += B_ptr[A_idx[k] + 1] - B_ptr[A_idx[k]];
+      if (products == 0) { C_ptr[i + 1] = 0; continue; }
+      const std::size_t T = table_size(products, ncols_B), mask = T - 1;
+      if (keys.size() < T) keys.resize(T);
+      std::fill(keys.begin(), keys.begin() + T, -1LL);
+      long long cnt = 0;
+      for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) {
+        const long long r = A_idx[k];
+        for (long long q = B_ptr[r]; q < B_ptr[r + 1]; ++q) {
+          const long long c = B_idx[q];
+          std::size_t s = hash_slot(c, mask);
+          while (keys[s] != -1 && keys[s] != c) s = (s + 1) & mask;
+          if (keys[s] == -1) { keys[s] = c; ++cnt; }
+        }
+      }
+      C_ptr[i + 1] = cnt;
+    }
+  }
+  return 0;
+}
+
+int mg_spgemm_fill_FP64_INT64(long long n_rows, long long ncols_B, const long long* A_ptr, const long long* A_idx,
+                              const double* A_val, const long long* B_ptr, const long long* B_idx,
+                              const double* B_val, const long long* C_ptr, long long* C_idx, double* C_val,
+                              long long nthreads) {
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+#pragma omp parallel
+  {
+    std::vector<long long> keys;
+    std::vector<double> vals;
+    std::vector<std::pair<long long, double>> row;
+#pragma omp for schedule(dynamic, 64)
+    for (long long i = 0; i < n_rows; ++i) {
+      const long long out0 = C_ptr[i], cnt = C_ptr[i + 1] - C_ptr[i];
+      if (cnt == 0) continue;
+      long long products = 0;
+      for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) products += B_ptr[A_idx[k] + 1] - B_ptr[A_idx[k]];
+      const std::size_t T = table_size(products, ncols_B), mask = T - 1;
+      if (keys.size() < T) { keys.resize(T); vals.resize(T); }
+      std::fill(keys.begin(), keys.begin() + T, -1LL);
+      for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) {  // accumulate in the order a serial Gustavson would
+        const long long r = A_idx[k];
+        const double a = A_val[k];
+        for (long long q = B_ptr[r]; q < B_ptr[r + 1]; ++q) {
+          const long long c = B_idx[q];
+          std::size_t s = hash_slot(c, mask);
+          while (keys[s] != -1 && keys[s] != c) s = (s + 1) & mask;
+          if (keys[s] == -1) { keys[s] = c; vals[s] = a * B_val[q]; }
+          else vals[s] += a * B_val[q];
+        }
+      }
+      row.clear();
+      for (std::size_t s = 0; s < T; ++s)
+        if (keys[s] != -1) row.emplace_back(keys[s], vals[s]);
+      std::sort(row.begin(), row.end(), [](const std::pair<long long, double>& x, const std::pair<long long, double>& y) { return x.first < y.first; });
+      for (long long j = 0; j < cnt; ++j) { C_idx[out0 + j] = row[(std::size_t)j].first; C_val[out0 + j] = row[(std::size_t)j].second; }
+    }
+  }
+  return 0;
+}
+
+long long mg_host_max_threads(void) { return (long long)omp_get_max_threads(); }
 
 }  // extern "C"

@@ -69,10 +69,11 @@ def _relax_param_arr(param: MGparam):
 
 
 def galerkin(R, A, P):
-    """A_c = R*(A*P): the CSR view of ``Act = Ps[l]*AT*Rs[l]`` evaluated left to right (MGsetup.jl:102)."""
-    Ac = (R @ (A @ P)).tocsr()
-    Ac.sort_indices()
-    return Ac
+    """A_c = R*(A*P): the CSR view of ``Act = Ps[l]*AT*Rs[l]`` evaluated left to right (MGsetup.jl:102).
+    The reference's serial Julia SpGEMM is the bulk of its setup time; here it is row-parallel on the host
+    (csrc/mg_host.cpp) - still CPU, still before the device ever sees the hierarchy."""
+    from .hostlib import spgemm
+    return spgemm(R, spgemm(A, P))
 
 
 def defineCoarsestAinv(param: MGparam, Ac) -> None:

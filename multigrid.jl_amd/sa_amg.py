@@ -23,20 +23,7 @@ import scipy.sparse as sp
 from .mgdef import MGparam, _release_device
 from .mgsetup import _as_csr, adjustMemoryForNumRHS, defineCoarsestAinv, galerkin, getRelaxPrec
 
-_HOSTLIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmghost.so")
-_hl = None
-
-
-def _hostlib():
-    global _hl
-    if _hl is None:
-        if not os.path.exists(_HOSTLIB):
-            raise RuntimeError(f"{_HOSTLIB} is missing: run __graft_entry__.build()")
-        _hl = C.CDLL(_HOSTLIB)
-        _hl.mg_sa_aggregate_FP64_INT64.restype = C.c_int
-        _hl.mg_sa_aggregate_FP64_INT64.argtypes = [C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
-                                                   C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
-    return _hl
+from .hostlib import lib as _hostlib, spgemm
 
 
 def getStrengthMatrix(A, strengthConnParam: float):
@@ -124,7 +111,7 @@ def SA_AMGsetup(A, param: MGparam, symm: bool = True, nrhs: int = 1, verbose: bo
         relaxPrecs.append(d)
         DA = sp.diags(d) @ Al                                            # (AT*diag(d))' (l.44)
         rho = min(float(abs(DA).sum()), float(abs(DA.data).max()))       # entry-wise norms (l.45)
-        P = (P0 - (1.33 / rho) * (DA @ P0)).tocsr()                      # l.46
+        P = (P0 - (1.33 / rho) * spgemm(DA, P0)).tocsr()                 # l.46
         P.sort_indices()
         R = sp.csr_matrix(P.T)                                           # l.47
         R.sort_indices()
