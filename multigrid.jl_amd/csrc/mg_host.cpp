@@ -97,6 +97,7 @@ int mg_sa_aggregate_FP64_INT64(long long n, const long long* colptr, const long 
 // spgemm_fill writes indices/values.
 // ------------------------------------------------------------------------------------------------
 namespace {
+constexpr long long DENSE_MAX_COLS = 1500000;  // 24 MB of accumulator per thread at most
 inline std::size_t table_size(long long products, long long ncols) {
   long long need = 2 * std::min(products, ncols) + 2;
   std::size_t t = 16;
@@ -112,6 +113,25 @@ int mg_spgemm_count_INT64(long long n_rows, long long ncols_B, const long long* 
                           const long long* B_ptr, const long long* B_idx, long long* C_ptr, long long nthreads) {
   if (nthreads > 0) omp_set_num_threads((int)nthreads);
   C_ptr[0] = 0;
+  if (ncols_B <= DENSE_MAX_COLS) {  // dense stamp array per thread: no per-row clearing
+#pragma omp parallel
+    {
+      std::vector<long long> stamp((std::size_t)ncols_B, -1LL);
+#pragma omp for schedule(dynamic, 16)
+      for (long long i = 0; i < n_rows; ++i) {
+        long long cnt = 0;
+        for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) {
+          const long long r = A_idx[k];
+          for (long long q = B_ptr[r]; q < B_ptr[r + 1]; ++q) {
+            const long long c = B_idx[q];
+            if (stamp[(std::size_t)c] != i) { stamp[(std::size_t)c] = i; ++cnt; }
+          }
+        }
+        C_ptr[i + 1] = cnt;
+      }
+    }
+    return 0;
+  }
 #pragma omp parallel
   {
     std::vector<long long> keys;
@@ -144,6 +164,35 @@ int mg_spgemm_fill_FP64_INT64(long long n_rows, long long ncols_B, const long lo
                               const double* B_val, const long long* C_ptr, long long* C_idx, double* C_val,
                               long long nthreads) {
   if (nthreads > 0) omp_set_num_threads((int)nthreads);
+  if (ncols_B <= DENSE_MAX_COLS) {
+#pragma omp parallel
+    {
+      std::vector<long long> stamp((std::size_t)ncols_B, -1LL);
+      std::vector<double> acc((std::size_t)ncols_B, 0.0);
+      std::vector<long long> touched;
+#pragma omp for schedule(dynamic, 16)
+      for (long long i = 0; i < n_rows; ++i) {
+        const long long out0 = C_ptr[i], cnt = C_ptr[i + 1] - C_ptr[i];
+        if (cnt == 0) continue;
+        touched.clear();
+        for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) {
+          const long long r = A_idx[k];
+          const double a = A_val[k];
+          for (long long q = B_ptr[r]; q < B_ptr[r + 1]; ++q) {
+            const std::size_t c = (std::size_t)B_idx[q];
+            if (stamp[c] != i) { stamp[c] = i; acc[c] = a * B_val[q]; touched.push_back((long long)c); }
+            else acc[c] += a * B_val[q];
+          }
+        }
+        std::sort(touched.begin(), touched.end());
+        for (long long j = 0; j < cnt; ++j) {
+          C_idx[out0 + j] = touched[(std::size_t)j];
+          C_val[out0 + j] = acc[(std::size_t)touched[(std::size_t)j]];
+        }
+      }
+    }
+    return 0;
+  }
 #pragma omp parallel
   {
     std::vector<long long> keys;
