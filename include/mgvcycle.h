@@ -76,6 +76,12 @@ int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which
 int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long long n,
                       long long relaxPre, long long relaxPost);
 
+/* Optional performance hint (results are unchanged): the rows of As[level] are the nodes of an x-fastest
+ * n1 x n2 x n3 regular grid (param.Meshes[level].n .+ 1 for geometric multigrid, MGsetup.jl:54).  Lets the
+ * library walk the row blocks in L2-sized y-tiles when three grid planes of the gathered vector do not fit
+ * an XCD's L2 (block right-hand sides, grids beyond ~400^2 nodes per plane).  n3 = 1 for 2-D. */
+int mg_set_grid_hint(mg_hierarchy* h, long long level, long long n1, long long n2, long long n3);
+
 /* cycleType: 'V', 'W' or 'F' (MGcycle.jl:78-85).  'K' is not on the device path yet. */
 int mg_set_cycle_type(mg_hierarchy* h, long long cycleType);
 

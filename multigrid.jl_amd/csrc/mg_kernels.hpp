@@ -55,6 +55,7 @@ struct CsrDev {
   const int* colidx;   // nnz (+pad), 0-based
   const double* val;   // nnz (+pad)
   const int* blk_row;  // nblocks+1 row-block boundaries
+  const int* sched;    // optional processing order of the row blocks (nullptr: natural order)
   int nblocks;
   int n_rows;
   int n_cols;
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
   __shared__ double red[BLK / 64];
 
   const int tid = threadIdx.x;
-  const int bid = xcd_band(blockIdx.x, A.nblocks);
+  int bid = xcd_band(blockIdx.x, A.nblocks);
+  if (A.sched) bid = A.sched[bid];
   const int r0 = A.blk_row[bid];
   const int r1 = A.blk_row[bid + 1];
   const int nrows = r1 - r0;
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int 
   __shared__ int srow[MAXROWS + 1];
 
   const int tid = threadIdx.x;
-  const int bid = xcd_band(blockIdx.x, A.nblocks);
+  int bid = xcd_band(blockIdx.x, A.nblocks);
+  if (A.sched) bid = A.sched[bid];
   const int r0 = A.blk_row[bid];
   const int r1 = A.blk_row[bid + 1];
   const int nrows = r1 - r0;

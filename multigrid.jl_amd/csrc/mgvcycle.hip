@@ -83,8 +83,10 @@ struct DevBuf {
 struct Csr {
   bool set = false;
   long long n_rows = 0, n_cols = 0, nnz = 0;
-  DevBuf<int> rowptr, colidx, blk_row;
+  DevBuf<int> rowptr, colidx, blk_row, sched;
   DevBuf<double> val;
+  std::vector<int> h_blk_row;  // host copy of the row-block boundaries (for building schedules)
+  bool has_sched = false;
   int nblocks = 0;
   bool nt = false;  // non-temporal loads of the matrix stream (mg_kernels.hpp load_stream)
   mgk::CsrDev dev() const {
@@ -93,6 +95,7 @@ struct Csr {
     d.colidx = colidx.p;
     d.val = val.p;
     d.blk_row = blk_row.p;
+    d.sched = has_sched ? sched.p : nullptr;
     d.nblocks = nblocks;
     d.n_rows = (int)n_rows;
     d.n_cols = (int)n_cols;
@@ -102,13 +105,16 @@ struct Csr {
     rowptr.release();
     colidx.release();
     blk_row.release();
+    sched.release();
+    has_sched = false;
     val.release();
     set = false;
   }
-  size_t bytes() const { return rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes(); }
+  size_t bytes() const { return rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes() + sched.bytes(); }
 };
 
 struct Level {
+  long long grid[3] = {0, 0, 0};  // optional hint: the rows are an x-fastest n1 x n2 x n3 nodal grid
   Csr A, P, R;  // P, R: transfer to/from the next coarser level (unset on the coarsest)
   DevBuf<double> d;
   bool relax_set = false;
@@ -489,8 +495,49 @@ int download_block(mg_hierarchy* h, const double* dev, double* host, long long n
   return MG_OK;
 }
 
+// L2-tiled processing order of the row blocks of M, whose rows form an x-fastest n1 x n2 x n3 grid.
+// In natural order two blocks that gather from the same z-neighbour planes are a whole plane apart; when
+// three planes of the gathered vector (x nrhs) exceed an XCD's 4 MiB L2 those gathers miss.  Walking the
+// grid in y-tiles (all z for T consecutive y-lines, then the next tile) brings the reuse distance down to
+// ~2T lines.  Pure scheduling: every block computes exactly what it computed before.
+int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
+  M.has_sched = false;
+  if (!M.set || grid[0] <= 0) return MG_OK;
+  const long long n1 = grid[0], n2 = grid[1], n3 = std::max<long long>(1, grid[2]);
+  if (n1 * n2 * n3 != M.n_rows || n3 < 2 || n2 < 8) return MG_OK;
+  // gathered-vector bytes per (y,z) line of the row grid, three z-planes in the window
+  const double line_bytes = 3.0 * ((double)M.n_cols / (double)(n2 * n3)) * 8.0 * (double)nrhs;
+  const double plane_window = line_bytes * (double)n2;
+  const double budget = 1.5e6;  // of the 4 MiB per-XCD L2 (the rest: matrix stream, b/d/out lines)
+  if (plane_window <= budget) return MG_OK;  // natural order already keeps the window in L2
+  long long T = (long long)(budget / line_bytes);
+  T = std::max<long long>(4, std::min<long long>(T, n2));
+  const int nb = M.nblocks;
+  std::vector<long long> key((size_t)nb);
+  for (int b = 0; b < nb; ++b) {
+    const long long r0 = M.h_blk_row[(size_t)b];
+    const long long y = (r0 / n1) % n2, z = r0 / (n1 * n2);
+    key[(size_t)b] = ((y / T) * n3 + z) * n2 + y;
+  }
+  std::vector<int> order((size_t)nb);
+  for (int b = 0; b < nb; ++b) order[(size_t)b] = b;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
+  MG_TRY(M.sched.alloc((size_t)nb));
+  HIP_TRY(hipMemcpy(M.sched.p, order.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice));
+  M.has_sched = true;
+  return MG_OK;
+}
+
 int alloc_scratch(mg_hierarchy* h) {
   const long long k = h->nrhs;
+  if (!std::getenv("MG_NO_SCHED")) {
+    for (int l = 0; l < (int)h->nlevels; ++l) {
+      Level& L = h->lev[(size_t)l];
+      MG_TRY(build_schedule(L.A, L.grid, k));
+      MG_TRY(build_schedule(L.P, L.grid, k));
+      if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
+    }
+  }
   long long nmax = 0;
   for (int l = 0; l < (int)h->nlevels; ++l) {
     Level& L = h->lev[l];
@@ -571,6 +618,7 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
   HIP_TRY(hipMemset(M->val.p, 0, ((size_t)nnz + pad) * sizeof(double)));
   HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(M->blk_row.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+  M->h_blk_row = blk;
   M->set = true;
   // cache policy of the matrix stream: non-temporal once the operator is too large to stay in the
   // 256 MiB Infinity Cache between two uses anyway (measured, profiles/r01_nt_ab.md: +2..17 % on the
@@ -684,6 +732,18 @@ int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long lo
   L.relax_set = true;
   L.npre = relaxPre;
   L.npost = relaxPost;
+  h->finalized = false;
+  return MG_OK;
+}
+
+int mg_set_grid_hint(mg_hierarchy* h, long long level, long long n1, long long n2, long long n3) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  if (n1 < 1 || n2 < 1 || n3 < 1) return fail(MG_ERR_INVALID, "grid dimensions must be >= 1");
+  Level& L = h->lev[(size_t)level - 1];
+  L.grid[0] = n1;
+  L.grid[1] = n2;
+  L.grid[2] = n3;
   h->finalized = false;
   return MG_OK;
 }
