@@ -34,6 +34,7 @@ SIGNATURES = {
     "mg_set_operator_FP64_INT64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _lp, _lp, _dp]),
     "mg_set_relax_FP64": (C.c_int, [_vp, _ll, _dp, _ll, _ll, _ll]),
     "mg_set_cycle_type": (C.c_int, [_vp, _ll]),
+    "mg_set_grid_hint": (C.c_int, [_vp, _ll, _ll, _ll, _ll]),
     "mg_set_coarse_dense_inverse_FP64": (C.c_int, [_vp, _ll, _dp]),
     "mg_finalize": (C.c_int, [_vp]),
     "mg_set_nrhs": (C.c_int, [_vp, _ll]),
@@ -166,6 +167,12 @@ class DeviceHierarchy:
                 _check(lib, lib.mg_set_relax_FP64(self.handle, l, _f64(d), d.size,
                                                   int(param.relaxPre(l)), int(param.relaxPost(l))),
                        f"mg_set_relax(level={l})")
+        # performance hint only: GMG levels are regular nodal grids (param.Meshes, MGsetup.jl:54)
+        for l, mesh in enumerate(getattr(param, "Meshes", []) or []):
+            if l < nl and mesh is not None:
+                nn = [int(k) + 1 for k in mesh.n] + [1]
+                if int(np.prod(nn)) == param.As[l].shape[0]:
+                    _check(lib, lib.mg_set_grid_hint(self.handle, l + 1, nn[0], nn[1], nn[2]), "mg_set_grid_hint")
         _check(lib, lib.mg_set_cycle_type(self.handle, ord(param.cycleType)), "mg_set_cycle_type")
         nc = int(param.As[-1].shape[0])
         if nc > DENSE_COARSE_MAX:
