@@ -508,7 +508,7 @@ int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
   // gathered-vector bytes per (y,z) line of the row grid, three z-planes in the window
   const double line_bytes = 3.0 * ((double)M.n_cols / (double)(n2 * n3)) * 8.0 * (double)nrhs;
   const double plane_window = line_bytes * (double)n2;
-  const double budget = 1.5e6;  // of the 4 MiB per-XCD L2 (the rest: matrix stream, b/d/out lines)
+  const double budget = 2.0e6;  // of the 4 MiB per-XCD L2 (the rest: matrix stream, b/d/out lines)
   if (plane_window <= budget) return MG_OK;  // natural order already keeps the window in L2
   long long T = (long long)(budget / line_bytes);
   T = std::max<long long>(4, std::min<long long>(T, n2));
@@ -530,7 +530,8 @@ int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
 
 int alloc_scratch(mg_hierarchy* h) {
   const long long k = h->nrhs;
-  if (!std::getenv("MG_NO_SCHED")) {
+  const char* no_sched = std::getenv("MG_NO_SCHED");
+  if (!(no_sched && no_sched[0] == '1')) {
     for (int l = 0; l < (int)h->nlevels; ++l) {
       Level& L = h->lev[(size_t)l];
       MG_TRY(build_schedule(L.A, L.grid, k));
