@@ -508,7 +508,8 @@ int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
   // gathered-vector bytes per (y,z) line of the row grid, three z-planes in the window
   const double line_bytes = 3.0 * ((double)M.n_cols / (double)(n2 * n3)) * 8.0 * (double)nrhs;
   const double plane_window = line_bytes * (double)n2;
-  const double budget = 2.0e6;  // of the 4 MiB per-XCD L2 (the rest: matrix stream, b/d/out lines)
+  double budget = 2.0e6;  // of the 4 MiB per-XCD L2 (the rest: matrix stream, b/d/out lines)
+  if (const char* e = std::getenv("MG_SCHED_BUDGET")) budget = std::max(1.0, atof(e));  // tests force tiling
   if (plane_window <= budget) return MG_OK;  // natural order already keeps the window in L2
   long long T = (long long)(budget / line_bytes);
   T = std::max<long long>(4, std::min<long long>(T, n2));

@@ -167,3 +167,26 @@ def test_hip_path_reproduces_golden(mg, built, path):
     mg.recursiveCycle(p, b, x1, 1)
     assert np.abs(x1 - g["x_first"]).max() <= RES_TOL * np.abs(g["x_first"]).max()
     mg.clear_(p)
+
+
+@pytest.mark.parametrize("nrhs,cells", [(1, [20, 18, 16]), (4, [16, 16, 16]), (1, [33, 31])])
+def test_tiled_block_schedule_changes_nothing(mg, built, nrhs, cells, monkeypatch):
+    """mg_set_grid_hint + a tiny L2 budget force the y-tiled row-block order on every level: results must be
+    IDENTICAL to the natural order (pure scheduling) and match the oracle."""
+    A, mesh = mg.poisson_shifted(cells)
+    b = mg.seeded_rhs(A, nrhs)
+    xs = []
+    for budget in ("1e12", "2000"):
+        monkeypatch.setenv("MG_SCHED_BUDGET", budget)
+        p = mg.getMGparam(np.float64, np.int64, 3, 8, 4, 1e-10, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+        mg.MGsetup(A, mesh, p, nrhs)
+        x = np.zeros_like(b)
+        mg.solveMG(p, b, x)
+        xs.append((x, p.resvec.copy()))
+        if budget == "2000":
+            xo = np.zeros_like(b)
+            hist = {}
+            orc.solveMG(p, b, xo, False, hist)
+            assert np.abs(p.resvec - hist["resvec"]).max() / hist["resvec"][0] < RES_TOL
+        mg.clear_(p)
+    assert np.array_equal(xs[0][0], xs[1][0]) and np.array_equal(xs[0][1], xs[1][1])
