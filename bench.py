@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--cells", type=int, default=0, help="override cells per dimension")
     ap.add_argument("--levels", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = 256^3 cells PER GPU (N=8 is BASELINE configs[3], 512^3), sharded host setup; "
+                         "strong = the same 256^3 grid cut into N boxes (every rank builds the global hierarchy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed kernel launches before warm-up")
     ap.add_argument("--cpu-cycles", type=int, default=0, help="cycles of the CPU baseline sample (0 = auto)")
@@ -85,6 +88,11 @@ def main():
     nrhs = 16 if args.workload == "c5" else 1
     levels = args.levels or levels_for(cells)
     K, W = args.steps, args.warmup
+
+    if world > 1 and args.scaling == "weak":
+        if args.workload != "c2":
+            raise SystemExit("multi-GPU weak scaling is defined for the c2/c4 Poisson workload")
+        return bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank)
 
     # ---- host setup (CPU, as in the reference) ---------------------------------------------------
     t0 = time.perf_counter()
@@ -248,6 +256,82 @@ def main():
         dist.destroy_process_group()
 
 
+def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
+    """N > 1, WEAK scaling: `cells`^3 per GPU; the global grid is cells x (boxes per dimension) - 512^3 on 8
+    GPUs (BASELINE.json configs[3]).  No global matrix exists anywhere: every rank builds its part of the
+    hierarchy on an overlapping box (multigrid.jl_amd/structured_setup.py)."""
+    from multigrid_jl_amd import distributed as dd, structured_setup as ss
+    share = os.environ.get("MG_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", local_rank)
+    domains = dd.default_domains(world, 3)
+    gcells = [cells * d for d in domains]
+    domain = np.ravel([[0.0, float(d)] for d in domains])          # h = 1/cells in every direction, as on one GPU
+    levels = args.levels or levels_for(min(gcells))
+    p = mg.getMGparam(np.float64, np.int64, levels, os.cpu_count() or 8, K, 0.0, "Jac", 0.8, 2, 1, "V",
+                      "NoMUMPS", 0.5, 0.0, "FullWeighting")
+    t0 = time.perf_counter()
+    be = dd.HipBackend(local_rank)
+    comm = dd.TorchComm(stage_through_host=share)
+    H, info = ss.structured_gmg(gcells, domains, comm, be, p, ss.poisson_operator(gcells, domain), domain=domain, nrhs=1)
+    t_setup = time.perf_counter() - t0
+    n = int(np.prod(np.asarray(gcells) + 1))
+    b_own, ssq = ss.local_rhs(info, 1)
+    red_dev = torch.device("cpu") if share else dev
+    tot = torch.tensor([ssq], device=red_dev, dtype=torch.float64)
+    dist.all_reduce(tot)
+    b = be.from_numpy(b_own / float(tot.item()) ** 0.5)
+    x = torch.zeros_like(b)
+    log(f"[rank {rank}] global {gcells} cells over boxes {domains}: own {H.levels[0].n_own} of {n} rows, "
+        f"{len(H.levels)} sharded levels + replicated tail of {H.n_tail} rows; halo A1 {H.levels[0].planA.n_halo}; "
+        f"sharded setup {t_setup:.1f}s")
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(20 if args.prewarm > 0 else 0):      # fixed count: every rank enters the same collectives
+        H.cycle(b, x, False)
+    if W > 0:
+        x.zero_()
+        H.solve(b, x, 0.0, W)
+    x.zero_()
+    barrier()
+    t0 = time.perf_counter()
+    iters, resvec = H.solve(b, x, 0.0, K)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert iters == K
+    tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    lb = torch.tensor([H.local_algorithmic_bytes()], device=red_dev, dtype=torch.float64)
+    dist.all_reduce(lb, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ach = float(lb.item()) / (dt / K) / 1e9
+        out = {
+            "metric": "V-cycle DoF-updates/s", "value": round(n * K / dt, 1), "unit": "DoF-updates/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D 7-pt Poisson, {cells}^3 cells per GPU = {gcells} cells global ({n} nodal DoF), "
+                                   f"GMG V(2,1) damped-Jacobi w=0.8, {levels} levels, nrhs=1, fp64, "
+                                   f"solveMG step = cycle + residual + norm",
+                       "cells_per_gpu": cells, "global_cells": gcells, "levels": levels, "nrhs": 1, "N": n,
+                       "parallelism": f"DomainDecomposition boxes {domains}, {len(H.levels)} sharded levels, replicated "
+                                      f"tail from {H.n_tail} rows, one all_to_all_single halo exchange per SpMV (RCCL), "
+                                      f"sharded host setup"},
+            "relres_after_steps": float(resvec[-1] / resvec[0]),
+            "setup_s": {"sharded_setup_incl_upload": round(t_setup, 2)},
+            "roofline": {"bound": "hbm", "kernel": "sharded levels of one V-cycle, per GPU (max over ranks)",
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def bench_distributed(args, mg, torch, dist, A, mesh, p, b_host, cells, nrhs, K, W, rank, world, local_rank,
                       t_op, t_setup):
     """N > 1: STRONG scaling of the same workload - the fine grid is sharded over the ranks by the
@@ -261,7 +345,7 @@ def bench_distributed(args, mg, torch, dist, A, mesh, p, b_host, cells, nrhs, K,
     be = dd.HipBackend(local_rank)
     share = os.environ.get("MG_BENCH_SHARE_GPU") == "1"
     comm = dd.TorchComm(stage_through_host=share)
-    H = dd.DistributedHierarchy(p, comm, be, owner, nrhs)
+    H = dd.DistributedHierarchy.from_global(p, comm, be, owner, nrhs)
     t_upload = time.perf_counter() - t0
     n = A.shape[0]
     log(f"[rank {rank}] sharded {cells}^3 cells over {domains}: own {H.levels[0].n_own} of {n} rows, "

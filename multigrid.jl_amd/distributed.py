@@ -311,54 +311,35 @@ def _sub_hierarchy(param: MGparam, start: int) -> MGparam:
 
 
 class DistributedHierarchy:
-    """The multi-GPU counterpart of ``DeviceHierarchy``: built by every rank from the (global) host
-    hierarchy ``param``; holds this rank's rows of the sharded levels plus the replicated tail."""
+    """The multi-GPU counterpart of ``DeviceHierarchy``: this rank's rows of the sharded levels plus the
+    replicated coarse tail.  Two builders:
 
-    def __init__(self, param: MGparam, comm, backend, fine_owner: np.ndarray, nrhs: int = 1,
-                 replicate_below: int = 300_000):
+    * ``from_global``     - every rank holds the global host hierarchy ``param`` (any CSR hierarchy, GMG or
+                            SA-AMG) and cuts its rows out of it;
+    * ``from_structured`` - ``structured_setup.py``: every rank builds only its own part of a GMG hierarchy
+                            on an overlapping local box (no global matrix ever exists) - what makes the
+                            512^3 / 8-GPU configuration feasible.
+    """
+
+    def __init__(self, comm, backend, local_levels, tail_param: MGparam, tail_owner, tail_local_index,
+                 tail_counts, rows_fine, cycleType: str, nl_total: int, nrhs: int = 1):
         self.comm = comm
-        self.be = backend
-        self.nrhs = int(nrhs)
-        self.cycleType = param.cycleType
+        self.be = be = backend
+        self.nrhs = k = int(nrhs)
+        self.cycleType = cycleType
         rank, size = comm.rank, comm.size
-        nl = len(param.As)
-        if nl < 2:
-            raise ValueError("a distributed hierarchy needs at least two levels")
-        # which levels are sharded: the finest one always; then while the level is large enough
-        parts = [Partition(fine_owner, size)]
-        a = 1
-        while a < nl - 1 and param.As[a].shape[0] > replicate_below:
-            try:
-                parts.append(parts[-1].coarsen(param.Ps[a - 1]))
-            except ValueError:
-                break
-            a += 1
-        # the partition of the first replicated level is still needed (rows of R, gather of bc)
-        self.first_tail = a
-        self.nl = nl
-        part_tail = parts[-1].coarsen(param.Ps[a - 1])
-        self.parts = parts
-        self.part_tail = part_tail
+        self.first_tail = len(local_levels)
+        self.nl = int(nl_total)
         self.levels: List[_Level] = []
-        be = backend
-        k = self.nrhs
-        for l in range(a):
+        for ld in local_levels:
             L = _Level()
-            part = parts[l]
-            cpart = parts[l + 1] if l + 1 < a else part_tail
-            L.n_own = int(part.counts[rank])
-            L.n_global = int(param.As[l].shape[0])
-            A_loc, L.planA = localize(param.As[l], part, part, rank)
-            R_loc, L.planR = localize(param.Rs[l], cpart, part, rank)
-            if l + 1 < a:
-                P_loc, L.planP = localize(param.Ps[l], part, cpart, rank)       # gathers the sharded x_{l+1}
-            else:
-                P_loc, L.planP = localize(param.Ps[l], part, None, rank)        # gathers the replicated tail solution
-            L.A, L.R, L.P = be.operator(A_loc), be.operator(R_loc), be.operator(P_loc)
-            L.nnzA, L.nnzR, L.nnzP = A_loc.nnz, R_loc.nnz, P_loc.nnz
-            L.d = be.from_numpy(np.asarray(param.relaxPrecs[l])[part.rows[rank]])
-            L.npre = max(1, int(param.relaxPre(l + 1)))          # relax() always updates once (MGcycle.jl:127-134)
-            L.npost = max(1, int(param.relaxPost(l + 1)))
+            L.n_own = int(ld["n_own"])
+            L.planA, L.planR, L.planP = ld["planA"], ld["planR"], ld["planP"]
+            L.A, L.R, L.P = be.operator(ld["A"]), be.operator(ld["R"]), be.operator(ld["P"])
+            L.nnzA, L.nnzR, L.nnzP = ld["A"].nnz, ld["R"].nnz, ld["P"].nnz
+            L.d = be.from_numpy(np.asarray(ld["d"], dtype=np.float64))
+            L.npre = max(1, int(ld["npre"]))            # relax() always updates once (MGcycle.jl:127-134)
+            L.npost = max(1, int(ld["npost"]))
             self.levels.append(L)
         # vectors: capacity = owned + the largest halo any operator appends to that vector
         for l, L in enumerate(self.levels):
@@ -381,18 +362,53 @@ class DistributedHierarchy:
                     flag += float(ns + plan.n_halo)
                     plan.active = size > 1 and float(comm.all_reduce_sum(flag).item()) > 0.0
         # replicated tail
-        nt = int(param.As[a].shape[0])
+        nt = int(tail_param.As[0].shape[0])
         self.n_tail = nt
-        self.tail = be.tail(_sub_hierarchy(param, a), k)
-        self.own_tail = int(part_tail.counts[rank])
-        self.max_tail = int(part_tail.counts.max())
+        self.tail = be.tail(tail_param, k)
+        tail_counts = np.asarray(tail_counts)
+        self.own_tail = int(tail_counts[rank])
+        self.max_tail = int(tail_counts.max())
         self.bc_pad = be.zeros(self.max_tail, k) if k > 1 else be.zeros(self.max_tail)
         self.bc_all = be.zeros(self.max_tail * size, k) if k > 1 else be.zeros(self.max_tail * size)
-        gather_index = part_tail.owner.astype(np.int64) * self.max_tail + part_tail.local_index
+        gather_index = np.asarray(tail_owner, dtype=np.int64) * self.max_tail + np.asarray(tail_local_index, dtype=np.int64)
         self.gather_index = be.index_tensor(gather_index)
         self.b_tail = be.zeros(nt, k) if k > 1 else be.zeros(nt)
         self.x_tail = be.zeros(nt, k) if k > 1 else be.zeros(nt)
-        self.rows_fine = parts[0].rows[rank]
+        self.rows_fine = np.asarray(rows_fine)
+
+    @classmethod
+    def from_global(cls, param: MGparam, comm, backend, fine_owner: np.ndarray, nrhs: int = 1,
+                    replicate_below: int = 300_000):
+        rank, size = comm.rank, comm.size
+        nl = len(param.As)
+        if nl < 2:
+            raise ValueError("a distributed hierarchy needs at least two levels")
+        # which levels are sharded: the finest one always; then while the level is large enough
+        parts = [Partition(fine_owner, size)]
+        a = 1
+        while a < nl - 1 and param.As[a].shape[0] > replicate_below:
+            try:
+                parts.append(parts[-1].coarsen(param.Ps[a - 1]))
+            except ValueError:
+                break
+            a += 1
+        # the partition of the first replicated level is still needed (rows of R, gather of bc)
+        part_tail = parts[-1].coarsen(param.Ps[a - 1])
+        local_levels = []
+        for l in range(a):
+            part = parts[l]
+            cpart = parts[l + 1] if l + 1 < a else part_tail
+            A_loc, planA = localize(param.As[l], part, part, rank)
+            R_loc, planR = localize(param.Rs[l], cpart, part, rank)
+            # the prolongation gathers the sharded x_{l+1}, or the replicated tail solution (no halo)
+            P_loc, planP = localize(param.Ps[l], part, cpart if l + 1 < a else None, rank)
+            local_levels.append(dict(n_own=int(part.counts[rank]), A=A_loc, planA=planA, R=R_loc, planR=planR,
+                                     P=P_loc, planP=planP, d=np.asarray(param.relaxPrecs[l])[part.rows[rank]],
+                                     npre=param.relaxPre(l + 1), npost=param.relaxPost(l + 1)))
+        H = cls(comm, backend, local_levels, _sub_hierarchy(param, a), part_tail.owner, part_tail.local_index,
+                part_tail.counts, parts[0].rows[rank], param.cycleType, nl, nrhs)
+        H.parts, H.part_tail = parts, part_tail
+        return H
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def scatter_fine(self, v_global: np.ndarray):

@@ -11,7 +11,7 @@ A, mesh = mg.poisson_shifted([cells] * 3)
 p = mg.getMGparam(np.float64, np.int64, lv, 8, 10, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
 mg.MGsetup(A, mesh, p, 1)
 be = dd.HipBackend(0)
-H = dd.DistributedHierarchy(p, dd.SingleComm(), be, dd.box_owner(mesh.n + 1, [1, 1, 1]), 1)
+H = dd.DistributedHierarchy.from_global(p, dd.SingleComm(), be, dd.box_owner(mesh.n + 1, [1, 1, 1]), 1)
 b = H.scatter_fine(mg.seeded_rhs(A)); x = torch.zeros_like(b)
 for i in range(3):
     x.zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()

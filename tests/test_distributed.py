@@ -68,7 +68,7 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q):
             from dist_cpu_backend import CpuCheckerBackend
             be = CpuCheckerBackend()
             comm = dd.TorchComm()
-        H = dd.DistributedHierarchy(p, comm, be, owner, nrhs, replicate_below=200)
+        H = dd.DistributedHierarchy.from_global(p, comm, be, owner, nrhs, replicate_below=200)
         assert len(H.levels) >= 2, "the test must exercise at least two sharded levels"
         b_loc = H.scatter_fine(b)
         x_loc = torch.zeros_like(b_loc)
@@ -177,3 +177,103 @@ def test_gloo_distributed_solve_matches_oracle(built, world, kind, nrhs, cyc):
                                                  (2, "sa", 1, "V")])
 def test_hip_distributed_solve_matches_oracle(built, world, kind, nrhs, cyc):
     _run(world, kind, nrhs, cyc, use_hip=True)
+
+
+# ---- sharded SETUP (structured_setup.py): every rank builds only its part -------------------------------
+def _worker_structured(rank, world, port, cells, levels, cyc, nrhs, use_hip, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import multigrid_jl_amd as mg
+        from multigrid_jl_amd import distributed as dd, structured_setup as ss
+        if use_hip:
+            be, comm = dd.HipBackend(0), dd.TorchComm(stage_through_host=True)
+        else:
+            from dist_cpu_backend import CpuCheckerBackend
+            be, comm = CpuCheckerBackend(), dd.TorchComm()
+        doms = dd.default_domains(world, len(cells))
+        p = mg.getMGparam(np.float64, np.int64, levels, 8, 5, 1e-10, "Jac", 0.8, 2, 1, cyc, "NoMUMPS", 0.5, 0.0)
+        H, info = ss.structured_gmg(cells, doms, comm, be, p, ss.poisson_operator(cells), nrhs=nrhs, replicate_below=1000)
+        # reference: the global hierarchy cut by from_global on the same partition
+        A, mesh = mg.poisson_shifted(cells)
+        pg = mg.getMGparam(np.float64, np.int64, levels, 8, 5, 1e-10, "Jac", 0.8, 2, 1, cyc, "NoMUMPS", 0.5, 0.0)
+        mg.MGsetup(A, mesh, pg, nrhs)
+        owner = dd.box_owner(mesh.n + 1, doms)
+        if not use_hip:
+            G = dd.DistributedHierarchy.from_global(pg, comm, be, owner, nrhs, replicate_below=1000)
+            assert len(G.levels) == len(H.levels) == info["sharded_levels"] >= 2
+            assert np.array_equal(G.rows_fine, H.rows_fine)
+            for Lg, Lh in zip(G.levels, H.levels):
+                for og, oh in ((Lg.A, Lh.A), (Lg.R, Lh.R), (Lg.P, Lh.P)):
+                    assert og.shape == oh.shape and og.nnz == oh.nnz
+                    assert np.array_equal(og.indptr, oh.indptr) and np.array_equal(og.indices, oh.indices)
+                    assert np.allclose(og.data, oh.data, rtol=1e-13, atol=0)
+                assert np.allclose(Lg.d.numpy(), Lh.d.numpy(), rtol=1e-13)
+                for pg_, ph_ in ((Lg.planA, Lh.planA), (Lg.planR, Lh.planR), (Lg.planP, Lh.planP)):
+                    if pg_ is None:
+                        assert ph_ is None
+                        continue
+                    assert pg_.send_splits == ph_.send_splits and pg_.recv_splits == ph_.recv_splits
+                    assert np.array_equal(pg_.send_idx, ph_.send_idx)
+        # the right-hand side built locally equals the global seeded one
+        b_glob = mg.seeded_rhs(A, nrhs)
+        b_own, ss2 = ss.local_rhs(info, nrhs)
+        tot = torch.tensor([ss2], dtype=torch.float64)
+        dist.all_reduce(tot)
+        b_own = b_own / float(tot.item()) ** 0.5
+        assert np.allclose(b_own, b_glob[H.rows_fine], rtol=1e-12, atol=1e-15)
+        b_loc = be.from_numpy(b_own)
+        x_loc = torch.zeros_like(b_loc)
+        it, resvec = H.solve(b_loc, x_loc, 1e-10, 5)
+        be.synchronize()
+        out = [None] * world
+        dist.all_gather_object(out, (H.rows_fine, x_loc.cpu().numpy()))
+        if rank == 0:
+            x = np.zeros_like(b_glob)
+            for rows, xl in out:
+                x[rows] = xl
+            q.put(("ok", it, resvec, x))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+def _run_structured(world, cells, levels, cyc, nrhs, use_hip=False):
+    from oracle import mg_oracle as orc
+    import multigrid_jl_amd as mg
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_structured, args=(r, world, port, cells, levels, cyc, nrhs, use_hip, q))
+             for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    _, it, resvec, x = res
+    A, mesh = mg.poisson_shifted(cells)
+    p = mg.getMGparam(np.float64, np.int64, levels, 8, 5, 1e-10, "Jac", 0.8, 2, 1, cyc, "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p, nrhs)
+    b = mg.seeded_rhs(A, nrhs)
+    xo = np.zeros_like(b)
+    hist = {}
+    orc.solveMG(p, b, xo, False, hist)
+    assert np.abs(resvec - hist["resvec"]).max() / hist["resvec"][0] < 1e-10
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+
+
+@pytest.mark.parametrize("world,cells,levels,cyc,nrhs", [(2, [32, 32, 32], 4, "V", 1), (4, [32, 32, 32], 4, "W", 2),
+                                                        (2, [128, 64], 4, "V", 1), (8, [32, 32, 32], 4, "V", 1)])
+def test_structured_setup_equals_global(built, world, cells, levels, cyc, nrhs):
+    _run_structured(world, cells, levels, cyc, nrhs)
+
+
+@pytest.mark.gpu
+def test_structured_setup_hip(built):
+    _run_structured(2, [32, 32, 32], 4, "V", 1, use_hip=True)
