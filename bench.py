@@ -279,7 +279,7 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
     red_dev = torch.device("cpu") if share else dev
     tot = torch.tensor([ssq], device=red_dev, dtype=torch.float64)
     dist.all_reduce(tot)
-    b = be.from_numpy(b_own / float(tot.item()) ** 0.5)
+    b = be.from_numpy(H.order_fine(b_own) / float(tot.item()) ** 0.5)
     x = torch.zeros_like(b)
     log(f"[rank {rank}] global {gcells} cells over boxes {domains}: own {H.levels[0].n_own} of {n} rows, "
         f"{len(H.levels)} sharded levels + replicated tail of {H.n_tail} rows; halo A1 {H.levels[0].planA.n_halo}; "

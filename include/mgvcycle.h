@@ -165,6 +165,12 @@ int mg_op_destroy(mg_operator* op);
 int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x_dev,
                          double beta, double* y_dev, const double* b_dev, const double* d_dev,
                          long long nrhs, void* stream);
+/* The operator holds the rows [row_offset, row_offset + n_rows) of the level (interior / boundary split of
+ * the overlapped halo exchange): y, b, d and the smoother's own-x term are read/written at that offset of the
+ * full-level vectors passed here; x is still the whole gathered vector. */
+int mg_op_apply_rows_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x_dev,
+                              double beta, double* y_dev, const double* b_dev, const double* d_dev,
+                              long long nrhs, long long row_offset, void* stream);
 int mg_op_info(mg_operator* op, long long* n_rows, long long* n_cols, long long* nnz,
                double* device_bytes);
 /* x = d.*b ; xout = x + d.*r ; out[0] = sum x^2 (workspace >= 1024 doubles) - asynchronous. */

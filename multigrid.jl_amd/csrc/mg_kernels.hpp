@@ -63,6 +63,7 @@ struct CsrDev {
 
 struct VecArgs {
   const double* x;  // gathered vector           [n_cols][nrhs]
+  const double* xs; // SMOOTH: the row's own x   [n_rows][nrhs] (== x unless the operator holds a row sub-range)
   double* y;        // output                    [n_rows][nrhs]
   const double* b;  // RESID / SMOOTH            [n_rows][nrhs]
   const double* d;  // SMOOTH: relaxPrec          [n_rows]
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
       double pb = 0.0, pd = 0.0, px = 0.0;
       if (MODE == AXPBY) pb = (v.beta != 0.0) ? v.beta * v.y[r0] : 0.0;
       else pb = v.b[r0];
-      if (MODE == SMOOTH) { pd = v.d[r0]; px = v.x[r0]; }
+      if (MODE == SMOOTH) { pd = v.d[r0]; px = v.xs[r0]; }
       v.y[r0] = epilogue<MODE>(v, r0, s, pb, pd, px);
     }
     return;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
     const int row = r0 + lrow;
     if (MODE == AXPBY) { if (v.beta != 0.0) pb = v.beta * v.y[row]; }
     else pb = v.b[row];
-    if (MODE == SMOOTH) { pd = v.d[row]; px = v.x[row]; }
+    if (MODE == SMOOTH) { pd = v.d[row]; px = v.xs[row]; }
   }
   // ---- gather x and stage the products --------------------------------------------------------
 #pragma unroll
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int 
         double pb = 0.0, pd = 0.0, px = 0.0;
         if (MODE == AXPBY) { if (v.beta != 0.0) pb = v.beta * v.y[o]; }
         else pb = v.b[o];
-        if (MODE == SMOOTH) { pd = v.d[row]; px = v.x[o]; }
+        if (MODE == SMOOTH) { pd = v.d[row]; px = v.xs[o]; }
         v.y[o] = epilogue<MODE>(v, row, acc, pb, pd, px);
       }
     }

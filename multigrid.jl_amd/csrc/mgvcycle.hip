@@ -281,6 +281,7 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
              const double* x, double* out) {
   mgk::VecArgs v{};
   v.x = x;
+  v.xs = x;
   v.y = out;
   v.b = b;
   v.d = d;
@@ -1128,14 +1129,21 @@ int mg_op_destroy(mg_operator* op) {
 
 int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
                          double* y, const double* b, const double* d, long long nrhs, void* stream) {
+  return mg_op_apply_rows_dev_FP64(op, kernel, alpha, x, beta, y, b, d, nrhs, 0, stream);
+}
+
+int mg_op_apply_rows_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
+                              double* y, const double* b, const double* d, long long nrhs,
+                              long long row_offset, void* stream) {
   if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
-  if (!x || !y || nrhs < 1) return fail(MG_ERR_INVALID, "null vector or nrhs < 1");
+  if (!x || !y || nrhs < 1 || row_offset < 0) return fail(MG_ERR_INVALID, "null vector, nrhs < 1 or negative row offset");
   if (kernel == MG_K_SMOOTH && y == x) return fail(MG_ERR_INVALID, "the Jacobi update must not alias x");
   mgk::VecArgs v{};
   v.x = x;
-  v.y = y;
-  v.b = b;
-  v.d = d;
+  v.xs = x + row_offset * nrhs;
+  v.y = y + row_offset * nrhs;
+  v.b = b ? b + row_offset * nrhs : nullptr;
+  v.d = d ? d + row_offset : nullptr;
   v.alpha = alpha;
   v.beta = beta;
   v.nrhs = (int)nrhs;

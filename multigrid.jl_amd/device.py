@@ -56,6 +56,7 @@ SIGNATURES = {
     "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
     "mg_op_destroy": (C.c_int, [_vp]),
     "mg_op_apply_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _vp]),
+    "mg_op_apply_rows_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _ll, _vp]),
     "mg_op_info": (C.c_int, [_vp, _lp, _lp, _lp, _dp]),
     "mg_vec_dscale_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _vp]),
     "mg_vec_xpdr_dev_FP64": (C.c_int, [_vp, _vp, _vp, _vp, _ll, _ll, _vp]),
@@ -331,11 +332,12 @@ class DeviceOperator:
                                                           _i64(rowval), _f64(nzval), C.byref(self.handle)),
                "mg_op_create")
 
-    def apply(self, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, stream=0):
-        _check(self.lib, self.lib.mg_op_apply_dev_FP64(self.handle, int(kernel), float(alpha), _ptr(x), float(beta),
-                                                       _ptr(y), _ptr(b) if b is not None else None,
-                                                       _ptr(d) if d is not None else None, int(nrhs), _vp(stream)),
-               "mg_op_apply_dev")
+    def apply(self, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, stream=0, row_offset=0):
+        _check(self.lib, self.lib.mg_op_apply_rows_dev_FP64(self.handle, int(kernel), float(alpha), _ptr(x), float(beta),
+                                                            _ptr(y), _ptr(b) if b is not None else None,
+                                                            _ptr(d) if d is not None else None, int(nrhs),
+                                                            int(row_offset), _vp(stream)),
+               "mg_op_apply_rows_dev")
 
     def close(self):
         if self.handle:

@@ -186,6 +186,19 @@ class TorchComm:
         else:
             self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
+    def all_to_all_start(self, out, inp, out_splits, in_splits):
+        """Begin the exchange and return a handle for ``finish`` (None if it already completed): with RCCL the
+        collective runs on torch's communication stream while the caller enqueues the interior kernel."""
+        if self.stage or not out.is_cuda:
+            self.all_to_all(out, inp, out_splits, in_splits)
+            return None
+        return self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
+
+    @staticmethod
+    def finish(handle):
+        if handle is not None:
+            handle.wait()            # the CURRENT stream waits for the collective; the host does not block
+
     def all_reduce_sum(self, t):
         if self.stage and t.is_cuda:
             c = t.cpu()
@@ -210,6 +223,13 @@ class SingleComm:
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         out.copy_(inp)
+
+    def all_to_all_start(self, out, inp, out_splits, in_splits):
+        return None
+
+    @staticmethod
+    def finish(handle):
+        pass
 
     def all_reduce_sum(self, t):
         return t
@@ -252,8 +272,8 @@ class HipBackend:
     def operator(self, M):
         return D.DeviceOperator(M, self.device_id)
 
-    def apply(self, op, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1):
-        op.apply(kernel, x, y, b, d, alpha, beta, nrhs, self.stream())
+    def apply(self, op, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, row_offset=0):
+        op.apply(kernel, x, y, b, d, alpha, beta, nrhs, self.stream(), row_offset)
 
     def dscale(self, d, b, x, n, nrhs):
         D.vec_dscale(d, b, x, n, nrhs, self.stream())
@@ -310,6 +330,53 @@ def _sub_hierarchy(param: MGparam, start: int) -> MGparam:
     return sub
 
 
+def _reorder_for_overlap(local_levels, rows_fine):
+    """Renumber every sharded level's owned rows as [interior | boundary], interior = rows of A whose columns
+    are all owned.  The interior part of an SpMV with A can then run while the halo is in flight, the boundary
+    part after it arrived.  A pure local permutation: applied consistently to the rows/owned columns of every
+    local operator, to d, to the send lists and to the global ids of the owned fine rows."""
+    perms, invs, nints = [], [], []
+    for ld in local_levels:
+        A = ld["A"]
+        n = ld["n_own"]
+        touches_halo = np.zeros(n, dtype=bool)
+        rows_of = np.repeat(np.arange(n), np.diff(A.indptr))
+        touches_halo[rows_of[A.indices >= n]] = True
+        perm = np.concatenate([np.nonzero(~touches_halo)[0], np.nonzero(touches_halo)[0]])
+        inv = np.empty(n, dtype=np.int64)
+        inv[perm] = np.arange(n)
+        perms.append(perm)
+        invs.append(inv)
+        nints.append(int((~touches_halo).sum()))
+
+    def remap_cols(M, inv):
+        M = M.tocsr(copy=True)
+        own = M.indices < inv.size
+        M.indices = np.where(own, inv[np.minimum(M.indices, inv.size - 1)], M.indices).astype(M.indices.dtype)
+        M.sort_indices()
+        return M
+
+    a = len(local_levels)
+    for l, ld in enumerate(local_levels):
+        perm, inv = perms[l], invs[l]
+        ld["A"] = remap_cols(ld["A"][perm, :], inv)
+        ld["d"] = np.asarray(ld["d"])[perm]
+        ld["planA"].send_idx = inv[ld["planA"].send_idx]
+        ld["planR"].send_idx = inv[ld["planR"].send_idx]
+        R = ld["R"] if l + 1 >= a else ld["R"][perms[l + 1], :]          # rows live on level l+1
+        ld["R"] = remap_cols(R, inv)
+        P = ld["P"][perm, :]
+        if l + 1 < a:
+            P = remap_cols(P, invs[l + 1])
+            ld["planP"].send_idx = invs[l + 1][ld["planP"].send_idx]
+        else:
+            P = P.tocsr()
+            P.sort_indices()
+        ld["P"] = P
+        ld["n_int"] = nints[l]
+    return np.asarray(rows_fine)[perms[0]], perms[0]
+
+
 class DistributedHierarchy:
     """The multi-GPU counterpart of ``DeviceHierarchy``: this rank's rows of the sharded levels plus the
     replicated coarse tail.  Two builders:
@@ -331,11 +398,17 @@ class DistributedHierarchy:
         self.first_tail = len(local_levels)
         self.nl = int(nl_total)
         self.levels: List[_Level] = []
+        rows_fine, self.fine_perm = _reorder_for_overlap(local_levels, rows_fine)
         for ld in local_levels:
             L = _Level()
             L.n_own = int(ld["n_own"])
+            L.n_int = int(ld["n_int"])
             L.planA, L.planR, L.planP = ld["planA"], ld["planR"], ld["planP"]
-            L.A, L.R, L.P = be.operator(ld["A"]), be.operator(ld["R"]), be.operator(ld["P"])
+            # A is held as two operators: interior rows (no halo columns) and boundary rows
+            A = ld["A"]
+            L.A_int = be.operator(A[: L.n_int, :]) if L.n_int > 0 else None
+            L.A_bnd = be.operator(A[L.n_int:, :]) if L.n_int < L.n_own else None
+            L.R, L.P = be.operator(ld["R"]), be.operator(ld["P"])
             L.nnzA, L.nnzR, L.nnzP = ld["A"].nnz, ld["R"].nnz, ld["P"].nnz
             L.d = be.from_numpy(np.asarray(ld["d"], dtype=np.float64))
             L.npre = max(1, int(ld["npre"]))            # relax() always updates once (MGcycle.jl:127-134)
@@ -415,16 +488,37 @@ class DistributedHierarchy:
         """This rank's rows of a global fine-level vector/block (host) as a device tensor."""
         return self.be.from_numpy(np.asarray(v_global)[self.rows_fine])
 
-    def exchange(self, plan: HaloPlan, buf):
-        """Fill the halo tail buf[n_own : n_own+n_halo] from the owners (one all_to_all_single)."""
+    def order_fine(self, v_own):
+        """A vector given on this rank's fine rows in ascending-global-id order -> this hierarchy's local
+        order ([interior | boundary], the order of ``rows_fine``)."""
+        return np.asarray(v_own)[self.fine_perm]
+
+    def exchange_start(self, plan: HaloPlan, buf):
+        """Pack the values the peers need and start filling the halo tail buf[n_own : n_own+n_halo]
+        (one all_to_all_single); returns a handle for ``comm.finish``."""
         if plan is None or not plan.active:
-            return
+            return None
         ns = int(plan.send_idx.size)
         send = plan.send_buf[:ns]
         if ns:
             self.be.index_select(buf, plan.send_idx_t, send)
         recv = buf[plan.n_own_src: plan.n_own_src + plan.n_halo]
-        self.comm.all_to_all(recv, send, plan.recv_splits, plan.send_splits)
+        return self.comm.all_to_all_start(recv, send, plan.recv_splits, plan.send_splits)
+
+    def exchange(self, plan: HaloPlan, buf):
+        self.comm.finish(self.exchange_start(plan, buf))
+
+    def apply_A(self, L, kernel, x, out, b):
+        """out = b - A x  /  out = x + d.*(b - A x) on this rank's rows with the halo exchange OVERLAPPED: the
+        interior rows (no halo column) are computed while the all_to_all is in flight on the communication
+        stream, the boundary rows once it has landed."""
+        be, k = self.be, self.nrhs
+        h = self.exchange_start(L.planA, x)
+        if L.A_int is not None:
+            be.apply(L.A_int, kernel, x, out, b=b, d=L.d, nrhs=k, row_offset=0)
+        self.comm.finish(h)
+        if L.A_bnd is not None:
+            be.apply(L.A_bnd, kernel, x, out, b=b, d=L.d, nrhs=k, row_offset=L.n_int)
 
     def norm(self, v, n_own):
         """Global Frobenius norm of a sharded vector (SolveFuncs.jl:15,20,30): local sum of squares + all-reduce."""
@@ -446,11 +540,9 @@ class DistributedHierarchy:
             cur, alt = alt, cur
             npre -= 1
         for _ in range(npre):
-            self.exchange(L.planA, cur)
-            be.apply(L.A, D.MG_K_SMOOTH, cur, alt, b=b, d=L.d, nrhs=k)
+            self.apply_A(L, D.MG_K_SMOOTH, cur, alt, b)
             cur, alt = alt, cur
-        self.exchange(L.planA, cur)
-        be.apply(L.A, D.MG_K_RESIDUAL, cur, L.r, b=b, nrhs=k)
+        self.apply_A(L, D.MG_K_RESIDUAL, cur, L.r, b)
         self.exchange(L.planR, L.r)
         if l + 1 < len(self.levels):
             C = self.levels[l + 1]
@@ -471,8 +563,7 @@ class DistributedHierarchy:
                 self.tail.cycle(self.b_tail, self.x_tail, False, "W" if ctype == "W" else "V")
             be.apply(L.P, D.MG_K_PROLONG, self.x_tail, cur, alpha=1.0, beta=1.0, nrhs=k)
         for _ in range(npost):
-            self.exchange(L.planA, cur)
-            be.apply(L.A, D.MG_K_SMOOTH, cur, alt, b=b, d=L.d, nrhs=k)
+            self.apply_A(L, D.MG_K_SMOOTH, cur, alt, b)
             cur, alt = alt, cur
         return cur
 
@@ -496,8 +587,7 @@ class DistributedHierarchy:
         if x_zero:
             res0 = self.norm(b_loc, L.n_own)
         else:
-            self.exchange(L.planA, cur)
-            be.apply(L.A, D.MG_K_RESIDUAL, cur, L.r, b=b_loc, nrhs=k)
+            self.apply_A(L, D.MG_K_RESIDUAL, cur, L.r, b_loc)
             res0 = self.norm(L.r, L.n_own)
         resvec = [res0]
         it = 0
@@ -506,8 +596,7 @@ class DistributedHierarchy:
             if out is not cur:
                 cur, alt = alt, cur
             x_zero = False
-            self.exchange(L.planA, cur)
-            be.apply(L.A, D.MG_K_RESIDUAL, cur, L.r, b=b_loc, nrhs=k)
+            self.apply_A(L, D.MG_K_RESIDUAL, cur, L.r, b_loc)
             res = self.norm(L.r, L.n_own)
             it += 1
             resvec.append(res)

@@ -27,19 +27,20 @@ class CpuCheckerBackend:
     def operator(self, M):
         return M.tocsr()
 
-    def apply(self, op, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1):
+    def apply(self, op, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, row_offset=0):
         nr, nc = op.shape
         xn = x.numpy()[:nc]
         Ax = op @ xn
         yn = y.numpy()
+        o = row_offset
         if kernel in (D.MG_K_SPMV, D.MG_K_RESTRICT, D.MG_K_PROLONG):
-            yn[:nr] = alpha * Ax + (beta * yn[:nr] if beta != 0.0 else 0.0)
+            yn[o:o + nr] = alpha * Ax + (beta * yn[o:o + nr] if beta != 0.0 else 0.0)
         elif kernel == D.MG_K_RESIDUAL:
-            yn[:nr] = b.numpy()[:nr] - Ax
+            yn[o:o + nr] = b.numpy()[o:o + nr] - Ax
         elif kernel == D.MG_K_SMOOTH:
-            dn = d.numpy()
+            dn = d.numpy()[o:o + nr]
             dd = dn if xn.ndim == 1 else dn[:, None]
-            yn[:nr] = xn[:nr] + dd * (b.numpy()[:nr] - Ax)
+            yn[o:o + nr] = x.numpy()[o:o + nr] + dd * (b.numpy()[o:o + nr] - Ax)
         else:
             raise ValueError(kernel)
 

@@ -205,7 +205,8 @@ def _worker_structured(rank, world, port, cells, levels, cyc, nrhs, use_hip, q):
             assert len(G.levels) == len(H.levels) == info["sharded_levels"] >= 2
             assert np.array_equal(G.rows_fine, H.rows_fine)
             for Lg, Lh in zip(G.levels, H.levels):
-                for og, oh in ((Lg.A, Lh.A), (Lg.R, Lh.R), (Lg.P, Lh.P)):
+                assert Lg.n_int == Lh.n_int
+                for og, oh in ((Lg.A_int, Lh.A_int), (Lg.A_bnd, Lh.A_bnd), (Lg.R, Lh.R), (Lg.P, Lh.P)):
                     assert og.shape == oh.shape and og.nnz == oh.nnz
                     assert np.array_equal(og.indptr, oh.indptr) and np.array_equal(og.indices, oh.indices)
                     assert np.allclose(og.data, oh.data, rtol=1e-13, atol=0)
@@ -221,7 +222,7 @@ def _worker_structured(rank, world, port, cells, levels, cyc, nrhs, use_hip, q):
         b_own, ss2 = ss.local_rhs(info, nrhs)
         tot = torch.tensor([ss2], dtype=torch.float64)
         dist.all_reduce(tot)
-        b_own = b_own / float(tot.item()) ** 0.5
+        b_own = H.order_fine(b_own) / float(tot.item()) ** 0.5
         assert np.allclose(b_own, b_glob[H.rows_fine], rtol=1e-12, atol=1e-15)
         b_loc = be.from_numpy(b_own)
         x_loc = torch.zeros_like(b_loc)
