@@ -89,6 +89,8 @@ def main():
     levels = args.levels or levels_for(cells)
     K, W = args.steps, args.warmup
 
+    if world > 1:
+        os.environ.setdefault("MG_HOST_THREADS", str(max(1, (os.cpu_count() or 8) // world)))
     if world > 1 and args.scaling == "weak":
         if args.workload != "c2":
             raise SystemExit("multi-GPU weak scaling is defined for the c2/c4 Poisson workload")

@@ -54,6 +54,8 @@ def spgemm(A, B, nthreads: int = 0):
     n = A.shape[0]
     Cp = np.zeros(n + 1, dtype=np.int64)
     L = lib()
+    if nthreads <= 0:      # torchrun exports OMP_NUM_THREADS=1 to every rank: MG_HOST_THREADS overrides it here
+        nthreads = int(os.environ.get("MG_HOST_THREADS", "0") or 0)
     L.mg_spgemm_count_INT64(n, B.shape[1], _p64(Ap), _p64(Ai), _p64(Bp), _p64(Bi), _p64(Cp), int(nthreads))
     np.cumsum(Cp, out=Cp)
     nnz = int(Cp[-1])
