@@ -116,6 +116,15 @@ int mg_cycle_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long
 int mg_solve_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
                   double tol, long long maxIter, long long* iters, double* resvec);
 
+/* solveCG_MG (SolveFuncs.jl:104-116): KrylovMethods.cg (v0.6.0, external) preconditioned with one cycle
+ * from x = 0 (getMultigridPreconditioner, SolveFuncs.jl:59), vectors resident on device across iterations.
+ * nrhs = 1 (blockCG is not on the device path).  resvec (length maxIter) receives ||r||/||b|| per iteration;
+ * flag: 0 converged, -1 maxIter reached, -2 breakdown (alpha = Inf or < 0), -9 b = 0. */
+int mg_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol,
+                long long maxIter, long long* iters, long long* flag, double* resvec);
+int mg_pcg_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n, double tol,
+                    long long maxIter, long long* iters, long long* flag, double* resvec);
+
 /* target = beta*target + alpha*Op*x on one level (SpMatMul.jl:4-13); column-major host blocks. */
 int mg_spmv_FP64(mg_hierarchy* h, long long level, long long which, double alpha, const double* x,
                  double beta, double* y, long long nrhs);

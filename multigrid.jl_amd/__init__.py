@@ -10,7 +10,7 @@ from .mgsetup import (MGsetup, getRelaxPrec, getSPAIprec, adjustMemoryForNumRHS,
                       getMultilevelOperatorConstructor, galerkin)
 from .transfer_operators import getFWInterp, get1DFWInterp
 from .sa_amg import (SA_AMGsetup, getAggregation, getStrengthMatrix, neighborhoodAggregationNew, aggrArray2P)
-from .solve_funcs import solveMG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
+from .solve_funcs import solveMG, solveCG_MG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
 from .operators import (getRegularMesh, getNodalGradientMatrix, getNodalLaplacianMatrix,
                         getNodalDivSigGradMatrix, poisson_shifted, anisotropic_divsiggrad, seeded_rhs)
 from . import device

@@ -368,6 +368,41 @@ __global__ __launch_bounds__(BLK) void sum_final(const double* __restrict__ part
   if (threadIdx.x == 0) out[0] = s;
 }
 
+// dot(x, y), first stage (second stage: sum_final)
+__global__ __launch_bounds__(BLK) void dot_partial(const double* __restrict__ x, const double* __restrict__ y,
+                                                   long long n, double* __restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const long long stride = (long long)gridDim.x * BLK;
+  double acc = 0.0;
+  const long long n2 = n >> 1;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n2; i += stride) {
+    const double2 a = reinterpret_cast<const double2*>(x)[i];
+    const double2 b = reinterpret_cast<const double2*>(y)[i];
+    acc += a.x * b.x + a.y * b.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * y[n - 1];
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// CG updates: x += alpha*p ; r -= alpha*Ap   (KrylovMethods cg: two BLAS.axpy!)
+__global__ __launch_bounds__(BLK) void cg_update_xr(double alpha, const double* __restrict__ p,
+                                                    const double* __restrict__ Ap, double* __restrict__ x,
+                                                    double* __restrict__ r, long long n) {
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+    x[i] += alpha * p[i];
+    r[i] -= alpha * Ap[i];
+  }
+}
+
+// p = z + beta*p   (scal! + axpy!)
+__global__ __launch_bounds__(BLK) void cg_update_p(double beta, const double* __restrict__ z,
+                                                   double* __restrict__ p, long long n) {
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) p[i] = beta * p[i] + z[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Coarsest solve x = Ainv * b with the explicit inverse (row-major n x n), MGcycle.jl:177.
 // One wavefront per (row, rhs column): coalesced sweep of the row of Ainv, shuffle reduction.

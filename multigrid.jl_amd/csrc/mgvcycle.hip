@@ -150,6 +150,8 @@ struct mg_hierarchy {
   int nred_blocks = 1024;
   // staging for the host-pointer API
   DevBuf<double> stage_b, stage_x, stage_t;
+  // Krylov work vectors (allocated on the first mg_pcg call)
+  DevBuf<double> kr, kz, kp, kAp;
   // fine-level operands of the last cycle/solve (used as inputs by mg_time_op_dev_FP64)
   const double* last_b = nullptr;
   double* last_x = nullptr;
@@ -469,6 +471,78 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
   return MG_OK;
 }
 
+// dot(x,y) on the host; synchronises the stream
+int dot_sync(mg_hierarchy* h, const double* x, const double* y, long long len, double* out) {
+  const int nb = (int)std::min<long long>(h->nred_blocks, std::max<long long>(1, (len / 2 + mgk::BLK - 1) / mgk::BLK));
+  hipLaunchKernelGGL(mgk::dot_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, x, y, len, h->partial.p);
+  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb, h->scalar.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(spin_sync(h->stream));
+  *out = *h->h_scalar;
+  return MG_OK;
+}
+
+// Preconditioned CG with one multigrid cycle (x = 0 on entry) as M: solveCG_MG (SolveFuncs.jl:104-116) ->
+// KrylovMethods.cg (v0.6.0, un-vendored: Manifest.toml:35-41), restated from its published algorithm:
+//   r = b - A x0 ; z = M r ; p = z ; nr0 = ||b||
+//   loop: Ap = A p ; gamma = r.z ; alpha = gamma / p.Ap ; (alpha == Inf || alpha < 0 -> flag -2)
+//         x += alpha p ; r -= alpha Ap ; resvec = ||r||/nr0 ; (<= tol -> flag 0)
+//         z = M r ; beta = z.r / gamma ; p = z + beta p
+int pcg_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long maxIter, long long* iters,
+            long long* flag_out, double* resvec) {
+  Level& L = h->lev[0];
+  const long long n = L.n;
+  if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "mg_pcg: block right-hand sides (KrylovMethods.blockCG) are not on the device path yet");
+  if (h->kr.n != (size_t)n) {
+    MG_TRY(h->kr.alloc((size_t)n));
+    MG_TRY(h->kz.alloc((size_t)n));
+    MG_TRY(h->kp.alloc((size_t)n));
+    MG_TRY(h->kAp.alloc((size_t)n));
+  }
+  double* r = h->kr.p;
+  double* z = h->kz.p;
+  double* p = h->kp.p;
+  double* Ap = h->kAp.p;
+  double nr0 = 0.0;
+  MG_TRY(norm_sync(h, b, n, &nr0));
+  long long it = 0, flag = -1;
+  if (nr0 == 0.0) {  // cg returns zeros, flag -9
+    MG_TRY(k_fill(h, x, n, 0.0));
+    HIP_TRY(spin_sync(h->stream));
+    if (iters) *iters = 0;
+    if (flag_out) *flag_out = -9;
+    return MG_OK;
+  }
+  MG_TRY(k_residual(h, 0, L.A, b, x, r));                              // r = b - A(x)
+  MG_TRY(cycle_dev(h, r, z, true));                                    // z = M(r), x = 0 on entry
+  HIP_TRY(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
+  for (long long k = 1; k <= maxIter; ++k) {
+    it = k;
+    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, p, 0.0, Ap));             // Ap = A(p)
+    double gamma = 0.0, pAp = 0.0, rn = 0.0;
+    MG_TRY(dot_sync(h, r, z, n, &gamma));
+    MG_TRY(dot_sync(h, p, Ap, n, &pAp));
+    const double alpha = gamma / pAp;
+    if (std::isinf(alpha) || alpha < 0.0) { flag = -2; break; }
+    hipLaunchKernelGGL(mgk::cg_update_xr, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, alpha, p, Ap, x, r, n);
+    HIP_TRY(hipGetLastError());
+    MG_TRY(norm_sync(h, r, n, &rn));
+    if (resvec) resvec[k - 1] = rn / nr0;
+    if (rn / nr0 <= tol) { flag = 0; break; }
+    MG_TRY(cycle_dev(h, r, z, true));
+    double zr = 0.0;
+    MG_TRY(dot_sync(h, z, r, n, &zr));
+    const double beta = zr / gamma;
+    hipLaunchKernelGGL(mgk::cg_update_p, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, beta, z, p, n);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(spin_sync(h->stream));
+  if (iters) *iters = it;
+  if (flag_out) *flag_out = flag;
+  return MG_OK;
+}
+
 // ---- host <-> device block transfer (column-major host <-> row-major device) --------------------
 int upload_block(mg_hierarchy* h, const double* host, double* dev, long long n, long long nrhs) {
   const size_t bytes = sizeof(double) * (size_t)n * (size_t)nrhs;
@@ -702,6 +776,10 @@ int mg_destroy(mg_hierarchy* h) {
   h->stage_b.release();
   h->stage_x.release();
   h->stage_t.release();
+  h->kr.release();
+  h->kz.release();
+  h->kp.release();
+  h->kAp.release();
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
   if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -933,6 +1011,29 @@ int mg_solve_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long
   MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
   MG_TRY(solve_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, resvec));
   MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_pcg_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol,
+                    long long maxIter, long long* iters, long long* flag, double* resvec) {
+  MG_TRY(check_ready(h, n, 1));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(pcg_dev(h, b, x, tol, maxIter, iters, flag, resvec));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol, long long maxIter,
+                long long* iters, long long* flag, double* resvec) {
+  MG_TRY(check_ready(h, n, 1));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
+  MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
+  MG_TRY(pcg_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec));
+  MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
   prof_collect(h);
   return MG_OK;
 }

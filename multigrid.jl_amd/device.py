@@ -42,6 +42,8 @@ SIGNATURES = {
     "mg_destroy": (C.c_int, [_vp]),
     "mg_cycle_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, _ll]),
     "mg_solve_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
+    "mg_pcg_FP64": (C.c_int, [_vp, _dp, _dp, _ll, C.c_double, _ll, _lp, _lp, _dp]),
+    "mg_pcg_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _lp, _dp]),
     "mg_spmv_FP64": (C.c_int, [_vp, _ll, _ll, C.c_double, _dp, C.c_double, _dp, _ll]),
     "mg_cycle_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
     "mg_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
@@ -236,6 +238,25 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_solve_FP64(self.handle, _f64(b), _f64(x), b.shape[0], nrhs, float(tol),
                                                 int(maxIter), C.byref(iters), _f64(resvec)), "mg_solve")
         return x, int(iters.value), resvec[: iters.value + 1]
+
+    def pcg(self, b, x, tol: float, maxIter: int):
+        """KrylovMethods.cg with the MG cycle as preconditioner; returns (x, flag, iters, resvec)."""
+        b = self._host_block(b)
+        x = self._host_block(x, True)
+        if b.ndim != 1:
+            raise MGDeviceError("mg_pcg: one right-hand side only (blockCG is not on the device path)")
+        iters, flag = C.c_longlong(0), C.c_longlong(0)
+        resvec = np.zeros(max(int(maxIter), 1))
+        _check(self.lib, self.lib.mg_pcg_FP64(self.handle, _f64(b), _f64(x), b.shape[0], float(tol), int(maxIter),
+                                              C.byref(iters), C.byref(flag), _f64(resvec)), "mg_pcg")
+        return x, int(flag.value), int(iters.value), resvec[: iters.value]
+
+    def pcg_dev(self, b, x, tol: float, maxIter: int):
+        iters, flag = C.c_longlong(0), C.c_longlong(0)
+        resvec = np.zeros(max(int(maxIter), 1))
+        _check(self.lib, self.lib.mg_pcg_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, float(tol), int(maxIter),
+                                                  C.byref(iters), C.byref(flag), _f64(resvec)), "mg_pcg_dev")
+        return int(flag.value), int(iters.value), resvec[: iters.value]
 
     def spmv(self, level: int, which: int, alpha: float, x, beta: float, y):
         x = self._host_block(x)

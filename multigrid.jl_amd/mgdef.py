@@ -51,6 +51,7 @@ class MGparam:
     # device side (no reference counterpart): handle of the HIP cycle library + last residual history
     device: Any = None
     resvec: Optional[np.ndarray] = None
+    flag: int = 0
 
 
 def getMGparam(VAL=np.float64, IND=np.int64, levels=3, numCores=8, maxIter=20, relativeTol=1e-6,

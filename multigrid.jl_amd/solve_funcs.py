@@ -63,6 +63,22 @@ def getMultigridPreconditioner(param: MGparam, B: np.ndarray, verbose: bool = Fa
     return MMG
 
 
+def solveCG_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, verbose: bool = False):
+    """``(x, param, iter) = solveCG_MG(AT,param,b,x0,verbose)`` (SolveFuncs.jl:104-116): KrylovMethods.cg with
+    the multigrid cycle as preconditioner, vectors resident on the device across iterations.  ``A`` is accepted
+    for signature parity; the operator applied is ``param.As[1]`` on the device (the reference passes the same
+    matrix twice).  x0 is updated in place.  One right-hand side (blockCG: not on the device path)."""
+    adjustMemoryForNumRHS(param, _ncols(b))
+    dev = to_device(param)
+    x, flag, it, resvec = dev.pcg(b, x0, param.relativeTol, param.maxOuterIter)
+    param.resvec = resvec
+    param.flag = flag
+    if verbose:
+        for k, r in enumerate(resvec):
+            print(f"{k + 1:3d}\t{r:1.2e}")
+    return x, param, it
+
+
 _WHICH = {"A": MG_OP_A, "P": MG_OP_P, "R": MG_OP_R}
 
 

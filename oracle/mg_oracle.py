@@ -422,3 +422,65 @@ def SA_AMGsetup_dense(Adense, levels, relaxType, relaxParam, theta, relaxPre, re
                      relaxPrecs=relaxPrecs, LU=spla.splu(sp.csc_matrix(As[-1])), relaxPre=pre, relaxPost=post,
                      cycleType=cycleType, relativeTol=relativeTol, maxOuterIter=maxOuterIter,
                      dense_As=As, dense_Ps=Ps, dense_Rs=Rs)
+
+
+# --------------------------------------------------------------------------------------------------
+# KrylovMethods.cg (v0.6.0 @master, un-vendored: reference Manifest.toml:35-41) as called by solveCG_MG
+# (SolveFuncs.jl:104-116).  The package source is not under /root/reference; this restates its published
+# algorithm (preconditioned CG with ||r||/||b|| <= tol stopping, flag -2 on alpha = Inf or < 0, -9 on b = 0).
+# --------------------------------------------------------------------------------------------------
+def cg(Afun, b, tol=1e-2, maxIter=100, M=None, x=None):
+    n = b.size
+    if np.linalg.norm(b) == 0:
+        return np.zeros(n), -9, 0.0, 0, np.array([0.0])
+    if x is None:
+        x = np.zeros(n)
+        r = b.copy()
+    else:
+        r = b - Afun(x)
+    z = M(r) if M is not None else r.copy()
+    p = z.copy()
+    nr0 = np.linalg.norm(b)
+    resvec = np.zeros(maxIter)
+    flag = -1
+    last = 0
+    for it in range(1, maxIter + 1):
+        last = it
+        Ap = Afun(p)
+        gamma = np.dot(r, z)
+        alpha = gamma / np.dot(p, Ap)
+        if np.isinf(alpha) or alpha < 0:
+            flag = -2
+            break
+        x += alpha * p
+        r -= alpha * Ap
+        resvec[it - 1] = np.linalg.norm(r) / nr0
+        if resvec[it - 1] <= tol:
+            flag = 0
+            break
+        z = M(r) if M is not None else r.copy()
+        beta = np.dot(z, r) / gamma
+        p = z + beta * p
+    return x, flag, resvec[last - 1], last, resvec[:last]
+
+
+def getMultigridPreconditioner(param, B):
+    """M(b) = (z .= 0; recursiveCycle(param,b,z,1); z)  (SolveFuncs.jl:59)."""
+    nrhs = 1 if B.ndim == 1 else B.shape[1]
+    mem = _Mem(param, nrhs)
+    z = np.zeros_like(B)
+
+    def MMG(b):
+        z[...] = 0.0
+        recursiveCycle(param, b, z, 1, mem)
+        return z.copy()
+
+    return MMG
+
+
+def solveCG_MG(param, b, x0):
+    """solveCG_MG (SolveFuncs.jl:104-116), one right-hand side."""
+    A = param.As[0]
+    x, flag, rn, it, resvec = cg(lambda v: A @ v, b, tol=param.relativeTol, maxIter=param.maxOuterIter,
+                                 M=getMultigridPreconditioner(param, b), x=x0)
+    return x, flag, it, resvec
