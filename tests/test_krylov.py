@@ -41,7 +41,7 @@ def test_reference_threshold_cg_sa(mg, built):
 def test_device_pcg_matches_oracle(mg, built, kind):
     if kind == "sa2d":
         A, p, b = _sa_problem(mg, [50, 50], 1e-8)
-        p.relativeTol, p.maxOuterIter = 1e-9, 12
+        p.relativeTol, p.maxOuterIter = 1e-9, 40
     else:
         A, mesh = mg.poisson_shifted([24, 24, 24])
         p = mg.getMGparam(np.float64, np.int64, 3, 8, 12, 1e-9, "Jac", 0.8, 2, 2, "V", "NoMUMPS", 0.5, 0.0)
