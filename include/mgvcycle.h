@@ -82,7 +82,12 @@ int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long lo
  * an XCD's L2 (block right-hand sides, grids beyond ~400^2 nodes per plane).  n3 = 1 for 2-D. */
 int mg_set_grid_hint(mg_hierarchy* h, long long level, long long n1, long long n2, long long n3);
 
-/* cycleType: 'V', 'W' or 'F' (MGcycle.jl:78-85).  'K' is not on the device path yet. */
+/* relaxType: 0 = pointwise relaxPrecs ("Jac", "SPAI": relax(), MGcycle.jl:122-136);
+ * 1 = "Jac-GMRES": FGMRES_relaxation with npre/npost inner directions, preconditioned by relaxPrecs
+ * (FGMRES.jl:48-126, MGcycle.jl:35-38,48-50,96-98).  Call before mg_finalize. */
+int mg_set_relax_type(mg_hierarchy* h, long long relaxType);
+
+/* cycleType: 'V', 'W', 'F' (MGcycle.jl:78-85) or 'K' (2-step FGMRES recursion, MGcycle.jl:72-76). */
 int mg_set_cycle_type(mg_hierarchy* h, long long cycleType);
 
 /* Coarsest solve, default branch `z = param.LU\b` (MGcycle.jl:177): the host factors the coarsest

@@ -396,6 +396,14 @@ __global__ __launch_bounds__(BLK) void cg_update_xr(double alpha, const double* 
   }
 }
 
+// y = a*x + b*y
+__global__ __launch_bounds__(BLK) void axpby_kernel(double a, const double* __restrict__ x, double b,
+                                                    double* __restrict__ y, long long n) {
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride)
+    y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+}
+
 // p = z + beta*p   (scal! + axpy!)
 __global__ __launch_bounds__(BLK) void cg_update_p(double beta, const double* __restrict__ z,
                                                    double* __restrict__ p, long long n) {

@@ -122,6 +122,10 @@ struct Level {
   long long n = 0;
   // CYCLEmem (MGdef.jl:56-60) plus the Jacobi ping-pong partner of x
   DevBuf<double> b, r, x0, x1;
+  // FGMRESmem (FGMRES.jl:3-8): Z and A*Z bases, `inner` contiguous vectors of n*nrhs each.
+  // relaxZ/relaxAZ: memRelax[level] (Jac-GMRES smoother); kZ/kAZ: memKcycle (K-cycle recursion INTO this level)
+  DevBuf<double> relaxZ, relaxAZ, kZ, kAZ;
+  long long relax_inner = 0;
 };
 
 struct ProfSlot {
@@ -137,6 +141,7 @@ struct mg_hierarchy {
   long long nlevels = 0;
   long long nrhs = 1;
   char cycle = 'V';
+  int relax_type = 0;  // 0: pointwise d (Jac / SPAI, MGcycle.jl:122-136); 1: Jac-GMRES (FGMRES.jl:48-126)
   bool finalized = false;
   std::vector<Level> lev;
   DevBuf<double> Ainv;  // row-major n_c x n_c
@@ -343,6 +348,112 @@ int norm_sync(mg_hierarchy* h, const double* x, long long len, double* out) {
   return MG_OK;
 }
 
+// ---- FGMRES_relaxation (FGMRES.jl:48-126) --------------------------------------------------------------
+// Moore-Penrose inverse of a small symmetric matrix (H = (AZ)'(AZ), k <= 16) by cyclic Jacobi rotations;
+// cut-off as Julia's pinv: rtol = eps * k relative to the largest singular value.
+void pinv_sym(const std::vector<double>& H, int k, std::vector<double>& Pinv) {
+  std::vector<double> A(H), V((size_t)k * k, 0.0);
+  for (int i = 0; i < k; ++i) V[(size_t)i * k + i] = 1.0;
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < k; ++p)
+      for (int q = p + 1; q < k; ++q) off += A[(size_t)p * k + q] * A[(size_t)p * k + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < k; ++p)
+      for (int q = p + 1; q < k; ++q) {
+        const double apq = A[(size_t)p * k + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[(size_t)q * k + q] - A[(size_t)p * k + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int i = 0; i < k; ++i) {
+          const double aip = A[(size_t)i * k + p], aiq = A[(size_t)i * k + q];
+          A[(size_t)i * k + p] = c * aip - sn * aiq;
+          A[(size_t)i * k + q] = sn * aip + c * aiq;
+        }
+        for (int i = 0; i < k; ++i) {
+          const double api = A[(size_t)p * k + i], aqi = A[(size_t)q * k + i];
+          A[(size_t)p * k + i] = c * api - sn * aqi;
+          A[(size_t)q * k + i] = sn * api + c * aqi;
+        }
+        for (int i = 0; i < k; ++i) {
+          const double vip = V[(size_t)i * k + p], viq = V[(size_t)i * k + q];
+          V[(size_t)i * k + p] = c * vip - sn * viq;
+          V[(size_t)i * k + q] = sn * vip + c * viq;
+        }
+      }
+  }
+  double smax = 0.0;
+  for (int i = 0; i < k; ++i) smax = std::max(smax, std::fabs(A[(size_t)i * k + i]));
+  const double tol = 2.220446049250313e-16 * k * smax;
+  Pinv.assign((size_t)k * k, 0.0);
+  for (int e = 0; e < k; ++e) {
+    const double lam = A[(size_t)e * k + e];
+    if (std::fabs(lam) <= tol) continue;
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j) Pinv[(size_t)i * k + j] += V[(size_t)i * k + e] * V[(size_t)j * k + e] / lam;
+  }
+}
+
+int k_axpby(mg_hierarchy* h, double a, const double* x, double b, double* y, long long n) {
+  hipLaunchKernelGGL(mgk::axpby_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, a, x, b, y, n);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+
+int dot_sync(mg_hierarchy* h, const double* x, const double* y, long long len, double* out);
+
+// x0 += Z*t where t minimises ||r0 - A Z t|| over the `inner` directions z_1 = M r0, z_j = M (A z_{j-1}).
+// prec(v, z) must write z = M v (length n*nrhs).  x0_is_zero: x0 is overwritten with the correction
+// (K-cycle: xc = 0 on entry, MGcycle.jl:63-64, and x0 doubles as scratch of the inner cycles).
+template <class Prec>
+int fgmres_relax(mg_hierarchy* h, int lv, const double* r0, double* x0, long long inner, Prec prec,
+                 double TOL, double* Zb, double* AZb, bool x0_is_zero) {
+  Level& L = h->lev[(size_t)lv];
+  const long long len = L.n * h->nrhs;
+  if (inner <= 0) {
+    if (x0_is_zero) MG_TRY(k_fill(h, x0, len, 0.0));
+    return MG_OK;  // w = Z*t with no columns: x0 unchanged (FGMRES.jl:119-121)
+  }
+  const int k = (int)inner;
+  double rnorm0 = 0.0;
+  MG_TRY(norm_sync(h, r0, len, &rnorm0));
+  std::vector<double> H((size_t)k * k, 0.0), xi((size_t)k, 0.0), t((size_t)k, 0.0), Pinv;
+  int used = 0;
+  for (int j = 0; j < k; ++j) {
+    double* z = Zb + (size_t)j * len;
+    double* w = AZb + (size_t)j * len;
+    MG_TRY(prec(j == 0 ? r0 : AZb + (size_t)(j - 1) * len, z));          // z = prec(r0) / prec(w)   (l.83-87)
+    MG_TRY(k_spmv(h, lv, MG_K_SPMV, L.A, 1.0, z, 0.0, w));                // w = A z                  (l.91)
+    used = j + 1;
+    for (int i = 0; i <= j; ++i) {                                       // t = AZ' * w              (l.95)
+      double d = 0.0;
+      MG_TRY(dot_sync(h, AZb + (size_t)i * len, w, len, &d));
+      H[(size_t)i * k + j] = d;
+      H[(size_t)j * k + i] = d;                                          // H[:,j] = t; H[j,:] = t'  (l.99-101)
+    }
+    MG_TRY(dot_sync(h, w, r0, len, &xi[(size_t)j]));                     // xi[j] = dot(w, r0)       (l.97)
+    pinv_sym(H, k, Pinv);                                                // t = pinv(H)*xi           (l.102)
+    double tHt = 0.0, txi = 0.0;
+    for (int a = 0; a < k; ++a) {
+      double s = 0.0;
+      for (int b = 0; b < k; ++b) s += Pinv[(size_t)a * k + b] * xi[(size_t)b];
+      t[(size_t)a] = s;
+    }
+    for (int a = 0; a < k; ++a) {
+      double s = 0.0;
+      for (int b = 0; b < k; ++b) s += H[(size_t)a * k + b] * t[(size_t)b];
+      tHt += t[(size_t)a] * s;
+      txi += t[(size_t)a] * xi[(size_t)a];
+    }
+    const double rn = std::sqrt(std::fabs(tHt - 2.0 * txi + rnorm0 * rnorm0));   // l.104
+    if (rn < TOL) break;                                                          // l.114-117
+  }
+  for (int j = 0; j < used; ++j)                                         // x0 += Z*t                (l.121-123)
+    MG_TRY(k_axpby(h, t[(size_t)j], Zb + (size_t)j * len, (j == 0 && x0_is_zero) ? 0.0 : 1.0, x0, len));
+  return MG_OK;
+}
+
 // ---- the cycle ------------------------------------------------------------------------------------
 // Returns in *result the buffer (xa or xb) that holds the level's x after the cycle.
 // l is 0-based.  xa holds the incoming x when !x_zero; xb is the Jacobi ping-pong partner.
@@ -361,11 +472,23 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   const long long len = L.n * h->nrhs;
   double* cur = xa;
   double* alt = xb;
+  const double gmresTol = 1e-5;  // MGcycle.jl:5
+  auto diag_prec = [&](const double* v, double* z) { return k_dscale(h, l, L.d.p, v, z, L.n); };  // MM (l.36-38)
   // relax() always performs at least one update: `for i=1:numit-1 ... end; x .+= d.*r` (MGcycle.jl:127-134)
   long long npre = std::max<long long>(1, L.npre);
   const long long npost = std::max<long long>(1, L.npost);
   // pre-smoothing (MGcycle.jl:26-31,54).  x == 0: r = b, so the first sweep is x = d.*b.
-  if (x_zero) {
+  if (h->relax_type == 1) {  // Jac-GMRES (MGcycle.jl:48-50): FGMRES on the residual, preconditioned by D
+    const double* r0 = b;
+    if (x_zero) {
+      MG_TRY(k_fill(h, cur, len, 0.0));
+    } else {
+      if (!r_valid) MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
+      r0 = L.r.p;
+    }
+    MG_TRY(fgmres_relax(h, l, r0, cur, L.npre, diag_prec, gmresTol, L.relaxZ.p, L.relaxAZ.p, false));
+    npre = 0;
+  } else if (x_zero) {
     MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
     --npre;
   } else if (r_valid) {
@@ -381,7 +504,19 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
   MG_TRY(k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, C.b.p));
   double* xc = nullptr;
-  MG_TRY(cycle_level(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
+  if (ctype == 'K' && l + 1 < nl - 1) {
+    // K-cycle (MGcycle.jl:72-76): 2 steps of FGMRES on A_{l+1} xc = bc, preconditioned by the K-cycle of level l+1
+    auto kprec = [&](const double* v, double* z) {
+      double* res = nullptr;
+      MG_TRY(cycle_level(h, l + 1, v, C.x0.p, C.x1.p, true, 'K', &res));
+      HIP_TRY(hipMemcpyAsync(z, res, sizeof(double) * C.n * h->nrhs, hipMemcpyDeviceToDevice, h->stream));
+      return (int)MG_OK;
+    };
+    MG_TRY(fgmres_relax(h, l + 1, C.b.p, C.x0.p, 2, kprec, gmresTol, C.kZ.p, C.kAZ.p, true));
+    xc = C.x0.p;
+  } else {
+    MG_TRY(cycle_level(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
+  }
   if (l + 1 < nl - 1) {  // MGcycle.jl:78-85
     if (ctype == 'W') {
       double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
@@ -394,11 +529,15 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   // x += P xc (MGcycle.jl:90)
   MG_TRY(k_spmv(h, l, MG_K_PROLONG, L.P, 1.0, xc, 1.0, cur));
   // post-smoothing (MGcycle.jl:92-102)
-  for (long long s = 0; s < npost; ++s) {
-    MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
-    std::swap(cur, alt);
+  if (h->relax_type == 1) {
+    MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
+    MG_TRY(fgmres_relax(h, l, L.r.p, cur, L.npost, diag_prec, gmresTol, L.relaxZ.p, L.relaxAZ.p, false));
+  } else {
+    for (long long s = 0; s < npost; ++s) {
+      MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
+      std::swap(cur, alt);
+    }
   }
-  (void)len;
   *result = cur;
   return MG_OK;
 }
@@ -630,6 +769,20 @@ int alloc_scratch(mg_hierarchy* h) {
       HIP_TRY(hipMemset(L.b.p, 0, L.b.bytes()));
       HIP_TRY(hipMemset(L.x0.p, 0, L.x0.bytes()));
     }
+    // FGMRESmem (MGsetup.jl:190-215): memRelax[l] for Jac-GMRES, memKcycle for levels 2..nl-1 of a K-cycle
+    L.relaxZ.release();
+    L.relaxAZ.release();
+    L.kZ.release();
+    L.kAZ.release();
+    if (h->relax_type == 1 && l < (int)h->nlevels - 1) {
+      L.relax_inner = std::max<long long>(1, std::max(L.npre, L.npost));
+      MG_TRY(L.relaxZ.alloc(len * (size_t)L.relax_inner));
+      MG_TRY(L.relaxAZ.alloc(len * (size_t)L.relax_inner));
+    }
+    if (h->cycle == 'K' && l > 0 && l < (int)h->nlevels - 1) {
+      MG_TRY(L.kZ.alloc(len * 2));
+      MG_TRY(L.kAZ.alloc(len * 2));
+    }
   }
   // host-pointer API staging (fine level) + transpose scratch (any level, for mg_spmv)
   MG_TRY(h->stage_b.alloc((size_t)nmax * k));
@@ -829,12 +982,19 @@ int mg_set_grid_hint(mg_hierarchy* h, long long level, long long n1, long long n
   return MG_OK;
 }
 
+int mg_set_relax_type(mg_hierarchy* h, long long relaxType) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (relaxType != 0 && relaxType != 1) return fail(MG_ERR_INVALID, "relaxType must be 0 (Jac/SPAI) or 1 (Jac-GMRES)");
+  h->relax_type = (int)relaxType;
+  h->finalized = false;
+  return MG_OK;
+}
+
 int mg_set_cycle_type(mg_hierarchy* h, long long cycleType) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (cycleType == 'K')
-    return fail(MG_ERR_UNSUPPORTED, "K-cycle (FGMRES recursion, MGcycle.jl:72-76) is not on the device path yet");
-  if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F')
-    return fail(MG_ERR_INVALID, "cycleType must be 'V', 'W' or 'F'");
+  if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F' && cycleType != 'K')
+    return fail(MG_ERR_INVALID, "cycleType must be 'V', 'W', 'F' or 'K'");
+  if ((cycleType == 'K') != (h->cycle == 'K')) h->finalized = false;  // memKcycle must be (de)allocated
   h->cycle = (char)cycleType;
   return MG_OK;
 }

@@ -34,6 +34,7 @@ SIGNATURES = {
     "mg_set_operator_FP64_INT64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _lp, _lp, _dp]),
     "mg_set_relax_FP64": (C.c_int, [_vp, _ll, _dp, _ll, _ll, _ll]),
     "mg_set_cycle_type": (C.c_int, [_vp, _ll]),
+    "mg_set_relax_type": (C.c_int, [_vp, _ll]),
     "mg_set_grid_hint": (C.c_int, [_vp, _ll, _ll, _ll, _ll]),
     "mg_set_coarse_dense_inverse_FP64": (C.c_int, [_vp, _ll, _dp]),
     "mg_finalize": (C.c_int, [_vp]),
@@ -176,6 +177,7 @@ class DeviceHierarchy:
                 nn = [int(k) + 1 for k in mesh.n] + [1]
                 if int(np.prod(nn)) == param.As[l].shape[0]:
                     _check(lib, lib.mg_set_grid_hint(self.handle, l + 1, nn[0], nn[1], nn[2]), "mg_set_grid_hint")
+        _check(lib, lib.mg_set_relax_type(self.handle, 1 if param.relaxType == "Jac-GMRES" else 0), "mg_set_relax_type")
         _check(lib, lib.mg_set_cycle_type(self.handle, ord(param.cycleType)), "mg_set_cycle_type")
         nc = int(param.As[-1].shape[0])
         if nc > DENSE_COARSE_MAX:

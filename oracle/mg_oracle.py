@@ -66,6 +66,38 @@ def relax(A, r, x, b, d, numit):
     return x
 
 
+def FGMRES_relaxation(Afun, r0, x0, inner, prec, TOL):
+    """FGMRES.jl:48-126: x0 += Z*t, t = pinv((AZ)'(AZ)) (AZ)'r0 over the directions z_1 = prec(r0),
+    z_j = prec(A z_{j-1}); blocks are treated as one long vector (l.51)."""
+    shape = r0.shape
+    nm = r0.size
+    rnorm0 = np.linalg.norm(r0)
+    H = np.zeros((inner, inner))
+    xi = np.zeros(inner)
+    t = np.zeros(inner)
+    Z = np.zeros((nm, inner))
+    AZ = np.zeros((nm, inner))
+    w = None
+    rnorms = np.zeros(inner)
+    for j in range(inner):
+        z = prec(r0) if j == 0 else prec(w)                  # l.83-87
+        Z[:, j] = np.asarray(z).reshape(nm, order="F")
+        w = Afun(z)                                          # l.91
+        AZ[:, j] = np.asarray(w).reshape(nm, order="F")
+        t = AZ.T @ AZ[:, j]                                  # gemv 'C' (l.95)
+        xi[j] = np.dot(AZ[:, j], np.asarray(r0).reshape(nm, order="F"))   # l.97
+        H[:, j] = t
+        H[j, :] = t
+        H = 0.5 * H + 0.5 * H.T
+        t = np.linalg.pinv(H) @ xi                           # l.102
+        rnorms[j] = np.sqrt(abs(t @ (H @ t) - 2.0 * (t @ xi) + rnorm0 ** 2))   # l.104
+        if rnorms[j] < TOL:                                  # l.114-117
+            break
+    if inner > 0:
+        x0 += (Z @ t).reshape(shape, order="F")              # l.121-123
+    return x0
+
+
 def solveCoarsest(param, b, x):
     """Default branch: z = param.LU \\ b ; x[:] = z  (MGcycle.jl:177-178)."""
     x[...] = param.LU.solve(np.asarray(b))
@@ -109,7 +141,14 @@ def recursiveCycle(param, b, x, level, mem=None, cycleType=None):
     R = param.Rs[level - 1]
     npresmth = param.relaxPre(level)
     npostsmth = param.relaxPost(level)
-    x = relax(A, r, x, b, D, npresmth)           # l.54
+    gmres_relax = getattr(param, "relaxType", "Jac") == "Jac-GMRES"
+    gmresTol = 1e-5                              # l.5
+    MM = lambda xx: _dmul(D, xx)                 # l.36-38
+    Afun = lambda z: A @ z                       # getAfun (SolveFuncs.jl:65-71)
+    if gmres_relax:
+        x = FGMRES_relaxation(Afun, r, x, npresmth, MM, gmresTol)        # l.48-50
+    else:
+        x = relax(A, r, x, b, D, npresmth)       # l.54
     SpMatMul(-1.0, A, x, 0.0, r)                 # l.58
     addVectors(1.0, b, r)                        # l.60
     xc = mem.x[level]
@@ -119,9 +158,16 @@ def recursiveCycle(param, b, x, level, mem=None, cycleType=None):
     if level == nlevels - 1:
         xc = solveCoarsest(param, bc, xc)        # l.67-69
     else:
-        if cycleType == "K":
-            raise NotImplementedError("K-cycle: SURVEY 8f-3")
-        xc = recursiveCycle(param, bc, xc, level + 1, mem, cycleType)          # l.78
+        if cycleType == "K":                     # l.72-76
+            Ac = As[level]
+
+            def MMG(v):
+                yz = np.zeros_like(v)
+                return recursiveCycle(param, v, yz, level + 1, mem, "K").copy()
+
+            xc = FGMRES_relaxation(lambda z: Ac @ z, bc.copy(), xc, 2, MMG, gmresTol)
+        else:
+            xc = recursiveCycle(param, bc, xc, level + 1, mem, cycleType)      # l.78
         if cycleType == "W":
             xc = recursiveCycle(param, bc, xc, level + 1, mem, "W")            # l.79-80
         elif cycleType == "F":
@@ -129,7 +175,10 @@ def recursiveCycle(param, b, x, level, mem=None, cycleType=None):
     SpMatMul(1.0, P, xc, 1.0, x)                 # x += P xc             (l.90)
     r[...] = b                                   # l.92
     SpMatMul(-1.0, A, x, 1.0, r)                 # l.93
-    x = relax(A, r, x, b, D, npostsmth)          # l.102
+    if gmres_relax:
+        x = FGMRES_relaxation(Afun, r, x, npostsmth, MM, gmresTol)       # l.96-98
+    else:
+        x = relax(A, r, x, b, D, npostsmth)      # l.102
     return x
 
 

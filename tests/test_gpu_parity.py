@@ -190,3 +190,22 @@ def test_tiled_block_schedule_changes_nothing(mg, built, nrhs, cells, monkeypatc
             assert np.abs(p.resvec - hist["resvec"]).max() / hist["resvec"][0] < RES_TOL
         mg.clear_(p)
     assert np.array_equal(xs[0][0], xs[1][0]) and np.array_equal(xs[0][1], xs[1][1])
+
+
+@pytest.mark.parametrize("cyc,relaxType,pre,post,nrhs", [("V", "Jac-GMRES", 1, 1, 1), ("V", "Jac-GMRES", 2, 1, 2),
+                                                        ("K", "Jac", 1, 1, 1), ("K", "Jac-GMRES", 1, 1, 3),
+                                                        ("W", "Jac-GMRES", 2, 2, 1)])
+def test_jac_gmres_and_kcycle(mg, built, cyc, relaxType, pre, post, nrhs):
+    """FGMRES_relaxation smoother (FGMRES.jl:48-126) and the K-cycle recursion (MGcycle.jl:72-76)."""
+    A, p, b = _setup(mg, [16, 16, 16], 4, relaxType, 0.75, pre, post, cyc, maxIter=5, nrhs=nrhs)
+    _compare_solve(mg, p, b)
+    mg.clear_(p)
+
+
+def test_reference_test_verbatim_gmgrap_poisson(mg, built):
+    """test/Multigrid/testGMGRAPforPoisson.jl:59-78 with its own parameters (Jac-GMRES 0.75, V(1,1), 4 levels,
+    nrhs 2, 5 cycles, seeded RHS): the device solve passes the reference's assertion ||AX-B|| < 0.01."""
+    A, p, b = _setup(mg, [32, 32, 16], 4, "Jac-GMRES", 0.75, 1, 1, "V", maxIter=5, nrhs=2)
+    x, hist = _compare_solve(mg, p, b)
+    assert np.linalg.norm(A @ x - b) < 0.01
+    mg.clear_(p)

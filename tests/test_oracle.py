@@ -166,3 +166,37 @@ def test_oracle_reproduces_golden(mg, path):
     assert it == int(g["iters"])
     assert np.abs(hist["resvec"] - g["resvec"]).max() / g["resvec"][0] < 1e-13
     assert np.abs(x - g["x_last"]).max() <= 1e-12 * np.abs(g["x_last"]).max()
+
+
+# ---- Jac-GMRES smoother and K-cycle (FGMRES.jl, MGcycle.jl:48-50,72-76) ------------------------------------
+def test_fgmres_relaxation_minimises_the_residual(mg):
+    """The correction Z*t must be the least-squares minimiser of ||r0 - A Z t||."""
+    A, mesh = mg.poisson_shifted([6, 6, 6])
+    rng = np.random.default_rng(2)
+    r0 = rng.standard_normal(A.shape[0])
+    d = 0.8 / A.diagonal()
+    x = orc.FGMRES_relaxation(lambda z: A @ z, r0, np.zeros_like(r0), 3, lambda v: d * v, 1e-30)
+    z1 = d * r0
+    z2 = d * (A @ z1)
+    z3 = d * (A @ z2)
+    Z = np.stack([z1, z2, z3], axis=1)
+    t = np.linalg.lstsq(A @ Z, r0, rcond=None)[0]
+    assert np.allclose(x, Z @ t, rtol=1e-8, atol=1e-12)
+    assert np.linalg.norm(r0 - A @ x) < np.linalg.norm(r0)
+
+
+def test_threshold_2d_poisson_jac_gmres(mg):
+    """testGMGRAPforPoisson.jl:8-40 verbatim parameters: 128^2 cells, 4 levels, Jac-GMRES 0.75, V(1,1),
+    nrhs = 2, 5 cycles -> ||AX-B|| < 0.005."""
+    A, p, b = _gmg(mg, [128, 128], 4, "Jac-GMRES", 0.75, 1, 1, "V", 2, 5)
+    x = np.zeros_like(b)
+    orc.solveMG(p, b, x)
+    assert np.linalg.norm(A @ x - b) < 0.005
+
+
+def test_threshold_3d_poisson_jac_gmres(mg):
+    """testGMGRAPforPoisson.jl:59-78 verbatim: 32x32x16 cells, Jac-GMRES, nrhs 2 -> < 0.01."""
+    A, p, b = _gmg(mg, [32, 32, 16], 4, "Jac-GMRES", 0.75, 1, 1, "V", 2, 5)
+    x = np.zeros_like(b)
+    orc.solveMG(p, b, x)
+    assert np.linalg.norm(A @ x - b) < 0.01
