@@ -62,6 +62,7 @@ struct CsrDev {
 };
 
 struct VecArgs {
+  double* sumsq;    // optional: per-row-block sum of squares of the output (fused ||r||^2, nrhs == 1)
   const double* x;  // gathered vector           [n_cols][nrhs]
   const double* xs; // SMOOTH: the row's own x   [n_rows][nrhs] (== x unless the operator holds a row sub-range)
   double* y;        // output                    [n_rows][nrhs]
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
       if (MODE == AXPBY) pb = (v.beta != 0.0) ? v.beta * v.y[r0] : 0.0;
       else pb = v.b[r0];
       if (MODE == SMOOTH) { pd = v.d[r0]; px = v.xs[r0]; }
-      v.y[r0] = epilogue<MODE>(v, r0, s, pb, pd, px);
+      const double o = epilogue<MODE>(v, r0, s, pb, pd, px);
+      v.y[r0] = o;
+      if (v.sumsq) v.sumsq[bid] = o * o;
     }
     return;
   }
@@ -176,7 +179,22 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
     for (int k = s + sub; k < e; k += tpr) acc += prod[k];
   }
   for (int o = tpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (owner) v.y[r0 + lrow] = epilogue<MODE>(v, r0 + lrow, acc, pb, pd, px);
+  double outv = 0.0;
+  if (owner) {
+    outv = epilogue<MODE>(v, r0 + lrow, acc, pb, pd, px);
+    v.y[r0 + lrow] = outv;
+  }
+  if (v.sumsq) {  // fused Frobenius norm (SolveFuncs.jl:30): deterministic per-block partial, summed by sum_final
+    double sq = outv * outv;
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) t += red[w];
+      v.sumsq[bid] = t;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -35,8 +35,8 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-// Busy-poll instead of hipStreamSynchronize: the blocking wait parks the thread on an interrupt whose
-// wake-up costs milliseconds on some hosts (measured: 10.0 vs 3.1 ms per solveMG step at 256^3).
+// Busy-poll instead of hipStreamSynchronize: one 8-byte readback per step sits on the critical path of the
+// solve loop, so the thread spins on hipStreamQuery rather than parking on an interrupt.
 static inline hipError_t spin_sync(hipStream_t s) {
   hipError_t e;
   while ((e = hipStreamQuery(s)) == hipErrorNotReady) {
@@ -283,6 +283,30 @@ int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const 
   ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, h->nrhs, true, false));
   return launch_csr<mgk::RESID>(h->stream, A, v);
 }
+int k_sumsq(mg_hierarchy* h, const double* x, long long len);
+// out = b - A*x and h->scalar = ||out||^2 in the same pass (nrhs == 1); falls back to two kernels for blocks
+int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x, double* out) {
+  if (h->nrhs != 1 || (size_t)A.nblocks > h->partial.n) {
+    MG_TRY(k_residual(h, level, A, b, x, out));
+    return k_sumsq(h, out, A.n_rows * h->nrhs);
+  }
+  mgk::VecArgs v{};
+  v.x = x;
+  v.y = out;
+  v.b = b;
+  v.nrhs = 1;
+  v.sumsq = h->partial.p;
+  {
+    ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false));
+    MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v));
+  }
+  ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)A.nblocks);
+  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, A.nblocks, h->scalar.p);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+int scalar_sync(mg_hierarchy* h, double* out);
+
 // out = x + d.*(b - A*x)
 int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const double* b,
              const double* x, double* out) {
@@ -339,13 +363,17 @@ int k_sumsq(mg_hierarchy* h, const double* x, long long len) {
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
-// host value of sqrt(sum of squares); synchronises the stream
-int norm_sync(mg_hierarchy* h, const double* x, long long len, double* out) {
-  MG_TRY(k_sumsq(h, x, len));
+// host value of sqrt(h->scalar); synchronises the stream
+int scalar_sync(mg_hierarchy* h, double* out) {
   HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(spin_sync(h->stream));
   *out = std::sqrt(*h->h_scalar);
   return MG_OK;
+}
+// host value of sqrt(sum of squares); synchronises the stream
+int norm_sync(mg_hierarchy* h, const double* x, long long len, double* out) {
+  MG_TRY(k_sumsq(h, x, len));
+  return scalar_sync(h, out);
 }
 
 // ---- FGMRES_relaxation (FGMRES.jl:48-126) --------------------------------------------------------------
@@ -575,8 +603,8 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
   if (x_zero) {
     MG_TRY(norm_sync(h, b, len, &res0));
   } else {
-    MG_TRY(k_residual(h, 0, L.A, b, x, L.r.p));
-    MG_TRY(norm_sync(h, L.r.p, len, &res0));
+    MG_TRY(k_residual_sumsq(h, 0, L.A, b, x, L.r.p));
+    MG_TRY(scalar_sync(h, &res0));
   }
   res = res0;
   if (resvec) resvec[0] = res0;
@@ -591,8 +619,8 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
     MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero));
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
-    MG_TRY(k_residual(h, 0, L.A, b, cur, L.r.p));  // SolveFuncs.jl:26-27
-    MG_TRY(norm_sync(h, L.r.p, len, &res));
+    MG_TRY(k_residual_sumsq(h, 0, L.A, b, cur, L.r.p));  // SolveFuncs.jl:26-30: r = b - A x and ||r|| in one pass
+    MG_TRY(scalar_sync(h, &res));
     ++it;
     if (dbg) {
       auto tnow = std::chrono::steady_clock::now();
@@ -1043,6 +1071,8 @@ int mg_finalize(mg_hierarchy* h) {
   if (h->n_coarse != h->lev[nl - 1].n)
     return fail(MG_ERR_INVALID, "coarse inverse order %lld != coarsest level size %lld", h->n_coarse, h->lev[nl - 1].n);
   MG_TRY(alloc_scratch(h));
+  if ((size_t)h->lev[0].A.nblocks > h->partial.n)  // the fused residual+norm writes one partial per row block
+    MG_TRY(h->partial.alloc((size_t)h->lev[0].A.nblocks));
   h->finalized = true;
   return MG_OK;
 }
