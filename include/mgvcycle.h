@@ -161,6 +161,10 @@ int mg_profile_enable(mg_hierarchy* h, long long on);
 int mg_profile_get(mg_hierarchy* h, long long level, long long kernel, double* total_ms,
                    long long* launches, double* bytes_per_launch);
 int mg_profile_reset(mg_hierarchy* h);
+/* Device format of one operator: number of distinct row patterns (0 = plain CSR with int32 column indices),
+ * dictionary length, and the index-side bytes (row pointers + column information) of one nrhs=1 launch. */
+int mg_operator_format(mg_hierarchy* h, long long level, long long which, long long* npatterns,
+                       long long* dict_entries, double* index_bytes_per_launch);
 /* Algorithmic HBM bytes of one full cycle (x0 = 0) with the current nrhs, DESIGN.md section 5. */
 int mg_cycle_bytes(mg_hierarchy* h, double* bytes);
 /* HBM bytes held by the hierarchy. */

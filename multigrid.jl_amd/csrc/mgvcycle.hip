@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mgvcycle.h"
@@ -85,6 +86,11 @@ struct Csr {
   long long n_rows = 0, n_cols = 0, nnz = 0;
   DevBuf<int> rowptr, colidx, blk_row, sched;
   DevBuf<double> val;
+  // pattern-coded column indices (csr_pattern_spmv): first column + pattern id per row, offset dictionary
+  DevBuf<int> firstcol, pat_ptr, pat_off;
+  DevBuf<unsigned short> pat;
+  bool has_pat = false;
+  long long npat = 0, dict_entries = 0;
   std::vector<int> h_blk_row;  // host copy of the row-block boundaries (for building schedules)
   bool has_sched = false;
   int nblocks = 0;
@@ -101,7 +107,20 @@ struct Csr {
     d.n_cols = (int)n_cols;
     return d;
   }
+  mgk::PatDev patdev() const {
+    mgk::PatDev p;
+    p.firstcol = firstcol.p;
+    p.pat = pat.p;
+    p.pat_ptr = pat_ptr.p;
+    p.pat_off = pat_off.p;
+    return p;
+  }
   void release() {
+    firstcol.release();
+    pat_ptr.release();
+    pat_off.release();
+    pat.release();
+    has_pat = false;
     rowptr.release();
     colidx.release();
     blk_row.release();
@@ -110,7 +129,10 @@ struct Csr {
     val.release();
     set = false;
   }
-  size_t bytes() const { return rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes() + sched.bytes(); }
+  size_t bytes() const {
+    return rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes() + sched.bytes() + firstcol.bytes() +
+           pat_ptr.bytes() + pat_off.bytes() + pat.bytes();
+  }
 };
 
 struct Level {
@@ -248,7 +270,10 @@ template <int MODE>
 int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
-  if (v.nrhs == 1) {
+  if (v.nrhs == 1 && M.has_pat) {
+    if (M.nt) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
+    else hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
+  } else if (v.nrhs == 1) {
     if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), v);
     else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), v);
   } else {
@@ -824,6 +849,59 @@ int alloc_scratch(mg_hierarchy* h) {
   return MG_OK;
 }
 
+// Dictionary-code the column indices: per row (first column, pattern id), pattern = cols - cols[0].
+// Adopted only if it is a clear win: <= 65535 patterns and a dictionary below 1/16 of the index array.
+int build_patterns(Csr* M, const std::vector<int>& rp, const std::vector<int>& ci) {
+  M->has_pat = false;
+  const long long n = M->n_rows;
+  std::vector<int> first((size_t)n, 0);
+  std::vector<unsigned short> pid((size_t)n, 0);
+  std::vector<int> pptr(1, 0), poff;
+  std::unordered_map<unsigned long long, std::vector<int>> table;  // hash -> pattern ids
+  const size_t dict_cap = (size_t)std::max<long long>(4096, M->nnz / 16);
+  for (long long i = 0; i < n; ++i) {
+    const int s = rp[(size_t)i], e = rp[(size_t)i + 1];
+    const int f = (e > s) ? ci[(size_t)s] : 0;
+    first[(size_t)i] = f;
+    unsigned long long hsh = 1469598103934665603ull ^ (unsigned long long)(e - s);
+    for (int k = s; k < e; ++k) {
+      hsh ^= (unsigned long long)(unsigned int)(ci[(size_t)k] - f);
+      hsh *= 1099511628211ull;
+    }
+    std::vector<int>& cand = table[hsh];
+    int found = -1;
+    for (int id : cand) {
+      const int ps = pptr[(size_t)id], len = pptr[(size_t)id + 1] - ps;
+      if (len != e - s) continue;
+      bool same = true;
+      for (int k = 0; k < len; ++k)
+        if (poff[(size_t)ps + k] != ci[(size_t)s + k] - f) { same = false; break; }
+      if (same) { found = id; break; }
+    }
+    if (found < 0) {
+      found = (int)pptr.size() - 1;
+      if (found >= 65535 || poff.size() + (size_t)(e - s) > dict_cap) return MG_OK;  // not a grid-like operator
+      for (int k = s; k < e; ++k) poff.push_back(ci[(size_t)k] - f);
+      pptr.push_back((int)poff.size());
+      cand.push_back(found);
+    }
+    pid[(size_t)i] = (unsigned short)found;
+  }
+  if (poff.empty()) poff.push_back(0);
+  MG_TRY(M->firstcol.alloc(first.size()));
+  MG_TRY(M->pat.alloc(pid.size()));
+  MG_TRY(M->pat_ptr.alloc(pptr.size()));
+  MG_TRY(M->pat_off.alloc(poff.size()));
+  HIP_TRY(hipMemcpy(M->firstcol.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->pat.p, pid.data(), pid.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->pat_ptr.p, pptr.data(), pptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->pat_off.p, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
+  M->npat = (long long)pptr.size() - 1;
+  M->dict_entries = (long long)poff.size();
+  M->has_pat = true;
+  return MG_OK;
+}
+
 // Validate Julia's (colptr,rowval,nzval) of the transposed CSC (1-based Int64), convert to 0-based int32
 // CSR (the reference's C side does the -1 per access, parRelax.h:24-27), cut the rows into row blocks
 // and upload.
@@ -883,6 +961,10 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
   // 685 MB..1.4 GB operators of C2, -5..25 % on the 89 MB ones); MG_NT=0/1 forces one policy
   M->nt = (12.0 * (double)nnz > 128.0e6);
   if (const char* e = std::getenv("MG_NT")) M->nt = (e[0] == '1');
+  {  // pattern-code the column indices when the operator has few distinct row patterns (grid operators)
+    const char* e = std::getenv("MG_NO_PATTERN");
+    if (!(e && e[0] == '1')) MG_TRY(build_patterns(M, rp, ci));
+  }
   return MG_OK;
 }
 
@@ -1345,6 +1427,20 @@ int mg_profile_get(mg_hierarchy* h, long long level, long long kernel, double* t
   if (total_ms) *total_ms = s.ms;
   if (launches) *launches = s.launches;
   if (bytes_per_launch) *bytes_per_launch = s.bytes;
+  return MG_OK;
+}
+
+int mg_operator_format(mg_hierarchy* h, long long level, long long which, long long* npatterns,
+                       long long* dict_entries, double* index_bytes_per_launch) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  Csr* M = pick(h, level, which);
+  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
+  if (npatterns) *npatterns = M->has_pat ? M->npat : 0;
+  if (dict_entries) *dict_entries = M->has_pat ? M->dict_entries : 0;
+  // bytes of row pointers + column information one nrhs=1 launch streams
+  if (index_bytes_per_launch)
+    *index_bytes_per_launch = M->has_pat ? 10.0 * (double)M->n_rows + 4.0 * (double)M->dict_entries
+                                         : 4.0 * (double)M->nnz + 4.0 * (double)(M->n_rows + 1);
   return MG_OK;
 }
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mg_profile_enable": (C.c_int, [_vp, _ll]),
     "mg_profile_get": (C.c_int, [_vp, _ll, _ll, _dp, _lp, _dp]),
     "mg_profile_reset": (C.c_int, [_vp]),
+    "mg_operator_format": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
     "mg_cycle_bytes": (C.c_int, [_vp, _dp]),
     "mg_device_bytes": (C.c_int, [_vp, _dp]),
     "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
@@ -326,6 +327,13 @@ class DeviceHierarchy:
                 if n.value:
                     out[(l, KERNEL_NAMES[k])] = (ms.value, int(n.value), bts.value)
         return out
+
+    def operator_format(self, level: int, which: int):
+        """(number of row patterns [0 = plain CSR], dictionary entries, index-side bytes per nrhs=1 launch)."""
+        npat, nd, ib = C.c_longlong(0), C.c_longlong(0), C.c_double(0)
+        _check(self.lib, self.lib.mg_operator_format(self.handle, level, which, C.byref(npat), C.byref(nd), C.byref(ib)),
+               "mg_operator_format")
+        return int(npat.value), int(nd.value), ib.value
 
     def cycle_bytes(self) -> float:
         v = C.c_double(0)

@@ -209,3 +209,44 @@ def test_reference_test_verbatim_gmgrap_poisson(mg, built):
     x, hist = _compare_solve(mg, p, b)
     assert np.linalg.norm(A @ x - b) < 0.01
     mg.clear_(p)
+
+
+def test_pattern_coded_kernel_paths(mg, built, monkeypatch):
+    """csr_pattern_spmv (dictionary-coded column indices) vs csr_stream_spmv (plain CSR) on the same operators,
+    including a banded operator whose identical rows are LONGER than one LDS chunk (long-row path) and every
+    fused epilogue, through the stand-alone operator entry points."""
+    import torch
+    import scipy.sparse as sp
+    from multigrid_jl_amd import device as D
+    rng = np.random.default_rng(7)
+    nr, L = 700, 2500                                    # 2500 > CHUNK-2: every row takes the long-row path
+    rows = np.repeat(np.arange(nr), L)
+    cols = rows + np.tile(np.arange(L), nr)
+    band = sp.csr_matrix((rng.standard_normal(nr * L), (rows, cols)), shape=(nr, nr + L))
+    A, _ = mg.poisson_shifted([14, 12, 10])
+    for M, square in ((band, False), (A, True)):
+        x = torch.from_numpy(rng.standard_normal(M.shape[1])).cuda()
+        b = torch.from_numpy(rng.standard_normal(M.shape[0])).cuda()
+        d = torch.from_numpy(rng.standard_normal(M.shape[0])).cuda()
+        outs = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("MG_NO_PATTERN", mode)
+            op = D.DeviceOperator(M, 0)
+            res = []
+            y = torch.from_numpy(rng.standard_normal(M.shape[0]) * 0 + 1.0).cuda()
+            op.apply(D.MG_K_SPMV, x, y, alpha=-0.5, beta=2.0)
+            res.append(y.cpu().numpy().copy())
+            op.apply(D.MG_K_RESIDUAL, x, y, b=b)
+            res.append(y.cpu().numpy().copy())
+            if square:
+                op.apply(D.MG_K_SMOOTH, x, y, b=b, d=d)
+                res.append(y.cpu().numpy().copy())
+            torch.cuda.synchronize()
+            outs[mode] = res
+            op.close()
+        xn, bn, dn = x.cpu().numpy(), b.cpu().numpy(), d.cpu().numpy()
+        want = [-0.5 * (M @ xn) + 2.0, bn - M @ xn] + ([xn + dn * (bn - M @ xn)] if square else [])
+        for got0, got1, w in zip(outs["0"], outs["1"], want):
+            scale = np.abs(w).max()
+            assert np.abs(got0 - w).max() / scale < KERNEL_TOL
+            assert np.abs(got1 - w).max() / scale < KERNEL_TOL
