@@ -210,18 +210,23 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
 // the dictionary would not be small (unstructured matrices).  Products are summed in stored order when one
 // lane owns a row - exactly the order of a sequential CPU row loop.
 // ------------------------------------------------------------------------------------------------
+constexpr int DICT_LDS = 1024;    // offset dictionaries up to this many entries are staged in LDS
 struct PatDev {
   const int* firstcol;            // n_rows: first column index of the row
   const unsigned short* pat;      // n_rows: pattern id
   const int* pat_ptr;             // npat+1
   const int* pat_off;             // concatenated offset lists (off[0] == 0)
+  int dict_entries;
+  int npat;
 };
 
-template <int MODE, bool NT>
+template <int MODE, bool NT, bool DLDS>
 __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecArgs v) {
   __shared__ double sval[CHUNK];
   __shared__ int srow[MAXROWS + 1];
   __shared__ double red[BLK / 64];
+  __shared__ int soff[DLDS ? DICT_LDS : 1];
+  __shared__ int sptr[DLDS ? DICT_LDS : 1];   // pattern start offsets (npat <= dict_entries <= DICT_LDS)
 
   const int tid = threadIdx.x;
   int bid = xcd_band(blockIdx.x, A.nblocks);
@@ -271,10 +276,16 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
   }
   if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
   if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
+  if (DLDS)
+    for (int i = tid; i < P.dict_entries; i += BLK) {
+      soff[i] = P.pat_off[i];
+      if (i < P.npat) sptr[i] = P.pat_ptr[i];
+    }
   int first = 0, po = 0;
   if (lrow < nrows) {
     first = P.firstcol[r0 + lrow];
-    po = P.pat_ptr[P.pat[r0 + lrow]];
+    po = P.pat[r0 + lrow];                      // pattern id; resolved to its dictionary offset below
+    if (!DLDS) po = P.pat_ptr[po];
   }
   double pb = 0.0, pd = 0.0, px = 0.0;
   if (owner) {
@@ -293,8 +304,21 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
   double acc = 0.0;
   if (lrow < nrows) {
     const int s = srow[lrow], e = srow[lrow + 1];
-    const int* off = P.pat_off + po - s;  // off[k] for k in [s, e)
-    int k = s + sub;
+    if (DLDS) po = sptr[po];
+    const int* off = (DLDS ? soff : P.pat_off) + po - s;  // off[k] for k in [s, e)
+    // first 8 entries of the lane: all gathers issued back to back, then summed in stored order
+    double xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = s + sub + j * tpr;
+      xv[j] = (kk < e) ? v.x[first + off[kk]] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = s + sub + j * tpr;
+      if (kk < e) acc += sval[kk] * xv[j];
+    }
+    int k = s + sub + 8 * tpr;
     for (; k + 3 * tpr < e; k += 4 * tpr) {
       const double x0 = v.x[first + off[k]];
       const double x1 = v.x[first + off[k + tpr]];
@@ -502,6 +526,16 @@ __global__ __launch_bounds__(BLK) void sumsq_partial(const double* __restrict__ 
     acc += t.x * t.x + t.y * t.y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * x[n - 1];
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(BLK) void sum_partial(const double* __restrict__ x, long long n,
+                                                   double* __restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const long long stride = (long long)gridDim.x * BLK;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) acc += x[i];
   const double s = block_sum(acc, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }

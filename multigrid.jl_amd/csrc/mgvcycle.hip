@@ -113,6 +113,8 @@ struct Csr {
     p.pat = pat.p;
     p.pat_ptr = pat_ptr.p;
     p.pat_off = pat_off.p;
+    p.dict_entries = (int)dict_entries;
+    p.npat = (int)npat;
     return p;
   }
   void release() {
@@ -172,7 +174,7 @@ struct mg_hierarchy {
   hipStream_t stream = nullptr;
   bool owns_stream = true;
   // reductions
-  DevBuf<double> partial, scalar;
+  DevBuf<double> partial, partial2, scalar;
   double* h_scalar = nullptr;  // pinned
   int nred_blocks = 1024;
   // staging for the host-pointer API
@@ -271,8 +273,11 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
   if (v.nrhs == 1 && M.has_pat) {
-    if (M.nt) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
-    else hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
+    const bool dl = M.dict_entries <= mgk::DICT_LDS;
+    if (M.nt && dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
+    else if (M.nt) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
+    else if (dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, false, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
+    else hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, false, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
   } else if (v.nrhs == 1) {
     if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), v);
     else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), v);
@@ -326,7 +331,9 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
     MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v));
   }
   ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)A.nblocks);
-  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, A.nblocks, h->scalar.p);
+  const int nb2 = std::min(256, (A.nblocks + mgk::BLK - 1) / mgk::BLK);
+  hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)A.nblocks, h->partial2.p);
+  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
@@ -854,6 +861,9 @@ int alloc_scratch(mg_hierarchy* h) {
 int build_patterns(Csr* M, const std::vector<int>& rp, const std::vector<int>& ci) {
   M->has_pat = false;
   const long long n = M->n_rows;
+  // short rows (full-weighting P: 1..8 entries) gain little index traffic and pay the extra dependent
+  // descriptor loads: measured +18 % time on C2's prolongation -> keep plain CSR below 5 entries per row
+  if (M->nnz < 5 * n) return MG_OK;
   std::vector<int> first((size_t)n, 0);
   std::vector<unsigned short> pid((size_t)n, 0);
   std::vector<int> pptr(1, 0), poff;
@@ -1008,7 +1018,7 @@ int mg_create(long long nlevels, long long nrhs, long long device_id, mg_hierarc
     delete h;
     return fail(MG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
   }
-  if (h->partial.alloc((size_t)h->nred_blocks) != MG_OK || h->scalar.alloc(1) != MG_OK ||
+  if (h->partial.alloc((size_t)h->nred_blocks) != MG_OK || h->partial2.alloc(256) != MG_OK || h->scalar.alloc(1) != MG_OK ||
       hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), sizeof(double)) != hipSuccess) {
     mg_destroy(h);
     return fail(MG_ERR_HIP, "allocation of reduction scratch failed");
@@ -1035,6 +1045,7 @@ int mg_destroy(mg_hierarchy* h) {
   }
   h->Ainv.release();
   h->partial.release();
+  h->partial2.release();
   h->scalar.release();
   h->stage_b.release();
   h->stage_x.release();

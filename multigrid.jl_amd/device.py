@@ -6,6 +6,10 @@ Float64 ``nzval`` - following the reference's ccall idiom (src/Multigrid/parRela
 
 There is NO CPU fallback: if the HIP library is missing or no GPU is visible, every entry point
 raises.
+
+Import order note: PyTorch wheels bundle their own libamdhip64; a process that wants to use torch.cuda as
+well must ``import torch`` BEFORE this library is loaded (bench.py and tests/conftest.py do), otherwise the
+system HIP runtime this library pulls in shadows torch's and torch.cuda fails to initialise.
 """
 from __future__ import annotations
 
