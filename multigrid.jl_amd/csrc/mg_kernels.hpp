@@ -351,182 +351,6 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
 }
 
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined, persistent form of csr_pattern_spmv.
-// In the one-block-per-workgroup kernel a workgroup first waits for its value stream (one HBM round trip)
-// and then for its gathers (one L2 round trip), back to back.  Here a workgroup walks several row blocks of
-// its XCD's band (grid-stride inside the band, so the set of blocks in flight per XCD is the same contiguous
-// window as before) and issues the loads of the NEXT block - values, row pointers, row descriptors, epilogue
-// operands - before it gathers for the CURRENT one: the two round trips overlap.
-// ------------------------------------------------------------------------------------------------
-template <int MODE, bool NT, bool DLDS>
-__global__ __launch_bounds__(BLK) void csr_pattern_spmv_pipe(CsrDev A, PatDev P, VecArgs v) {
-  __shared__ double sval[CHUNK];
-  __shared__ int srow[MAXROWS + 1];
-  __shared__ double red[BLK / 64];
-  __shared__ int soff[DLDS ? DICT_LDS : 1];
-  __shared__ int sptr[DLDS ? DICT_LDS : 1];
-
-  const int tid = threadIdx.x;
-  // this workgroup's XCD band and its stride inside it
-  const int nb = A.nblocks;
-  const int q = nb >> 3, rem = nb & 7;
-  const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
-  const int band0 = xcd * q + (xcd < rem ? xcd : rem);
-  const int bandn = q + (xcd < rem ? 1 : 0);
-  const int wstride = ((int)gridDim.x + 7 - xcd) >> 3;  // workgroups that landed on this XCD
-  if (DLDS) {
-    for (int i = tid; i < P.dict_entries; i += BLK) {
-      soff[i] = P.pat_off[i];
-      if (i < P.npat) sptr[i] = P.pat_ptr[i];
-    }
-  }
-  // registers describing / holding the block whose loads are in flight
-  int bid_n = -1, r0_n = 0, nrows_n = 0, k0_n = 0, k1_n = 0, rp_n = 0, first_n = 0, po_n = 0;
-  bool long_n = false;
-  d2_t va_n[PAIRS];
-  double pb_n = 0.0, pd_n = 0.0, px_n = 0.0;
-
-  auto issue = [&](int j) {  // start every global load of band block j (or mark "none")
-    bid_n = -1;
-    if (j >= bandn) return;
-    int b = band0 + j;
-    if (A.sched) b = A.sched[b];
-    bid_n = b;
-    r0_n = A.blk_row[b];
-    const int r1 = A.blk_row[b + 1];
-    nrows_n = r1 - r0_n;
-    k0_n = A.rowptr[r0_n];
-    k1_n = A.rowptr[r1];
-    long_n = (nrows_n == 1 && (k1_n - k0_n) > CHUNK - 2);
-    if (long_n) return;
-    const int base = k0_n & ~1;
-#pragma unroll
-    for (int it = 0; it < PAIRS; ++it) {
-      const int idx = base + it * (2 * BLK) + 2 * tid;
-      va_n[it] = (idx < k1_n) ? load_stream<NT>(A.val + idx) : d2_t{0.0, 0.0};
-    }
-    rp_n = (tid <= nrows_n) ? A.rowptr[r0_n + (tid < nrows_n ? tid : nrows_n)] - base : 0;
-    int sh = 0;
-    while (sh < 6 && (2 << sh) * nrows_n <= BLK) ++sh;
-    const int lrow = tid >> sh;
-    const bool own = (lrow < nrows_n) && ((tid & ((1 << sh) - 1)) == 0);
-    first_n = 0;
-    po_n = 0;
-    if (lrow < nrows_n) {
-      first_n = P.firstcol[r0_n + lrow];
-      po_n = P.pat[r0_n + lrow];
-      if (!DLDS) po_n = P.pat_ptr[po_n];
-    }
-    pb_n = 0.0;
-    pd_n = 0.0;
-    px_n = 0.0;
-    if (own) {
-      const int row = r0_n + lrow;
-      if (MODE == AXPBY) { if (v.beta != 0.0) pb_n = v.beta * v.y[row]; }
-      else pb_n = v.b[row];
-      if (MODE == SMOOTH) { pd_n = v.d[row]; px_n = v.xs[row]; }
-    }
-  };
-
-  issue(widx);
-  for (int j = widx; j < bandn; j += wstride) {
-    // ---- take over the block whose loads were issued ----------------------------------------------
-    const int bid = bid_n, r0 = r0_n, nrows = nrows_n, k0 = k0_n, k1 = k1_n;
-    const bool longrow = long_n;
-    const int first = first_n;
-    int po = po_n;
-    const double pb = pb_n, pd = pd_n, px = px_n;
-    if (!longrow) {
-      const int base = k0 & ~1;
-#pragma unroll
-      for (int it = 0; it < PAIRS; ++it) {
-        const int idx = base + it * (2 * BLK) + 2 * tid;
-        if (idx < k1) *reinterpret_cast<d2_t*>(&sval[it * (2 * BLK) + 2 * tid]) = va_n[it];
-      }
-      if (tid <= nrows) srow[tid] = rp_n;
-      if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
-    }
-    __syncthreads();
-    issue(j + wstride);  // next block's loads fly while this block gathers
-    if (longrow) {
-      const int f = P.firstcol[r0];
-      const int pp = P.pat_ptr[P.pat[r0]];
-      double acc = 0.0;
-      for (int k = k0 + tid; k < k1; k += BLK) acc += A.val[k] * v.x[f + P.pat_off[pp + (k - k0)]];
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      if ((tid & 63) == 0) red[tid >> 6] = acc;
-      __syncthreads();
-      if (tid == 0) {
-        double s = 0.0;
-        for (int w = 0; w < BLK / 64; ++w) s += red[w];
-        double qb = 0.0, qd = 0.0, qx = 0.0;
-        if (MODE == AXPBY) qb = (v.beta != 0.0) ? v.beta * v.y[r0] : 0.0;
-        else qb = v.b[r0];
-        if (MODE == SMOOTH) { qd = v.d[r0]; qx = v.xs[r0]; }
-        const double o = epilogue<MODE>(v, r0, s, qb, qd, qx);
-        v.y[r0] = o;
-        if (v.sumsq) v.sumsq[bid] = o * o;
-      }
-      __syncthreads();
-      continue;
-    }
-    int sh = 0;
-    while (sh < 6 && (2 << sh) * nrows <= BLK) ++sh;
-    const int tpr = 1 << sh;
-    const int lrow = tid >> sh;
-    const int sub = tid & (tpr - 1);
-    const bool owner = (lrow < nrows) && (sub == 0);
-    double acc = 0.0;
-    if (lrow < nrows) {
-      const int s = srow[lrow], e = srow[lrow + 1];
-      if (DLDS) po = sptr[po];
-      const int* off = (DLDS ? soff : P.pat_off) + po - s;
-      double xv[8];
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const int kk = s + sub + jj * tpr;
-        xv[jj] = (kk < e) ? v.x[first + off[kk]] : 0.0;
-      }
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const int kk = s + sub + jj * tpr;
-        if (kk < e) acc += sval[kk] * xv[jj];
-      }
-      int k = s + sub + 8 * tpr;
-      for (; k + 3 * tpr < e; k += 4 * tpr) {
-        const double x0 = v.x[first + off[k]];
-        const double x1 = v.x[first + off[k + tpr]];
-        const double x2 = v.x[first + off[k + 2 * tpr]];
-        const double x3 = v.x[first + off[k + 3 * tpr]];
-        acc += sval[k] * x0;
-        acc += sval[k + tpr] * x1;
-        acc += sval[k + 2 * tpr] * x2;
-        acc += sval[k + 3 * tpr] * x3;
-      }
-      for (; k < e; k += tpr) acc += sval[k] * v.x[first + off[k]];
-    }
-    for (int o = tpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    double outv = 0.0;
-    if (owner) {
-      outv = epilogue<MODE>(v, r0 + lrow, acc, pb, pd, px);
-      v.y[r0 + lrow] = outv;
-    }
-    if (v.sumsq) {
-      double sq = outv * outv;
-      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-      if ((tid & 63) == 0) red[tid >> 6] = sq;
-      __syncthreads();
-      if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < BLK / 64; ++w) t += red[w];
-        v.sumsq[bid] = t;
-      }
-    }
-    __syncthreads();  // LDS is rewritten by the next block
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // CSR-stream SpMM, nrhs > 1, vectors row-major [n][nrhs].
 // The nnz segment (values AND column indices) is staged in LDS with coalesced loads; then G lanes
 // (G = pow2 >= nrhs, <= 64) own one row x one RHS column each and walk the row from LDS (broadcast

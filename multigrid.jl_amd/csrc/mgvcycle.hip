@@ -268,33 +268,11 @@ int pow2_ge(long long v) {
   return g;
 }
 
-template <class K>
-void launch_pipe(K kernel, hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
-  static const int grid = [&] {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, mgk::BLK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024;
-    if (const char* e = std::getenv("MG_PIPE_PER_CU")) per_cu = std::max(1, atoi(e));
-    return std::max(8, (per_cu * prop.multiProcessorCount) & ~7);
-  }();
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(mgk::BLK), 0, stream, M.dev(), M.patdev(), v);
-}
-
 template <int MODE>
 int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
-  static const int pipe_mode = [] { const char* e = std::getenv("MG_PIPE"); return e ? atoi(e) : 1; }();
-  if (v.nrhs == 1 && M.has_pat && pipe_mode && M.nblocks >= 4 * 2048) {
-    // persistent, software-pipelined form: as many workgroups as are co-resident walk the row blocks of
-    // their XCD's band (grid from the occupancy query, a multiple of 8 so that every XCD gets the same count)
-    const bool dl = M.dict_entries <= mgk::DICT_LDS;
-    if (M.nt && dl) launch_pipe(mgk::csr_pattern_spmv_pipe<MODE, true, true>, stream, M, v);
-    else if (M.nt) launch_pipe(mgk::csr_pattern_spmv_pipe<MODE, true, false>, stream, M, v);
-    else if (dl) launch_pipe(mgk::csr_pattern_spmv_pipe<MODE, false, true>, stream, M, v);
-    else launch_pipe(mgk::csr_pattern_spmv_pipe<MODE, false, false>, stream, M, v);
-  } else if (v.nrhs == 1 && M.has_pat) {
+  if (v.nrhs == 1 && M.has_pat) {
     const bool dl = M.dict_entries <= mgk::DICT_LDS;
     if (M.nt && dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
     else if (M.nt) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
