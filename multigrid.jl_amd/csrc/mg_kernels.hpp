@@ -211,7 +211,14 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
 // lane owns a row - exactly the order of a sequential CPU row loop.
 // ------------------------------------------------------------------------------------------------
 constexpr int DICT_LDS = 1024;    // offset dictionaries up to this many entries are staged in LDS
+constexpr int MAXRUNS = 32;       // row blocks with at most this many descriptor runs use the run-length form
 struct PatDev {
+  // Run-length form of the row descriptors: inside a row block, consecutive rows that share a pattern and
+  // whose first column advances by a constant stride form one run {local row0, pattern id, first column of
+  // row0, stride, value offset of row0} (5 ints).  A grid line is 1-3 runs, so the per-row descriptor
+  // traffic (row pointer 4 B + first column 4 B + pattern id 2 B) shrinks to a few dozen bytes per block.
+  const int* run_ptr;             // nblocks+1 (nullptr: no run form); run_ptr[b+1]-run_ptr[b] == 0: per-row form
+  const int* runs;                // 5 ints per run
   const int* firstcol;            // n_rows: first column index of the row
   const unsigned short* pat;      // n_rows: pattern id
   const int* pat_ptr;             // npat+1
@@ -274,15 +281,25 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
     const int idx = base + it * (2 * BLK) + 2 * tid;
     va[it] = (idx < k1) ? load_stream<NT>(A.val + idx) : d2_t{0.0, 0.0};
   }
-  if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
-  if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
+  __shared__ int srun[5 * MAXRUNS];
+  int nruns = 0, run0 = 0;
+  if (P.run_ptr) {
+    run0 = P.run_ptr[bid];
+    nruns = P.run_ptr[bid + 1] - run0;
+  }
+  if (nruns > 0) {
+    if (tid < 5 * nruns) srun[tid] = P.runs[5 * run0 + tid];
+  } else {
+    if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
+    if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
+  }
   if (DLDS)
-    for (int i = tid; i < P.dict_entries; i += BLK) {
-      soff[i] = P.pat_off[i];
-      if (i < P.npat) sptr[i] = P.pat_ptr[i];
+    for (int i = tid; i < DICT_LDS; i += BLK) {
+      if (i < P.dict_entries) soff[i] = P.pat_off[i];
+      if (i <= P.npat) sptr[i] = P.pat_ptr[i];
     }
   int first = 0, po = 0;
-  if (lrow < nrows) {
+  if (nruns == 0 && lrow < nrows) {
     first = P.firstcol[r0 + lrow];
     po = P.pat[r0 + lrow];                      // pattern id; resolved to its dictionary offset below
     if (!DLDS) po = P.pat_ptr[po];
@@ -303,8 +320,23 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
   // ---- row phase: gather addresses come from the pattern, not from a loaded index -----------------
   double acc = 0.0;
   if (lrow < nrows) {
-    const int s = srow[lrow], e = srow[lrow + 1];
-    if (DLDS) po = sptr[po];
+    int s, e;
+    if (nruns > 0) {  // locate the row's run (1-3 runs per grid line) and derive its descriptor
+      int ri = 0;
+      while (ri + 1 < nruns && srun[5 * (ri + 1)] <= lrow) ++ri;
+      const int dr = lrow - srun[5 * ri];
+      po = srun[5 * ri + 1];
+      first = srun[5 * ri + 2] + dr * srun[5 * ri + 3];
+      const int p0 = DLDS ? sptr[po] : P.pat_ptr[po];
+      const int len = (DLDS ? sptr[po + 1] : P.pat_ptr[po + 1]) - p0;
+      s = srun[5 * ri + 4] + dr * len - base;
+      e = s + len;
+      po = p0;
+    } else {
+      s = srow[lrow];
+      e = srow[lrow + 1];
+      if (DLDS) po = sptr[po];
+    }
     const int* off = (DLDS ? soff : P.pat_off) + po - s;  // off[k] for k in [s, e)
     // first 8 entries of the lane: all gathers issued back to back, then summed in stored order
     double xv[8];

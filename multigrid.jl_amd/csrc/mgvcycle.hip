@@ -87,8 +87,10 @@ struct Csr {
   DevBuf<int> rowptr, colidx, blk_row, sched;
   DevBuf<double> val;
   // pattern-coded column indices (csr_pattern_spmv): first column + pattern id per row, offset dictionary
-  DevBuf<int> firstcol, pat_ptr, pat_off;
+  DevBuf<int> firstcol, pat_ptr, pat_off, run_ptr, runs;
   DevBuf<unsigned short> pat;
+  bool has_runs = false;
+  long long nruns_total = 0;
   bool has_pat = false;
   long long npat = 0, dict_entries = 0;
   std::vector<int> h_blk_row;  // host copy of the row-block boundaries (for building schedules)
@@ -115,9 +117,14 @@ struct Csr {
     p.pat_off = pat_off.p;
     p.dict_entries = (int)dict_entries;
     p.npat = (int)npat;
+    p.run_ptr = has_runs ? run_ptr.p : nullptr;
+    p.runs = has_runs ? runs.p : nullptr;
     return p;
   }
   void release() {
+    run_ptr.release();
+    runs.release();
+    has_runs = false;
     firstcol.release();
     pat_ptr.release();
     pat_off.release();
@@ -133,7 +140,7 @@ struct Csr {
   }
   size_t bytes() const {
     return rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes() + sched.bytes() + firstcol.bytes() +
-           pat_ptr.bytes() + pat_off.bytes() + pat.bytes();
+           pat_ptr.bytes() + pat_off.bytes() + pat.bytes() + run_ptr.bytes() + runs.bytes();
   }
 };
 
@@ -273,7 +280,7 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
   if (v.nrhs == 1 && M.has_pat) {
-    const bool dl = M.dict_entries <= mgk::DICT_LDS;
+    const bool dl = M.dict_entries <= mgk::DICT_LDS && M.npat < mgk::DICT_LDS;
     if (M.nt && dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
     else if (M.nt) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
     else if (dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, false, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
@@ -909,6 +916,45 @@ int build_patterns(Csr* M, const std::vector<int>& rp, const std::vector<int>& c
   M->npat = (long long)pptr.size() - 1;
   M->dict_entries = (long long)poff.size();
   M->has_pat = true;
+  // run-length form of the row descriptors, per row block
+  {
+    const char* e = std::getenv("MG_NO_RUNS");
+    if (e && e[0] == '1') return MG_OK;
+  }
+  const int nb = M->nblocks;
+  std::vector<int> rptr((size_t)nb + 1, 0), runs;
+  for (int b = 0; b < nb; ++b) {
+    const int r0 = M->h_blk_row[(size_t)b], r1 = M->h_blk_row[(size_t)b + 1];
+    const size_t mark = runs.size();
+    int count = 0;
+    bool ok = true;
+    int i = r0;
+    while (i < r1) {
+      const int pidv = pid[(size_t)i], f0 = first[(size_t)i];
+      int stride = 0, j = i + 1;
+      if (j < r1 && pid[(size_t)j] == pidv) {
+        stride = first[(size_t)j] - f0;
+        while (j < r1 && pid[(size_t)j] == pidv && first[(size_t)j] == f0 + (j - i) * stride) ++j;
+      }
+      if (++count > mgk::MAXRUNS) { ok = false; break; }
+      runs.push_back(i - r0);
+      runs.push_back(pidv);
+      runs.push_back(f0);
+      runs.push_back(stride);
+      runs.push_back(rp[(size_t)i]);
+      i = j;
+    }
+    const bool longrow = (r1 - r0 == 1) && (rp[(size_t)r1] - rp[(size_t)r0] > mgk::CHUNK - 2);
+    if (!ok || longrow) runs.resize(mark);  // this block keeps the per-row descriptors
+    rptr[(size_t)b + 1] = (int)(runs.size() / 5);
+  }
+  if (runs.empty()) return MG_OK;
+  MG_TRY(M->run_ptr.alloc(rptr.size()));
+  MG_TRY(M->runs.alloc(runs.size()));
+  HIP_TRY(hipMemcpy(M->run_ptr.p, rptr.data(), rptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->runs.p, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice));
+  M->nruns_total = (long long)(runs.size() / 5);
+  M->has_runs = true;
   return MG_OK;
 }
 
@@ -1450,8 +1496,10 @@ int mg_operator_format(mg_hierarchy* h, long long level, long long which, long l
   if (dict_entries) *dict_entries = M->has_pat ? M->dict_entries : 0;
   // bytes of row pointers + column information one nrhs=1 launch streams
   if (index_bytes_per_launch)
-    *index_bytes_per_launch = M->has_pat ? 10.0 * (double)M->n_rows + 4.0 * (double)M->dict_entries
-                                         : 4.0 * (double)M->nnz + 4.0 * (double)(M->n_rows + 1);
+    *index_bytes_per_launch = M->has_pat
+        ? (M->has_runs ? 20.0 * (double)M->nruns_total + 8.0 * (double)M->nblocks : 10.0 * (double)M->n_rows) +
+              4.0 * (double)M->dict_entries
+        : 4.0 * (double)M->nnz + 4.0 * (double)(M->n_rows + 1);
   return MG_OK;
 }
 
