@@ -50,11 +50,15 @@ def _problem(kind, nrhs, cyc):
     return mg, A, p, b, nodes
 
 
-def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q):
+def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo"):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         from multigrid_jl_amd import distributed as dd
         mg, A, p, b, nodes = _problem(kind, nrhs, cyc)
         if nodes is not None:
@@ -63,7 +67,7 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q):
             owner = dd.block_owner(A.shape[0], world)
         if use_hip:
             be = dd.HipBackend(0)
-            comm = dd.TorchComm(stage_through_host=True)
+            comm = dd.TorchComm(stage_through_host=(backend != "nccl"))
         else:
             from dist_cpu_backend import CpuCheckerBackend
             be = CpuCheckerBackend()
@@ -78,7 +82,7 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q):
         H.cycle(b_loc, x2, False)
         be.synchronize()
         out = [None] * world
-        dist.all_gather_object(out, (H.rows_fine, x_loc.cpu().numpy(), x2.cpu().numpy()))
+        dist.all_gather_object(out, (H.rows_fine, x_loc.cpu().numpy(), x2.cpu().numpy()))   # (NCCL: via cuda:0)
         if rank == 0:
             x = np.zeros_like(b)
             xc = np.zeros_like(b)
@@ -94,12 +98,12 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q):
         raise
 
 
-def _run(world, kind, nrhs, cyc, use_hip=False):
+def _run(world, kind, nrhs, cyc, use_hip=False, backend="gloo"):
     from oracle import mg_oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nrhs, cyc, use_hip, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nrhs, cyc, use_hip, q, backend)) for r in range(world)]
     for pr in procs:
         pr.start()
     res = q.get(timeout=300)
@@ -273,6 +277,13 @@ def _run_structured(world, cells, levels, cyc, nrhs, use_hip=False):
                                                         (2, [128, 64], 4, "V", 1), (8, [32, 32, 32], 4, "V", 1)])
 def test_structured_setup_equals_global(built, world, cells, levels, cyc, nrhs):
     _run_structured(world, cells, levels, cyc, nrhs)
+
+
+@pytest.mark.gpu
+def test_hip_distributed_over_rccl_world1(built):
+    """The un-staged RCCL code path (device tensors straight into torch.distributed 'nccl': all_gather_into_tensor,
+    all_reduce, all_gather_object) with the one rank a single-GPU box allows."""
+    _run(1, "gmg3d", 1, "V", use_hip=True, backend="nccl")
 
 
 @pytest.mark.gpu
