@@ -28,8 +28,18 @@ namespace mgk {
 constexpr int BLK = MG_BLK;         // threads per workgroup (4 waves)
 constexpr int ITEMS = MG_ITEMS;     // non-zeros per thread per chunk
 constexpr int CHUNK = BLK * ITEMS;  // 2048 non-zeros staged per workgroup (16 KiB of products)
-constexpr int MAXROWS = BLK;        // rows per row block (one LDS row-pointer slot per thread)
+#ifndef MG_MAXROWS
+#define MG_MAXROWS MG_BLK
+#endif
+constexpr int MAXROWS = MG_MAXROWS;        // rows per row block (one LDS row-pointer slot per thread)
 constexpr int PAIRS = ITEMS / 2;
+// The block-RHS kernels use their own, smaller row blocks: half the LDS per workgroup lets the wave limit (8
+// workgroups per CU) instead of LDS set the occupancy - measured on C5: fused sweep 2.51 -> 2.18 ms
+// (profiles/r01_nt_ab.md).
+constexpr int MM_ITEMS = 4;
+constexpr int MM_CHUNK = BLK * MM_ITEMS;  // 1024 non-zeros (values + column indices: 12 KiB of LDS)
+constexpr int MM_MAXROWS = 128;
+constexpr int MM_PAIRS = MM_ITEMS / 2;
 
 enum Mode { AXPBY = 0, RESID = 1, SMOOTH = 2 };
 
@@ -390,9 +400,9 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
 // ------------------------------------------------------------------------------------------------
 template <int MODE, bool NT>
 __global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int G) {
-  __shared__ double sval[CHUNK];
-  __shared__ int scol[CHUNK];
-  __shared__ int srow[MAXROWS + 1];
+  __shared__ double sval[MM_CHUNK];
+  __shared__ int scol[MM_CHUNK];
+  __shared__ int srow[MM_MAXROWS + 1];
 
   const int tid = threadIdx.x;
   int bid = xcd_band(blockIdx.x, A.nblocks);
@@ -407,11 +417,11 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int 
   const int c = tid - grp * G;
   const int ngrp = BLK / G;
 
-  const bool longrow = (nrows == 1 && (k1 - k0) > CHUNK - 2);
+  const bool longrow = (nrows == 1 && (k1 - k0) > MM_CHUNK - 2);
   if (!longrow) {
     const int base = k0 & ~1;
 #pragma unroll
-    for (int it = 0; it < PAIRS; ++it) {
+    for (int it = 0; it < MM_PAIRS; ++it) {
       const int idx = base + it * (2 * BLK) + 2 * tid;
       if (idx < k1) {
         *reinterpret_cast<d2_t*>(&sval[it * (2 * BLK) + 2 * tid]) = load_stream<NT>(A.val + idx);
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int 
       }
     }
     if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
-    if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
+    if (tid == 0 && nrows == MM_MAXROWS) srow[MM_MAXROWS] = k1 - base;
     __syncthreads();
   }
   for (int c0 = 0; c0 < nrhs; c0 += G) {

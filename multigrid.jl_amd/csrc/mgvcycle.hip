@@ -85,6 +85,10 @@ struct Csr {
   bool set = false;
   long long n_rows = 0, n_cols = 0, nnz = 0;
   DevBuf<int> rowptr, colidx, blk_row, sched;
+  DevBuf<int> blk_row_mm, sched_mm;  // second, smaller row-block partition for the block-RHS kernels
+  std::vector<int> h_blk_row_mm;
+  bool has_sched_mm = false;
+  int nblocks_mm = 0;
   DevBuf<double> val;
   // pattern-coded column indices (csr_pattern_spmv): first column + pattern id per row, offset dictionary
   DevBuf<int> firstcol, pat_ptr, pat_off, run_ptr, runs;
@@ -107,6 +111,13 @@ struct Csr {
     d.nblocks = nblocks;
     d.n_rows = (int)n_rows;
     d.n_cols = (int)n_cols;
+    return d;
+  }
+  mgk::CsrDev dev_mm() const {
+    mgk::CsrDev d = dev();
+    d.blk_row = blk_row_mm.p;
+    d.sched = has_sched_mm ? sched_mm.p : nullptr;
+    d.nblocks = nblocks_mm;
     return d;
   }
   mgk::PatDev patdev() const {
@@ -135,11 +146,14 @@ struct Csr {
     blk_row.release();
     sched.release();
     has_sched = false;
+    blk_row_mm.release();
+    sched_mm.release();
+    has_sched_mm = false;
     val.release();
     set = false;
   }
   size_t bytes() const {
-    return rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes() + sched.bytes() + firstcol.bytes() +
+    return blk_row_mm.bytes() + sched_mm.bytes() + rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes() + sched.bytes() + firstcol.bytes() +
            pat_ptr.bytes() + pat_off.bytes() + pat.bytes() + run_ptr.bytes() + runs.bytes();
   }
 };
@@ -290,8 +304,9 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
     else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), v);
   } else {
     const int G = pow2_ge(v.nrhs);
-    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, true>), grid, blk, 0, stream, M.dev(), v, G);
-    else hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, false>), grid, blk, 0, stream, M.dev(), v, G);
+    const dim3 grid_mm(M.nblocks_mm);
+    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, true>), grid_mm, blk, 0, stream, M.dev_mm(), v, G);
+    else hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, false>), grid_mm, blk, 0, stream, M.dev_mm(), v, G);
   }
   HIP_TRY(hipGetLastError());
   return MG_OK;
@@ -781,8 +796,15 @@ int download_block(mg_hierarchy* h, const double* dev, double* host, long long n
 // three planes of the gathered vector (x nrhs) exceed an XCD's 4 MiB L2 those gathers miss.  Walking the
 // grid in y-tiles (all z for T consecutive y-lines, then the next tile) brings the reuse distance down to
 // ~2T lines.  Pure scheduling: every block computes exactly what it computed before.
+int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const std::vector<int>& h_blk, int nb,
+                       DevBuf<int>& sched, bool& has);
 int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
-  M.has_sched = false;
+  MG_TRY(build_schedule_for(M, grid, nrhs, M.h_blk_row, M.nblocks, M.sched, M.has_sched));
+  return build_schedule_for(M, grid, nrhs, M.h_blk_row_mm, M.nblocks_mm, M.sched_mm, M.has_sched_mm);
+}
+int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const std::vector<int>& h_blk, int nb,
+                       DevBuf<int>& sched, bool& has) {
+  has = false;
   if (!M.set || grid[0] <= 0) return MG_OK;
   const long long n1 = grid[0], n2 = grid[1], n3 = std::max<long long>(1, grid[2]);
   if (n1 * n2 * n3 != M.n_rows || n3 < 2 || n2 < 8) return MG_OK;
@@ -794,19 +816,18 @@ int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
   if (plane_window <= budget) return MG_OK;  // natural order already keeps the window in L2
   long long T = (long long)(budget / line_bytes);
   T = std::max<long long>(4, std::min<long long>(T, n2));
-  const int nb = M.nblocks;
   std::vector<long long> key((size_t)nb);
   for (int b = 0; b < nb; ++b) {
-    const long long r0 = M.h_blk_row[(size_t)b];
+    const long long r0 = h_blk[(size_t)b];
     const long long y = (r0 / n1) % n2, z = r0 / (n1 * n2);
     key[(size_t)b] = ((y / T) * n3 + z) * n2 + y;
   }
   std::vector<int> order((size_t)nb);
   for (int b = 0; b < nb; ++b) order[(size_t)b] = b;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
-  MG_TRY(M.sched.alloc((size_t)nb));
-  HIP_TRY(hipMemcpy(M.sched.p, order.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice));
-  M.has_sched = true;
+  MG_TRY(sched.alloc((size_t)nb));
+  HIP_TRY(hipMemcpy(sched.p, order.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice));
+  has = true;
   return MG_OK;
 }
 
@@ -988,17 +1009,22 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
     if (c < 0 || c >= n_cols) return fail(MG_ERR_INVALID, "rowval[%lld]=%lld outside 1..%lld", k + 1, rowval[k], n_cols);
     ci[(size_t)k] = (int)c;
   }
-  // row blocks: consecutive rows, <= MAXROWS rows and an (even-aligned) nnz span <= CHUNK
-  std::vector<int> blk;
-  blk.push_back(0);
-  long long r = 0;
-  while (r < n_rows) {
-    const long long base = rp[(size_t)r] & ~1LL;
-    long long e = r + 1;  // a block always holds at least one row (a longer row takes the long-row path)
-    while (e < n_rows && (e - r) < mgk::MAXROWS && (rp[(size_t)e + 1] - base) <= mgk::CHUNK) ++e;
-    blk.push_back((int)e);
-    r = e;
-  }
+  // row blocks: consecutive rows, <= maxrows rows and an (even-aligned) nnz span <= chunk
+  auto make_blocks = [&](int maxrows, int chunk) {
+    std::vector<int> bl;
+    bl.push_back(0);
+    long long r = 0;
+    while (r < n_rows) {
+      const long long base = rp[(size_t)r] & ~1LL;
+      long long e = r + 1;  // a block always holds at least one row (a longer row takes the long-row path)
+      while (e < n_rows && (e - r) < maxrows && (rp[(size_t)e + 1] - base) <= chunk) ++e;
+      bl.push_back((int)e);
+      r = e;
+    }
+    return bl;
+  };
+  std::vector<int> blk = make_blocks(mgk::MAXROWS, mgk::CHUNK);
+  std::vector<int> blk_mm = make_blocks(mgk::MM_MAXROWS, mgk::MM_CHUNK);
   M->release();
   M->n_rows = n_rows;
   M->n_cols = n_cols;
@@ -1014,6 +1040,10 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
   HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(M->blk_row.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
   M->h_blk_row = blk;
+  M->nblocks_mm = (int)blk_mm.size() - 1;
+  MG_TRY(M->blk_row_mm.alloc(blk_mm.size()));
+  HIP_TRY(hipMemcpy(M->blk_row_mm.p, blk_mm.data(), blk_mm.size() * sizeof(int), hipMemcpyHostToDevice));
+  M->h_blk_row_mm = blk_mm;
   M->set = true;
   // cache policy of the matrix stream: non-temporal once the operator is too large to stay in the
   // 256 MiB Infinity Cache between two uses anyway (measured, profiles/r01_nt_ab.md: +2..17 % on the
