@@ -130,6 +130,16 @@ int mg_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double
 int mg_pcg_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n, double tol,
                     long long maxIter, long long* iters, long long* flag, double* resvec);
 
+/* solveBiCGSTAB_MG (SolveFuncs.jl:87-101): KrylovMethods.bicgstb (external) with M1 = one cycle from x = 0,
+ * M2 = identity.  resvec (length 2*maxIter+1) receives ||r0||/||b|| and two entries per iteration; *nres their
+ * number.  flag: 0 converged, -1 maxIter, -2 breakdown, -3 converged on the half step, -9 b = 0.  nrhs = 1. */
+int mg_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol,
+                     long long maxIter, long long* iters, long long* flag, double* resvec,
+                     long long* nres);
+int mg_bicgstab_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n, double tol,
+                         long long maxIter, long long* iters, long long* flag, double* resvec,
+                         long long* nres);
+
 /* target = beta*target + alpha*Op*x on one level (SpMatMul.jl:4-13); column-major host blocks. */
 int mg_spmv_FP64(mg_hierarchy* h, long long level, long long which, double alpha, const double* x,
                  double beta, double* y, long long nrhs);

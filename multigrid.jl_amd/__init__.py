@@ -10,9 +10,11 @@ from .mgsetup import (MGsetup, getRelaxPrec, getSPAIprec, adjustMemoryForNumRHS,
                       getMultilevelOperatorConstructor, galerkin)
 from .transfer_operators import getFWInterp, get1DFWInterp
 from .sa_amg import (SA_AMGsetup, getAggregation, getStrengthMatrix, neighborhoodAggregationNew, aggrArray2P)
-from .solve_funcs import solveMG, solveCG_MG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
+from .solve_funcs import solveMG, solveCG_MG, solveBiCGSTAB_MG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
 from .operators import (getRegularMesh, getNodalGradientMatrix, getNodalLaplacianMatrix,
                         getNodalDivSigGradMatrix, poisson_shifted, anisotropic_divsiggrad, seeded_rhs)
+from .wrappers import (MGsolver, getMGsolver, getSA_AMGsolver, solveLinearSystem_, setupSolver, copySolverWrapper,
+                       clearSolver_)
 from . import device
 
 __all__ = [n for n in dir() if not n.startswith("_")]

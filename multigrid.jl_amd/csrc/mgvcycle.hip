@@ -201,7 +201,7 @@ struct mg_hierarchy {
   // staging for the host-pointer API
   DevBuf<double> stage_b, stage_x, stage_t;
   // Krylov work vectors (allocated on the first mg_pcg call)
-  DevBuf<double> kr, kz, kp, kAp;
+  DevBuf<double> kr, kz, kp, kAp, kw;
   // fine-level operands of the last cycle/solve (used as inputs by mg_time_op_dev_FP64)
   const double* last_b = nullptr;
   double* last_x = nullptr;
@@ -764,6 +764,105 @@ int pcg_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long m
   return MG_OK;
 }
 
+// Preconditioned BiCGSTAB with the multigrid cycle as M1 (M2 = identity): solveBiCGSTAB_MG (SolveFuncs.jl:87-101)
+// -> KrylovMethods.bicgstb (v0.6.0, un-vendored).  Restated from the published algorithm (van der Vorst 1992 as in
+// Barrett et al., "Templates", which KrylovMethods follows): resvec[0] = ||r0||/||b||, then two entries per
+// iteration (||s||/||b|| after the first half step, ||r||/||b|| after the second); flags: 0 converged,
+// -1 maxIter, -2 breakdown (rho == 0 or omega == 0), -3 converged on the half step, -9 b == 0.
+int bicgstab_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long maxIter, long long* iters,
+                 long long* flag_out, double* resvec, long long* nres) {
+  Level& L = h->lev[0];
+  const long long n = L.n;
+  if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "mg_bicgstab: block right-hand sides (blockBiCGSTB) are not on the device path yet");
+  if (h->kr.n != (size_t)n) {
+    MG_TRY(h->kr.alloc((size_t)n));
+    MG_TRY(h->kz.alloc((size_t)n));
+    MG_TRY(h->kp.alloc((size_t)n));
+    MG_TRY(h->kAp.alloc((size_t)n));
+  }
+  if (h->kw.n != (size_t)n * 4) MG_TRY(h->kw.alloc((size_t)n * 4));
+  double* r = h->kr.p;       // residual, then s
+  double* phat = h->kz.p;    // M p / M s
+  double* p = h->kp.p;
+  double* v = h->kAp.p;
+  double* rtld = h->kw.p;
+  double* t = h->kw.p + n;
+  double* shat = h->kw.p + 2 * n;
+  double bn = 0.0, err = 0.0;
+  MG_TRY(norm_sync(h, b, n, &bn));
+  long long it = 0, flag = -1, nr = 0;
+  if (bn == 0.0) {
+    MG_TRY(k_fill(h, x, n, 0.0));
+    HIP_TRY(spin_sync(h->stream));
+    if (iters) *iters = 0;
+    if (flag_out) *flag_out = -9;
+    if (nres) *nres = 0;
+    return MG_OK;
+  }
+  MG_TRY(k_residual(h, 0, L.A, b, x, r));
+  MG_TRY(norm_sync(h, r, n, &err));
+  err /= bn;
+  if (resvec) resvec[nr] = err;
+  ++nr;
+  if (err < tol) {
+    if (iters) *iters = 0;
+    if (flag_out) *flag_out = 0;
+    if (nres) *nres = nr;
+    return MG_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(rtld, r, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
+  double omega = 1.0, alpha = 0.0, rho1 = 0.0;
+  for (long long k = 1; k <= maxIter; ++k) {
+    it = k;
+    double rho = 0.0;
+    MG_TRY(dot_sync(h, rtld, r, n, &rho));
+    if (rho == 0.0) { flag = -2; break; }
+    if (k > 1) {
+      const double beta = (rho / rho1) * (alpha / omega);
+      MG_TRY(k_axpby(h, -omega, v, 1.0, p, n));      // p = p - omega v
+      MG_TRY(k_axpby(h, 1.0, r, beta, p, n));        // p = r + beta p
+    } else {
+      HIP_TRY(hipMemcpyAsync(p, r, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
+    }
+    MG_TRY(cycle_dev(h, p, phat, true));              // p_hat = M1(p)
+    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, phat, 0.0, v));
+    double rv = 0.0;
+    MG_TRY(dot_sync(h, rtld, v, n, &rv));
+    alpha = rho / rv;
+    MG_TRY(k_axpby(h, -alpha, v, 1.0, r, n));         // s = r - alpha v (in r)
+    double sn = 0.0;
+    MG_TRY(norm_sync(h, r, n, &sn));
+    if (resvec) resvec[nr] = sn / bn;
+    ++nr;
+    if (sn / bn < tol) {                              // converged on the half step
+      MG_TRY(k_axpby(h, alpha, phat, 1.0, x, n));
+      flag = -3;
+      break;
+    }
+    MG_TRY(cycle_dev(h, r, shat, true));              // s_hat = M1(s)
+    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, shat, 0.0, t));
+    double ts = 0.0, tt = 0.0;
+    MG_TRY(dot_sync(h, t, r, n, &ts));
+    MG_TRY(dot_sync(h, t, t, n, &tt));
+    omega = ts / tt;
+    MG_TRY(k_axpby(h, alpha, phat, 1.0, x, n));
+    MG_TRY(k_axpby(h, omega, shat, 1.0, x, n));       // x += alpha p_hat + omega s_hat
+    MG_TRY(k_axpby(h, -omega, t, 1.0, r, n));         // r = s - omega t
+    MG_TRY(norm_sync(h, r, n, &err));
+    err /= bn;
+    if (resvec) resvec[nr] = err;
+    ++nr;
+    if (err <= tol) { flag = 0; break; }
+    if (omega == 0.0) { flag = -2; break; }
+    rho1 = rho;
+  }
+  HIP_TRY(spin_sync(h->stream));
+  if (iters) *iters = it;
+  if (flag_out) *flag_out = flag;
+  if (nres) *nres = nr;
+  return MG_OK;
+}
+
 // ---- host <-> device block transfer (column-major host <-> row-major device) --------------------
 int upload_block(mg_hierarchy* h, const double* host, double* dev, long long n, long long nrhs) {
   const size_t bytes = sizeof(double) * (size_t)n * (size_t)nrhs;
@@ -1133,6 +1232,7 @@ int mg_destroy(mg_hierarchy* h) {
   h->kz.release();
   h->kp.release();
   h->kAp.release();
+  h->kw.release();
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
   if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1402,6 +1502,29 @@ int mg_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double
   MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
   MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
   MG_TRY(pcg_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec));
+  MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_bicgstab_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol,
+                         long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
+  MG_TRY(check_ready(h, n, 1));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(bicgstab_dev(h, b, x, tol, maxIter, iters, flag, resvec, nres));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol, long long maxIter,
+                     long long* iters, long long* flag, double* resvec, long long* nres) {
+  MG_TRY(check_ready(h, n, 1));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
+  MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
+  MG_TRY(bicgstab_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec, nres));
   MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
   prof_collect(h);
   return MG_OK;

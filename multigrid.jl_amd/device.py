@@ -49,6 +49,8 @@ SIGNATURES = {
     "mg_solve_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
     "mg_pcg_FP64": (C.c_int, [_vp, _dp, _dp, _ll, C.c_double, _ll, _lp, _lp, _dp]),
     "mg_pcg_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _lp, _dp]),
+    "mg_bicgstab_FP64": (C.c_int, [_vp, _dp, _dp, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
+    "mg_bicgstab_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
     "mg_spmv_FP64": (C.c_int, [_vp, _ll, _ll, C.c_double, _dp, C.c_double, _dp, _ll]),
     "mg_cycle_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
     "mg_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
@@ -257,6 +259,18 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_pcg_FP64(self.handle, _f64(b), _f64(x), b.shape[0], float(tol), int(maxIter),
                                               C.byref(iters), C.byref(flag), _f64(resvec)), "mg_pcg")
         return x, int(flag.value), int(iters.value), resvec[: iters.value]
+
+    def bicgstab(self, b, x, tol: float, maxIter: int):
+        """KrylovMethods.bicgstb with the MG cycle as M1; returns (x, flag, iters, resvec)."""
+        b = self._host_block(b)
+        x = self._host_block(x, True)
+        if b.ndim != 1:
+            raise MGDeviceError("mg_bicgstab: one right-hand side only (blockBiCGSTB is not on the device path)")
+        iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        resvec = np.zeros(2 * int(maxIter) + 1)
+        _check(self.lib, self.lib.mg_bicgstab_FP64(self.handle, _f64(b), _f64(x), b.shape[0], float(tol), int(maxIter),
+                                                   C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)), "mg_bicgstab")
+        return x, int(flag.value), int(iters.value), resvec[: nres.value]
 
     def pcg_dev(self, b, x, tol: float, maxIter: int):
         iters, flag = C.c_longlong(0), C.c_longlong(0)

@@ -79,6 +79,18 @@ def solveCG_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, verbose: bool =
     return x, param, it
 
 
+def solveBiCGSTAB_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, verbose: bool = False):
+    """``(x, param, iter, nprec) = solveBiCGSTAB_MG(AT,param,b,x0,verbose)`` (SolveFuncs.jl:87-101): KrylovMethods.bicgstb
+    with M1 = the multigrid cycle, M2 = identity, on the device.  One right-hand side."""
+    adjustMemoryForNumRHS(param, _ncols(b))
+    dev = to_device(param)
+    x, flag, it, resvec = dev.bicgstab(b, x0, param.relativeTol, param.maxOuterIter)
+    param.resvec = resvec
+    param.flag = flag
+    nprec = 2 * it * _ncols(b) + (flag == -3) * _ncols(b)        # SolveFuncs.jl:99 as written
+    return x, param, it, nprec
+
+
 _WHICH = {"A": MG_OP_A, "P": MG_OP_P, "R": MG_OP_R}
 
 

@@ -533,3 +533,67 @@ def solveCG_MG(param, b, x0):
     x, flag, rn, it, resvec = cg(lambda v: A @ v, b, tol=param.relativeTol, maxIter=param.maxOuterIter,
                                  M=getMultigridPreconditioner(param, b), x=x0)
     return x, flag, it, resvec
+
+
+def bicgstb(Afun, b, tol=1e-6, maxIter=100, M1=None, x=None):
+    """KrylovMethods.bicgstb (v0.6.0, un-vendored) as called by solveBiCGSTAB_MG (SolveFuncs.jl:87-101), restated from
+    the published algorithm (van der Vorst; Barrett et al. 'Templates').  M2 = identity.  Flags as documented in
+    include/mgvcycle.h (mg_bicgstab_FP64)."""
+    n = b.size
+    bn = np.linalg.norm(b)
+    if bn == 0:
+        return np.zeros(n), -9, 0, np.array([0.0])
+    if x is None:
+        x = np.zeros(n)
+    r = b - Afun(x)
+    M = M1 if M1 is not None else (lambda v: v.copy())
+    resvec = [np.linalg.norm(r) / bn]
+    if resvec[0] < tol:
+        return x, 0, 0, np.array(resvec)
+    rtld = r.copy()
+    omega, alpha, rho1 = 1.0, 0.0, 0.0
+    p = np.zeros(n)
+    v = np.zeros(n)
+    flag, it = -1, 0
+    for k in range(1, maxIter + 1):
+        it = k
+        rho = np.dot(rtld, r)
+        if rho == 0.0:
+            flag = -2
+            break
+        if k > 1:
+            beta = (rho / rho1) * (alpha / omega)
+            p = r + beta * (p - omega * v)
+        else:
+            p = r.copy()
+        phat = M(p)
+        v = Afun(phat)
+        alpha = rho / np.dot(rtld, v)
+        s = r - alpha * v
+        sn = np.linalg.norm(s) / bn
+        resvec.append(sn)
+        if sn < tol:
+            x += alpha * phat
+            flag = -3
+            break
+        shat = M(s)
+        t = Afun(shat)
+        omega = np.dot(t, s) / np.dot(t, t)
+        x += alpha * phat + omega * shat
+        r = s - omega * t
+        err = np.linalg.norm(r) / bn
+        resvec.append(err)
+        if err <= tol:
+            flag = 0
+            break
+        if omega == 0.0:
+            flag = -2
+            break
+        rho1 = rho
+    return x, flag, it, np.array(resvec)
+
+
+def solveBiCGSTAB_MG(param, b, x0):
+    A = param.As[0]
+    return bicgstb(lambda v: A @ v, b, tol=param.relativeTol, maxIter=param.maxOuterIter,
+                   M1=getMultigridPreconditioner(param, b), x=x0)

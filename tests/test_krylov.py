@@ -57,3 +57,76 @@ def test_device_pcg_matches_oracle(mg, built, kind):
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-8
     mg.clear_(p)
+
+
+def test_reference_threshold_bicgstab_sa(mg, built):
+    """testSAforDivSigGrad.jl:47-50: BiCGSTAB preconditioned with SA-AMG -> ||Ax-b|| < 0.005 (tol 1e-4, 5 iterations)."""
+    A, p, b = _sa_problem(mg, [50, 50], 1e-8)
+    x, flag, it, rv = orc.solveBiCGSTAB_MG(p, b, np.zeros_like(b))
+    assert np.linalg.norm(A @ x - b) < 0.005
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sa2d", "gmg3d"])
+def test_device_bicgstab_matches_oracle(mg, built, kind):
+    if kind == "sa2d":
+        A, p, b = _sa_problem(mg, [50, 50], 1e-8)
+        p.relativeTol, p.maxOuterIter = 1e-9, 30
+    else:
+        A, mesh = mg.poisson_shifted([24, 24, 24])
+        p = mg.getMGparam(np.float64, np.int64, 3, 8, 10, 1e-9, "Jac", 0.8, 2, 2, "V", "NoMUMPS", 0.5, 0.0)
+        mg.MGsetup(A, mesh, p)
+        b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    x, _, it, nprec = mg.solveBiCGSTAB_MG(A, p, b, x)
+    xo, flag, ito, rvo = orc.solveBiCGSTAB_MG(p, b, np.zeros_like(b))
+    assert it == ito and p.flag == flag and flag in (0, -3)
+    assert len(p.resvec) == len(rvo)
+    assert np.abs(p.resvec - rvo).max() / rvo[0] < 1e-8
+    assert np.abs(x - xo).max() <= 1e-8 * np.abs(xo).max()
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-8
+    mg.clear_(p)
+
+
+# ---- jInv solver wrappers (MGWrapper.jl, SAAMGWrapper.jl) -------------------------------------------------------
+def test_wrapper_host_logic(mg, built):
+    A, mesh = mg.poisson_shifted([8, 8])
+    p = mg.getMGparam(levels=3, relaxType="Jac", relaxParam=0.8, maxIter=7)
+    s = mg.getMGsolver(p, mesh, 1, "PCG")
+    assert s.Krylov == "PCG" and s.tol == p.relativeTol and s.MG.Meshes[0] is mesh and s.nIter == 0
+    c = mg.copySolverWrapper(s)
+    assert c.MG is not s.MG and c.MG.maxOuterIter == 7 and not mg.hierarchyExists(c.MG)
+    X = np.ones(A.shape[0])
+    mg.solveLinearSystem_(A, np.zeros(A.shape[0]), X, s)          # norm(B) == 0 -> X = 0, no setup (l.37-40)
+    assert not X.any() and not mg.hierarchyExists(s.MG)
+    mg.setupSolver(A, s)
+    assert mg.hierarchyExists(s.MG)
+    mg.clearSolver_(s)
+    assert not mg.hierarchyExists(s.MG) and s.doClear == 0
+    g = mg.getMGsolver(mg.getMGparam(levels=2, relaxType="Jac"), mesh, 1)      # default Krylov "GMRES"
+    with pytest.raises(NotImplementedError):
+        mg.solveLinearSystem_(A, np.ones(A.shape[0]), np.zeros(A.shape[0]), g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kry", ["PCG", "BiCGSTAB", "MG"])
+def test_wrapper_solves_like_the_reference_tests(mg, built, kry):
+    """testLinSolveMGWrapper.jl:13-39 shape: 2-D 51^2 nodes, 5 levels, V(2,2) SPAI, relres < tol (1e-2)."""
+    from multigrid_jl_amd.operators import getRegularMesh, getNodalLaplacianMatrix, opnorm1
+    mesh = getRegularMesh([0, 1, 0, 1], [48, 48])
+    A = getNodalLaplacianMatrix(mesh)
+    A = (A + 1e-4 * opnorm1(A) * sp.identity(A.shape[0])).tocsr()
+    p = mg.getMGparam(np.float64, np.int64, 5, 8, 10, 1e-2, "SPAI", 1.0, 2, 2, "V", "NoMUMPS")
+    s = mg.getMGsolver(p, mesh, 1, kry)
+    rng = np.random.default_rng(4)
+    B = A @ rng.random(A.shape[0])
+    X = np.zeros_like(B)
+    Xr, s = mg.solveLinearSystem_(A, B, X, s)
+    assert Xr is X and s.nIter > 0 and s.timeSetup > 0 and s.timeSolve > 0
+    assert np.linalg.norm(A @ X - B) / np.linalg.norm(B) < 1e-2
+    sa = mg.getSA_AMGsolver(mg.getMGparam(np.float64, np.int64, 3, 8, 10, 1e-2, "SPAI", 1.0, 1, 1, "V", "Julia"), "PCG")
+    X2 = np.zeros_like(B)
+    mg.solveLinearSystem_(A, B, X2, sa)
+    assert np.linalg.norm(A @ X2 - B) / np.linalg.norm(B) < 1e-2
+    mg.clearSolver_(s)
+    mg.clearSolver_(sa)
