@@ -653,4 +653,72 @@ __global__ __launch_bounds__(BLK) void dense_apply(const double* __restrict__ Ai
   if (lane == 0) x[(size_t)row * nrhs + c] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Numeric Galerkin product on a FIXED sparsity: C = R*(A*P) (replaceMatrixInHierarchy, MGsetup.jl:226-270:
+// `Act = Ps[l]*AT*Rs[l]` with unchanged P, R; the pattern of C is the one the host setup produced).
+// One wavefront (a 64-thread workgroup) per coarse row i: lanes split the entries (i,k) of R's row, walk A's
+// row k and P's rows j, find the column in C's (sorted) row by binary search in LDS and accumulate there
+// with LDS atomics.  Rows of C longer than RAP_CAP are left to the host path.
+// ------------------------------------------------------------------------------------------------
+constexpr int RAP_CAP = 1024;
+__global__ __launch_bounds__(64) void rap_numeric(CsrDev R, CsrDev A, CsrDev P, const int* __restrict__ Crowptr,
+                                                  const int* __restrict__ Ccol, double* __restrict__ Cval) {
+  __shared__ int scol[RAP_CAP];
+  __shared__ double sacc[RAP_CAP];
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int c0 = Crowptr[i];
+  const int len = Crowptr[i + 1] - c0;
+  for (int t = lane; t < len; t += 64) {
+    scol[t] = Ccol[c0 + t];
+    sacc[t] = 0.0;
+  }
+  __syncthreads();
+  for (int kk = R.rowptr[i] + lane; kk < R.rowptr[i + 1]; kk += 64) {
+    const int k = R.colidx[kk];
+    const double rv = R.val[kk];
+    for (int jj = A.rowptr[k]; jj < A.rowptr[k + 1]; ++jj) {
+      const int j = A.colidx[jj];
+      const double ra = rv * A.val[jj];
+      for (int pp = P.rowptr[j]; pp < P.rowptr[j + 1]; ++pp) {
+        const int c = P.colidx[pp];
+        if (len == 0) continue;
+        int lo = 0, hi = len - 1;
+        while (lo < hi) {  // the pattern of C contains every reachable column by construction
+          const int mid = (lo + hi) >> 1;
+          if (scol[mid] < c) lo = mid + 1;
+          else hi = mid;
+        }
+        if (scol[lo] == c) atomicAdd(&sacc[lo], ra * P.val[pp]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = lane; t < len; t += 64) Cval[c0 + t] = sacc[t];
+}
+
+// d[i] = omega / a_ii  (getRelaxPrec "Jac", MGsetup.jl:145-147); s[j] += a_ij^2 (getSPAIprec, MGsetup.jl:359-362)
+__global__ __launch_bounds__(BLK) void relax_jacobi(CsrDev A, double omega, double* __restrict__ d) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= A.n_rows) return;
+  double diag = 0.0;
+  for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+    if (A.colidx[k] == i) diag = A.val[k];
+  d[i] = omega / diag;
+}
+__global__ __launch_bounds__(BLK) void colsumsq_kernel(CsrDev A, double* __restrict__ s) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= A.n_rows) return;
+  for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) atomicAdd(&s[A.colidx[k]], A.val[k] * A.val[k]);
+}
+__global__ __launch_bounds__(BLK) void relax_spai(CsrDev A, double omega, const double* __restrict__ s,
+                                                  double* __restrict__ d) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= A.n_rows) return;
+  double diag = 0.0;
+  for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+    if (A.colidx[k] == i) diag = A.val[k];
+  d[i] = omega * diag / s[i];
+}
+
 }  // namespace mgk

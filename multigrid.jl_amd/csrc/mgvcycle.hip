@@ -98,6 +98,7 @@ struct Csr {
   bool has_pat = false;
   long long npat = 0, dict_entries = 0;
   std::vector<int> h_blk_row;  // host copy of the row-block boundaries (for building schedules)
+  int max_row_nnz = 0;
   bool has_sched = false;
   int nblocks = 0;
   bool nt = false;  // non-temporal loads of the matrix stream (mg_kernels.hpp load_stream)
@@ -1139,6 +1140,8 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
   HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(M->blk_row.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
   M->h_blk_row = blk;
+  M->max_row_nnz = 0;
+  for (long long i = 0; i < n_rows; ++i) M->max_row_nnz = std::max(M->max_row_nnz, rp[(size_t)i + 1] - rp[(size_t)i]);
   M->nblocks_mm = (int)blk_mm.size() - 1;
   MG_TRY(M->blk_row_mm.alloc(blk_mm.size()));
   HIP_TRY(hipMemcpy(M->blk_row_mm.p, blk_mm.data(), blk_mm.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1202,6 +1205,70 @@ int mg_create(long long nlevels, long long nrhs, long long device_id, mg_hierarc
     return fail(MG_ERR_HIP, "allocation of reduction scratch failed");
   }
   *out = h;
+  return MG_OK;
+}
+
+// replaceMatrixInHierarchy on the device (MGsetup.jl:226-270): new fine values (same sparsity), then per level
+// relaxPrecs[l] = getRelaxPrec(As[l]) and As[l+1] = Ps[l]*As[l]*Rs[l] on the fixed patterns.  The coarsest
+// factorisation stays with the host: fetch the coarsest values with mg_get_values_FP64, factor, hand the
+// inverse back with mg_set_coarse_dense_inverse_FP64 and call mg_finalize.
+int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long long relaxKind,
+                const double* omega, long long* levels_done) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  if (!fine_nzval || !omega) return fail(MG_ERR_INVALID, "null argument");
+  if (relaxKind != 0 && relaxKind != 1) return fail(MG_ERR_INVALID, "relaxKind must be 0 (Jac) or 1 (SPAI)");
+  Level& L0 = h->lev[0];
+  if (nnz != L0.A.nnz) return fail(MG_ERR_INVALID, "nnz=%lld differs from the stored fine pattern (%lld)", nnz, L0.A.nnz);
+  (void)hipSetDevice(h->device);
+  const int nl = (int)h->nlevels;
+  for (int l = 0; l + 1 < nl; ++l)
+    if (h->lev[(size_t)l + 1].A.max_row_nnz > mgk::RAP_CAP) {
+      if (levels_done) *levels_done = 0;
+      return fail(MG_ERR_UNSUPPORTED, "As[%d] has rows with %d entries (> %d): use the host path", l + 2,
+                  h->lev[(size_t)l + 1].A.max_row_nnz, mgk::RAP_CAP);
+    }
+  HIP_TRY(spin_sync(h->stream));
+  HIP_TRY(hipMemcpyAsync(L0.A.val.p, fine_nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  for (int l = 0; l + 1 < nl; ++l) {
+    Level& L = h->lev[(size_t)l];
+    Level& C = h->lev[(size_t)l + 1];
+    const int nb = (int)((L.n + mgk::BLK - 1) / mgk::BLK);
+    if (relaxKind == 0) {
+      hipLaunchKernelGGL(mgk::relax_jacobi, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), omega[l], L.d.p);
+    } else {
+      HIP_TRY(hipMemsetAsync(L.r.p, 0, sizeof(double) * (size_t)L.n, h->stream));  // L.r as scratch for the column sums
+      hipLaunchKernelGGL(mgk::colsumsq_kernel, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), L.r.p);
+      hipLaunchKernelGGL(mgk::relax_spai, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), omega[l], L.r.p, L.d.p);
+    }
+    hipLaunchKernelGGL(mgk::rap_numeric, dim3((unsigned)C.n), dim3(64), 0, h->stream, L.R.dev(), L.A.dev(), L.P.dev(),
+                       C.A.rowptr.p, C.A.colidx.p, C.A.val.p);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(spin_sync(h->stream));
+  if (levels_done) *levels_done = nl - 1;
+  return MG_OK;
+}
+
+int mg_get_values_FP64(mg_hierarchy* h, long long level, long long which, double* out, long long nnz) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  Csr* M = pick(h, level, which);
+  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
+  if (!out || nnz != M->nnz) return fail(MG_ERR_INVALID, "nnz=%lld differs from the stored pattern (%lld)", nnz, M->nnz);
+  (void)hipSetDevice(h->device);
+  HIP_TRY(spin_sync(h->stream));
+  HIP_TRY(hipMemcpy(out, M->val.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
+  return MG_OK;
+}
+
+int mg_get_relax_FP64(mg_hierarchy* h, long long level, double* out, long long n) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  Level& L = h->lev[(size_t)level - 1];
+  if (!out || !L.relax_set || n != (long long)L.d.n) return fail(MG_ERR_INVALID, "relaxPrecs[%lld] not set or wrong length", level);
+  (void)hipSetDevice(h->device);
+  HIP_TRY(spin_sync(h->stream));
+  HIP_TRY(hipMemcpy(out, L.d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return MG_OK;
 }
 

@@ -44,6 +44,9 @@ SIGNATURES = {
     "mg_finalize": (C.c_int, [_vp]),
     "mg_set_nrhs": (C.c_int, [_vp, _ll]),
     "mg_replace_values_FP64": (C.c_int, [_vp, _ll, _ll, _dp, _ll]),
+    "mg_rap_FP64": (C.c_int, [_vp, _dp, _ll, _ll, _dp, _lp]),
+    "mg_get_values_FP64": (C.c_int, [_vp, _ll, _ll, _dp, _ll]),
+    "mg_get_relax_FP64": (C.c_int, [_vp, _ll, _dp, _ll]),
     "mg_destroy": (C.c_int, [_vp]),
     "mg_cycle_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, _ll]),
     "mg_solve_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
@@ -205,6 +208,35 @@ class DeviceHierarchy:
         nz = np.ascontiguousarray(M.data, dtype=np.float64)
         _check(self.lib, self.lib.mg_replace_values_FP64(self.handle, level, which, _f64(nz), nz.size),
                "mg_replace_values")
+
+    def replace_matrix(self, param, A_new) -> None:
+        """replaceMatrixInHierarchy on the device: numeric Galerkin products + relaxPrecs on the fixed patterns
+        (mg_rap_FP64), host copies of the hierarchy refreshed from HBM, coarsest level re-factored on the host."""
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        lib = self.lib
+        nz = np.ascontiguousarray(A_new.data, dtype=np.float64)
+        rp = param.relaxParam
+        omega = np.ascontiguousarray([float(rp[l]) if isinstance(rp, (list, tuple, np.ndarray)) else float(rp)
+                                      for l in range(self.nlevels)], dtype=np.float64)
+        kind = 1 if param.relaxType == "SPAI" else 0
+        done = C.c_longlong(0)
+        _check(lib, lib.mg_rap_FP64(self.handle, _f64(nz), nz.size, kind, _f64(omega), C.byref(done)), "mg_rap")
+        param.As[0] = A_new
+        for l in range(2, self.nlevels + 1):                       # refresh the host copies (same patterns)
+            M = param.As[l - 1]
+            vals = np.empty(M.nnz, dtype=np.float64)
+            _check(lib, lib.mg_get_values_FP64(self.handle, l, MG_OP_A, _f64(vals), vals.size), "mg_get_values")
+            M.data[:] = vals
+        for l in range(1, self.nlevels):
+            d = np.empty(param.As[l - 1].shape[0], dtype=np.float64)
+            _check(lib, lib.mg_get_relax_FP64(self.handle, l, _f64(d), d.size), "mg_get_relax")
+            param.relaxPrecs[l - 1] = d
+        param.LU = spla.splu(sp.csc_matrix(param.As[-1]))          # defineCoarsestAinv (MGsetup.jl:350)
+        nc = int(param.As[-1].shape[0])
+        Ainv = np.asfortranarray(param.LU.solve(np.eye(nc)))
+        _check(lib, lib.mg_set_coarse_dense_inverse_FP64(self.handle, nc, _f64(Ainv)), "mg_set_coarse_dense_inverse")
+        _check(lib, lib.mg_finalize(self.handle), "mg_finalize")
 
     def close(self):
         if self.handle:

@@ -169,7 +169,20 @@ def adjustMemoryForNumRHS(param: MGparam, nrhs: int = 1, verbose: bool = False) 
 def replaceMatrixInHierarchy(param: MGparam, A, verbose: bool = False) -> None:
     """New fine matrix, same P/R: recompute relaxPrecs, Galerkin products and the coarse LU (MGsetup.jl:226-270)."""
     relaxParamArr = _relax_param_arr(param)
-    param.As[0] = _as_csr(A)
+    A = _as_csr(A)
+    if param.device is not None and param.relaxType in ("Jac", "Jac-GMRES", "SPAI"):
+        old = param.As[0]
+        same = (A.shape == old.shape and A.nnz == old.nnz and np.array_equal(A.indptr, old.indptr)
+                and np.array_equal(A.indices, old.indices))
+        if same:
+            from .device import MGDeviceError
+            try:   # numeric-only Galerkin products on the device (fixed P, R and patterns: SURVEY 8f-2)
+                param.device.replace_matrix(param, A)
+                param.doTranspose = 0
+                return
+            except MGDeviceError:
+                pass   # e.g. SA-AMG rows beyond the kernel's cap: the host path below applies
+    param.As[0] = A
     for l in range(1, param.levels):
         Al = param.As[l - 1]
         param.relaxPrecs[l - 1] = getRelaxPrec(Al, param.relaxType, relaxParamArr[l - 1])

@@ -250,3 +250,38 @@ def test_pattern_coded_kernel_paths(mg, built, monkeypatch):
             scale = np.abs(w).max()
             assert np.abs(got0 - w).max() / scale < KERNEL_TOL
             assert np.abs(got1 - w).max() / scale < KERNEL_TOL
+
+
+@pytest.mark.parametrize("relaxType,omega,cells", [("Jac", 0.8, [16, 16, 16]), ("SPAI", 1.0, [24, 20])])
+def test_replace_matrix_on_device(mg, built, relaxType, omega, cells):
+    """replaceMatrixInHierarchy (MGsetup.jl:226-270) with a resident hierarchy: the numeric Galerkin products and
+    relaxPrecs are recomputed on the device (mg_rap_FP64) and must equal the host products; the following solve must
+    match the oracle on the refreshed host hierarchy."""
+    import scipy.sparse as sp
+    from multigrid_jl_amd.mgsetup import galerkin
+    A, mesh = mg.poisson_shifted(cells)
+    p = mg.getMGparam(np.float64, np.int64, 3, 8, 6, 1e-10, relaxType, omega, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p)
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    mg.solveMG(p, b, x)                                   # uploads the hierarchy
+    assert p.device is not None
+    rng = np.random.default_rng(8)
+    A2 = A.copy()
+    A2.data = A.data * (1.0 + 0.3 * rng.random(A.nnz))    # same sparsity, new (non-symmetric) values
+    A2 = (A2 + sp.diags(np.full(A.shape[0], A.diagonal().max()))).tocsr()
+    A2.sort_indices()
+    assert np.array_equal(A2.indices, A.indices)
+    dev_before = p.device
+    mg.replaceMatrixInHierarchy(p, A2)
+    assert p.device is dev_before                         # stayed resident: the device path was taken
+    Al = A2
+    for l in range(len(p.As) - 1):
+        assert np.allclose(p.relaxPrecs[l], mg.getRelaxPrec(Al, relaxType, omega), rtol=1e-13)
+        Al = galerkin(p.Rs[l], Al, p.Ps[l])
+        assert np.array_equal(Al.indices, p.As[l + 1].indices)
+        assert np.abs(Al.data - p.As[l + 1].data).max() <= 1e-13 * np.abs(Al.data).max()
+    b2 = A2 @ rng.random(A.shape[0])
+    b2 /= np.linalg.norm(b2)
+    _compare_solve(mg, p, b2)
+    mg.clear_(p)
