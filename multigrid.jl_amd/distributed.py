@@ -449,9 +449,19 @@ class DistributedHierarchy:
         self.x_tail = be.zeros(nt, k) if k > 1 else be.zeros(nt)
         self.rows_fine = np.asarray(rows_fine)
 
+    @staticmethod
+    def check_supported(param: MGparam):
+        """The sharded schedule implements the pointwise smoothers and V/W/F cycles; anything else must fail loudly
+        rather than silently run a different method."""
+        if param.relaxType not in ("Jac", "SPAI"):
+            raise NotImplementedError(f"relaxType={param.relaxType!r} is not implemented in the multi-GPU cycle")
+        if param.cycleType not in ("V", "W", "F"):
+            raise NotImplementedError(f"cycleType={param.cycleType!r} is not implemented in the multi-GPU cycle")
+
     @classmethod
     def from_global(cls, param: MGparam, comm, backend, fine_owner: np.ndarray, nrhs: int = 1,
                     replicate_below: int = 300_000):
+        cls.check_supported(param)
         rank, size = comm.rank, comm.size
         nl = len(param.As)
         if nl < 2:

@@ -127,6 +127,7 @@ def structured_gmg(global_cells, numDomains, comm, backend, param: MGparam, oper
     ``MGsetup``.  ``gather_objects(obj) -> list`` defaults to ``torch.distributed.all_gather_object``.
     Returns (hierarchy, info) where info holds the level geometry (for building right-hand sides).
     """
+    DistributedHierarchy.check_supported(param)
     cells = np.asarray(global_cells, dtype=np.int64)
     nd = np.asarray(numDomains, dtype=np.int64)
     dim = cells.size

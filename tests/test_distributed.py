@@ -289,3 +289,12 @@ def test_hip_distributed_over_rccl_world1(built):
 @pytest.mark.gpu
 def test_structured_setup_hip(built):
     _run_structured(2, [32, 32, 32], 4, "V", 1, use_hip=True)
+
+
+def test_unsupported_settings_fail_loudly():
+    import multigrid_jl_amd as mg
+    from multigrid_jl_amd import distributed as dd
+    for kw in (dict(relaxType="Jac-GMRES"), dict(cycleType="K", relaxType="Jac")):
+        p = mg.getMGparam(**kw)
+        with pytest.raises(NotImplementedError):
+            dd.DistributedHierarchy.check_supported(p)

@@ -285,3 +285,28 @@ def test_replace_matrix_on_device(mg, built, relaxType, omega, cells):
     b2 /= np.linalg.norm(b2)
     _compare_solve(mg, p, b2)
     mg.clear_(p)
+
+
+def test_c_abi_error_codes(mg, built):
+    """Every misuse returns a status + message (include/mgvcycle.h), never a crash or a silent fallback."""
+    import ctypes as C
+    from multigrid_jl_amd import device as D
+    lib = D.load_library()
+    h = C.c_void_p()
+    assert lib.mg_create(0, 1, 0, C.byref(h)) == 1 and b"nlevels" in lib.mg_last_error()          # MG_ERR_INVALID
+    assert lib.mg_create(2, 1, 99, C.byref(h)) == 1
+    assert lib.mg_create(2, 1, 0, C.byref(h)) == 0
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_longlong))
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    # 0-based pointer array, out-of-range column, non-monotone pointers
+    assert lib.mg_set_operator_FP64_INT64(h, 1, 0, 2, 2, i64([0, 1, 2]), i64([1, 2]), f64([1.0, 1.0])) == 1
+    assert lib.mg_set_operator_FP64_INT64(h, 1, 0, 2, 2, i64([1, 2, 3]), i64([1, 3]), f64([1.0, 1.0])) == 1
+    assert lib.mg_set_operator_FP64_INT64(h, 1, 0, 2, 2, i64([1, 3, 2]), i64([1, 2]), f64([1.0, 1.0])) == 1
+    assert lib.mg_set_operator_FP64_INT64(h, 2, 1, 2, 2, i64([1, 2, 3]), i64([1, 2]), f64([1.0, 1.0])) == 1   # P on the coarsest
+    assert lib.mg_set_operator_FP64_INT64(h, 1, 0, 2, 2, i64([1, 2, 3]), i64([1, 2]), f64([1.0, 1.0])) == 0
+    assert lib.mg_finalize(h) == 3 and b"was not set" in lib.mg_last_error()                       # MG_ERR_STATE
+    b = np.zeros(2)
+    assert lib.mg_cycle_FP64(h, f64(b), f64(b), 2, 1, 1) == 3                                       # not finalized
+    assert lib.mg_set_cycle_type(h, ord("Z")) == 1
+    assert lib.mg_set_relax_type(h, 7) == 1
+    assert lib.mg_destroy(h) == 0
