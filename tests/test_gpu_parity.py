@@ -296,8 +296,15 @@ def test_c_abi_error_codes(mg, built):
     assert lib.mg_create(0, 1, 0, C.byref(h)) == 1 and b"nlevels" in lib.mg_last_error()          # MG_ERR_INVALID
     assert lib.mg_create(2, 1, 99, C.byref(h)) == 1
     assert lib.mg_create(2, 1, 0, C.byref(h)) == 0
-    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_longlong))
-    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    keep = []                                   # the arrays must outlive the calls
+
+    def i64(a):
+        keep.append(np.ascontiguousarray(a, dtype=np.int64))
+        return keep[-1].ctypes.data_as(C.POINTER(C.c_longlong))
+
+    def f64(a):
+        keep.append(np.ascontiguousarray(a, dtype=np.float64))
+        return keep[-1].ctypes.data_as(C.POINTER(C.c_double))
     # 0-based pointer array, out-of-range column, non-monotone pointers
     assert lib.mg_set_operator_FP64_INT64(h, 1, 0, 2, 2, i64([0, 1, 2]), i64([1, 2]), f64([1.0, 1.0])) == 1
     assert lib.mg_set_operator_FP64_INT64(h, 1, 0, 2, 2, i64([1, 2, 3]), i64([1, 3]), f64([1.0, 1.0])) == 1
