@@ -97,7 +97,7 @@ int mg_sa_aggregate_FP64_INT64(long long n, const long long* colptr, const long 
 // spgemm_fill writes indices/values.
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr long long DENSE_MAX_COLS = 1500000;  // 24 MB of accumulator per thread at most
+constexpr long long DENSE_MAX_COLS = 20000000;  // <= 240 MB of stamp+accumulator per thread (hosts of GPU nodes have TBs)
 inline std::size_t table_size(long long products, long long ncols) {
   long long need = 2 * std::min(products, ncols) + 2;
   std::size_t t = 16;
@@ -116,7 +116,7 @@ int mg_spgemm_count_INT64(long long n_rows, long long ncols_B, const long long* 
   if (ncols_B <= DENSE_MAX_COLS) {  // dense stamp array per thread: no per-row clearing
 #pragma omp parallel
     {
-      std::vector<long long> stamp((std::size_t)ncols_B, -1LL);
+      std::vector<int> stamp((std::size_t)ncols_B, -1);
 #pragma omp for schedule(dynamic, 16)
       for (long long i = 0; i < n_rows; ++i) {
         long long cnt = 0;
@@ -124,7 +124,7 @@ int mg_spgemm_count_INT64(long long n_rows, long long ncols_B, const long long* 
           const long long r = A_idx[k];
           for (long long q = B_ptr[r]; q < B_ptr[r + 1]; ++q) {
             const long long c = B_idx[q];
-            if (stamp[(std::size_t)c] != i) { stamp[(std::size_t)c] = i; ++cnt; }
+            if (stamp[(std::size_t)c] != (int)i) { stamp[(std::size_t)c] = (int)i; ++cnt; }
           }
         }
         C_ptr[i + 1] = cnt;
@@ -167,7 +167,7 @@ int mg_spgemm_fill_FP64_INT64(long long n_rows, long long ncols_B, const long lo
   if (ncols_B <= DENSE_MAX_COLS) {
 #pragma omp parallel
     {
-      std::vector<long long> stamp((std::size_t)ncols_B, -1LL);
+      std::vector<int> stamp((std::size_t)ncols_B, -1);
       std::vector<double> acc((std::size_t)ncols_B, 0.0);
       std::vector<long long> touched;
 #pragma omp for schedule(dynamic, 16)
@@ -180,7 +180,7 @@ int mg_spgemm_fill_FP64_INT64(long long n_rows, long long ncols_B, const long lo
           const double a = A_val[k];
           for (long long q = B_ptr[r]; q < B_ptr[r + 1]; ++q) {
             const std::size_t c = (std::size_t)B_idx[q];
-            if (stamp[c] != i) { stamp[c] = i; acc[c] = a * B_val[q]; touched.push_back((long long)c); }
+            if (stamp[c] != (int)i) { stamp[c] = (int)i; acc[c] = a * B_val[q]; touched.push_back((long long)c); }
             else acc[c] += a * B_val[q];
           }
         }

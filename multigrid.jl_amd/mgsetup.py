@@ -48,8 +48,7 @@ def getSPAIprec(A):
     (equal to the row norm only for symmetric A).
     """
     A = _as_csr(A)
-    s = np.zeros(A.shape[1])
-    np.add.at(s, A.indices, A.data * A.data)
+    s = np.bincount(A.indices, weights=A.data * A.data, minlength=A.shape[1])
     return A.diagonal() / s
 
 

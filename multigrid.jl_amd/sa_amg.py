@@ -37,7 +37,8 @@ def getStrengthMatrix(A, strengthConnParam: float):
     mm = 1e-16 * S.data.max()
     rows = np.repeat(np.arange(n), np.diff(S.indptr))
     rowmax = np.full(n, mm)
-    np.maximum.at(rowmax, rows, S.data)
+    nonempty = np.diff(S.indptr) > 0
+    rowmax[nonempty] = np.maximum(mm, np.maximum.reduceat(S.data, S.indptr[:-1][nonempty]))
     S.data = S.data * (1.0 / rowmax)[rows]          # scal_k = 1/maxVal_j; nzval *= scal_k (l.100-103)
     S.data[S.indices == rows] = 1.0
     S.data[S.data < strengthConnParam] = 0.0
