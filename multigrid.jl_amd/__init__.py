@@ -8,7 +8,8 @@ from .mgdef import (MGparam, getMGparam, hierarchyExists, destroyCoarsestLU, cop
 from .mgsetup import (MGsetup, getRelaxPrec, getSPAIprec, adjustMemoryForNumRHS, replaceMatrixInHierarchy,
                       transposeHierarchy, defineCoarsestAinv, multilevelOperatorConstructor,
                       getMultilevelOperatorConstructor, galerkin)
-from .transfer_operators import getFWInterp, get1DFWInterp
+from .transfer_operators import (getFWInterp, get1DFWInterp, restrictCellCenteredVariables, restrictNodalVariables,
+                                 getRestrictionCellCentered)
 from .sa_amg import (SA_AMGsetup, getAggregation, getStrengthMatrix, neighborhoodAggregationNew, aggrArray2P)
 from .solve_funcs import solveMG, solveCG_MG, solveBiCGSTAB_MG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
 from .operators import (getRegularMesh, getNodalGradientMatrix, getNodalLaplacianMatrix,

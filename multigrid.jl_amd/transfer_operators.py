@@ -51,3 +51,44 @@ def getFWInterp(n_nodes, geometric: bool = False):
         raise ValueError("getFWInterp: 2-D or 3-D only")
     P.sort_indices()
     return P, np.asarray(ncs, dtype=np.int64)
+
+
+# ---- coefficient restriction for rediscretisation (GeometricTransferOperators.jl:52-82; Systems.jl:134-183) ----
+def get1DRestrictionCells(n: int):
+    """2:1 aggregation of cells, rows (1, 1); identity below 8 cells (Systems.jl:134-148)."""
+    n = int(n)
+    if n < 8:
+        return sp.identity(n, format="csr"), n
+    nc = n // 2
+    if 2 * nc != n:
+        raise ValueError("Err: get1DRestrictionCells(): size should be a multiplication of 2")
+    rows = np.repeat(np.arange(nc), 2)
+    cols = np.arange(n)
+    return sp.csr_matrix((np.ones(n), (rows, cols)), shape=(nc, n)), nc
+
+
+def getRestrictionCellCentered(n):
+    """kron(R3, kron(R2, R1)) of the 1-D cell aggregations (Systems.jl:167-183); n = cells per dimension."""
+    n = [int(k) for k in n]
+    Rs, ncs = zip(*[get1DRestrictionCells(k) for k in n])
+    if len(n) == 2:
+        R = sp.kron(Rs[1], Rs[0], format="csr")
+    elif len(n) == 3:
+        R = sp.kron(Rs[2], sp.kron(Rs[1], Rs[0], format="csr"), format="csr")
+    else:
+        raise ValueError("getRestrictionCells() : Dimension not supported!")
+    return R, np.asarray(ncs, dtype=np.int64)
+
+
+def restrictCellCenteredVariables(rho, n):
+    """rho_c = 0.5^dim * (R*rho): the mean over each 2^dim block of cells (GeometricTransferOperators.jl:52-58)."""
+    R, nc = getRestrictionCellCentered(n)
+    scale = 0.5 ** len(n)
+    rho_c = scale * (R @ np.asarray(rho, dtype=np.float64).ravel())
+    return rho_c, (R * scale).tocsr()
+
+
+def restrictNodalVariables(rho, n_nodes):
+    """rho_c = 0.5^dim * (P'*rho) with the geometric full-weighting P (GeometricTransferOperators.jl:60-67)."""
+    P, nc = getFWInterp(n_nodes, True)
+    return (0.5 ** len(n_nodes)) * (P.T @ np.asarray(rho, dtype=np.float64).ravel())

@@ -317,3 +317,16 @@ def test_c_abi_error_codes(mg, built):
     assert lib.mg_set_cycle_type(h, ord("Z")) == 1
     assert lib.mg_set_relax_type(h, 7) == 1
     assert lib.mg_destroy(h) == 0
+
+
+def test_rediscretised_hierarchy_on_device(mg, built):
+    """The geometric / re-discretisation mode of MGsetup (multilevelOperatorConstructor, testGMG.jl:70-75)."""
+    from test_oracle import _rediscretisation_problem
+    mesh, sig, op, restrict = _rediscretisation_problem(mg)
+    p = mg.getMGparam(np.float64, np.int64, 4, 2, 5, 1e-10, "Jac", 0.8, 1, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(mg.getMultilevelOperatorConstructor(sig, op, restrict), mesh, p)
+    rng = np.random.default_rng(0)
+    b = p.As[0] @ rng.random(p.As[0].shape[0])
+    b /= np.linalg.norm(b)
+    _compare_solve(mg, p, b)
+    mg.clear_(p)

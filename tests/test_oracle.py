@@ -200,3 +200,40 @@ def test_threshold_3d_poisson_jac_gmres(mg):
     x = np.zeros_like(b)
     orc.solveMG(p, b, x)
     assert np.linalg.norm(A @ x - b) < 0.01
+
+
+# ---- rediscretisation path (multilevelOperatorConstructor, MGsetup.jl:25-33,104-106; testGMG.jl:48-75) ---------------
+def _rediscretisation_problem(mg):
+    from multigrid_jl_amd.operators import getRegularMesh, getNodalDivSigGradMatrix, getNodalLaplacianMatrix
+    import scipy.sparse as sp
+    mesh = getRegularMesh([0.0, 1.0, 0.0, 1.0], [128, 128])
+    shift = 1e-4 * 4.0 * 2 * 128 ** 2                       # keeps the coarsest LU non-singular (the reference's Neumann
+    xc = (np.arange(128) + 0.5) / 128                        # operator is singular: testGMG.jl relies on UMFPACK coping)
+    X1, X2 = np.meshgrid(xc, xc, indexing="ij")
+    sig = (3 * X1 * (1 - X1) + 2 * X2 * (1 - X2)).ravel(order="F")             # testGMG.jl:58-60
+
+    def op(m, s):
+        A = getNodalDivSigGradMatrix(m, s)
+        return (A + shift * sp.identity(A.shape[0])).tocsr()
+
+    restrict = lambda mf, mc, pf, level: mg.restrictCellCenteredVariables(pf, mf.n)[0]       # testGMG.jl:71
+    return mesh, sig, op, restrict
+
+
+def test_rediscretisation_hierarchy_and_threshold(mg):
+    """testGMG.jl:70-75: coefficients restricted level by level, operator re-discretised (geometric mode), 4 levels,
+    Jac 0.8, V(1,1), 5 cycles -> ||Ax-b|| < 0.005."""
+    mesh, sig, op, restrict = _rediscretisation_problem(mg)
+    p = mg.getMGparam(np.float64, np.int64, 4, 2, 5, 1e-2, "Jac", 0.8, 1, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(mg.getMultilevelOperatorConstructor(sig, op, restrict), mesh, p)
+    assert [a.shape[0] for a in p.As] == [129 ** 2, 65 ** 2, 33 ** 2, 17 ** 2]
+    s2 = mg.restrictCellCenteredVariables(sig, [128, 128])[0]
+    assert np.allclose(s2.reshape(64, 64, order="F")[0, 0], sig.reshape(128, 128, order="F")[:2, :2].mean())
+    A2 = op(p.Meshes[1], s2)
+    assert abs(p.As[1] - A2).max() < 1e-12 * abs(A2).max()          # level 2 IS the re-discretised operator, not R*A*P
+    rng = np.random.default_rng(0)
+    b = p.As[0] @ rng.random(p.As[0].shape[0])
+    b /= np.linalg.norm(b)
+    x = np.zeros_like(b)
+    orc.solveMG(p, b, x)
+    assert np.linalg.norm(p.As[0] @ x - b) < 0.005
