@@ -32,6 +32,29 @@ CASES = {
 }
 
 
+# SA-AMG cases ("a 17^3 SA-AMG log-normal sigma case"): name -> (cells, shift, levels, nrhs, cycle, maxIter)
+SA_CASES = {
+    "sa_divsiggrad17_v11_spai_nrhs3": ([16, 16, 16], 1e-6, 3, 3, "V", 5),        # testSAforDivSigGrad.jl:96-112 shape
+    "sa_divsiggrad2d_51_v11_spai": ([50, 50], 1e-8, 3, 1, "V", 5),               # testSAforDivSigGrad.jl:9-38 shape
+}
+
+
+def build_sa_case(name):
+    import scipy.sparse as sp
+    from multigrid_jl_amd.operators import getRegularMesh, getNodalDivSigGradMatrix, entrynorm1
+    cells, shift, levels, nrhs, cyc, maxit = SA_CASES[name]
+    rng = np.random.default_rng(42)
+    mesh = getRegularMesh([0, 1] * len(cells), cells)
+    m = np.exp(rng.standard_normal(mesh.nc))
+    A = getNodalDivSigGradMatrix(mesh, m)
+    A = (A + shift * entrynorm1(A) * sp.identity(A.shape[0])).tocsr()
+    A.sort_indices()
+    p = mg.getMGparam(np.float64, np.int64, levels, 2, maxit, 1e-10, "SPAI", 1.0, 1, 1, cyc, "Julia")
+    mg.SA_AMGsetup(A, p, True, nrhs)
+    b = mg.seeded_rhs(A, nrhs)
+    return A, p, b
+
+
 def fingerprint(param):
     fp = []
     for name in ("As", "Ps", "Rs"):
@@ -58,6 +81,14 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), b=b, resvec=hist["resvec"], x_first=hist["xs"][0],
                             x_last=hist["xs"][-1], iters=it, fingerprint=fingerprint(p),
                             relaxPrec0=p.relaxPrecs[0])
+        print(f"{name}: {it} cycles, relres {hist['resvec'][-1] / hist['resvec'][0]:.3e}")
+    for name in SA_CASES:
+        A, p, b = build_sa_case(name)
+        x = np.zeros_like(b)
+        hist = {}
+        _, _, it = orc.solveMG(p, b, x, False, hist)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), b=b, resvec=hist["resvec"], x_first=hist["xs"][0],
+                            x_last=hist["xs"][-1], iters=it, fingerprint=fingerprint(p), relaxPrec0=p.relaxPrecs[0])
         print(f"{name}: {it} cycles, relres {hist['resvec'][-1] / hist['resvec'][0]:.3e}")
 
 

@@ -146,7 +146,7 @@ import os
 _GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(_GOLD, "gmg_*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(_GOLD, "*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
 def test_hip_path_reproduces_golden(mg, built, path):
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(_GOLD, "make_golden.py"))
@@ -154,7 +154,7 @@ def test_hip_path_reproduces_golden(mg, built, path):
     spec.loader.exec_module(mk)
     name = os.path.basename(path)[:-4]
     g = np.load(path)
-    A, p, b = mk.build_case(name)
+    A, p, b = mk.build_sa_case(name) if name in mk.SA_CASES else mk.build_case(name)
     assert np.allclose(b, g["b"], rtol=1e-12, atol=1e-15)      # regenerated RHS (last bits vary with the host BLAS)
     b = np.asfortranarray(g["b"])                               # the fixture is the input
     x = np.zeros_like(b)
