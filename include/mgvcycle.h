@@ -150,6 +150,12 @@ int mg_bicgstab_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, lo
                          long long maxIter, long long* iters, long long* flag, double* resvec,
                          long long* nres);
 
+/* solveGMRES_MG (SolveFuncs.jl:119-133): KrylovMethods.fgmres (external), flexible restarted GMRES(inner) with one
+ * cycle from x = 0 as preconditioner.  maxIter counts restarts; resvec (length inner*maxIter) receives the residual
+ * estimate after every inner step, *nres their number, *iters the total number of inner steps.  nrhs = 1. */
+int mg_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long inner, double tol,
+                   long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres);
+
 /* target = beta*target + alpha*Op*x on one level (SpMatMul.jl:4-13); column-major host blocks. */
 int mg_spmv_FP64(mg_hierarchy* h, long long level, long long which, double alpha, const double* x,
                  double beta, double* y, long long nrhs);

@@ -11,7 +11,7 @@ from .mgsetup import (MGsetup, getRelaxPrec, getSPAIprec, adjustMemoryForNumRHS,
 from .transfer_operators import (getFWInterp, get1DFWInterp, restrictCellCenteredVariables, restrictNodalVariables,
                                  getRestrictionCellCentered)
 from .sa_amg import (SA_AMGsetup, getAggregation, getStrengthMatrix, neighborhoodAggregationNew, aggrArray2P)
-from .solve_funcs import solveMG, solveCG_MG, solveBiCGSTAB_MG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
+from .solve_funcs import solveMG, solveCG_MG, solveBiCGSTAB_MG, solveGMRES_MG, recursiveCycle, SpMatMul, getMultigridPreconditioner, to_device
 from .operators import (getRegularMesh, getNodalGradientMatrix, getNodalLaplacianMatrix,
                         getNodalDivSigGradMatrix, poisson_shifted, anisotropic_divsiggrad, seeded_rhs)
 from .wrappers import (MGsolver, getMGsolver, getSA_AMGsolver, solveLinearSystem_, setupSolver, copySolverWrapper,

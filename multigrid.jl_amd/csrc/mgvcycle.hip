@@ -864,6 +864,103 @@ int bicgstab_dev(mg_hierarchy* h, const double* b, double* x, double tol, long l
   return MG_OK;
 }
 
+// Flexible restarted GMRES with the multigrid cycle as (right) preconditioner: solveGMRES_MG (SolveFuncs.jl:119-133)
+// -> KrylovMethods.fgmres (v0.6.0, un-vendored), restated from the published algorithm (Saad's FGMRES(m): modified
+// Gram-Schmidt Arnoldi, Givens rotations, residual estimate |s_{i+1}|/||b|| after every inner step).  maxIter counts
+// restarts, `inner` is the Krylov dimension; resvec gets one entry per inner step; flag 0 converged, -1 not, -9 b = 0.
+int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, double tol, long long maxIter,
+               long long* iters, long long* flag_out, double* resvec, long long* nres) {
+  Level& L = h->lev[0];
+  const long long n = L.n;
+  if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "mg_fgmres: block right-hand sides (blockFGMRES) are not on the device path yet");
+  if (inner < 1 || inner > 64) return fail(MG_ERR_INVALID, "inner must be in [1,64]");
+  const int m = (int)inner;
+  if (h->kw.n != (size_t)n * (size_t)(2 * m + 2)) MG_TRY(h->kw.alloc((size_t)n * (size_t)(2 * m + 2)));
+  double* V = h->kw.p;                         // m+1 basis vectors
+  double* Z = h->kw.p + (size_t)(m + 1) * n;   // m preconditioned vectors
+  double* r = Z + (size_t)m * n;               // residual / w
+  double bn = 0.0, rn = 0.0;
+  MG_TRY(norm_sync(h, b, n, &bn));
+  long long nr = 0, flag = -1, total = 0;
+  if (bn == 0.0) {
+    MG_TRY(k_fill(h, x, n, 0.0));
+    HIP_TRY(spin_sync(h->stream));
+    if (iters) *iters = 0;
+    if (flag_out) *flag_out = -9;
+    if (nres) *nres = 0;
+    return MG_OK;
+  }
+  MG_TRY(k_residual(h, 0, L.A, b, x, r));
+  MG_TRY(norm_sync(h, r, n, &rn));
+  double err = rn / bn;
+  if (err < tol) {
+    if (iters) *iters = 0;
+    if (flag_out) *flag_out = 0;
+    if (nres) *nres = 0;
+    return MG_OK;
+  }
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs((size_t)m, 0.0), sn((size_t)m, 0.0), s((size_t)m + 1, 0.0), y((size_t)m, 0.0);
+  auto Hat = [&](int i, int j) -> double& { return H[(size_t)i * m + j]; };
+  for (long long it = 1; it <= maxIter && flag != 0; ++it) {
+    MG_TRY(k_axpby(h, 1.0 / rn, r, 0.0, V, n));                          // V[:,1] = r/||r||
+    std::fill(s.begin(), s.end(), 0.0);
+    s[0] = rn;
+    int used = 0;
+    for (int i = 0; i < m; ++i) {
+      double* vi = V + (size_t)i * n;
+      double* zi = Z + (size_t)i * n;
+      double* w = V + (size_t)(i + 1) * n;
+      MG_TRY(cycle_dev(h, vi, zi, true));                                 // z = M(V[:,i])
+      MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, zi, 0.0, w));              // w = A z
+      for (int k = 0; k <= i; ++k) {                                      // modified Gram-Schmidt
+        double hk = 0.0;
+        MG_TRY(dot_sync(h, w, V + (size_t)k * n, n, &hk));
+        Hat(k, i) = hk;
+        MG_TRY(k_axpby(h, -hk, V + (size_t)k * n, 1.0, w, n));
+      }
+      double wn = 0.0;
+      MG_TRY(norm_sync(h, w, n, &wn));
+      Hat(i + 1, i) = wn;
+      if (wn != 0.0) MG_TRY(k_axpby(h, 1.0 / wn, w, 0.0, w, n));
+      for (int k = 0; k < i; ++k) {                                       // previous rotations
+        const double t = cs[(size_t)k] * Hat(k, i) + sn[(size_t)k] * Hat(k + 1, i);
+        Hat(k + 1, i) = -sn[(size_t)k] * Hat(k, i) + cs[(size_t)k] * Hat(k + 1, i);
+        Hat(k, i) = t;
+      }
+      const double a = Hat(i, i), bq = Hat(i + 1, i);
+      const double rr = std::hypot(a, bq);
+      cs[(size_t)i] = (rr == 0.0) ? 1.0 : a / rr;
+      sn[(size_t)i] = (rr == 0.0) ? 0.0 : bq / rr;
+      Hat(i, i) = rr;
+      Hat(i + 1, i) = 0.0;
+      s[(size_t)i + 1] = -sn[(size_t)i] * s[(size_t)i];
+      s[(size_t)i] = cs[(size_t)i] * s[(size_t)i];
+      err = std::fabs(s[(size_t)i + 1]) / bn;
+      if (resvec) resvec[nr] = err;
+      ++nr;
+      ++total;
+      used = i + 1;
+      if (err <= tol) { flag = 0; break; }
+    }
+    for (int i = used - 1; i >= 0; --i) {                                 // y = H \ s (upper triangular)
+      double acc = s[(size_t)i];
+      for (int k = i + 1; k < used; ++k) acc -= Hat(i, k) * y[(size_t)k];
+      y[(size_t)i] = acc / Hat(i, i);
+    }
+    for (int i = 0; i < used; ++i) MG_TRY(k_axpby(h, y[(size_t)i], Z + (size_t)i * n, 1.0, x, n));   // x += Z y
+    if (flag == 0) break;
+    MG_TRY(k_residual(h, 0, L.A, b, x, r));
+    MG_TRY(norm_sync(h, r, n, &rn));
+    err = rn / bn;
+    if (err <= tol) { flag = 0; break; }
+  }
+  HIP_TRY(spin_sync(h->stream));
+  if (iters) *iters = total;
+  if (flag_out) *flag_out = flag;
+  if (nres) *nres = nr;
+  return MG_OK;
+}
+
 // ---- host <-> device block transfer (column-major host <-> row-major device) --------------------
 int upload_block(mg_hierarchy* h, const double* host, double* dev, long long n, long long nrhs) {
   const size_t bytes = sizeof(double) * (size_t)n * (size_t)nrhs;
@@ -1569,6 +1666,19 @@ int mg_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double
   MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
   MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
   MG_TRY(pcg_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec));
+  MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long inner, double tol,
+                   long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
+  MG_TRY(check_ready(h, n, 1));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
+  MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
+  MG_TRY(fgmres_dev(h, h->stage_b.p, h->stage_x.p, inner, tol, maxIter, iters, flag, resvec, nres));
   MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
   prof_collect(h);
   return MG_OK;

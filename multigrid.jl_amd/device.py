@@ -54,6 +54,7 @@ SIGNATURES = {
     "mg_pcg_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _lp, _dp]),
     "mg_bicgstab_FP64": (C.c_int, [_vp, _dp, _dp, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
     "mg_bicgstab_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
+    "mg_fgmres_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
     "mg_spmv_FP64": (C.c_int, [_vp, _ll, _ll, C.c_double, _dp, C.c_double, _dp, _ll]),
     "mg_cycle_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
     "mg_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
@@ -302,6 +303,19 @@ class DeviceHierarchy:
         resvec = np.zeros(2 * int(maxIter) + 1)
         _check(self.lib, self.lib.mg_bicgstab_FP64(self.handle, _f64(b), _f64(x), b.shape[0], float(tol), int(maxIter),
                                                    C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)), "mg_bicgstab")
+        return x, int(flag.value), int(iters.value), resvec[: nres.value]
+
+    def fgmres(self, b, x, inner: int, tol: float, maxIter: int):
+        """KrylovMethods.fgmres (flexible) with the MG cycle as preconditioner; returns (x, flag, iters, resvec)."""
+        b = self._host_block(b)
+        x = self._host_block(x, True)
+        if b.ndim != 1:
+            raise MGDeviceError("mg_fgmres: one right-hand side only (blockFGMRES is not on the device path)")
+        iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        resvec = np.zeros(max(1, int(inner) * int(maxIter)))
+        _check(self.lib, self.lib.mg_fgmres_FP64(self.handle, _f64(b), _f64(x), b.shape[0], int(inner), float(tol),
+                                                 int(maxIter), C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)),
+               "mg_fgmres")
         return x, int(flag.value), int(iters.value), resvec[: nres.value]
 
     def pcg_dev(self, b, x, tol: float, maxIter: int):

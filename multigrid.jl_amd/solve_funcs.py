@@ -91,6 +91,18 @@ def solveBiCGSTAB_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, verbose: 
     return x, param, it, nprec
 
 
+def solveGMRES_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, flexible: bool, inner: int, verbose: bool = False):
+    """``(x, param, iter, resvec) = solveGMRES_MG(AT,param,b,x0,flexible,inner,verbose)`` (SolveFuncs.jl:119-133):
+    KrylovMethods.fgmres with the multigrid cycle as preconditioner on the device (always the flexible variant: the
+    cycle is a fixed linear operator, so flexible and standard GMRES generate the same iterates).  One right-hand side."""
+    adjustMemoryForNumRHS(param, _ncols(b))
+    dev = to_device(param)
+    x, flag, it, resvec = dev.fgmres(b, x0, inner, param.relativeTol, param.maxOuterIter)
+    param.resvec = resvec
+    param.flag = flag
+    return x, param, it, resvec
+
+
 _WHICH = {"A": MG_OP_A, "P": MG_OP_P, "R": MG_OP_R}
 
 

@@ -3,8 +3,8 @@
 Mirrors reference src/Multigrid/MGWrapper.jl (l.6-103) and SAAMGWrapper.jl (l.5-94): lazy setup on the first
 solve, transpose handling for non-symmetric operators, the Krylov switch, timing counters.  The solve itself
 runs on the device (``solve_funcs``).  Krylov drivers available here: "PCG" (``solveCG_MG``), "BiCGSTAB"
-(``solveBiCGSTAB_MG``) and plain cycles (anything else for ``MGsolver``, ``solveMG``); "GMRES"
-(KrylovMethods.fgmres) is not on the device path.
+(``solveBiCGSTAB_MG``), "GMRES" (``solveGMRES_MG``, FGMRES(5) as MGWrapper.jl:69-71) and plain cycles (anything else
+for ``MGsolver``, ``solveMG``).
 """
 from __future__ import annotations
 
@@ -18,7 +18,7 @@ import scipy.sparse as sp
 from .mgdef import MGparam, clear_, copySolver as _copy_param, hierarchyExists
 from .mgsetup import MGsetup, transposeHierarchy
 from .sa_amg import SA_AMGsetup
-from .solve_funcs import solveBiCGSTAB_MG, solveCG_MG, solveMG
+from .solve_funcs import solveBiCGSTAB_MG, solveCG_MG, solveGMRES_MG, solveMG
 
 
 @dataclass
@@ -87,8 +87,9 @@ def solveLinearSystem_(A, B: np.ndarray, X: np.ndarray, param: MGsolver, doTrans
     elif param.Krylov == "PCG":
         _, _, num_iter = solveCG_MG(param.MG.As[0], param.MG, Bf, Xv, verbose)
     elif param.Krylov == "GMRES":
-        raise NotImplementedError("Krylov='GMRES' (KrylovMethods.fgmres) is not on the device path: use 'PCG', "
-                                  "'BiCGSTAB' or plain cycles")
+        if param.kind == "SA":
+            raise ValueError("SA_AMGsolver supports Krylov 'BiCGSTAB' or 'PCG' (SAAMGWrapper.jl:61-65)")
+        _, _, num_iter, _ = solveGMRES_MG(param.MG.As[0], param.MG, Bf, Xv, True, 5, verbose)     # MGWrapper.jl:69-71
     elif param.kind == "SA":
         raise ValueError("SA_AMGsolver supports Krylov 'BiCGSTAB' or 'PCG' (SAAMGWrapper.jl:61-65)")
     else:

@@ -597,3 +597,73 @@ def solveBiCGSTAB_MG(param, b, x0):
     A = param.As[0]
     return bicgstb(lambda v: A @ v, b, tol=param.relativeTol, maxIter=param.maxOuterIter,
                    M1=getMultigridPreconditioner(param, b), x=x0)
+
+
+def fgmres(Afun, b, restrt, tol=1e-2, maxIter=100, M=None, x=None):
+    """KrylovMethods.fgmres (v0.6.0, un-vendored) as called by solveGMRES_MG (SolveFuncs.jl:119-133), flexible variant,
+    restated from the published algorithm (Saad, FGMRES(m)): MGS Arnoldi, Givens rotations, residual estimate per
+    inner step.  Returns (x, flag, total inner steps, resvec)."""
+    n = b.size
+    bn = np.linalg.norm(b)
+    if bn == 0:
+        return np.zeros(n), -9, 0, np.zeros(0)
+    if x is None:
+        x = np.zeros(n)
+    Mf = M if M is not None else (lambda v: v.copy())
+    r = b - Afun(x)
+    rn = np.linalg.norm(r)
+    if rn / bn < tol:
+        return x, 0, 0, np.zeros(0)
+    m = restrt
+    resvec, flag, total = [], -1, 0
+    for it in range(1, maxIter + 1):
+        V = np.zeros((n, m + 1))
+        Z = np.zeros((n, m))
+        H = np.zeros((m + 1, m))
+        cs = np.zeros(m)
+        sn = np.zeros(m)
+        s = np.zeros(m + 1)
+        V[:, 0] = r / rn
+        s[0] = rn
+        used = 0
+        for i in range(m):
+            Z[:, i] = Mf(V[:, i])
+            w = Afun(Z[:, i])
+            for k in range(i + 1):
+                H[k, i] = np.dot(w, V[:, k])
+                w = w - H[k, i] * V[:, k]
+            H[i + 1, i] = np.linalg.norm(w)
+            if H[i + 1, i] != 0:
+                V[:, i + 1] = w / H[i + 1, i]
+            for k in range(i):
+                t = cs[k] * H[k, i] + sn[k] * H[k + 1, i]
+                H[k + 1, i] = -sn[k] * H[k, i] + cs[k] * H[k + 1, i]
+                H[k, i] = t
+            rr = np.hypot(H[i, i], H[i + 1, i])
+            cs[i], sn[i] = (1.0, 0.0) if rr == 0 else (H[i, i] / rr, H[i + 1, i] / rr)
+            H[i, i], H[i + 1, i] = rr, 0.0
+            s[i + 1] = -sn[i] * s[i]
+            s[i] = cs[i] * s[i]
+            err = abs(s[i + 1]) / bn
+            resvec.append(err)
+            total += 1
+            used = i + 1
+            if err <= tol:
+                flag = 0
+                break
+        y = np.linalg.solve(np.triu(H[:used, :used]), s[:used])
+        x = x + Z[:, :used] @ y
+        if flag == 0:
+            break
+        r = b - Afun(x)
+        rn = np.linalg.norm(r)
+        if rn / bn <= tol:
+            flag = 0
+            break
+    return x, flag, total, np.array(resvec)
+
+
+def solveGMRES_MG(param, b, x0, inner):
+    A = param.As[0]
+    return fgmres(lambda v: A @ v, b, inner, tol=param.relativeTol, maxIter=param.maxOuterIter,
+                  M=getMultigridPreconditioner(param, b), x=x0)

@@ -103,13 +103,12 @@ def test_wrapper_host_logic(mg, built):
     assert mg.hierarchyExists(s.MG)
     mg.clearSolver_(s)
     assert not mg.hierarchyExists(s.MG) and s.doClear == 0
-    g = mg.getMGsolver(mg.getMGparam(levels=2, relaxType="Jac"), mesh, 1)      # default Krylov "GMRES"
-    with pytest.raises(NotImplementedError):
-        mg.solveLinearSystem_(A, np.ones(A.shape[0]), np.zeros(A.shape[0]), g)
+    g = mg.getMGsolver(mg.getMGparam(levels=2, relaxType="Jac"), mesh, 1)
+    assert g.Krylov == "GMRES"                                                  # the reference's default (MGWrapper.jl:22)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kry", ["PCG", "BiCGSTAB", "MG"])
+@pytest.mark.parametrize("kry", ["PCG", "BiCGSTAB", "GMRES", "MG"])
 def test_wrapper_solves_like_the_reference_tests(mg, built, kry):
     """testLinSolveMGWrapper.jl:13-39 shape: 2-D 51^2 nodes, 5 levels, V(2,2) SPAI, relres < tol (1e-2)."""
     from multigrid_jl_amd.operators import getRegularMesh, getNodalLaplacianMatrix, opnorm1
@@ -130,3 +129,33 @@ def test_wrapper_solves_like_the_reference_tests(mg, built, kry):
     assert np.linalg.norm(A @ X2 - B) / np.linalg.norm(B) < 1e-2
     mg.clearSolver_(s)
     mg.clearSolver_(sa)
+
+
+def test_reference_threshold_gmres_gmg(mg, built):
+    """testGMGRAPforPoisson.jl:48-55: GMRES(10) preconditioned with GMG (Jac-GMRES smoother) -> ||Ax-b|| < 0.001
+    (one right-hand side here; the reference uses blockFGMRES on 2)."""
+    A, mesh = mg.poisson_shifted([128, 128])
+    p = mg.getMGparam(np.float64, np.int64, 4, 8, 5, 1e-10, "Jac-GMRES", 0.75, 1, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p)
+    rng = np.random.default_rng(1)
+    b = A @ rng.random(A.shape[0])
+    b /= np.linalg.norm(b)
+    x, flag, it, rv = orc.solveGMRES_MG(p, b, np.zeros_like(b), 10)
+    assert np.linalg.norm(A @ x - b) < 0.001
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inner", [2, 5])
+def test_device_fgmres_matches_oracle(mg, built, inner):
+    A, mesh = mg.poisson_shifted([24, 24, 24])
+    p = mg.getMGparam(np.float64, np.int64, 3, 8, 4, 1e-9, "Jac", 0.8, 1, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p)
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    x, _, it, rv = mg.solveGMRES_MG(A, p, b, x, True, inner)
+    xo, flag, ito, rvo = orc.solveGMRES_MG(p, b, np.zeros_like(b), inner)
+    assert it == ito and p.flag == flag == 0 and len(rv) == len(rvo)
+    assert np.abs(rv - rvo).max() / rvo[0] < 1e-8
+    assert np.abs(x - xo).max() <= 1e-8 * np.abs(xo).max()
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-8
+    mg.clear_(p)
