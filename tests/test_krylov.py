@@ -148,7 +148,7 @@ def test_reference_threshold_gmres_gmg(mg, built):
 @pytest.mark.parametrize("inner", [2, 5])
 def test_device_fgmres_matches_oracle(mg, built, inner):
     A, mesh = mg.poisson_shifted([24, 24, 24])
-    p = mg.getMGparam(np.float64, np.int64, 3, 8, 4, 1e-9, "Jac", 0.8, 1, 1, "V", "NoMUMPS", 0.5, 0.0)
+    p = mg.getMGparam(np.float64, np.int64, 3, 8, 12, 1e-9, "Jac", 0.8, 1, 1, "V", "NoMUMPS", 0.5, 0.0)
     mg.MGsetup(A, mesh, p)
     b = mg.seeded_rhs(A)
     x = np.zeros_like(b)
