@@ -95,6 +95,14 @@ int mg_set_cycle_type(mg_hierarchy* h, long long cycleType);
  * column-major n x n, applied on device as a dense product. */
 int mg_set_coarse_dense_inverse_FP64(mg_hierarchy* h, long long n, const double* Ainv_colmajor);
 
+/* The same solve from SPARSE factors, for coarsest levels too large for an explicit inverse: the layout of the
+ * reference's native applier (deps/src/parLU.cpp:120-190 / setupLUFactor, parallelJuliaSolver.jl:113-148): CSR L
+ * with the diagonal LAST in every row, CSR U with the diagonal FIRST, 1-based Int64 pointers/indices, p and q with
+ * A[p,q] = L*U, so that x[q] = U \ (L \ b[p]).  Applied by one workgroup walking the dependency levels. */
+int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* Lptr, const long long* Lcol,
+                                const double* Lval, const long long* Uptr, const long long* Ucol,
+                                const double* Uval, const long long* p, const long long* q);
+
 /* Validate the hierarchy (shapes chain, every level complete), build the row-block partitions,
  * allocate the per-level b/r/x scratch (CYCLEmem, MGdef.jl:56-60). */
 int mg_finalize(mg_hierarchy* h);

@@ -654,6 +654,96 @@ __global__ __launch_bounds__(BLK) void dense_apply(const double* __restrict__ Ai
 }
 
 // ------------------------------------------------------------------------------------------------
+// Coarsest solve with sparse triangular factors, x[q] = U \ (L \ b[p]) - the reference's own native scheme for
+// applying Julia's (UMFPACK) factors: deps/src/parLU.cpp:120-190, CSR factors with L's diagonal LAST and U's
+// diagonal FIRST in every row.  Used when the coarsest level is too large for the explicit inverse.
+// One 1024-thread workgroup walks the dependency LEVELS of L and then of U (rows of one level are independent;
+// level sets are computed on the host at setup), one wavefront per row, a workgroup barrier between levels:
+// no inter-workgroup waiting, so nothing can hang.  Latency-bound by design (a coarse level).
+// ------------------------------------------------------------------------------------------------
+struct LuDev {
+  int n;
+  const int* Lptr; const int* Lcol; const double* Lval;   // CSR, diagonal last
+  const int* Uptr; const int* Ucol; const double* Uval;   // CSR, diagonal first
+  const int* p; const int* q;                             // 0-based permutations
+  const int* Lorder; const int* Llvl; int nLlvl;          // rows sorted by level, level pointers
+  const int* Uorder; const int* Ulvl; int nUlvl;
+};
+
+// One triangular sweep over the dependency levels.  A level with >= 16 rows gives every wavefront its own rows; a
+// level with fewer rows (the dense trailing supernodes of a factor are chains of single-row levels) splits each row
+// over g = 16/rows wavefronts and combines their partial sums through LDS.  Up to 4 right-hand-side columns travel
+// together (y is row-interleaved like every other device vector).
+template <bool LOWER>
+__device__ __forceinline__ void sptrsv_sweep(const int* __restrict__ ptr, const int* __restrict__ col,
+                                             const double* __restrict__ val, const int* __restrict__ order,
+                                             const int* __restrict__ lvl, int nlvl, const int* __restrict__ perm,
+                                             const double* __restrict__ b, double* y, int nrhs, int c0, int nc,
+                                             double (*sred)[4]) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int l = 0; l < nlvl; ++l) {
+    const int t0 = lvl[l], t1 = lvl[l + 1], cnt = t1 - t0;
+    int g = 1;
+    while (g * 2 * cnt <= nw) g *= 2;
+    const int part = wave & (g - 1), stride = nw / g;
+    for (int t = t0 + wave / g; t < t1; t += stride) {
+      const int row = order[t];
+      const int s = LOWER ? ptr[row] : ptr[row] + 1;
+      const int e = LOWER ? ptr[row + 1] - 1 : ptr[row + 1];
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = s + part * 64 + lane; k < e; k += 64 * g) {
+        const double v = val[k];
+        const double* yy = y + (size_t)col[k] * nrhs + c0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < nc) acc[u] += v * yy[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
+      if (g == 1) {
+        if (lane < nc) {
+          const double dg = val[LOWER ? e : s - 1];
+          const double rhs = LOWER ? b[(size_t)perm[row] * nrhs + c0 + lane] : y[(size_t)row * nrhs + c0 + lane];
+          const double a = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+          y[(size_t)row * nrhs + c0 + lane] = (rhs - a) / dg;
+        }
+      } else if (lane < 4) {
+        sred[wave][lane] = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      }
+    }
+    if (g > 1) {
+      __syncthreads();
+      const int t = t0 + wave / g;
+      if (part == 0 && t < t1 && lane < nc) {
+        const int row = order[t];
+        double a = 0.0;
+        for (int w = 0; w < g; ++w) a += sred[wave + w][lane];
+        const double dg = val[LOWER ? ptr[row + 1] - 1 : ptr[row]];
+        const double rhs = LOWER ? b[(size_t)perm[row] * nrhs + c0 + lane] : y[(size_t)row * nrhs + c0 + lane];
+        y[(size_t)row * nrhs + c0 + lane] = (rhs - a) / dg;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void sptrsv_lu(LuDev F, const double* __restrict__ b, double* __restrict__ x,
+                                                  double* work, int nrhs) {
+  __shared__ double sred[16][4];
+  for (int c0 = 0; c0 < nrhs; c0 += 4) {
+    const int nc = min(4, nrhs - c0);
+    sptrsv_sweep<true>(F.Lptr, F.Lcol, F.Lval, F.Lorder, F.Llvl, F.nLlvl, F.p, b, work, nrhs, c0, nc, sred);   // y = L \\ b[p]
+    sptrsv_sweep<false>(F.Uptr, F.Ucol, F.Uval, F.Uorder, F.Ulvl, F.nUlvl, F.p, b, work, nrhs, c0, nc, sred);  // y = U \\ y
+    for (int i = threadIdx.x; i < F.n * nc; i += blockDim.x) {
+      const int r = i / nc, u = i - r * nc;
+      x[(size_t)F.q[r] * nrhs + c0 + u] = work[(size_t)r * nrhs + c0 + u];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Numeric Galerkin product on a FIXED sparsity: C = R*(A*P) (replaceMatrixInHierarchy, MGsetup.jl:226-270:
 // `Act = Ps[l]*AT*Rs[l]` with unchanged P, R; the pattern of C is the one the host setup produced).
 // One wavefront (a 64-thread workgroup) per coarse row i: lanes split the entries (i,k) of R's row, walk A's

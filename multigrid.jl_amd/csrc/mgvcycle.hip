@@ -193,6 +193,11 @@ struct mg_hierarchy {
   DevBuf<double> Ainv;  // row-major n_c x n_c
   long long n_coarse = 0;
   bool coarse_set = false;
+  // sparse-factor form of the coarsest solve (parLU layout), used instead of Ainv when coarse_lu is true
+  bool coarse_lu = false;
+  DevBuf<int> luLptr, luLcol, luUptr, luUcol, luP, luQ, luLorder, luLlvl, luUorder, luUlvl;
+  DevBuf<double> luLval, luUval, luWork;
+  int nLlvl = 0, nUlvl = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = true;
   // reductions
@@ -398,6 +403,19 @@ int k_fill(mg_hierarchy* h, double* x, long long n, double val) {
 }
 int k_coarse(mg_hierarchy* h, int level, const double* b, double* x) {
   const long long n = h->n_coarse;
+  if (h->coarse_lu) {
+    ProfScope ps(h, level, MG_K_COARSE, 12.0 * (double)(h->luLval.n + h->luUval.n) + 16.0 * (double)n * (double)h->nrhs);
+    mgk::LuDev F;
+    F.n = (int)n;
+    F.Lptr = h->luLptr.p; F.Lcol = h->luLcol.p; F.Lval = h->luLval.p;
+    F.Uptr = h->luUptr.p; F.Ucol = h->luUcol.p; F.Uval = h->luUval.p;
+    F.p = h->luP.p; F.q = h->luQ.p;
+    F.Lorder = h->luLorder.p; F.Llvl = h->luLlvl.p; F.nLlvl = h->nLlvl;
+    F.Uorder = h->luUorder.p; F.Ulvl = h->luUlvl.p; F.nUlvl = h->nUlvl;
+    hipLaunchKernelGGL(mgk::sptrsv_lu, dim3(1), dim3(1024), 0, h->stream, F, b, x, h->luWork.p, (int)h->nrhs);
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+  }
   ProfScope ps(h, level, MG_K_COARSE,
                8.0 * ((double)n * (double)n + 2.0 * (double)n * (double)h->nrhs));
   const long long waves = n * h->nrhs;
@@ -624,6 +642,14 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   *result = cur;
   return MG_OK;
 }
+
+// Setup entry points copy with blocking hipMemcpy on the NULL stream while every kernel runs on the handle's
+// non-blocking stream, which does not order against it.  A blocking copy from pageable memory may return once the
+// data sits in the runtime's staging buffer, the DMA still in flight (seen on MI355X: a solve launched right after
+// an upload read zeros).  Every uploading entry point therefore ends with a device-wide fence.
+struct UploadFence {
+  ~UploadFence() { (void)hipDeviceSynchronize(); }
+};
 
 int check_ready(mg_hierarchy* h, long long n, long long nrhs) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
@@ -1030,6 +1056,7 @@ int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const st
 
 int alloc_scratch(mg_hierarchy* h) {
   const long long k = h->nrhs;
+  if (h->coarse_lu) MG_TRY(h->luWork.alloc((size_t)h->n_coarse * (size_t)k));
   const char* no_sched = std::getenv("MG_NO_SCHED");
   if (!(no_sched && no_sched[0] == '1')) {
     for (int l = 0; l < (int)h->nlevels; ++l) {
@@ -1386,6 +1413,12 @@ int mg_destroy(mg_hierarchy* h) {
     L.x1.release();
   }
   h->Ainv.release();
+  for (DevBuf<int>* d : {&h->luLptr, &h->luLcol, &h->luUptr, &h->luUcol, &h->luP, &h->luQ, &h->luLorder, &h->luLlvl,
+                         &h->luUorder, &h->luUlvl})
+    d->release();
+  h->luLval.release();
+  h->luUval.release();
+  h->luWork.release();
   h->partial.release();
   h->partial2.release();
   h->scalar.release();
@@ -1406,6 +1439,7 @@ int mg_destroy(mg_hierarchy* h) {
 int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which, long long n_rows,
                                long long n_cols, const long long* colptr, const long long* rowval,
                                const double* nzval) {
+  UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   Csr* M = pick(h, level, which);
   if (!M) return fail(MG_ERR_INVALID, "bad (level=%lld, which=%lld)", level, which);
@@ -1419,6 +1453,7 @@ int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which
 
 int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long long n,
                       long long relaxPre, long long relaxPost) {
+  UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
   if (!d || n < 1) return fail(MG_ERR_INVALID, "empty relaxPrec");
@@ -1464,6 +1499,7 @@ int mg_set_cycle_type(mg_hierarchy* h, long long cycleType) {
 }
 
 int mg_set_coarse_dense_inverse_FP64(mg_hierarchy* h, long long n, const double* Ainv) {
+  UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   if (n < 1 || !Ainv) return fail(MG_ERR_INVALID, "empty coarse inverse");
   if (n > 46000) return fail(MG_ERR_UNSUPPORTED, "dense coarse inverse of order %lld is too large", n);
@@ -1476,11 +1512,100 @@ int mg_set_coarse_dense_inverse_FP64(mg_hierarchy* h, long long n, const double*
   HIP_TRY(hipMemcpy(h->Ainv.p, rm.data(), rm.size() * sizeof(double), hipMemcpyHostToDevice));
   h->n_coarse = n;
   h->coarse_set = true;
+  h->coarse_lu = false;
+  h->finalized = false;
+  return MG_OK;
+}
+
+// Coarsest solve from sparse LU factors in the layout of the reference's native applier (deps/src/parLU.cpp:120-190;
+// produced by setupLUFactor, parallelJuliaSolver.jl:113-148): CSR L (diagonal last in each row) and U (diagonal first),
+// 1-based Int64 row pointers / column indices, permutations p, q with A[p,q] = L*U, i.e. x[q] = U \ (L \ b[p]).
+int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* Lptr, const long long* Lcol,
+                                const double* Lval, const long long* Uptr, const long long* Ucol,
+                                const double* Uval, const long long* p, const long long* q) {
+  UploadFence upload_fence;
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (n < 1 || !Lptr || !Lcol || !Lval || !Uptr || !Ucol || !Uval || !p || !q) return fail(MG_ERR_INVALID, "null or empty factor");
+  if (n >= (1LL << 31) - 1 || Lptr[n] - 1 >= (1LL << 31) || Uptr[n] - 1 >= (1LL << 31))
+    return fail(MG_ERR_UNSUPPORTED, "factors exceed int32 device indices");
+  (void)hipSetDevice(h->device);
+  const size_t N = (size_t)n;
+  auto conv = [&](const long long* ptr, const long long* col, bool lower, std::vector<int>& P, std::vector<int>& Cc,
+                  std::vector<int>& order, std::vector<int>& lvlptr) -> int {
+    const long long nnz = ptr[n] - 1;
+    P.resize(N + 1);
+    Cc.resize((size_t)nnz);
+    for (size_t i = 0; i <= N; ++i) P[i] = (int)(ptr[i] - 1);
+    for (long long k = 0; k < nnz; ++k) {
+      const long long c = col[k] - 1;
+      if (c < 0 || c >= n) return fail(MG_ERR_INVALID, "factor column index out of range");
+      Cc[(size_t)k] = (int)c;
+    }
+    std::vector<int> lvl(N, 0);
+    int nl = 0;
+    if (lower) {
+      for (size_t i = 0; i < N; ++i) {
+        if (P[i + 1] - P[i] < 1 || Cc[(size_t)P[i + 1] - 1] != (int)i) return fail(MG_ERR_INVALID, "L: the diagonal must be the last entry of row %zu", i + 1);
+        int m = 0;
+        for (int k = P[i]; k < P[i + 1] - 1; ++k) {
+          if (Cc[(size_t)k] >= (int)i) return fail(MG_ERR_INVALID, "L is not lower triangular");
+          m = std::max(m, lvl[(size_t)Cc[(size_t)k]] + 1);
+        }
+        lvl[i] = m;
+        nl = std::max(nl, m + 1);
+      }
+    } else {
+      for (size_t ii = N; ii-- > 0;) {
+        if (P[ii + 1] - P[ii] < 1 || Cc[(size_t)P[ii]] != (int)ii) return fail(MG_ERR_INVALID, "U: the diagonal must be the first entry of row %zu", ii + 1);
+        int m = 0;
+        for (int k = P[ii] + 1; k < P[ii + 1]; ++k) {
+          if (Cc[(size_t)k] <= (int)ii) return fail(MG_ERR_INVALID, "U is not upper triangular");
+          m = std::max(m, lvl[(size_t)Cc[(size_t)k]] + 1);
+        }
+        lvl[ii] = m;
+        nl = std::max(nl, m + 1);
+      }
+    }
+    lvlptr.assign((size_t)nl + 1, 0);
+    for (size_t i = 0; i < N; ++i) lvlptr[(size_t)lvl[i] + 1]++;
+    for (int l = 0; l < nl; ++l) lvlptr[(size_t)l + 1] += lvlptr[(size_t)l];
+    order.resize(N);
+    std::vector<int> pos(lvlptr.begin(), lvlptr.end() - 1);
+    for (size_t i = 0; i < N; ++i) order[(size_t)pos[(size_t)lvl[i]]++] = (int)i;
+    return MG_OK;
+  };
+  std::vector<int> LP, LC, LO, LL, UP, UC, UO, UL, pp(N), qq(N);
+  MG_TRY(conv(Lptr, Lcol, true, LP, LC, LO, LL));
+  MG_TRY(conv(Uptr, Ucol, false, UP, UC, UO, UL));
+  for (size_t i = 0; i < N; ++i) {
+    if (p[i] < 1 || p[i] > n || q[i] < 1 || q[i] > n) return fail(MG_ERR_INVALID, "permutation entry out of range");
+    pp[i] = (int)(p[i] - 1);
+    qq[i] = (int)(q[i] - 1);
+  }
+  auto up_i = [&](DevBuf<int>& d, const std::vector<int>& v) -> int {
+    MG_TRY(d.alloc(v.size()));
+    HIP_TRY(hipMemcpy(d.p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    return MG_OK;
+  };
+  MG_TRY(up_i(h->luLptr, LP)); MG_TRY(up_i(h->luLcol, LC)); MG_TRY(up_i(h->luLorder, LO)); MG_TRY(up_i(h->luLlvl, LL));
+  MG_TRY(up_i(h->luUptr, UP)); MG_TRY(up_i(h->luUcol, UC)); MG_TRY(up_i(h->luUorder, UO)); MG_TRY(up_i(h->luUlvl, UL));
+  MG_TRY(up_i(h->luP, pp)); MG_TRY(up_i(h->luQ, qq));
+  MG_TRY(h->luLval.alloc(LC.size()));
+  MG_TRY(h->luUval.alloc(UC.size()));
+  HIP_TRY(hipMemcpy(h->luLval.p, Lval, LC.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->luUval.p, Uval, UC.size() * sizeof(double), hipMemcpyHostToDevice));
+  h->nLlvl = (int)LL.size() - 1;
+  h->nUlvl = (int)UL.size() - 1;
+  h->n_coarse = n;
+  h->coarse_set = true;
+  h->coarse_lu = true;
+  h->Ainv.release();
   h->finalized = false;
   return MG_OK;
 }
 
 int mg_finalize(mg_hierarchy* h) {
+  UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   (void)hipSetDevice(h->device);
   const int nl = (int)h->nlevels;
@@ -1514,6 +1639,7 @@ int mg_finalize(mg_hierarchy* h) {
 }
 
 int mg_set_nrhs(mg_hierarchy* h, long long nrhs) {
+  UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   if (nrhs < 1) return fail(MG_ERR_INVALID, "nrhs must be >= 1");
   if (nrhs == h->nrhs) return MG_OK;
@@ -1528,6 +1654,7 @@ int mg_set_nrhs(mg_hierarchy* h, long long nrhs) {
 
 int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, const double* nzval,
                            long long nnz) {
+  UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   Csr* M = pick(h, level, which);
   if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
@@ -1779,7 +1906,8 @@ int mg_time_op_dev_FP64(mg_hierarchy* h, long long level, long long kernel, long
       case MG_K_COARSE:
         if (!coarsest) rc = fail(MG_ERR_INVALID, "MG_K_COARSE runs on the coarsest level only");
         else rc = k_coarse(h, l, L.b.p, L.x0.p);
-        bts = 8.0 * ((double)L.n * (double)L.n + 2.0 * (double)L.n * (double)nrhs);
+        bts = h->coarse_lu ? 12.0 * (double)(h->luLval.n + h->luUval.n) + 16.0 * (double)L.n * (double)nrhs
+                           : 8.0 * ((double)L.n * (double)L.n + 2.0 * (double)L.n * (double)nrhs);
         break;
       case MG_K_NORM:
         rc = k_sumsq(h, L.r.p, L.n * nrhs);
@@ -1886,6 +2014,7 @@ struct mg_operator {
 int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_cols,
                             const long long* colptr, const long long* rowval, const double* nzval,
                             mg_operator** out) {
+  UploadFence upload_fence;
   if (!out) return fail(MG_ERR_INVALID, "out is null");
   *out = nullptr;
   int ndev = 0;

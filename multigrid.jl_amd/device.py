@@ -41,6 +41,7 @@ SIGNATURES = {
     "mg_set_relax_type": (C.c_int, [_vp, _ll]),
     "mg_set_grid_hint": (C.c_int, [_vp, _ll, _ll, _ll, _ll]),
     "mg_set_coarse_dense_inverse_FP64": (C.c_int, [_vp, _ll, _dp]),
+    "mg_set_coarse_lu_FP64_INT64": (C.c_int, [_vp, _ll, _lp, _lp, _dp, _lp, _lp, _dp, _lp, _lp]),
     "mg_finalize": (C.c_int, [_vp]),
     "mg_set_nrhs": (C.c_int, [_vp, _ll]),
     "mg_replace_values_FP64": (C.c_int, [_vp, _ll, _ll, _dp, _ll]),
@@ -190,16 +191,33 @@ class DeviceHierarchy:
                     _check(lib, lib.mg_set_grid_hint(self.handle, l + 1, nn[0], nn[1], nn[2]), "mg_set_grid_hint")
         _check(lib, lib.mg_set_relax_type(self.handle, 1 if param.relaxType == "Jac-GMRES" else 0), "mg_set_relax_type")
         _check(lib, lib.mg_set_cycle_type(self.handle, ord(param.cycleType)), "mg_set_cycle_type")
-        nc = int(param.As[-1].shape[0])
-        if nc > DENSE_COARSE_MAX:
-            raise MGDeviceError(
-                f"coarsest level has {nc} rows: the dense-inverse coarse solve is capped at {DENSE_COARSE_MAX}; "
-                "use more levels")
         if param.LU is None:
             raise MGDeviceError("param.LU is empty: run MGsetup / SA_AMGsetup first")
-        Ainv = np.asfortranarray(param.LU.solve(np.eye(nc)))        # LU \ I, column-major
-        _check(lib, lib.mg_set_coarse_dense_inverse_FP64(self.handle, nc, _f64(Ainv)), "mg_set_coarse_dense_inverse")
+        self._set_coarse(param)
         _check(lib, lib.mg_finalize(self.handle), "mg_finalize")
+
+    def _set_coarse(self, param, force_sparse: bool = False):
+        """`z = param.LU\\b` (MGcycle.jl:177) on the device: the explicit inverse for small coarsest levels, the sparse
+        L/U factors in the reference's parLU layout (mg_set_coarse_lu_FP64_INT64) above DENSE_COARSE_MAX rows."""
+        import scipy.sparse as sp
+        lib = self.lib
+        nc = int(param.As[-1].shape[0])
+        if nc <= DENSE_COARSE_MAX and not force_sparse:
+            Ainv = np.asfortranarray(param.LU.solve(np.eye(nc)))        # LU \ I, column-major
+            _check(lib, lib.mg_set_coarse_dense_inverse_FP64(self.handle, nc, _f64(Ainv)), "mg_set_coarse_dense_inverse")
+            return
+        lu = param.LU
+        L = sp.csr_matrix(lu.L)
+        U = sp.csr_matrix(lu.U)
+        L.sort_indices()
+        U.sort_indices()                                                # lower: diagonal last; upper: diagonal first
+        a64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        Lp, Lc, Lv = a64(L.indptr) + 1, a64(L.indices) + 1, np.ascontiguousarray(L.data, dtype=np.float64)
+        Up, Uc, Uv = a64(U.indptr) + 1, a64(U.indices) + 1, np.ascontiguousarray(U.data, dtype=np.float64)
+        p = a64(np.argsort(lu.perm_r)) + 1                              # A[p, q] = L U
+        q = a64(np.argsort(lu.perm_c)) + 1
+        _check(lib, lib.mg_set_coarse_lu_FP64_INT64(self.handle, nc, _i64(Lp), _i64(Lc), _f64(Lv), _i64(Up), _i64(Uc),
+                                                    _f64(Uv), _i64(p), _i64(q)), "mg_set_coarse_lu")
 
     def set_nrhs(self, nrhs: int):
         _check(self.lib, self.lib.mg_set_nrhs(self.handle, int(nrhs)), "mg_set_nrhs")
@@ -233,10 +251,9 @@ class DeviceHierarchy:
             d = np.empty(param.As[l - 1].shape[0], dtype=np.float64)
             _check(lib, lib.mg_get_relax_FP64(self.handle, l, _f64(d), d.size), "mg_get_relax")
             param.relaxPrecs[l - 1] = d
-        param.LU = spla.splu(sp.csc_matrix(param.As[-1]))          # defineCoarsestAinv (MGsetup.jl:350)
-        nc = int(param.As[-1].shape[0])
-        Ainv = np.asfortranarray(param.LU.solve(np.eye(nc)))
-        _check(lib, lib.mg_set_coarse_dense_inverse_FP64(self.handle, nc, _f64(Ainv)), "mg_set_coarse_dense_inverse")
+        from .mgsetup import coarse_lu
+        param.LU = coarse_lu(param.As[-1])                           # defineCoarsestAinv (MGsetup.jl:350)
+        self._set_coarse(param)
         _check(lib, lib.mg_finalize(self.handle), "mg_finalize")
 
     def close(self):

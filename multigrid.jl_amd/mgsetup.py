@@ -82,7 +82,14 @@ def defineCoarsestAinv(param: MGparam, Ac) -> None:
     if param.coarseSolveType == "GMRES":
         # Jacobi-preconditioned FGMRES coarse solve (MGcycle.jl:152-168): SURVEY 8f-3, not on the device path yet.
         raise NotImplementedError("coarseSolveType='GMRES' is a 'next' row (SURVEY 8f-3)")
-    param.LU = spla.splu(sp.csc_matrix(Ac))
+    param.LU = coarse_lu(Ac)
+
+
+def coarse_lu(Ac):
+    """``lu(sparse(AT'))`` (MGsetup.jl:350).  Julia's lu is UMFPACK, which orders symmetric-pattern matrices by AMD on
+    A+A'; SuperLU's closest ordering is MMD on A'+A (half the fill of its COLAMD default on these operators: 18M vs
+    40M nonzeros per factor on a 33^3 27-point level)."""
+    return spla.splu(sp.csc_matrix(Ac), permc_spec="MMD_AT_PLUS_A")
 
 
 def MGsetup(ATf, Mesh, param: MGparam, nrhs: int = 1, verbose: bool = False) -> MGparam:
@@ -205,5 +212,5 @@ def transposeHierarchy(param: MGparam, verbose: bool = False) -> None:
         param.Rs[l - 1] = _as_csr(newP.T)
         param.As[l] = _as_csr(param.As[l].T)
     destroyCoarsestLU(param)
-    param.LU = spla.splu(sp.csc_matrix(param.As[-1]))
+    param.LU = coarse_lu(param.As[-1])
     _release_device(param)

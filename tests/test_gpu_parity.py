@@ -330,3 +330,43 @@ def test_rediscretised_hierarchy_on_device(mg, built):
     b /= np.linalg.norm(b)
     _compare_solve(mg, p, b)
     mg.clear_(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells,levels,nrhs", [([16, 16, 16], 3, 1), ([32, 32], 3, 3), ([24, 24, 24], 2, 2)])
+def test_sparse_lu_coarse_solve(mg, built, cells, levels, nrhs, monkeypatch):
+    """Coarsest levels above the dense-inverse cap are solved on the device from the SPARSE factors in the layout of
+    the reference's native applier (mg_set_coarse_lu_FP64_INT64 <-> deps/src/parLU.cpp:120-190).  Forced here on small
+    hierarchies: the whole solve must match the oracle exactly as the dense-inverse path does, and (where the
+    reference binary was built) the coarse solve alone must match applyLUsolve_FP64_INT64."""
+    from multigrid_jl_amd import device as D
+    monkeypatch.setattr(D, "DENSE_COARSE_MAX", 0)
+    A, p, b = _setup(mg, cells, levels, nrhs=nrhs)
+    _compare_solve(mg, p, b)
+    # the coarse solve in isolation: a 1-level "hierarchy" is just x = LU \ b (recursiveCycle at the coarsest level)
+    Ac = p.As[-1]
+    q = mg.getMGparam(np.float64, np.int64, 1, 8, 1, 1e-10, "Jac", 0.8, 2, 1)
+    q.As, q.Ps, q.Rs, q.relaxPrecs, q.LU, q.Meshes, q.levels = [Ac], [], [], [], p.LU, [p.Meshes[-1]], 1
+    q.nrhs = nrhs
+    rng = np.random.default_rng(5)
+    B = np.asfortranarray(rng.standard_normal((Ac.shape[0], nrhs))) if nrhs > 1 else rng.standard_normal(Ac.shape[0])
+    X = mg.recursiveCycle(q, B.copy(order="F"), np.zeros_like(B, order="F"), 1)
+    Xo = p.LU.solve(B)
+    assert np.abs(X - Xo).max() <= 1e-12 * np.abs(Xo).max()
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "parLU.so")
+    if os.path.exists(ref):
+        from test_reference_parlu import _ref_lu_solve
+        Xr = _ref_lu_solve(p.LU, B)
+        assert np.abs(X - Xr).max() <= 1e-12 * np.abs(Xr).max()
+    mg.clear_(q)
+    mg.clear_(p)
+
+
+@pytest.mark.gpu
+def test_large_coarsest_level_uses_sparse_factors(mg, built):
+    """levels=2 on 64^3 leaves a 33^3 = 35 937-row coarsest level (> 16 384): the reference handles any size through
+    its sparse LU (MGsetup.jl:350), so must the device path."""
+    A, p, b = _setup(mg, [64, 64, 64], 2, maxIter=4)
+    assert p.As[-1].shape[0] == 33 ** 3
+    _compare_solve(mg, p, b)
+    mg.clear_(p)
