@@ -198,8 +198,20 @@ def main():
             traffic = json.load(open(tfile)).get(f"{args.workload}_{cells}", {}).get("smooth_symbol_bytes_per_launch")
         except Exception:
             traffic = None
-    kname = ("mgk::csr_stream_spmv<2, true>" if nrhs == 1 else "mgk::csr_stream_spmm<2, true>") if nt_levels else \
-        ("mgk::csr_stream_spmv<2, false>" if nrhs == 1 else "mgk::csr_stream_spmm<2, false>")
+    # the kernel SYMBOL serving those levels (as `rocprofv3 --stats` names it): pattern-coded operators run
+    # csr_pattern_spmv<MODE=2 (smooth), NT, DLDS> at nrhs == 1, everything else csr_stream_spmv / csr_stream_spmm
+    nt = "true" if nt_levels else "false"
+    lv = nt_levels or list(range(1, len(p.As)))
+    fmts = [h.operator_format(l, mg.device.MG_OP_A) for l in lv]
+    if nrhs > 1:
+        kname = f"mgk::csr_stream_spmm<2, {nt}>"
+    elif all(f[0] > 0 for f in fmts):
+        dlds = "true" if all(f[1] <= 1024 and f[0] < 1024 for f in fmts) else "false"
+        kname = f"mgk::csr_pattern_spmv<2, {nt}, {dlds}>"
+    elif all(f[0] == 0 for f in fmts):
+        kname = f"mgk::csr_stream_spmv<2, {nt}>"
+    else:
+        kname = f"mgk::csr_pattern_spmv<2, {nt}, *> + mgk::csr_stream_spmv<2, {nt}> (mixed formats)"
     if not sm_all:
         sm_all = [v for (l, k), v in prof.items() if k == "smooth"]
         all_ms = sum(v[0] for v in sm_all); all_cnt = sum(v[1] for v in sm_all); all_bytes = sum(v[2] * v[1] for v in sm_all)
