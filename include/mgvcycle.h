@@ -199,6 +199,12 @@ int mg_profile_reset(mg_hierarchy* h);
  * dictionary length, and the index-side bytes (row pointers + column information) of one nrhs=1 launch. */
 int mg_operator_format(mg_hierarchy* h, long long level, long long which, long long* npatterns,
                        long long* dict_entries, double* index_bytes_per_launch);
+/* Row-class form of one operator (csr_rowclass_spmv): number of distinct rows (same column offsets from the row's
+ * first column AND bit-identical values; 0 = the operator is not stored that way), dictionary length, and the
+ * matrix-side bytes one nrhs=1 launch of the kernel in use actually streams (row classes: 6 B/row + dictionary;
+ * pattern-coded: 8 B/nnz + descriptors; plain CSR: 12 B/nnz + row pointers).  Lossless; chosen at upload. */
+int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, long long* nclasses,
+                           long long* dict_entries, double* matrix_bytes_per_launch);
 /* Algorithmic HBM bytes of one full cycle (x0 = 0) with the current nrhs, DESIGN.md section 5. */
 int mg_cycle_bytes(mg_hierarchy* h, double* bytes);
 /* HBM bytes held by the hierarchy. */

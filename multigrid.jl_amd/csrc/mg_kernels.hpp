@@ -393,6 +393,160 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-class SpMV (value-indexed, pattern-coded CSR; one right-hand side).
+// Operators of constant-coefficient stencils - and their Galerkin coarse operators, and the full-weighting P / R -
+// consist of a handful of distinct rows: the same column offsets (relative to the row's first column) carrying the
+// same values.  The host finds these classes at upload (bit-exact comparison of offsets and values, mgvcycle.hip
+// build_rowclasses) and, when the dictionary is small, the device keeps per row only {first column int32, class
+// uint16}; offsets and values come from the dictionary.  The matrix stream (12 B per non-zero) disappears: a launch
+// moves 6 B per row plus the vectors.  LOSSLESS: the products and their summation order (ascending k, as in the
+// reference's CSR loop, SpMatMul.jl:4-13 / parRelax.cpp) are those of the CSR arrays, which stay resident for the
+// block-RHS kernels, the numeric Galerkin product and mg_get_values.  Operators without this redundancy (variable
+// coefficients, SA-AMG levels) never get here and use the kernels above.
+// One thread per row: consecutive lanes gather consecutive x entries (coalesced) and the dictionary loads of a wave
+// whose 64 rows share one class are wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------------------
+struct RowClassDev {
+  const int* firstcol;          // n_rows
+  const unsigned short* cls;    // n_rows
+  const int* cls_ptr;           // ncls + 1
+  const int* cls_off;           // dictionary: column offset from the row's first column
+  const double* cls_val;        // dictionary: value
+  int nblocks;                  // ceil(n_rows / RC_ROWS)
+  int n_rows;
+};
+
+#ifndef MG_RC_RPT
+#define MG_RC_RPT 2
+#endif
+constexpr int RC_RPT = MG_RC_RPT;       // rows per lane: RC_RPT independent gather chains in flight
+constexpr int RC_ROWS = BLK * RC_RPT;   // rows per workgroup (lane t holds rows t, t + BLK, ...)
+
+template <int MODE>
+__global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs v) {
+  __shared__ double red[BLK / 64];
+  const int tid = threadIdx.x;
+  const int bid = xcd_band(blockIdx.x, C.nblocks);
+  const int base = bid * RC_ROWS + tid;
+  int first[RC_RPT], cls[RC_RPT];
+  double pb[RC_RPT], pd[RC_RPT], px[RC_RPT], acc[RC_RPT];
+#pragma unroll
+  for (int j = 0; j < RC_RPT; ++j) {
+    const int row = base + j * BLK;
+    const int rr = row < C.n_rows ? row : C.n_rows - 1;   // dead lanes repeat the last row (never stored)
+    first[j] = C.firstcol[rr];
+    cls[j] = C.cls[rr];
+    pb[j] = pd[j] = px[j] = 0.0;
+    acc[j] = 0.0;
+    if (MODE == AXPBY) {
+      if (v.beta != 0.0) pb[j] = v.beta * v.y[rr];
+    } else {
+      pb[j] = v.b[rr];
+      if (MODE == SMOOTH) {
+        pd[j] = v.d[rr];
+        px[j] = v.xs[rr];
+      }
+    }
+  }
+  // Waterfall over the distinct classes held by the wave (one for a grid interior; a line end or a coarse/fine
+  // parity adds a pass).  A pass serves every lane x slot of class cc with wave-uniform dictionary accesses (scalar
+  // loads): k outermost, the gathers of all slots issued back to back.  Slots of another class gather at the
+  // leader's base instead (a valid, discarded broadcast read), so nothing is masked.  The membership predicates come
+  // from ballot masks, not from `cls == cc`: the compiler would otherwise substitute the per-lane value for the
+  // uniform cc inside the branch and fall back to per-lane (vector) dictionary loads.
+  const unsigned long long lanebit = 1ull << (tid & 63);
+  unsigned long long todo[RC_RPT];
+#pragma unroll
+  for (int j = 0; j < RC_RPT; ++j) todo[j] = __ballot(1);
+  for (;;) {
+    int cc = 0, lead = 0;
+    bool any = false;
+#pragma unroll
+    for (int j = RC_RPT - 1; j >= 0; --j)
+      if (todo[j]) {   // wave-uniform
+        const int l = __builtin_ctzll(todo[j]);
+        cc = __builtin_amdgcn_readlane(cls[j], l);
+        lead = __builtin_amdgcn_readlane(first[j], l);
+        any = true;
+      }
+    if (!any) break;
+    bool in[RC_RPT];
+    const double* xb[RC_RPT];
+    double a[RC_RPT];
+#pragma unroll
+    for (int j = 0; j < RC_RPT; ++j) {
+      const unsigned long long m = __ballot(cls[j] == cc) & todo[j];
+      todo[j] &= ~m;
+      in[j] = (m & lanebit) != 0;
+      xb[j] = v.x + (in[j] ? first[j] : lead);
+      a[j] = 0.0;
+    }
+#if defined(MG_RC_EXP) && MG_RC_EXP == 1   // timing experiment only (wrong results): one gather per row
+    const int s = C.cls_ptr[cc], e = s + 1;
+#else
+    const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
+#endif
+    int k = s;
+    for (; k + 3 < e; k += 4) {
+#if defined(MG_RC_EXP) && MG_RC_EXP == 2   // timing experiment only (wrong results): every gather at offset 0
+      const int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+#else
+      const int o0 = C.cls_off[k], o1 = C.cls_off[k + 1], o2 = C.cls_off[k + 2], o3 = C.cls_off[k + 3];
+#endif
+      const double a0 = C.cls_val[k], a1 = C.cls_val[k + 1], a2 = C.cls_val[k + 2], a3 = C.cls_val[k + 3];
+      double x0[RC_RPT], x1[RC_RPT], x2[RC_RPT], x3[RC_RPT];
+#pragma unroll
+      for (int j = 0; j < RC_RPT; ++j) {
+        x0[j] = xb[j][o0];
+        x1[j] = xb[j][o1];
+        x2[j] = xb[j][o2];
+        x3[j] = xb[j][o3];
+      }
+#pragma unroll
+      for (int j = 0; j < RC_RPT; ++j) {
+        a[j] += a0 * x0[j];
+        a[j] += a1 * x1[j];
+        a[j] += a2 * x2[j];
+        a[j] += a3 * x3[j];
+      }
+    }
+    for (; k < e; ++k) {
+#if defined(MG_RC_EXP) && MG_RC_EXP == 2
+      const int o0 = 0;
+#else
+      const int o0 = C.cls_off[k];
+#endif
+      const double a0 = C.cls_val[k];
+#pragma unroll
+      for (int j = 0; j < RC_RPT; ++j) a[j] += a0 * xb[j][o0];
+    }
+#pragma unroll
+    for (int j = 0; j < RC_RPT; ++j)
+      if (in[j]) acc[j] = a[j];
+  }
+  double sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < RC_RPT; ++j) {
+    const int row = base + j * BLK;
+    if (row < C.n_rows) {
+      const double outv = epilogue<MODE>(v, row, acc[j], pb[j], pd[j], px[j]);
+      v.y[row] = outv;
+      sq += outv * outv;
+    }
+  }
+  if (v.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) t += red[w];
+      v.sumsq[bid] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // CSR-stream SpMM, nrhs > 1, vectors row-major [n][nrhs].
 // The nnz segment (values AND column indices) is staged in LDS with coalesced loads; then G lanes
 // (G = pow2 >= nrhs, <= 64) own one row x one RHS column each and walk the row from LDS (broadcast

@@ -97,6 +97,13 @@ struct Csr {
   long long nruns_total = 0;
   bool has_pat = false;
   long long npat = 0, dict_entries = 0;
+  // row classes (csr_rowclass_spmv): first column + class id per row, dictionary of (offset, value) rows
+  DevBuf<int> rc_first, rc_ptr, rc_off;
+  DevBuf<unsigned short> rc_cls;
+  DevBuf<double> rc_val;
+  bool has_rc = false;
+  long long rc_ncls = 0, rc_entries = 0;
+  std::vector<int> h_rp, h_ci;  // host pattern, kept only while has_rc (to re-derive the classes for new values)
   std::vector<int> h_blk_row;  // host copy of the row-block boundaries (for building schedules)
   int max_row_nnz = 0;
   bool has_sched = false;
@@ -121,6 +128,29 @@ struct Csr {
     d.nblocks = nblocks_mm;
     return d;
   }
+  int rc_blocks() const { return (int)((n_rows + mgk::RC_ROWS - 1) / mgk::RC_ROWS); }
+  // workgroups of the nrhs == 1 product (one fused ||r||^2 partial each)
+  int blocks1() const { return has_rc ? rc_blocks() : nblocks; }
+  mgk::RowClassDev rcdev() const {
+    mgk::RowClassDev c;
+    c.firstcol = rc_first.p;
+    c.cls = rc_cls.p;
+    c.cls_ptr = rc_ptr.p;
+    c.cls_off = rc_off.p;
+    c.cls_val = rc_val.p;
+    c.nblocks = rc_blocks();
+    c.n_rows = (int)n_rows;
+    return c;
+  }
+  void drop_rc() {
+    rc_first.release();
+    rc_ptr.release();
+    rc_off.release();
+    rc_cls.release();
+    rc_val.release();
+    has_rc = false;
+    rc_ncls = rc_entries = 0;
+  }
   mgk::PatDev patdev() const {
     mgk::PatDev p;
     p.firstcol = firstcol.p;
@@ -134,6 +164,11 @@ struct Csr {
     return p;
   }
   void release() {
+    drop_rc();
+    h_rp.clear();
+    h_rp.shrink_to_fit();
+    h_ci.clear();
+    h_ci.shrink_to_fit();
     run_ptr.release();
     runs.release();
     has_runs = false;
@@ -299,7 +334,9 @@ template <int MODE>
 int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
-  if (v.nrhs == 1 && M.has_pat) {
+  if (v.nrhs == 1 && M.has_rc) {
+    hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE>), dim3(M.rc_blocks()), blk, 0, stream, M.rcdev(), v);
+  } else if (v.nrhs == 1 && M.has_pat) {
     const bool dl = M.dict_entries <= mgk::DICT_LDS && M.npat < mgk::DICT_LDS;
     if (M.nt && dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
     else if (M.nt) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
@@ -344,7 +381,8 @@ int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const 
 int k_sumsq(mg_hierarchy* h, const double* x, long long len);
 // out = b - A*x and h->scalar = ||out||^2 in the same pass (nrhs == 1); falls back to two kernels for blocks
 int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x, double* out) {
-  if (h->nrhs != 1 || (size_t)A.nblocks > h->partial.n) {
+  const int nb1 = A.blocks1();
+  if (h->nrhs != 1 || (size_t)nb1 > h->partial.n) {
     MG_TRY(k_residual(h, level, A, b, x, out));
     return k_sumsq(h, out, A.n_rows * h->nrhs);
   }
@@ -358,9 +396,9 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
     ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false));
     MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v));
   }
-  ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)A.nblocks);
-  const int nb2 = std::min(256, (A.nblocks + mgk::BLK - 1) / mgk::BLK);
-  hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)A.nblocks, h->partial2.p);
+  ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1);
+  const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
+  hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
   hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
   HIP_TRY(hipGetLastError());
   return MG_OK;
@@ -1206,6 +1244,82 @@ int build_patterns(Csr* M, const std::vector<int>& rp, const std::vector<int>& c
   return MG_OK;
 }
 
+// Row classes: rows with identical column offsets (relative to the row's first column) AND bit-identical values.
+// Accepted when the operator really is that redundant: at most 65535 classes and a dictionary of at most
+// min(nnz/16, 2^18) entries (3 MiB: L2-resident).  Anything else keeps the streaming formats.  Lossless.
+int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
+  M->drop_rc();
+  const long long n = M->n_rows;
+  if (n < 1 || M->nnz < 1) return MG_OK;
+  const size_t cap = (size_t)std::min<long long>(1LL << 18, std::max<long long>(64, M->nnz / 16));
+  std::vector<int> first((size_t)n, 0), cptr(1, 0), coff;
+  std::vector<unsigned short> cid((size_t)n, 0);
+  std::vector<double> cval;
+  std::unordered_map<unsigned long long, std::vector<int>> table;
+  for (long long i = 0; i < n; ++i) {
+    const int s = rp[(size_t)i], e = rp[(size_t)i + 1];
+    const int f = (e > s) ? ci[(size_t)s] : 0;
+    first[(size_t)i] = f;
+    unsigned long long hsh = 1469598103934665603ull ^ (unsigned long long)(e - s);
+    for (int k = s; k < e; ++k) {
+      unsigned long long bits;
+      std::memcpy(&bits, &val[(size_t)k], 8);
+      hsh ^= (unsigned long long)(unsigned int)(ci[(size_t)k] - f);
+      hsh *= 1099511628211ull;
+      hsh ^= bits;
+      hsh *= 1099511628211ull;
+    }
+    std::vector<int>& cand = table[hsh];
+    int found = -1;
+    for (int id : cand) {
+      const int ps = cptr[(size_t)id], len = cptr[(size_t)id + 1] - ps;
+      if (len != e - s) continue;
+      bool same = true;
+      for (int k = 0; k < len && same; ++k)
+        same = coff[(size_t)ps + k] == ci[(size_t)s + k] - f &&
+               std::memcmp(&cval[(size_t)ps + k], &val[(size_t)s + k], 8) == 0;
+      if (same) { found = id; break; }
+    }
+    if (found < 0) {
+      found = (int)cptr.size() - 1;
+      if (found >= 65535 || coff.size() + (size_t)(e - s) > cap) return MG_OK;  // not that redundant
+      for (int k = s; k < e; ++k) {
+        coff.push_back(ci[(size_t)k] - f);
+        cval.push_back(val[(size_t)k]);
+      }
+      cptr.push_back((int)coff.size());
+      cand.push_back(found);
+    }
+    cid[(size_t)i] = (unsigned short)found;
+  }
+  if (coff.empty()) { coff.push_back(0); cval.push_back(0.0); }
+  MG_TRY(M->rc_first.alloc(first.size()));
+  MG_TRY(M->rc_cls.alloc(cid.size()));
+  MG_TRY(M->rc_ptr.alloc(cptr.size()));
+  MG_TRY(M->rc_off.alloc(coff.size()));
+  MG_TRY(M->rc_val.alloc(cval.size()));
+  HIP_TRY(hipMemcpy(M->rc_first.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->rc_cls.p, cid.data(), cid.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->rc_ptr.p, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->rc_off.p, coff.data(), coff.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M->rc_val.p, cval.data(), cval.size() * sizeof(double), hipMemcpyHostToDevice));
+  M->rc_ncls = (long long)cptr.size() - 1;
+  M->rc_entries = (long long)coff.size();
+  M->has_rc = true;
+  return MG_OK;
+}
+bool rowclass_enabled() {
+  const char* e = std::getenv("MG_NO_ROWCLASS");
+  return !(e && e[0] == '1');
+}
+// New values on the stored pattern (mg_replace_values_FP64, mg_rap_FP64): the classes are re-derived from the host
+// pattern kept for that purpose; an operator that is no longer redundant falls back to the streaming kernels.
+int refresh_rowclasses(Csr* M, const double* val) {
+  if (!M->has_rc) return MG_OK;
+  if (M->h_rp.size() != (size_t)M->n_rows + 1) { M->drop_rc(); return MG_OK; }
+  return build_rowclasses(M, M->h_rp.data(), M->h_ci.data(), val);
+}
+
 // Validate Julia's (colptr,rowval,nzval) of the transposed CSC (1-based Int64), convert to 0-based int32
 // CSR (the reference's C side does the -1 per access, parRelax.h:24-27), cut the rows into row blocks
 // and upload.
@@ -1276,6 +1390,13 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
   // 685 MB..1.4 GB operators of C2, -5..25 % on the 89 MB ones); MG_NT=0/1 forces one policy
   M->nt = (12.0 * (double)nnz > 128.0e6);
   if (const char* e = std::getenv("MG_NT")) M->nt = (e[0] == '1');
+  if (rowclass_enabled()) {  // few distinct rows (offsets AND values): no matrix stream at all at nrhs == 1
+    MG_TRY(build_rowclasses(M, rp.data(), ci.data(), nzval));
+    if (M->has_rc) {
+      M->h_rp = rp;
+      M->h_ci = ci;
+    }
+  }
   {  // pattern-code the column indices when the operator has few distinct row patterns (grid operators)
     const char* e = std::getenv("MG_NO_PATTERN");
     if (!(e && e[0] == '1')) MG_TRY(build_patterns(M, rp, ci));
@@ -1370,6 +1491,16 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(spin_sync(h->stream));
+  // row-class dictionaries follow the new values (coarse values come back from HBM; the atomically accumulated
+  // products are usually no longer bit-identical from row to row, in which case the level reverts to streaming)
+  MG_TRY(refresh_rowclasses(&L0.A, fine_nzval));
+  for (int l = 1; l < nl; ++l) {
+    Csr& Ac = h->lev[(size_t)l].A;
+    if (!Ac.has_rc) continue;
+    std::vector<double> hv((size_t)Ac.nnz);
+    HIP_TRY(hipMemcpy(hv.data(), Ac.val.p, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
+    MG_TRY(refresh_rowclasses(&Ac, hv.data()));
+  }
   if (levels_done) *levels_done = nl - 1;
   return MG_OK;
 }
@@ -1662,7 +1793,7 @@ int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, co
   (void)hipSetDevice(h->device);
   HIP_TRY(spin_sync(h->stream));
   HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-  return MG_OK;
+  return refresh_rowclasses(M, nzval);
 }
 
 // ---- device-resident hot path ---------------------------------------------------------------------
@@ -1968,6 +2099,26 @@ int mg_operator_format(mg_hierarchy* h, long long level, long long which, long l
         ? (M->has_runs ? 20.0 * (double)M->nruns_total + 8.0 * (double)M->nblocks : 10.0 * (double)M->n_rows) +
               4.0 * (double)M->dict_entries
         : 4.0 * (double)M->nnz + 4.0 * (double)(M->n_rows + 1);
+  return MG_OK;
+}
+
+int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, long long* nclasses,
+                           long long* dict_entries, double* matrix_bytes_per_launch) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  Csr* M = pick(h, level, which);
+  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
+  if (nclasses) *nclasses = M->has_rc ? M->rc_ncls : 0;
+  if (dict_entries) *dict_entries = M->has_rc ? M->rc_entries : 0;
+  if (matrix_bytes_per_launch) {
+    if (M->has_rc) {
+      *matrix_bytes_per_launch = 6.0 * (double)M->n_rows + 12.0 * (double)M->rc_entries;
+    } else if (M->has_pat) {
+      *matrix_bytes_per_launch = 8.0 * (double)M->nnz + 4.0 * (double)M->dict_entries +
+          (M->has_runs ? 20.0 * (double)M->nruns_total + 8.0 * (double)M->nblocks : 10.0 * (double)M->n_rows);
+    } else {
+      *matrix_bytes_per_launch = 12.0 * (double)M->nnz + 4.0 * (double)(M->n_rows + 1);
+    }
+  }
   return MG_OK;
 }
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mg_profile_get": (C.c_int, [_vp, _ll, _ll, _dp, _lp, _dp]),
     "mg_profile_reset": (C.c_int, [_vp]),
     "mg_operator_format": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
+    "mg_operator_rowclasses": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
     "mg_cycle_bytes": (C.c_int, [_vp, _dp]),
     "mg_device_bytes": (C.c_int, [_vp, _dp]),
     "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
@@ -415,6 +416,14 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_operator_format(self.handle, level, which, C.byref(npat), C.byref(nd), C.byref(ib)),
                "mg_operator_format")
         return int(npat.value), int(nd.value), ib.value
+
+    def operator_rowclasses(self, level: int, which: int):
+        """(number of row classes [0 = not stored that way], dictionary entries, matrix-side bytes one nrhs=1 launch of
+        the kernel in use streams)."""
+        nc, nd, mb = C.c_longlong(0), C.c_longlong(0), C.c_double(0)
+        _check(self.lib, self.lib.mg_operator_rowclasses(self.handle, level, which, C.byref(nc), C.byref(nd), C.byref(mb)),
+               "mg_operator_rowclasses")
+        return int(nc.value), int(nd.value), mb.value
 
     def cycle_bytes(self) -> float:
         v = C.c_double(0)

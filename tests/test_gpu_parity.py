@@ -218,6 +218,7 @@ def test_pattern_coded_kernel_paths(mg, built, monkeypatch):
     import torch
     import scipy.sparse as sp
     from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_NO_ROWCLASS", "1")            # this test is about the two STREAMING formats
     rng = np.random.default_rng(7)
     nr, L = 700, 2500                                    # 2500 > CHUNK-2: every row takes the long-row path
     rows = np.repeat(np.arange(nr), L)
@@ -369,4 +370,79 @@ def test_large_coarsest_level_uses_sparse_factors(mg, built):
     A, p, b = _setup(mg, [64, 64, 64], 2, maxIter=4)
     assert p.As[-1].shape[0] == 33 ** 3
     _compare_solve(mg, p, b)
+    mg.clear_(p)
+
+
+@pytest.mark.gpu
+def test_rowclass_kernel_paths(mg, built, monkeypatch):
+    """csr_rowclass_spmv (rows stored as {first column, class id}, offsets AND values from a dictionary) against the
+    streaming kernels on the same operators: every fused epilogue, A / P / R of a GMG hierarchy, the fused ||r||^2,
+    a solve under both settings, and an operator WITHOUT redundant rows (must not be stored that way)."""
+    import torch
+    import scipy.sparse as sp
+    from multigrid_jl_amd import device as D
+    rng = np.random.default_rng(17)
+    A, _ = mg.poisson_shifted([14, 12, 10])
+    Arand = A.copy()
+    Arand.data = rng.standard_normal(A.nnz)              # same pattern, all rows distinct
+    P = mg.getFWInterp(np.array([15, 13, 11]))[0]
+    R = (0.125 * P.T).tocsr()
+    for M, square in ((A, True), (P, False), (R, False), (Arand, True)):
+        x = torch.from_numpy(rng.standard_normal(M.shape[1])).cuda()
+        b = torch.from_numpy(rng.standard_normal(M.shape[0])).cuda()
+        d = torch.from_numpy(rng.standard_normal(M.shape[0])).cuda()
+        outs = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("MG_NO_ROWCLASS", mode)
+            op = D.DeviceOperator(M, 0)
+            res = []
+            y = torch.ones(M.shape[0], dtype=torch.float64, device="cuda")
+            op.apply(D.MG_K_SPMV, x, y, alpha=-0.5, beta=2.0)
+            res.append(y.cpu().numpy().copy())
+            op.apply(D.MG_K_SPMV, x, y, alpha=1.0, beta=0.0)
+            res.append(y.cpu().numpy().copy())
+            op.apply(D.MG_K_RESIDUAL, x, y, b=b)
+            res.append(y.cpu().numpy().copy())
+            if square:
+                op.apply(D.MG_K_SMOOTH, x, y, b=b, d=d)
+                res.append(y.cpu().numpy().copy())
+            torch.cuda.synchronize()
+            outs[mode] = res
+            op.close()
+        xn, bn, dn = x.cpu().numpy(), b.cpu().numpy(), d.cpu().numpy()
+        want = [-0.5 * (M @ xn) + 2.0, M @ xn, bn - M @ xn] + ([xn + dn * (bn - M @ xn)] if square else [])
+        for got0, got1, w in zip(outs["0"], outs["1"], want):
+            scale = np.abs(w).max()
+            assert np.abs(got0 - w).max() / scale < KERNEL_TOL
+            assert np.abs(got1 - w).max() / scale < KERNEL_TOL
+    # inside a hierarchy: which operators are stored as row classes, and the solve is the same either way
+    hist = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MG_NO_ROWCLASS", mode)
+        A, p, b = _setup(mg, [20, 18, 16], 3)
+        x = np.zeros_like(b)
+        mg.solveMG(p, b, x)
+        fm = {(l, w): p.device.operator_rowclasses(l, k)[0] for l in (1, 2)
+              for w, k in (("A", D.MG_OP_A), ("P", D.MG_OP_P), ("R", D.MG_OP_R))}
+        if mode == "0":
+            # constant-coefficient GMG: the fine operators qualify (tiny coarse ones may not: dictionary > nnz/16)
+            assert all(v > 0 for (l, w), v in fm.items() if l == 1), fm
+        else:
+            assert all(v == 0 for v in fm.values()), fm
+        hist[mode] = (x.copy(), np.asarray(p.resvec).copy())
+        _compare_solve(mg, p, b)
+        mg.clear_(p)
+    assert np.abs(hist["0"][1] - hist["1"][1]).max() <= RES_TOL * hist["1"][1][0]
+    assert np.abs(hist["0"][0] - hist["1"][0]).max() <= RES_TOL * np.abs(hist["1"][0]).max()
+    # a hierarchy on the non-redundant operator keeps the streaming formats
+    monkeypatch.setenv("MG_NO_ROWCLASS", "0")
+    Ad, mesh = mg.poisson_shifted([12, 12, 12])
+    sig = sp.diags(1.0 + rng.random(Ad.shape[0]))
+    Av = (sig @ Ad @ sig).tocsr()                         # SPD, variable coefficients
+    p = mg.getMGparam(np.float64, np.int64, 2, 8, 4, 1e-10, "Jac", 0.8, 2, 1)
+    mg.MGsetup(Av, mesh, p, 1)
+    bv = mg.seeded_rhs(Av, 1)
+    _compare_solve(mg, p, bv)
+    assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] == 0
+    assert p.device.operator_rowclasses(1, D.MG_OP_P)[0] > 0
     mg.clear_(p)
