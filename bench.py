@@ -252,6 +252,7 @@ def main():
                                     "streamed_bytes_per_launch": (fine_streamed if nrhs == 1 else None),
                                     "streamed_achieved": (round(fine_streamed / (ms_s / cnt_s) / 1e6, 1) if nrhs == 1 else None)},
                 "residual_level1": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in dom["residual"].items()},
+                "kernel_ms_per_step": round(tot_ms / K, 4),
                 "step_algorithmic_GB": round(step_bytes / 1e9, 4),
                 "step_hbm_gbs": round(step_bytes / (dt / K) / 1e9, 1),
                 "kernel_time_share": {f"L{l}:{k}": round(v[0] / tot_ms, 4) for (l, k), v in sorted(prof.items()) if v[0] / tot_ms > 0.01}}

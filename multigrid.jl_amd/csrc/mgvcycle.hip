@@ -1293,6 +1293,31 @@ int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
     cid[(size_t)i] = (unsigned short)found;
   }
   if (coff.empty()) { coff.push_back(0); cval.push_back(0.0); }
+  {
+    // The kernel serves one class per waterfall pass: it only pays when a wavefront's 64 consecutive rows hold few
+    // classes.  Measured on C2: levels of 35 937 rows and fewer (every wave sees a dozen classes, and the whole level
+    // is L2-resident anyway) ran 3x slower than with the streaming kernels -> require <= 4 classes per wave on
+    // average, and enough rows for the matrix stream to matter.
+    long long min_rows = 100000, max_passes = 4;   // MG_ROWCLASS_MIN_ROWS / MG_ROWCLASS_MAX_PASSES: tests, A/B
+    if (const char* e = std::getenv("MG_ROWCLASS_MIN_ROWS")) min_rows = std::atoll(e);
+    if (const char* e = std::getenv("MG_ROWCLASS_MAX_PASSES")) max_passes = std::atoll(e);
+    if (n < min_rows) return MG_OK;
+    long long passes = 0, waves = 0;
+    for (long long w0 = 0; w0 < n; w0 += 64) {
+      unsigned short seen[64];
+      int ns = 0;
+      const long long w1 = std::min(n, w0 + 64);
+      for (long long i = w0; i < w1; ++i) {
+        bool dup = false;
+        for (int t = 0; t < ns; ++t)
+          if (seen[t] == cid[(size_t)i]) { dup = true; break; }
+        if (!dup) seen[ns++] = cid[(size_t)i];
+      }
+      passes += ns;
+      ++waves;
+    }
+    if (passes > max_passes * waves) return MG_OK;
+  }
   MG_TRY(M->rc_first.alloc(first.size()));
   MG_TRY(M->rc_cls.alloc(cid.size()));
   MG_TRY(M->rc_ptr.alloc(cptr.size()));

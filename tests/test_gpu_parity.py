@@ -381,6 +381,9 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
     import torch
     import scipy.sparse as sp
     from multigrid_jl_amd import device as D
+    # by default only operators of >= 100 000 rows with <= 4 classes per wavefront are stored this way
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     rng = np.random.default_rng(17)
     A, _ = mg.poisson_shifted([14, 12, 10])
     Arand = A.copy()
@@ -445,4 +448,12 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
     _compare_solve(mg, p, bv)
     assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] == 0
     assert p.device.operator_rowclasses(1, D.MG_OP_P)[0] > 0
+    mg.clear_(p)
+    # default thresholds: a 64x64x48-cell grid qualifies on the fine level only (small levels stay streaming)
+    monkeypatch.delenv("MG_ROWCLASS_MIN_ROWS")
+    monkeypatch.delenv("MG_ROWCLASS_MAX_PASSES")
+    A, p, b = _setup(mg, [64, 64, 48], 4, maxIter=4)
+    _compare_solve(mg, p, b)
+    assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] > 0
+    assert p.device.operator_rowclasses(3, D.MG_OP_A)[0] == 0
     mg.clear_(p)
