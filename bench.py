@@ -214,7 +214,8 @@ def main():
     streamed = None
     if nrhs == 1:
         # matrix-side bytes of the kernel in use + the vectors of a SMOOTH launch (x gathered once, b, d, x' written)
-        per_level = {l: rcs[l][2] + 32.0 * p.As[l - 1].shape[0] for l in lv}
+        # vectors of a SMOOTH launch: x gathered once, b, x' written (+ d unless it comes from the class dictionary)
+        per_level = {l: rcs[l][2] + (24.0 if (rcs[l][0] > 0 and h.operator_rowclass_flags(l, mg.device.MG_OP_A)[1]) else 32.0) * p.As[l - 1].shape[0] for l in lv}
         cnts = {l: prof[(l, "smooth")][1] for l in lv if (l, "smooth") in prof}
         tot = sum(cnts.values())
         streamed = sum(per_level[l] * cnts[l] for l in cnts) / tot if tot else None
@@ -245,7 +246,10 @@ def main():
                             "constant-coefficient workload): frac > 1 is traffic avoided, NOT bandwidth above peak - "
                             "`streamed_frac` is the bandwidth figure. Operators without that redundancy (e.g. workload "
                             "c3) run the streaming kernels." if fmt_name in ("row classes", "mixed") else "")),
-                "row_classes": {f"L{l}": {"classes": rcs[l][0], "dictionary_entries": rcs[l][1]} for l in lv},
+                "row_classes": {f"L{l}": {"classes": rcs[l][0], "dictionary_entries": rcs[l][1],
+                                          "implicit_first_column": h.operator_rowclass_flags(l, mg.device.MG_OP_A)[0],
+                                          "relaxPrec_from_dictionary": h.operator_rowclass_flags(l, mg.device.MG_OP_A)[1]}
+                                for l in lv if rcs[l][0] > 0},
                 "fine_level_only": {"launches": cnt_s, "avg_launch_ms": round(ms_s / cnt_s, 5),
                                     "algorithmic_bytes_per_launch": bts_s, "achieved": round(achieved, 1),
                                     "frac": round(achieved / HBM_PEAK_GBS, 4),

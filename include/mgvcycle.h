@@ -205,6 +205,11 @@ int mg_operator_format(mg_hierarchy* h, long long level, long long which, long l
  * pattern-coded: 8 B/nnz + descriptors; plain CSR: 12 B/nnz + row pointers).  Lossless; chosen at upload. */
 int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, long long* nclasses,
                            long long* dict_entries, double* matrix_bytes_per_launch);
+/* Two refinements of the row-class form: implicit_first = 1 when the class also fixes (first column - row index), so
+ * no per-row first column is stored (2 B/row instead of 6); class_relax = 1 when the level's relaxPrec is constant per
+ * class and the fused sweep reads it from the dictionary instead of streaming 8 B/row. */
+int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which, long long* implicit_first,
+                               long long* class_relax);
 /* Algorithmic HBM bytes of one full cycle (x0 = 0) with the current nrhs, DESIGN.md section 5. */
 int mg_cycle_bytes(mg_hierarchy* h, double* bytes);
 /* HBM bytes held by the hierarchy. */

@@ -407,11 +407,13 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
 // whose 64 rows share one class are wave-uniform (scalar loads).
 // ------------------------------------------------------------------------------------------------
 struct RowClassDev {
-  const int* firstcol;          // n_rows
+  const int* firstcol;          // n_rows; nullptr: first column = row + cls_delta[class] (square grid operators)
   const unsigned short* cls;    // n_rows
   const int* cls_ptr;           // ncls + 1
   const int* cls_off;           // dictionary: column offset from the row's first column
   const double* cls_val;        // dictionary: value
+  const int* cls_delta;         // ncls: first column minus row index (only when firstcol == nullptr)
+  const double* cls_d;          // ncls: the level's relaxPrec of every row of the class (SMOOTH with v.d == nullptr)
   int nblocks;                  // ceil(n_rows / RC_ROWS)
   int n_rows;
 };
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
   for (int j = 0; j < RC_RPT; ++j) {
     const int row = base + j * BLK;
     const int rr = row < C.n_rows ? row : C.n_rows - 1;   // dead lanes repeat the last row (never stored)
-    first[j] = C.firstcol[rr];
+    first[j] = C.firstcol ? C.firstcol[rr] : rr;            // implicit form: the class delta is added in its pass
     cls[j] = C.cls[rr];
     pb[j] = pd[j] = px[j] = 0.0;
     acc[j] = 0.0;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
     } else {
       pb[j] = v.b[rr];
       if (MODE == SMOOTH) {
-        pd[j] = v.d[rr];
+        if (v.d) pd[j] = v.d[rr];                           // else: class-constant, set in the class's pass
         px[j] = v.xs[rr];
       }
     }
@@ -470,6 +472,10 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
         any = true;
       }
     if (!any) break;
+    const int delta = C.firstcol ? 0 : C.cls_delta[cc];
+    lead += delta;
+    double dcc = 0.0;
+    if (MODE == SMOOTH && !v.d) dcc = C.cls_d[cc];
     bool in[RC_RPT];
     const double* xb[RC_RPT];
     double a[RC_RPT];
@@ -478,7 +484,8 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
       const unsigned long long m = __ballot(cls[j] == cc) & todo[j];
       todo[j] &= ~m;
       in[j] = (m & lanebit) != 0;
-      xb[j] = v.x + (in[j] ? first[j] : lead);
+      xb[j] = v.x + (in[j] ? first[j] + delta : lead);
+      if (MODE == SMOOTH && !v.d && in[j]) pd[j] = dcc;
       a[j] = 0.0;
     }
 #if defined(MG_RC_EXP) && MG_RC_EXP == 1   // timing experiment only (wrong results): one gather per row

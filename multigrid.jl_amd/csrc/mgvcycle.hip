@@ -98,10 +98,13 @@ struct Csr {
   bool has_pat = false;
   long long npat = 0, dict_entries = 0;
   // row classes (csr_rowclass_spmv): first column + class id per row, dictionary of (offset, value) rows
-  DevBuf<int> rc_first, rc_ptr, rc_off;
+  DevBuf<int> rc_first, rc_ptr, rc_off, rc_delta;
   DevBuf<unsigned short> rc_cls;
-  DevBuf<double> rc_val;
+  DevBuf<double> rc_val, rc_d;
   bool has_rc = false;
+  bool rc_implicit = false;   // first column = row + rc_delta[class]: no per-row first-column stream
+  bool rc_has_d = false;      // the level's relaxPrec is constant per class: SMOOTH reads it from rc_d
+  std::vector<unsigned short> h_cls;  // host class ids (to test vectors for class-constancy)
   long long rc_ncls = 0, rc_entries = 0;
   std::vector<int> h_rp, h_ci;  // host pattern, kept only while has_rc (to re-derive the classes for new values)
   std::vector<int> h_blk_row;  // host copy of the row-block boundaries (for building schedules)
@@ -133,7 +136,9 @@ struct Csr {
   int blocks1() const { return has_rc ? rc_blocks() : nblocks; }
   mgk::RowClassDev rcdev() const {
     mgk::RowClassDev c;
-    c.firstcol = rc_first.p;
+    c.firstcol = rc_implicit ? nullptr : rc_first.p;
+    c.cls_delta = rc_delta.p;
+    c.cls_d = rc_d.p;
     c.cls = rc_cls.p;
     c.cls_ptr = rc_ptr.p;
     c.cls_off = rc_off.p;
@@ -148,7 +153,13 @@ struct Csr {
     rc_off.release();
     rc_cls.release();
     rc_val.release();
+    rc_delta.release();
+    rc_d.release();
+    h_cls.clear();
+    h_cls.shrink_to_fit();
     has_rc = false;
+    rc_implicit = false;
+    rc_has_d = false;
     rc_ncls = rc_entries = 0;
   }
   mgk::PatDev patdev() const {
@@ -414,6 +425,8 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
   v.y = out;
   v.b = b;
   v.d = d;
+  // the level's own relaxPrec, constant per row class: read from the dictionary instead of streamed (rc_d)
+  if (h->nrhs == 1 && A.has_rc && A.rc_has_d && d == h->lev[(size_t)level].d.p && &A == &h->lev[(size_t)level].A) v.d = nullptr;
   v.nrhs = (int)h->nrhs;
   ProfScope ps(h, level, MG_K_SMOOTH, spmv_bytes(A, h->nrhs, true, true));
   return launch_csr<mgk::SMOOTH>(h->stream, A, v);
@@ -1247,12 +1260,12 @@ int build_patterns(Csr* M, const std::vector<int>& rp, const std::vector<int>& c
 // Row classes: rows with identical column offsets (relative to the row's first column) AND bit-identical values.
 // Accepted when the operator really is that redundant: at most 65535 classes and a dictionary of at most
 // min(nnz/16, 2^18) entries (3 MiB: L2-resident).  Anything else keeps the streaming formats.  Lossless.
-int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
+int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val, bool implicit) {
   M->drop_rc();
   const long long n = M->n_rows;
   if (n < 1 || M->nnz < 1) return MG_OK;
   const size_t cap = (size_t)std::min<long long>(1LL << 18, std::max<long long>(64, M->nnz / 16));
-  std::vector<int> first((size_t)n, 0), cptr(1, 0), coff;
+  std::vector<int> first((size_t)n, 0), cptr(1, 0), coff, cdelta;
   std::vector<unsigned short> cid((size_t)n, 0);
   std::vector<double> cval;
   std::unordered_map<unsigned long long, std::vector<int>> table;
@@ -1261,6 +1274,11 @@ int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
     const int f = (e > s) ? ci[(size_t)s] : 0;
     first[(size_t)i] = f;
     unsigned long long hsh = 1469598103934665603ull ^ (unsigned long long)(e - s);
+    const int dlt = (int)(f - i);
+    if (implicit) {
+      hsh ^= (unsigned long long)(unsigned int)dlt;
+      hsh *= 1099511628211ull;
+    }
     for (int k = s; k < e; ++k) {
       unsigned long long bits;
       std::memcpy(&bits, &val[(size_t)k], 8);
@@ -1274,6 +1292,7 @@ int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
     for (int id : cand) {
       const int ps = cptr[(size_t)id], len = cptr[(size_t)id + 1] - ps;
       if (len != e - s) continue;
+      if (implicit && cdelta[(size_t)id] != dlt) continue;
       bool same = true;
       for (int k = 0; k < len && same; ++k)
         same = coff[(size_t)ps + k] == ci[(size_t)s + k] - f &&
@@ -1288,6 +1307,7 @@ int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
         cval.push_back(val[(size_t)k]);
       }
       cptr.push_back((int)coff.size());
+      cdelta.push_back(dlt);
       cand.push_back(found);
     }
     cid[(size_t)i] = (unsigned short)found;
@@ -1318,12 +1338,15 @@ int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
     }
     if (passes > max_passes * waves) return MG_OK;
   }
-  MG_TRY(M->rc_first.alloc(first.size()));
+  if (cdelta.empty()) cdelta.push_back(0);
+  if (!implicit) MG_TRY(M->rc_first.alloc(first.size()));
+  MG_TRY(M->rc_delta.alloc(cdelta.size()));
+  HIP_TRY(hipMemcpy(M->rc_delta.p, cdelta.data(), cdelta.size() * sizeof(int), hipMemcpyHostToDevice));
   MG_TRY(M->rc_cls.alloc(cid.size()));
   MG_TRY(M->rc_ptr.alloc(cptr.size()));
   MG_TRY(M->rc_off.alloc(coff.size()));
   MG_TRY(M->rc_val.alloc(cval.size()));
-  HIP_TRY(hipMemcpy(M->rc_first.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!implicit) HIP_TRY(hipMemcpy(M->rc_first.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(M->rc_cls.p, cid.data(), cid.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(M->rc_ptr.p, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(M->rc_off.p, coff.data(), coff.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1331,6 +1354,38 @@ int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
   M->rc_ncls = (long long)cptr.size() - 1;
   M->rc_entries = (long long)coff.size();
   M->has_rc = true;
+  M->rc_implicit = implicit;
+  M->h_cls.swap(cid);
+  return MG_OK;
+}
+// Square operators first try the form without a first-column stream (the class also fixes first column - row).
+int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
+  if (M->n_rows == M->n_cols) {
+    const char* e = std::getenv("MG_NO_IMPLICIT_FIRST");
+    if (!(e && e[0] == '1')) {
+      MG_TRY(build_rowclasses_try(M, rp, ci, val, true));
+      if (M->has_rc) return MG_OK;
+    }
+  }
+  return build_rowclasses_try(M, rp, ci, val, false);
+}
+// relaxPrec constant per class (d = omega/a_ii and a_ii is part of the class): keep it in the dictionary
+int derive_class_d(Level& L) {
+  Csr& A = L.A;
+  A.rc_has_d = false;
+  if (!A.has_rc || A.h_cls.size() != (size_t)A.n_rows || L.d.n != (size_t)A.n_rows) return MG_OK;
+  if (const char* e = std::getenv("MG_NO_CLASS_D")) if (e[0] == '1') return MG_OK;
+  std::vector<double> hd((size_t)A.n_rows), dc((size_t)A.rc_ncls, 0.0);
+  std::vector<char> seen((size_t)A.rc_ncls, 0);
+  HIP_TRY(hipMemcpy(hd.data(), L.d.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < hd.size(); ++i) {
+    const unsigned short c = A.h_cls[i];
+    if (!seen[c]) { seen[c] = 1; dc[c] = hd[i]; }
+    else if (std::memcmp(&dc[c], &hd[i], 8) != 0) return MG_OK;   // not class-constant: keep streaming d
+  }
+  MG_TRY(A.rc_d.alloc(dc.size()));
+  HIP_TRY(hipMemcpy(A.rc_d.p, dc.data(), dc.size() * sizeof(double), hipMemcpyHostToDevice));
+  A.rc_has_d = true;
   return MG_OK;
 }
 bool rowclass_enabled() {
@@ -1526,6 +1581,7 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
     HIP_TRY(hipMemcpy(hv.data(), Ac.val.p, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
     MG_TRY(refresh_rowclasses(&Ac, hv.data()));
   }
+  for (int l = 0; l + 1 < nl; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));   // relaxPrecs were recomputed above
   if (levels_done) *levels_done = nl - 1;
   return MG_OK;
 }
@@ -1619,6 +1675,7 @@ int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long lo
   MG_TRY(L.d.alloc((size_t)n));
   HIP_TRY(hipMemcpy(L.d.p, d, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
   L.relax_set = true;
+  L.A.rc_has_d = false;   // re-derived by mg_finalize
   L.npre = relaxPre;
   L.npost = relaxPost;
   h->finalized = false;
@@ -1787,6 +1844,7 @@ int mg_finalize(mg_hierarchy* h) {
   if (!h->coarse_set) return fail(MG_ERR_STATE, "the coarsest solve was not set");
   if (h->n_coarse != h->lev[nl - 1].n)
     return fail(MG_ERR_INVALID, "coarse inverse order %lld != coarsest level size %lld", h->n_coarse, h->lev[nl - 1].n);
+  for (int l = 0; l < nl - 1; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));
   MG_TRY(alloc_scratch(h));
   if ((size_t)h->lev[0].A.nblocks > h->partial.n)  // the fused residual+norm writes one partial per row block
     MG_TRY(h->partial.alloc((size_t)h->lev[0].A.nblocks));
@@ -1818,7 +1876,9 @@ int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, co
   (void)hipSetDevice(h->device);
   HIP_TRY(spin_sync(h->stream));
   HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-  return refresh_rowclasses(M, nzval);
+  MG_TRY(refresh_rowclasses(M, nzval));
+  if (which == MG_OP_A && h->lev[(size_t)level - 1].relax_set) MG_TRY(derive_class_d(h->lev[(size_t)level - 1]));
+  return MG_OK;
 }
 
 // ---- device-resident hot path ---------------------------------------------------------------------
@@ -2136,7 +2196,7 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
   if (dict_entries) *dict_entries = M->has_rc ? M->rc_entries : 0;
   if (matrix_bytes_per_launch) {
     if (M->has_rc) {
-      *matrix_bytes_per_launch = 6.0 * (double)M->n_rows + 12.0 * (double)M->rc_entries;
+      *matrix_bytes_per_launch = (M->rc_implicit ? 2.0 : 6.0) * (double)M->n_rows + 12.0 * (double)M->rc_entries;
     } else if (M->has_pat) {
       *matrix_bytes_per_launch = 8.0 * (double)M->nnz + 4.0 * (double)M->dict_entries +
           (M->has_runs ? 20.0 * (double)M->nruns_total + 8.0 * (double)M->nblocks : 10.0 * (double)M->n_rows);
@@ -2144,6 +2204,16 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
       *matrix_bytes_per_launch = 12.0 * (double)M->nnz + 4.0 * (double)(M->n_rows + 1);
     }
   }
+  return MG_OK;
+}
+
+int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which, long long* implicit_first,
+                               long long* class_relax) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  Csr* M = pick(h, level, which);
+  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
+  if (implicit_first) *implicit_first = (M->has_rc && M->rc_implicit) ? 1 : 0;
+  if (class_relax) *class_relax = (M->has_rc && M->rc_has_d) ? 1 : 0;
   return MG_OK;
 }
 

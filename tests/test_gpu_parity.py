@@ -437,6 +437,22 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
         mg.clear_(p)
     assert np.abs(hist["0"][1] - hist["1"][1]).max() <= RES_TOL * hist["1"][1][0]
     assert np.abs(hist["0"][0] - hist["1"][0]).max() <= RES_TOL * np.abs(hist["1"][0]).max()
+    # refinements: implicit first column (square operators) and relaxPrec from the class dictionary, each switchable
+    monkeypatch.setenv("MG_NO_ROWCLASS", "0")
+    for relaxType, omega in (("Jac", 0.8), ("SPAI", 1.0)):
+        for no_first, no_d in (("0", "0"), ("1", "0"), ("0", "1")):
+            monkeypatch.setenv("MG_NO_IMPLICIT_FIRST", no_first)
+            monkeypatch.setenv("MG_NO_CLASS_D", no_d)
+            A, p, b = _setup(mg, [20, 18, 16], 3, relaxType=relaxType, omega=omega)
+            _compare_solve(mg, p, b)
+            fa = p.device.operator_rowclass_flags(1, D.MG_OP_A)
+            fp = p.device.operator_rowclass_flags(1, D.MG_OP_P)
+            assert fa[0] == (no_first == "0") and fp == (False, False), (fa, fp)
+            if relaxType == "Jac":
+                assert fa[1] == (no_d == "0"), fa             # omega/a_ii is constant per class by construction
+            mg.clear_(p)
+    monkeypatch.delenv("MG_NO_IMPLICIT_FIRST")
+    monkeypatch.delenv("MG_NO_CLASS_D")
     # a hierarchy on the non-redundant operator keeps the streaming formats
     monkeypatch.setenv("MG_NO_ROWCLASS", "0")
     Ad, mesh = mg.poisson_shifted([12, 12, 12])
