@@ -554,6 +554,287 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-class SpMV with LDS windows (square operators in the implicit-first form).
+// The plain row-class kernel above is bound by L2->L1 line traffic: every dictionary entry is its own gather and
+// the y+-1 / z+-1 neighbours of a grid row arrive as separate, unaligned 512-byte requests (~25 cache lines of x
+// per 64 rows; profiles/r01_nt_ab.md).  Here a workgroup owns RW_ROWS consecutive rows and, for the class of its
+// middle row (the "staged class": a grid interior), loads the UNION of what the member rows gather -
+// entry k of the class reads x[row + delta + off_k], i.e. the window [rmin + delta + off_k, rmax + delta + off_k];
+// overlapping windows (x+-1 and y+-1 neighbours of a few consecutive grid lines) merge - into LDS once, with
+// contiguous coalesced loads (~14 lines of x per 64 rows), and the member rows then read LDS.  Rows of any other
+// class (grid-line ends, boundary planes) take the waterfall path of the kernel above.  Purely a data-movement
+// change: products and their order are unchanged.  Nothing here knows about grids: the staged class is the operator's
+// most frequent one and the kernel is used only when its windows fit (RW_CAP doubles, RW_MAXINT windows, RW_MAXLEN
+// entries; decided by the host at upload).
+// ------------------------------------------------------------------------------------------------
+#ifndef MG_RW_RPT
+#define MG_RW_RPT 2
+#endif
+constexpr int RW_RPT = MG_RW_RPT;
+constexpr int RW_ROWS = BLK * RW_RPT;   // 1024 rows per workgroup
+constexpr int RW_CAP = 6144;            // doubles of x staged per workgroup (48 KiB)
+constexpr int RW_MAXLEN = 32;           // dictionary entries of the staged class
+constexpr int RW_MAXINT = 8;            // disjoint windows
+// Window layout, computed once on the host (build_rowclasses) from the operator's most frequent class for
+// W = RW_ROWS:  meta[0] that class, [1] number of windows, [2] LDS index of shift 0 (the row's own x) or -1,
+// [3] doubles staged, [4] unused, then per window {first shift, length, LDS base}.
+// A dictionary entry of ANY class with shift sh = delta_c + off reads x[row + sh]; when sh is one of the staged
+// shifts its LDS index is cls_lb[entry] (x[row + sh] <-> win[cls_lb + (row - r0)], r0 = first row of the
+// workgroup), else cls_lb = -1 and the entry gathers from global memory.  Boundary classes of a grid operator are
+// subsets of the interior class's shifts, so in practice every gather is served from LDS.
+constexpr int RW_META_HDR = 5;
+
+template <int MODE>
+__global__ __launch_bounds__(BLK) void csr_rowclass_window_spmv(RowClassDev C, VecArgs v, const int* __restrict__ meta,
+                                                                const int* __restrict__ cls_lb, int nblocks_w,
+                                                                int n_cols) {
+  extern __shared__ double win[];
+  __shared__ double red[BLK / 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int bid = xcd_band(blockIdx.x, nblocks_w);
+  const int r0 = bid * RW_ROWS;
+  const int cd = meta[0], nwin = meta[1], lb0 = meta[2];
+  const int* __restrict__ ivs = meta + RW_META_HDR;
+  int row[RW_RPT], cls[RW_RPT], idx[RW_RPT];
+  double pb[RW_RPT], pd[RW_RPT], px[RW_RPT], acc[RW_RPT];
+  bool live[RW_RPT];
+#pragma unroll
+  for (int j = 0; j < RW_RPT; ++j) {
+    row[j] = r0 + j * BLK + tid;
+    live[j] = row[j] < C.n_rows;
+    const int rr = live[j] ? row[j] : C.n_rows - 1;
+    idx[j] = rr - r0;
+    cls[j] = C.cls[rr];
+    pb[j] = pd[j] = px[j] = 0.0;
+    acc[j] = 0.0;
+    if (MODE == AXPBY) {
+      if (v.beta != 0.0) pb[j] = v.beta * v.y[rr];
+    } else {
+      pb[j] = v.b[rr];
+      if (MODE == SMOOTH && v.d) pd[j] = v.d[rr];
+    }
+  }
+  // stage the windows (clamped at the ends of x: no row reads a clamped slot through a staged shift)
+  const int delta_cd = C.cls_delta[cd];
+  for (int m = 0; m < nwin; ++m) {
+    const int g0 = r0 + delta_cd + ivs[3 * m], L = ivs[3 * m + 1], B = ivs[3 * m + 2];
+    for (int i = tid; i < L; i += BLK) win[B + i] = v.x[min(max(g0 + i, 0), n_cols - 1)];
+  }
+  __syncthreads();
+  if (MODE == SMOOTH) {
+    const bool own = (lb0 >= 0) && (v.xs == v.x);
+#pragma unroll
+    for (int j = 0; j < RW_RPT; ++j)
+      if (live[j]) px[j] = own ? win[lb0 + idx[j]] : v.xs[row[j]];
+  }
+  // waterfall over the classes the wave holds, as in csr_rowclass_spmv, with the gathers served from LDS
+  const unsigned long long lanebit = 1ull << lane;
+  unsigned long long todo[RW_RPT];
+#pragma unroll
+  for (int j = 0; j < RW_RPT; ++j) todo[j] = __ballot(live[j]);
+  for (;;) {
+    int cc = 0, lead = 0;
+    bool any = false;
+#pragma unroll
+    for (int j = RW_RPT - 1; j >= 0; --j)
+      if (todo[j]) {
+        const int l = __builtin_ctzll(todo[j]);
+        cc = __builtin_amdgcn_readlane(cls[j], l);
+        lead = __builtin_amdgcn_readlane(row[j], l);
+        any = true;
+      }
+    if (!any) break;
+    const int delta = C.cls_delta[cc];
+    lead += delta;
+    double dcc = 0.0;
+    if (MODE == SMOOTH && !v.d) dcc = C.cls_d[cc];
+    bool in[RW_RPT];
+    double a[RW_RPT];
+#pragma unroll
+    for (int j = 0; j < RW_RPT; ++j) {
+      const unsigned long long m = __ballot(cls[j] == cc) & todo[j];
+      todo[j] &= ~m;
+      in[j] = (m & lanebit) != 0;
+      if (MODE == SMOOTH && !v.d && in[j]) pd[j] = dcc;
+      a[j] = 0.0;
+    }
+    const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
+    for (int k = s; k < e; ++k) {
+      const int lb = cls_lb[k];
+      const double a0 = C.cls_val[k];
+      if (lb >= 0) {   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < RW_RPT; ++j) a[j] += a0 * win[lb + idx[j]];   // rows of another class: a valid slot, unused
+      } else {
+        const int o0 = C.cls_off[k];
+#pragma unroll
+        for (int j = 0; j < RW_RPT; ++j) a[j] += a0 * v.x[(in[j] ? row[j] + delta : lead) + o0];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RW_RPT; ++j)
+      if (in[j]) acc[j] = a[j];
+  }
+  double sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < RW_RPT; ++j) {
+    if (live[j]) {
+      const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], px[j]);
+      v.y[row[j]] = outv;
+      sq += outv * outv;
+    }
+  }
+  if (v.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) t += red[w];
+      v.sumsq[bid] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-class SpMV on plane tiles (square operators in the implicit-first form whose rows the caller declared to be an
+// n1 x n2 x n3 grid, mg_set_grid_hint; P = n1*n2 rows per plane).
+// Measured (profiles/r01_nt_ab.md): the row-class sweeps run at ~5.5 TB/s of L1 FILLS, HBM and L2 hits alike - each
+// CU keeps a bounded number of cache-line fills in flight - so what is left to win is the fill volume.  In row order a
+// row's z+-1 neighbours are P rows away: every x line is filled three times per sweep (once as the row's own
+// plane, twice as a neighbour plane).  Here a 1024-thread workgroup owns the SAME RT_CR-row chunk of RT_NP consecutive
+// planes (slot j of a lane = plane j) and stages RT_NP + 2 slabs of x (chunk +- HALO rows, planes -1 .. RT_NP) in LDS:
+// 6 slabs serve 4 planes, i.e. ~2.3 fills of x per row instead of 4.  Every dictionary entry of every class whose
+// shift (delta + offset) is dz*P + rest with |dz| <= 1, |rest| <= HALO reads LDS (index precomputed by the host in
+// tile_lb), anything else gathers from global memory, so correctness never depends on the hint being "true": it is
+// a row partition plus a cache.  Products and summation order are unchanged.
+// ------------------------------------------------------------------------------------------------
+constexpr int RT_NP = 4;        // planes per workgroup = rows per lane
+constexpr int RT_CR = 1024;     // rows of a plane per workgroup = threads per workgroup
+
+struct TileDev {
+  const int* tile_lb;   // per dictionary entry: LDS index of (slot 0, lane 0) or -1
+  int P;                // rows per plane
+  int nplanes;          // n_rows == nplanes * P
+  int halo;             // slab = RT_CR + 2*halo entries of x
+  int chunks;           // ceil(P / RT_CR)
+  int nblocks;          // ceil(nplanes / RT_NP) * chunks
+  int n_cols;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C, VecArgs v, TileDev T) {
+  extern __shared__ double win[];
+  __shared__ double red[RT_CR / 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int bid = xcd_band(blockIdx.x, T.nblocks);
+  const int g = bid / T.chunks, c = bid - g * T.chunks;
+  const int SL = RT_CR + 2 * T.halo;
+  const int pl0 = g * RT_NP;                           // first plane of the tile
+  const int inplane = c * RT_CR + tid;                 // position of the lane's rows inside their planes
+  int row[RT_NP], cls[RT_NP];
+  double pb[RT_NP], pd[RT_NP], px[RT_NP], acc[RT_NP];
+  bool live[RT_NP];
+#pragma unroll
+  for (int j = 0; j < RT_NP; ++j) {
+    live[j] = (pl0 + j < T.nplanes) && (inplane < T.P);
+    row[j] = (pl0 + j) * T.P + inplane;
+    const int rr = live[j] ? row[j] : C.n_rows - 1;
+    cls[j] = C.cls[rr];
+    pb[j] = pd[j] = px[j] = 0.0;
+    acc[j] = 0.0;
+    if (MODE == AXPBY) {
+      if (v.beta != 0.0) pb[j] = v.beta * v.y[rr];
+    } else {
+      pb[j] = v.b[rr];
+      if (MODE == SMOOTH && v.d) pd[j] = v.d[rr];
+    }
+  }
+  // stage slabs q = 0 .. RT_NP+1 <-> planes pl0-1 .. pl0+RT_NP, rows [c*RT_CR - halo, c*RT_CR + RT_CR + halo)
+  for (int q = 0; q < RT_NP + 2; ++q) {
+    const long long g0 = (long long)(pl0 + q - 1) * T.P + c * RT_CR - T.halo;
+    for (int i = tid; i < SL; i += RT_CR) {
+      long long gi = g0 + i;
+      gi = gi < 0 ? 0 : (gi > T.n_cols - 1 ? T.n_cols - 1 : gi);
+      win[q * SL + i] = v.x[gi];
+    }
+  }
+  __syncthreads();
+  if (MODE == SMOOTH) {
+    const bool own = (v.xs == v.x);
+#pragma unroll
+    for (int j = 0; j < RT_NP; ++j)
+      if (live[j]) px[j] = own ? win[(j + 1) * SL + T.halo + tid] : v.xs[row[j]];
+  }
+  const unsigned long long lanebit = 1ull << lane;
+  unsigned long long todo[RT_NP];
+#pragma unroll
+  for (int j = 0; j < RT_NP; ++j) todo[j] = __ballot(live[j]);
+  for (;;) {
+    int cc = 0, lead = 0;
+    bool any = false;
+#pragma unroll
+    for (int j = RT_NP - 1; j >= 0; --j)
+      if (todo[j]) {
+        const int l = __builtin_ctzll(todo[j]);
+        cc = __builtin_amdgcn_readlane(cls[j], l);
+        lead = __builtin_amdgcn_readlane(row[j], l);
+        any = true;
+      }
+    if (!any) break;
+    const int delta = C.cls_delta[cc];
+    lead += delta;
+    double dcc = 0.0;
+    if (MODE == SMOOTH && !v.d) dcc = C.cls_d[cc];
+    bool in[RT_NP];
+    double a[RT_NP];
+#pragma unroll
+    for (int j = 0; j < RT_NP; ++j) {
+      const unsigned long long m = __ballot(cls[j] == cc) & todo[j];
+      todo[j] &= ~m;
+      in[j] = (m & lanebit) != 0;
+      if (MODE == SMOOTH && !v.d && in[j]) pd[j] = dcc;
+      a[j] = 0.0;
+    }
+    const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
+    for (int k = s; k < e; ++k) {
+      const int lb = T.tile_lb[k];
+      const double a0 = C.cls_val[k];
+      if (lb >= 0) {   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < RT_NP; ++j) a[j] += a0 * win[lb + j * SL + tid];   // other classes: a valid slot, unused
+      } else {
+        const int o0 = C.cls_off[k];
+#pragma unroll
+        for (int j = 0; j < RT_NP; ++j) a[j] += a0 * v.x[(in[j] ? row[j] + delta : lead) + o0];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RT_NP; ++j)
+      if (in[j]) acc[j] = a[j];
+  }
+  double sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < RT_NP; ++j) {
+    if (live[j]) {
+      const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], px[j]);
+      v.y[row[j]] = outv;
+      sq += outv * outv;
+    }
+  }
+  if (v.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < RT_CR / 64; ++w) t += red[w];
+      v.sumsq[bid] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // CSR-stream SpMM, nrhs > 1, vectors row-major [n][nrhs].
 // The nnz segment (values AND column indices) is staged in LDS with coalesced loads; then G lanes
 // (G = pow2 >= nrhs, <= 64) own one row x one RHS column each and walk the row from LDS (broadcast

@@ -98,12 +98,18 @@ struct Csr {
   bool has_pat = false;
   long long npat = 0, dict_entries = 0;
   // row classes (csr_rowclass_spmv): first column + class id per row, dictionary of (offset, value) rows
-  DevBuf<int> rc_first, rc_ptr, rc_off, rc_delta;
+  DevBuf<int> rc_first, rc_ptr, rc_off, rc_delta, rw_meta, rw_lb, rt_lb;
+  std::vector<int> h_rc_ptr, h_rc_off, h_rc_delta;   // host copy of the dictionary (tile index tables)
+  int rc_major = 0;         // most frequent class
+  bool rc_tile = false;     // csr_rowclass_tile_spmv (plane tiles from the grid hint)
+  int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
+  int rw_doubles = 0;   // x entries a workgroup of csr_rowclass_window_spmv stages in LDS
   DevBuf<unsigned short> rc_cls;
   DevBuf<double> rc_val, rc_d;
   bool has_rc = false;
   bool rc_implicit = false;   // first column = row + rc_delta[class]: no per-row first-column stream
   bool rc_has_d = false;      // the level's relaxPrec is constant per class: SMOOTH reads it from rc_d
+  bool rc_window = false;     // csr_rowclass_window_spmv: the most frequent class's windows fit in LDS
   std::vector<unsigned short> h_cls;  // host class ids (to test vectors for class-constancy)
   long long rc_ncls = 0, rc_entries = 0;
   std::vector<int> h_rp, h_ci;  // host pattern, kept only while has_rc (to re-derive the classes for new values)
@@ -133,7 +139,19 @@ struct Csr {
   }
   int rc_blocks() const { return (int)((n_rows + mgk::RC_ROWS - 1) / mgk::RC_ROWS); }
   // workgroups of the nrhs == 1 product (one fused ||r||^2 partial each)
-  int blocks1() const { return has_rc ? rc_blocks() : nblocks; }
+  int rw_blocks() const { return (int)((n_rows + mgk::RW_ROWS - 1) / mgk::RW_ROWS); }
+  int blocks1() const { return has_rc ? (rc_tile ? rt_nblocks : rc_window ? rw_blocks() : rc_blocks()) : nblocks; }
+  mgk::TileDev tiledev() const {
+    mgk::TileDev t;
+    t.tile_lb = rt_lb.p;
+    t.P = rt_P;
+    t.nplanes = rt_nplanes;
+    t.halo = rt_halo;
+    t.chunks = rt_chunks;
+    t.nblocks = rt_nblocks;
+    t.n_cols = (int)n_cols;
+    return t;
+  }
   mgk::RowClassDev rcdev() const {
     mgk::RowClassDev c;
     c.firstcol = rc_implicit ? nullptr : rc_first.p;
@@ -154,12 +172,20 @@ struct Csr {
     rc_cls.release();
     rc_val.release();
     rc_delta.release();
+    rw_meta.release();
+    rw_lb.release();
+    rt_lb.release();
+    rc_tile = false;
+    h_rc_ptr.clear();
+    h_rc_off.clear();
+    h_rc_delta.clear();
     rc_d.release();
     h_cls.clear();
     h_cls.shrink_to_fit();
     has_rc = false;
     rc_implicit = false;
     rc_has_d = false;
+    rc_window = false;
     rc_ncls = rc_entries = 0;
   }
   mgk::PatDev patdev() const {
@@ -345,7 +371,13 @@ template <int MODE>
 int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
-  if (v.nrhs == 1 && M.has_rc) {
+  if (v.nrhs == 1 && M.has_rc && M.rc_tile && v.y != v.x) {
+    const size_t lds = (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * M.rt_halo) * sizeof(double);
+    hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE>), dim3(M.rt_nblocks), dim3(mgk::RT_CR), lds, stream, M.rcdev(), v, M.tiledev());
+  } else if (v.nrhs == 1 && M.has_rc && M.rc_window && v.y != v.x) {   // (staging reads x block-wide: never in place)
+    hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE>), dim3(M.rw_blocks()), blk, (size_t)M.rw_doubles * sizeof(double),
+                       stream, M.rcdev(), v, M.rw_meta.p, M.rw_lb.p, M.rw_blocks(), (int)M.n_cols);
+  } else if (v.nrhs == 1 && M.has_rc) {
     hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE>), dim3(M.rc_blocks()), blk, 0, stream, M.rcdev(), v);
   } else if (v.nrhs == 1 && M.has_pat) {
     const bool dl = M.dict_entries <= mgk::DICT_LDS && M.npat < mgk::DICT_LDS;
@@ -1072,6 +1104,52 @@ int download_block(mg_hierarchy* h, const double* dev, double* host, long long n
 // ~2T lines.  Pure scheduling: every block computes exactly what it computed before.
 int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const std::vector<int>& h_blk, int nb,
                        DevBuf<int>& sched, bool& has);
+// Plane tiles for csr_rowclass_tile_spmv: needs the row-class form without a first-column stream and a grid hint
+// whose plane size divides the row count; the halo is what the most frequent class reaches inside a plane.
+int build_tile(Csr& A, const long long grid[3]) {
+  A.rc_tile = false;
+  if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty()) return MG_OK;
+  if (const char* e = std::getenv("MG_NO_TILE")) if (e[0] == '1') return MG_OK;
+  if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != A.n_rows) return MG_OK;
+  const long long P = grid[0] * grid[1];
+  if (P < mgk::RT_CR / 2 || P >= (1LL << 30)) return MG_OK;
+  auto split = [&](long long sh, long long& dz, long long& rest) {
+    dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
+    rest = sh - dz * P;
+  };
+  const int cm = A.rc_major;
+  {
+    long long min_len = 12;   // as for the window kernel: the 7-point level is faster without staging
+    if (const char* ml = std::getenv("MG_STAGE_MIN_LEN")) min_len = std::atoll(ml);
+    if (A.h_rc_ptr[(size_t)cm + 1] - A.h_rc_ptr[(size_t)cm] < min_len) return MG_OK;
+  }
+  long long halo = 1;
+  for (int k = A.h_rc_ptr[(size_t)cm]; k < A.h_rc_ptr[(size_t)cm + 1]; ++k) {
+    long long dz, rest;
+    split((long long)A.h_rc_delta[(size_t)cm] + A.h_rc_off[(size_t)k], dz, rest);
+    if (dz < -1 || dz > 1) return MG_OK;
+    halo = std::max(halo, rest < 0 ? -rest : rest);
+  }
+  const long long SL = mgk::RT_CR + 2 * halo;
+  if ((mgk::RT_NP + 2) * SL * 8 > 80 * 1024) return MG_OK;   // two workgroups per CU
+  std::vector<int> lbs(A.h_rc_off.size(), -1);
+  for (size_t c = 0; c + 1 < A.h_rc_ptr.size(); ++c)
+    for (int k = A.h_rc_ptr[c]; k < A.h_rc_ptr[c + 1]; ++k) {
+      long long dz, rest;
+      split((long long)A.h_rc_delta[c] + A.h_rc_off[(size_t)k], dz, rest);
+      if (dz >= -1 && dz <= 1 && rest >= -halo && rest <= halo) lbs[(size_t)k] = (int)((dz + 1) * SL + rest + halo);
+    }
+  MG_TRY(A.rt_lb.alloc(lbs.size()));
+  HIP_TRY(hipMemcpy(A.rt_lb.p, lbs.data(), lbs.size() * sizeof(int), hipMemcpyHostToDevice));
+  A.rt_P = (int)P;
+  A.rt_nplanes = (int)grid[2];
+  A.rt_halo = (int)halo;
+  A.rt_chunks = (int)((P + mgk::RT_CR - 1) / mgk::RT_CR);
+  A.rt_nblocks = (int)(((grid[2] + mgk::RT_NP - 1) / mgk::RT_NP) * A.rt_chunks);
+  A.rc_tile = true;
+  return MG_OK;
+}
+
 int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
   MG_TRY(build_schedule_for(M, grid, nrhs, M.h_blk_row, M.nblocks, M.sched, M.has_sched));
   return build_schedule_for(M, grid, nrhs, M.h_blk_row_mm, M.nblocks_mm, M.sched_mm, M.has_sched_mm);
@@ -1113,6 +1191,7 @@ int alloc_scratch(mg_hierarchy* h) {
     for (int l = 0; l < (int)h->nlevels; ++l) {
       Level& L = h->lev[(size_t)l];
       MG_TRY(build_schedule(L.A, L.grid, k));
+      MG_TRY(build_tile(L.A, L.grid));
       MG_TRY(build_schedule(L.P, L.grid, k));
       if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
     }
@@ -1355,6 +1434,67 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   M->rc_entries = (long long)coff.size();
   M->has_rc = true;
   M->rc_implicit = implicit;
+  M->h_rc_ptr = cptr;
+  M->h_rc_off = coff;
+  M->h_rc_delta = cdelta;
+  if (implicit) {   // LDS-window kernel: do the windows of the most frequent class fit for a full workgroup of rows?
+    const char* e = std::getenv("MG_NO_WINDOW");
+    std::vector<long long> cnt(cptr.size() - 1, 0);
+    for (long long i = 0; i < n; ++i) cnt[cid[(size_t)i]]++;
+    const size_t cm = (size_t)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
+    M->rc_major = (int)cm;
+    const int ps = cptr[cm], len = cptr[cm + 1] - ps;
+    // measured on C2 (profiles/r01_nt_ab.md): staging pays on the 27-point levels (-15 %), not on the 7-point one
+    long long min_len = 12;
+    if (const char* ml = std::getenv("MG_STAGE_MIN_LEN")) min_len = std::atoll(ml);
+    bool ok = !(e && e[0] == '1') && len >= min_len && len <= mgk::RW_MAXLEN && 2 * cnt[cm] >= n;
+    if (ok) {
+      const long long W = mgk::RW_ROWS;
+      std::vector<int> meta(mgk::RW_META_HDR, 0), ivs;
+      std::unordered_map<long long, int> lb_of_shift;   // staged shift (delta + off) -> LDS index
+      const long long dcm = cdelta[cm];
+      long long base = 0, o_start = coff[(size_t)ps], o_end = o_start;
+      for (int k = 0; k < len; ++k) {
+        const long long off = coff[(size_t)ps + k];
+        if (k > 0 && off > o_end + W) {   // a new window (offsets ascend: CSR rows are sorted)
+          ivs.push_back((int)o_start);
+          ivs.push_back((int)(o_end - o_start + W));
+          ivs.push_back((int)base);
+          base += o_end - o_start + W;
+          o_start = off;
+        }
+        o_end = off;
+        lb_of_shift[dcm + off] = (int)(base + (off - o_start));
+      }
+      ivs.push_back((int)o_start);
+      ivs.push_back((int)(o_end - o_start + W));
+      ivs.push_back((int)base);
+      base += o_end - o_start + W;
+      const int nint = (int)(ivs.size() / 3);
+      ok = base <= mgk::RW_CAP && nint <= mgk::RW_MAXINT;
+      if (ok) {
+        meta[0] = (int)cm;
+        meta[1] = nint;
+        auto it0 = lb_of_shift.find(0);
+        meta[2] = it0 == lb_of_shift.end() ? -1 : it0->second;
+        meta[3] = (int)base;
+        meta.insert(meta.end(), ivs.begin(), ivs.end());
+        // every dictionary entry of every class: the LDS index of its shift, or -1 (gathers from global memory)
+        std::vector<int> lbs(coff.size(), -1);
+        for (size_t c = 0; c + 1 < cptr.size(); ++c)
+          for (int k = cptr[c]; k < cptr[c + 1]; ++k) {
+            auto it = lb_of_shift.find((long long)cdelta[c] + coff[(size_t)k]);
+            if (it != lb_of_shift.end()) lbs[(size_t)k] = it->second;
+          }
+        MG_TRY(M->rw_meta.alloc(meta.size()));
+        HIP_TRY(hipMemcpy(M->rw_meta.p, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+        MG_TRY(M->rw_lb.alloc(lbs.size()));
+        HIP_TRY(hipMemcpy(M->rw_lb.p, lbs.data(), lbs.size() * sizeof(int), hipMemcpyHostToDevice));
+        M->rw_doubles = (int)base;
+      }
+    }
+    M->rc_window = ok;
+  }
   M->h_cls.swap(cid);
   return MG_OK;
 }

@@ -384,6 +384,7 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
     # by default only operators of >= 100 000 rows with <= 4 classes per wavefront are stored this way
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_STAGE_MIN_LEN", "0")          # LDS-staged variants also on the 7-point level
     rng = np.random.default_rng(17)
     A, _ = mg.poisson_shifted([14, 12, 10])
     Arand = A.copy()
@@ -440,10 +441,14 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
     # refinements: implicit first column (square operators) and relaxPrec from the class dictionary, each switchable
     monkeypatch.setenv("MG_NO_ROWCLASS", "0")
     for relaxType, omega in (("Jac", 0.8), ("SPAI", 1.0)):
-        for no_first, no_d in (("0", "0"), ("1", "0"), ("0", "1")):
+        for no_first, no_d, no_win, no_tile in (("0", "0", "0", "0"), ("1", "0", "0", "0"), ("0", "1", "0", "0"),
+                                                ("0", "0", "1", "1"), ("0", "1", "1", "1"), ("0", "0", "0", "1"),
+                                                ("0", "1", "0", "1")):
             monkeypatch.setenv("MG_NO_IMPLICIT_FIRST", no_first)
             monkeypatch.setenv("MG_NO_CLASS_D", no_d)
-            A, p, b = _setup(mg, [20, 18, 16], 3, relaxType=relaxType, omega=omega)
+            monkeypatch.setenv("MG_NO_WINDOW", no_win)        # csr_rowclass_window_spmv (LDS windows) on / off
+            monkeypatch.setenv("MG_NO_TILE", no_tile)         # csr_rowclass_tile_spmv (plane tiles from the grid hint)
+            A, p, b = _setup(mg, [32, 24, 8], 3, relaxType=relaxType, omega=omega)   # 33x25 = 825 rows per plane
             _compare_solve(mg, p, b)
             fa = p.device.operator_rowclass_flags(1, D.MG_OP_A)
             fp = p.device.operator_rowclass_flags(1, D.MG_OP_P)
@@ -453,6 +458,8 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
             mg.clear_(p)
     monkeypatch.delenv("MG_NO_IMPLICIT_FIRST")
     monkeypatch.delenv("MG_NO_CLASS_D")
+    monkeypatch.delenv("MG_NO_WINDOW")
+    monkeypatch.delenv("MG_NO_TILE")
     # a hierarchy on the non-redundant operator keeps the streaming formats
     monkeypatch.setenv("MG_NO_ROWCLASS", "0")
     Ad, mesh = mg.poisson_shifted([12, 12, 12])
@@ -468,6 +475,7 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
     # default thresholds: a 64x64x48-cell grid qualifies on the fine level only (small levels stay streaming)
     monkeypatch.delenv("MG_ROWCLASS_MIN_ROWS")
     monkeypatch.delenv("MG_ROWCLASS_MAX_PASSES")
+    monkeypatch.delenv("MG_STAGE_MIN_LEN")
     A, p, b = _setup(mg, [64, 64, 48], 4, maxIter=4)
     _compare_solve(mg, p, b)
     assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] > 0
