@@ -198,7 +198,10 @@ def main():
         if nrhs > 1:
             sym[l], fmt_of[l] = f"mgk::csr_stream_spmm<2, {ntl}>", "plain CSR (block right-hand sides)"
         elif rcs[l][0] > 0:
-            sym[l], fmt_of[l] = "mgk::csr_rowclass_spmv<2>", "row classes"
+            var = h.operator_kernel_variant(l, mg.device.MG_OP_A)
+            sym[l] = {0: "mgk::csr_rowclass_spmv<2>", 1: "mgk::csr_rowclass_window_spmv<2>",
+                      2: "mgk::csr_rowclass_tile_spmv<2>"}[var]
+            fmt_of[l] = "row classes"
         elif fmts[l][0] > 0:
             dl = "true" if (fmts[l][1] <= 1024 and fmts[l][0] < 1024) else "false"
             sym[l], fmt_of[l] = f"mgk::csr_pattern_spmv<2, {ntl}, {dl}>", "pattern-coded"

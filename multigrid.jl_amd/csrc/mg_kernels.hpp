@@ -733,7 +733,7 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
   const int pl0 = g * RT_NP;                           // first plane of the tile
   const int inplane = c * RT_CR + tid;                 // position of the lane's rows inside their planes
   int row[RT_NP], cls[RT_NP];
-  double pb[RT_NP], pd[RT_NP], px[RT_NP], acc[RT_NP];
+  double pb[RT_NP], pd[RT_NP], acc[RT_NP];   // (the row's own x is read from LDS in the epilogue: registers are tight)
   bool live[RT_NP];
 #pragma unroll
   for (int j = 0; j < RT_NP; ++j) {
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
     row[j] = (pl0 + j) * T.P + inplane;
     const int rr = live[j] ? row[j] : C.n_rows - 1;
     cls[j] = C.cls[rr];
-    pb[j] = pd[j] = px[j] = 0.0;
+    pb[j] = pd[j] = 0.0;
     acc[j] = 0.0;
     if (MODE == AXPBY) {
       if (v.beta != 0.0) pb[j] = v.beta * v.y[rr];
@@ -760,12 +760,6 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
     }
   }
   __syncthreads();
-  if (MODE == SMOOTH) {
-    const bool own = (v.xs == v.x);
-#pragma unroll
-    for (int j = 0; j < RT_NP; ++j)
-      if (live[j]) px[j] = own ? win[(j + 1) * SL + T.halo + tid] : v.xs[row[j]];
-  }
   const unsigned long long lanebit = 1ull << lane;
   unsigned long long todo[RT_NP];
 #pragma unroll
@@ -817,7 +811,9 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
 #pragma unroll
   for (int j = 0; j < RT_NP; ++j) {
     if (live[j]) {
-      const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], px[j]);
+      double pxj = 0.0;
+      if (MODE == SMOOTH) pxj = (v.xs == v.x) ? win[(j + 1) * SL + T.halo + tid] : v.xs[row[j]];
+      const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], pxj);
       v.y[row[j]] = outv;
       sq += outv * outv;
     }

@@ -1119,7 +1119,7 @@ int build_tile(Csr& A, const long long grid[3]) {
   };
   const int cm = A.rc_major;
   {
-    long long min_len = 12;   // as for the window kernel: the 7-point level is faster without staging
+    long long min_len = 1;    // as for the window kernel
     if (const char* ml = std::getenv("MG_STAGE_MIN_LEN")) min_len = std::atoll(ml);
     if (A.h_rc_ptr[(size_t)cm + 1] - A.h_rc_ptr[(size_t)cm] < min_len) return MG_OK;
   }
@@ -1444,8 +1444,9 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     const size_t cm = (size_t)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
     M->rc_major = (int)cm;
     const int ps = cptr[cm], len = cptr[cm + 1] - ps;
-    // measured on C2 (profiles/r01_nt_ab.md): staging pays on the 27-point levels (-15 %), not on the 7-point one
-    long long min_len = 12;
+    // MG_STAGE_MIN_LEN: shortest class worth staging (A/B switch; measured on C2, profiles/r01_nt_ab.md:
+    // -25 % on the 27-point levels, -5 % on the 7-point one with the spill-free tile kernel)
+    long long min_len = 1;
     if (const char* ml = std::getenv("MG_STAGE_MIN_LEN")) min_len = std::atoll(ml);
     bool ok = !(e && e[0] == '1') && len >= min_len && len <= mgk::RW_MAXLEN && 2 * cnt[cm] >= n;
     if (ok) {
@@ -2348,12 +2349,13 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
 }
 
 int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which, long long* implicit_first,
-                               long long* class_relax) {
+                               long long* class_relax, long long* kernel_variant) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   Csr* M = pick(h, level, which);
   if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
   if (implicit_first) *implicit_first = (M->has_rc && M->rc_implicit) ? 1 : 0;
   if (class_relax) *class_relax = (M->has_rc && M->rc_has_d) ? 1 : 0;
+  if (kernel_variant) *kernel_variant = !M->has_rc ? -1 : M->rc_tile ? 2 : M->rc_window ? 1 : 0;
   return MG_OK;
 }
 
