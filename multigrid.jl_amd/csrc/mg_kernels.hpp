@@ -953,6 +953,23 @@ __global__ __launch_bounds__(BLK) void xpdr_kernel(const double* __restrict__ x,
   }
 }
 
+// xout = x + d.*r with the class-constant relaxPrec of a row-class operator: 2 B/row of class ids instead of 8 B/row
+__global__ __launch_bounds__(BLK) void xpdr_cls_kernel(const double* __restrict__ x,
+                                                       const unsigned short* __restrict__ cls,
+                                                       const double* __restrict__ dcls,
+                                                       const double* __restrict__ r,
+                                                       double* __restrict__ xout, long long n) {
+  const long long stride = (long long)gridDim.x * BLK;
+  const long long n2 = n >> 1;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n2; i += stride) {
+    const double2 xx = reinterpret_cast<const double2*>(x)[i];
+    const ushort2 cc = reinterpret_cast<const ushort2*>(cls)[i];
+    const double2 rr = reinterpret_cast<const double2*>(r)[i];
+    reinterpret_cast<double2*>(xout)[i] = make_double2(xx.x + dcls[cc.x] * rr.x, xx.y + dcls[cc.y] * rr.y);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) xout[n - 1] = x[n - 1] + dcls[cls[n - 1]] * r[n - 1];
+}
+
 __global__ __launch_bounds__(BLK) void fill_kernel(double* __restrict__ x, long long n, double val) {
   const long long stride = (long long)gridDim.x * BLK;
   for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) x[i] = val;

@@ -474,6 +474,14 @@ int k_dscale(mg_hierarchy* h, int level, const double* d, const double* b, doubl
 int k_xpdr(mg_hierarchy* h, int level, const double* x, const double* d, const double* r, double* xout,
            long long n) {
   ProfScope ps(h, level, MG_K_DSCALE, 8.0 * (double)n * (1.0 + 3.0 * (double)h->nrhs));
+  const Csr& A = h->lev[(size_t)level].A;
+  if (h->nrhs == 1 && A.has_rc && A.rc_has_d && d == h->lev[(size_t)level].d.p && n == A.n_rows) {
+    // the level's relaxPrec is constant per row class: stream the 2-byte class ids instead of d
+    hipLaunchKernelGGL(mgk::xpdr_cls_kernel, dim3(grid_for(n / 2 + 1)), dim3(mgk::BLK), 0, h->stream, x, A.rc_cls.p,
+                       A.rc_d.p, r, xout, n);
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+  }
   hipLaunchKernelGGL(mgk::xpdr_kernel, dim3(grid_for(n * h->nrhs / 2 + 1)), dim3(mgk::BLK), 0,
                      h->stream, x, d, r, xout, n, (int)h->nrhs);
   HIP_TRY(hipGetLastError());
@@ -1112,7 +1120,7 @@ int build_tile(Csr& A, const long long grid[3]) {
   if (const char* e = std::getenv("MG_NO_TILE")) if (e[0] == '1') return MG_OK;
   if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != A.n_rows) return MG_OK;
   const long long P = grid[0] * grid[1];
-  if (P < mgk::RT_CR / 2 || P >= (1LL << 30)) return MG_OK;
+  if (P < mgk::RT_CR / 2 || A.n_rows + (mgk::RT_NP + 2) * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
   auto split = [&](long long sh, long long& dz, long long& rest) {
     dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
     rest = sh - dz * P;
