@@ -43,6 +43,8 @@ def parse():
                     help="N>1: weak = 256^3 cells PER GPU (N=8 is BASELINE configs[3], 512^3), sharded host setup; "
                          "strong = the same 256^3 grid cut into N boxes (every rank builds the global hierarchy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded-path", action="store_true",
+                    help="diagnostic: run the N>1 (Python-sequenced, sharded) weak-scaling path with world size 1")
     ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed kernel launches before warm-up")
     ap.add_argument("--cpu-cycles", type=int, default=0, help="cycles of the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -72,6 +74,14 @@ def main():
     share = os.environ.get("MG_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    if world == 1 and args.force_sharded_path:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -91,7 +101,7 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MG_HOST_THREADS", str(max(1, (os.cpu_count() or 8) // world)))
-    if world > 1 and args.scaling == "weak":
+    if (world > 1 or args.force_sharded_path) and args.scaling == "weak":
         if args.workload != "c2":
             raise SystemExit("multi-GPU weak scaling is defined for the c2/c4 Poisson workload")
         return bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank)

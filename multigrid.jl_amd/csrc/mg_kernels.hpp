@@ -77,7 +77,8 @@ struct VecArgs {
   const double* xs; // SMOOTH: the row's own x   [n_rows][nrhs] (== x unless the operator holds a row sub-range)
   double* y;        // output                    [n_rows][nrhs]
   const double* b;  // RESID / SMOOTH            [n_rows][nrhs]
-  const double* d;  // SMOOTH: relaxPrec          [n_rows]
+  const double* d;  // SMOOTH: relaxPrec          [n_rows]; nullptr in the row-class kernels = read it from the class dictionary
+  const double* d_full;  // SMOOTH: always the relaxPrec vector (exception rows of a row-class operator)
   double alpha;     // AXPBY
   double beta;      // AXPBY
   int nrhs;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
   const unsigned long long lanebit = 1ull << (tid & 63);
   unsigned long long todo[RC_RPT];
 #pragma unroll
-  for (int j = 0; j < RC_RPT; ++j) todo[j] = __ballot(1);
+  for (int j = 0; j < RC_RPT; ++j) todo[j] = __ballot(cls[j] != 0xFFFF);   // 0xFFFF: exception row (csr_rows_spmv)
   for (;;) {
     int cc = 0, lead = 0;
     bool any = false;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
 #pragma unroll
   for (int j = 0; j < RC_RPT; ++j) {
     const int row = base + j * BLK;
-    if (row < C.n_rows) {
+    if (row < C.n_rows && cls[j] != 0xFFFF) {
       const double outv = epilogue<MODE>(v, row, acc[j], pb[j], pd[j], px[j]);
       v.y[row] = outv;
       sq += outv * outv;
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_window_spmv(RowClassDev C, V
     const int rr = live[j] ? row[j] : C.n_rows - 1;
     idx[j] = rr - r0;
     cls[j] = C.cls[rr];
+    live[j] = live[j] && cls[j] != 0xFFFF;   // exception rows are computed by csr_rows_spmv
     pb[j] = pd[j] = px[j] = 0.0;
     acc[j] = 0.0;
     if (MODE == AXPBY) {
@@ -741,6 +743,7 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
     row[j] = (pl0 + j) * T.P + inplane;
     const int rr = live[j] ? row[j] : C.n_rows - 1;
     cls[j] = C.cls[rr];
+    live[j] = live[j] && cls[j] != 0xFFFF;   // exception rows are computed by csr_rows_spmv
     pb[j] = pd[j] = 0.0;
     acc[j] = 0.0;
     if (MODE == AXPBY) {
@@ -826,6 +829,47 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
       double t = 0.0;
       for (int w = 0; w < RT_CR / 64; ++w) t += red[w];
       v.sumsq[bid] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exception rows of a row-class operator (rows whose class was too rare for the dictionary: a few per cent next to
+// sub-domain faces or irregular boundaries): one lane per listed row, straight from the CSR arrays, same epilogues.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLK) void csr_rows_spmv(CsrDev A, const int* __restrict__ rows, int nrows, VecArgs v,
+                                                     int sumsq_off) {
+  __shared__ double red[BLK / 64];
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * BLK + tid;
+  double outv = 0.0;
+  if (i < nrows) {
+    const int row = rows[i];
+    double pb = 0.0, pd = 0.0, px = 0.0;
+    if (MODE == AXPBY) {
+      if (v.beta != 0.0) pb = v.beta * v.y[row];
+    } else {
+      pb = v.b[row];
+      if (MODE == SMOOTH) {
+        pd = v.d[row];
+        px = v.xs[row];
+      }
+    }
+    double acc = 0.0;
+    for (int k = A.rowptr[row]; k < A.rowptr[row + 1]; ++k) acc += A.val[k] * v.x[A.colidx[k]];
+    outv = epilogue<MODE>(v, row, acc, pb, pd, px);
+    v.y[row] = outv;
+  }
+  if (v.sumsq) {
+    double sq = outv * outv;
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) t += red[w];
+      v.sumsq[sumsq_off + blockIdx.x] = t;
     }
   }
 }
@@ -957,6 +1001,7 @@ __global__ __launch_bounds__(BLK) void xpdr_kernel(const double* __restrict__ x,
 __global__ __launch_bounds__(BLK) void xpdr_cls_kernel(const double* __restrict__ x,
                                                        const unsigned short* __restrict__ cls,
                                                        const double* __restrict__ dcls,
+                                                       const double* __restrict__ d,
                                                        const double* __restrict__ r,
                                                        double* __restrict__ xout, long long n) {
   const long long stride = (long long)gridDim.x * BLK;
@@ -965,9 +1010,14 @@ __global__ __launch_bounds__(BLK) void xpdr_cls_kernel(const double* __restrict_
     const double2 xx = reinterpret_cast<const double2*>(x)[i];
     const ushort2 cc = reinterpret_cast<const ushort2*>(cls)[i];
     const double2 rr = reinterpret_cast<const double2*>(r)[i];
-    reinterpret_cast<double2*>(xout)[i] = make_double2(xx.x + dcls[cc.x] * rr.x, xx.y + dcls[cc.y] * rr.y);
+    const double d0 = cc.x != 0xFFFF ? dcls[cc.x] : d[2 * i];       // exception rows: d from memory
+    const double d1 = cc.y != 0xFFFF ? dcls[cc.y] : d[2 * i + 1];
+    reinterpret_cast<double2*>(xout)[i] = make_double2(xx.x + d0 * rr.x, xx.y + d1 * rr.y);
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) xout[n - 1] = x[n - 1] + dcls[cls[n - 1]] * r[n - 1];
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned short c = cls[n - 1];
+    xout[n - 1] = x[n - 1] + (c != 0xFFFF ? dcls[c] : d[n - 1]) * r[n - 1];
+  }
 }
 
 __global__ __launch_bounds__(BLK) void fill_kernel(double* __restrict__ x, long long n, double val) {

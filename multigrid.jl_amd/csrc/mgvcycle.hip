@@ -98,7 +98,8 @@ struct Csr {
   bool has_pat = false;
   long long npat = 0, dict_entries = 0;
   // row classes (csr_rowclass_spmv): first column + class id per row, dictionary of (offset, value) rows
-  DevBuf<int> rc_first, rc_ptr, rc_off, rc_delta, rw_meta, rw_lb, rt_lb;
+  DevBuf<int> rc_first, rc_ptr, rc_off, rc_delta, rw_meta, rw_lb, rt_lb, rc_exc;
+  int rc_nexc = 0;          // exception rows (class id 0xFFFF), computed by csr_rows_spmv from the CSR arrays
   std::vector<int> h_rc_ptr, h_rc_off, h_rc_delta;   // host copy of the dictionary (tile index tables)
   int rc_major = 0;         // most frequent class
   bool rc_tile = false;     // csr_rowclass_tile_spmv (plane tiles from the grid hint)
@@ -140,7 +141,8 @@ struct Csr {
   int rc_blocks() const { return (int)((n_rows + mgk::RC_ROWS - 1) / mgk::RC_ROWS); }
   // workgroups of the nrhs == 1 product (one fused ||r||^2 partial each)
   int rw_blocks() const { return (int)((n_rows + mgk::RW_ROWS - 1) / mgk::RW_ROWS); }
-  int blocks1() const { return has_rc ? (rc_tile ? rt_nblocks : rc_window ? rw_blocks() : rc_blocks()) : nblocks; }
+  int exc_blocks() const { return (rc_nexc + mgk::BLK - 1) / mgk::BLK; }
+  int blocks1() const { return has_rc ? (rc_tile ? rt_nblocks : rc_window ? rw_blocks() : rc_blocks()) + exc_blocks() : nblocks; }
   mgk::TileDev tiledev() const {
     mgk::TileDev t;
     t.tile_lb = rt_lb.p;
@@ -175,6 +177,8 @@ struct Csr {
     rw_meta.release();
     rw_lb.release();
     rt_lb.release();
+    rc_exc.release();
+    rc_nexc = 0;
     rc_tile = false;
     h_rc_ptr.clear();
     h_rc_off.clear();
@@ -371,14 +375,25 @@ template <int MODE>
 int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
-  if (v.nrhs == 1 && M.has_rc && M.rc_tile && v.y != v.x) {
-    const size_t lds = (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * M.rt_halo) * sizeof(double);
-    hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE>), dim3(M.rt_nblocks), dim3(mgk::RT_CR), lds, stream, M.rcdev(), v, M.tiledev());
-  } else if (v.nrhs == 1 && M.has_rc && M.rc_window && v.y != v.x) {   // (staging reads x block-wide: never in place)
-    hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE>), dim3(M.rw_blocks()), blk, (size_t)M.rw_doubles * sizeof(double),
-                       stream, M.rcdev(), v, M.rw_meta.p, M.rw_lb.p, M.rw_blocks(), (int)M.n_cols);
-  } else if (v.nrhs == 1 && M.has_rc) {
-    hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE>), dim3(M.rc_blocks()), blk, 0, stream, M.rcdev(), v);
+  if (v.nrhs == 1 && M.has_rc) {
+    int nb_main;
+    if (M.rc_tile && v.y != v.x) {   // (the staged variants read x workgroup-wide: never in place)
+      const size_t lds = (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * M.rt_halo) * sizeof(double);
+      nb_main = M.rt_nblocks;
+      hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, M.rcdev(), v, M.tiledev());
+    } else if (M.rc_window && v.y != v.x) {
+      nb_main = M.rw_blocks();
+      hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE>), dim3(nb_main), blk, (size_t)M.rw_doubles * sizeof(double),
+                         stream, M.rcdev(), v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
+    } else {
+      nb_main = M.rc_blocks();
+      hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE>), dim3(nb_main), blk, 0, stream, M.rcdev(), v);
+    }
+    if (M.rc_nexc > 0) {   // rows of rare classes, from the CSR arrays; their ||r||^2 partials follow the others
+      mgk::VecArgs ve = v;
+      ve.d = v.d_full;
+      hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3(M.exc_blocks()), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, nb_main);
+    }
   } else if (v.nrhs == 1 && M.has_pat) {
     const bool dl = M.dict_entries <= mgk::DICT_LDS && M.npat < mgk::DICT_LDS;
     if (M.nt && dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
@@ -457,6 +472,7 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
   v.y = out;
   v.b = b;
   v.d = d;
+  v.d_full = d;
   // the level's own relaxPrec, constant per row class: read from the dictionary instead of streamed (rc_d)
   if (h->nrhs == 1 && A.has_rc && A.rc_has_d && d == h->lev[(size_t)level].d.p && &A == &h->lev[(size_t)level].A) v.d = nullptr;
   v.nrhs = (int)h->nrhs;
@@ -478,7 +494,7 @@ int k_xpdr(mg_hierarchy* h, int level, const double* x, const double* d, const d
   if (h->nrhs == 1 && A.has_rc && A.rc_has_d && d == h->lev[(size_t)level].d.p && n == A.n_rows) {
     // the level's relaxPrec is constant per row class: stream the 2-byte class ids instead of d
     hipLaunchKernelGGL(mgk::xpdr_cls_kernel, dim3(grid_for(n / 2 + 1)), dim3(mgk::BLK), 0, h->stream, x, A.rc_cls.p,
-                       A.rc_d.p, r, xout, n);
+                       A.rc_d.p, d, r, xout, n);
     HIP_TRY(hipGetLastError());
     return MG_OK;
   }
@@ -1352,9 +1368,13 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   const long long n = M->n_rows;
   if (n < 1 || M->nnz < 1) return MG_OK;
   const size_t cap = (size_t)std::min<long long>(1LL << 18, std::max<long long>(64, M->nnz / 16));
-  std::vector<int> first((size_t)n, 0), cptr(1, 0), coff, cdelta;
-  std::vector<unsigned short> cid((size_t)n, 0);
-  std::vector<double> cval;
+  // Phase 1: classify every row (raw classes, unbounded ids).  Mostly regular operators - a grid operator whose
+  // rows were renumbered near sub-domain faces, irregular boundaries - have a few popular classes and a tail of
+  // singletons; give up only when the operator is irregular throughout.
+  const size_t raw_cls_cap = (size_t)std::max<long long>(65535, n / 8);
+  const size_t raw_ent_cap = (size_t)std::max<long long>((long long)cap, M->nnz / 4);
+  std::vector<int> first((size_t)n, 0), rptr(1, 0), roff, rdelta, rid((size_t)n, 0);
+  std::vector<double> rval;
   std::unordered_map<unsigned long long, std::vector<int>> table;
   for (long long i = 0; i < n; ++i) {
     const int s = rp[(size_t)i], e = rp[(size_t)i + 1];
@@ -1377,28 +1397,66 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     std::vector<int>& cand = table[hsh];
     int found = -1;
     for (int id : cand) {
-      const int ps = cptr[(size_t)id], len = cptr[(size_t)id + 1] - ps;
+      const int ps = rptr[(size_t)id], len = rptr[(size_t)id + 1] - ps;
       if (len != e - s) continue;
-      if (implicit && cdelta[(size_t)id] != dlt) continue;
+      if (implicit && rdelta[(size_t)id] != dlt) continue;
       bool same = true;
       for (int k = 0; k < len && same; ++k)
-        same = coff[(size_t)ps + k] == ci[(size_t)s + k] - f &&
-               std::memcmp(&cval[(size_t)ps + k], &val[(size_t)s + k], 8) == 0;
+        same = roff[(size_t)ps + k] == ci[(size_t)s + k] - f &&
+               std::memcmp(&rval[(size_t)ps + k], &val[(size_t)s + k], 8) == 0;
       if (same) { found = id; break; }
     }
     if (found < 0) {
-      found = (int)cptr.size() - 1;
-      if (found >= 65535 || coff.size() + (size_t)(e - s) > cap) return MG_OK;  // not that redundant
+      found = (int)rptr.size() - 1;
+      if ((size_t)found >= raw_cls_cap || roff.size() + (size_t)(e - s) > raw_ent_cap) return MG_OK;  // irregular
       for (int k = s; k < e; ++k) {
-        coff.push_back(ci[(size_t)k] - f);
-        cval.push_back(val[(size_t)k]);
+        roff.push_back(ci[(size_t)k] - f);
+        rval.push_back(val[(size_t)k]);
       }
-      cptr.push_back((int)coff.size());
-      cdelta.push_back(dlt);
+      rptr.push_back((int)roff.size());
+      rdelta.push_back(dlt);
       cand.push_back(found);
     }
-    cid[(size_t)i] = (unsigned short)found;
+    rid[(size_t)i] = found;
   }
+  table.clear();
+  // Phase 2: keep the most frequent classes that fit the id width and the dictionary cap; rows of any other class
+  // are EXCEPTION rows (class id 0xFFFF): the row-class kernels skip them and csr_rows_spmv computes them from the
+  // CSR arrays.  Accepted when the kept classes cover enough rows (MG_ROWCLASS_MIN_COVER, default 0.9).
+  const size_t nraw = rptr.size() - 1;
+  std::vector<long long> freq(nraw, 0);
+  for (long long i = 0; i < n; ++i) freq[(size_t)rid[(size_t)i]]++;
+  std::vector<int> order(nraw);
+  for (size_t c = 0; c < nraw; ++c) order[c] = (int)c;
+  std::sort(order.begin(), order.end(), [&](int x, int y) { return freq[(size_t)x] != freq[(size_t)y] ? freq[(size_t)x] > freq[(size_t)y] : x < y; });
+  std::vector<int> remap(nraw, 0xFFFF), cptr(1, 0), coff, cdelta;
+  std::vector<double> cval;
+  long long covered = 0;
+  for (size_t t = 0; t < nraw && cptr.size() - 1 < 65535; ++t) {
+    const int c = order[t];
+    const int ps = rptr[(size_t)c], len = rptr[(size_t)c + 1] - ps;
+    if (freq[(size_t)c] < 2 && nraw > 1) break;                 // singletons are never worth a dictionary slot
+    if (coff.size() + (size_t)len > cap) break;
+    remap[(size_t)c] = (int)cptr.size() - 1;
+    coff.insert(coff.end(), roff.begin() + ps, roff.begin() + ps + len);
+    cval.insert(cval.end(), rval.begin() + ps, rval.begin() + ps + len);
+    cptr.push_back((int)coff.size());
+    cdelta.push_back(rdelta[(size_t)c]);
+    covered += freq[(size_t)c];
+  }
+  {
+    double min_cover = 0.9;
+    if (const char* e = std::getenv("MG_ROWCLASS_MIN_COVER")) min_cover = std::atof(e);
+    if (cptr.size() < 2 || (double)covered < min_cover * (double)n) return MG_OK;
+  }
+  std::vector<unsigned short> cid((size_t)n, 0);
+  std::vector<int> exc;
+  for (long long i = 0; i < n; ++i) {
+    const int c = remap[(size_t)rid[(size_t)i]];
+    cid[(size_t)i] = (unsigned short)c;
+    if (c == 0xFFFF) exc.push_back((int)i);
+  }
+  { std::vector<int>().swap(rid); std::vector<int>().swap(roff); std::vector<double>().swap(rval); }
   if (coff.empty()) { coff.push_back(0); cval.push_back(0.0); }
   {
     // The kernel serves one class per waterfall pass: it only pays when a wavefront's 64 consecutive rows hold few
@@ -1415,6 +1473,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
       int ns = 0;
       const long long w1 = std::min(n, w0 + 64);
       for (long long i = w0; i < w1; ++i) {
+        if (cid[(size_t)i] == 0xFFFF) continue;   // exception rows cost no pass
         bool dup = false;
         for (int t = 0; t < ns; ++t)
           if (seen[t] == cid[(size_t)i]) { dup = true; break; }
@@ -1440,6 +1499,11 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   HIP_TRY(hipMemcpy(M->rc_val.p, cval.data(), cval.size() * sizeof(double), hipMemcpyHostToDevice));
   M->rc_ncls = (long long)cptr.size() - 1;
   M->rc_entries = (long long)coff.size();
+  M->rc_nexc = (int)exc.size();
+  if (!exc.empty()) {
+    MG_TRY(M->rc_exc.alloc(exc.size()));
+    HIP_TRY(hipMemcpy(M->rc_exc.p, exc.data(), exc.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   M->has_rc = true;
   M->rc_implicit = implicit;
   M->h_rc_ptr = cptr;
@@ -1448,7 +1512,8 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   if (implicit) {   // LDS-window kernel: do the windows of the most frequent class fit for a full workgroup of rows?
     const char* e = std::getenv("MG_NO_WINDOW");
     std::vector<long long> cnt(cptr.size() - 1, 0);
-    for (long long i = 0; i < n; ++i) cnt[cid[(size_t)i]]++;
+    for (long long i = 0; i < n; ++i)
+      if (cid[(size_t)i] != 0xFFFF) cnt[cid[(size_t)i]]++;
     const size_t cm = (size_t)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
     M->rc_major = (int)cm;
     const int ps = cptr[cm], len = cptr[cm + 1] - ps;
@@ -1529,6 +1594,7 @@ int derive_class_d(Level& L) {
   HIP_TRY(hipMemcpy(hd.data(), L.d.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < hd.size(); ++i) {
     const unsigned short c = A.h_cls[i];
+    if (c == 0xFFFF) continue;   // exception rows read d from memory (csr_rows_spmv, xpdr_cls_kernel)
     if (!seen[c]) { seen[c] = 1; dc[c] = hd[i]; }
     else if (std::memcmp(&dc[c], &hd[i], 8) != 0) return MG_OK;   // not class-constant: keep streaming d
   }
@@ -1630,6 +1696,11 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
     const char* e = std::getenv("MG_NO_PATTERN");
     if (!(e && e[0] == '1')) MG_TRY(build_patterns(M, rp, ci));
   }
+  if (const char* e = std::getenv("MG_DEBUG_FORMAT"))
+    if (e[0] == '1')
+      std::fprintf(stderr, "[mgvcycle] operator %lld x %lld, nnz %lld: row classes %lld (dictionary %lld, exception rows %d, "
+                   "implicit first %d, window %d), patterns %lld\n", M->n_rows, M->n_cols, M->nnz, M->has_rc ? M->rc_ncls : 0,
+                   M->has_rc ? M->rc_entries : 0, M->rc_nexc, (int)M->rc_implicit, (int)M->rc_window, M->has_pat ? M->npat : 0);
   return MG_OK;
 }
 
@@ -2455,6 +2526,7 @@ int mg_op_apply_rows_dev_FP64(mg_operator* op, long long kernel, double alpha, c
   v.y = y + row_offset * nrhs;
   v.b = b ? b + row_offset * nrhs : nullptr;
   v.d = d ? d + row_offset : nullptr;
+  v.d_full = v.d;
   v.alpha = alpha;
   v.beta = beta;
   v.nrhs = (int)nrhs;

@@ -183,6 +183,18 @@ def test_hip_distributed_solve_matches_oracle(built, world, kind, nrhs, cyc):
     _run(world, kind, nrhs, cyc, use_hip=True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_hip_distributed_rowclass_with_exception_rows(built, world, monkeypatch):
+    """Local operators of a sharded level are regular except next to the sub-domain faces (rows renumbered into the
+    [interior | boundary] order, halo columns appended): with the size thresholds lifted they are stored as row classes
+    plus EXCEPTION rows (csr_rows_spmv) and the sharded solve must still match the oracle."""
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.2")
+    _run(world, "gmg3d", 1, "V", use_hip=True)
+
+
 # ---- sharded SETUP (structured_setup.py): every rank builds only its part -------------------------------
 def _worker_structured(rank, world, port, cells, levels, cyc, nrhs, use_hip, q):
     try:

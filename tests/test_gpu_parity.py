@@ -481,3 +481,51 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
     assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] > 0
     assert p.device.operator_rowclasses(3, D.MG_OP_A)[0] == 0
     mg.clear_(p)
+
+
+@pytest.mark.gpu
+def test_rowclass_exception_rows(mg, built, monkeypatch):
+    """A mostly regular operator: 3 % of the rows of a Poisson matrix get unique values, a few more get an extra
+    entry.  The popular classes stay in the dictionary, the odd rows become exception rows computed from the CSR
+    arrays (csr_rows_spmv); every fused epilogue and the fused ||r||^2 must match scipy."""
+    import torch
+    import scipy.sparse as sp
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    rng = np.random.default_rng(23)
+    A, mesh = mg.poisson_shifted([24, 20, 18])
+    A = A.tolil()
+    n = A.shape[0]
+    odd = rng.choice(n, size=n // 33, replace=False)
+    for i in odd[: len(odd) // 2]:
+        A[i, i] = A[i, i] * (1.0 + rng.random())               # unique values
+    for i in odd[len(odd) // 2:]:
+        A[i, (i * 7 + 3) % n] = 0.125 * rng.random()           # an extra entry somewhere
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    x = torch.from_numpy(rng.standard_normal(n)).cuda()
+    b = torch.from_numpy(rng.standard_normal(n)).cuda()
+    d = torch.from_numpy(rng.standard_normal(n)).cuda()
+    for stage in ("0", "1"):                                    # staged (window) and plain row-class kernels
+        monkeypatch.setenv("MG_NO_WINDOW", stage)
+        op = D.DeviceOperator(A, 0)
+        y = torch.ones(n, dtype=torch.float64, device="cuda")
+        xn, bn, dn = x.cpu().numpy(), b.cpu().numpy(), d.cpu().numpy()
+        op.apply(D.MG_K_SPMV, x, y, alpha=-0.5, beta=2.0)
+        want = -0.5 * (A @ xn) + 2.0
+        assert np.abs(y.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
+        op.apply(D.MG_K_RESIDUAL, x, y, b=b)
+        want = bn - A @ xn
+        assert np.abs(y.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
+        op.apply(D.MG_K_SMOOTH, x, y, b=b, d=d)
+        want = xn + dn * (bn - A @ xn)
+        assert np.abs(y.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
+        op.close()
+    # inside a hierarchy (fused residual + norm, class-constant relaxPrec with exception rows, xpdr): vs the oracle
+    p = mg.getMGparam(np.float64, np.int64, 2, 8, 6, 1e-10, "Jac", 0.8, 2, 1)
+    mg.MGsetup(A, mesh, p, 1)
+    bb = mg.seeded_rhs(A, 1)
+    _compare_solve(mg, p, bb)
+    assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] > 0
+    mg.clear_(p)
