@@ -529,3 +529,48 @@ def test_rowclass_exception_rows(mg, built, monkeypatch):
     _compare_solve(mg, p, bb)
     assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] > 0
     mg.clear_(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells,levels", [([33, 25, 7], 2), ([40, 30, 5], 3), ([63, 17, 9], 2), ([31, 37], 3), ([129, 9], 2),
+                                           ([23, 23, 23], 3), ([70, 10, 3], 2)])
+def test_rowclass_variants_on_odd_grids(mg, built, cells, levels, monkeypatch):
+    """Every row-class kernel variant (plain / window / plane tile, with and without the implicit first column and the
+    dictionary relaxPrec) on grids whose sizes are not multiples of anything convenient (partial chunks, partial
+    planes groups, planes smaller or larger than a workgroup, 2-D): fused residual, fused sweep and the transfer
+    products of every level against scipy, through the device-resident entry points."""
+    import torch
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    rng = np.random.default_rng(sum(cells))
+    seen = set()
+    for no_tile, no_win, no_first in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
+        monkeypatch.setenv("MG_NO_TILE", no_tile)
+        monkeypatch.setenv("MG_NO_WINDOW", no_win)
+        monkeypatch.setenv("MG_NO_IMPLICIT_FIRST", no_first)
+        A, p, b = _setup(mg, cells, levels)
+        h = mg.to_device(p)
+        for l in range(1, p.levels):
+            Al, Pl, Rl, dl = p.As[l - 1], p.Ps[l - 1], p.Rs[l - 1], p.relaxPrecs[l - 1]
+            seen.add(h.operator_kernel_variant(l, D.MG_OP_A))
+            xn, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+            x, bb = torch.from_numpy(xn).cuda(), torch.from_numpy(bn).cuda()
+            out = torch.zeros_like(x)
+            h.fused_dev(l, D.MG_K_RESIDUAL, bb, x, out)
+            want = bn - Al @ xn
+            assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
+            h.fused_dev(l, D.MG_K_SMOOTH, bb, x, out)
+            want = xn + dl * (bn - Al @ xn)
+            assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
+            xc = rng.standard_normal(Pl.shape[1])
+            got = mg.SpMatMul(p, l, "P", xc, xn.copy(), 1.0, 1.0)
+            want = xn + Pl @ xc
+            assert np.abs(got - want).max() / np.abs(want).max() < KERNEL_TOL
+            got = mg.SpMatMul(p, l, "R", xn, np.zeros(Rl.shape[0]), 1.0, 0.0)
+            want = Rl @ xn
+            assert np.abs(got - want).max() / np.abs(want).max() < KERNEL_TOL
+        _compare_solve(mg, p, b)
+        mg.clear_(p)
+    assert 0 in seen                      # the plain row-class kernel ran in the last configuration
