@@ -103,6 +103,11 @@ int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* L
                                 const double* Lval, const long long* Uptr, const long long* Ucol,
                                 const double* Uval, const long long* p, const long long* q);
 
+/* coarseSolveType "GMRES" (MGcycle.jl:152-168): the coarsest level is solved by one restart of Jacobi-preconditioned
+ * FGMRES(10) with tol 0.01 from x = 0; d = relaxParam ./ diag(A_c) is what defineCoarsestAinv keeps in param.LU
+ * (MGsetup.jl:334).  One right-hand side (the reference's blockFGMRES branch is rejected). */
+int mg_set_coarse_gmres_FP64(mg_hierarchy* h, long long n, const double* d);
+
 /* Validate the hierarchy (shapes chain, every level complete), build the row-block partitions,
  * allocate the per-level b/r/x scratch (CYCLEmem, MGdef.jl:56-60). */
 int mg_finalize(mg_hierarchy* h);

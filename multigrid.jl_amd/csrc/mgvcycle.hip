@@ -284,6 +284,8 @@ struct mg_hierarchy {
   DevBuf<double> stage_b, stage_x, stage_t;
   // Krylov work vectors (allocated on the first mg_pcg call)
   DevBuf<double> kr, kz, kp, kAp, kw;
+  DevBuf<double> kwc, coarse_d;   // coarseSolveType "GMRES": FGMRES work space and the Jacobi preconditioner of the coarsest level
+  bool coarse_gmres = false;
   // fine-level operands of the last cycle/solve (used as inputs by mg_time_op_dev_FP64)
   const double* last_b = nullptr;
   double* last_x = nullptr;
@@ -508,8 +510,19 @@ int k_fill(mg_hierarchy* h, double* x, long long n, double val) {
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
+int fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>& work, const double* b,
+                double* x, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
+                double* resvec, long long* nres);
 int k_coarse(mg_hierarchy* h, int level, const double* b, double* x) {
   const long long n = h->n_coarse;
+  if (h->coarse_gmres) {
+    // coarseSolveType "GMRES" (MGcycle.jl:152-168): x = 0; one restart of FGMRES(10), tol 0.01, M = d .* v with
+    // d = relaxParam ./ diag(A_c) (defineCoarsestAinv, MGsetup.jl:334)
+    if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "coarseSolveType GMRES with a block of right-hand sides (blockFGMRES) is not on the device path");
+    ProfScope ps(h, level, MG_K_COARSE, 0.0);
+    MG_TRY(k_fill(h, x, n, 0.0));
+    return fgmres_core(h, level, 1, h->coarse_d.p, h->kwc, b, x, 10, 0.01, 1, nullptr, nullptr, nullptr, nullptr);
+  }
   if (h->coarse_lu) {
     ProfScope ps(h, level, MG_K_COARSE, 12.0 * (double)(h->luLval.n + h->luUval.n) + 16.0 * (double)n * (double)h->nrhs);
     mgk::LuDev F;
@@ -1001,16 +1014,19 @@ int bicgstab_dev(mg_hierarchy* h, const double* b, double* x, double tol, long l
 // -> KrylovMethods.fgmres (v0.6.0, un-vendored), restated from the published algorithm (Saad's FGMRES(m): modified
 // Gram-Schmidt Arnoldi, Givens rotations, residual estimate |s_{i+1}|/||b|| after every inner step).  maxIter counts
 // restarts, `inner` is the Krylov dimension; resvec gets one entry per inner step; flag 0 converged, -1 not, -9 b = 0.
-int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, double tol, long long maxIter,
-               long long* iters, long long* flag_out, double* resvec, long long* nres) {
-  Level& L = h->lev[0];
+// Flexible restarted GMRES on level `lv` (0-based).  precond 0: one multigrid cycle from level 0 (solveGMRES_MG,
+// lv must be 0); precond 1: z = dprec .* v (the Jacobi-preconditioned coarsest solve, MGcycle.jl:152-168).
+int fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>& work, const double* b,
+                double* x, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
+                double* resvec, long long* nres) {
+  Level& L = h->lev[(size_t)lv];
   const long long n = L.n;
-  if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "mg_fgmres: block right-hand sides (blockFGMRES) are not on the device path yet");
+  if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "fgmres: block right-hand sides (blockFGMRES) are not on the device path yet");
   if (inner < 1 || inner > 64) return fail(MG_ERR_INVALID, "inner must be in [1,64]");
   const int m = (int)inner;
-  if (h->kw.n != (size_t)n * (size_t)(2 * m + 2)) MG_TRY(h->kw.alloc((size_t)n * (size_t)(2 * m + 2)));
-  double* V = h->kw.p;                         // m+1 basis vectors
-  double* Z = h->kw.p + (size_t)(m + 1) * n;   // m preconditioned vectors
+  if (work.n != (size_t)n * (size_t)(2 * m + 2)) MG_TRY(work.alloc((size_t)n * (size_t)(2 * m + 2)));
+  double* V = work.p;                         // m+1 basis vectors
+  double* Z = work.p + (size_t)(m + 1) * n;   // m preconditioned vectors
   double* r = Z + (size_t)m * n;               // residual / w
   double bn = 0.0, rn = 0.0;
   MG_TRY(norm_sync(h, b, n, &bn));
@@ -1023,7 +1039,7 @@ int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, dou
     if (nres) *nres = 0;
     return MG_OK;
   }
-  MG_TRY(k_residual(h, 0, L.A, b, x, r));
+  MG_TRY(k_residual(h, lv, L.A, b, x, r));
   MG_TRY(norm_sync(h, r, n, &rn));
   double err = rn / bn;
   if (err < tol) {
@@ -1043,8 +1059,9 @@ int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, dou
       double* vi = V + (size_t)i * n;
       double* zi = Z + (size_t)i * n;
       double* w = V + (size_t)(i + 1) * n;
-      MG_TRY(cycle_dev(h, vi, zi, true));                                 // z = M(V[:,i])
-      MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, zi, 0.0, w));              // w = A z
+      if (precond == 0) MG_TRY(cycle_dev(h, vi, zi, true));               // z = M(V[:,i])
+      else MG_TRY(k_dscale(h, lv, dprec, vi, zi, n));
+      MG_TRY(k_spmv(h, lv, MG_K_SPMV, L.A, 1.0, zi, 0.0, w));             // w = A z
       for (int k = 0; k <= i; ++k) {                                      // modified Gram-Schmidt
         double hk = 0.0;
         MG_TRY(dot_sync(h, w, V + (size_t)k * n, n, &hk));
@@ -1082,7 +1099,7 @@ int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, dou
     }
     for (int i = 0; i < used; ++i) MG_TRY(k_axpby(h, y[(size_t)i], Z + (size_t)i * n, 1.0, x, n));   // x += Z y
     if (flag == 0) break;
-    MG_TRY(k_residual(h, 0, L.A, b, x, r));
+    MG_TRY(k_residual(h, lv, L.A, b, x, r));
     MG_TRY(norm_sync(h, r, n, &rn));
     err = rn / bn;
     if (err <= tol) { flag = 0; break; }
@@ -1092,6 +1109,11 @@ int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, dou
   if (flag_out) *flag_out = flag;
   if (nres) *nres = nr;
   return MG_OK;
+}
+
+int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, double tol, long long maxIter,
+               long long* iters, long long* flag_out, double* resvec, long long* nres) {
+  return fgmres_core(h, 0, 0, nullptr, h->kw, b, x, inner, tol, maxIter, iters, flag_out, resvec, nres);
 }
 
 // ---- host <-> device block transfer (column-major host <-> row-major device) --------------------
@@ -1851,6 +1873,8 @@ int mg_destroy(mg_hierarchy* h) {
   h->luLval.release();
   h->luUval.release();
   h->luWork.release();
+  h->kwc.release();
+  h->coarse_d.release();
   h->partial.release();
   h->partial2.release();
   h->scalar.release();
@@ -1946,6 +1970,7 @@ int mg_set_coarse_dense_inverse_FP64(mg_hierarchy* h, long long n, const double*
   h->n_coarse = n;
   h->coarse_set = true;
   h->coarse_lu = false;
+  h->coarse_gmres = false;
   h->finalized = false;
   return MG_OK;
 }
@@ -2032,6 +2057,25 @@ int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* L
   h->n_coarse = n;
   h->coarse_set = true;
   h->coarse_lu = true;
+  h->coarse_gmres = false;
+  h->Ainv.release();
+  h->finalized = false;
+  return MG_OK;
+}
+
+// Coarsest solve by Jacobi-preconditioned FGMRES (coarseSolveType "GMRES", MGcycle.jl:152-168): d = relaxParam ./ diag(A_c)
+// as defineCoarsestAinv stores it in param.LU (MGsetup.jl:334).
+int mg_set_coarse_gmres_FP64(mg_hierarchy* h, long long n, const double* d) {
+  UploadFence upload_fence;
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (n < 1 || !d) return fail(MG_ERR_INVALID, "empty preconditioner");
+  (void)hipSetDevice(h->device);
+  MG_TRY(h->coarse_d.alloc((size_t)n));
+  HIP_TRY(hipMemcpy(h->coarse_d.p, d, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  h->n_coarse = n;
+  h->coarse_set = true;
+  h->coarse_gmres = true;
+  h->coarse_lu = false;
   h->Ainv.release();
   h->finalized = false;
   return MG_OK;

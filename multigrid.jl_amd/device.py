@@ -42,6 +42,7 @@ SIGNATURES = {
     "mg_set_grid_hint": (C.c_int, [_vp, _ll, _ll, _ll, _ll]),
     "mg_set_coarse_dense_inverse_FP64": (C.c_int, [_vp, _ll, _dp]),
     "mg_set_coarse_lu_FP64_INT64": (C.c_int, [_vp, _ll, _lp, _lp, _dp, _lp, _lp, _dp, _lp, _lp]),
+    "mg_set_coarse_gmres_FP64": (C.c_int, [_vp, _ll, _dp]),
     "mg_finalize": (C.c_int, [_vp]),
     "mg_set_nrhs": (C.c_int, [_vp, _ll]),
     "mg_replace_values_FP64": (C.c_int, [_vp, _ll, _ll, _dp, _ll]),
@@ -204,6 +205,10 @@ class DeviceHierarchy:
         import scipy.sparse as sp
         lib = self.lib
         nc = int(param.As[-1].shape[0])
+        if param.coarseSolveType == "GMRES":                            # param.LU = relaxParam ./ diag(A_c)
+            d = np.ascontiguousarray(param.LU, dtype=np.float64)
+            _check(lib, lib.mg_set_coarse_gmres_FP64(self.handle, nc, _f64(d)), "mg_set_coarse_gmres")
+            return
         if nc <= DENSE_COARSE_MAX and not force_sparse:
             Ainv = np.asfortranarray(param.LU.solve(np.eye(nc)))        # LU \ I, column-major
             _check(lib, lib.mg_set_coarse_dense_inverse_FP64(self.handle, nc, _f64(Ainv)), "mg_set_coarse_dense_inverse")
@@ -253,8 +258,8 @@ class DeviceHierarchy:
             d = np.empty(param.As[l - 1].shape[0], dtype=np.float64)
             _check(lib, lib.mg_get_relax_FP64(self.handle, l, _f64(d), d.size), "mg_get_relax")
             param.relaxPrecs[l - 1] = d
-        from .mgsetup import coarse_lu
-        param.LU = coarse_lu(param.As[-1])                           # defineCoarsestAinv (MGsetup.jl:350)
+        from .mgsetup import defineCoarsestAinv
+        defineCoarsestAinv(param, param.As[-1])                      # (MGsetup.jl:323-355)
         self._set_coarse(param)
         _check(lib, lib.mg_finalize(self.handle), "mg_finalize")
 

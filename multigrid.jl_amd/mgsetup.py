@@ -80,8 +80,12 @@ def defineCoarsestAinv(param: MGparam, Ac) -> None:
     if param.coarseSolveType == "MUMPS":
         raise NotImplementedError("MUMPS coarse solve is dead code in the reference (Multigrid.jl:29-40)")
     if param.coarseSolveType == "GMRES":
-        # Jacobi-preconditioned FGMRES coarse solve (MGcycle.jl:152-168): SURVEY 8f-3, not on the device path yet.
-        raise NotImplementedError("coarseSolveType='GMRES' is a 'next' row (SURVEY 8f-3)")
+        # Jacobi-preconditioned FGMRES coarse solve (MGcycle.jl:152-168): param.LU = relaxParam ./ diag(AT) (l.334),
+        # which only broadcasts for a scalar relaxParam
+        if isinstance(param.relaxParam, (list, tuple, np.ndarray)):
+            raise ValueError("coarseSolveType='GMRES' needs a scalar relaxParam (MGsetup.jl:334 broadcasts it over diag(AT))")
+        param.LU = np.ascontiguousarray(float(param.relaxParam) / _as_csr(Ac).diagonal(), dtype=np.float64)
+        return
     param.LU = coarse_lu(Ac)
 
 
@@ -212,5 +216,5 @@ def transposeHierarchy(param: MGparam, verbose: bool = False) -> None:
         param.Rs[l - 1] = _as_csr(newP.T)
         param.As[l] = _as_csr(param.As[l].T)
     destroyCoarsestLU(param)
-    param.LU = coarse_lu(param.As[-1])
+    defineCoarsestAinv(param, param.As[-1])
     _release_device(param)

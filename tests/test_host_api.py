@@ -89,7 +89,11 @@ def test_copy_clear(mg):
 def test_unsupported_options_are_loud(mg):
     A, mesh = mg.poisson_shifted([4, 4])
     with pytest.raises(NotImplementedError):
-        mg.MGsetup(A, mesh, mg.getMGparam(coarseSolveType="GMRES", relaxType="Jac"))
+        mg.MGsetup(A, mesh, mg.getMGparam(coarseSolveType="MUMPS", relaxType="Jac"))
+    with pytest.raises(ValueError):                                   # relaxParam ./ diag(AT) needs a scalar (MGsetup.jl:334)
+        mg.MGsetup(A, mesh, mg.getMGparam(coarseSolveType="GMRES", relaxType="Jac", relaxParam=[0.8, 0.8, 0.8]))
+    p = mg.MGsetup(A, mesh, mg.getMGparam(coarseSolveType="GMRES", relaxType="Jac", relaxParam=0.8))
+    assert np.allclose(p.LU, 0.8 / p.As[-1].diagonal())               # what defineCoarsestAinv keeps in param.LU
     with pytest.raises(NotImplementedError):
         mg.MGsetup(A, mesh, mg.getMGparam(transferOperatorType="SystemsFacesLinear"))
     with pytest.raises(ValueError):

@@ -235,3 +235,21 @@ def test_rediscretisation_hierarchy_and_threshold(mg):
     x = np.zeros_like(b)
     orc.solveMG(p, b, x)
     assert np.linalg.norm(p.As[0] @ x - b) < 0.005
+
+
+def test_gmres_coarse_solve_oracle():
+    """coarseSolveType "GMRES" (MGcycle.jl:152-168): the coarsest level is solved inexactly (one FGMRES(10) restart to
+    1e-2), so a cycle still contracts - just not as fast as with the LU - and the hierarchy is otherwise unchanged."""
+    import multigrid_jl_amd as mg
+    A, mesh = mg.poisson_shifted([16, 16, 16])
+    hist = {}
+    for cst in ("NoMUMPS", "GMRES"):
+        p = mg.getMGparam(np.float64, np.int64, 3, 8, 10, 1e-8, "Jac", 0.8, 2, 1, "V", cst, 0.5, 0.0)
+        mg.MGsetup(A, mesh, p, 1)
+        b = mg.seeded_rhs(A, 1)
+        x = np.zeros_like(b)
+        h = {}
+        orc.solveMG(p, b, x, False, h)
+        hist[cst] = h["resvec"]
+    assert hist["GMRES"][-1] < 1e-4 * hist["GMRES"][0]
+    assert hist["GMRES"][-1] >= hist["NoMUMPS"][-1] * 0.5                # never better than the exact coarse solve by much
