@@ -382,6 +382,13 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
     if (M.rc_tile && v.y != v.x) {   // (the staged variants read x workgroup-wide: never in place)
       const size_t lds = (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * M.rt_halo) * sizeof(double);
       nb_main = M.rt_nblocks;
+      static bool lds_attr_set[3] = {false, false, false};   // up to 80 KiB of dynamic LDS: lift the 64 KiB default once
+      if (!lds_attr_set[MODE]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipGetLastError();
+        lds_attr_set[MODE] = true;
+      }
       hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, M.rcdev(), v, M.tiledev());
     } else if (M.rc_window && v.y != v.x) {
       nb_main = M.rw_blocks();
@@ -1824,6 +1831,7 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
     MG_TRY(refresh_rowclasses(&Ac, hv.data()));
   }
   for (int l = 0; l + 1 < nl; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));   // relaxPrecs were recomputed above
+  for (int l = 0; l < nl; ++l) MG_TRY(build_tile(h->lev[(size_t)l].A, h->lev[(size_t)l].grid));   // tile tables follow the new classes
   if (levels_done) *levels_done = nl - 1;
   return MG_OK;
 }
@@ -2141,7 +2149,11 @@ int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, co
   HIP_TRY(spin_sync(h->stream));
   HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
   MG_TRY(refresh_rowclasses(M, nzval));
-  if (which == MG_OP_A && h->lev[(size_t)level - 1].relax_set) MG_TRY(derive_class_d(h->lev[(size_t)level - 1]));
+  if (which == MG_OP_A) {
+    Level& L = h->lev[(size_t)level - 1];
+    if (L.relax_set) MG_TRY(derive_class_d(L));
+    MG_TRY(build_tile(L.A, L.grid));
+  }
   return MG_OK;
 }
 
