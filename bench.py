@@ -208,9 +208,10 @@ def main():
         if nrhs > 1:
             sym[l], fmt_of[l] = f"mgk::csr_stream_spmm<2, {ntl}>", "plain CSR (block right-hand sides)"
         elif rcs[l][0] > 0:
-            var = h.operator_kernel_variant(l, mg.device.MG_OP_A)
-            sym[l] = {0: "mgk::csr_rowclass_spmv<2>", 1: "mgk::csr_rowclass_window_spmv<2>",
-                      2: "mgk::csr_rowclass_tile_spmv<2>"}[var]
+            var, nexc = h.operator_kernel_info(l, mg.device.MG_OP_A)
+            inl = "true" if 0 < nexc <= 256 else "false"   # a short list of exception rows is handled in-kernel
+            sym[l] = {0: "mgk::csr_rowclass_spmv<2, %s>", 1: "mgk::csr_rowclass_window_spmv<2, %s>",
+                      2: "mgk::csr_rowclass_tile_spmv<2, %s>"}[var] % inl
             fmt_of[l] = "row classes"
         elif fmts[l][0] > 0:
             dl = "true" if (fmts[l][1] <= 1024 and fmts[l][0] < 1024) else "false"

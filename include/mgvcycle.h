@@ -214,9 +214,11 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
  * no per-row first column is stored (2 B/row instead of 6); class_relax = 1 when the level's relaxPrec is constant per
  * class and the fused sweep reads it from the dictionary instead of streaming 8 B/row; kernel_variant = which kernel
  * serves the operator at nrhs == 1: -1 none (streaming formats), 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv
- * (x staged in LDS per workgroup of consecutive rows), 2 csr_rowclass_tile_spmv (plane tiles from the grid hint). */
+ * (x staged in LDS per workgroup of consecutive rows), 2 csr_rowclass_tile_spmv (plane tiles from the grid hint);
+ * exception_rows = rows outside the dictionary classes (computed from the CSR arrays: in the last workgroup of the
+ * row-class kernel when there are at most 256 of them - second template argument `true` - else by csr_rows_spmv). */
 int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which, long long* implicit_first,
-                               long long* class_relax, long long* kernel_variant);
+                               long long* class_relax, long long* kernel_variant, long long* exception_rows);
 /* Algorithmic HBM bytes of one full cycle (x0 = 0) with the current nrhs, DESIGN.md section 5. */
 int mg_cycle_bytes(mg_hierarchy* h, double* bytes);
 /* HBM bytes held by the hierarchy. */

@@ -415,9 +415,37 @@ struct RowClassDev {
   const double* cls_val;        // dictionary: value
   const int* cls_delta;         // ncls: first column minus row index (only when firstcol == nullptr)
   const double* cls_d;          // ncls: the level's relaxPrec of every row of the class (SMOOTH with v.d == nullptr)
+  // a handful of exception rows (class id 0xFFFF) are computed by the last workgroup of the row-class kernel itself,
+  // from the CSR arrays; longer lists get their own launch (csr_rows_spmv)
+  const int* exc_rows;
+  int nexc_inline;              // <= BLK, 0 = none handled in-kernel
+  const int* rowptr;
+  const int* colidx;
+  const double* val;
   int nblocks;                  // ceil(n_rows / RC_ROWS)
   int n_rows;
 };
+
+template <int MODE>
+__device__ __forceinline__ double rowclass_exception_rows(const RowClassDev& C, const VecArgs& v, int tid) {
+  if (tid >= C.nexc_inline) return 0.0;
+  const int row = C.exc_rows[tid];
+  double pb = 0.0, pd = 0.0, px = 0.0;
+  if (MODE == AXPBY) {
+    if (v.beta != 0.0) pb = v.beta * v.y[row];
+  } else {
+    pb = v.b[row];
+    if (MODE == SMOOTH) {
+      pd = v.d_full[row];
+      px = v.xs[row];
+    }
+  }
+  double acc = 0.0;
+  for (int k = C.rowptr[row]; k < C.rowptr[row + 1]; ++k) acc += C.val[k] * v.x[C.colidx[k]];
+  const double outv = epilogue<MODE>(v, row, acc, pb, pd, px);
+  v.y[row] = outv;
+  return outv * outv;
+}
 
 #ifndef MG_RC_RPT
 #define MG_RC_RPT 2
@@ -425,7 +453,7 @@ struct RowClassDev {
 constexpr int RC_RPT = MG_RC_RPT;       // rows per lane: RC_RPT independent gather chains in flight
 constexpr int RC_ROWS = BLK * RC_RPT;   // rows per workgroup (lane t holds rows t, t + BLK, ...)
 
-template <int MODE>
+template <int MODE, bool EXC>
 __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs v) {
   __shared__ double red[BLK / 64];
   const int tid = threadIdx.x;
@@ -542,6 +570,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
       sq += outv * outv;
     }
   }
+  if (EXC && blockIdx.x == gridDim.x - 1) sq += rowclass_exception_rows<MODE>(C, v, tid);   // EXC: C.nexc_inline > 0
   if (v.sumsq) {
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if ((tid & 63) == 0) red[tid >> 6] = sq;
@@ -585,7 +614,7 @@ constexpr int RW_MAXINT = 8;            // disjoint windows
 // subsets of the interior class's shifts, so in practice every gather is served from LDS.
 constexpr int RW_META_HDR = 5;
 
-template <int MODE>
+template <int MODE, bool EXC>
 __global__ __launch_bounds__(BLK) void csr_rowclass_window_spmv(RowClassDev C, VecArgs v, const int* __restrict__ meta,
                                                                 const int* __restrict__ cls_lb, int nblocks_w,
                                                                 int n_cols) {
@@ -686,6 +715,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_window_spmv(RowClassDev C, V
       sq += outv * outv;
     }
   }
+  if (EXC && blockIdx.x == gridDim.x - 1) sq += rowclass_exception_rows<MODE>(C, v, tid);   // EXC: C.nexc_inline > 0
   if (v.sumsq) {
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) red[wave] = sq;
@@ -724,7 +754,7 @@ struct TileDev {
   int n_cols;
 };
 
-template <int MODE>
+template <int MODE, bool EXC>
 __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C, VecArgs v, TileDev T) {
   extern __shared__ double win[];
   __shared__ double red[RT_CR / 64];
@@ -821,6 +851,7 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
       sq += outv * outv;
     }
   }
+  if (EXC && blockIdx.x == gridDim.x - 1) sq += rowclass_exception_rows<MODE>(C, v, tid);   // EXC: C.nexc_inline > 0
   if (v.sumsq) {
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) red[wave] = sq;

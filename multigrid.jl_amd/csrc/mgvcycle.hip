@@ -141,7 +141,7 @@ struct Csr {
   int rc_blocks() const { return (int)((n_rows + mgk::RC_ROWS - 1) / mgk::RC_ROWS); }
   // workgroups of the nrhs == 1 product (one fused ||r||^2 partial each)
   int rw_blocks() const { return (int)((n_rows + mgk::RW_ROWS - 1) / mgk::RW_ROWS); }
-  int exc_blocks() const { return (rc_nexc + mgk::BLK - 1) / mgk::BLK; }
+  int exc_blocks() const { return rc_nexc > mgk::BLK ? (rc_nexc + mgk::BLK - 1) / mgk::BLK : 0; }   // short lists: in-kernel
   int blocks1() const { return has_rc ? (rc_tile ? rt_nblocks : rc_window ? rw_blocks() : rc_blocks()) + exc_blocks() : nblocks; }
   mgk::TileDev tiledev() const {
     mgk::TileDev t;
@@ -159,6 +159,11 @@ struct Csr {
     c.firstcol = rc_implicit ? nullptr : rc_first.p;
     c.cls_delta = rc_delta.p;
     c.cls_d = rc_d.p;
+    c.exc_rows = rc_exc.p;
+    c.nexc_inline = (rc_nexc > 0 && rc_nexc <= mgk::BLK) ? rc_nexc : 0;
+    c.rowptr = rowptr.p;
+    c.colidx = colidx.p;
+    c.val = val.p;
     c.cls = rc_cls.p;
     c.cls_ptr = rc_ptr.p;
     c.cls_off = rc_off.p;
@@ -379,26 +384,33 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
   const dim3 grid(M.nblocks), blk(mgk::BLK);
   if (v.nrhs == 1 && M.has_rc) {
     int nb_main;
+    const mgk::RowClassDev C = M.rcdev();
+    const bool exc = C.nexc_inline > 0;   // a short list of exception rows rides in the last workgroup
     if (M.rc_tile && v.y != v.x) {   // (the staged variants read x workgroup-wide: never in place)
       const size_t lds = (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * M.rt_halo) * sizeof(double);
       nb_main = M.rt_nblocks;
       static bool lds_attr_set[3] = {false, false, false};   // up to 80 KiB of dynamic LDS: lift the 64 KiB default once
       if (!lds_attr_set[MODE]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipGetLastError();
         lds_attr_set[MODE] = true;
       }
-      hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, M.rcdev(), v, M.tiledev());
+      if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, true>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, C, v, M.tiledev());
+      else hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, false>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, C, v, M.tiledev());
     } else if (M.rc_window && v.y != v.x) {
       nb_main = M.rw_blocks();
-      hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE>), dim3(nb_main), blk, (size_t)M.rw_doubles * sizeof(double),
-                         stream, M.rcdev(), v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
+      const size_t lds = (size_t)M.rw_doubles * sizeof(double);
+      if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, true>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
+      else hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, false>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
     } else {
       nb_main = M.rc_blocks();
-      hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE>), dim3(nb_main), blk, 0, stream, M.rcdev(), v);
+      if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, true>), dim3(nb_main), blk, 0, stream, C, v);
+      else hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, false>), dim3(nb_main), blk, 0, stream, C, v);
     }
-    if (M.rc_nexc > 0) {   // rows of rare classes, from the CSR arrays; their ||r||^2 partials follow the others
+    if (M.rc_nexc > mgk::BLK) {   // rows of rare classes, from the CSR arrays; their ||r||^2 partials follow the others
       mgk::VecArgs ve = v;
       ve.d = v.d_full;
       hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3(M.exc_blocks()), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, nb_main);
@@ -1460,11 +1472,15 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   std::sort(order.begin(), order.end(), [&](int x, int y) { return freq[(size_t)x] != freq[(size_t)y] ? freq[(size_t)x] > freq[(size_t)y] : x < y; });
   std::vector<int> remap(nraw, 0xFFFF), cptr(1, 0), coff, cdelta;
   std::vector<double> cval;
-  long long covered = 0;
+  long long covered = 0, nsingle = 0, keep_single = 1024;   // MG_ROWCLASS_KEEP_SINGLETONS: tests
+  if (const char* e = std::getenv("MG_ROWCLASS_KEEP_SINGLETONS")) keep_single = std::atoll(e);
+  for (size_t c = 0; c < nraw; ++c) nsingle += freq[c] == 1;
   for (size_t t = 0; t < nraw && cptr.size() - 1 < 65535; ++t) {
     const int c = order[t];
     const int ps = rptr[(size_t)c], len = rptr[(size_t)c + 1] - ps;
-    if (freq[(size_t)c] < 2 && nraw > 1) break;                 // singletons are never worth a dictionary slot
+    // a few singletons (the corners of a box) may as well live in the dictionary; a long tail of them (rows next
+    // to sub-domain faces) becomes exception rows
+    if (freq[(size_t)c] < 2 && nsingle > keep_single) break;
     if (coff.size() + (size_t)len > cap) break;
     remap[(size_t)c] = (int)cptr.size() - 1;
     coff.insert(coff.end(), roff.begin() + ps, roff.begin() + ps + len);
@@ -2484,13 +2500,14 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
 }
 
 int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which, long long* implicit_first,
-                               long long* class_relax, long long* kernel_variant) {
+                               long long* class_relax, long long* kernel_variant, long long* exception_rows) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   Csr* M = pick(h, level, which);
   if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
   if (implicit_first) *implicit_first = (M->has_rc && M->rc_implicit) ? 1 : 0;
   if (class_relax) *class_relax = (M->has_rc && M->rc_has_d) ? 1 : 0;
   if (kernel_variant) *kernel_variant = !M->has_rc ? -1 : M->rc_tile ? 2 : M->rc_window ? 1 : 0;
+  if (exception_rows) *exception_rows = M->has_rc ? M->rc_nexc : 0;
   return MG_OK;
 }
 

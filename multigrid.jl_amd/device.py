@@ -68,7 +68,7 @@ SIGNATURES = {
     "mg_profile_reset": (C.c_int, [_vp]),
     "mg_operator_format": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
     "mg_operator_rowclasses": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
-    "mg_operator_rowclass_flags": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _lp]),
+    "mg_operator_rowclass_flags": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _lp, _lp]),
     "mg_cycle_bytes": (C.c_int, [_vp, _dp]),
     "mg_device_bytes": (C.c_int, [_vp, _dp]),
     "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
@@ -433,17 +433,21 @@ class DeviceHierarchy:
 
     def operator_rowclass_flags(self, level: int, which: int):
         """(implicit first column, relaxPrec read from the class dictionary) of a row-class operator."""
-        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
-        _check(self.lib, self.lib.mg_operator_rowclass_flags(self.handle, level, which, C.byref(a), C.byref(b), C.byref(c)),
-               "mg_operator_rowclass_flags")
+        a, b, c, e = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        _check(self.lib, self.lib.mg_operator_rowclass_flags(self.handle, level, which, C.byref(a), C.byref(b), C.byref(c),
+                                                             C.byref(e)), "mg_operator_rowclass_flags")
         return bool(a.value), bool(b.value)
 
     def operator_kernel_variant(self, level: int, which: int) -> int:
         """-1 streaming formats, 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv, 2 csr_rowclass_tile_spmv."""
-        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
-        _check(self.lib, self.lib.mg_operator_rowclass_flags(self.handle, level, which, C.byref(a), C.byref(b), C.byref(c)),
-               "mg_operator_rowclass_flags")
-        return int(c.value)
+        return self.operator_kernel_info(level, which)[0]
+
+    def operator_kernel_info(self, level: int, which: int):
+        """(kernel variant as above, number of exception rows)."""
+        a, b, c, e = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        _check(self.lib, self.lib.mg_operator_rowclass_flags(self.handle, level, which, C.byref(a), C.byref(b), C.byref(c),
+                                                             C.byref(e)), "mg_operator_rowclass_flags")
+        return int(c.value), int(e.value)
 
     def cycle_bytes(self) -> float:
         v = C.c_double(0)

@@ -192,6 +192,7 @@ def test_hip_distributed_rowclass_with_exception_rows(built, world, monkeypatch)
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.2")
+    monkeypatch.setenv("MG_ROWCLASS_KEEP_SINGLETONS", "0")
     _run(world, "gmg3d", 1, "V", use_hip=True)
 
 

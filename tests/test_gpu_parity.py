@@ -484,7 +484,8 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_rowclass_exception_rows(mg, built, monkeypatch):
+@pytest.mark.parametrize("n_odd", [0, 6])          # 0: 3 % of the rows (own launch); 6: handled inside the main kernel
+def test_rowclass_exception_rows(mg, built, monkeypatch, n_odd):
     """A mostly regular operator: 3 % of the rows of a Poisson matrix get unique values, a few more get an extra
     entry.  The popular classes stay in the dictionary, the odd rows become exception rows computed from the CSR
     arrays (csr_rows_spmv); every fused epilogue and the fused ||r||^2 must match scipy."""
@@ -493,11 +494,12 @@ def test_rowclass_exception_rows(mg, built, monkeypatch):
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_KEEP_SINGLETONS", "0")    # unique rows become exception rows, not dictionary classes
     rng = np.random.default_rng(23)
     A, mesh = mg.poisson_shifted([24, 20, 18])
     A = A.tolil()
     n = A.shape[0]
-    odd = rng.choice(n, size=n // 33, replace=False)
+    odd = rng.choice(n, size=(n_odd or n // 33), replace=False)
     for i in odd[: len(odd) // 2]:
         A[i, i] = A[i, i] * (1.0 + rng.random())               # unique values
     for i in odd[len(odd) // 2:]:
@@ -528,6 +530,8 @@ def test_rowclass_exception_rows(mg, built, monkeypatch):
     bb = mg.seeded_rhs(A, 1)
     _compare_solve(mg, p, bb)
     assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] > 0
+    nexc = p.device.operator_kernel_info(1, D.MG_OP_A)[1]
+    assert (0 < nexc <= 256) if n_odd else nexc > 256          # in-kernel handling / own launch
     mg.clear_(p)
 
 
