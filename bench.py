@@ -388,7 +388,10 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
             "setup_s": {"sharded_setup_incl_upload": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "kernel": "sharded levels of one V-cycle, per GPU (max over ranks)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None},
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "ALGORITHMIC (CSR-priced) bytes of the rank's sharded levels / step time; the local "
+                                 "operators of this constant-coefficient workload are stored as row classes (no matrix "
+                                 "stream), so this is not a bandwidth figure - see the N=1 line's `streamed_*` fields"},
             "cpu_baseline": None,
         }
         print(json.dumps(out), flush=True)
