@@ -447,8 +447,10 @@ __device__ __forceinline__ double rowclass_exception_rows(const RowClassDev& C, 
   return outv * outv;
 }
 
+// rows per lane of the plain row-class kernel: 1 measured best once the staged variants serve the square operators
+// (profiles/r01_nt_ab.md: transfer operators -4 %, sharded path -2 %)
 #ifndef MG_RC_RPT
-#define MG_RC_RPT 2
+#define MG_RC_RPT 1
 #endif
 constexpr int RC_RPT = MG_RC_RPT;       // rows per lane: RC_RPT independent gather chains in flight
 constexpr int RC_ROWS = BLK * RC_RPT;   // rows per workgroup (lane t holds rows t, t + BLK, ...)
