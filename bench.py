@@ -282,7 +282,7 @@ def main():
         cores = c_oracle.max_threads()
         co = c_oracle.COracle(p, nrhs)
         xc = np.zeros_like(b_host)
-        ncyc = args.cpu_cycles or (2 if cells >= 200 else 10)
+        ncyc = args.cpu_cycles or (12 if cells >= 200 else 50)   # about 10 s of host work (128 threads)
         if nrhs > 1:
             ncyc = args.cpu_cycles or 1
         co.solveMG(b_host, xc, 0.0, 1, cores)          # warm-up cycle
