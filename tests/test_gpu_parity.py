@@ -597,3 +597,22 @@ def test_gmres_coarse_solve(mg, built, cyc, cells, levels):
     with pytest.raises(mg.device.MGDeviceError):
         mg.solveMG(p, b2, np.zeros_like(b2))
     mg.clear_(p)
+
+
+@pytest.mark.gpu
+def test_wrong_grid_hint_changes_nothing(mg, built, monkeypatch):
+    """The grid hint only selects a row partition and what is staged in LDS: with a hint that multiplies out to the
+    row count but describes the wrong grid (dimensions permuted), entries whose shift is not in the staged set gather
+    from global memory and the solve is still the oracle's."""
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    A, p, b = _setup(mg, [40, 30, 5], 2)                    # nodes 41 x 31 x 6
+    h = mg.to_device(p)
+    assert h.operator_kernel_variant(1, D.MG_OP_A) == 2     # plane tiles with the true hint
+    for wrong in ((6, 31, 41), (31, 41, 6), (41 * 31, 3, 2)):
+        rc = h.lib.mg_set_grid_hint(h.handle, 1, *wrong)
+        assert rc == 0
+        assert h.lib.mg_finalize(h.handle) == 0
+        _compare_solve(mg, p, b)
+    mg.clear_(p)
