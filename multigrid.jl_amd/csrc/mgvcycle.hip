@@ -1211,6 +1211,13 @@ int build_tile(Csr& A, const long long grid[3]) {
   A.rt_halo = (int)halo;
   A.rt_chunks = (int)((P + mgk::RT_CR - 1) / mgk::RT_CR);
   A.rt_nblocks = (int)(((grid[2] + mgk::RT_NP - 1) / mgk::RT_NP) * A.rt_chunks);
+  {
+    // 4096 rows per workgroup: a level that yields fewer workgroups than the chip has CUs is latency-bound and runs
+    // faster on the 256/512-row kernels (C2 level 3, 65^3 rows: 85 workgroups, 26 us against 17 us)
+    long long min_wg = 256;
+    if (const char* e = std::getenv("MG_TILE_MIN_WG")) min_wg = std::atoll(e);
+    if (A.rt_nblocks < min_wg) return MG_OK;
+  }
   A.rc_tile = true;
   return MG_OK;
 }
@@ -1566,7 +1573,11 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     // -25 % on the 27-point levels, -5 % on the 7-point one with the spill-free tile kernel)
     long long min_len = 1;
     if (const char* ml = std::getenv("MG_STAGE_MIN_LEN")) min_len = std::atoll(ml);
-    bool ok = !(e && e[0] == '1') && len >= min_len && len <= mgk::RW_MAXLEN && 2 * cnt[cm] >= n;
+    // small levels are latency-bound and faster on the plain kernel (C2 level 3, 65^3 rows: 15 us against 23 us)
+    long long min_wg = 2048;
+    if (const char* mw = std::getenv("MG_WINDOW_MIN_WG")) min_wg = std::atoll(mw);
+    bool ok = !(e && e[0] == '1') && len >= min_len && len <= mgk::RW_MAXLEN && 2 * cnt[cm] >= n &&
+              (n + mgk::RW_ROWS - 1) / mgk::RW_ROWS >= min_wg;
     if (ok) {
       const long long W = mgk::RW_ROWS;
       std::vector<int> meta(mgk::RW_META_HDR, 0), ivs;

@@ -385,6 +385,8 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_STAGE_MIN_LEN", "0")          # LDS-staged variants also on the 7-point level
+    monkeypatch.setenv("MG_TILE_MIN_WG", "0")            # ... and on levels with few workgroups
+    monkeypatch.setenv("MG_WINDOW_MIN_WG", "0")
     rng = np.random.default_rng(17)
     A, _ = mg.poisson_shifted([14, 12, 10])
     Arand = A.copy()
@@ -495,6 +497,8 @@ def test_rowclass_exception_rows(mg, built, monkeypatch, n_odd):
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_KEEP_SINGLETONS", "0")    # unique rows become exception rows, not dictionary classes
+    monkeypatch.setenv("MG_WINDOW_MIN_WG", "0")
+    monkeypatch.setenv("MG_TILE_MIN_WG", "0")
     rng = np.random.default_rng(23)
     A, mesh = mg.poisson_shifted([24, 20, 18])
     A = A.tolil()
@@ -548,6 +552,8 @@ def test_rowclass_variants_on_odd_grids(mg, built, cells, levels, monkeypatch):
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    monkeypatch.setenv("MG_TILE_MIN_WG", "0")
+    monkeypatch.setenv("MG_WINDOW_MIN_WG", "0")
     rng = np.random.default_rng(sum(cells))
     seen = set()
     for no_tile, no_win, no_first in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
@@ -607,6 +613,7 @@ def test_wrong_grid_hint_changes_nothing(mg, built, monkeypatch):
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_TILE_MIN_WG", "0")
     A, p, b = _setup(mg, [40, 30, 5], 2)                    # nodes 41 x 31 x 6
     h = mg.to_device(p)
     assert h.operator_kernel_variant(1, D.MG_OP_A) == 2     # plane tiles with the true hint
