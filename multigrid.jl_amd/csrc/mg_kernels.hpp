@@ -79,6 +79,8 @@ struct VecArgs {
   const double* b;  // RESID / SMOOTH            [n_rows][nrhs]
   const double* d;  // SMOOTH: relaxPrec          [n_rows]; nullptr in the row-class kernels = read it from the class dictionary
   const double* d_full;  // SMOOTH: always the relaxPrec vector (exception rows of a row-class operator)
+  double* y2;       // RESID, csr_rowclass_tile_spmv only: optional second output x + d.*(b - A x), i.e. the first
+                    // damped-Jacobi update of the NEXT cycle, written while r and x are at hand (solve loop)
   double alpha;     // AXPBY
   double beta;      // AXPBY
   int nrhs;
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
       if (v.beta != 0.0) pb[j] = v.beta * v.y[rr];
     } else {
       pb[j] = v.b[rr];
-      if (MODE == SMOOTH && v.d) pd[j] = v.d[rr];
+      if ((MODE == SMOOTH || (MODE == RESID && v.y2)) && v.d) pd[j] = v.d[rr];
     }
   }
   // stage slabs q = 0 .. RT_NP+1 <-> planes pl0-1 .. pl0+RT_NP, rows [c*RT_CR - halo, c*RT_CR + RT_CR + halo)
@@ -814,7 +816,8 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
     const int delta = C.cls_delta[cc];
     lead += delta;
     double dcc = 0.0;
-    if (MODE == SMOOTH && !v.d) dcc = C.cls_d[cc];
+    const bool class_d = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
+    if (class_d) dcc = C.cls_d[cc];
     bool in[RT_NP];
     double a[RT_NP];
 #pragma unroll
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
       const unsigned long long m = __ballot(cls[j] == cc) & todo[j];
       todo[j] &= ~m;
       in[j] = (m & lanebit) != 0;
-      if (MODE == SMOOTH && !v.d && in[j]) pd[j] = dcc;
+      if (class_d && in[j]) pd[j] = dcc;
       a[j] = 0.0;
     }
     const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
@@ -850,6 +853,7 @@ __global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C
       if (MODE == SMOOTH) pxj = (v.xs == v.x) ? win[(j + 1) * SL + T.halo + tid] : v.xs[row[j]];
       const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], pxj);
       v.y[row[j]] = outv;
+      if (MODE == RESID && v.y2) v.y2[row[j]] = win[(j + 1) * SL + T.halo + tid] + pd[j] * outv;   // x + d.*r
       sq += outv * outv;
     }
   }

@@ -459,7 +459,11 @@ int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const 
 }
 int k_sumsq(mg_hierarchy* h, const double* x, long long len);
 // out = b - A*x and h->scalar = ||out||^2 in the same pass (nrhs == 1); falls back to two kernels for blocks
-int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x, double* out) {
+// xnext (optional): also write x + d.*(b - A x), the first damped-Jacobi update of the next cycle, when the kernel
+// that serves A can do it (plane-tile row-class kernel, level's own relaxPrec); *xnext_done reports whether it was.
+int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x, double* out,
+                     double* xnext = nullptr, bool* xnext_done = nullptr) {
+  if (xnext_done) *xnext_done = false;
   const int nb1 = A.blocks1();
   if (h->nrhs != 1 || (size_t)nb1 > h->partial.n) {
     MG_TRY(k_residual(h, level, A, b, x, out));
@@ -471,8 +475,16 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
   v.b = b;
   v.nrhs = 1;
   v.sumsq = h->partial.p;
+  if (xnext && A.has_rc && A.rc_tile && A.rc_nexc == 0 && out != x && xnext != x && h->relax_type == 0 &&
+      &A == &h->lev[(size_t)level].A && !std::getenv("MG_NO_FUSED_NEXT")) {
+    v.y2 = xnext;
+    v.xs = x;
+    v.d = A.rc_has_d ? nullptr : h->lev[(size_t)level].d.p;
+    v.d_full = h->lev[(size_t)level].d.p;
+    if (xnext_done) *xnext_done = true;
+  }
   {
-    ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false));
+    ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false) + (v.y2 ? 8.0 * (double)A.n_rows : 0.0));
     MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v));
   }
   ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1);
@@ -699,8 +711,10 @@ int fgmres_relax(mg_hierarchy* h, int lv, const double* r0, double* x0, long lon
 // l is 0-based.  xa holds the incoming x when !x_zero; xb is the Jacobi ping-pong partner.
 // r_valid: L.r already holds b - A*x for the incoming x (solveMG computed it for its stopping test,
 // SolveFuncs.jl:26-30, and recursiveCycle would recompute the same values, MGcycle.jl:26-31).
+// x1_ready (with r_valid): xb already holds xa + d.*r, the first pre-smoothing update (written by the residual kernel
+// of the previous solve step, k_residual_sumsq's xnext).
 int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero,
-                char ctype, double** result, bool r_valid = false) {
+                char ctype, double** result, bool r_valid = false, bool x1_ready = false) {
   const int nl = (int)h->nlevels;
   if (l == nl - 1) {  // solveCoarsest (MGcycle.jl:13-18,67-69,177): x = LU \ b
     MG_TRY(k_coarse(h, l, b, xa));
@@ -732,7 +746,7 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
     --npre;
   } else if (r_valid) {
-    MG_TRY(k_xpdr(h, l, cur, L.d.p, L.r.p, alt, L.n));
+    if (!x1_ready) MG_TRY(k_xpdr(h, l, cur, L.d.p, L.r.p, alt, L.n));
     std::swap(cur, alt);
     --npre;
   }
@@ -833,13 +847,16 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
   double* alt = L.x1.p;
   const bool dbg = std::getenv("MG_DEBUG_TIMING") != nullptr;
   auto tprev = std::chrono::steady_clock::now();
+  bool x1_ready = false;
   for (long long count = 1; count <= maxIter; ++count) {
     double* out = nullptr;
     // from the second step on, L.r = b - A*x is the residual just computed for the stopping test
-    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero));
+    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero, x1_ready));
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
-    MG_TRY(k_residual_sumsq(h, 0, L.A, b, cur, L.r.p));  // SolveFuncs.jl:26-30: r = b - A x and ||r|| in one pass
+    // SolveFuncs.jl:26-30: r = b - A x and ||r|| in one pass; where the kernel allows, the same pass also writes
+    // alt = x + d.*r, the first pre-smoothing update of the next cycle (unused if this was the last step)
+    MG_TRY(k_residual_sumsq(h, 0, L.A, b, cur, L.r.p, count < maxIter ? alt : nullptr, &x1_ready));
     MG_TRY(scalar_sync(h, &res));
     ++it;
     if (dbg) {
