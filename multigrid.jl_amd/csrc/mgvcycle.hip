@@ -1483,6 +1483,9 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
       cand.push_back(found);
     }
     rid[(size_t)i] = found;
+    // early exit for operators that are irregular from the start (SA-AMG levels: 2.5 G non-zeros in C3's hierarchy
+    // would otherwise be hashed up to the caps above): more than half of the first 8192 rows distinct
+    if (i == 8191 && rptr.size() - 1 > 4096) return MG_OK;
   }
   table.clear();
   // Phase 2: keep the most frequent classes that fit the id width and the dictionary cap; rows of any other class
