@@ -745,8 +745,14 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_window_spmv(RowClassDev C, V
 // tile_lb), anything else gathers from global memory, so correctness never depends on the hint being "true": it is
 // a row partition plus a cache.  Products and summation order are unchanged.
 // ------------------------------------------------------------------------------------------------
-constexpr int RT_NP = 4;        // planes per workgroup = rows per lane
-constexpr int RT_CR = 1024;     // rows of a plane per workgroup = threads per workgroup
+#ifndef MG_RT_CR
+#define MG_RT_CR 1024
+#endif
+#ifndef MG_RT_NP
+#define MG_RT_NP 4
+#endif
+constexpr int RT_NP = MG_RT_NP;   // planes per workgroup = rows per lane
+constexpr int RT_CR = MG_RT_CR;   // rows of a plane per workgroup = threads per workgroup
 
 struct TileDev {
   const int* tile_lb;   // per dictionary entry: LDS index of (slot 0, lane 0) or -1
@@ -759,7 +765,7 @@ struct TileDev {
 };
 
 template <int MODE, bool EXC>
-__global__ __launch_bounds__(RT_CR, 8) void csr_rowclass_tile_spmv(RowClassDev C, VecArgs v, TileDev T) {
+__global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_tile_spmv(RowClassDev C, VecArgs v, TileDev T) {
   extern __shared__ double win[];
   __shared__ double red[RT_CR / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
