@@ -1,0 +1,55 @@
+"""Randomised stress of the row-class kernel variants against scipy (run on a GPU box).
+usage: stress_rowclass.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+os.environ.update(MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.05",
+                  MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_STAGE_MIN_LEN="0")
+import multigrid_jl_amd as mg
+from multigrid_jl_amd import device as D
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = 0.0
+for case in range(ncases):
+    dim = int(rng.choice([2, 3]))
+    cells = [int(rng.integers(3, 90)) for _ in range(dim)] if dim == 2 else \
+            [int(rng.integers(3, 70)), int(rng.integers(3, 40)), int(rng.integers(2, 14))]
+    levels = int(rng.integers(2, 4))
+    env = dict(MG_NO_TILE=str(int(rng.integers(0, 2))), MG_NO_WINDOW=str(int(rng.integers(0, 2))),
+               MG_NO_IMPLICIT_FIRST=str(int(rng.integers(0, 2))), MG_NO_CLASS_D=str(int(rng.integers(0, 2))),
+               MG_ROWCLASS_KEEP_SINGLETONS=str(int(rng.choice([0, 1024]))))
+    os.environ.update(env)
+    relax = str(rng.choice(["Jac", "SPAI"]))
+    A, mesh = mg.poisson_shifted(cells)
+    p = mg.getMGparam(np.float64, np.int64, levels, 8, 4, 1e-10, relax, 0.8 if relax == "Jac" else 1.0, 2, 1)
+    mg.MGsetup(A, mesh, p, 1)
+    h = mg.to_device(p)
+    for l in range(1, p.levels):
+        Al, Pl, Rl, dl = p.As[l - 1], p.Ps[l - 1], p.Rs[l - 1], p.relaxPrecs[l - 1]
+        xn, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+        x, bb = torch.from_numpy(xn).cuda(), torch.from_numpy(bn).cuda()
+        out = torch.zeros_like(x)
+        h.fused_dev(l, D.MG_K_RESIDUAL, bb, x, out)
+        w = bn - Al @ xn
+        e1 = np.abs(out.cpu().numpy() - w).max() / np.abs(w).max()
+        h.fused_dev(l, D.MG_K_SMOOTH, bb, x, out)
+        w = xn + dl * (bn - Al @ xn)
+        e2 = np.abs(out.cpu().numpy() - w).max() / np.abs(w).max()
+        xc = rng.standard_normal(Pl.shape[1])
+        e3 = np.abs(mg.SpMatMul(p, l, "P", xc, xn.copy(), 1.0, 1.0) - (xn + Pl @ xc)).max()
+        e4 = np.abs(mg.SpMatMul(p, l, "R", xn, np.zeros(Rl.shape[0]), 1.0, 0.0) - Rl @ xn).max() / np.abs(Rl @ xn).max()
+        worst = max(worst, e1, e2, e3, e4)
+        if max(e1, e2, e3, e4) > 1e-12:
+            print("FAIL", cells, levels, env, l, e1, e2, e3, e4, flush=True)
+            sys.exit(1)
+    b = mg.seeded_rhs(A, 1)
+    xs = np.zeros_like(b)
+    mg.solveMG(p, b, xs)
+    rr = np.linalg.norm(A @ xs - b) / np.linalg.norm(b)
+    if not np.isfinite(rr) or abs(rr - p.resvec[-1] / 1.0) > 1e-9 * max(1.0, p.resvec[0]):
+        print("FAIL solve", cells, levels, env, rr, p.resvec[-1], flush=True)
+        sys.exit(1)
+    mg.clear_(p)
+print(f"{ncases} cases ok, worst kernel error {worst:.2e}")
