@@ -457,17 +457,22 @@ __device__ __forceinline__ double rowclass_exception_rows(const RowClassDev& C, 
 constexpr int RC_RPT = MG_RC_RPT;       // rows per lane: RC_RPT independent gather chains in flight
 constexpr int RC_ROWS = BLK * RC_RPT;   // rows per workgroup (lane t holds rows t, t + BLK, ...)
 
-template <int MODE, bool EXC>
+// PAIR = false: lane t holds row t of its workgroup's 256 (RPT = 1).  PAIR = true: lane t holds rows 2t and 2t+1 of
+// 512 - for operators whose classes alternate from row to row (a prolongation: even / odd fine nodes) each class then
+// fills a whole waterfall pass instead of half the lanes of two (chosen per operator by the host, build_rowclasses).
+template <int MODE, bool EXC, bool PAIR>
 __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs v) {
+  constexpr int RPT = PAIR ? 2 : RC_RPT;
+  constexpr int RSTRIDE = PAIR ? 1 : BLK;
   __shared__ double red[BLK / 64];
   const int tid = threadIdx.x;
   const int bid = xcd_band(blockIdx.x, C.nblocks);
-  const int base = bid * RC_ROWS + tid;
-  int first[RC_RPT], cls[RC_RPT];
-  double pb[RC_RPT], pd[RC_RPT], px[RC_RPT], acc[RC_RPT];
+  const int base = PAIR ? bid * (BLK * 2) + 2 * tid : bid * RC_ROWS + tid;
+  int first[RPT], cls[RPT];
+  double pb[RPT], pd[RPT], px[RPT], acc[RPT];
 #pragma unroll
-  for (int j = 0; j < RC_RPT; ++j) {
-    const int row = base + j * BLK;
+  for (int j = 0; j < RPT; ++j) {
+    const int row = base + j * RSTRIDE;
     const int rr = row < C.n_rows ? row : C.n_rows - 1;   // dead lanes repeat the last row (never stored)
     first[j] = C.firstcol ? C.firstcol[rr] : rr;            // implicit form: the class delta is added in its pass
     cls[j] = C.cls[rr];
@@ -490,14 +495,14 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
   // from ballot masks, not from `cls == cc`: the compiler would otherwise substitute the per-lane value for the
   // uniform cc inside the branch and fall back to per-lane (vector) dictionary loads.
   const unsigned long long lanebit = 1ull << (tid & 63);
-  unsigned long long todo[RC_RPT];
+  unsigned long long todo[RPT];
 #pragma unroll
-  for (int j = 0; j < RC_RPT; ++j) todo[j] = __ballot(cls[j] != 0xFFFF);   // 0xFFFF: exception row (csr_rows_spmv)
+  for (int j = 0; j < RPT; ++j) todo[j] = __ballot(cls[j] != 0xFFFF);   // 0xFFFF: exception row (csr_rows_spmv)
   for (;;) {
     int cc = 0, lead = 0;
     bool any = false;
 #pragma unroll
-    for (int j = RC_RPT - 1; j >= 0; --j)
+    for (int j = RPT - 1; j >= 0; --j)
       if (todo[j]) {   // wave-uniform
         const int l = __builtin_ctzll(todo[j]);
         cc = __builtin_amdgcn_readlane(cls[j], l);
@@ -509,11 +514,11 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
     lead += delta;
     double dcc = 0.0;
     if (MODE == SMOOTH && !v.d) dcc = C.cls_d[cc];
-    bool in[RC_RPT];
-    const double* xb[RC_RPT];
-    double a[RC_RPT];
+    bool in[RPT];
+    const double* xb[RPT];
+    double a[RPT];
 #pragma unroll
-    for (int j = 0; j < RC_RPT; ++j) {
+    for (int j = 0; j < RPT; ++j) {
       const unsigned long long m = __ballot(cls[j] == cc) & todo[j];
       todo[j] &= ~m;
       in[j] = (m & lanebit) != 0;
@@ -534,16 +539,16 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
       const int o0 = C.cls_off[k], o1 = C.cls_off[k + 1], o2 = C.cls_off[k + 2], o3 = C.cls_off[k + 3];
 #endif
       const double a0 = C.cls_val[k], a1 = C.cls_val[k + 1], a2 = C.cls_val[k + 2], a3 = C.cls_val[k + 3];
-      double x0[RC_RPT], x1[RC_RPT], x2[RC_RPT], x3[RC_RPT];
+      double x0[RPT], x1[RPT], x2[RPT], x3[RPT];
 #pragma unroll
-      for (int j = 0; j < RC_RPT; ++j) {
+      for (int j = 0; j < RPT; ++j) {
         x0[j] = xb[j][o0];
         x1[j] = xb[j][o1];
         x2[j] = xb[j][o2];
         x3[j] = xb[j][o3];
       }
 #pragma unroll
-      for (int j = 0; j < RC_RPT; ++j) {
+      for (int j = 0; j < RPT; ++j) {
         a[j] += a0 * x0[j];
         a[j] += a1 * x1[j];
         a[j] += a2 * x2[j];
@@ -558,16 +563,16 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
 #endif
       const double a0 = C.cls_val[k];
 #pragma unroll
-      for (int j = 0; j < RC_RPT; ++j) a[j] += a0 * xb[j][o0];
+      for (int j = 0; j < RPT; ++j) a[j] += a0 * xb[j][o0];
     }
 #pragma unroll
-    for (int j = 0; j < RC_RPT; ++j)
+    for (int j = 0; j < RPT; ++j)
       if (in[j]) acc[j] = a[j];
   }
   double sq = 0.0;
 #pragma unroll
-  for (int j = 0; j < RC_RPT; ++j) {
-    const int row = base + j * BLK;
+  for (int j = 0; j < RPT; ++j) {
+    const int row = base + j * RSTRIDE;
     if (row < C.n_rows && cls[j] != 0xFFFF) {
       const double outv = epilogue<MODE>(v, row, acc[j], pb[j], pd[j], px[j]);
       v.y[row] = outv;

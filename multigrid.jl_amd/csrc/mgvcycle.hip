@@ -138,7 +138,11 @@ struct Csr {
     d.nblocks = nblocks_mm;
     return d;
   }
-  int rc_blocks() const { return (int)((n_rows + mgk::RC_ROWS - 1) / mgk::RC_ROWS); }
+  bool rc_pair = false;     // plain row-class kernel with two consecutive rows per lane (alternating classes)
+  int rc_blocks() const {
+    const long long rows = rc_pair ? 2 * mgk::BLK : mgk::RC_ROWS;
+    return (int)((n_rows + rows - 1) / rows);
+  }
   // workgroups of the nrhs == 1 product (one fused ||r||^2 partial each)
   int rw_blocks() const { return (int)((n_rows + mgk::RW_ROWS - 1) / mgk::RW_ROWS); }
   int exc_blocks() const { return rc_nexc > mgk::BLK ? (rc_nexc + mgk::BLK - 1) / mgk::BLK : 0; }   // short lists: in-kernel
@@ -195,6 +199,7 @@ struct Csr {
     rc_implicit = false;
     rc_has_d = false;
     rc_window = false;
+    rc_pair = false;
     rc_ncls = rc_entries = 0;
   }
   mgk::PatDev patdev() const {
@@ -407,8 +412,13 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
       else hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, false>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
     } else {
       nb_main = M.rc_blocks();
-      if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, true>), dim3(nb_main), blk, 0, stream, C, v);
-      else hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, false>), dim3(nb_main), blk, 0, stream, C, v);
+      if (M.rc_pair) {
+        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, true, true>), dim3(nb_main), blk, 0, stream, C, v);
+        else hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, false, true>), dim3(nb_main), blk, 0, stream, C, v);
+      } else {
+        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, true, false>), dim3(nb_main), blk, 0, stream, C, v);
+        else hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, false, false>), dim3(nb_main), blk, 0, stream, C, v);
+      }
     }
     if (M.rc_nexc > mgk::BLK) {   // rows of rare classes, from the CSR arrays; their ||r||^2 partials follow the others
       mgk::VecArgs ve = v;
@@ -1432,6 +1442,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   M->drop_rc();
   const long long n = M->n_rows;
   if (n < 1 || M->nnz < 1) return MG_OK;
+  bool pair_choice = false;
   const size_t cap = (size_t)std::min<long long>(1LL << 18, std::max<long long>(64, M->nnz / 16));
   // Phase 1: classify every row (raw classes, unbounded ids).  Mostly regular operators - a grid operator whose
   // rows were renumbered near sub-domain faces, irregular boundaries - have a few popular classes and a tail of
@@ -1555,6 +1566,27 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
       ++waves;
     }
     if (passes > max_passes * waves) return MG_OK;
+    // two consecutive rows per lane when that roughly halves the passes (classes alternating row by row)
+    long long passes2 = 0;
+    for (long long w0 = 0; w0 < n; w0 += 128) {
+      unsigned short seen[128];
+      int ns = 0;
+      const long long w1 = std::min(n, w0 + 128);
+      for (long long i = w0; i < w1; ++i) {
+        if (cid[(size_t)i] == 0xFFFF) continue;
+        bool dup = false;
+        for (int t = 0; t < ns; ++t)
+          if (seen[t] == cid[(size_t)i]) { dup = true; break; }
+        if (!dup) seen[ns++] = cid[(size_t)i];
+      }
+      passes2 += ns;
+    }
+    const char* np = std::getenv("MG_NO_PAIR");
+    // (only where a wave really holds alternating classes: uniform operators measured slower this way, R1 70 -> 84 us)
+    // and only on large operators - C2's level 3 (65^3 rows, 4 classes per wave) ran 30 % slower paired
+    long long pair_min = 1000000;
+    if (const char* pm = std::getenv("MG_PAIR_MIN_ROWS")) pair_min = std::atoll(pm);
+    pair_choice = !(np && np[0] == '1') && n >= pair_min && 2 * passes >= 3 * waves && 10 * passes2 <= 7 * passes;
   }
   if (cdelta.empty()) cdelta.push_back(0);
   if (!implicit) MG_TRY(M->rc_first.alloc(first.size()));
@@ -1578,6 +1610,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   }
   M->has_rc = true;
   M->rc_implicit = implicit;
+  M->rc_pair = pair_choice;
   M->h_rc_ptr = cptr;
   M->h_rc_off = coff;
   M->h_rc_delta = cdelta;
@@ -1775,8 +1808,9 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
   if (const char* e = std::getenv("MG_DEBUG_FORMAT"))
     if (e[0] == '1')
       std::fprintf(stderr, "[mgvcycle] operator %lld x %lld, nnz %lld: row classes %lld (dictionary %lld, exception rows %d, "
-                   "implicit first %d, window %d), patterns %lld\n", M->n_rows, M->n_cols, M->nnz, M->has_rc ? M->rc_ncls : 0,
-                   M->has_rc ? M->rc_entries : 0, M->rc_nexc, (int)M->rc_implicit, (int)M->rc_window, M->has_pat ? M->npat : 0);
+                   "implicit first %d, window %d, paired rows %d), patterns %lld\n", M->n_rows, M->n_cols, M->nnz, M->has_rc ? M->rc_ncls : 0,
+                   M->has_rc ? M->rc_entries : 0, M->rc_nexc, (int)M->rc_implicit, (int)M->rc_window, (int)M->rc_pair,
+                   M->has_pat ? M->npat : 0);
   return MG_OK;
 }
 

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 os.environ.update(MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.05",
-                  MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_STAGE_MIN_LEN="0")
+                  MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_STAGE_MIN_LEN="0", MG_PAIR_MIN_ROWS="0")
 import multigrid_jl_amd as mg
 from multigrid_jl_amd import device as D
 
@@ -19,7 +19,7 @@ for case in range(ncases):
     levels = int(rng.integers(2, 4))
     env = dict(MG_NO_TILE=str(int(rng.integers(0, 2))), MG_NO_WINDOW=str(int(rng.integers(0, 2))),
                MG_NO_IMPLICIT_FIRST=str(int(rng.integers(0, 2))), MG_NO_CLASS_D=str(int(rng.integers(0, 2))),
-               MG_ROWCLASS_KEEP_SINGLETONS=str(int(rng.choice([0, 1024]))))
+               MG_ROWCLASS_KEEP_SINGLETONS=str(int(rng.choice([0, 1024]))), MG_NO_PAIR=str(int(rng.integers(0, 2))))
     os.environ.update(env)
     relax = str(rng.choice(["Jac", "SPAI"]))
     A, mesh = mg.poisson_shifted(cells)

@@ -554,6 +554,7 @@ def test_rowclass_variants_on_odd_grids(mg, built, cells, levels, monkeypatch):
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_TILE_MIN_WG", "0")
     monkeypatch.setenv("MG_WINDOW_MIN_WG", "0")
+    monkeypatch.setenv("MG_PAIR_MIN_ROWS", "0")          # paired-rows variant of the plain kernel for P (alternating classes)
     rng = np.random.default_rng(sum(cells))
     seen = set()
     for no_tile, no_win, no_first in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
