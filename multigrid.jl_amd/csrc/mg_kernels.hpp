@@ -863,7 +863,7 @@ __global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_til
       double pxj = 0.0;
       if (MODE == SMOOTH) pxj = (v.xs == v.x) ? win[(j + 1) * SL + T.halo + tid] : v.xs[row[j]];
       const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], pxj);
-      v.y[row[j]] = outv;
+      if (MODE != RESID || v.y) v.y[row[j]] = outv;   // (the solve loop needs only ||r|| and x + d.*r: y may be null)
       if (MODE == RESID && v.y2) v.y2[row[j]] = win[(j + 1) * SL + T.halo + tid] + pd[j] * outv;   // x + d.*r
       sq += outv * outv;
     }

@@ -471,8 +471,10 @@ int k_sumsq(mg_hierarchy* h, const double* x, long long len);
 // out = b - A*x and h->scalar = ||out||^2 in the same pass (nrhs == 1); falls back to two kernels for blocks
 // xnext (optional): also write x + d.*(b - A x), the first damped-Jacobi update of the next cycle, when the kernel
 // that serves A can do it (plane-tile row-class kernel, level's own relaxPrec); *xnext_done reports whether it was.
+// r_dead: the caller will not read `out` when xnext was written (the solve loop: the next cycle starts from xnext and
+// recomputes its own residual), so the store of r is skipped as well.
 int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x, double* out,
-                     double* xnext = nullptr, bool* xnext_done = nullptr) {
+                     double* xnext = nullptr, bool* xnext_done = nullptr, bool r_dead = false) {
   if (xnext_done) *xnext_done = false;
   const int nb1 = A.blocks1();
   if (h->nrhs != 1 || (size_t)nb1 > h->partial.n) {
@@ -488,13 +490,14 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
   if (xnext && A.has_rc && A.rc_tile && A.rc_nexc == 0 && out != x && xnext != x && h->relax_type == 0 &&
       &A == &h->lev[(size_t)level].A && !std::getenv("MG_NO_FUSED_NEXT")) {
     v.y2 = xnext;
+    if (r_dead) v.y = nullptr;
     v.xs = x;
     v.d = A.rc_has_d ? nullptr : h->lev[(size_t)level].d.p;
     v.d_full = h->lev[(size_t)level].d.p;
     if (xnext_done) *xnext_done = true;
   }
   {
-    ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false) + (v.y2 ? 8.0 * (double)A.n_rows : 0.0));
+    ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false) + ((v.y2 && v.y) ? 8.0 * (double)A.n_rows : 0.0));
     MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v));
   }
   ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1);
@@ -866,7 +869,7 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
     x_zero = false;
     // SolveFuncs.jl:26-30: r = b - A x and ||r|| in one pass; where the kernel allows, the same pass also writes
     // alt = x + d.*r, the first pre-smoothing update of the next cycle (unused if this was the last step)
-    MG_TRY(k_residual_sumsq(h, 0, L.A, b, cur, L.r.p, count < maxIter ? alt : nullptr, &x1_ready));
+    MG_TRY(k_residual_sumsq(h, 0, L.A, b, cur, L.r.p, count < maxIter ? alt : nullptr, &x1_ready, /*r_dead=*/true));
     MG_TRY(scalar_sync(h, &res));
     ++it;
     if (dbg) {
