@@ -19,6 +19,12 @@ import os
 import sys
 import time
 
+# the CPU baseline's OpenMP threads are pinned one per core, spread over the sockets (must be set before any
+# OpenMP runtime is loaded, i.e. before torch / the oracle library are imported)
+if os.environ.get("WORLD_SIZE", "1") == "1":      # (one rank only: N ranks pinning to the same cores would collide)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -47,6 +53,8 @@ def parse():
                     help="diagnostic: run the N>1 (Python-sequenced, sharded) weak-scaling path with world size 1")
     ap.add_argument("--prewarm", type=float, default=0.5, help="seconds of untimed kernel launches before warm-up")
     ap.add_argument("--cpu-cycles", type=int, default=0, help="cycles of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; the median is reported")
+    ap.add_argument("--no-generic-pass", action="store_true", help="skip the second pass with the streaming formats forced")
     return ap.parse_args()
 
 
@@ -156,147 +164,107 @@ def main():
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < args.prewarm:
         h.time_op(1, mg.device.MG_K_RESIDUAL, 50)
-    # ---- W untimed warm-up steps, then exactly K timed steps ----------------------------------------
+    # ---- W untimed warm-up steps, then exactly K timed steps; the region is repeated `--repeats` times (each one
+    # bracketed by barrier + synchronize, x reset to 0 outside it) and the MEDIAN region is reported ---------------
     if W > 0:
         h.solve_dev(b, x, 0.0, W)
-    x.zero_()
-    barrier()
-    t0 = time.perf_counter()
-    iters, resvec = h.solve_dev(b, x, 0.0, K)
-    barrier()
-    dt = time.perf_counter() - t0
-    assert iters == K
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    region = []
+    for _ in range(max(1, args.repeats)):
+        x.zero_()
+        barrier()
+        t0 = time.perf_counter()
+        iters, resvec = h.solve_dev(b, x, 0.0, K)
+        barrier()
+        region.append(time.perf_counter() - t0)
+        assert iters == K
+    dt = float(np.median(region))
     relres = float(resvec[-1] / resvec[0])
-    dof_per_s = world * n * nrhs * K / dt          # replicas when world > 1
+    dof_per_s = world * n * nrhs * K / dt
 
     # ---- per-kernel HIP-event accounting over the same K steps (separate, instrumented pass) -----
-    h.profile_reset()
-    h.profile_enable(True)
-    x.zero_()
-    torch.cuda.synchronize()
-    h.solve_dev(b, x, 0.0, K)
-    h.profile_enable(False)
-    prof = h.profile()
-    tot_ms = sum(v[0] for v in prof.values())
-    # dominant kernel: the fine-level fused smoother/residual SpMV (csr_stream_spmv/spmm on As[1])
-    dom = {}
-    for name in ("smooth", "residual"):
-        ms, cnt, bts = prof[(1, name)]
-        dom[name] = {"avg_ms": ms / cnt, "launches": cnt, "bytes": bts, "gbs": bts / (ms / cnt) / 1e6}
+    prof, moved, tot_ms = profiled_pass(h, b, x, K, torch)
+    kname, fmt_name = kernel_symbol(h, mg, p, 1, nrhs)
     ms_s, cnt_s, bts_s = prof[(1, "smooth")]
-    achieved = bts_s / (ms_s / cnt_s) / 1e6        # GB/s, fine level
-    step_bytes = sum(v[2] * v[1] for v in prof.values()) / K            # algorithmic bytes per step (all launches)
-    # ---- what the kernel serving the fine sweep really is, and what it really streams -----------------
-    # The hierarchy chooses a device format per operator at upload (lossless):
-    #   row classes   csr_rowclass_spmv<MODE>          6 B/row + dictionary; NO matrix stream (constant-coefficient
-    #                                                  stencils, their Galerkin operators, full-weighting P/R)
-    #   pattern-coded csr_pattern_spmv<MODE,NT,DLDS>   8 B/nnz + row descriptors
-    #   plain CSR     csr_stream_spmv<MODE,NT>         12 B/nnz + row pointers   (csr_stream_spmm at nrhs > 1)
-    # `achieved`/`frac` keep the prescribed definition (ALGORITHMIC CSR bytes / kernel time); `streamed_*` is
-    # what the kernel in use moves.  With row classes frac can exceed 1: that is traffic AVOIDED, not bandwidth.
-    # The roofline object aggregates the fine level's kernel SYMBOL over every level that symbol serves (what
-    # `rocprofv3 --stats` averages per kernel name).
-    rcs, fmts, sym, fmt_of = {}, {}, {}, {}
-    for l in range(1, len(p.As)):
-        rcs[l] = h.operator_rowclasses(l, mg.device.MG_OP_A)
-        fmts[l] = h.operator_format(l, mg.device.MG_OP_A)
-        ntl = "true" if 12.0 * p.As[l - 1].nnz > 128.0e6 else "false"
-        if nrhs > 1:
-            sym[l], fmt_of[l] = f"mgk::csr_stream_spmm<2, {ntl}>", "plain CSR (block right-hand sides)"
-        elif rcs[l][0] > 0:
-            var, nexc = h.operator_kernel_info(l, mg.device.MG_OP_A)
-            inl = "true" if 0 < nexc <= 256 else "false"   # a short list of exception rows is handled in-kernel
-            sym[l] = {0: "mgk::csr_rowclass_spmv<2, %s>", 1: "mgk::csr_rowclass_window_spmv<2, %s>",
-                      2: "mgk::csr_rowclass_tile_spmv<2, %s>"}[var] % inl
-            fmt_of[l] = "row classes"
-        elif fmts[l][0] > 0:
-            dl = "true" if (fmts[l][1] <= 1024 and fmts[l][0] < 1024) else "false"
-            sym[l], fmt_of[l] = f"mgk::csr_pattern_spmv<2, {ntl}, {dl}>", "pattern-coded"
-        else:
-            sym[l], fmt_of[l] = f"mgk::csr_stream_spmv<2, {ntl}>", "plain CSR"
-    kname, fmt_name = sym[1], fmt_of[1]
-    lv = [l for l in sym if sym[l] == kname and (l, "smooth") in prof]
-    sm_all = [prof[(l, "smooth")] for l in lv]
-    all_ms = sum(v[0] for v in sm_all)
-    all_cnt = sum(v[1] for v in sm_all)
-    all_bytes = sum(v[2] * v[1] for v in sm_all)
-    n1, nnz1 = p.As[0].shape[0], p.As[0].nnz
-    streamed = None
-    if nrhs == 1:
-        # matrix-side bytes of the kernel in use + the vectors of a SMOOTH launch (x gathered once, b, d, x' written)
-        # vectors of a SMOOTH launch: x gathered once, b, x' written (+ d unless it comes from the class dictionary)
-        per_level = {l: rcs[l][2] + (24.0 if (rcs[l][0] > 0 and h.operator_rowclass_flags(l, mg.device.MG_OP_A)[1]) else 32.0) * p.As[l - 1].shape[0] for l in lv}
-        cnts = {l: prof[(l, "smooth")][1] for l in lv if (l, "smooth") in prof}
-        tot = sum(cnts.values())
-        streamed = sum(per_level[l] * cnts[l] for l in cnts) / tot if tot else None
-        fine_streamed = per_level.get(1)
-    ach_sym = all_bytes / all_ms / 1e6
-    avg_ms = all_ms / all_cnt
-    traffic = None
+    avg_s = ms_s / cnt_s
+    mv_s = moved[(1, "smooth")]
+    step_bytes = sum(v[2] * v[1] for v in prof.values()) / K            # algorithmic (CSR-priced) bytes per step
+    step_moved = sum(moved[k] * prof[k][1] for k in prof) / K           # bytes the kernels in use have to move per step
+    traffic_prof = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
-        try:   # only a PMC figure measured for THIS kernel symbol counts
+        try:   # an OFFLINE rocprofv3 --pmc figure for this kernel symbol (never measured inside this run)
             ent = json.load(open(tfile)).get(f"{args.workload}_{cells}", {})
             if ent.get("kernel") == kname:
-                traffic = ent.get("smooth_symbol_bytes_per_launch")
+                traffic_prof = {"bytes_per_launch": ent.get("smooth_symbol_bytes_per_launch"),
+                                "measured_at_commit": ent.get("commit"), "file": "profiles/pmc_traffic.json"}
         except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": kname + " (fused damped-Jacobi sweep x' = x + d.*(b - A x)), levels " + str(lv),
-                "achieved": round(ach_sym, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach_sym / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(all_bytes / all_cnt, 1),
-                "avg_launch_ms": round(avg_ms, 5), "launches": all_cnt,
+            traffic_prof = None
+    kern_table = {}
+    for (l, k), v in sorted(prof.items()):
+        if v[0] / tot_ms > 0.01:
+            a = v[0] / v[1]
+            kern_table[f"L{l}:{k}"] = {"avg_ms": round(a, 5), "launches_per_step": round(v[1] / K, 2),
+                                       "share": round(v[0] / tot_ms, 4), "moved_MB": round(moved[(l, k)] / 1e6, 2),
+                                       "frac": round(moved[(l, k)] / a / 1e6 / HBM_PEAK_GBS, 4)}
+    roofline = {"bound": "hbm",
+                "kernel": kname + " (fine-level fused damped-Jacobi sweep x' = x + d.*(b - A x), level 1)",
+                "achieved": round(mv_s / avg_s / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(mv_s / avg_s / 1e6 / HBM_PEAK_GBS, 4),
+                "traffic": None, "traffic_from_profile": traffic_prof,
+                "bytes_per_launch": mv_s, "avg_launch_ms": round(avg_s, 5), "launches": cnt_s,
                 "device_format": fmt_name,
-                "streamed_bytes_per_launch": (round(streamed, 1) if streamed else None),
-                "streamed_achieved": (round(streamed / avg_ms / 1e6, 1) if streamed else None),
-                "streamed_frac": (round(streamed / avg_ms / 1e6 / HBM_PEAK_GBS, 4) if streamed else None),
-                "note": ("`achieved`/`frac` price the launch at the CSR algorithmic bytes (12 B/nnz + vectors), as the "
-                         "metric is defined; the kernel in use (`device_format`) moves `streamed_bytes_per_launch`. "
-                         + ("Row classes remove the matrix stream for operators made of a few distinct rows (this "
-                            "constant-coefficient workload): frac > 1 is traffic avoided, NOT bandwidth above peak - "
-                            "`streamed_frac` is the bandwidth figure. Operators without that redundancy (e.g. workload "
-                            "c3) run the streaming kernels." if fmt_name in ("row classes", "mixed") else "")),
-                "row_classes": {f"L{l}": {"classes": rcs[l][0], "dictionary_entries": rcs[l][1],
-                                          "implicit_first_column": h.operator_rowclass_flags(l, mg.device.MG_OP_A)[0],
-                                          "relaxPrec_from_dictionary": h.operator_rowclass_flags(l, mg.device.MG_OP_A)[1]}
-                                for l in lv if rcs[l][0] > 0},
-                "fine_level_only": {"launches": cnt_s, "avg_launch_ms": round(ms_s / cnt_s, 5),
-                                    "algorithmic_bytes_per_launch": bts_s, "achieved": round(achieved, 1),
-                                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                                    "streamed_bytes_per_launch": (fine_streamed if nrhs == 1 else None),
-                                    "streamed_achieved": (round(fine_streamed / (ms_s / cnt_s) / 1e6, 1) if nrhs == 1 else None)},
-                "residual_level1": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in dom["residual"].items()},
+                "definition": "achieved = bytes the kernel IN USE has to move for one launch (device format's matrix side "
+                              "+ every vector element once; mg_profile_get_moved) / its average HIP-event duration in this "
+                              "run; always <= HBM peak. `csr_equivalent` prices the same launch at SURVEY 8d's CSR bytes "
+                              "(12 B/nnz + 4 B/row + vectors): with row classes that exceeds the peak - traffic avoided, "
+                              "not bandwidth.",
+                "csr_equivalent": {"bytes_per_launch": bts_s, "achieved": round(bts_s / avg_s / 1e6, 1),
+                                   "ratio_to_peak": round(bts_s / avg_s / 1e6 / HBM_PEAK_GBS, 4)},
                 "kernel_ms_per_step": round(tot_ms / K, 4),
-                "step_algorithmic_GB": round(step_bytes / 1e9, 4),
-                "step_hbm_gbs": round(step_bytes / (dt / K) / 1e9, 1),
-                "kernel_time_share": {f"L{l}:{k}": round(v[0] / tot_ms, 4) for (l, k), v in sorted(prof.items()) if v[0] / tot_ms > 0.01}}
+                "step_moved_GB": round(step_moved / 1e9, 4), "step_moved_gbs": round(step_moved / (dt / K) / 1e9, 1),
+                "step_csr_equivalent_GB": round(step_bytes / 1e9, 4),
+                "kernels": kern_table}
+    if nrhs == 1:
+        rc = h.operator_rowclasses(1, mg.device.MG_OP_A)
+        if rc[0] > 0:
+            fl = h.operator_rowclass_flags(1, mg.device.MG_OP_A)
+            roofline["row_classes_L1"] = {"classes": rc[0], "dictionary_entries": rc[1], "implicit_first_column": fl[0],
+                                          "relaxPrec_from_dictionary": fl[1]}
+
+    # ---- the same K steps with the STREAMING formats forced for this handle (mg_set_option no_rowclass = 1): what
+    # an operator without repeated rows gets (variable coefficients, SA-AMG); its SURVEY 8d fraction ------------------
+    if nrhs == 1 and roofline.get("row_classes_L1") and not args.no_generic_pass:
+        hg = mg.device.DeviceHierarchy(p, device_id=local_rank, nrhs=nrhs, options={"no_rowclass": 1})
+        xg = torch.zeros_like(b)
+        hg.solve_dev(b, xg, 0.0, max(1, W))
+        xg.zero_()
+        barrier()
+        t0 = time.perf_counter()
+        itg, resg = hg.solve_dev(b, xg, 0.0, K)
+        barrier()
+        dtg = time.perf_counter() - t0
+        profg, movedg, totg = profiled_pass(hg, b, xg, K, torch)
+        kg, fg = kernel_symbol(hg, mg, p, 1, nrhs)
+        msg, cntg, btsg = profg[(1, "smooth")]
+        ag = msg / cntg
+        roofline["generic_csr"] = {
+            "kernel": kg, "device_format": fg, "avg_launch_ms": round(ag, 5), "launches": cntg,
+            "algorithmic_bytes_per_launch": btsg, "achieved": round(btsg / ag / 1e6, 1),
+            "frac": round(btsg / ag / 1e6 / HBM_PEAK_GBS, 4),
+            "moved_bytes_per_launch": movedg[(1, "smooth")],
+            "moved_frac": round(movedg[(1, "smooth")] / ag / 1e6 / HBM_PEAK_GBS, 4),
+            "ms_per_step": round(dtg / K * 1e3, 4), "dof_updates_per_s": round(n * nrhs * K / dtg, 1),
+            "resvec_rel_diff_vs_default": float(np.abs(resg - resvec).max() / resvec[0]),
+            "note": "fine-level fused sweep of the same workload with row classes disabled through the API for a second "
+                    "handle; `frac` is SURVEY 8d's ALGORITHMIC CSR bytes / time / peak (the north_star's 60 % target), "
+                    "`moved_frac` uses the bytes the pattern-coded kernel streams"}
+        hg.close()
+        del xg
 
     # ---- CPU baseline: the C/OpenMP oracle ("port") on a bounded sample of the same workload ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import c_oracle
-        cores = c_oracle.max_threads()
-        co = c_oracle.COracle(p, nrhs)
-        xc = np.zeros_like(b_host)
-        ncyc = args.cpu_cycles or (12 if cells >= 200 else 50)   # about 10 s of host work (128 threads)
-        if nrhs > 1:
-            ncyc = args.cpu_cycles or 1
-        co.solveMG(b_host, xc, 0.0, 1, cores)          # warm-up cycle
-        xc[...] = 0.0
-        t0 = time.perf_counter()
-        it, rv = co.solveMG(b_host, xc, 0.0, ncyc, cores)
-        tc = time.perf_counter() - t0
-        cpu = {"value": round(n * nrhs * it / tc, 1), "unit": "DoF-updates/s", "cores": cores, "kind": "port",
-               "sample": f"{it} solveMG steps of the same workload ({cells}^3 cells, nrhs={nrhs}) on the C/OpenMP oracle, "
-                         f"Int64 indices, unfused op sequence, {tc:.2f}s",
-               "relres_after_sample": float(rv[-1] / rv[0])}
-        # parity spot-check at full size: the oracle's residual history on its sample vs the device's
-        k = min(len(rv), len(resvec))
-        cpu["resvec_rel_diff_vs_gpu"] = float(np.abs(rv[:k] - resvec[:k]).max() / resvec[0])
+        cpu = cpu_baseline(args, p, b_host, n, nrhs, cells, resvec)
 
     if rank == 0:
         out = {
@@ -309,6 +277,8 @@ def main():
                        "cells": cells, "levels": p.levels, "nrhs": nrhs, "N": n, "nnz": int(A.nnz),
                        "level_rows": [int(a.shape[0]) for a in p.As], "level_nnz": [int(a.nnz) for a in p.As],
                        "parallelism": "1 process per GPU"},
+            "timed_regions_ms_per_step": [round(r / K * 1e3, 4) for r in region],
+            "timing": f"median of {len(region)} regions of exactly {K} steps each (barrier + synchronize on both sides)",
             "relres_after_steps": relres,
             "setup_s": {"operator": round(t_op, 2), "MGsetup": round(t_setup, 2), "upload": round(t_upload, 2)},
             "roofline": roofline,
@@ -318,6 +288,127 @@ def main():
     mg.clear_(p)
     if world > 1:
         dist.destroy_process_group()
+
+
+def profiled_pass(h, b, x, K, torch):
+    """K instrumented steps: every launch bracketed by HIP events on the library's stream."""
+    h.profile_reset()
+    h.profile_enable(True)
+    x.zero_()
+    torch.cuda.synchronize()
+    h.solve_dev(b, x, 0.0, K)
+    h.profile_enable(False)
+    prof = h.profile()
+    return prof, h.profile_moved(), sum(v[0] for v in prof.values())
+
+
+def kernel_symbol(h, mg, p, l, nrhs):
+    """(kernel symbol, device format) of the fused sweep on level l - the name rocprofv3 --stats lists."""
+    D = mg.device
+    ntl = "true" if 12.0 * p.As[l - 1].nnz > 128.0e6 else "false"
+    if nrhs > 1:
+        return f"mgk::csr_stream_spmm<2, {ntl}>", "plain CSR (block right-hand sides)"
+    rc = h.operator_rowclasses(l, D.MG_OP_A)
+    if rc[0] > 0:
+        var, nexc = h.operator_kernel_info(l, D.MG_OP_A)
+        inl = "true" if 0 < nexc <= 256 else "false"   # a short list of exception rows is handled in-kernel
+        return ({0: "mgk::csr_rowclass_spmv<2, %s, false>", 1: "mgk::csr_rowclass_window_spmv<2, %s>",
+                 2: "mgk::csr_rowclass_tile_spmv<2, %s>", 3: "mgk::csr_rowclass_march_spmv<2, %s, false>"}[var] % inl,
+                "row classes")
+    fm = h.operator_format(l, D.MG_OP_A)
+    if fm[0] > 0:
+        dl = "true" if (fm[1] <= 1024 and fm[0] < 1024) else "false"
+        return f"mgk::csr_pattern_spmv<2, {ntl}, {dl}>", "pattern-coded"
+    return f"mgk::csr_stream_spmv<2, {ntl}>", "plain CSR"
+
+
+def host_info():
+    """Logical / physical cores and NUMA nodes of this host (Linux)."""
+    logical = os.cpu_count() or 1
+    phys, nodes = set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+        nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except Exception:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = logical
+    return {"logical": logical, "physical": len(phys) or logical, "numa_nodes": nodes or None, "usable": avail}
+
+
+def reference_width_bytes(p, nrhs):
+    """Bytes ONE solveMG step of the unfused reference sequence moves at the reference's widths (Int64 indices and
+    pointers: 16 B/nnz + 8 B/row, every vector operand of every separate op; MGcycle.jl:26-102, SolveFuncs.jl:24-37),
+    V-cycle, x != 0 on the fine level, x = 0 on the coarse ones."""
+    tot = 0.0
+    nl = len(p.As)
+
+    def spmv(M, beta_nonzero):
+        r, c = M.shape
+        return nrhs * (16.0 * M.nnz + 8.0 * (r + 1) + 8.0 * c + (16.0 if beta_nonzero else 8.0) * r)
+
+    for l in range(nl - 1):
+        A = p.As[l]
+        nloc = A.shape[0] * nrhs
+        npre, npost = max(1, int(p.relaxPre(l + 1))), max(1, int(p.relaxPost(l + 1)))
+        sweep = 32.0 * nloc + spmv(A, False) + 24.0 * nloc        # x += d.*r ; r = -A x ; r += b
+        tot += 16.0 * nloc + 8.0 * nloc                           # r = b ; norm(x)
+        if l == 0:
+            tot += spmv(A, True)                                  # r -= A x
+        tot += (npre - 1) * sweep + 32.0 * nloc                   # relax pre
+        tot += spmv(A, False) + 24.0 * nloc                       # r = b - A x
+        tot += 8.0 * p.As[l + 1].shape[0] * nrhs + spmv(p.Rs[l], False) + spmv(p.Ps[l], True)
+        tot += 16.0 * nloc + spmv(A, True)                        # r = b ; r -= A x
+        tot += (npost - 1) * sweep + 32.0 * nloc                  # relax post
+    nc = p.As[-1].shape[0]
+    tot += 8.0 * nc * nc + 24.0 * nc * nrhs
+    A = p.As[0]
+    tot += spmv(A, False) + 24.0 * A.shape[0] * nrhs + 8.0 * A.shape[0] * nrhs     # solveMG: r = b - A x ; norm
+    return tot
+
+
+def cpu_baseline(args, p, b_host, n, nrhs, cells, resvec_gpu):
+    """The C/OpenMP oracle ("port") timed on this host: (a) all PHYSICAL cores, (b) numCores = 8, the reference's default
+    (MGdef.jl:156).  The hierarchy, the scratch and b/x are first-touched by the threads that stream them."""
+    from oracle import c_oracle
+    info = host_info()
+    cores = max(1, min(info["physical"], info["usable"], c_oracle.max_threads()))
+    ref_bytes = reference_width_bytes(p, nrhs)
+    out = {}
+    for tag, nthr, ncyc in (("all", cores, args.cpu_cycles or (16 if cells >= 200 else 50)),
+                            ("numCores8", min(8, cores), args.cpu_cycles or (3 if cells >= 200 else 20))):
+        if nrhs > 1:
+            ncyc = args.cpu_cycles or 1
+        co = c_oracle.COracle(p, nrhs, first_touch_threads=nthr)
+        co.solveMG_placed(b_host, 0.0, 1, nthr)          # warm-up cycle
+        it, rv, _, tc = co.solveMG_placed(b_host, 0.0, ncyc, nthr)
+        co.close()
+        out[tag] = {"value": round(n * nrhs * it / tc, 1), "cores": nthr, "steps": it, "seconds": round(tc, 2),
+                    "gbs_reference_widths": round(ref_bytes * it / tc / 1e9, 1)}
+        if tag == "all":
+            k = min(len(rv), len(resvec_gpu))
+            out["resvec_rel_diff_vs_gpu"] = float(np.abs(rv[:k] - resvec_gpu[:k]).max() / resvec_gpu[0])
+            out["relres_after_sample"] = float(rv[-1] / rv[0])
+    a = out["all"]
+    return {"value": a["value"], "unit": "DoF-updates/s", "cores": a["cores"], "kind": "port",
+            "sample": f"{a['steps']} solveMG steps of the same workload ({cells}^3 cells, nrhs={nrhs}) on the C/OpenMP oracle: "
+                      f"Int64 indices, unfused op sequence, hierarchy and vectors first-touched by the streaming threads, "
+                      f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, {a['seconds']}s",
+            "gbs_reference_widths": a["gbs_reference_widths"],
+            "reference_width_bytes_per_step": ref_bytes,
+            "numCores8": out["numCores8"], "host": info,
+            "relres_after_sample": out["relres_after_sample"], "resvec_rel_diff_vs_gpu": out["resvec_rel_diff_vs_gpu"]}
 
 
 def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):

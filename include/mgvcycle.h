@@ -58,7 +58,8 @@ typedef struct mg_hierarchy mg_hierarchy;
 #define MG_K_DSCALE 5   /* x = d.*b (first sweep from x=0) (MGcycle.jl:134)            */
 #define MG_K_COARSE 6   /* xc = LU \ bc                    (MGcycle.jl:177)            */
 #define MG_K_NORM 7     /* ||r||^2                         (SolveFuncs.jl:30)          */
-#define MG_K_COUNT 8
+#define MG_K_SMOOTH_PROLONG 8 /* x' = xp + d.*(b - A*xp), xp = x + P*xc: MGcycle.jl:90 fused into the first post-sweep */
+#define MG_K_COUNT 9
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 
@@ -81,6 +82,12 @@ int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long lo
  * library walk the row blocks in L2-sized y-tiles when three grid planes of the gathered vector do not fit
  * an XCD's L2 (block right-hand sides, grids beyond ~400^2 nodes per plane).  n3 = 1 for 2-D. */
 int mg_set_grid_hint(mg_hierarchy* h, long long level, long long n1, long long n2, long long n3);
+
+/* Override one format-selection switch of THIS handle (DESIGN.md section 3 lists them; key = the environment name
+ * without the MG_ prefix, lower case: "no_rowclass", "no_tile", "tile_min_wg", "nt", ...).  The environment itself is
+ * read once, inside mg_create; nothing on the launch path reads it.  Applies to operators uploaded after the call
+ * (call it right after mg_create), e.g. mg_set_option(h, "no_rowclass", 1) forces the streaming CSR formats. */
+int mg_set_option(mg_hierarchy* h, const char* key, double value);
 
 /* relaxType: 0 = pointwise relaxPrecs ("Jac", "SPAI": relax(), MGcycle.jl:122-136);
  * 1 = "Jac-GMRES": FGMRES_relaxation with npre/npost inner directions, preconditioned by relaxPrecs
@@ -200,6 +207,10 @@ int mg_profile_enable(mg_hierarchy* h, long long on);
 int mg_profile_get(mg_hierarchy* h, long long level, long long kernel, double* total_ms,
                    long long* launches, double* bytes_per_launch);
 int mg_profile_reset(mg_hierarchy* h);
+/* Bytes one launch of the kernel IN USE has to move: the device format's matrix side (row classes: 2 or 6 B/row +
+ * dictionary; pattern-coded: 8 B/nnz + descriptors; plain CSR: 12 B/nnz + row pointers) + every vector element once.
+ * This - not the CSR-priced figure of mg_profile_get - is what a bandwidth fraction must be computed from. */
+int mg_profile_get_moved(mg_hierarchy* h, long long level, long long kernel, double* moved_bytes_per_launch);
 /* Device format of one operator: number of distinct row patterns (0 = plain CSR with int32 column indices),
  * dictionary length, and the index-side bytes (row pointers + column information) of one nrhs=1 launch. */
 int mg_operator_format(mg_hierarchy* h, long long level, long long which, long long* npatterns,
@@ -214,7 +225,8 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
  * no per-row first column is stored (2 B/row instead of 6); class_relax = 1 when the level's relaxPrec is constant per
  * class and the fused sweep reads it from the dictionary instead of streaming 8 B/row; kernel_variant = which kernel
  * serves the operator at nrhs == 1: -1 none (streaming formats), 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv
- * (x staged in LDS per workgroup of consecutive rows), 2 csr_rowclass_tile_spmv (plane tiles from the grid hint);
+ * (x staged in LDS per workgroup of consecutive rows), 2 csr_rowclass_tile_spmv (plane tiles from the grid hint),
+ * 3 csr_rowclass_march_spmv (z-marching ring of slabs from the grid hint);
  * exception_rows = rows outside the dictionary classes (computed from the CSR arrays: in the last workgroup of the
  * row-class kernel when there are at most 256 of them - second template argument `true` - else by csr_rows_spmv). */
 int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which, long long* implicit_first,

@@ -526,18 +526,10 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
       if (MODE == SMOOTH && !v.d && in[j]) pd[j] = dcc;
       a[j] = 0.0;
     }
-#if defined(MG_RC_EXP) && MG_RC_EXP == 1   // timing experiment only (wrong results): one gather per row
-    const int s = C.cls_ptr[cc], e = s + 1;
-#else
     const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
-#endif
     int k = s;
     for (; k + 3 < e; k += 4) {
-#if defined(MG_RC_EXP) && MG_RC_EXP == 2   // timing experiment only (wrong results): every gather at offset 0
-      const int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-#else
       const int o0 = C.cls_off[k], o1 = C.cls_off[k + 1], o2 = C.cls_off[k + 2], o3 = C.cls_off[k + 3];
-#endif
       const double a0 = C.cls_val[k], a1 = C.cls_val[k + 1], a2 = C.cls_val[k + 2], a3 = C.cls_val[k + 3];
       double x0[RPT], x1[RPT], x2[RPT], x3[RPT];
 #pragma unroll
@@ -556,11 +548,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
       }
     }
     for (; k < e; ++k) {
-#if defined(MG_RC_EXP) && MG_RC_EXP == 2
-      const int o0 = 0;
-#else
       const int o0 = C.cls_off[k];
-#endif
       const double a0 = C.cls_val[k];
 #pragma unroll
       for (int j = 0; j < RPT; ++j) a[j] += a0 * xb[j][o0];
@@ -879,6 +867,289 @@ __global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_til
       v.sumsq[bid] = t;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-class SpMV marching along z (square operators in the implicit-first form with a grid hint; P = n1*n2 rows per
+// plane).  The plane-tile kernel above re-stages RT_NP + 2 slabs for RT_NP planes and alternates a load phase with a
+// compute phase; here a workgroup owns ONE in-plane chunk of RM_C rows and walks a run of consecutive planes with a ring
+// of four slabs in LDS: every plane of x is staged once per chunk (in-plane halo rows come from the neighbour chunk's
+// lines in L2), the slab of plane z+3 is in flight in registers while plane z is computed, and there is one barrier
+// per plane.  The (chunk, plane) items are dealt to the workgroups as equal contiguous ranges of the chunk-major
+// list, so a launch is exactly one balanced round of the resident workgroups whatever the grid (a range that runs off
+// the end of a chunk continues at plane 0 of the next one).  Slabs start at an EVEN global index so that the staging
+// loads are 16 bytes per lane; the 0/1 entry shift this causes is a per-plane scalar.
+// Optional prologue (PRO): the staged vector is x + Pm*xc instead of x - the coarse-grid correction x += P*xc
+// (MGcycle.jl:90) is applied while the slab passes through registers, in the arithmetic of the stand-alone product
+// (entries in stored order, then 1.0*acc + x), so the post-smoothing sweep needs no prolongation launch and x is not
+// read-modified-written in HBM.  Correct for ANY operator in this form: entries whose shift is not dz*P + rest with
+// |dz| <= 1, |rest| <= halo gather from global memory (never the case for a grid operator).
+// ------------------------------------------------------------------------------------------------
+constexpr int RM_C = 1024;    // rows of a plane per workgroup = threads per workgroup
+constexpr int RM_RING = 4;    // slabs in LDS: planes z-1, z, z+1 in use, z+2 being written
+
+struct MarchDev {
+  const int* lb;     // per dictionary entry: ((rest + halo) << 2) | (dz + 1), or -1: gather from global memory
+  int P;             // rows per plane
+  int nplanes;       // n_rows == nplanes * P
+  int halo;          // slab = RM_C + 2*halo entries of x (+ alignment pad)
+  int chunks;        // ceil(P / RM_C)
+  int nblocks;       // workgroups; each gets chunks*nplanes/nblocks consecutive (chunk, plane) items
+  int n_cols;
+};
+
+// The coarse-grid correction fused into the staging of csr_rowclass_march_spmv: Pm in row-class form (any variant).
+struct ProDev {
+  RowClassDev Pm;
+  const double* xc;
+};
+
+// (Pm*xc)[row] for the lane's two consecutive rows e0, e0+1 (waterfall over Pm's classes as in csr_rowclass_spmv's
+// PAIR form: a prolongation alternates classes from row to row).  Rows outside [0, n) contribute 0.
+__device__ __forceinline__ void march_prolong_pair(const ProDev& Q, long long e0, bool act, double& p0, double& p1) {
+  const RowClassDev& C = Q.Pm;
+  int first[2], cls[2];
+  bool ok[2];
+  double acc[2] = {0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long long r = e0 + j;
+    ok[j] = act && r >= 0 && r < C.n_rows;
+    const int rr = ok[j] ? (int)r : 0;
+    cls[j] = C.cls[rr];
+    first[j] = C.firstcol ? C.firstcol[rr] : rr;
+    ok[j] = ok[j] && cls[j] != 0xFFFF;
+  }
+  const unsigned long long lanebit = 1ull << (threadIdx.x & 63);
+  unsigned long long todo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) todo[j] = __ballot(ok[j]);
+  for (;;) {
+    int cc = 0, lead = 0;
+    bool any = false;
+#pragma unroll
+    for (int j = 1; j >= 0; --j)
+      if (todo[j]) {
+        const int l = __builtin_ctzll(todo[j]);
+        cc = __builtin_amdgcn_readlane(cls[j], l);
+        lead = __builtin_amdgcn_readlane(first[j], l);
+        any = true;
+      }
+    if (!any) break;
+    const int delta = C.firstcol ? 0 : C.cls_delta[cc];
+    lead += delta;
+    bool in[2];
+    const double* xb[2];
+    double a[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned long long m = __ballot(cls[j] == cc) & todo[j];
+      todo[j] &= ~m;
+      in[j] = (m & lanebit) != 0;
+      xb[j] = Q.xc + (in[j] ? first[j] + delta : lead);
+      a[j] = 0.0;
+    }
+    const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
+    int k = s;
+    for (; k + 3 < e; k += 4) {
+      const int o0 = C.cls_off[k], o1 = C.cls_off[k + 1], o2 = C.cls_off[k + 2], o3 = C.cls_off[k + 3];
+      const double a0 = C.cls_val[k], a1 = C.cls_val[k + 1], a2 = C.cls_val[k + 2], a3 = C.cls_val[k + 3];
+      double x0[2], x1[2], x2[2], x3[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        x0[j] = xb[j][o0];
+        x1[j] = xb[j][o1];
+        x2[j] = xb[j][o2];
+        x3[j] = xb[j][o3];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        a[j] += a0 * x0[j];
+        a[j] += a1 * x1[j];
+        a[j] += a2 * x2[j];
+        a[j] += a3 * x3[j];
+      }
+    }
+    for (; k < e; ++k) {
+      const int o0 = C.cls_off[k];
+      const double a0 = C.cls_val[k];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a[j] += a0 * xb[j][o0];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (in[j]) acc[j] = a[j];
+  }
+  p0 = acc[0];
+  p1 = acc[1];
+}
+
+// one 16-byte pair of the slab: global entries e0, e0 + 1 (e0 even); clamped scalar loads at the ends of the vector
+// (no live row reads a clamped slot through a staged shift)
+__device__ __forceinline__ d2_t march_load_pair(const double* __restrict__ x, long long e0, bool act, int n_cols) {
+  d2_t r = d2_t{0.0, 0.0};
+  if (act) {
+    if (e0 >= 0 && e0 + 1 < n_cols) {
+      r = *reinterpret_cast<const d2_t*>(x + e0);
+    } else {
+      const long long n1 = n_cols - 1;
+      const long long c0 = e0 < 0 ? 0 : (e0 > n1 ? n1 : e0), c1 = e0 + 1 < 0 ? 0 : (e0 + 1 > n1 ? n1 : e0 + 1);
+      r.x = x[c0];
+      r.y = x[c1];
+    }
+  }
+  return r;
+}
+// pair -> LDS; PRO: x + Pm*xc for the pair's two rows, in the arithmetic of the stand-alone AXPBY product
+// (alpha = beta = 1: 1.0*acc + 1.0*x)
+template <bool PRO>
+__device__ __forceinline__ d2_t march_stage(const ProDev& Q, long long e0, bool act, d2_t val) {
+  if (PRO) {
+    double p0, p1;
+    march_prolong_pair(Q, e0, act, p0, p1);
+    val.x = 1.0 * p0 + 1.0 * val.x;
+    val.y = 1.0 * p1 + 1.0 * val.y;
+  }
+  return val;
+}
+
+template <int MODE, bool EXC, bool PRO>
+__global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C, VecArgs v, MarchDev T, ProDev Q) {
+  extern __shared__ double win[];
+  __shared__ double red[RM_C / 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int w = xcd_band(blockIdx.x, T.nblocks);
+  const int SL = RM_C + 2 * T.halo;
+  const int SLP = (SL + 3) & ~1;                       // even, >= SL + 1 (the alignment shift)
+  const int npair = (SL + 2) >> 1;                     // 16-byte pairs per slab (<= RM_C: host check)
+  const long long tot = (long long)T.chunks * T.nplanes;
+  long long it = tot * w / T.nblocks;
+  const long long it_end = tot * (w + 1) / T.nblocks;
+  const unsigned long long lanebit = 1ull << lane;
+  const bool class_d = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
+  const bool own_lds = (v.xs == v.x) || PRO;
+  double sq = 0.0;
+
+  // slab of plane p of chunk c: global entries [a0, a0 + 2*npair), a0 = even floor of p*P + c*RM_C - halo
+#define MARCH_G0(c, p) ((long long)(p) * T.P + (long long)(c) * RM_C - T.halo)
+#define MARCH_LOAD(c, p) march_load_pair(v.x, MARCH_G0(c, p) & ~1LL, tid < npair, T.n_cols)
+#define MARCH_STAGE(c, p, slot, val)                                                                    \
+  do {                                                                                                  \
+    const d2_t sv_ = march_stage<PRO>(Q, (MARCH_G0(c, p) & ~1LL) + 2 * tid, tid < npair, val);          \
+    if (tid < npair) {                                                                                  \
+      win[(slot) * SLP + 2 * tid] = sv_.x;                                                              \
+      win[(slot) * SLP + 2 * tid + 1] = sv_.y;                                                          \
+    }                                                                                                   \
+  } while (0)
+  while (it < it_end) {
+    const int c = (int)(it / T.nplanes);
+    const int z0 = (int)(it - (long long)c * T.nplanes);
+    const int z1 = (int)((it_end - it) < (long long)(T.nplanes - z0) ? z0 + (it_end - it) : T.nplanes);
+    it += z1 - z0;
+    const int inplane = c * RM_C + tid;
+    const bool rowlive = inplane < T.P;
+    // ---- fill the ring: planes z0-1, z0, z0+1; plane z0+2 goes into registers -------------------------------------
+    {
+      const d2_t q0 = MARCH_LOAD(c, z0 - 1), q1 = MARCH_LOAD(c, z0), q2 = MARCH_LOAD(c, z0 + 1);
+      MARCH_STAGE(c, z0 - 1, 0, q0);
+      MARCH_STAGE(c, z0, 1, q1);
+      MARCH_STAGE(c, z0 + 1, 2, q2);
+    }
+    d2_t pre = MARCH_LOAD(c, z0 + 2);
+    int ncls;
+    double npb = 0.0, npd = 0.0;
+    {
+      const int row = z0 * T.P + inplane;
+      const int rr = rowlive ? row : C.n_rows - 1;
+      ncls = C.cls[rr];
+      if (MODE == AXPBY) {
+        if (v.beta != 0.0) npb = v.beta * v.y[rr];
+      } else {
+        npb = v.b[rr];
+        if ((MODE == SMOOTH || (MODE == RESID && v.y2)) && v.d) npd = v.d[rr];
+      }
+    }
+    __syncthreads();
+    for (int z = z0; z < z1; ++z) {
+      const int q = z - z0 + 1;                        // ring index of plane z (plane z0-1 is 0)
+      // ---- plane z+2 into its slot (that of plane z-2, last read before the previous barrier); plane z+3 in flight ----
+      if (z + 2 <= z1) MARCH_STAGE(c, z + 2, (q + 2) & 3, pre);   // (planes beyond z1 are not needed by this run)
+      const bool more = z + 1 < z1;
+      if (z + 3 <= z1) pre = MARCH_LOAD(c, z + 3);
+      const int cls = ncls;
+      const double pb = npb;
+      double pd = npd;
+      if (more) {
+        const int row = (z + 1) * T.P + inplane;
+        const int rr = rowlive ? row : C.n_rows - 1;
+        ncls = C.cls[rr];
+        if (MODE == AXPBY) {
+          if (v.beta != 0.0) npb = v.beta * v.y[rr];
+        } else {
+          npb = v.b[rr];
+          if ((MODE == SMOOTH || (MODE == RESID && v.y2)) && v.d) npd = v.d[rr];
+        }
+      }
+      // ---- compute plane z from the ring ------------------------------------------------------------------------
+      const int row = z * T.P + inplane;
+      const bool live = rowlive && cls != 0xFFFF;      // exception rows are computed by csr_rows_spmv
+      const int sb0 = ((q - 1) & 3) * SLP + (int)(MARCH_G0(c, z - 1) & 1LL);
+      const int sb1 = (q & 3) * SLP + (int)(MARCH_G0(c, z) & 1LL);
+      const int sb2 = ((q + 1) & 3) * SLP + (int)(MARCH_G0(c, z + 1) & 1LL);
+      double acc = 0.0;
+      unsigned long long todo = __ballot(live);
+      while (todo) {
+        const int l = __builtin_ctzll(todo);
+        const int cc = __builtin_amdgcn_readlane(cls, l);
+        const int delta = C.cls_delta[cc];
+        const int lead = __builtin_amdgcn_readlane(row, l) + delta;
+        const unsigned long long m = __ballot(cls == cc) & todo;
+        todo &= ~m;
+        const bool in = (m & lanebit) != 0;
+        if (class_d && in) pd = C.cls_d[cc];
+        double a = 0.0;
+        const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
+        for (int k = s; k < e; ++k) {
+          const int lb = T.lb[k];
+          const double a0 = C.cls_val[k];
+          if (lb >= 0) {   // wave-uniform
+            const int dz1 = lb & 3;
+            const int sb = dz1 == 0 ? sb0 : (dz1 == 1 ? sb1 : sb2);
+            a += a0 * win[sb + (lb >> 2) + tid];       // rows of another class: a valid slot, unused
+          } else {
+            double xg = v.x[(in ? row + delta : lead) + C.cls_off[k]];
+            asm volatile("" : "+v"(xg));               // (keeps the two loads apart: merged into one flat load, the
+            a += a0 * xg;                              //  LDS -> flat cast trips a gfx950 instruction-selection bug)
+          }
+        }
+        if (in) acc = a;
+      }
+      if (live) {
+        const double own = win[sb1 + T.halo + tid];
+        double pxj = own;
+        if (MODE == SMOOTH && !own_lds) pxj = v.xs[row];
+        const double outv = epilogue<MODE>(v, row, acc, pb, pd, pxj);
+        if (MODE != RESID || v.y) v.y[row] = outv;     // (the solve loop needs only ||r|| and x + d.*r: y may be null)
+        if (MODE == RESID && v.y2) v.y2[row] = own + pd * outv;   // x + d.*r
+        sq += outv * outv;
+      }
+      __syncthreads();
+    }
+  }
+  if (EXC && blockIdx.x == gridDim.x - 1) sq += rowclass_exception_rows<MODE>(C, v, tid);   // EXC: C.nexc_inline > 0
+  if (v.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w2 = 0; w2 < RM_C / 64; ++w2) t += red[w2];
+      v.sumsq[w] = t;
+    }
+  }
+#undef MARCH_G0
+#undef MARCH_LOAD
+#undef MARCH_STAGE
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
+#include <cstddef>
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
@@ -48,6 +50,78 @@ static inline hipError_t spin_sync(hipStream_t s) {
   return e;
 }
 
+
+// Switches and thresholds of the format selection (A/B measurements, tests).  Read from the environment ONCE per
+// handle - at mg_create / mg_op_create - and kept in the handle; mg_set_option overrides single entries through the
+// API before the operators are uploaded.  Nothing on the launch path reads the environment.
+struct Options {
+  bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
+  bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
+  bool no_march = false, no_fuse_prolong = false;
+  bool debug_format = false, debug_timing = false;
+  int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
+  long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
+  long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
+  double rowclass_min_cover = 0.9, sched_budget = 2.0e6;
+  struct Entry { const char* env; const char* key; int kind; size_t off; };   // kind 0 bool, 1 long long, 2 double, 3 int
+  static const Entry* table(size_t* n);
+  bool set(const char* key, double v, bool by_env);
+  static Options from_env();
+};
+#define MG_OPT(env, key, kind, field) {env, key, kind, offsetof(Options, field)}
+const Options::Entry* Options::table(size_t* n) {
+  static const Entry t[] = {
+      MG_OPT("MG_NO_ROWCLASS", "no_rowclass", 0, no_rowclass), MG_OPT("MG_NO_IMPLICIT_FIRST", "no_implicit_first", 0, no_implicit_first),
+      MG_OPT("MG_NO_CLASS_D", "no_class_d", 0, no_class_d), MG_OPT("MG_NO_TILE", "no_tile", 0, no_tile),
+      MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
+      MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
+      MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_FUSE_PROLONG", "no_fuse_prolong", 0, no_fuse_prolong),
+      MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
+      MG_OPT("MG_NT", "nt", 3, nt),
+      MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
+      MG_OPT("MG_ROWCLASS_MAX_PASSES", "rowclass_max_passes", 1, rowclass_max_passes),
+      MG_OPT("MG_ROWCLASS_KEEP_SINGLETONS", "rowclass_keep_singletons", 1, rowclass_keep_singletons),
+      MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
+      MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
+      MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg),
+      MG_OPT("MG_ROWCLASS_MIN_COVER", "rowclass_min_cover", 2, rowclass_min_cover),
+      MG_OPT("MG_SCHED_BUDGET", "sched_budget", 2, sched_budget),
+  };
+  *n = sizeof t / sizeof t[0];
+  return t;
+}
+#undef MG_OPT
+bool Options::set(const char* key, double v, bool by_env) {
+  size_t n = 0;
+  const Entry* t = table(&n);
+  for (size_t i = 0; i < n; ++i) {
+    if (std::strcmp(by_env ? t[i].env : t[i].key, key) != 0) continue;
+    char* base = reinterpret_cast<char*>(this) + t[i].off;
+    switch (t[i].kind) {
+      case 0: *reinterpret_cast<bool*>(base) = (v != 0.0); break;
+      case 1: *reinterpret_cast<long long*>(base) = (long long)v; break;
+      case 2: *reinterpret_cast<double*>(base) = v; break;
+      default: *reinterpret_cast<int*>(base) = (int)v; break;
+    }
+    return true;
+  }
+  return false;
+}
+Options Options::from_env() {
+  Options o;
+  size_t n = 0;
+  const Entry* t = table(&n);
+  for (size_t i = 0; i < n; ++i)
+    if (const char* e = std::getenv(t[i].env)) {
+      // historical semantics of the boolean switches: "1" switches on, anything else off (MG_DEBUG_TIMING: any value)
+      if (t[i].kind == 0) o.set(t[i].env, (e[0] == '1' || std::strcmp(t[i].env, "MG_DEBUG_TIMING") == 0) ? 1.0 : 0.0, true);
+      else o.set(t[i].env, std::atof(e), true);
+    }
+  if (o.sched_budget < 1.0) o.sched_budget = 1.0;
+  return o;
+}
+
 #define HIP_TRY(expr)                                                                        \
   do {                                                                                       \
     hipError_t e_ = (expr);                                                                  \
@@ -82,6 +156,7 @@ struct DevBuf {
 };
 
 struct Csr {
+  Options opt;   // copied from the owning handle at upload
   bool set = false;
   long long n_rows = 0, n_cols = 0, nnz = 0;
   DevBuf<int> rowptr, colidx, blk_row, sched;
@@ -103,6 +178,9 @@ struct Csr {
   std::vector<int> h_rc_ptr, h_rc_off, h_rc_delta;   // host copy of the dictionary (tile index tables)
   int rc_major = 0;         // most frequent class
   bool rc_tile = false;     // csr_rowclass_tile_spmv (plane tiles from the grid hint)
+  bool rc_march = false;    // csr_rowclass_march_spmv (z-marching ring of slabs; preferred over the tiles when set)
+  DevBuf<int> rm_lb;
+  int rm_P = 0, rm_nplanes = 0, rm_halo = 0, rm_chunks = 0, rm_nblocks = 0;
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   int rw_doubles = 0;   // x entries a workgroup of csr_rowclass_window_spmv stages in LDS
   DevBuf<unsigned short> rc_cls;
@@ -146,7 +224,18 @@ struct Csr {
   // workgroups of the nrhs == 1 product (one fused ||r||^2 partial each)
   int rw_blocks() const { return (int)((n_rows + mgk::RW_ROWS - 1) / mgk::RW_ROWS); }
   int exc_blocks() const { return rc_nexc > mgk::BLK ? (rc_nexc + mgk::BLK - 1) / mgk::BLK : 0; }   // short lists: in-kernel
-  int blocks1() const { return has_rc ? (rc_tile ? rt_nblocks : rc_window ? rw_blocks() : rc_blocks()) + exc_blocks() : nblocks; }
+  int blocks1() const { return has_rc ? (rc_march ? rm_nblocks : rc_tile ? rt_nblocks : rc_window ? rw_blocks() : rc_blocks()) + exc_blocks() : nblocks; }
+  mgk::MarchDev marchdev() const {
+    mgk::MarchDev t;
+    t.lb = rm_lb.p;
+    t.P = rm_P;
+    t.nplanes = rm_nplanes;
+    t.halo = rm_halo;
+    t.chunks = rm_chunks;
+    t.nblocks = rm_nblocks;
+    t.n_cols = (int)n_cols;
+    return t;
+  }
   mgk::TileDev tiledev() const {
     mgk::TileDev t;
     t.tile_lb = rt_lb.p;
@@ -186,9 +275,11 @@ struct Csr {
     rw_meta.release();
     rw_lb.release();
     rt_lb.release();
+    rm_lb.release();
     rc_exc.release();
     rc_nexc = 0;
     rc_tile = false;
+    rc_march = false;
     h_rc_ptr.clear();
     h_rc_off.clear();
     h_rc_delta.clear();
@@ -263,12 +354,14 @@ struct Level {
 struct ProfSlot {
   double ms = 0.0;
   long long launches = 0;
-  double bytes = 0.0;
+  double bytes = 0.0;   // algorithmic (CSR-priced) bytes of one launch, SURVEY 8d
+  double moved = 0.0;   // bytes the kernel IN USE has to move for one launch (device format + each vector once)
 };
 
 }  // namespace
 
 struct mg_hierarchy {
+  Options opt;
   int device = 0;
   long long nlevels = 0;
   long long nrhs = 1;
@@ -305,7 +398,7 @@ struct mg_hierarchy {
   struct Pending {
     hipEvent_t a, b;
     int level, kernel;
-    double bytes;
+    double bytes, moved;
   };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> ev_pool;
@@ -321,6 +414,24 @@ double spmv_bytes(const Csr& M, long long nrhs, bool reads_y_or_b, bool smooth) 
   bts += 8.0 * (double)nrhs * (double)(M.n_cols + M.n_rows);  // x read, y written
   if (reads_y_or_b) bts += 8.0 * (double)nrhs * (double)M.n_rows;
   if (smooth) bts += 8.0 * (double)M.n_rows;  // d; the x[row] term is the already-counted x read
+  return bts;
+}
+
+// Matrix-side bytes one launch of the kernel IN USE streams for M (the device format chosen at upload).
+double format_bytes(const Csr& M, long long nrhs) {
+  if (nrhs == 1 && M.has_rc)
+    return (M.rc_implicit ? 2.0 : 6.0) * (double)M.n_rows + 12.0 * (double)M.rc_entries;
+  if (nrhs == 1 && M.has_pat)
+    return 8.0 * (double)M.nnz + 4.0 * (double)M.dict_entries +
+           (M.has_runs ? 20.0 * (double)M.nruns_total + 8.0 * (double)M.nblocks : 10.0 * (double)M.n_rows);
+  return 12.0 * (double)M.nnz + 4.0 * (double)(M.n_rows + 1);
+}
+// Compulsory bytes of one launch in that format: the matrix side above + every vector element once
+// (class_d: the relaxPrec comes from the class dictionary instead of an 8 B/row stream).
+double moved_bytes(const Csr& M, long long nrhs, bool reads_y_or_b, bool smooth, bool class_d = false) {
+  double bts = format_bytes(M, nrhs) + 8.0 * (double)nrhs * (double)(M.n_cols + M.n_rows);
+  if (reads_y_or_b) bts += 8.0 * (double)nrhs * (double)M.n_rows;
+  if (smooth && !class_d) bts += 8.0 * (double)M.n_rows;
   return bts;
 }
 
@@ -345,13 +456,14 @@ struct ProfScope {
   mg_hierarchy* h;
   bool on;
   mg_hierarchy::Pending p;
-  ProfScope(mg_hierarchy* h_, int level, int kernel, double bytes) : h(h_), on(h_->prof) {
+  ProfScope(mg_hierarchy* h_, int level, int kernel, double bytes, double moved = -1.0) : h(h_), on(h_->prof) {
     if (!on) return;
     p.a = get_event(h);
     p.b = get_event(h);
     p.level = level;
     p.kernel = kernel;
     p.bytes = bytes;
+    p.moved = moved < 0.0 ? bytes : moved;
     (void)hipEventRecord(p.a, h->stream);
   }
   ~ProfScope() {
@@ -369,6 +481,7 @@ void prof_collect(mg_hierarchy* h) {
       s.ms += ms;
       s.launches += 1;
       s.bytes = p.bytes;
+      s.moved = p.moved;
     }
     h->ev_pool.push_back(p.a);
     h->ev_pool.push_back(p.b);
@@ -383,15 +496,51 @@ int pow2_ge(long long v) {
   return g;
 }
 
+// can the z-marching kernel serve this launch?  (staged variants read x workgroup-wide: never in place; its staging
+// loads are 16 bytes wide: x must be 16-byte aligned, which every allocation base is)
+bool march_ok(const Csr& M, const mgk::VecArgs& v) {
+  return v.nrhs == 1 && M.has_rc && M.rc_march && v.y != v.x && v.y2 != v.x && (reinterpret_cast<uintptr_t>(v.x) & 15) == 0;
+}
+
+// nparts (optional): number of per-workgroup ||out||^2 partials the launch writes to v.sumsq.
+// pro (optional, SMOOTH on a marching operator only): stage x + Pm*xc instead of x (the fused coarse-grid correction).
 template <int MODE>
-int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
+int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* nparts = nullptr,
+               const mgk::ProDev* pro = nullptr) {
+  if (nparts) *nparts = M.nblocks;
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
+  if (pro && !march_ok(M, v)) return fail(MG_ERR_STATE, "fused prolongation needs the marching kernel");
   if (v.nrhs == 1 && M.has_rc) {
     int nb_main;
     const mgk::RowClassDev C = M.rcdev();
     const bool exc = C.nexc_inline > 0;   // a short list of exception rows rides in the last workgroup
-    if (M.rc_tile && v.y != v.x) {   // (the staged variants read x workgroup-wide: never in place)
+    if (march_ok(M, v)) {
+      const mgk::MarchDev T = M.marchdev();
+      const int SL = mgk::RM_C + 2 * M.rm_halo;
+      const size_t lds = (size_t)mgk::RM_RING * (size_t)((SL + 3) & ~1) * sizeof(double);
+      nb_main = M.rm_nblocks;
+      static bool lds_attr_set[3] = {false, false, false};
+      if (!lds_attr_set[MODE]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march_spmv<MODE, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march_spmv<MODE, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (MODE == mgk::SMOOTH) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march_spmv<mgk::SMOOTH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march_spmv<mgk::SMOOTH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        }
+        (void)hipGetLastError();
+        lds_attr_set[MODE] = true;
+      }
+      mgk::ProDev Q{};
+      if (pro) Q = *pro;
+      if (MODE == mgk::SMOOTH && pro) {
+        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<mgk::SMOOTH, true, true>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
+        else hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<mgk::SMOOTH, false, true>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
+      } else {
+        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<MODE, true, false>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
+        else hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<MODE, false, false>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
+      }
+    } else if (M.rc_tile && v.y != v.x) {   // (the staged variants read x workgroup-wide: never in place)
       const size_t lds = (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * M.rt_halo) * sizeof(double);
       nb_main = M.rt_nblocks;
       static bool lds_attr_set[3] = {false, false, false};   // up to 80 KiB of dynamic LDS: lift the 64 KiB default once
@@ -425,6 +574,7 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v) {
       ve.d = v.d_full;
       hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3(M.exc_blocks()), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, nb_main);
     }
+    if (nparts) *nparts = nb_main + M.exc_blocks();
   } else if (v.nrhs == 1 && M.has_pat) {
     const bool dl = M.dict_entries <= mgk::DICT_LDS && M.npat < mgk::DICT_LDS;
     if (M.nt && dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
@@ -453,7 +603,7 @@ int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, con
   v.alpha = alpha;
   v.beta = beta;
   v.nrhs = (int)h->nrhs;
-  ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false));
+  ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false), moved_bytes(M, h->nrhs, beta != 0.0, false));
   return launch_csr<mgk::AXPBY>(h->stream, M, v);
 }
 // out = b - A*x
@@ -464,7 +614,7 @@ int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const 
   v.y = out;
   v.b = b;
   v.nrhs = (int)h->nrhs;
-  ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, h->nrhs, true, false));
+  ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, h->nrhs, true, false), moved_bytes(A, h->nrhs, true, false));
   return launch_csr<mgk::RESID>(h->stream, A, v);
 }
 int k_sumsq(mg_hierarchy* h, const double* x, long long len);
@@ -476,8 +626,7 @@ int k_sumsq(mg_hierarchy* h, const double* x, long long len);
 int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x, double* out,
                      double* xnext = nullptr, bool* xnext_done = nullptr, bool r_dead = false) {
   if (xnext_done) *xnext_done = false;
-  const int nb1 = A.blocks1();
-  if (h->nrhs != 1 || (size_t)nb1 > h->partial.n) {
+  if (h->nrhs != 1 || (size_t)std::max(A.blocks1(), A.nblocks) > h->partial.n) {
     MG_TRY(k_residual(h, level, A, b, x, out));
     return k_sumsq(h, out, A.n_rows * h->nrhs);
   }
@@ -487,8 +636,9 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
   v.b = b;
   v.nrhs = 1;
   v.sumsq = h->partial.p;
-  if (xnext && A.has_rc && A.rc_tile && A.rc_nexc == 0 && out != x && xnext != x && h->relax_type == 0 &&
-      &A == &h->lev[(size_t)level].A && !std::getenv("MG_NO_FUSED_NEXT")) {
+  // the LDS-staged row-class kernels (march, tile) have x, r and the class's relaxPrec at hand: second output
+  if (xnext && A.has_rc && (A.rc_tile || march_ok(A, v)) && A.rc_nexc == 0 && out != x && xnext != x && h->relax_type == 0 &&
+      &A == &h->lev[(size_t)level].A && !h->opt.no_fused_next) {
     v.y2 = xnext;
     if (r_dead) v.y = nullptr;
     v.xs = x;
@@ -496,11 +646,13 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
     v.d_full = h->lev[(size_t)level].d.p;
     if (xnext_done) *xnext_done = true;
   }
+  int nb1 = 0;
   {
-    ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false) + ((v.y2 && v.y) ? 8.0 * (double)A.n_rows : 0.0));
-    MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v));
+    ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false) + ((v.y2 && v.y) ? 8.0 * (double)A.n_rows : 0.0),
+                 moved_bytes(A, 1, true, false) - (v.y ? 0.0 : 8.0 * (double)A.n_rows) + (v.y2 ? 8.0 * (double)A.n_rows : 0.0));
+    MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v, &nb1));
   }
-  ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1);
+  ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
   const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
   hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
   hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
@@ -522,8 +674,35 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
   // the level's own relaxPrec, constant per row class: read from the dictionary instead of streamed (rc_d)
   if (h->nrhs == 1 && A.has_rc && A.rc_has_d && d == h->lev[(size_t)level].d.p && &A == &h->lev[(size_t)level].A) v.d = nullptr;
   v.nrhs = (int)h->nrhs;
-  ProfScope ps(h, level, MG_K_SMOOTH, spmv_bytes(A, h->nrhs, true, true));
+  ProfScope ps(h, level, MG_K_SMOOTH, spmv_bytes(A, h->nrhs, true, true), moved_bytes(A, h->nrhs, true, true, v.d == nullptr));
   return launch_csr<mgk::SMOOTH>(h->stream, A, v);
+}
+// Can the coarse-grid correction of level `level` ride in the staging of the first post-smoothing sweep?
+// (one right-hand side, pointwise smoother, A on the marching kernel, P in row-class form without exception rows)
+bool can_fuse_prolong(mg_hierarchy* h, int level, const double* x, const double* out) {
+  const Level& L = h->lev[(size_t)level];
+  if (h->opt.no_fuse_prolong || h->nrhs != 1 || h->relax_type != 0) return false;
+  if (!L.A.has_rc || !L.A.rc_march || !L.P.has_rc || L.P.rc_nexc != 0) return false;
+  return out != x && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+// out = xp + d.*(b - A*xp) with xp = x + P*xc: the prolongation (MGcycle.jl:90) and the first post-smoothing sweep
+// (l.92-102) in ONE pass over the level - x + P*xc exists only in LDS (x itself is left as it was).
+int k_smooth_prolong(mg_hierarchy* h, int level, const double* b, const double* x, const double* xc, double* out) {
+  Level& L = h->lev[(size_t)level];
+  mgk::VecArgs v{};
+  v.x = x;
+  v.xs = x;
+  v.y = out;
+  v.b = b;
+  v.d = L.A.rc_has_d ? nullptr : L.d.p;
+  v.d_full = L.d.p;
+  v.nrhs = 1;
+  mgk::ProDev Q{};
+  Q.Pm = L.P.rcdev();
+  Q.xc = xc;
+  ProfScope ps(h, level, MG_K_SMOOTH_PROLONG, spmv_bytes(L.A, 1, true, true) + spmv_bytes(L.P, 1, true, false),
+               moved_bytes(L.A, 1, true, true, v.d == nullptr) + format_bytes(L.P, 1) + 8.0 * (double)L.P.n_cols);
+  return launch_csr<mgk::SMOOTH>(h->stream, L.A, v, nullptr, &Q);
 }
 int k_dscale(mg_hierarchy* h, int level, const double* d, const double* b, double* x, long long n) {
   ProfScope ps(h, level, MG_K_DSCALE, 8.0 * (double)n * (1.0 + 2.0 * (double)h->nrhs));
@@ -793,14 +972,20 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
       MG_TRY(cycle_level(h, l + 1, C.b.p, xc, other, false, 'V', &xc));
     }
   }
-  // x += P xc (MGcycle.jl:90)
-  MG_TRY(k_spmv(h, l, MG_K_PROLONG, L.P, 1.0, xc, 1.0, cur));
-  // post-smoothing (MGcycle.jl:92-102)
+  // x += P xc (MGcycle.jl:90) and post-smoothing (l.92-102)
+  long long post_done = 0;
+  if (can_fuse_prolong(h, l, cur, alt)) {   // prolongation fused into the staging of the first sweep
+    MG_TRY(k_smooth_prolong(h, l, b, cur, xc, alt));
+    std::swap(cur, alt);
+    post_done = 1;
+  } else {
+    MG_TRY(k_spmv(h, l, MG_K_PROLONG, L.P, 1.0, xc, 1.0, cur));
+  }
   if (h->relax_type == 1) {
     MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
     MG_TRY(fgmres_relax(h, l, L.r.p, cur, L.npost, diag_prec, gmresTol, L.relaxZ.p, L.relaxAZ.p, false));
   } else {
-    for (long long s = 0; s < npost; ++s) {
+    for (long long s = post_done; s < npost; ++s) {
       MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
       std::swap(cur, alt);
     }
@@ -858,7 +1043,7 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
   long long it = 0;
   double* cur = x;
   double* alt = L.x1.p;
-  const bool dbg = std::getenv("MG_DEBUG_TIMING") != nullptr;
+  const bool dbg = h->opt.debug_timing;
   auto tprev = std::chrono::steady_clock::now();
   bool x1_ready = false;
   for (long long count = 1; count <= maxIter; ++count) {
@@ -1204,7 +1389,7 @@ int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const st
 int build_tile(Csr& A, const long long grid[3]) {
   A.rc_tile = false;
   if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty()) return MG_OK;
-  if (const char* e = std::getenv("MG_NO_TILE")) if (e[0] == '1') return MG_OK;
+  if (A.opt.no_tile) return MG_OK;
   if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != A.n_rows) return MG_OK;
   const long long P = grid[0] * grid[1];
   if (P < mgk::RT_CR / 2 || A.n_rows + (mgk::RT_NP + 2) * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
@@ -1214,8 +1399,7 @@ int build_tile(Csr& A, const long long grid[3]) {
   };
   const int cm = A.rc_major;
   {
-    long long min_len = 1;    // as for the window kernel
-    if (const char* ml = std::getenv("MG_STAGE_MIN_LEN")) min_len = std::atoll(ml);
+    const long long min_len = A.opt.stage_min_len;    // as for the window kernel
     if (A.h_rc_ptr[(size_t)cm + 1] - A.h_rc_ptr[(size_t)cm] < min_len) return MG_OK;
   }
   long long halo = 1;
@@ -1244,11 +1428,56 @@ int build_tile(Csr& A, const long long grid[3]) {
   {
     // 4096 rows per workgroup: a level that yields fewer workgroups than the chip has CUs is latency-bound and runs
     // faster on the 256/512-row kernels (C2 level 3, 65^3 rows: 85 workgroups, 26 us against 17 us)
-    long long min_wg = 256;
-    if (const char* e = std::getenv("MG_TILE_MIN_WG")) min_wg = std::atoll(e);
-    if (A.rt_nblocks < min_wg) return MG_OK;
+    if (A.rt_nblocks < A.opt.tile_min_wg) return MG_OK;
   }
   A.rc_tile = true;
+  return MG_OK;
+}
+
+// z-marching form (csr_rowclass_march_spmv): same preconditions as the plane tiles; the workgroups are one balanced
+// round of the resident slots (2 per CU), each with at least 8 planes to walk.
+int build_march(Csr& A, const long long grid[3]) {
+  A.rc_march = false;
+  if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march) return MG_OK;
+  if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != A.n_rows) return MG_OK;
+  const long long P = grid[0] * grid[1];
+  if (P < 64 || A.n_rows + 4 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
+  auto split = [&](long long sh, long long& dz, long long& rest) {
+    dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
+    rest = sh - dz * P;
+  };
+  const int cm = A.rc_major;
+  if (A.h_rc_ptr[(size_t)cm + 1] - A.h_rc_ptr[(size_t)cm] < A.opt.stage_min_len) return MG_OK;
+  long long halo = 1;
+  for (int k = A.h_rc_ptr[(size_t)cm]; k < A.h_rc_ptr[(size_t)cm + 1]; ++k) {
+    long long dz, rest;
+    split((long long)A.h_rc_delta[(size_t)cm] + A.h_rc_off[(size_t)k], dz, rest);
+    if (dz < -1 || dz > 1) return MG_OK;
+    halo = std::max(halo, rest < 0 ? -rest : rest);
+  }
+  if (halo > 510) return MG_OK;   // one 16-byte pair per thread covers the slab
+  std::vector<int> lbs(A.h_rc_off.size(), -1);
+  for (size_t c = 0; c + 1 < A.h_rc_ptr.size(); ++c)
+    for (int k = A.h_rc_ptr[c]; k < A.h_rc_ptr[c + 1]; ++k) {
+      long long dz, rest;
+      split((long long)A.h_rc_delta[c] + A.h_rc_off[(size_t)k], dz, rest);
+      if (dz >= -1 && dz <= 1 && rest >= -halo && rest <= halo) lbs[(size_t)k] = (int)(((rest + halo) << 2) | (dz + 1));
+    }
+  const long long chunks = (P + mgk::RM_C - 1) / mgk::RM_C;
+  const long long items = chunks * grid[2];
+  int dev = 0, ncu = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const long long nb = std::max<long long>(1, std::min<long long>(2LL * ncu, items / 8));
+  if (nb < A.opt.march_min_wg) return MG_OK;   // small levels: latency-bound, the other kernels serve them
+  MG_TRY(A.rm_lb.alloc(lbs.size()));
+  HIP_TRY(hipMemcpy(A.rm_lb.p, lbs.data(), lbs.size() * sizeof(int), hipMemcpyHostToDevice));
+  A.rm_P = (int)P;
+  A.rm_nplanes = (int)grid[2];
+  A.rm_halo = (int)halo;
+  A.rm_chunks = (int)chunks;
+  A.rm_nblocks = (int)nb;
+  A.rc_march = true;
   return MG_OK;
 }
 
@@ -1265,8 +1494,7 @@ int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const st
   // gathered-vector bytes per (y,z) line of the row grid, three z-planes in the window
   const double line_bytes = 3.0 * ((double)M.n_cols / (double)(n2 * n3)) * 8.0 * (double)nrhs;
   const double plane_window = line_bytes * (double)n2;
-  double budget = 2.0e6;  // of the 4 MiB per-XCD L2 (the rest: matrix stream, b/d/out lines)
-  if (const char* e = std::getenv("MG_SCHED_BUDGET")) budget = std::max(1.0, atof(e));  // tests force tiling
+  const double budget = M.opt.sched_budget;  // default 2 MB of the 4 MiB per-XCD L2 (the rest: matrix stream, b/d/out lines); tests force tiling
   if (plane_window <= budget) return MG_OK;  // natural order already keeps the window in L2
   long long T = (long long)(budget / line_bytes);
   T = std::max<long long>(4, std::min<long long>(T, n2));
@@ -1288,12 +1516,12 @@ int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const st
 int alloc_scratch(mg_hierarchy* h) {
   const long long k = h->nrhs;
   if (h->coarse_lu) MG_TRY(h->luWork.alloc((size_t)h->n_coarse * (size_t)k));
-  const char* no_sched = std::getenv("MG_NO_SCHED");
-  if (!(no_sched && no_sched[0] == '1')) {
+  if (!h->opt.no_sched) {
     for (int l = 0; l < (int)h->nlevels; ++l) {
       Level& L = h->lev[(size_t)l];
       MG_TRY(build_schedule(L.A, L.grid, k));
       MG_TRY(build_tile(L.A, L.grid));
+      MG_TRY(build_march(L.A, L.grid));
       MG_TRY(build_schedule(L.P, L.grid, k));
       if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
     }
@@ -1395,8 +1623,7 @@ int build_patterns(Csr* M, const std::vector<int>& rp, const std::vector<int>& c
   M->has_pat = true;
   // run-length form of the row descriptors, per row block
   {
-    const char* e = std::getenv("MG_NO_RUNS");
-    if (e && e[0] == '1') return MG_OK;
+    if (M->opt.no_runs) return MG_OK;
     // the descriptors are 10 B/row: worth compressing next to 56 B/row of values (7-point), not next to
     // 216 B/row (27-point), where the run lookup costs more than it saves (measured -5 % / +4 %)
     if (M->nnz >= 16 * n) return MG_OK;
@@ -1513,8 +1740,8 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   std::sort(order.begin(), order.end(), [&](int x, int y) { return freq[(size_t)x] != freq[(size_t)y] ? freq[(size_t)x] > freq[(size_t)y] : x < y; });
   std::vector<int> remap(nraw, 0xFFFF), cptr(1, 0), coff, cdelta;
   std::vector<double> cval;
-  long long covered = 0, nsingle = 0, keep_single = 1024;   // MG_ROWCLASS_KEEP_SINGLETONS: tests
-  if (const char* e = std::getenv("MG_ROWCLASS_KEEP_SINGLETONS")) keep_single = std::atoll(e);
+  long long covered = 0, nsingle = 0;
+  const long long keep_single = M->opt.rowclass_keep_singletons;   // default 1024; tests
   for (size_t c = 0; c < nraw; ++c) nsingle += freq[c] == 1;
   for (size_t t = 0; t < nraw && cptr.size() - 1 < 65535; ++t) {
     const int c = order[t];
@@ -1531,8 +1758,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     covered += freq[(size_t)c];
   }
   {
-    double min_cover = 0.9;
-    if (const char* e = std::getenv("MG_ROWCLASS_MIN_COVER")) min_cover = std::atof(e);
+    const double min_cover = M->opt.rowclass_min_cover;
     if (cptr.size() < 2 || (double)covered < min_cover * (double)n) return MG_OK;
   }
   std::vector<unsigned short> cid((size_t)n, 0);
@@ -1549,9 +1775,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     // classes.  Measured on C2: levels of 35 937 rows and fewer (every wave sees a dozen classes, and the whole level
     // is L2-resident anyway) ran 3x slower than with the streaming kernels -> require <= 4 classes per wave on
     // average, and enough rows for the matrix stream to matter.
-    long long min_rows = 100000, max_passes = 4;   // MG_ROWCLASS_MIN_ROWS / MG_ROWCLASS_MAX_PASSES: tests, A/B
-    if (const char* e = std::getenv("MG_ROWCLASS_MIN_ROWS")) min_rows = std::atoll(e);
-    if (const char* e = std::getenv("MG_ROWCLASS_MAX_PASSES")) max_passes = std::atoll(e);
+    const long long min_rows = M->opt.rowclass_min_rows, max_passes = M->opt.rowclass_max_passes;   // 100000 / 4; tests, A/B
     if (n < min_rows) return MG_OK;
     long long passes = 0, waves = 0;
     for (long long w0 = 0; w0 < n; w0 += 64) {
@@ -1584,12 +1808,10 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
       }
       passes2 += ns;
     }
-    const char* np = std::getenv("MG_NO_PAIR");
     // (only where a wave really holds alternating classes: uniform operators measured slower this way, R1 70 -> 84 us)
     // and only on large operators - C2's level 3 (65^3 rows, 4 classes per wave) ran 30 % slower paired
-    long long pair_min = 1000000;
-    if (const char* pm = std::getenv("MG_PAIR_MIN_ROWS")) pair_min = std::atoll(pm);
-    pair_choice = !(np && np[0] == '1') && n >= pair_min && 2 * passes >= 3 * waves && 10 * passes2 <= 7 * passes;
+    const long long pair_min = M->opt.pair_min_rows;
+    pair_choice = !M->opt.no_pair && n >= pair_min && 2 * passes >= 3 * waves && 10 * passes2 <= 7 * passes;
   }
   if (cdelta.empty()) cdelta.push_back(0);
   if (!implicit) MG_TRY(M->rc_first.alloc(first.size()));
@@ -1618,7 +1840,6 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   M->h_rc_off = coff;
   M->h_rc_delta = cdelta;
   if (implicit) {   // LDS-window kernel: do the windows of the most frequent class fit for a full workgroup of rows?
-    const char* e = std::getenv("MG_NO_WINDOW");
     std::vector<long long> cnt(cptr.size() - 1, 0);
     for (long long i = 0; i < n; ++i)
       if (cid[(size_t)i] != 0xFFFF) cnt[cid[(size_t)i]]++;
@@ -1627,12 +1848,10 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     const int ps = cptr[cm], len = cptr[cm + 1] - ps;
     // MG_STAGE_MIN_LEN: shortest class worth staging (A/B switch; measured on C2, profiles/r01_nt_ab.md:
     // -25 % on the 27-point levels, -5 % on the 7-point one with the spill-free tile kernel)
-    long long min_len = 1;
-    if (const char* ml = std::getenv("MG_STAGE_MIN_LEN")) min_len = std::atoll(ml);
+    const long long min_len = M->opt.stage_min_len;
     // small levels are latency-bound and faster on the plain kernel (C2 level 3, 65^3 rows: 15 us against 23 us)
-    long long min_wg = 2048;
-    if (const char* mw = std::getenv("MG_WINDOW_MIN_WG")) min_wg = std::atoll(mw);
-    bool ok = !(e && e[0] == '1') && len >= min_len && len <= mgk::RW_MAXLEN && 2 * cnt[cm] >= n &&
+    const long long min_wg = M->opt.window_min_wg;
+    bool ok = !M->opt.no_window && len >= min_len && len <= mgk::RW_MAXLEN && 2 * cnt[cm] >= n &&
               (n + mgk::RW_ROWS - 1) / mgk::RW_ROWS >= min_wg;
     if (ok) {
       const long long W = mgk::RW_ROWS;
@@ -1687,8 +1906,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
 // Square operators first try the form without a first-column stream (the class also fixes first column - row).
 int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
   if (M->n_rows == M->n_cols) {
-    const char* e = std::getenv("MG_NO_IMPLICIT_FIRST");
-    if (!(e && e[0] == '1')) {
+    if (!M->opt.no_implicit_first) {
       MG_TRY(build_rowclasses_try(M, rp, ci, val, true));
       if (M->has_rc) return MG_OK;
     }
@@ -1700,7 +1918,7 @@ int derive_class_d(Level& L) {
   Csr& A = L.A;
   A.rc_has_d = false;
   if (!A.has_rc || A.h_cls.size() != (size_t)A.n_rows || L.d.n != (size_t)A.n_rows) return MG_OK;
-  if (const char* e = std::getenv("MG_NO_CLASS_D")) if (e[0] == '1') return MG_OK;
+  if (A.opt.no_class_d) return MG_OK;
   std::vector<double> hd((size_t)A.n_rows), dc((size_t)A.rc_ncls, 0.0);
   std::vector<char> seen((size_t)A.rc_ncls, 0);
   HIP_TRY(hipMemcpy(hd.data(), L.d.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1715,10 +1933,6 @@ int derive_class_d(Level& L) {
   A.rc_has_d = true;
   return MG_OK;
 }
-bool rowclass_enabled() {
-  const char* e = std::getenv("MG_NO_ROWCLASS");
-  return !(e && e[0] == '1');
-}
 // New values on the stored pattern (mg_replace_values_FP64, mg_rap_FP64): the classes are re-derived from the host
 // pattern kept for that purpose; an operator that is no longer redundant falls back to the streaming kernels.
 int refresh_rowclasses(Csr* M, const double* val) {
@@ -1730,7 +1944,7 @@ int refresh_rowclasses(Csr* M, const double* val) {
 // Validate Julia's (colptr,rowval,nzval) of the transposed CSC (1-based Int64), convert to 0-based int32
 // CSR (the reference's C side does the -1 per access, parRelax.h:24-27), cut the rows into row blocks
 // and upload.
-int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colptr,
+int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, const long long* colptr,
                const long long* rowval, const double* nzval) {
   if (n_rows < 1 || n_cols < 1 || !colptr || !rowval || !nzval)
     return fail(MG_ERR_INVALID, "empty operator or null array");
@@ -1771,6 +1985,7 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
   std::vector<int> blk = make_blocks(mgk::MAXROWS, mgk::CHUNK);
   std::vector<int> blk_mm = make_blocks(mgk::MM_MAXROWS, mgk::MM_CHUNK);
   M->release();
+  M->opt = opt;
   M->n_rows = n_rows;
   M->n_cols = n_cols;
   M->nnz = nnz;
@@ -1796,8 +2011,8 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
   // 256 MiB Infinity Cache between two uses anyway (measured, profiles/r01_nt_ab.md: +2..17 % on the
   // 685 MB..1.4 GB operators of C2, -5..25 % on the 89 MB ones); MG_NT=0/1 forces one policy
   M->nt = (12.0 * (double)nnz > 128.0e6);
-  if (const char* e = std::getenv("MG_NT")) M->nt = (e[0] == '1');
-  if (rowclass_enabled()) {  // few distinct rows (offsets AND values): no matrix stream at all at nrhs == 1
+  if (M->opt.nt >= 0) M->nt = (M->opt.nt == 1);
+  if (!M->opt.no_rowclass) {  // few distinct rows (offsets AND values): no matrix stream at all at nrhs == 1
     MG_TRY(build_rowclasses(M, rp.data(), ci.data(), nzval));
     if (M->has_rc) {
       M->h_rp = rp;
@@ -1805,11 +2020,9 @@ int upload_csr(Csr* M, long long n_rows, long long n_cols, const long long* colp
     }
   }
   {  // pattern-code the column indices when the operator has few distinct row patterns (grid operators)
-    const char* e = std::getenv("MG_NO_PATTERN");
-    if (!(e && e[0] == '1')) MG_TRY(build_patterns(M, rp, ci));
+    if (!M->opt.no_pattern) MG_TRY(build_patterns(M, rp, ci));
   }
-  if (const char* e = std::getenv("MG_DEBUG_FORMAT"))
-    if (e[0] == '1')
+  if (M->opt.debug_format)
       std::fprintf(stderr, "[mgvcycle] operator %lld x %lld, nnz %lld: row classes %lld (dictionary %lld, exception rows %d, "
                    "implicit first %d, window %d, paired rows %d), patterns %lld\n", M->n_rows, M->n_cols, M->nnz, M->has_rc ? M->rc_ncls : 0,
                    M->has_rc ? M->rc_entries : 0, M->rc_nexc, (int)M->rc_implicit, (int)M->rc_window, (int)M->rc_pair,
@@ -1847,6 +2060,7 @@ int mg_create(long long nlevels, long long nrhs, long long device_id, mg_hierarc
   if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
   HIP_TRY(hipSetDevice((int)device_id));
   mg_hierarchy* h = new mg_hierarchy();
+  h->opt = Options::from_env();   // the only place the environment is read for this handle
   h->device = (int)device_id;
   h->nlevels = nlevels;
   h->nrhs = nrhs;
@@ -1915,7 +2129,10 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
     MG_TRY(refresh_rowclasses(&Ac, hv.data()));
   }
   for (int l = 0; l + 1 < nl; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));   // relaxPrecs were recomputed above
-  for (int l = 0; l < nl; ++l) MG_TRY(build_tile(h->lev[(size_t)l].A, h->lev[(size_t)l].grid));   // tile tables follow the new classes
+  for (int l = 0; l < nl; ++l) {   // tile / march tables follow the new classes
+    MG_TRY(build_tile(h->lev[(size_t)l].A, h->lev[(size_t)l].grid));
+    MG_TRY(build_march(h->lev[(size_t)l].A, h->lev[(size_t)l].grid));
+  }
   if (levels_done) *levels_done = nl - 1;
   return MG_OK;
 }
@@ -1994,7 +2211,7 @@ int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which
   if ((which == MG_OP_P || which == MG_OP_R) && level == h->nlevels)
     return fail(MG_ERR_INVALID, "the coarsest level %lld has no transfer operators", level);
   (void)hipSetDevice(h->device);
-  MG_TRY(upload_csr(M, n_rows, n_cols, colptr, rowval, nzval));
+  MG_TRY(upload_csr(M, h->opt, n_rows, n_cols, colptr, rowval, nzval));
   h->finalized = false;
   return MG_OK;
 }
@@ -2014,6 +2231,21 @@ int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long lo
   L.A.rc_has_d = false;   // re-derived by mg_finalize
   L.npre = relaxPre;
   L.npost = relaxPost;
+  h->finalized = false;
+  return MG_OK;
+}
+
+// Override one format-selection switch of this handle (the names of DESIGN.md's table without the MG_ prefix, lower
+// case: "no_rowclass", "no_tile", "tile_min_wg", ...).  Takes effect for operators uploaded afterwards and for the next
+// mg_finalize; call it right after mg_create.
+int mg_set_option(mg_hierarchy* h, const char* key, double value) {
+  if (!h || !key) return fail(MG_ERR_INVALID, "null argument");
+  if (!h->opt.set(key, value, false)) return fail(MG_ERR_INVALID, "unknown option '%s'", key);
+  for (auto& L : h->lev) {
+    L.A.opt = h->opt;
+    L.P.opt = h->opt;
+    L.R.opt = h->opt;
+  }
   h->finalized = false;
   return MG_OK;
 }
@@ -2237,6 +2469,7 @@ int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, co
     Level& L = h->lev[(size_t)level - 1];
     if (L.relax_set) MG_TRY(derive_class_d(L));
     MG_TRY(build_tile(L.A, L.grid));
+    MG_TRY(build_march(L.A, L.grid));
   }
   return MG_OK;
 }
@@ -2531,6 +2764,14 @@ int mg_profile_get(mg_hierarchy* h, long long level, long long kernel, double* t
   return MG_OK;
 }
 
+int mg_profile_get_moved(mg_hierarchy* h, long long level, long long kernel, double* moved_bytes_per_launch) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (level < 1 || level > h->nlevels || kernel < 0 || kernel >= MG_K_COUNT || !moved_bytes_per_launch)
+    return fail(MG_ERR_INVALID, "bad (level=%lld, kernel=%lld)", level, kernel);
+  *moved_bytes_per_launch = h->slots[(size_t)(level - 1) * MG_K_COUNT + (size_t)kernel].moved;
+  return MG_OK;
+}
+
 int mg_operator_format(mg_hierarchy* h, long long level, long long which, long long* npatterns,
                        long long* dict_entries, double* index_bytes_per_launch) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
@@ -2574,7 +2815,7 @@ int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which
   if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
   if (implicit_first) *implicit_first = (M->has_rc && M->rc_implicit) ? 1 : 0;
   if (class_relax) *class_relax = (M->has_rc && M->rc_has_d) ? 1 : 0;
-  if (kernel_variant) *kernel_variant = !M->has_rc ? -1 : M->rc_tile ? 2 : M->rc_window ? 1 : 0;
+  if (kernel_variant) *kernel_variant = !M->has_rc ? -1 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : 0;
   if (exception_rows) *exception_rows = M->has_rc ? M->rc_nexc : 0;
   return MG_OK;
 }
@@ -2632,7 +2873,7 @@ int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_c
   HIP_TRY(hipSetDevice((int)device_id));
   mg_operator* op = new mg_operator();
   op->device = (int)device_id;
-  const int rc = upload_csr(&op->M, n_rows, n_cols, colptr, rowval, nzval);
+  const int rc = upload_csr(&op->M, Options::from_env(), n_rows, n_cols, colptr, rowval, nzval);
   if (rc != MG_OK) {
     op->M.release();
     delete op;

@@ -24,8 +24,8 @@ LIB_PATH = os.environ.get("MGVCYCLE_LIB") or os.path.join(_HERE, "csrc", "libmgv
 
 MG_OP_A, MG_OP_P, MG_OP_R = 0, 1, 2
 (MG_K_SPMV, MG_K_RESIDUAL, MG_K_SMOOTH, MG_K_RESTRICT, MG_K_PROLONG, MG_K_DSCALE, MG_K_COARSE,
- MG_K_NORM, MG_K_COUNT) = range(9)
-KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm"]
+ MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_COUNT) = range(10)
+KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm", "smooth+prolong"]
 
 _ll = C.c_longlong
 _dp = C.POINTER(C.c_double)
@@ -40,6 +40,7 @@ SIGNATURES = {
     "mg_set_cycle_type": (C.c_int, [_vp, _ll]),
     "mg_set_relax_type": (C.c_int, [_vp, _ll]),
     "mg_set_grid_hint": (C.c_int, [_vp, _ll, _ll, _ll, _ll]),
+    "mg_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "mg_set_coarse_dense_inverse_FP64": (C.c_int, [_vp, _ll, _dp]),
     "mg_set_coarse_lu_FP64_INT64": (C.c_int, [_vp, _ll, _lp, _lp, _dp, _lp, _lp, _dp, _lp, _lp]),
     "mg_set_coarse_gmres_FP64": (C.c_int, [_vp, _ll, _dp]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     "mg_profile_enable": (C.c_int, [_vp, _ll]),
     "mg_profile_get": (C.c_int, [_vp, _ll, _ll, _dp, _lp, _dp]),
     "mg_profile_reset": (C.c_int, [_vp]),
+    "mg_profile_get_moved": (C.c_int, [_vp, _ll, _ll, _dp]),
     "mg_operator_format": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
     "mg_operator_rowclasses": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
     "mg_operator_rowclass_flags": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _lp, _lp]),
@@ -153,7 +155,8 @@ DENSE_COARSE_MAX = 16384
 class DeviceHierarchy:
     """Owns one ``mg_hierarchy`` handle (HBM copy of As/Ps/Rs/relaxPrecs + coarse inverse)."""
 
-    def __init__(self, param, device_id: int = 0, nrhs: Optional[int] = None):
+    def __init__(self, param, device_id: int = 0, nrhs: Optional[int] = None, options: Optional[dict] = None):
+        """options: per-handle format switches (mg_set_option), e.g. {"no_rowclass": 1} forces the streaming formats."""
         self.lib = load_library()
         self.handle = _vp()
         self.nlevels = len(param.As)
@@ -162,6 +165,8 @@ class DeviceHierarchy:
         lib = self.lib
         _check(lib, lib.mg_create(self.nlevels, self.nrhs, int(device_id), C.byref(self.handle)), "mg_create")
         try:
+            for key, val in (options or {}).items():
+                _check(lib, lib.mg_set_option(self.handle, key.encode(), float(val)), f"mg_set_option({key})")
             self._upload(param)
         except Exception:
             self.close()
@@ -414,6 +419,16 @@ class DeviceHierarchy:
                        "mg_profile_get")
                 if n.value:
                     out[(l, KERNEL_NAMES[k])] = (ms.value, int(n.value), bts.value)
+        return out
+
+    def profile_moved(self):
+        """{(level, kernel_name): bytes one launch of the kernel in use has to move} (device format + each vector once)."""
+        out = {}
+        for (l, name) in self.profile():
+            mv = C.c_double(0)
+            _check(self.lib, self.lib.mg_profile_get_moved(self.handle, l, KERNEL_NAMES.index(name), C.byref(mv)),
+                   "mg_profile_get_moved")
+            out[(l, name)] = mv.value
         return out
 
     def operator_format(self, level: int, which: int):

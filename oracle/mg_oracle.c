@@ -163,3 +163,49 @@ i64 oracle_solveMG(const oracle_level* lev, i64 nlevels, const double* Ainv, con
 }
 
 i64 oracle_max_threads(void) { return (i64)omp_get_max_threads(); }
+
+/* ---- NUMA placement for the timed baseline (bench.py cpu_baseline) ---------------------------------------------
+ * numpy allocates and fills every array from ONE thread, so all pages of the hierarchy land on one NUMA node and the
+ * row-parallel loops above pull them across the socket interconnect.  These helpers clone an array into fresh
+ * (untouched) memory with the SAME static row partition the kernels use, so that each page is first touched - and
+ * therefore placed - by the thread that will stream it. */
+void* oracle_numa_clone_csr_FP64_INT64(i64 n_rows, const i64* colptr, const i64* rowval, const double* nzval,
+                                       i64** out_colptr, i64** out_rowval, double** out_nzval, i64 numCores) {
+  omp_set_num_threads((int)numCores);
+  const i64 nnz = colptr[n_rows] - 1;
+  i64* cp = (i64*)malloc(sizeof(i64) * (size_t)(n_rows + 1));
+  i64* rv = (i64*)malloc(sizeof(i64) * (size_t)(nnz > 0 ? nnz : 1));
+  double* nz = (double*)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+  if (!cp || !rv || !nz) { free(cp); free(rv); free(nz); return NULL; }
+#pragma omp parallel for schedule(static)
+  for (i64 i = 0; i < n_rows; ++i) {
+    cp[i] = colptr[i];
+    for (i64 k = colptr[i] - 1; k < colptr[i + 1] - 1; ++k) {
+      rv[k] = rowval[k];
+      nz[k] = nzval[k];
+    }
+  }
+  cp[n_rows] = colptr[n_rows];
+  *out_colptr = cp;
+  *out_rowval = rv;
+  *out_nzval = nz;
+  return cp;
+}
+double* oracle_numa_clone_vec(const double* src, i64 n, i64 nrhs, i64 numCores) {
+  omp_set_num_threads((int)numCores);
+  double* v = (double*)malloc(sizeof(double) * (size_t)(n * nrhs > 0 ? n * nrhs : 1));
+  if (!v) return NULL;
+  for (i64 c = 0; c < nrhs; ++c) {
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) v[c * n + i] = src ? src[c * n + i] : 0.0;
+  }
+  return v;
+}
+void oracle_copy_vec(const double* src, double* dst, i64 n, i64 nrhs, i64 numCores) {
+  omp_set_num_threads((int)numCores);
+  for (i64 c = 0; c < nrhs; ++c) {
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) dst[c * n + i] = src[c * n + i];
+  }
+}
+void oracle_free(void* p) { free(p); }

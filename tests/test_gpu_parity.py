@@ -624,3 +624,92 @@ def test_wrong_grid_hint_changes_nothing(mg, built, monkeypatch):
         assert h.lib.mg_finalize(h.handle) == 0
         _compare_solve(mg, p, b)
     mg.clear_(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells,levels,cyc,pre,post", [([33, 25, 7], 2, "V", 2, 1), ([40, 30, 9], 3, "W", 1, 2), ([23, 23, 23], 3, "V", 2, 1),
+                                                       ([70, 10, 12], 2, "F", 2, 2), ([64, 64, 20], 3, "V", 2, 1), ([31, 37], 3, "V", 2, 1)])
+def test_march_kernel_and_fused_prolongation(mg, built, monkeypatch, cells, levels, cyc, pre, post):
+    """csr_rowclass_march_spmv (z-marching ring of slabs) and the coarse-grid correction fused into the staging of the
+    first post-smoothing sweep: kernel-level products against scipy, the solve against the oracle, and bit-identical
+    iterates against the plane-tile kernel / the separate prolongation launch (same products, same order)."""
+    import torch
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    monkeypatch.setenv("MG_TILE_MIN_WG", "0")
+    monkeypatch.setenv("MG_WINDOW_MIN_WG", "0")
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    monkeypatch.setenv("MG_PAIR_MIN_ROWS", "0")
+    rng = np.random.default_rng(sum(cells) + 1)
+    runs = {}
+    for name, no_march, no_fuse in (("march+fused", "0", "0"), ("march", "0", "1"), ("tile", "1", "0")):
+        monkeypatch.setenv("MG_NO_MARCH", no_march)
+        monkeypatch.setenv("MG_NO_FUSE_PROLONG", no_fuse)
+        A, p, b = _setup(mg, cells, levels, "Jac", 0.8, pre, post, cyc, maxIter=5)
+        h = mg.to_device(p)
+        var = h.operator_kernel_variant(1, D.MG_OP_A)
+        if len(cells) == 3:
+            assert var == (3 if no_march == "0" else 2), var
+        for l in range(1, p.levels):
+            Al, dl = p.As[l - 1], p.relaxPrecs[l - 1]
+            xn, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+            x, bb = torch.from_numpy(xn).cuda(), torch.from_numpy(bn).cuda()
+            out = torch.zeros_like(x)
+            h.fused_dev(l, D.MG_K_RESIDUAL, bb, x, out)
+            want = bn - Al @ xn
+            assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
+            h.fused_dev(l, D.MG_K_SMOOTH, bb, x, out)
+            want = xn + dl * (bn - Al @ xn)
+            assert np.abs(out.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
+            y = torch.from_numpy(bn.copy()).cuda()
+            h.spmv_dev(l, D.MG_OP_A, -0.5, x, 2.0, y)
+            want = -0.5 * (Al @ xn) + 2.0 * bn
+            assert np.abs(y.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
+        x, hist = _compare_solve(mg, p, b)
+        # non-zero initial guess (the first sweep is a full fused sweep then) through the device entry point
+        x0 = rng.standard_normal(b.shape)
+        x1 = x0.copy()
+        mg.recursiveCycle(p, b, x1, 1)
+        xo = orc.recursiveCycle(p, b, x0.copy(), 1)
+        assert np.abs(x1 - xo).max() <= RES_TOL * np.abs(xo).max()
+        runs[name] = (x.copy(), np.asarray(p.resvec).copy(), x1.copy())
+        mg.clear_(p)
+    for other in ("march", "tile"):
+        assert np.array_equal(runs["march+fused"][0], runs[other][0]), other          # same products, same order
+        assert np.array_equal(runs["march+fused"][2], runs[other][2]), other
+        assert np.abs(runs["march+fused"][1] - runs[other][1]).max() <= 1e-14 * runs[other][1][0]
+
+
+@pytest.mark.gpu
+def test_march_with_wrong_grid_hint_and_exception_rows(mg, built, monkeypatch):
+    """The marching kernel with a hint that describes the wrong grid (unstaged shifts gather from global memory) and
+    with a few perturbed rows (exception rows computed from the CSR arrays): the solve is still the oracle's."""
+    import scipy.sparse as sp
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_KEEP_SINGLETONS", "0")
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    A, p, b = _setup(mg, [40, 30, 5], 2)                    # nodes 41 x 31 x 6
+    h = mg.to_device(p)
+    assert h.operator_kernel_variant(1, D.MG_OP_A) == 3
+    for wrong in ((6, 31, 41), (31, 41, 6), (41 * 31, 3, 2)):
+        assert h.lib.mg_set_grid_hint(h.handle, 1, *wrong) == 0
+        assert h.lib.mg_finalize(h.handle) == 0
+        _compare_solve(mg, p, b)
+    mg.clear_(p)
+    rng = np.random.default_rng(3)
+    A, mesh = mg.poisson_shifted([24, 20, 18])
+    A = A.tolil()
+    for i in rng.choice(A.shape[0], size=6, replace=False):
+        A[i, i] = A[i, i] * (1.0 + rng.random())
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    p = mg.getMGparam(np.float64, np.int64, 2, 8, 6, 1e-10, "Jac", 0.8, 2, 1)
+    mg.MGsetup(A, mesh, p, 1)
+    bb = mg.seeded_rhs(A, 1)
+    _compare_solve(mg, p, bb)
+    assert p.device.operator_kernel_info(1, D.MG_OP_A) == (3, 6)
+    mg.clear_(p)
