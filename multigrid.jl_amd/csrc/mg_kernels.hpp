@@ -871,118 +871,61 @@ __global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_til
 
 // ------------------------------------------------------------------------------------------------
 // Row-class SpMV marching along z (square operators in the implicit-first form with a grid hint; P = n1*n2 rows per
-// plane).  The plane-tile kernel above re-stages RT_NP + 2 slabs for RT_NP planes and alternates a load phase with a
-// compute phase; here a workgroup owns ONE in-plane chunk of RM_C rows and walks a run of consecutive planes with a ring
-// of four slabs in LDS: every plane of x is staged once per chunk (in-plane halo rows come from the neighbour chunk's
-// lines in L2), the slab of plane z+3 is in flight in registers while plane z is computed, and there is one barrier
-// per plane.  The (chunk, plane) items are dealt to the workgroups as equal contiguous ranges of the chunk-major
-// list, so a launch is exactly one balanced round of the resident workgroups whatever the grid (a range that runs off
-// the end of a chunk continues at plane 0 of the next one).  Slabs start at an EVEN global index so that the staging
-// loads are 16 bytes per lane; the 0/1 entry shift this causes is a per-plane scalar.
+// plane).  Measured on C2's fine level (profiles/r02_march_ab.md): the plane-tile kernel above spends ~105 us in its
+// load phases (8-byte loads, six slabs per four planes) and ~90 us in the class passes (a chain of scalar dictionary
+// loads -> LDS read -> FMA per entry), overlapping only across the two workgroups of a CU.  Here
+//  * a workgroup owns ONE in-plane chunk of RM_C rows and walks a run of consecutive planes with a ring of four slabs
+//    in LDS: every plane of x is staged once per chunk (in-plane halo rows come from the neighbour chunk's lines in
+//    L2), with 16-byte loads (slabs start at an even global index; the 0/1 entry shift is a per-plane scalar);
+//  * the loads of plane z+3 are in flight in registers while plane z is computed; everything loaded is consumed at the
+//    top of the next iteration and the stores of a plane are issued one iteration late, so the one vector-memory wait
+//    per iteration never stalls on anything younger than a plane's worth of work; one barrier per plane;
+//  * the class dictionary lives in LDS as 16-byte records {value, LDS index code} and every LANE walks the entries of
+//    its own row's class (ascending k: the summation order of the CSR row): no waterfall passes, no scalar chain -
+//    boundary rows cost nothing extra, and the compiler can keep several LDS reads in flight;
+//  * the (chunk, plane) items are dealt to the workgroups as equal contiguous ranges of the chunk-major list, so a
+//    launch is exactly one balanced round of the resident workgroups (a range that runs off the end of a chunk
+//    continues at plane 0 of the next one).
 // Optional prologue (PRO): the staged vector is x + Pm*xc instead of x - the coarse-grid correction x += P*xc
 // (MGcycle.jl:90) is applied while the slab passes through registers, in the arithmetic of the stand-alone product
 // (entries in stored order, then 1.0*acc + x), so the post-smoothing sweep needs no prolongation launch and x is not
-// read-modified-written in HBM.  Correct for ANY operator in this form: entries whose shift is not dz*P + rest with
-// |dz| <= 1, |rest| <= halo gather from global memory (never the case for a grid operator).
+// read-modified-written in HBM.
+// The host selects this kernel only when EVERY dictionary entry of every class is a staged shift dz*P + rest with
+// |dz| <= 1, |rest| <= halo (true for grid operators; anything else keeps the plane-tile kernel and its global gathers).
 // ------------------------------------------------------------------------------------------------
 constexpr int RM_C = 1024;    // rows of a plane per workgroup = threads per workgroup
 constexpr int RM_RING = 4;    // slabs in LDS: planes z-1, z, z+1 in use, z+2 being written
+constexpr int RM_DCAP = 512;  // dictionary entries of the operator
+constexpr int RM_NCLS = 128;  // classes of the operator
+constexpr int RM_PDCAP = 128; // dictionary entries / classes of the fused prolongation
+constexpr int RM_PNCLS = 64;
+constexpr int RM_DICT_BYTES = 16 * RM_DCAP + 8 * RM_NCLS + 4 * (RM_NCLS + 4) + 16 * RM_PDCAP + 4 * (RM_PNCLS + 4) + 4 * RM_PNCLS;
 
 struct MarchDev {
-  const int* lb;     // per dictionary entry: ((rest + halo) << 2) | (dz + 1), or -1: gather from global memory
+  const int* lb;     // per dictionary entry: ((rest + halo) << 2) | (dz + 1)   (all >= 0: host check)
   int P;             // rows per plane
   int nplanes;       // n_rows == nplanes * P
   int halo;          // slab = RM_C + 2*halo entries of x (+ alignment pad)
   int chunks;        // ceil(P / RM_C)
   int nblocks;       // workgroups; each gets chunks*nplanes/nblocks consecutive (chunk, plane) items
   int n_cols;
+  int ncls, nent;    // classes / dictionary entries (<= RM_NCLS / RM_DCAP)
+  int maxlen;        // longest class
 };
 
-// The coarse-grid correction fused into the staging of csr_rowclass_march_spmv: Pm in row-class form (any variant).
+// The coarse-grid correction fused into the staging of csr_rowclass_march_spmv: Pm in row-class form (any variant
+// without exception rows; at most RM_PNCLS classes / RM_PDCAP entries; longest class maxlen).
 struct ProDev {
   RowClassDev Pm;
   const double* xc;
+  int ncls, nent, maxlen;
 };
 
-// (Pm*xc)[row] for the lane's two consecutive rows e0, e0+1 (waterfall over Pm's classes as in csr_rowclass_spmv's
-// PAIR form: a prolongation alternates classes from row to row).  Rows outside [0, n) contribute 0.
-__device__ __forceinline__ void march_prolong_pair(const ProDev& Q, long long e0, bool act, double& p0, double& p1) {
-  const RowClassDev& C = Q.Pm;
-  int first[2], cls[2];
-  bool ok[2];
-  double acc[2] = {0.0, 0.0};
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long long r = e0 + j;
-    ok[j] = act && r >= 0 && r < C.n_rows;
-    const int rr = ok[j] ? (int)r : 0;
-    cls[j] = C.cls[rr];
-    first[j] = C.firstcol ? C.firstcol[rr] : rr;
-    ok[j] = ok[j] && cls[j] != 0xFFFF;
-  }
-  const unsigned long long lanebit = 1ull << (threadIdx.x & 63);
-  unsigned long long todo[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) todo[j] = __ballot(ok[j]);
-  for (;;) {
-    int cc = 0, lead = 0;
-    bool any = false;
-#pragma unroll
-    for (int j = 1; j >= 0; --j)
-      if (todo[j]) {
-        const int l = __builtin_ctzll(todo[j]);
-        cc = __builtin_amdgcn_readlane(cls[j], l);
-        lead = __builtin_amdgcn_readlane(first[j], l);
-        any = true;
-      }
-    if (!any) break;
-    const int delta = C.firstcol ? 0 : C.cls_delta[cc];
-    lead += delta;
-    bool in[2];
-    const double* xb[2];
-    double a[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const unsigned long long m = __ballot(cls[j] == cc) & todo[j];
-      todo[j] &= ~m;
-      in[j] = (m & lanebit) != 0;
-      xb[j] = Q.xc + (in[j] ? first[j] + delta : lead);
-      a[j] = 0.0;
-    }
-    const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
-    int k = s;
-    for (; k + 3 < e; k += 4) {
-      const int o0 = C.cls_off[k], o1 = C.cls_off[k + 1], o2 = C.cls_off[k + 2], o3 = C.cls_off[k + 3];
-      const double a0 = C.cls_val[k], a1 = C.cls_val[k + 1], a2 = C.cls_val[k + 2], a3 = C.cls_val[k + 3];
-      double x0[2], x1[2], x2[2], x3[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        x0[j] = xb[j][o0];
-        x1[j] = xb[j][o1];
-        x2[j] = xb[j][o2];
-        x3[j] = xb[j][o3];
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        a[j] += a0 * x0[j];
-        a[j] += a1 * x1[j];
-        a[j] += a2 * x2[j];
-        a[j] += a3 * x3[j];
-      }
-    }
-    for (; k < e; ++k) {
-      const int o0 = C.cls_off[k];
-      const double a0 = C.cls_val[k];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) a[j] += a0 * xb[j][o0];
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (in[j]) acc[j] = a[j];
-  }
-  p0 = acc[0];
-  p1 = acc[1];
-}
+struct MarchEnt {   // one dictionary record in LDS
+  double val;
+  int code;         // A: LDS index code ((rest + halo) << 2 | dz + 1); Pm: column offset from the row's first column
+  int pad;
+};
 
 // one 16-byte pair of the slab: global entries e0, e0 + 1 (e0 even); clamped scalar loads at the ends of the vector
 // (no live row reads a clamped slot through a staged shift)
@@ -1000,17 +943,40 @@ __device__ __forceinline__ d2_t march_load_pair(const double* __restrict__ x, lo
   }
   return r;
 }
-// pair -> LDS; PRO: x + Pm*xc for the pair's two rows, in the arithmetic of the stand-alone AXPBY product
-// (alpha = beta = 1: 1.0*acc + 1.0*x)
-template <bool PRO>
-__device__ __forceinline__ d2_t march_stage(const ProDev& Q, long long e0, bool act, d2_t val) {
-  if (PRO) {
-    double p0, p1;
-    march_prolong_pair(Q, e0, act, p0, p1);
-    val.x = 1.0 * p0 + 1.0 * val.x;
-    val.y = 1.0 * p1 + 1.0 * val.y;
+
+// class ids and first columns of the prolongation's rows e0, e0 + 1 (prefetched one plane ahead of their use)
+struct ProRows {
+  int cls0, cls1, first0, first1;
+};
+__device__ __forceinline__ ProRows march_load_prorows(const RowClassDev& Pm, long long e0, bool act) {
+  ProRows r;
+  r.cls0 = r.cls1 = 0xFFFF;   // 0xFFFF: no contribution
+  r.first0 = r.first1 = 0;
+  if (act) {
+    if (e0 >= 0 && e0 + 1 < Pm.n_rows) {
+      const unsigned int cc = *reinterpret_cast<const unsigned int*>(Pm.cls + e0);   // e0 is even: 4-byte aligned
+      r.cls0 = (int)(cc & 0xFFFFu);
+      r.cls1 = (int)(cc >> 16);
+      if (Pm.firstcol) {
+        const i2_t f = *reinterpret_cast<const i2_t*>(Pm.firstcol + e0);
+        r.first0 = f.x;
+        r.first1 = f.y;
+      } else {
+        r.first0 = (int)e0;
+        r.first1 = (int)e0 + 1;
+      }
+    } else {
+      if (e0 >= 0 && e0 < Pm.n_rows) {
+        r.cls0 = Pm.cls[e0];
+        r.first0 = Pm.firstcol ? Pm.firstcol[e0] : (int)e0;
+      }
+      if (e0 + 1 >= 0 && e0 + 1 < Pm.n_rows) {
+        r.cls1 = Pm.cls[e0 + 1];
+        r.first1 = Pm.firstcol ? Pm.firstcol[e0 + 1] : (int)e0 + 1;
+      }
+    }
   }
-  return val;
+  return r;
 }
 
 template <int MODE, bool EXC, bool PRO>
@@ -1022,25 +988,89 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
   const int SL = RM_C + 2 * T.halo;
   const int SLP = (SL + 3) & ~1;                       // even, >= SL + 1 (the alignment shift)
   const int npair = (SL + 2) >> 1;                     // 16-byte pairs per slab (<= RM_C: host check)
+  // ---- LDS: ring of slabs | dictionaries ----------------------------------------------------------------------
+  MarchEnt* dent = reinterpret_cast<MarchEnt*>(win + RM_RING * SLP);      // [RM_DCAP]
+  double* dd = reinterpret_cast<double*>(dent + RM_DCAP);                 // [RM_NCLS] class relaxPrec
+  int* dptr = reinterpret_cast<int*>(dd + RM_NCLS);                       // [RM_NCLS + 1] (+3 pad)
+  MarchEnt* pent = reinterpret_cast<MarchEnt*>(dptr + RM_NCLS + 4);       // [RM_PDCAP]
+  int* pptr = reinterpret_cast<int*>(pent + RM_PDCAP);                    // [RM_PNCLS + 1] (+3 pad)
+  int* pdelta = pptr + RM_PNCLS + 4;                                      // [RM_PNCLS]
+  const bool class_d = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
+  for (int i = tid; i < T.nent; i += RM_C) {
+    MarchEnt e;
+    e.val = C.cls_val[i];
+    e.code = T.lb[i];
+    e.pad = 0;
+    dent[i] = e;
+  }
+  for (int i = tid; i <= T.ncls; i += RM_C) dptr[i] = C.cls_ptr[i];
+  for (int i = tid; i < T.ncls; i += RM_C) dd[i] = class_d ? C.cls_d[i] : 0.0;
+  if (PRO) {
+    for (int i = tid; i < Q.nent; i += RM_C) {
+      MarchEnt e;
+      e.val = Q.Pm.cls_val[i];
+      e.code = Q.Pm.cls_off[i];
+      e.pad = 0;
+      pent[i] = e;
+    }
+    for (int i = tid; i <= Q.ncls; i += RM_C) pptr[i] = Q.Pm.cls_ptr[i];
+    for (int i = tid; i < Q.ncls; i += RM_C) pdelta[i] = Q.Pm.firstcol ? 0 : Q.Pm.cls_delta[i];
+  }
   const long long tot = (long long)T.chunks * T.nplanes;
   long long it = tot * w / T.nblocks;
   const long long it_end = tot * (w + 1) / T.nblocks;
-  const unsigned long long lanebit = 1ull << lane;
-  const bool class_d = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
-  const bool own_lds = (v.xs == v.x) || PRO;
+  const bool pact = tid < npair;
   double sq = 0.0;
 
   // slab of plane p of chunk c: global entries [a0, a0 + 2*npair), a0 = even floor of p*P + c*RM_C - halo
 #define MARCH_G0(c, p) ((long long)(p) * T.P + (long long)(c) * RM_C - T.halo)
-#define MARCH_LOAD(c, p) march_load_pair(v.x, MARCH_G0(c, p) & ~1LL, tid < npair, T.n_cols)
-#define MARCH_STAGE(c, p, slot, val)                                                                    \
-  do {                                                                                                  \
-    const d2_t sv_ = march_stage<PRO>(Q, (MARCH_G0(c, p) & ~1LL) + 2 * tid, tid < npair, val);          \
-    if (tid < npair) {                                                                                  \
-      win[(slot) * SLP + 2 * tid] = sv_.x;                                                              \
-      win[(slot) * SLP + 2 * tid + 1] = sv_.y;                                                          \
-    }                                                                                                   \
+#define MARCH_E0(c, p) ((MARCH_G0(c, p) & ~1LL) + 2 * tid)
+  // (Pm*xc) for the pair's two rows: every lane walks the entries of its own rows' classes (dictionary in LDS), four
+  // entries of each row per trip - eight gathers of xc (global memory: L2) in flight, then the additions in stored
+  // order; rows without a class (cls 0xFFFF: outside the vector) contribute 0
+#define MARCH_PROLONG_PAIR(pr, out0_, out1_)                                                                           \
+  do {                                                                                                                 \
+    const bool ok0_ = (pr).cls0 != 0xFFFF, ok1_ = (pr).cls1 != 0xFFFF;                                                 \
+    const int c0_ = ok0_ ? (pr).cls0 : 0, c1_ = ok1_ ? (pr).cls1 : 0;                                                  \
+    const int s0_ = pptr[c0_], s1_ = pptr[c1_];                                                                        \
+    const int len0_ = ok0_ ? pptr[c0_ + 1] - s0_ : 0, len1_ = ok1_ ? pptr[c1_ + 1] - s1_ : 0;                          \
+    const double* xb0_ = Q.xc + ((pr).first0 + pdelta[c0_]);                                                           \
+    const double* xb1_ = Q.xc + ((pr).first1 + pdelta[c1_]);                                                           \
+    double a0_ = 0.0, a1_ = 0.0;                                                                                       \
+    for (int k_ = 0; k_ < Q.maxlen; k_ += 4) {                                                                         \
+      double g0_[4], g1_[4];                                                                                           \
+      const int m0_ = len0_ > 0 ? len0_ - 1 : 0, m1_ = len1_ > 0 ? len1_ - 1 : 0;                                      \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                               \
+        g0_[u_] = (k_ + u_ < len0_) ? xb0_[pent[s0_ + min(k_ + u_, m0_)].code] : 0.0;                                  \
+        g1_[u_] = (k_ + u_ < len1_) ? xb1_[pent[s1_ + min(k_ + u_, m1_)].code] : 0.0;                                  \
+      }                                                                                                                \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                               \
+        const double t0_ = a0_ + pent[s0_ + min(k_ + u_, m0_)].val * g0_[u_];                                          \
+        const double t1_ = a1_ + pent[s1_ + min(k_ + u_, m1_)].val * g1_[u_];                                          \
+        a0_ = (k_ + u_ < len0_) ? t0_ : a0_;                                                                           \
+        a1_ = (k_ + u_ < len1_) ? t1_ : a1_;                                                                           \
+      }                                                                                                                \
+    }                                                                                                                  \
+    (out0_) = a0_;                                                                                                     \
+    (out1_) = a1_;                                                                                                     \
   } while (0)
+  // pair -> LDS; PRO: x + P*xc in the arithmetic of the stand-alone product (alpha = beta = 1: 1.0*acc + 1.0*x)
+#define MARCH_STAGE(slot, val, pr)                                                                                     \
+  do {                                                                                                                 \
+    d2_t sv_ = (val);                                                                                                  \
+    if (PRO) {                                                                                                         \
+      double acc0_, acc1_;                                                                                             \
+      MARCH_PROLONG_PAIR(pr, acc0_, acc1_);                                                                            \
+      sv_.x = 1.0 * acc0_ + 1.0 * sv_.x;                                                                               \
+      sv_.y = 1.0 * acc1_ + 1.0 * sv_.y;                                                                               \
+    }                                                                                                                  \
+    if (pact) {                                                                                                        \
+      win[(slot) * SLP + 2 * tid] = sv_.x;                                                                             \
+      win[(slot) * SLP + 2 * tid + 1] = sv_.y;                                                                         \
+    }                                                                                                                  \
+  } while (0)
+
+  __syncthreads();   // dictionaries in place
   while (it < it_end) {
     const int c = (int)(it / T.nplanes);
     const int z0 = (int)(it - (long long)c * T.nplanes);
@@ -1049,13 +1079,25 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
     const int inplane = c * RM_C + tid;
     const bool rowlive = inplane < T.P;
     // ---- fill the ring: planes z0-1, z0, z0+1; plane z0+2 goes into registers -------------------------------------
-    {
-      const d2_t q0 = MARCH_LOAD(c, z0 - 1), q1 = MARCH_LOAD(c, z0), q2 = MARCH_LOAD(c, z0 + 1);
-      MARCH_STAGE(c, z0 - 1, 0, q0);
-      MARCH_STAGE(c, z0, 1, q1);
-      MARCH_STAGE(c, z0 + 1, 2, q2);
+    d2_t pre;
+    ProRows prow{};
+    if (PRO) {   // (one plane at a time: the fused prolongation needs the registers)
+#pragma unroll 1
+      for (int pp = 0; pp < 3; ++pp) {
+        const d2_t qq = march_load_pair(v.x, MARCH_E0(c, z0 - 1 + pp), pact, T.n_cols);
+        const ProRows rr = march_load_prorows(Q.Pm, MARCH_E0(c, z0 - 1 + pp), pact);
+        MARCH_STAGE(pp, qq, rr);
+      }
+    } else {
+      const d2_t q0 = march_load_pair(v.x, MARCH_E0(c, z0 - 1), pact, T.n_cols);
+      const d2_t q1 = march_load_pair(v.x, MARCH_E0(c, z0), pact, T.n_cols);
+      const d2_t q2 = march_load_pair(v.x, MARCH_E0(c, z0 + 1), pact, T.n_cols);
+      MARCH_STAGE(0, q0, prow);
+      MARCH_STAGE(1, q1, prow);
+      MARCH_STAGE(2, q2, prow);
     }
-    d2_t pre = MARCH_LOAD(c, z0 + 2);
+    pre = march_load_pair(v.x, MARCH_E0(c, z0 + 2), pact, T.n_cols);
+    if (PRO) prow = march_load_prorows(Q.Pm, MARCH_E0(c, z0 + 2), pact);
     int ncls;
     double npb = 0.0, npd = 0.0;
     {
@@ -1070,16 +1112,31 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
       }
     }
     __syncthreads();
+    // Every vector-memory result is consumed at the TOP of an iteration, one full iteration after it was issued, and
+    // the stores of a plane are issued at the top of the NEXT iteration: the single wait per iteration then never
+    // stalls on an operation younger than one plane's worth of work.
+    double st_out = 0.0, st_out2 = 0.0;
+    int st_row = -1;
     for (int z = z0; z < z1; ++z) {
       const int q = z - z0 + 1;                        // ring index of plane z (plane z0-1 is 0)
-      // ---- plane z+2 into its slot (that of plane z-2, last read before the previous barrier); plane z+3 in flight ----
-      if (z + 2 <= z1) MARCH_STAGE(c, z + 2, (q + 2) & 3, pre);   // (planes beyond z1 are not needed by this run)
-      const bool more = z + 1 < z1;
-      if (z + 3 <= z1) pre = MARCH_LOAD(c, z + 3);
-      const int cls = ncls;
-      const double pb = npb;
-      double pd = npd;
-      if (more) {
+      d2_t cur = pre;
+      ProRows crow = prow;
+      int cls = ncls;
+      double pb = npb, pd = npd;
+      asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cls), "+v"(pb), "+v"(pd));   // the wait of this iteration
+      if (PRO) asm volatile("" : "+v"(crow.cls0), "+v"(crow.cls1), "+v"(crow.first0), "+v"(crow.first1));
+      // ---- plane z+2 into its slot (that of plane z-2, last read before the previous barrier) ----------------------
+      if (z + 2 <= z1) MARCH_STAGE((q + 2) & 3, cur, crow);   // (planes beyond z1 are not needed by this run)
+      // ---- stores of plane z-1, then the loads of plane z+3 and of the row operands of plane z+1 ---------------------
+      if (st_row >= 0) {
+        if (MODE != RESID || v.y) v.y[st_row] = st_out;   // (the solve loop needs only ||r|| and x + d.*r: y may be null)
+        if (MODE == RESID && v.y2) v.y2[st_row] = st_out2;
+      }
+      if (z + 3 <= z1) {
+        pre = march_load_pair(v.x, MARCH_E0(c, z + 3), pact, T.n_cols);
+        if (PRO) prow = march_load_prorows(Q.Pm, MARCH_E0(c, z + 3), pact);
+      }
+      if (z + 1 < z1) {
         const int row = (z + 1) * T.P + inplane;
         const int rr = rowlive ? row : C.n_rows - 1;
         ncls = C.cls[rr];
@@ -1090,50 +1147,48 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
           if ((MODE == SMOOTH || (MODE == RESID && v.y2)) && v.d) npd = v.d[rr];
         }
       }
-      // ---- compute plane z from the ring ------------------------------------------------------------------------
+      // ---- compute plane z from the ring: every lane walks its own row's class ------------------------------------
       const int row = z * T.P + inplane;
       const bool live = rowlive && cls != 0xFFFF;      // exception rows are computed by csr_rows_spmv
-      const int sb0 = ((q - 1) & 3) * SLP + (int)(MARCH_G0(c, z - 1) & 1LL);
-      const int sb1 = (q & 3) * SLP + (int)(MARCH_G0(c, z) & 1LL);
-      const int sb2 = ((q + 1) & 3) * SLP + (int)(MARCH_G0(c, z + 1) & 1LL);
+      const int sb0 = ((q - 1) & 3) * SLP + (int)(MARCH_G0(c, z - 1) & 1LL) + tid;
+      const int sb1 = (q & 3) * SLP + (int)(MARCH_G0(c, z) & 1LL) + tid;
+      const int sb2 = ((q + 1) & 3) * SLP + (int)(MARCH_G0(c, z + 1) & 1LL) + tid;
+      const int cq = live ? cls : 0;
+      const int s = dptr[cq], len = live ? dptr[cq + 1] - s : 0;
+      if (class_d) pd = dd[cq];
       double acc = 0.0;
-      unsigned long long todo = __ballot(live);
-      while (todo) {
-        const int l = __builtin_ctzll(todo);
-        const int cc = __builtin_amdgcn_readlane(cls, l);
-        const int delta = C.cls_delta[cc];
-        const int lead = __builtin_amdgcn_readlane(row, l) + delta;
-        const unsigned long long m = __ballot(cls == cc) & todo;
-        todo &= ~m;
-        const bool in = (m & lanebit) != 0;
-        if (class_d && in) pd = C.cls_d[cc];
-        double a = 0.0;
-        const int s = C.cls_ptr[cc], e = C.cls_ptr[cc + 1];
-        for (int k = s; k < e; ++k) {
-          const int lb = T.lb[k];
-          const double a0 = C.cls_val[k];
-          if (lb >= 0) {   // wave-uniform
-            const int dz1 = lb & 3;
-            const int sb = dz1 == 0 ? sb0 : (dz1 == 1 ? sb1 : sb2);
-            a += a0 * win[sb + (lb >> 2) + tid];       // rows of another class: a valid slot, unused
-          } else {
-            double xg = v.x[(in ? row + delta : lead) + C.cls_off[k]];
-            asm volatile("" : "+v"(xg));               // (keeps the two loads apart: merged into one flat load, the
-            a += a0 * xg;                              //  LDS -> flat cast trips a gfx950 instruction-selection bug)
-          }
+      // four entries per trip: four dictionary reads, then four x reads in flight; entries beyond the lane's class
+      // re-read its last one and are not added (the order of the additions is the stored order of the row)
+      for (int k = 0; k < T.maxlen; k += 4) {
+        MarchEnt e[4];
+        double xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = dent[s + min(k + u, len - 1 < 0 ? 0 : len - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int dz1 = e[u].code & 3;
+          xv[u] = win[(dz1 == 0 ? sb0 : (dz1 == 1 ? sb1 : sb2)) + (e[u].code >> 2)];
         }
-        if (in) acc = a;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double t = acc + e[u].val * xv[u];
+          acc = (k + u < len) ? t : acc;
+        }
       }
+      st_row = -1;
       if (live) {
-        const double own = win[sb1 + T.halo + tid];
-        double pxj = own;
-        if (MODE == SMOOTH && !own_lds) pxj = v.xs[row];
-        const double outv = epilogue<MODE>(v, row, acc, pb, pd, pxj);
-        if (MODE != RESID || v.y) v.y[row] = outv;     // (the solve loop needs only ||r|| and x + d.*r: y may be null)
-        if (MODE == RESID && v.y2) v.y2[row] = own + pd * outv;   // x + d.*r
+        const double own = win[sb1 + T.halo];          // the row's own x (SMOOTH: v.xs == v.x is a launch condition)
+        const double outv = epilogue<MODE>(v, row, acc, pb, pd, own);
+        st_row = row;
+        st_out = outv;
+        if (MODE == RESID && v.y2) st_out2 = own + pd * outv;   // x + d.*r
         sq += outv * outv;
       }
       __syncthreads();
+    }
+    if (st_row >= 0) {   // the last plane of the run
+      if (MODE != RESID || v.y) v.y[st_row] = st_out;
+      if (MODE == RESID && v.y2) v.y2[st_row] = st_out2;
     }
   }
   if (EXC && blockIdx.x == gridDim.x - 1) sq += rowclass_exception_rows<MODE>(C, v, tid);   // EXC: C.nexc_inline > 0
@@ -1148,8 +1203,9 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
     }
   }
 #undef MARCH_G0
-#undef MARCH_LOAD
+#undef MARCH_E0
 #undef MARCH_STAGE
+#undef MARCH_PROLONG_PAIR
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -57,11 +57,12 @@ static inline hipError_t spin_sync(hipStream_t s) {
 struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
-  bool no_march = false, no_fuse_prolong = false;
+  bool no_march = false, fuse_prolong = false;
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
   long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
+  long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
   double rowclass_min_cover = 0.9, sched_budget = 2.0e6;
   struct Entry { const char* env; const char* key; int kind; size_t off; };   // kind 0 bool, 1 long long, 2 double, 3 int
   static const Entry* table(size_t* n);
@@ -76,7 +77,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_FUSE_PROLONG", "no_fuse_prolong", 0, no_fuse_prolong),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -84,7 +85,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_ROWCLASS_KEEP_SINGLETONS", "rowclass_keep_singletons", 1, rowclass_keep_singletons),
       MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
       MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
-      MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg),
+      MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
       MG_OPT("MG_ROWCLASS_MIN_COVER", "rowclass_min_cover", 2, rowclass_min_cover),
       MG_OPT("MG_SCHED_BUDGET", "sched_budget", 2, sched_budget),
   };
@@ -234,8 +235,12 @@ struct Csr {
     t.chunks = rm_chunks;
     t.nblocks = rm_nblocks;
     t.n_cols = (int)n_cols;
+    t.ncls = (int)rc_ncls;
+    t.nent = (int)rc_entries;
+    t.maxlen = rc_maxlen;
     return t;
   }
+  int rc_maxlen = 0;        // longest class of the dictionary
   mgk::TileDev tiledev() const {
     mgk::TileDev t;
     t.tile_lb = rt_lb.p;
@@ -499,7 +504,8 @@ int pow2_ge(long long v) {
 // can the z-marching kernel serve this launch?  (staged variants read x workgroup-wide: never in place; its staging
 // loads are 16 bytes wide: x must be 16-byte aligned, which every allocation base is)
 bool march_ok(const Csr& M, const mgk::VecArgs& v) {
-  return v.nrhs == 1 && M.has_rc && M.rc_march && v.y != v.x && v.y2 != v.x && (reinterpret_cast<uintptr_t>(v.x) & 15) == 0;
+  return v.nrhs == 1 && M.has_rc && M.rc_march && v.y != v.x && v.y2 != v.x && (v.xs == nullptr || v.xs == v.x) &&
+         (reinterpret_cast<uintptr_t>(v.x) & 15) == 0;
 }
 
 // nparts (optional): number of per-workgroup ||out||^2 partials the launch writes to v.sumsq.
@@ -518,7 +524,7 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
     if (march_ok(M, v)) {
       const mgk::MarchDev T = M.marchdev();
       const int SL = mgk::RM_C + 2 * M.rm_halo;
-      const size_t lds = (size_t)mgk::RM_RING * (size_t)((SL + 3) & ~1) * sizeof(double);
+      const size_t lds = (size_t)mgk::RM_RING * (size_t)((SL + 3) & ~1) * sizeof(double) + mgk::RM_DICT_BYTES;
       nb_main = M.rm_nblocks;
       static bool lds_attr_set[3] = {false, false, false};
       if (!lds_attr_set[MODE]) {
@@ -681,8 +687,9 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
 // (one right-hand side, pointwise smoother, A on the marching kernel, P in row-class form without exception rows)
 bool can_fuse_prolong(mg_hierarchy* h, int level, const double* x, const double* out) {
   const Level& L = h->lev[(size_t)level];
-  if (h->opt.no_fuse_prolong || h->nrhs != 1 || h->relax_type != 0) return false;
+  if (!h->opt.fuse_prolong || h->nrhs != 1 || h->relax_type != 0) return false;   // off by default: measured slower (DESIGN)
   if (!L.A.has_rc || !L.A.rc_march || !L.P.has_rc || L.P.rc_nexc != 0) return false;
+  if (L.P.rc_ncls > mgk::RM_PNCLS || L.P.rc_entries > mgk::RM_PDCAP) return false;
   return out != x && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
 // out = xp + d.*(b - A*xp) with xp = x + P*xc: the prolongation (MGcycle.jl:90) and the first post-smoothing sweep
@@ -700,6 +707,9 @@ int k_smooth_prolong(mg_hierarchy* h, int level, const double* b, const double* 
   mgk::ProDev Q{};
   Q.Pm = L.P.rcdev();
   Q.xc = xc;
+  Q.ncls = (int)L.P.rc_ncls;
+  Q.nent = (int)L.P.rc_entries;
+  Q.maxlen = L.P.rc_maxlen;
   ProfScope ps(h, level, MG_K_SMOOTH_PROLONG, spmv_bytes(L.A, 1, true, true) + spmv_bytes(L.P, 1, true, false),
                moved_bytes(L.A, 1, true, true, v.d == nullptr) + format_bytes(L.P, 1) + 8.0 * (double)L.P.n_cols);
   return launch_csr<mgk::SMOOTH>(h->stream, L.A, v, nullptr, &Q);
@@ -1456,12 +1466,15 @@ int build_march(Csr& A, const long long grid[3]) {
     halo = std::max(halo, rest < 0 ? -rest : rest);
   }
   if (halo > 510) return MG_OK;   // one 16-byte pair per thread covers the slab
+  if (A.rc_ncls > mgk::RM_NCLS || A.rc_entries > mgk::RM_DCAP) return MG_OK;   // the dictionary lives in LDS
+  if (A.rc_maxlen > A.opt.march_max_len) return MG_OK;
   std::vector<int> lbs(A.h_rc_off.size(), -1);
   for (size_t c = 0; c + 1 < A.h_rc_ptr.size(); ++c)
     for (int k = A.h_rc_ptr[c]; k < A.h_rc_ptr[c + 1]; ++k) {
       long long dz, rest;
       split((long long)A.h_rc_delta[c] + A.h_rc_off[(size_t)k], dz, rest);
       if (dz >= -1 && dz <= 1 && rest >= -halo && rest <= halo) lbs[(size_t)k] = (int)(((rest + halo) << 2) | (dz + 1));
+      else return MG_OK;   // an entry outside the staged shifts (not a grid operator / wrong hint): plane tiles + gathers
     }
   const long long chunks = (P + mgk::RM_C - 1) / mgk::RM_C;
   const long long items = chunks * grid[2];
@@ -1839,6 +1852,8 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   M->h_rc_ptr = cptr;
   M->h_rc_off = coff;
   M->h_rc_delta = cdelta;
+  M->rc_maxlen = 0;
+  for (size_t c = 0; c + 1 < cptr.size(); ++c) M->rc_maxlen = std::max(M->rc_maxlen, cptr[c + 1] - cptr[c]);
   if (implicit) {   // LDS-window kernel: do the windows of the most frequent class fit for a full workgroup of rows?
     std::vector<long long> cnt(cptr.size() - 1, 0);
     for (long long i = 0; i < n; ++i)

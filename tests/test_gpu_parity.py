@@ -641,12 +641,13 @@ def test_march_kernel_and_fused_prolongation(mg, built, monkeypatch, cells, leve
     monkeypatch.setenv("MG_TILE_MIN_WG", "0")
     monkeypatch.setenv("MG_WINDOW_MIN_WG", "0")
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    monkeypatch.setenv("MG_MARCH_MAX_LEN", "64")         # also on the 27-point coarse levels
     monkeypatch.setenv("MG_PAIR_MIN_ROWS", "0")
     rng = np.random.default_rng(sum(cells) + 1)
     runs = {}
-    for name, no_march, no_fuse in (("march+fused", "0", "0"), ("march", "0", "1"), ("tile", "1", "0")):
+    for name, no_march, fuse in (("march+fused", "0", "1"), ("march", "0", "0"), ("tile", "1", "0")):
         monkeypatch.setenv("MG_NO_MARCH", no_march)
-        monkeypatch.setenv("MG_NO_FUSE_PROLONG", no_fuse)
+        monkeypatch.setenv("MG_FUSE_PROLONG", fuse)
         A, p, b = _setup(mg, cells, levels, "Jac", 0.8, pre, post, cyc, maxIter=5)
         h = mg.to_device(p)
         var = h.operator_kernel_variant(1, D.MG_OP_A)
@@ -669,7 +670,7 @@ def test_march_kernel_and_fused_prolongation(mg, built, monkeypatch, cells, leve
             assert np.abs(y.cpu().numpy() - want).max() / np.abs(want).max() < KERNEL_TOL
         x, hist = _compare_solve(mg, p, b)
         # non-zero initial guess (the first sweep is a full fused sweep then) through the device entry point
-        x0 = rng.standard_normal(b.shape)
+        x0 = np.random.default_rng(99).standard_normal(b.shape)
         x1 = x0.copy()
         mg.recursiveCycle(p, b, x1, 1)
         xo = orc.recursiveCycle(p, b, x0.copy(), 1)
@@ -711,5 +712,6 @@ def test_march_with_wrong_grid_hint_and_exception_rows(mg, built, monkeypatch):
     mg.MGsetup(A, mesh, p, 1)
     bb = mg.seeded_rhs(A, 1)
     _compare_solve(mg, p, bb)
-    assert p.device.operator_kernel_info(1, D.MG_OP_A) == (3, 6)
+    var, nexc = p.device.operator_kernel_info(1, D.MG_OP_A)
+    assert var == 3 and 6 <= nexc <= 256, (var, nexc)        # the perturbed rows (+ the singleton corner classes) in-kernel
     mg.clear_(p)
