@@ -269,6 +269,24 @@ int mg_set_stream(mg_hierarchy* h, void* stream);
 int mg_cycle_async_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n,
                             long long nrhs, long long x_is_zero);
 
+/* ---- hybrid Kaczmarz relaxation --------------------------------------------------------------------------
+ * Replaces the reference's native applyHybridKaczmarz_FP64_INT64 (deps/src/parRelax.h:7-43; ccall at
+ * src/Multigrid/parRelax.jl:61-64) with the same arguments: rowptr/colA 1-based Int64 and valA of the transposed CSC
+ * (= CSR of A), ArrIdxs the domainLength x numDomains UInt32 array of 1-based row lists (0 = padding,
+ * DDService.jl:2-18), invD = omega ./ sum(|A|^2 over each row) (parRelax.jl:44).  create uploads once; apply runs
+ * `numit` sweeps on x (in/out) and b, n x nrhs column-major.  sequential = 1: one wavefront walks the sub-domains in
+ * order (bit-identical to the reference binary with numCores = 1); 0: one wavefront per sub-domain, unsynchronised
+ * between sub-domains like the reference's OpenMP threads. */
+typedef struct mg_kaczmarz mg_kaczmarz;
+int mg_kaczmarz_create_FP64_INT64(long long device_id, long long n, const long long* rowptr, const double* valA,
+                                  const long long* colA, long long numDomains, long long domainLength,
+                                  const unsigned int* ArrIdxs, const double* invD, mg_kaczmarz** out);
+int mg_kaczmarz_apply_FP64(mg_kaczmarz* k, double* x, const double* b, long long nrhs, long long numit,
+                           long long sequential);
+int mg_kaczmarz_apply_dev_FP64(mg_kaczmarz* k, double* x_dev, const double* b_dev, long long nrhs, long long numit,
+                               long long sequential);
+int mg_kaczmarz_destroy(mg_kaczmarz* k);
+
 const char* mg_last_error(void);
 const char* mg_version(void);
 

@@ -16,6 +16,10 @@ from .operators import (getRegularMesh, getNodalGradientMatrix, getNodalLaplacia
                         getNodalDivSigGradMatrix, poisson_shifted, anisotropic_divsiggrad, seeded_rhs)
 from .wrappers import (MGsolver, getMGsolver, getSA_AMGsolver, solveLinearSystem_, setupSolver, copySolverWrapper,
                        clearSolver_)
+from .par_relax import (hybridKaczmarz, getHybridKaczmarz, setupHybridKaczmarz, getHybridKaczmarzPrecond,
+                        applyHybridKaczmarz)
+from .dd_indices import (getIndicesOfCellsArray, getNodalIndicesOfCell, getOriginalBoundingBoxCells, getBoxWithOverlap,
+                         cs2loc, loc2cs)
 from . import device
 
 __all__ = [n for n in dir() if not n.startswith("_")]

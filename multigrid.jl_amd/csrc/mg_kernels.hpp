@@ -1691,4 +1691,54 @@ __global__ __launch_bounds__(BLK) void relax_spai(CsrDev A, double omega, const 
   d[i] = omega * diag / s[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hybrid Kaczmarz relaxation (reference native: deps/src/parRelax.h:7-43, applyHybridKaczmarz_FP64_INT64).
+// Sub-domains in parallel, the rows listed for a sub-domain strictly in order: for row i
+//   inner = (b_i - sum_k a_ik x_k) * invD_i ;  x_k += inner * a_ik  for every k of the row.
+// One wavefront per sub-domain.  The lanes fetch the row's entries and products in parallel, lane 0 subtracts the
+// products IN STORED ORDER (the reference's sequential loop, l.24-27), every product and sum is rounded separately
+// (no FMA contraction: the reference is plain C), so with `domains_per_launch` = all (one wavefront walks every
+// sub-domain in order) the result equals the reference binary run with one thread bit for bit.  x is read and written
+// through L2 (agent-scope relaxed atomics): a row sees the updates of the rows before it, and - as with the
+// reference's OpenMP threads - whatever the neighbouring sub-domains have written so far.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void hybrid_kaczmarz(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                      const double* __restrict__ val, const unsigned int* __restrict__ arr,
+                                                      int num_domains, int domain_length, double* x,
+                                                      const double* __restrict__ b, int nrhs, long long n,
+                                                      const double* __restrict__ invD, int sequential) {
+#pragma clang fp contract(off)   // every product and sum rounded separately, as in the reference's plain C (no FMA)
+  const int lane = threadIdx.x;
+  const int d0 = sequential ? 0 : blockIdx.x, d1 = sequential ? num_domains : blockIdx.x + 1;
+  for (int dom = d0; dom < d1; ++dom) {
+    for (int i = 0; i < domain_length; ++i) {
+      const unsigned int row1 = arr[(size_t)dom * domain_length + i];
+      if (row1 == 0) continue;   // zero padding (wave-uniform)
+      const int row = (int)row1 - 1;
+      const int s = rowptr[row], e = rowptr[row + 1];
+      const double di = invD[row];
+      for (int c = 0; c < nrhs; ++c) {
+        double* xc = x + (size_t)c * n;
+        double inner = b[(size_t)c * n + row];
+        for (int k0 = s; k0 < e; k0 += 64) {
+          const int k = k0 + lane;
+          double prod = 0.0;
+          if (k < e) prod = val[k] * __hip_atomic_load(&xc[col[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int cnt = min(64, e - k0);
+          for (int t = 0; t < cnt; ++t) inner = inner - __shfl(prod, t);   // stored order
+        }
+        inner = inner * di;
+        for (int k = s + lane; k < e; k += 64) {
+          const double old = __hip_atomic_load(&xc[col[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double upd = inner * val[k];
+          __hip_atomic_store(&xc[col[k]], old + upd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the next row of this wavefront must see these stores: wait until L2 has acknowledged them (loads and stores
+        // of one wavefront are not ordered against each other otherwise); the loads above bypass L1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+  }
+}
+
 }  // namespace mgk

@@ -2981,6 +2981,127 @@ int mg_vec_sumsq_dev_FP64(const double* x, long long len, double* workspace, dou
   return MG_OK;
 }
 
+// ---- hybrid Kaczmarz relaxation (deps/src/parRelax.h:7-43) -------------------------------------------------------------
+struct mg_kaczmarz {
+  int device = 0;
+  long long n = 0, nnz = 0, num_domains = 0, domain_length = 0;
+  DevBuf<int> rowptr, col;
+  DevBuf<double> val, invD, x, b;
+  DevBuf<unsigned int> arr;
+  hipStream_t stream = nullptr;
+};
+
+int mg_kaczmarz_create_FP64_INT64(long long device_id, long long n, const long long* rowptr, const double* valA,
+                                  const long long* colA, long long numDomains, long long domainLength,
+                                  const unsigned int* ArrIdxs, const double* invD, mg_kaczmarz** out) {
+  UploadFence upload_fence;
+  if (!out) return fail(MG_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (n < 1 || !rowptr || !valA || !colA || !ArrIdxs || !invD || numDomains < 1 || domainLength < 1)
+    return fail(MG_ERR_INVALID, "null or empty argument");
+  if (n >= (1LL << 31) - 1 || numDomains * domainLength >= (1LL << 31)) return fail(MG_ERR_UNSUPPORTED, "dimension exceeds int32 device indices");
+  if (rowptr[0] != 1) return fail(MG_ERR_INVALID, "rowptr[1] must be 1 (1-based Julia arrays expected)");
+  const long long nnz = rowptr[n] - 1;
+  if (nnz < 0 || nnz >= (1LL << 31) - 1) return fail(MG_ERR_UNSUPPORTED, "nnz does not fit int32");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the relaxation has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
+  std::vector<int> rp((size_t)n + 1), ci((size_t)std::max<long long>(nnz, 1));
+  for (long long i = 0; i <= n; ++i) {
+    const long long v = rowptr[i] - 1;
+    if (v < 0 || v > nnz || (i > 0 && v < rp[(size_t)i - 1])) return fail(MG_ERR_INVALID, "rowptr is not a monotone 1-based pointer array");
+    rp[(size_t)i] = (int)v;
+  }
+  for (long long k = 0; k < nnz; ++k) {
+    const long long c = colA[k] - 1;
+    if (c < 0 || c >= n) return fail(MG_ERR_INVALID, "column index out of range");
+    ci[(size_t)k] = (int)c;
+  }
+  for (long long t = 0; t < numDomains * domainLength; ++t)
+    if ((long long)ArrIdxs[t] > n) return fail(MG_ERR_INVALID, "ArrIdxs entry %u exceeds n=%lld", ArrIdxs[t], n);
+  HIP_TRY(hipSetDevice((int)device_id));
+  mg_kaczmarz* k = new mg_kaczmarz();
+  k->device = (int)device_id;
+  k->n = n;
+  k->nnz = nnz;
+  k->num_domains = numDomains;
+  k->domain_length = domainLength;
+  int rc = MG_OK;
+  auto up = [&]() -> int {
+    MG_TRY(k->rowptr.alloc(rp.size()));
+    MG_TRY(k->col.alloc(ci.size()));
+    MG_TRY(k->val.alloc((size_t)std::max<long long>(nnz, 1)));
+    MG_TRY(k->invD.alloc((size_t)n));
+    MG_TRY(k->arr.alloc((size_t)(numDomains * domainLength)));
+    HIP_TRY(hipMemcpy(k->rowptr.p, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(k->col.p, ci.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(k->val.p, valA, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(k->invD.p, invD, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(k->arr.p, ArrIdxs, (size_t)(numDomains * domainLength) * sizeof(unsigned int), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+    return MG_OK;
+  };
+  rc = up();
+  if (rc != MG_OK) {
+    mg_kaczmarz_destroy(k);
+    return rc;
+  }
+  *out = k;
+  return MG_OK;
+}
+
+int mg_kaczmarz_destroy(mg_kaczmarz* k) {
+  if (!k) return MG_OK;
+  (void)hipSetDevice(k->device);
+  if (k->stream) {
+    (void)spin_sync(k->stream);
+    (void)hipStreamDestroy(k->stream);
+  }
+  k->rowptr.release();
+  k->col.release();
+  k->val.release();
+  k->invD.release();
+  k->arr.release();
+  k->x.release();
+  k->b.release();
+  delete k;
+  return MG_OK;
+}
+
+// numit sweeps on device-resident x (in/out) and b, column-major n x nrhs; one launch per sweep (the barrier the
+// reference's `omp for` has between sweeps).  sequential != 0: one wavefront walks all sub-domains in order (the
+// reference with one thread); otherwise one wavefront per sub-domain.
+int mg_kaczmarz_apply_dev_FP64(mg_kaczmarz* k, double* x_dev, const double* b_dev, long long nrhs, long long numit,
+                               long long sequential) {
+  if (!k || !x_dev || !b_dev || nrhs < 1 || numit < 0) return fail(MG_ERR_INVALID, "bad argument");
+  (void)hipSetDevice(k->device);
+  for (long long it = 0; it < numit; ++it)
+    hipLaunchKernelGGL(mgk::hybrid_kaczmarz, dim3(sequential ? 1u : (unsigned)k->num_domains), dim3(64), 0, k->stream,
+                       k->rowptr.p, k->col.p, k->val.p, k->arr.p, (int)k->num_domains, (int)k->domain_length, x_dev, b_dev,
+                       (int)nrhs, k->n, k->invD.p, sequential ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(spin_sync(k->stream));
+  return MG_OK;
+}
+
+// Host buffers, exactly the reference's call (parRelax.jl:61-64): x (in/out) and b are n x nrhs column-major.
+int mg_kaczmarz_apply_FP64(mg_kaczmarz* k, double* x, const double* b, long long nrhs, long long numit, long long sequential) {
+  if (!k || !x || !b || nrhs < 1 || numit < 0) return fail(MG_ERR_INVALID, "bad argument");
+  (void)hipSetDevice(k->device);
+  const size_t len = (size_t)k->n * (size_t)nrhs;
+  if (k->x.n != len) {
+    MG_TRY(k->x.alloc(len));
+    MG_TRY(k->b.alloc(len));
+  }
+  HIP_TRY(hipMemcpyAsync(k->x.p, x, len * sizeof(double), hipMemcpyHostToDevice, k->stream));
+  HIP_TRY(hipMemcpyAsync(k->b.p, b, len * sizeof(double), hipMemcpyHostToDevice, k->stream));
+  MG_TRY(mg_kaczmarz_apply_dev_FP64(k, k->x.p, k->b.p, nrhs, numit, sequential));
+  HIP_TRY(hipMemcpyAsync(x, k->x.p, len * sizeof(double), hipMemcpyDeviceToHost, k->stream));
+  HIP_TRY(spin_sync(k->stream));
+  return MG_OK;
+}
+
 // Run the hierarchy's kernels on the caller's stream (e.g. torch's current stream) instead of its own.
 int mg_set_stream(mg_hierarchy* h, void* stream) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");

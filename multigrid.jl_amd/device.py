@@ -83,6 +83,10 @@ SIGNATURES = {
     "mg_vec_sumsq_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp]),
     "mg_set_stream": (C.c_int, [_vp, _vp]),
     "mg_cycle_async_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
+    "mg_kaczmarz_create_FP64_INT64": (C.c_int, [_ll, _ll, _lp, _dp, _lp, _ll, _ll, C.POINTER(C.c_uint), _dp, C.POINTER(_vp)]),
+    "mg_kaczmarz_apply_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, _ll]),
+    "mg_kaczmarz_apply_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
+    "mg_kaczmarz_destroy": (C.c_int, [_vp]),
     "mg_last_error": (C.c_char_p, []),
     "mg_version": (C.c_char_p, []),
 }

@@ -678,3 +678,96 @@ def solveGMRES_MG(param, b, x0, inner):
     A = param.As[0]
     return fgmres(lambda v: A @ v, b, inner, tol=param.relativeTol, maxIter=param.maxOuterIter,
                   M=getMultigridPreconditioner(param, b), x=x0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Hybrid Kaczmarz (deps/src/parRelax.h:7-43, src/Multigrid/parRelax.jl:31-65; src/DomainDecomposition/DDService.jl:2-18,
+# DDIndices.jl:41-92,141-162).  PINNED against the reference's own compiled code: tests/test_reference_parrelax.py runs
+# oracle/_ref/parRelax.so (built from deps/src/parRelax.c by oracle/Makefile) with numCores = 1 on the same arrays.
+# ---------------------------------------------------------------------------------------------------------------------
+def cs2loc(cs, n):
+    """DDService.jl:38-48 (1-based linear -> 1-based per-dimension box index, x fastest)."""
+    n = [int(k) for k in n]
+    if len(n) == 3:
+        return [(cs - 1) % n[0] + 1, ((cs - 1) % (n[0] * n[1])) // n[0] + 1, (cs - 1) // (n[0] * n[1]) + 1]
+    return [(cs - 1) % n[0] + 1, (cs - 1) // n[0] + 1]
+
+
+def getOriginalBoundingBoxCells(NumCells, overlap, i, nc):
+    """DDIndices.jl:41-47."""
+    NumCells, i, nc = np.asarray(NumCells), np.asarray(i), np.asarray(nc)
+    cellSize = nc // NumCells
+    ul = (i - 1) * cellSize + 1
+    br = ul + (cellSize - 1)
+    br[i == NumCells] = nc[i == NumCells]
+    return ul, br
+
+
+def getBoxWithOverlap(ul, br, nc, overlap):
+    """DDIndices.jl:61-92: extend the box by the overlap where it does not touch the boundary."""
+    ul, br = np.array(ul).copy(), np.array(br).copy()
+    nul, nbr = ul.copy(), br.copy()
+    for d in range(len(nc)):
+        if ul[d] > 1:
+            nul[d] -= overlap[d]
+        if br[d] < nc[d]:
+            nbr[d] += overlap[d]
+    return nul, nbr
+
+
+def getNodalIndicesOfCell(NumCells, overlap, i, nc):
+    """DDIndices.jl:141-162 (1-based nodal indices of sub-domain i, x fastest; its 3-D stride is (nc[1]+1)*(nc[1]+1),
+    l.157 - reproduced literally)."""
+    nc = np.asarray(nc)
+    dim = len(nc)
+    ul, br = getOriginalBoundingBoxCells(NumCells, overlap, i, nc)
+    ul, br = getBoxWithOverlap(ul, br + 1, nc + 1, overlap)
+    r = [np.arange(ul[d], br[d] + 1) for d in range(dim)]
+    if dim == 2:
+        I1, I2 = np.meshgrid(r[0], r[1], indexing="ij")
+        return (I1.ravel(order="F") + (I2.ravel(order="F") - 1) * (nc[0] + 1)).astype(np.int64)
+    I1, I2, I3 = np.meshgrid(r[0], r[1], r[2], indexing="ij")
+    return (I1.ravel(order="F") + (I2.ravel(order="F") - 1) * (nc[0] + 1)
+            + (I3.ravel(order="F") - 1) * ((nc[0] + 1) * (nc[0] + 1))).astype(np.int64)
+
+
+def getIndicesOfCellsArray(n_cells, overlap, numDomains, getIndicesOfCell=getNodalIndicesOfCell):
+    """DDService.jl:2-18: column ic = the (1-based) indices of sub-domain ic, zero padded to the length of the middle one."""
+    n_cells = np.asarray(n_cells)
+    numDomains = [int(k) for k in numDomains]
+    mid = getIndicesOfCell(numDomains, overlap, n_cells // 2 + 1, n_cells)
+    Arr = np.zeros((len(mid), int(np.prod(numDomains))), dtype=np.uint32, order="F")
+    for ic in range(1, Arr.shape[1] + 1):
+        II = getIndicesOfCell(numDomains, overlap, np.asarray(cs2loc(ic, numDomains)), n_cells)
+        Arr[: len(II), ic - 1] = II
+    return Arr
+
+
+def hybrid_kaczmarz_invdiag(A, omega):
+    """parRelax.jl:44: omega ./ sum(conj(AT).*AT, dims=1)  = omega / ||row i of A||^2."""
+    A = sp.csr_matrix(A)
+    return omega / np.asarray(A.multiply(A).sum(axis=1)).ravel()
+
+
+def applyHybridKaczmarz(A, ArrIdxs, x, b, invD, numit):
+    """parRelax.h:7-43 with ONE thread (domains in order, rows of a domain in order): for every listed row,
+    inner = (b_i - a_i.x) * invD_i ; x[cols] += inner * a_i.  x (n x nrhs, column-major or 1-D) is updated in place."""
+    A = sp.csr_matrix(A)
+    rp, ci, va = A.indptr, A.indices, A.data
+    X = x.reshape(A.shape[0], -1, order="F") if x.ndim == 1 else x
+    B = b.reshape(A.shape[0], -1, order="F") if b.ndim == 1 else b
+    for _ in range(int(numit)):
+        for dom in range(ArrIdxs.shape[1]):
+            for row1 in ArrIdxs[:, dom]:
+                if row1 == 0:
+                    continue
+                i = int(row1) - 1
+                s, e = rp[i], rp[i + 1]
+                for c in range(X.shape[1]):
+                    inner = B[i, c]
+                    for k in range(s, e):                 # sequential, stored order (l.24-27)
+                        inner -= va[k] * X[ci[k], c]
+                    inner *= invD[i]
+                    for k in range(s, e):                 # l.29-32
+                        X[ci[k], c] += inner * va[k]
+    return x
