@@ -176,6 +176,39 @@ int mg_bicgstab_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, lo
 int mg_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long inner, double tol,
                    long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres);
 
+/* The block branches of the same three drivers (size(b,2) > 1: KrylovMethods.blockCG / blockBiCGSTB / blockFGMRES,
+ * SolveFuncs.jl:95,113,130), nrhs <= 16, every n x nrhs block resident in HBM across iterations.  The package is not
+ * vendored: the published algorithms are restated in oracle/mg_oracle.py (O'Leary's block CG with a pseudo-inverse of
+ * P'AP; El Guennouni-Jbilou-Sadok block BiCGSTAB, M1 = the cycle; block flexible GMRES with block modified Gram-Schmidt,
+ * blocks orthonormalised by Cholesky QR applied twice).  Stopping: max over columns of ||r_j||/||b_j|| <= tol (CG,
+ * BiCGSTAB; resmat is maxIter x nrhs row-major, resvec as for the single-vector driver), Frobenius norm for FGMRES.
+ * Flags as for the single-vector drivers.  b / x: column-major host blocks, or row-major [n][nrhs] device blocks (_dev). */
+int mg_block_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
+                      long long maxIter, long long* iters, long long* flag, double* resmat);
+int mg_block_pcg_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n, long long nrhs, double tol,
+                          long long maxIter, long long* iters, long long* flag, double* resmat);
+int mg_block_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
+                           long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres);
+int mg_block_bicgstab_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n, long long nrhs,
+                               double tol, long long maxIter, long long* iters, long long* flag, double* resvec,
+                               long long* nres);
+int mg_block_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, long long inner,
+                         double tol, long long maxIter, long long* iters, long long* flag, double* resvec,
+                         long long* nres);
+int mg_block_fgmres_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n, long long nrhs,
+                             long long inner, double tol, long long maxIter, long long* iters, long long* flag,
+                             double* resvec, long long* nres);
+
+/* Mixed-precision preconditioner hook of getMultigridPreconditioner (SolveFuncs.jl:52-58): a Float32 block against the
+ * Float64 hierarchy - bl .= b; z .= 0; recursiveCycle(param,bl,z,1); z2 .= z.  Column-major n x nrhs host blocks. */
+int mg_cycle_mixed_FP32(mg_hierarchy* h, const float* b32, float* z32, long long n, long long nrhs);
+
+/* Page-lock / release a long-lived host array (the preconditioner's z = param.memCycle[1].x, a solver's b and x) so the
+ * host-pointer entry points above copy it at full PCIe rate.  The caller owns the lifetime: unregister before the
+ * array is freed or resized (hipHostRegister / hipHostUnregister). */
+int mg_host_register(void* ptr, long long bytes);
+int mg_host_unregister(void* ptr);
+
 /* target = beta*target + alpha*Op*x on one level (SpMatMul.jl:4-13); column-major host blocks. */
 int mg_spmv_FP64(mg_hierarchy* h, long long level, long long which, double alpha, const double* x,
                  double beta, double* y, long long nrhs);

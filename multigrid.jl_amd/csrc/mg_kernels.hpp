@@ -1692,6 +1692,81 @@ __global__ __launch_bounds__(BLK) void relax_spai(CsrDev A, double omega, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Block-vector helpers of the block Krylov drivers (blocks are row-major [n][k], k <= 16).
+//   blk_gram_partial / blk_gram_final:  G = X' Y  (k x k), deterministic two-stage reduction
+//   blk_comb:                           out[i,:] = s * add[i,:] + in[i,:] * C   (C k x k row-major; out may alias in / add)
+// ------------------------------------------------------------------------------------------------
+constexpr int BLK_KMAX = 16;
+__global__ __launch_bounds__(BLK) void blk_gram_partial(const double* __restrict__ X, const double* __restrict__ Y,
+                                                        long long n, int k, double* __restrict__ partial) {
+  __shared__ double red[BLK / 64][BLK_KMAX];
+  const int a = blockIdx.y;
+  double acc[BLK_KMAX];
+#pragma unroll
+  for (int b = 0; b < BLK_KMAX; ++b) acc[b] = 0.0;
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+    const double xa = X[i * k + a];
+#pragma unroll
+    for (int b = 0; b < BLK_KMAX; ++b)
+      if (b < k) acc[b] += xa * Y[i * k + b];
+  }
+#pragma unroll
+  for (int b = 0; b < BLK_KMAX; ++b) {
+    double t = acc[b];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][b] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < k) {
+    double t = 0.0;
+    for (int w = 0; w < BLK / 64; ++w) t += red[w][threadIdx.x];
+    partial[((size_t)blockIdx.x * k + a) * k + threadIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(BLK) void blk_gram_final(const double* __restrict__ partial, int nb, int k,
+                                                      double* __restrict__ out) {
+  const int e = threadIdx.x;   // entry a*k + b
+  if (e >= k * k) return;
+  double t = 0.0;
+  for (int p = 0; p < nb; ++p) t += partial[(size_t)p * k * k + e];
+  out[e] = t;
+}
+__global__ __launch_bounds__(BLK) void blk_comb(double* out, const double* add, double s, const double* in,
+                                                const double* __restrict__ Cm, long long n, int k) {
+  __shared__ double sc[BLK_KMAX * BLK_KMAX];
+  for (int t = threadIdx.x; t < k * k; t += BLK) sc[t] = Cm[t];
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+    double row[BLK_KMAX], o[BLK_KMAX];
+#pragma unroll
+    for (int a = 0; a < BLK_KMAX; ++a) row[a] = a < k ? in[i * k + a] : 0.0;
+#pragma unroll
+    for (int b = 0; b < BLK_KMAX; ++b) o[b] = (b < k && add) ? s * add[i * k + b] : 0.0;
+#pragma unroll
+    for (int a = 0; a < BLK_KMAX; ++a)
+      if (a < k) {
+#pragma unroll
+        for (int b = 0; b < BLK_KMAX; ++b)
+          if (b < k) o[b] += row[a] * sc[a * k + b];
+      }
+#pragma unroll
+    for (int b = 0; b < BLK_KMAX; ++b)
+      if (b < k) out[i * k + b] = o[b];
+  }
+}
+// float <-> double conversion of a block (mixed-precision preconditioner hook, SolveFuncs.jl:52-58)
+__global__ __launch_bounds__(BLK) void f32_to_f64(const float* __restrict__ in, double* __restrict__ out, long long n) {
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) out[i] = (double)in[i];
+}
+__global__ __launch_bounds__(BLK) void f64_to_f32(const double* __restrict__ in, float* __restrict__ out, long long n) {
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) out[i] = (float)in[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Hybrid Kaczmarz relaxation (reference native: deps/src/parRelax.h:7-43, applyHybridKaczmarz_FP64_INT64).
 // Sub-domains in parallel, the rows listed for a sub-domain strictly in order: for row i
 //   inner = (b_i - sum_k a_ik x_k) * invD_i ;  x_k += inner * a_ik  for every k of the row.

@@ -392,6 +392,10 @@ struct mg_hierarchy {
   DevBuf<double> stage_b, stage_x, stage_t;
   // Krylov work vectors (allocated on the first mg_pcg call)
   DevBuf<double> kr, kz, kp, kAp, kw;
+  DevBuf<double> blk_partial, blk_c;   // block Krylov: Gram partials, coefficient slots
+  double* h_blk = nullptr;             // pinned k x k readback
+  double* h_blk_c = nullptr;           // pinned ring of coefficient matrices
+  unsigned blk_c_next = 0;
   DevBuf<double> kwc, coarse_d;   // coarseSolveType "GMRES": FGMRES work space and the Jacobi preconditioner of the coarsest level
   bool coarse_gmres = false;
   // fine-level operands of the last cycle/solve (used as inputs by mg_time_op_dev_FP64)
@@ -1360,6 +1364,446 @@ int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, dou
   return fgmres_core(h, 0, 0, nullptr, h->kw, b, x, inner, tol, maxIter, iters, flag_out, resvec, nres);
 }
 
+// ---- block Krylov drivers (SolveFuncs.jl:95,113,130 -> KrylovMethods.blockBiCGSTB / blockCG / blockFGMRES) -----------
+// The package is not vendored; the published algorithms (O'Leary's block CG, El Guennouni-Jbilou-
+// Sadok block BiCGSTAB, block flexible GMRES) are implemented here with every n x k block resident in HBM (row-major [n][k], k <= 16): products with A
+// are SpMM launches, the preconditioner is one cycle on the whole block, k x k Gram matrices come back through one
+// 8*k*k-byte readback each, and the small dense algebra (pseudo-inverse, LU solve, triangular factor, block least
+// squares) runs on the host.
+struct SmallMat {   // row-major dense helper, host
+  int r = 0, c = 0;
+  std::vector<double> a;
+  SmallMat() {}
+  SmallMat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
+  double& operator()(int i, int j) { return a[(size_t)i * c + j]; }
+  double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+};
+SmallMat sm_mul(const SmallMat& A, const SmallMat& B) {
+  SmallMat C(A.r, B.c);
+  for (int i = 0; i < A.r; ++i)
+    for (int k = 0; k < A.c; ++k) {
+      const double v = A(i, k);
+      for (int j = 0; j < B.c; ++j) C(i, j) += v * B(k, j);
+    }
+  return C;
+}
+SmallMat sm_T(const SmallMat& A) {
+  SmallMat C(A.c, A.r);
+  for (int i = 0; i < A.r; ++i)
+    for (int j = 0; j < A.c; ++j) C(j, i) = A(i, j);
+  return C;
+}
+// X = A \ B by Gaussian elimination with partial pivoting (A k x k); false if singular
+bool sm_solve(SmallMat A, SmallMat B, SmallMat& X) {
+  const int k = A.r;
+  for (int p = 0; p < k; ++p) {
+    int piv = p;
+    for (int i = p + 1; i < k; ++i)
+      if (std::fabs(A(i, p)) > std::fabs(A(piv, p))) piv = i;
+    if (A(piv, p) == 0.0) return false;
+    if (piv != p) {
+      for (int j = 0; j < k; ++j) std::swap(A(p, j), A(piv, j));
+      for (int j = 0; j < B.c; ++j) std::swap(B(p, j), B(piv, j));
+    }
+    for (int i = p + 1; i < k; ++i) {
+      const double f = A(i, p) / A(p, p);
+      if (f == 0.0) continue;
+      for (int j = p; j < k; ++j) A(i, j) -= f * A(p, j);
+      for (int j = 0; j < B.c; ++j) B(i, j) -= f * B(p, j);
+    }
+  }
+  X = SmallMat(k, B.c);
+  for (int j = 0; j < B.c; ++j)
+    for (int i = k - 1; i >= 0; --i) {
+      double acc = B(i, j);
+      for (int t = i + 1; t < k; ++t) acc -= A(i, t) * X(t, j);
+      X(i, j) = acc / A(i, i);
+    }
+  return true;
+}
+// upper triangular Rf with G = Rf'Rf for a positive SEMI-definite Gram matrix
+SmallMat sm_chol_semidefinite(const SmallMat& G, double rtol = 1e-14) {
+  const int k = G.r;
+  SmallMat R(k, k);
+  for (int c = 0; c < k; ++c) {
+    double d = G(c, c);
+    for (int a = 0; a < c; ++a) d -= R(a, c) * R(a, c);
+    if (G(c, c) <= 0.0 || d <= rtol * G(c, c)) continue;
+    R(c, c) = std::sqrt(d);
+    for (int j = c + 1; j < k; ++j) {
+      double t = G(c, j);
+      for (int a = 0; a < c; ++a) t -= R(a, c) * R(a, j);
+      R(c, j) = t / R(c, c);
+    }
+  }
+  return R;
+}
+// T with W*T = W*Rf^+: T[:,c] = (e_c - T[:,:c] Rf[:c,c]) / Rf[c,c], zero for zero pivots
+SmallMat sm_tri_pinv(const SmallMat& R) {
+  const int k = R.r;
+  SmallMat T(k, k);
+  for (int c = 0; c < k; ++c) {
+    if (R(c, c) == 0.0) continue;
+    for (int i = 0; i < k; ++i) {
+      double t = (i == c) ? 1.0 : 0.0;
+      for (int a = 0; a < c; ++a) t -= T(i, a) * R(a, c);
+      T(i, c) = t / R(c, c);
+    }
+  }
+  return T;
+}
+// min || xi - H Y ||_F over Y by Householder QR of H (rows x cols, rows >= cols); returns the residual norm
+double sm_lstsq(SmallMat H, SmallMat xi, SmallMat& Y) {
+  const int m = H.r, n = H.c, k = xi.c;
+  for (int j = 0; j < n; ++j) {
+    double nrm = 0.0;
+    for (int i = j; i < m; ++i) nrm += H(i, j) * H(i, j);
+    nrm = std::sqrt(nrm);
+    if (nrm == 0.0) continue;
+    const double alpha = H(j, j) > 0 ? -nrm : nrm;
+    std::vector<double> v((size_t)m, 0.0);
+    for (int i = j; i < m; ++i) v[(size_t)i] = H(i, j);
+    v[(size_t)j] -= alpha;
+    double vn = 0.0;
+    for (int i = j; i < m; ++i) vn += v[(size_t)i] * v[(size_t)i];
+    if (vn == 0.0) continue;
+    for (int c = j; c < n; ++c) {
+      double d = 0.0;
+      for (int i = j; i < m; ++i) d += v[(size_t)i] * H(i, c);
+      d *= 2.0 / vn;
+      for (int i = j; i < m; ++i) H(i, c) -= d * v[(size_t)i];
+    }
+    for (int c = 0; c < k; ++c) {
+      double d = 0.0;
+      for (int i = j; i < m; ++i) d += v[(size_t)i] * xi(i, c);
+      d *= 2.0 / vn;
+      for (int i = j; i < m; ++i) xi(i, c) -= d * v[(size_t)i];
+    }
+  }
+  Y = SmallMat(n, k);
+  for (int c = 0; c < k; ++c)
+    for (int i = n - 1; i >= 0; --i) {
+      double acc = xi(i, c);
+      for (int t = i + 1; t < n; ++t) acc -= H(i, t) * Y(t, c);
+      Y(i, c) = (H(i, i) != 0.0) ? acc / H(i, i) : 0.0;
+    }
+  double res = 0.0;
+  for (int i = n; i < m; ++i)
+    for (int c = 0; c < k; ++c) res += xi(i, c) * xi(i, c);
+  return std::sqrt(res);
+}
+
+// G = X'Y (k x k) to the host; synchronises the stream
+int blk_gram(mg_hierarchy* h, const double* X, const double* Y, long long n, int k, SmallMat& G) {
+  const int nb = (int)std::min<long long>(256, std::max<long long>(1, (n + mgk::BLK - 1) / mgk::BLK));
+  if (h->blk_partial.n < (size_t)nb * k * k + (size_t)k * k) MG_TRY(h->blk_partial.alloc((size_t)nb * k * k + (size_t)k * k));
+  if (!h->h_blk) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_blk), sizeof(double) * mgk::BLK_KMAX * mgk::BLK_KMAX));
+  double* out = h->blk_partial.p + (size_t)nb * k * k;
+  hipLaunchKernelGGL(mgk::blk_gram_partial, dim3(nb, k), dim3(mgk::BLK), 0, h->stream, X, Y, n, k, h->blk_partial.p);
+  hipLaunchKernelGGL(mgk::blk_gram_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->blk_partial.p, nb, k, out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->h_blk, out, sizeof(double) * k * k, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(spin_sync(h->stream));
+  G = SmallMat(k, k);
+  std::memcpy(G.a.data(), h->h_blk, sizeof(double) * k * k);
+  return MG_OK;
+}
+// out = s*add + in*C   (add may be null; out may alias in or add)
+int blk_comb(mg_hierarchy* h, double* out, const double* add, double s, const double* in, const SmallMat& Cm, long long n, int k) {
+  if (h->blk_c.n < (size_t)mgk::BLK_KMAX * mgk::BLK_KMAX * 8) MG_TRY(h->blk_c.alloc((size_t)mgk::BLK_KMAX * mgk::BLK_KMAX * 8));
+  // a ring of 8 coefficient slots (pinned host + device): copies are asynchronous and earlier launches may still read
+  // theirs; the stream is drained once per lap of the ring
+  constexpr size_t SLOT = (size_t)mgk::BLK_KMAX * mgk::BLK_KMAX;
+  if (!h->h_blk_c) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_blk_c), sizeof(double) * SLOT * 8));
+  const unsigned si = h->blk_c_next++ % 8;
+  if (si == 0 && h->blk_c_next > 1) HIP_TRY(spin_sync(h->stream));
+  double* slot = h->blk_c.p + si * SLOT;
+  std::memcpy(h->h_blk_c + si * SLOT, Cm.a.data(), sizeof(double) * k * k);
+  HIP_TRY(hipMemcpyAsync(slot, h->h_blk_c + si * SLOT, sizeof(double) * k * k, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(mgk::blk_comb, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, out, add, s, in, slot, n, k);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+SmallMat sm_scaled_identity(int k, double v) {
+  SmallMat I(k, k);
+  for (int i = 0; i < k; ++i) I(i, i) = v;
+  return I;
+}
+int blk_colnorms(mg_hierarchy* h, const double* X, long long n, int k, std::vector<double>& out) {
+  SmallMat G;
+  MG_TRY(blk_gram(h, X, X, n, k, G));
+  out.assign((size_t)k, 0.0);
+  for (int j = 0; j < k; ++j) out[(size_t)j] = std::sqrt(std::max(0.0, G(j, j)));
+  return MG_OK;
+}
+int blk_work(mg_hierarchy* h, size_t nblocks, long long n, int k, double** base) {
+  const size_t need = nblocks * (size_t)n * (size_t)k;
+  if (h->kw.n < need) MG_TRY(h->kw.alloc(need));
+  *base = h->kw.p;
+  return MG_OK;
+}
+
+// blockCG (O'Leary 1980): Alpha = pinv(P'Q) P'R ; X += P Alpha ; R -= Q Alpha ; Beta = -pinv(P'Q) Q'Z ; P = Z + P Beta
+int block_pcg_dev(mg_hierarchy* h, const double* B, double* X, double tol, long long maxIter, long long* iters,
+                  long long* flag_out, double* resmat) {
+  Level& L = h->lev[0];
+  const long long n = L.n;
+  const int k = (int)h->nrhs;
+  if (k > mgk::BLK_KMAX) return fail(MG_ERR_UNSUPPORTED, "block Krylov drivers hold at most %d right-hand sides", mgk::BLK_KMAX);
+  const size_t len = (size_t)n * k;
+  double* w = nullptr;
+  MG_TRY(blk_work(h, 4, n, k, &w));
+  double *R = w, *Z = w + len, *P = w + 2 * len, *Q = w + 3 * len;
+  std::vector<double> nb, rn;
+  MG_TRY(blk_colnorms(h, B, n, k, nb));
+  long long it = 0, flag = -1;
+  bool any = false;
+  for (double v : nb) any = any || v > 0.0;
+  if (!any) {
+    MG_TRY(k_fill(h, X, (long long)len, 0.0));
+    HIP_TRY(spin_sync(h->stream));
+    if (iters) *iters = 0;
+    if (flag_out) *flag_out = -9;
+    return MG_OK;
+  }
+  for (double& v : nb) if (!(v > 0.0)) v = 1.0;
+  MG_TRY(k_residual(h, 0, L.A, B, X, R));                         // R = B - A X
+  MG_TRY(cycle_dev(h, R, Z, true));                               // Z = M(R)
+  HIP_TRY(hipMemcpyAsync(P, Z, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
+  for (long long iter = 1; iter <= maxIter; ++iter) {
+    it = iter;
+    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, P, 0.0, Q));         // Q = A P
+    SmallMat PTQ, PTR, QTZ;
+    MG_TRY(blk_gram(h, P, Q, n, k, PTQ));
+    MG_TRY(blk_gram(h, P, R, n, k, PTR));
+    std::vector<double> Hs((size_t)k * k), Pinv;
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j) Hs[(size_t)i * k + j] = 0.5 * (PTQ(i, j) + PTQ(j, i));
+    pinv_sym(Hs, k, Pinv);
+    SmallMat Pi(k, k);
+    Pi.a = Pinv;
+    const SmallMat Alpha = sm_mul(Pi, PTR);
+    MG_TRY(blk_comb(h, X, X, 1.0, P, Alpha, n, k));               // X += P Alpha
+    SmallMat negAlpha = Alpha;
+    for (double& v : negAlpha.a) v = -v;
+    MG_TRY(blk_comb(h, R, R, 1.0, Q, negAlpha, n, k));            // R -= Q Alpha
+    MG_TRY(blk_colnorms(h, R, n, k, rn));
+    double worst = 0.0;
+    for (int j = 0; j < k; ++j) {
+      const double rel = rn[(size_t)j] / nb[(size_t)j];
+      if (resmat) resmat[(size_t)(iter - 1) * k + j] = rel;
+      worst = std::max(worst, rel);
+    }
+    if (worst <= tol) { flag = 0; break; }
+    MG_TRY(cycle_dev(h, R, Z, true));
+    MG_TRY(blk_gram(h, Q, Z, n, k, QTZ));
+    SmallMat Beta = sm_mul(Pi, QTZ);
+    for (double& v : Beta.a) v = -v;
+    MG_TRY(blk_comb(h, P, Z, 1.0, P, Beta, n, k));                // P = Z + P Beta
+  }
+  HIP_TRY(spin_sync(h->stream));
+  if (iters) *iters = it;
+  if (flag_out) *flag_out = flag;
+  return MG_OK;
+}
+
+// blockBiCGSTB (El Guennouni, Jbilou, Sadok 2003), right-preconditioned by the cycle
+int block_bicgstab_dev(mg_hierarchy* h, const double* B, double* X, double tol, long long maxIter, long long* iters,
+                       long long* flag_out, double* resvec, long long* nres) {
+  Level& L = h->lev[0];
+  const long long n = L.n;
+  const int k = (int)h->nrhs;
+  if (k > mgk::BLK_KMAX) return fail(MG_ERR_UNSUPPORTED, "block Krylov drivers hold at most %d right-hand sides", mgk::BLK_KMAX);
+  const size_t len = (size_t)n * k;
+  double* w = nullptr;
+  MG_TRY(blk_work(h, 7, n, k, &w));
+  double *R = w, *R0 = w + len, *P = w + 2 * len, *Ph = w + 3 * len, *V = w + 4 * len, *Sh = w + 5 * len, *T = w + 6 * len;
+  std::vector<double> nb, rn;
+  MG_TRY(blk_colnorms(h, B, n, k, nb));
+  long long it = 0, flag = -1, nr = 0;
+  bool any = false;
+  for (double v : nb) any = any || v > 0.0;
+  auto finish = [&](long long f) {
+    if (iters) *iters = it;
+    if (flag_out) *flag_out = f;
+    if (nres) *nres = nr;
+    return (int)MG_OK;
+  };
+  if (!any) {
+    MG_TRY(k_fill(h, X, (long long)len, 0.0));
+    HIP_TRY(spin_sync(h->stream));
+    return finish(-9);
+  }
+  for (double& v : nb) if (!(v > 0.0)) v = 1.0;
+  auto worst_rel = [&](const double* blk, double* out) -> int {
+    MG_TRY(blk_colnorms(h, blk, n, k, rn));
+    double wv = 0.0;
+    for (int j = 0; j < k; ++j) wv = std::max(wv, rn[(size_t)j] / nb[(size_t)j]);
+    *out = wv;
+    return MG_OK;
+  };
+  MG_TRY(k_residual(h, 0, L.A, B, X, R));
+  double err = 0.0;
+  MG_TRY(worst_rel(R, &err));
+  if (resvec) resvec[nr] = err;
+  ++nr;
+  if (err < tol) return finish(0);
+  HIP_TRY(hipMemcpyAsync(R0, R, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(P, R, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
+  const SmallMat I1 = sm_scaled_identity(k, 1.0);
+  for (long long iter = 1; iter <= maxIter; ++iter) {
+    it = iter;
+    MG_TRY(cycle_dev(h, P, Ph, true));                            // Phat = M(P)
+    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, Ph, 0.0, V));        // V = A Phat
+    SmallMat RtV, RtR, alpha;
+    MG_TRY(blk_gram(h, R0, V, n, k, RtV));
+    MG_TRY(blk_gram(h, R0, R, n, k, RtR));
+    if (!sm_solve(RtV, RtR, alpha)) { flag = -2; break; }
+    SmallMat nalpha = alpha;
+    for (double& v : nalpha.a) v = -v;
+    MG_TRY(blk_comb(h, R, R, 1.0, V, nalpha, n, k));              // S = R - V alpha   (in R)
+    double sn = 0.0;
+    MG_TRY(worst_rel(R, &sn));
+    if (resvec) resvec[nr] = sn;
+    ++nr;
+    if (sn < tol) {
+      MG_TRY(blk_comb(h, X, X, 1.0, Ph, alpha, n, k));
+      flag = -3;
+      break;
+    }
+    MG_TRY(cycle_dev(h, R, Sh, true));                            // Shat = M(S)
+    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, Sh, 0.0, T));        // T = A Shat
+    SmallMat TS, TT;
+    MG_TRY(blk_gram(h, T, R, n, k, TS));
+    MG_TRY(blk_gram(h, T, T, n, k, TT));
+    double ts = 0.0, tt = 0.0;
+    for (int j = 0; j < k; ++j) { ts += TS(j, j); tt += TT(j, j); }
+    if (tt == 0.0) { flag = -2; break; }
+    const double omega = ts / tt;
+    MG_TRY(blk_comb(h, X, X, 1.0, Ph, alpha, n, k));              // X += Phat alpha + omega Shat
+    MG_TRY(blk_comb(h, X, X, 1.0, Sh, sm_scaled_identity(k, omega), n, k));
+    MG_TRY(blk_comb(h, R, R, 1.0, T, sm_scaled_identity(k, -omega), n, k));   // R = S - omega T
+    MG_TRY(worst_rel(R, &err));
+    if (resvec) resvec[nr] = err;
+    ++nr;
+    if (err <= tol) { flag = 0; break; }
+    if (omega == 0.0) { flag = -2; break; }
+    SmallMat RtT, beta;
+    MG_TRY(blk_gram(h, R0, T, n, k, RtT));
+    if (!sm_solve(RtV, RtT, beta)) { flag = -2; break; }
+    for (double& v : beta.a) v = -v;
+    MG_TRY(blk_comb(h, P, P, 1.0, V, sm_scaled_identity(k, -omega), n, k));   // P - omega V
+    MG_TRY(blk_comb(h, P, R, 1.0, P, beta, n, k));                // P = R + (P - omega V) beta
+  }
+  HIP_TRY(spin_sync(h->stream));
+  return finish(flag);
+}
+
+// W -> orthonormal block (in place) by Cholesky QR applied twice; Rf with W_in = Q Rf
+int blk_cholqr(mg_hierarchy* h, double* W, long long n, int k, SmallMat& Rf) {
+  SmallMat G;
+  MG_TRY(blk_gram(h, W, W, n, k, G));
+  const SmallMat R1 = sm_chol_semidefinite(G);
+  MG_TRY(blk_comb(h, W, nullptr, 0.0, W, sm_tri_pinv(R1), n, k));
+  MG_TRY(blk_gram(h, W, W, n, k, G));
+  const SmallMat R2 = sm_chol_semidefinite(G);
+  MG_TRY(blk_comb(h, W, nullptr, 0.0, W, sm_tri_pinv(R2), n, k));
+  Rf = sm_mul(R2, R1);
+  return MG_OK;
+}
+
+// blockFGMRES: block flexible GMRES(inner), block modified Gram-Schmidt, exact block least squares per inner step
+int block_fgmres_dev(mg_hierarchy* h, const double* B, double* X, long long inner, double tol, long long maxIter,
+                     long long* iters, long long* flag_out, double* resvec, long long* nres) {
+  Level& L = h->lev[0];
+  const long long n = L.n;
+  const int k = (int)h->nrhs;
+  if (k > mgk::BLK_KMAX) return fail(MG_ERR_UNSUPPORTED, "block Krylov drivers hold at most %d right-hand sides", mgk::BLK_KMAX);
+  if (inner < 1 || inner > 64) return fail(MG_ERR_INVALID, "inner must be in [1,64]");
+  const int m = (int)inner;
+  const size_t len = (size_t)n * k;
+  double* w = nullptr;
+  MG_TRY(blk_work(h, (size_t)(2 * m + 2), n, k, &w));
+  double* Vb = w;                              // m+1 blocks
+  double* Zb = w + (size_t)(m + 1) * len;      // m blocks
+  double* R = Zb + (size_t)m * len;            // residual / W
+  long long nr = 0, flag = -1, total = 0;
+  auto finish = [&](long long f) {
+    if (iters) *iters = total;
+    if (flag_out) *flag_out = f;
+    if (nres) *nres = nr;
+    return (int)MG_OK;
+  };
+  auto fro = [&](const double* blk, double* out) -> int {
+    std::vector<double> cn;
+    MG_TRY(blk_colnorms(h, blk, n, k, cn));
+    double s2 = 0.0;
+    for (double v : cn) s2 += v * v;
+    *out = std::sqrt(s2);
+    return MG_OK;
+  };
+  double bn = 0.0, rn = 0.0;
+  MG_TRY(fro(B, &bn));
+  if (bn == 0.0) {
+    MG_TRY(k_fill(h, X, (long long)len, 0.0));
+    HIP_TRY(spin_sync(h->stream));
+    return finish(-9);
+  }
+  MG_TRY(k_residual(h, 0, L.A, B, X, R));
+  MG_TRY(fro(R, &rn));
+  if (rn / bn < tol) return finish(0);
+  for (long long it = 1; it <= maxIter && flag != 0; ++it) {
+    SmallMat H((m + 1) * k, m * k), xi((m + 1) * k, k), Rf, Y;
+    HIP_TRY(hipMemcpyAsync(Vb, R, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
+    MG_TRY(blk_cholqr(h, Vb, n, k, Rf));
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j) xi(i, j) = Rf(i, j);
+    int used = 0;
+    for (int j = 0; j < m; ++j) {
+      double* Vj = Vb + (size_t)j * len;
+      double* Zj = Zb + (size_t)j * len;
+      double* W = Vb + (size_t)(j + 1) * len;
+      MG_TRY(cycle_dev(h, Vj, Zj, true));                          // Z_j = M(V_j)
+      MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, Zj, 0.0, W));       // W = A Z_j
+      for (int i = 0; i <= j; ++i) {                               // block modified Gram-Schmidt
+        SmallMat Hij;
+        MG_TRY(blk_gram(h, Vb + (size_t)i * len, W, n, k, Hij));
+        for (int a = 0; a < k; ++a)
+          for (int b = 0; b < k; ++b) H(i * k + a, j * k + b) = Hij(a, b);
+        for (double& v : Hij.a) v = -v;
+        MG_TRY(blk_comb(h, W, W, 1.0, Vb + (size_t)i * len, Hij, n, k));
+      }
+      SmallMat Hn;
+      MG_TRY(blk_cholqr(h, W, n, k, Hn));
+      for (int a = 0; a < k; ++a)
+        for (int b = 0; b < k; ++b) H((j + 1) * k + a, j * k + b) = Hn(a, b);
+      SmallMat Hb((j + 2) * k, (j + 1) * k), xb((j + 2) * k, k);
+      for (int a = 0; a < Hb.r; ++a) {
+        for (int b = 0; b < Hb.c; ++b) Hb(a, b) = H(a, b);
+        for (int b = 0; b < k; ++b) xb(a, b) = xi(a, b);
+      }
+      const double err = sm_lstsq(Hb, xb, Y) / bn;
+      if (resvec) resvec[nr] = err;
+      ++nr;
+      ++total;
+      used = j + 1;
+      if (err <= tol) { flag = 0; break; }
+    }
+    for (int j = 0; j < used; ++j) {                               // X += Z_j Y_j
+      SmallMat Yj(k, k);
+      for (int a = 0; a < k; ++a)
+        for (int b = 0; b < k; ++b) Yj(a, b) = Y(j * k + a, b);
+      MG_TRY(blk_comb(h, X, X, 1.0, Zb + (size_t)j * len, Yj, n, k));
+    }
+    if (flag == 0) break;
+    MG_TRY(k_residual(h, 0, L.A, B, X, R));
+    MG_TRY(fro(R, &rn));
+    if (rn / bn <= tol) { flag = 0; break; }
+  }
+  HIP_TRY(spin_sync(h->stream));
+  return finish(flag);
+}
+
 // ---- host <-> device block transfer (column-major host <-> row-major device) --------------------
 int upload_block(mg_hierarchy* h, const double* host, double* dev, long long n, long long nrhs) {
   const size_t bytes = sizeof(double) * (size_t)n * (size_t)nrhs;
@@ -2211,6 +2655,10 @@ int mg_destroy(mg_hierarchy* h) {
   h->kAp.release();
   h->kw.release();
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
+  if (h->h_blk) (void)hipHostFree(h->h_blk);
+  if (h->h_blk_c) (void)hipHostFree(h->h_blk_c);
+  h->blk_partial.release();
+  h->blk_c.release();
   if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MG_OK;
@@ -2655,6 +3103,116 @@ int mg_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long long n, d
   MG_TRY(bicgstab_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec, nres));
   MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
   prof_collect(h);
+  return MG_OK;
+}
+
+// ---- block Krylov drivers: host (column-major n x nrhs) and device-resident (row-major [n][nrhs]) forms ---------------
+int mg_block_pcg_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
+                          long long maxIter, long long* iters, long long* flag, double* resmat) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(block_pcg_dev(h, b, x, tol, maxIter, iters, flag, resmat));
+  prof_collect(h);
+  return MG_OK;
+}
+int mg_block_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
+                      long long maxIter, long long* iters, long long* flag, double* resmat) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
+  MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
+  MG_TRY(block_pcg_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resmat));
+  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
+  prof_collect(h);
+  return MG_OK;
+}
+int mg_block_bicgstab_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
+                               long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(block_bicgstab_dev(h, b, x, tol, maxIter, iters, flag, resvec, nres));
+  prof_collect(h);
+  return MG_OK;
+}
+int mg_block_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
+                           long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
+  MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
+  MG_TRY(block_bicgstab_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec, nres));
+  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
+  prof_collect(h);
+  return MG_OK;
+}
+int mg_block_fgmres_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, long long inner,
+                             double tol, long long maxIter, long long* iters, long long* flag, double* resvec,
+                             long long* nres) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(block_fgmres_dev(h, b, x, inner, tol, maxIter, iters, flag, resvec, nres));
+  prof_collect(h);
+  return MG_OK;
+}
+int mg_block_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, long long inner,
+                         double tol, long long maxIter, long long* iters, long long* flag, double* resvec,
+                         long long* nres) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
+  MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
+  MG_TRY(block_fgmres_dev(h, h->stage_b.p, h->stage_x.p, inner, tol, maxIter, iters, flag, resvec, nres));
+  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
+  prof_collect(h);
+  return MG_OK;
+}
+
+// Mixed-precision preconditioner hook (getMultigridPreconditioner, SolveFuncs.jl:52-58): the caller's block is Float32,
+// the hierarchy Float64: bl .= b ; z .= 0 ; recursiveCycle(param, bl, z, 1) ; z2 .= z.  b32 / z32: n x nrhs column-major.
+int mg_cycle_mixed_FP32(mg_hierarchy* h, const float* b32, float* z32, long long n, long long nrhs) {
+  MG_TRY(check_ready(h, n, nrhs));
+  if (!b32 || !z32) return fail(MG_ERR_INVALID, "null vector");
+  (void)hipSetDevice(h->device);
+  const long long len = n * nrhs;
+  float* f32 = reinterpret_cast<float*>(h->stage_t.p);              // n*nrhs doubles of scratch hold n*nrhs floats twice over
+  HIP_TRY(hipMemcpyAsync(f32, b32, sizeof(float) * (size_t)len, hipMemcpyHostToDevice, h->stream));
+  if (nrhs == 1) {
+    hipLaunchKernelGGL(mgk::f32_to_f64, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, f32, h->stage_b.p, len);
+  } else {   // column-major float -> row-major double through stage_x
+    hipLaunchKernelGGL(mgk::f32_to_f64, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, f32, h->stage_x.p, len);
+    hipLaunchKernelGGL(mgk::colmajor_to_rowmajor, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, h->stage_x.p, h->stage_b.p, n, (int)nrhs);
+  }
+  HIP_TRY(hipGetLastError());
+  MG_TRY(cycle_dev(h, h->stage_b.p, h->stage_x.p, true));
+  if (nrhs == 1) {
+    hipLaunchKernelGGL(mgk::f64_to_f32, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, h->stage_x.p, f32, len);
+  } else {
+    hipLaunchKernelGGL(mgk::rowmajor_to_colmajor, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, h->stage_x.p, h->stage_b.p, n, (int)nrhs);
+    hipLaunchKernelGGL(mgk::f64_to_f32, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, h->stage_b.p, f32, len);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(z32, f32, sizeof(float) * (size_t)len, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(spin_sync(h->stream));
+  prof_collect(h);
+  return MG_OK;
+}
+
+// Page-lock a long-lived host array (param.memCycle[1].x, the caller's b) so that the host-pointer entry points move it
+// at full PCIe rate: the CALLER owns the lifetime - unregister before the array is freed or resized.
+int mg_host_register(void* ptr, long long bytes) {
+  if (!ptr || bytes < 1) return fail(MG_ERR_INVALID, "null pointer or empty range");
+  HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+  return MG_OK;
+}
+int mg_host_unregister(void* ptr) {
+  if (!ptr) return fail(MG_ERR_INVALID, "null pointer");
+  HIP_TRY(hipHostUnregister(ptr));
   return MG_OK;
 }
 

@@ -58,6 +58,15 @@ SIGNATURES = {
     "mg_bicgstab_FP64": (C.c_int, [_vp, _dp, _dp, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
     "mg_bicgstab_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
     "mg_fgmres_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
+    "mg_block_pcg_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp]),
+    "mg_block_pcg_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp]),
+    "mg_block_bicgstab_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
+    "mg_block_bicgstab_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
+    "mg_block_fgmres_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
+    "mg_block_fgmres_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
+    "mg_cycle_mixed_FP32": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _ll, _ll]),
+    "mg_host_register": (C.c_int, [_vp, _ll]),
+    "mg_host_unregister": (C.c_int, [_vp]),
     "mg_spmv_FP64": (C.c_int, [_vp, _ll, _ll, C.c_double, _dp, C.c_double, _dp, _ll]),
     "mg_cycle_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
     "mg_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
@@ -207,6 +216,37 @@ class DeviceHierarchy:
             raise MGDeviceError("param.LU is empty: run MGsetup / SA_AMGsetup first")
         self._set_coarse(param)
         _check(lib, lib.mg_finalize(self.handle), "mg_finalize")
+        self._schedule = self._schedule_of(param)
+
+    def _schedule_of(self, param):
+        nl = self.nlevels
+        return (param.cycleType, param.relaxType, tuple(int(param.relaxPre(l)) for l in range(1, nl)),
+                tuple(int(param.relaxPost(l)) for l in range(1, nl)))
+
+    def sync_schedule(self, param):
+        """Push cycleType / relaxType / sweep counts to the device when they were changed on ``param`` after the upload."""
+        sig = self._schedule_of(param)
+        if sig == getattr(self, "_schedule", sig):
+            self._schedule = sig
+            return
+        lib = self.lib
+        old = self._schedule
+        refinalize = False
+        if sig[1] != old[1]:
+            _check(lib, lib.mg_set_relax_type(self.handle, 1 if param.relaxType == "Jac-GMRES" else 0), "mg_set_relax_type")
+            refinalize = True
+        if sig[2] != old[2] or sig[3] != old[3]:
+            for l in range(1, self.nlevels):
+                d = np.ascontiguousarray(param.relaxPrecs[l - 1], dtype=np.float64)
+                _check(lib, lib.mg_set_relax_FP64(self.handle, l, _f64(d), d.size, sig[2][l - 1], sig[3][l - 1]),
+                       f"mg_set_relax(level={l})")
+            refinalize = True
+        if sig[0] != old[0]:
+            _check(lib, lib.mg_set_cycle_type(self.handle, ord(param.cycleType)), "mg_set_cycle_type")
+            refinalize = refinalize or "K" in (sig[0], old[0])
+        if refinalize:
+            _check(lib, lib.mg_finalize(self.handle), "mg_finalize")
+        self._schedule = sig
 
     def _set_coarse(self, param, force_sparse: bool = False):
         """`z = param.LU\\b` (MGcycle.jl:177) on the device: the explicit inverse for small coarsest levels, the sparse
@@ -315,11 +355,19 @@ class DeviceHierarchy:
         return x, int(iters.value), resvec[: iters.value + 1]
 
     def pcg(self, b, x, tol: float, maxIter: int):
-        """KrylovMethods.cg with the MG cycle as preconditioner; returns (x, flag, iters, resvec)."""
+        """KrylovMethods.cg / blockCG with the MG cycle as preconditioner; returns (x, flag, iters, resvec)
+        (resvec: ||r||/||b|| per iteration; for a block the maximum over the columns)."""
         b = self._host_block(b)
         x = self._host_block(x, True)
+        if b.ndim != 1 and b.shape[1] > 1:
+            iters, flag = C.c_longlong(0), C.c_longlong(0)
+            resmat = np.zeros((max(int(maxIter), 1), b.shape[1]))
+            _check(self.lib, self.lib.mg_block_pcg_FP64(self.handle, _f64(b), _f64(x), b.shape[0], b.shape[1], float(tol),
+                                                        int(maxIter), C.byref(iters), C.byref(flag), _f64(resmat)), "mg_block_pcg")
+            self.last_resmat = resmat[: iters.value]
+            return x, int(flag.value), int(iters.value), resmat[: iters.value].max(axis=1) if iters.value else np.zeros(0)
         if b.ndim != 1:
-            raise MGDeviceError("mg_pcg: one right-hand side only (blockCG is not on the device path)")
+            b, x = b[:, 0], x[:, 0]
         iters, flag = C.c_longlong(0), C.c_longlong(0)
         resvec = np.zeros(max(int(maxIter), 1))
         _check(self.lib, self.lib.mg_pcg_FP64(self.handle, _f64(b), _f64(x), b.shape[0], float(tol), int(maxIter),
@@ -330,10 +378,15 @@ class DeviceHierarchy:
         """KrylovMethods.bicgstb with the MG cycle as M1; returns (x, flag, iters, resvec)."""
         b = self._host_block(b)
         x = self._host_block(x, True)
-        if b.ndim != 1:
-            raise MGDeviceError("mg_bicgstab: one right-hand side only (blockBiCGSTB is not on the device path)")
         iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
         resvec = np.zeros(2 * int(maxIter) + 1)
+        if b.ndim != 1 and b.shape[1] > 1:
+            _check(self.lib, self.lib.mg_block_bicgstab_FP64(self.handle, _f64(b), _f64(x), b.shape[0], b.shape[1], float(tol),
+                                                             int(maxIter), C.byref(iters), C.byref(flag), _f64(resvec),
+                                                             C.byref(nres)), "mg_block_bicgstab")
+            return x, int(flag.value), int(iters.value), resvec[: nres.value]
+        if b.ndim != 1:
+            b, x = b[:, 0], x[:, 0]
         _check(self.lib, self.lib.mg_bicgstab_FP64(self.handle, _f64(b), _f64(x), b.shape[0], float(tol), int(maxIter),
                                                    C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)), "mg_bicgstab")
         return x, int(flag.value), int(iters.value), resvec[: nres.value]
@@ -342,14 +395,31 @@ class DeviceHierarchy:
         """KrylovMethods.fgmres (flexible) with the MG cycle as preconditioner; returns (x, flag, iters, resvec)."""
         b = self._host_block(b)
         x = self._host_block(x, True)
-        if b.ndim != 1:
-            raise MGDeviceError("mg_fgmres: one right-hand side only (blockFGMRES is not on the device path)")
         iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
         resvec = np.zeros(max(1, int(inner) * int(maxIter)))
+        if b.ndim != 1 and b.shape[1] > 1:
+            _check(self.lib, self.lib.mg_block_fgmres_FP64(self.handle, _f64(b), _f64(x), b.shape[0], b.shape[1], int(inner),
+                                                           float(tol), int(maxIter), C.byref(iters), C.byref(flag), _f64(resvec),
+                                                           C.byref(nres)), "mg_block_fgmres")
+            return x, int(flag.value), int(iters.value), resvec[: nres.value]
+        if b.ndim != 1:
+            b, x = b[:, 0], x[:, 0]
         _check(self.lib, self.lib.mg_fgmres_FP64(self.handle, _f64(b), _f64(x), b.shape[0], int(inner), float(tol),
                                                  int(maxIter), C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)),
                "mg_fgmres")
         return x, int(flag.value), int(iters.value), resvec[: nres.value]
+
+    def cycle_mixed_f32(self, b32, z32):
+        """getMultigridPreconditioner's mixed-precision branch (SolveFuncs.jl:52-58): Float32 block, Float64 hierarchy."""
+        if b32.dtype != np.float32 or z32.dtype != np.float32:
+            raise TypeError("expected float32 arrays")
+        nrhs = 1 if b32.ndim == 1 else b32.shape[1]
+        if b32.ndim == 2 and nrhs > 1 and not (b32.flags.f_contiguous and z32.flags.f_contiguous):
+            raise ValueError("2-D blocks must be column-major (Julia layout)")
+        fp = C.POINTER(C.c_float)
+        _check(self.lib, self.lib.mg_cycle_mixed_FP32(self.handle, b32.ctypes.data_as(fp), z32.ctypes.data_as(fp), b32.shape[0], nrhs),
+               "mg_cycle_mixed_FP32")
+        return z32
 
     def pcg_dev(self, b, x, tol: float, maxIter: int):
         iters, flag = C.c_longlong(0), C.c_longlong(0)
@@ -513,6 +583,17 @@ class DeviceOperator:
             self.close()
         except Exception:
             pass
+
+
+def host_register(a: np.ndarray):
+    """Page-lock a long-lived numpy array (mg_host_register); the caller unregisters it before it is freed."""
+    lib = load_library()
+    _check(lib, lib.mg_host_register(_vp(a.ctypes.data), a.nbytes), "mg_host_register")
+
+
+def host_unregister(a: np.ndarray):
+    lib = load_library()
+    _check(lib, lib.mg_host_unregister(_vp(a.ctypes.data)), "mg_host_unregister")
 
 
 def vec_dscale(d, b, x, n, nrhs=1, stream=0):

@@ -56,13 +56,17 @@ def spgemm(A, B, nthreads: int = 0):
     L = lib()
     if nthreads <= 0:      # torchrun exports OMP_NUM_THREADS=1 to every rank: MG_HOST_THREADS overrides it here
         nthreads = int(os.environ.get("MG_HOST_THREADS", "0") or 0)
-    L.mg_spgemm_count_INT64(n, B.shape[1], _p64(Ap), _p64(Ai), _p64(Bp), _p64(Bi), _p64(Cp), int(nthreads))
+    rc = L.mg_spgemm_count_INT64(n, B.shape[1], _p64(Ap), _p64(Ai), _p64(Bp), _p64(Bi), _p64(Cp), int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"mg_spgemm_count_INT64 failed (status {rc})")
     np.cumsum(Cp, out=Cp)
     nnz = int(Cp[-1])
     Ci = np.empty(max(nnz, 1), dtype=np.int64)
     Cv = np.empty(max(nnz, 1), dtype=np.float64)
-    L.mg_spgemm_fill_FP64_INT64(n, B.shape[1], _p64(Ap), _p64(Ai), _pf(Av), _p64(Bp), _p64(Bi), _pf(Bv), _p64(Cp),
-                                _p64(Ci), _pf(Cv), int(nthreads))
+    rc = L.mg_spgemm_fill_FP64_INT64(n, B.shape[1], _p64(Ap), _p64(Ai), _pf(Av), _p64(Bp), _p64(Bi), _pf(Bv), _p64(Cp),
+                                     _p64(Ci), _pf(Cv), int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"mg_spgemm_fill_FP64_INT64 failed (status {rc})")
     idx_t = np.int32 if max(nnz, B.shape[1]) < 2 ** 31 - 1 else np.int64
     Cm = sp.csr_matrix((Cv[:nnz], Ci[:nnz].astype(idx_t), Cp.astype(idx_t)), shape=(n, B.shape[1]))
     Cm.has_sorted_indices = True

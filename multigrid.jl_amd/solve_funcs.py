@@ -23,6 +23,10 @@ def to_device(param: MGparam, device_id: int = 0) -> DeviceHierarchy:
         raise RuntimeError("The Hierarchy is empty - run a setup first.")
     if param.device is None:
         param.device = DeviceHierarchy(param, device_id=device_id, nrhs=max(1, param.nrhs))
+    else:
+        # the reference reads cycleType / relaxType / relaxPre / relaxPost from param on every cycle
+        # (MGcycle.jl:44-45,72-85): follow changes made after the upload
+        param.device.sync_schedule(param)
     return param.device
 
 
@@ -53,6 +57,14 @@ def getMultigridPreconditioner(param: MGparam, B: np.ndarray, verbose: bool = Fa
         print("You have to do a setup first.")
     adjustMemoryForNumRHS(param, _ncols(B))
     dev = to_device(param)
+    if B.dtype == np.float32:            # mixed precision (SolveFuncs.jl:52-58): bl .= b; cycle in Float64; z2 .= z
+        z2 = np.zeros_like(B, order="F")
+
+        def MMG32(b):
+            dev.cycle_mixed_f32(np.asfortranarray(b, dtype=np.float32), z2)
+            return z2
+
+        return MMG32
     z = np.zeros_like(B, order="F")
 
     def MMG(b):
@@ -67,7 +79,7 @@ def solveCG_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, verbose: bool =
     """``(x, param, iter) = solveCG_MG(AT,param,b,x0,verbose)`` (SolveFuncs.jl:104-116): KrylovMethods.cg with
     the multigrid cycle as preconditioner, vectors resident on the device across iterations.  ``A`` is accepted
     for signature parity; the operator applied is ``param.As[1]`` on the device (the reference passes the same
-    matrix twice).  x0 is updated in place.  One right-hand side (blockCG: not on the device path)."""
+    matrix twice).  x0 is updated in place.  ``size(b,2) > 1`` takes the blockCG branch (l.113), also on the device."""
     adjustMemoryForNumRHS(param, _ncols(b))
     dev = to_device(param)
     x, flag, it, resvec = dev.pcg(b, x0, param.relativeTol, param.maxOuterIter)
@@ -81,7 +93,7 @@ def solveCG_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, verbose: bool =
 
 def solveBiCGSTAB_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, verbose: bool = False):
     """``(x, param, iter, nprec) = solveBiCGSTAB_MG(AT,param,b,x0,verbose)`` (SolveFuncs.jl:87-101): KrylovMethods.bicgstb
-    with M1 = the multigrid cycle, M2 = identity, on the device.  One right-hand side."""
+    with M1 = the multigrid cycle, M2 = identity, on the device; blocks take the blockBiCGSTB branch (l.95)."""
     adjustMemoryForNumRHS(param, _ncols(b))
     dev = to_device(param)
     x, flag, it, resvec = dev.bicgstab(b, x0, param.relativeTol, param.maxOuterIter)
@@ -94,7 +106,8 @@ def solveBiCGSTAB_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, verbose: 
 def solveGMRES_MG(A, param: MGparam, b: np.ndarray, x0: np.ndarray, flexible: bool, inner: int, verbose: bool = False):
     """``(x, param, iter, resvec) = solveGMRES_MG(AT,param,b,x0,flexible,inner,verbose)`` (SolveFuncs.jl:119-133):
     KrylovMethods.fgmres with the multigrid cycle as preconditioner on the device (always the flexible variant: the
-    cycle is a fixed linear operator, so flexible and standard GMRES generate the same iterates).  One right-hand side."""
+    cycle is a fixed linear operator, so flexible and standard GMRES generate the same iterates); blocks take the
+    blockFGMRES branch (l.130)."""
     adjustMemoryForNumRHS(param, _ncols(b))
     dev = to_device(param)
     x, flag, it, resvec = dev.fgmres(b, x0, inner, param.relativeTol, param.maxOuterIter)

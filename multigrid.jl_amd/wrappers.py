@@ -67,8 +67,12 @@ def solveLinearSystem_(A, B: np.ndarray, X: np.ndarray, param: MGsolver, doTrans
     verbose = param.out > 0
     if not hierarchyExists(param.MG):
         doTi = (doTranspose + 1) % 2 if param.isTranspose else doTranspose
-        if param.sym != 1 and doTi == 0:
-            A = sp.csr_matrix(A.T)                                   # "Transposing!!!" (l.54-56)
+        # The reference hands MGsetup the TRANSPOSED matrix (it stores AT and applies AT'), so it transposes for
+        # doTransposeIterative == 0 (MGWrapper.jl:54-56).  This package's MGsetup(M) sets up and applies M itself (CSR
+        # of the operator, tests/test_host_api.py: As[1] == R*A*P), so the operator to hand over is A for
+        # doTransposeIterative == 0 and A' for 1: the condition is the other way round.
+        if param.sym != 1 and doTi == 1:
+            A = sp.csr_matrix(A.T)
         t0 = time.perf_counter()
         if param.kind == "SA":
             SA_AMGsetup(A, param.MG, param.sym == 1, nrhs, verbose)

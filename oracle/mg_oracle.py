@@ -771,3 +771,198 @@ def applyHybridKaczmarz(A, ArrIdxs, x, b, invD, numit):
                     for k in range(s, e):                 # l.29-32
                         X[ci[k], c] += inner * va[k]
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Block Krylov methods (KrylovMethods v0.6.0, un-vendored: blockCG, blockBiCGSTB, blockFGMRES; call sites
+# SolveFuncs.jl:95,113,130).  The package source is not in the reference tree, so these restate the PUBLISHED
+# algorithms the package implements (O'Leary 1980 block CG with a pseudo-inverse of P'AP; El Guennouni, Jbilou and
+# Sadok 2003 block BiCGSTAB; block flexible GMRES with block modified Gram-Schmidt).  Stopping rules follow the
+# package's documented convention: per-column relative residuals, all columns <= tol (blockCG / blockBiCGSTB), Frobenius
+# norm for blockFGMRES.  Exact flag values cannot be checked offline; they are documented in include/mgvcycle.h.
+# ---------------------------------------------------------------------------------------------------------------------
+def _colnorms(M_):
+    return np.sqrt((M_ * M_).sum(axis=0))
+
+
+def blockCG(Afun, B, tol=1e-2, maxIter=100, M=None, X=None):
+    """O'Leary's block CG: Alpha = pinv(P'Q) P'R ; X += P Alpha ; R -= Q Alpha ; Beta = -pinv(P'Q) Q'Z ; P = Z + P Beta.
+    Returns (X, flag, resmat[iter, nrhs] of ||r_j||/||b_j||, iterations)."""
+    B = np.asarray(B, dtype=np.float64)
+    n, k = B.shape
+    nb = _colnorms(B)
+    if not np.any(nb > 0):
+        return np.zeros((n, k)), -9, np.zeros((0, k)), 0
+    nb = np.where(nb > 0, nb, 1.0)
+    if X is None:
+        X = np.zeros((n, k))
+        R = B.copy()
+    else:
+        R = B - Afun(X)
+    Mf = M if M is not None else (lambda V: V.copy())
+    Z = Mf(R).copy()
+    P = Z.copy()
+    res = []
+    flag, it = -1, 0
+    for it in range(1, maxIter + 1):
+        Q = Afun(P).copy()
+        PTQ = P.T @ Q
+        pinvPTQ = np.linalg.pinv(0.5 * (PTQ + PTQ.T))            # P'AP is symmetric for the s.p.d. operators CG is for
+        Alpha = pinvPTQ @ (P.T @ R)
+        X += P @ Alpha
+        R -= Q @ Alpha
+        res.append(_colnorms(R) / nb)
+        if res[-1].max() <= tol:
+            flag = 0
+            break
+        Z = Mf(R).copy()
+        Beta = -pinvPTQ @ (Q.T @ Z)
+        P = Z + P @ Beta
+    return X, flag, np.array(res), it
+
+
+def blockBiCGSTB(Afun, B, tol=1e-6, maxIter=100, M1=None, X=None):
+    """Block BiCGSTAB (El Guennouni / Jbilou / Sadok) with right preconditioning by M1 (M2 = identity):
+    Phat = M(P); V = A Phat; alpha = (R0'V) \ (R0'R); S = R - V alpha; Shat = M(S); T = A Shat;
+    omega = <T,S>_F / <T,T>_F; X += Phat alpha + omega Shat; R = S - omega T; beta = -(R0'V) \ (R0'T);
+    P = R + (P - omega V) beta.  Residual entries: max_j ||s_j||/||b_j|| after the half step, max_j ||r_j||/||b_j||
+    after the full one.  Returns (X, flag, iterations, resvec)."""
+    B = np.asarray(B, dtype=np.float64)
+    n, k = B.shape
+    nb = _colnorms(B)
+    if not np.any(nb > 0):
+        return np.zeros((n, k)), -9, 0, np.zeros(0)
+    nb = np.where(nb > 0, nb, 1.0)
+    if X is None:
+        X = np.zeros((n, k))
+    Mf = M1 if M1 is not None else (lambda V: V.copy())
+    R = B - Afun(X)
+    resvec = [(_colnorms(R) / nb).max()]
+    if resvec[0] < tol:
+        return X, 0, 0, np.array(resvec)
+    R0 = R.copy()
+    P = R.copy()
+    flag, it = -1, 0
+    for it in range(1, maxIter + 1):
+        Phat = Mf(P).copy()
+        V = Afun(Phat).copy()
+        RtV = R0.T @ V
+        alpha = np.linalg.solve(RtV, R0.T @ R)
+        S = R - V @ alpha
+        sn = (_colnorms(S) / nb).max()
+        resvec.append(sn)
+        if sn < tol:
+            X += Phat @ alpha
+            flag = -3
+            break
+        Shat = Mf(S).copy()
+        T = Afun(Shat).copy()
+        tt = (T * T).sum()
+        if tt == 0.0:
+            flag = -2
+            break
+        omega = (T * S).sum() / tt
+        X += Phat @ alpha + omega * Shat
+        R = S - omega * T
+        err = (_colnorms(R) / nb).max()
+        resvec.append(err)
+        if err <= tol:
+            flag = 0
+            break
+        if omega == 0.0:
+            flag = -2
+            break
+        beta = -np.linalg.solve(RtV, R0.T @ T)
+        P = R + (P - omega * V) @ beta
+    return X, flag, it, np.array(resvec)
+
+
+def _chol_semidefinite(G, rtol=1e-14):
+    """Upper triangular Rf with G = Rf' Rf for a positive SEMI-definite Gram matrix: a column whose pivot falls below
+    rtol * G[c,c] is linearly dependent on the earlier ones and gets a zero row / zero diagonal (its direction is dropped)."""
+    k = G.shape[0]
+    Rf = np.zeros((k, k))
+    for c in range(k):
+        d = G[c, c] - np.dot(Rf[:c, c], Rf[:c, c])
+        if G[c, c] <= 0.0 or d <= rtol * G[c, c]:
+            continue
+        Rf[c, c] = np.sqrt(d)
+        for j in range(c + 1, k):
+            Rf[c, j] = (G[c, j] - np.dot(Rf[:c, c], Rf[:c, j])) / Rf[c, c]
+    return Rf
+
+
+def _tri_pinv_apply(W, Rf):
+    """Q = W Rf^+ for the upper triangular Rf of _chol_semidefinite (zero pivots give zero columns of Q)."""
+    k = Rf.shape[0]
+    Q = np.zeros_like(W)
+    for c in range(k):
+        if Rf[c, c] == 0.0:
+            continue
+        Q[:, c] = (W[:, c] - Q[:, :c] @ Rf[:c, c]) / Rf[c, c]
+    return Q
+
+
+def _cholqr(W):
+    """Orthonormal basis of the columns of W by Cholesky QR applied twice (Gram matrix -> triangular factor -> Q = W Rf^+),
+    rank deficiency tolerated: (Q, Rf) with W = Q Rf, Rf upper triangular."""
+    R1 = _chol_semidefinite(W.T @ W)
+    Q = _tri_pinv_apply(W, R1)
+    R2 = _chol_semidefinite(Q.T @ Q)
+    Q = _tri_pinv_apply(Q, R2)
+    return Q, R2 @ R1
+
+
+def blockFGMRES(Afun, B, restrt, tol=1e-2, maxIter=100, M=None, X=None):
+    """Block flexible GMRES(restrt): block modified Gram-Schmidt Arnoldi on n x k blocks (orthonormalised by Cholesky QR
+    applied twice - the package uses Julia's qr; any orthonormal basis of the same block gives the same iterates), the
+    small block least-squares problem solved exactly after every inner step, residual estimate ||xi - H Y||_F/||B||_F.
+    Returns (X, flag, total inner steps, resvec)."""
+    B = np.asarray(B, dtype=np.float64)
+    n, k = B.shape
+    bn = np.linalg.norm(B)
+    if bn == 0:
+        return np.zeros((n, k)), -9, 0, np.zeros(0)
+    if X is None:
+        X = np.zeros((n, k))
+    Mf = M if M is not None else (lambda V: V.copy())
+    R = B - Afun(X)
+    if np.linalg.norm(R) / bn < tol:
+        return X, 0, 0, np.zeros(0)
+    m = restrt
+    resvec, flag, total = [], -1, 0
+    for it in range(1, maxIter + 1):
+        V = [None] * (m + 1)
+        Z = [None] * m
+        H = np.zeros(((m + 1) * k, m * k))
+        V[0], Rf = _cholqr(R)
+        xi = np.zeros(((m + 1) * k, k))
+        xi[:k] = Rf
+        used, Y = 0, None
+        for j in range(m):
+            Z[j] = Mf(V[j]).copy()
+            W = Afun(Z[j]).copy()
+            for i in range(j + 1):
+                Hij = V[i].T @ W
+                H[i * k:(i + 1) * k, j * k:(j + 1) * k] = Hij
+                W = W - V[i] @ Hij
+            V[j + 1], Hn = _cholqr(W)
+            H[(j + 1) * k:(j + 2) * k, j * k:(j + 1) * k] = Hn
+            Hb = H[:(j + 2) * k, :(j + 1) * k]
+            Y = np.linalg.lstsq(Hb, xi[:(j + 2) * k], rcond=None)[0]
+            err = np.linalg.norm(xi[:(j + 2) * k] - Hb @ Y) / bn
+            resvec.append(err)
+            total += 1
+            used = j + 1
+            if err <= tol:
+                flag = 0
+                break
+        for j in range(used):
+            X = X + Z[j] @ Y[j * k:(j + 1) * k]
+        if flag == 0:
+            break
+        R = B - Afun(X)
+        if np.linalg.norm(R) / bn <= tol:
+            flag = 0
+            break
+    return X, flag, total, np.array(resvec)
