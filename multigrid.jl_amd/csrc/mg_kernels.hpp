@@ -581,6 +581,123 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-class SpMV, every lane walking its own row's class (any operator in row-class form whose dictionary fits LDS:
+// at most RL_DCAP entries / RL_NCLS classes).  The waterfall kernel above serves one class per pass with a chain of
+// scalar dictionary loads; measured on C2 (profiles/r02_march_ab.md) that chain, not memory, bounds it wherever a
+// wavefront holds more than one class (a prolongation alternates classes from row to row, a restriction has 27 entries
+// per row).  Here the dictionary lives in LDS as 16-byte records {value, column offset}, a lane reads the records of its
+// own class (ascending k: the summation order of the CSR row) four at a time and keeps the four gathers of each of its
+// two rows in flight.  No passes, no scalar chain; rows of different classes in one wavefront cost nothing extra.
+// ------------------------------------------------------------------------------------------------
+constexpr int RL_DCAP = 512;
+constexpr int RL_NCLS = 128;
+constexpr int RL_ROWS = 2 * BLK;   // rows per workgroup (lane t: rows t and t + BLK)
+struct LaneDev {
+  int ncls, nent, maxlen, nblocks;
+};
+struct LaneEnt {
+  double val;
+  int off;
+  int pad;
+};
+
+template <int MODE, bool EXC>
+__global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, VecArgs v, LaneDev T) {
+  __shared__ LaneEnt ent[RL_DCAP];
+  __shared__ int ptr[RL_NCLS + 1];
+  __shared__ int delta[RL_NCLS];
+  __shared__ double dd[RL_NCLS];
+  __shared__ double red[BLK / 64];
+  const int tid = threadIdx.x;
+  const int bid = xcd_band(blockIdx.x, T.nblocks);
+  const bool class_d = (MODE == SMOOTH) && !v.d;
+  for (int i = tid; i < T.nent; i += BLK) {
+    LaneEnt e;
+    e.val = C.cls_val[i];
+    e.off = C.cls_off[i];
+    e.pad = 0;
+    ent[i] = e;
+  }
+  for (int i = tid; i <= T.ncls; i += BLK) ptr[i] = C.cls_ptr[i];
+  for (int i = tid; i < T.ncls; i += BLK) {
+    delta[i] = C.firstcol ? 0 : C.cls_delta[i];
+    dd[i] = class_d ? C.cls_d[i] : 0.0;
+  }
+  int row[2], s[2], len[2];
+  const double* xb[2];
+  double pb[2], pd[2], px[2], acc[2];
+  bool live[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    row[j] = bid * RL_ROWS + j * BLK + tid;
+    const bool in = row[j] < C.n_rows;
+    const int rr = in ? row[j] : C.n_rows - 1;
+    const int cls = C.cls[rr];
+    live[j] = in && cls != 0xFFFF;                          // 0xFFFF: exception row (csr_rows_spmv)
+    const int first = C.firstcol ? C.firstcol[rr] : rr;
+    pb[j] = pd[j] = px[j] = 0.0;
+    acc[j] = 0.0;
+    if (MODE == AXPBY) {
+      if (v.beta != 0.0) pb[j] = v.beta * v.y[rr];
+    } else {
+      pb[j] = v.b[rr];
+      if (MODE == SMOOTH) {
+        if (v.d) pd[j] = v.d[rr];
+        px[j] = v.xs[rr];
+      }
+    }
+    s[j] = live[j] ? cls : 0;                               // (class id for now; resolved after the barrier)
+    xb[j] = v.x + first;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cq = s[j];
+    s[j] = ptr[cq];
+    len[j] = live[j] ? ptr[cq + 1] - s[j] : 0;
+    xb[j] += delta[cq];
+    if (class_d) pd[j] = dd[cq];
+  }
+  for (int k = 0; k < T.maxlen; k += 4) {
+    double g[2][4];
+    int id[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        id[j][u] = s[j] + min(k + u, len[j] > 0 ? len[j] - 1 : 0);
+        g[j][u] = (k + u < len[j]) ? xb[j][ent[id[j][u]].off] : 0.0;
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double t = acc[j] + ent[id[j][u]].val * g[j][u];
+        acc[j] = (k + u < len[j]) ? t : acc[j];
+      }
+  }
+  double sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (live[j]) {
+      const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], px[j]);
+      v.y[row[j]] = outv;
+      sq += outv * outv;
+    }
+  if (EXC && blockIdx.x == gridDim.x - 1) sq += rowclass_exception_rows<MODE>(C, v, tid);   // EXC: C.nexc_inline > 0
+  if (v.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) t += red[w];
+      v.sumsq[bid] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row-class SpMV with LDS windows (square operators in the implicit-first form).
 // The plain row-class kernel above is bound by L2->L1 line traffic: every dictionary entry is its own gather and
 // the y+-1 / z+-1 neighbours of a grid row arrive as separate, unaligned 512-byte requests (~25 cache lines of x
@@ -1626,9 +1743,11 @@ __global__ __launch_bounds__(1024) void sptrsv_lu(LuDev F, const double* __restr
 // ------------------------------------------------------------------------------------------------
 // Numeric Galerkin product on a FIXED sparsity: C = R*(A*P) (replaceMatrixInHierarchy, MGsetup.jl:226-270:
 // `Act = Ps[l]*AT*Rs[l]` with unchanged P, R; the pattern of C is the one the host setup produced).
-// One wavefront (a 64-thread workgroup) per coarse row i: lanes split the entries (i,k) of R's row, walk A's
-// row k and P's rows j, find the column in C's (sorted) row by binary search in LDS and accumulate there
-// with LDS atomics.  Rows of C longer than RAP_CAP are left to the host path.
+// One wavefront (a 64-thread workgroup) per coarse row i.  DETERMINISTIC: the entries (i,k) of R's row and (k,j) of
+// A's rows are walked one after the other in stored order; only the entries (j,c) of ONE row of P - distinct target
+// columns - are spread over the lanes, each lane finds its column in C's (sorted) row by binary search in LDS and adds
+// there without atomics.  Every entry of C is therefore the same sum in the same order on every run.
+// Rows of C longer than RAP_CAP are left to the host path.
 // ------------------------------------------------------------------------------------------------
 constexpr int RAP_CAP = 1024;
 __global__ __launch_bounds__(64) void rap_numeric(CsrDev R, CsrDev A, CsrDev P, const int* __restrict__ Crowptr,
@@ -1644,22 +1763,24 @@ __global__ __launch_bounds__(64) void rap_numeric(CsrDev R, CsrDev A, CsrDev P, 
     sacc[t] = 0.0;
   }
   __syncthreads();
-  for (int kk = R.rowptr[i] + lane; kk < R.rowptr[i + 1]; kk += 64) {
-    const int k = R.colidx[kk];
-    const double rv = R.val[kk];
-    for (int jj = A.rowptr[k]; jj < A.rowptr[k + 1]; ++jj) {
-      const int j = A.colidx[jj];
-      const double ra = rv * A.val[jj];
-      for (int pp = P.rowptr[j]; pp < P.rowptr[j + 1]; ++pp) {
-        const int c = P.colidx[pp];
-        if (len == 0) continue;
-        int lo = 0, hi = len - 1;
-        while (lo < hi) {  // the pattern of C contains every reachable column by construction
-          const int mid = (lo + hi) >> 1;
-          if (scol[mid] < c) lo = mid + 1;
-          else hi = mid;
+  if (len > 0) {
+    for (int kk = R.rowptr[i]; kk < R.rowptr[i + 1]; ++kk) {        // wave-uniform, stored order
+      const int k = R.colidx[kk];
+      const double rv = R.val[kk];
+      for (int jj = A.rowptr[k]; jj < A.rowptr[k + 1]; ++jj) {      // wave-uniform, stored order
+        const int j = A.colidx[jj];
+        const double ra = rv * A.val[jj];
+        for (int pp = P.rowptr[j] + lane; pp < P.rowptr[j + 1]; pp += 64) {   // distinct columns: one lane each
+          const int c = P.colidx[pp];
+          int lo = 0, hi = len - 1;
+          while (lo < hi) {  // the pattern of C contains every reachable column by construction
+            const int mid = (lo + hi) >> 1;
+            if (scol[mid] < c) lo = mid + 1;
+            else hi = mid;
+          }
+          if (scol[lo] == c) sacc[lo] += ra * P.val[pp];
         }
-        if (scol[lo] == c) atomicAdd(&sacc[lo], ra * P.val[pp]);
+        __builtin_amdgcn_wave_barrier();   // one wavefront: LDS accesses of the next row of P follow in program order
       }
     }
   }

@@ -57,7 +57,7 @@ static inline hipError_t spin_sync(hipStream_t s) {
 struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
-  bool no_march = false, fuse_prolong = false;
+  bool no_march = false, fuse_prolong = false, no_lane = false;
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -77,7 +77,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -218,8 +218,11 @@ struct Csr {
     return d;
   }
   bool rc_pair = false;     // plain row-class kernel with two consecutive rows per lane (alternating classes)
+  // csr_rowclass_lane_spmv (every lane walks its own class, dictionary in LDS) replaces the waterfall kernel when the
+  // dictionary fits
+  bool rc_lane() const { return has_rc && !opt.no_lane && rc_ncls <= mgk::RL_NCLS && rc_entries <= mgk::RL_DCAP; }
   int rc_blocks() const {
-    const long long rows = rc_pair ? 2 * mgk::BLK : mgk::RC_ROWS;
+    const long long rows = rc_lane() ? mgk::RL_ROWS : (rc_pair ? 2 * mgk::BLK : mgk::RC_ROWS);
     return (int)((n_rows + rows - 1) / rows);
   }
   // workgroups of the nrhs == 1 product (one fused ||r||^2 partial each)
@@ -569,6 +572,15 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
       const size_t lds = (size_t)M.rw_doubles * sizeof(double);
       if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, true>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
       else hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, false>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
+    } else if (M.rc_lane()) {
+      nb_main = M.rc_blocks();
+      mgk::LaneDev T;
+      T.ncls = (int)M.rc_ncls;
+      T.nent = (int)M.rc_entries;
+      T.maxlen = M.rc_maxlen;
+      T.nblocks = nb_main;
+      if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmv<MODE, true>), dim3(nb_main), blk, 0, stream, C, v, T);
+      else hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmv<MODE, false>), dim3(nb_main), blk, 0, stream, C, v, T);
     } else {
       nb_main = M.rc_blocks();
       if (M.rc_pair) {
@@ -2577,8 +2589,8 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(spin_sync(h->stream));
-  // row-class dictionaries follow the new values (coarse values come back from HBM; the atomically accumulated
-  // products are usually no longer bit-identical from row to row, in which case the level reverts to streaming)
+  // row-class dictionaries follow the new values (coarse values come back from HBM; rap_numeric adds every entry in a
+  // fixed order, so rows that were bit-identical before a constant-coefficient update still are afterwards)
   MG_TRY(refresh_rowclasses(&L0.A, fine_nzval));
   for (int l = 1; l < nl; ++l) {
     Csr& Ac = h->lev[(size_t)l].A;
@@ -3388,7 +3400,7 @@ int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which
   if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
   if (implicit_first) *implicit_first = (M->has_rc && M->rc_implicit) ? 1 : 0;
   if (class_relax) *class_relax = (M->has_rc && M->rc_has_d) ? 1 : 0;
-  if (kernel_variant) *kernel_variant = !M->has_rc ? -1 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : 0;
+  if (kernel_variant) *kernel_variant = !M->has_rc ? -1 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : M->rc_lane() ? 4 : 0;
   if (exception_rows) *exception_rows = M->has_rc ? M->rc_nexc : 0;
   return MG_OK;
 }

@@ -285,6 +285,11 @@ def test_replace_matrix_on_device(mg, built, relaxType, omega, cells):
     b2 = A2 @ rng.random(A.shape[0])
     b2 /= np.linalg.norm(b2)
     _compare_solve(mg, p, b2)
+    # the device product is deterministic (no atomics): a second pass over the same values gives the same bits
+    first = [M.data.copy() for M in p.As[1:]]
+    mg.replaceMatrixInHierarchy(p, A2)
+    for v0, M in zip(first, p.As[1:]):
+        assert np.array_equal(v0, M.data)
     mg.clear_(p)
 
 
@@ -557,10 +562,12 @@ def test_rowclass_variants_on_odd_grids(mg, built, cells, levels, monkeypatch):
     monkeypatch.setenv("MG_PAIR_MIN_ROWS", "0")          # paired-rows variant of the plain kernel for P (alternating classes)
     rng = np.random.default_rng(sum(cells))
     seen = set()
-    for no_tile, no_win, no_first in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
+    for no_tile, no_win, no_first, no_lane in (("0", "0", "0", "0"), ("1", "0", "0", "0"), ("1", "1", "0", "0"),
+                                               ("1", "1", "1", "0"), ("1", "1", "0", "1"), ("1", "1", "1", "1")):
         monkeypatch.setenv("MG_NO_TILE", no_tile)
         monkeypatch.setenv("MG_NO_WINDOW", no_win)
         monkeypatch.setenv("MG_NO_IMPLICIT_FIRST", no_first)
+        monkeypatch.setenv("MG_NO_LANE", no_lane)              # csr_rowclass_lane_spmv / the waterfall kernel
         A, p, b = _setup(mg, cells, levels)
         h = mg.to_device(p)
         for l in range(1, p.levels):
@@ -584,7 +591,7 @@ def test_rowclass_variants_on_odd_grids(mg, built, cells, levels, monkeypatch):
             assert np.abs(got - want).max() / np.abs(want).max() < KERNEL_TOL
         _compare_solve(mg, p, b)
         mg.clear_(p)
-    assert 0 in seen                      # the plain row-class kernel ran in the last configuration
+    assert 0 in seen and 4 in seen        # the waterfall and the per-lane row-class kernels both ran
 
 
 @pytest.mark.gpu
