@@ -314,7 +314,7 @@ def kernel_symbol(h, mg, p, l, nrhs):
         inl = "true" if 0 < nexc <= 256 else "false"   # a short list of exception rows is handled in-kernel
         return ({0: "mgk::csr_rowclass_spmv<2, %s, false>", 1: "mgk::csr_rowclass_window_spmv<2, %s>",
                  2: "mgk::csr_rowclass_tile_spmv<2, %s>", 3: "mgk::csr_rowclass_march_spmv<2, %s, false>",
-                 4: "mgk::csr_rowclass_lane_spmv<2, %s>"}[var] % inl,
+                 4: "mgk::csr_rowclass_lane_spmv<2, %s, true>"}[var] % inl,
                 "row classes")
     fm = h.operator_format(l, D.MG_OP_A)
     if fm[0] > 0:

@@ -601,7 +601,9 @@ struct LaneEnt {
   int pad;
 };
 
-template <int MODE, bool EXC>
+// PAIR: lane t holds the ADJACENT rows 2t, 2t+1 of its workgroup's 512 (16-byte loads / stores of the row operands;
+// chosen for operators whose classes alternate row by row, i.e. prolongations); else rows t and t + 256.
+template <int MODE, bool EXC, bool PAIR>
 __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, VecArgs v, LaneDev T) {
   __shared__ LaneEnt ent[RL_DCAP];
   __shared__ int ptr[RL_NCLS + 1];
@@ -627,27 +629,71 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
   const double* xb[2];
   double pb[2], pd[2], px[2], acc[2];
   bool live[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    row[j] = bid * RL_ROWS + j * BLK + tid;
-    const bool in = row[j] < C.n_rows;
-    const int rr = in ? row[j] : C.n_rows - 1;
-    const int cls = C.cls[rr];
-    live[j] = in && cls != 0xFFFF;                          // 0xFFFF: exception row (csr_rows_spmv)
-    const int first = C.firstcol ? C.firstcol[rr] : rr;
-    pb[j] = pd[j] = px[j] = 0.0;
-    acc[j] = 0.0;
+  const int r0 = bid * RL_ROWS + 2 * tid;
+  const bool both = PAIR && (r0 + 1 < C.n_rows);
+  if (both) {   // 16-byte / 8-byte / 4-byte loads of the two adjacent rows' operands (r0 is even)
+    const unsigned int cc = *reinterpret_cast<const unsigned int*>(C.cls + r0);
+    const int c0 = (int)(cc & 0xFFFFu), c1 = (int)(cc >> 16);
+    int f0 = r0, f1 = r0 + 1;
+    if (C.firstcol) {
+      const i2_t f = *reinterpret_cast<const i2_t*>(C.firstcol + r0);
+      f0 = f.x;
+      f1 = f.y;
+    }
+    row[0] = r0;
+    row[1] = r0 + 1;
+    live[0] = c0 != 0xFFFF;
+    live[1] = c1 != 0xFFFF;
+    s[0] = live[0] ? c0 : 0;
+    s[1] = live[1] ? c1 : 0;
+    xb[0] = v.x + f0;
+    xb[1] = v.x + f1;
+    pb[0] = pb[1] = pd[0] = pd[1] = px[0] = px[1] = 0.0;
+    acc[0] = acc[1] = 0.0;
     if (MODE == AXPBY) {
-      if (v.beta != 0.0) pb[j] = v.beta * v.y[rr];
+      if (v.beta != 0.0) {
+        const d2_t yy = *reinterpret_cast<const d2_t*>(v.y + r0);
+        pb[0] = v.beta * yy.x;
+        pb[1] = v.beta * yy.y;
+      }
     } else {
-      pb[j] = v.b[rr];
+      const d2_t bb = *reinterpret_cast<const d2_t*>(v.b + r0);
+      pb[0] = bb.x;
+      pb[1] = bb.y;
       if (MODE == SMOOTH) {
-        if (v.d) pd[j] = v.d[rr];
-        px[j] = v.xs[rr];
+        if (v.d) {
+          const d2_t t = *reinterpret_cast<const d2_t*>(v.d + r0);
+          pd[0] = t.x;
+          pd[1] = t.y;
+        }
+        const d2_t xx = *reinterpret_cast<const d2_t*>(v.xs + r0);
+        px[0] = xx.x;
+        px[1] = xx.y;
       }
     }
-    s[j] = live[j] ? cls : 0;                               // (class id for now; resolved after the barrier)
-    xb[j] = v.x + first;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      row[j] = PAIR ? r0 + j : bid * RL_ROWS + j * BLK + tid;
+      const bool in = row[j] < C.n_rows;
+      const int rr = in ? row[j] : C.n_rows - 1;
+      const int cls = C.cls[rr];
+      live[j] = in && cls != 0xFFFF;                          // 0xFFFF: exception row (csr_rows_spmv)
+      const int first = C.firstcol ? C.firstcol[rr] : rr;
+      pb[j] = pd[j] = px[j] = 0.0;
+      acc[j] = 0.0;
+      if (MODE == AXPBY) {
+        if (v.beta != 0.0) pb[j] = v.beta * v.y[rr];
+      } else {
+        pb[j] = v.b[rr];
+        if (MODE == SMOOTH) {
+          if (v.d) pd[j] = v.d[rr];
+          px[j] = v.xs[rr];
+        }
+      }
+      s[j] = live[j] ? cls : 0;                               // (class id for now; resolved after the barrier)
+      xb[j] = v.x + first;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -677,13 +723,21 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
       }
   }
   double sq = 0.0;
+  if (both && live[0] && live[1]) {
+    d2_t o;
+    o.x = epilogue<MODE>(v, row[0], acc[0], pb[0], pd[0], px[0]);
+    o.y = epilogue<MODE>(v, row[1], acc[1], pb[1], pd[1], px[1]);
+    *reinterpret_cast<d2_t*>(v.y + r0) = o;
+    sq = o.x * o.x + o.y * o.y;
+  } else {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-    if (live[j]) {
-      const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], px[j]);
-      v.y[row[j]] = outv;
-      sq += outv * outv;
-    }
+    for (int j = 0; j < 2; ++j)
+      if (live[j]) {
+        const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], px[j]);
+        v.y[row[j]] = outv;
+        sq += outv * outv;
+      }
+  }
   if (EXC && blockIdx.x == gridDim.x - 1) sq += rowclass_exception_rows<MODE>(C, v, tid);   // EXC: C.nexc_inline > 0
   if (v.sumsq) {
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
