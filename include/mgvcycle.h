@@ -321,6 +321,45 @@ int mg_kaczmarz_apply_dev_FP64(mg_kaczmarz* k, double* x_dev, const double* b_de
                                long long sequential);
 int mg_kaczmarz_destroy(mg_kaczmarz* k);
 
+/* ---- native multi-GPU sequencer (one process per GPU) ---------------------------------------------------------
+ * The sharded cycle of src/DomainDecomposition's partition (box rule DDIndices.jl:41-47, numbering DDService.jl:27-48;
+ * worker map analogue DDParallel.jl:105,133-139) behind the C ABI: the host cuts every sharded level into local
+ * operators [owned | halo] (mg_op_create_FP64_INT64) and halo plans; this handle owns the vectors and the hot loop -
+ * per SpMV the boundary values are packed, exchanged with ncclSend/ncclRecv inside ncclGroupStart/End on a SIDE stream
+ * while the interior rows run, the boundary rows after the event; one scalar all-reduce per solveMG step; levels below
+ * the sharded ones are all-gathered and run replicated by an ordinary mg_hierarchy (the tail).  One right-hand side.
+ * Transport: RCCL (pass the 128-byte id of mg_dist_unique_id, broadcast by the host, to mg_dist_create) or a
+ * host-staged plug-in (tests; several ranks sharing one GPU).  Levels are 1-based; `which` is MG_OP_A / P / R. */
+typedef struct mg_dist mg_dist;
+/* op 0: all_to_all (send/recv splits per peer, in doubles) ; 1: all_reduce sum of `count` doubles ; 2: all_gather of `count`
+ * doubles per rank.  Host buffers.  Returns 0 on success. */
+typedef int (*mg_exchange_fn)(void* user, long long op, const double* send, const long long* send_splits, double* recv,
+                              const long long* recv_splits, long long count);
+int mg_dist_unique_id(char* id128);
+int mg_dist_create(long long device_id, long long rank, long long world, const char* unique_id128, long long nlevels_sharded,
+                   long long nlevels_total, long long cycleType, mg_dist** out);
+int mg_dist_set_exchange_plugin(mg_dist* h, mg_exchange_fn fn, void* user);
+/* This rank's part of sharded level `level`: rows renumbered [interior | boundary] (interior = rows of A without halo
+ * columns), A held as two operators, P / R with halo columns appended, relaxPrecs of the owned rows (device). */
+int mg_dist_set_level(mg_dist* h, long long level, long long n_own, long long n_int, mg_operator* A_int, mg_operator* A_bnd,
+                      mg_operator* P, mg_operator* R, const double* d_dev, long long relaxPre, long long relaxPost);
+/* Halo plan of one operator: the source vector is [n_own_src owned | n_halo received]; send_idx (0-based, into the owned
+ * part) grouped by destination rank with send_splits[world]; recv_splits[world]; active = 0 if no rank exchanges anything. */
+int mg_dist_set_plan_INT64(mg_dist* h, long long level, long long which, long long n_own_src, long long n_halo,
+                           long long n_send, const long long* send_idx, const long long* send_splits,
+                           const long long* recv_splits, long long active);
+/* The replicated tail: an mg_hierarchy of the levels below the sharded ones (its stream is re-pointed to this handle's),
+ * this rank's share own_tail of its first level, the padded share max_tail, and gather_index[n_tail] into the
+ * all-gathered [world][max_tail] array. */
+int mg_dist_set_tail_INT64(mg_dist* h, mg_hierarchy* tail, long long n_tail, long long own_tail, long long max_tail,
+                           const long long* gather_index);
+int mg_dist_finalize(mg_dist* h);
+/* b_loc / x_loc: this rank's fine rows (device, n_own doubles, the [interior | boundary] order). */
+int mg_dist_cycle_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long long n_own, long long x_is_zero);
+int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long long n_own, double tol, long long maxIter,
+                           long long* iters, double* resvec);
+int mg_dist_destroy(mg_dist* h);
+
 const char* mg_last_error(void);
 const char* mg_version(void);
 

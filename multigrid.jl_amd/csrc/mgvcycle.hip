@@ -3681,6 +3681,519 @@ int mg_kaczmarz_apply_FP64(mg_kaczmarz* k, double* x, const double* b, long long
   return MG_OK;
 }
 
+// =================================================================================================================
+// Native multi-GPU sequencer (one process per GPU): the level schedule of the sharded cycle in C++, halo exchange by
+// RCCL send/recv on a side stream overlapped with the interior rows, scalar all-reduce for the norm, replicated tail.
+// Partition: the reference's DomainDecomposition box rule (DDIndices.jl:41-47, DDService.jl:27-48); worker map analogue:
+// DDParallel.jl:105,133-139.  The host (multigrid.jl_amd/distributed.py, or the Julia glue) cuts the hierarchy into
+// local operators [owned | halo] and send lists; this code owns the vectors and the hot loop.
+// =================================================================================================================
+#include <dlfcn.h>
+namespace {
+// RCCL is loaded lazily (dlopen) so that single-GPU users of the library do not depend on it.
+struct Rccl {
+  typedef struct { char internal[128]; } UniqueId;
+  void* lib = nullptr;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load() {
+    if (lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);          // the copy torch already mapped, if any
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) return false;
+    auto sym = [&](const char* n) { return dlsym(lib, n); };
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && AllGather;
+  }
+};
+Rccl g_rccl;
+constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;   // ncclFloat64, ncclSum (rccl.h)
+
+struct DistPlan {
+  bool set = false, active = false;
+  long long n_own_src = 0, n_halo = 0, n_send = 0;
+  DevBuf<int> send_idx;
+  DevBuf<double> send_buf;
+  std::vector<long long> send_splits, recv_splits;   // per peer
+  double *h_send = nullptr, *h_recv = nullptr;       // pinned staging (plug-in transport)
+};
+struct DistLevel {
+  long long n_own = 0, n_int = 0;
+  mg_operator *A_int = nullptr, *A_bnd = nullptr, *P = nullptr, *R = nullptr;   // borrowed handles
+  const double* d = nullptr;                                                    // borrowed device vector (n_own)
+  long long npre = 1, npost = 1;
+  DistPlan planA, planR, planP;
+  long long cap_x = 0, cap_r = 0;
+  DevBuf<double> x0, x1, r, b;
+};
+}  // namespace
+
+__global__ __launch_bounds__(256) void dist_pack(const double* __restrict__ src, const int* __restrict__ idx,
+                                                 double* __restrict__ dst, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ __launch_bounds__(256) void dist_gather64(const double* __restrict__ src, const long long* __restrict__ idx,
+                                                     double* __restrict__ dst, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+struct mg_dist {
+  int device = 0, rank = 0, world = 1;
+  void* comm = nullptr;                 // ncclComm_t (RCCL transport)
+  mg_exchange_fn plug = nullptr;        // host-staged transport (tests / one shared GPU)
+  void* plug_user = nullptr;
+  hipStream_t stream = nullptr, side = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_landed = nullptr;
+  std::vector<DistLevel> lev;
+  char cycle = 'V';
+  bool finalized = false;
+  // replicated tail
+  mg_hierarchy* tail = nullptr;
+  long long n_tail = 0, own_tail = 0, max_tail = 0, nl_total = 0;
+  DevBuf<double> bc_pad, bc_all, b_tail, x_tail;
+  DevBuf<long long> gather_index;
+  // reductions
+  DevBuf<double> partial, scalar;
+  double* h_scalar = nullptr;
+  double* h_stage = nullptr;            // pinned staging for the plug-in collectives
+  size_t h_stage_n = 0;
+};
+
+namespace {
+int dist_nccl(int rc, const char* what) {
+  if (rc == 0) return MG_OK;
+  return fail(MG_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+}
+#define NCCL_TRY(expr) MG_TRY(dist_nccl((expr), #expr))
+
+int dist_stage(mg_dist* h, size_t n) {
+  if (h->h_stage_n >= n) return MG_OK;
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), sizeof(double) * n));
+  h->h_stage_n = n;
+  return MG_OK;
+}
+
+// Start filling the halo tail buf[n_own_src : n_own_src + n_halo] (values the peers need are packed first).
+// RCCL: pack on the compute stream, send/recv on the side stream; the compute stream goes on.  Plug-in: done on return.
+int dist_exchange_start(mg_dist* h, DistPlan& p, double* buf) {
+  if (!p.set || !p.active) return MG_OK;
+  if (p.n_send > 0)
+    hipLaunchKernelGGL(dist_pack, dim3((unsigned)((p.n_send + 255) / 256)), dim3(256), 0, h->stream, buf, p.send_idx.p, p.send_buf.p, p.n_send);
+  HIP_TRY(hipGetLastError());
+  double* recv = buf + p.n_own_src;
+  if (h->comm) {
+    HIP_TRY(hipEventRecord(h->ev_packed, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_packed, 0));
+    NCCL_TRY(g_rccl.GroupStart());
+    long long so = 0, ro = 0;
+    for (int peer = 0; peer < h->world; ++peer) {
+      const long long ns = p.send_splits[(size_t)peer], nr = p.recv_splits[(size_t)peer];
+      if (ns > 0) NCCL_TRY(g_rccl.Send(p.send_buf.p + so, (size_t)ns, NCCL_DOUBLE, peer, h->comm, h->side));
+      if (nr > 0) NCCL_TRY(g_rccl.Recv(recv + ro, (size_t)nr, NCCL_DOUBLE, peer, h->comm, h->side));
+      so += ns;
+      ro += nr;
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipEventRecord(h->ev_landed, h->side));
+    return MG_OK;
+  }
+  // host-staged transport
+  if (p.n_send > 0) HIP_TRY(hipMemcpyAsync(p.h_send, p.send_buf.p, sizeof(double) * (size_t)p.n_send, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(spin_sync(h->stream));
+  if (h->plug(h->plug_user, 0, p.h_send, p.send_splits.data(), p.h_recv, p.recv_splits.data(), 0) != 0)
+    return fail(MG_ERR_HIP, "exchange plug-in failed (all_to_all)");
+  if (p.n_halo > 0) HIP_TRY(hipMemcpyAsync(recv, p.h_recv, sizeof(double) * (size_t)p.n_halo, hipMemcpyHostToDevice, h->stream));
+  return MG_OK;
+}
+// Make the compute stream wait for the halo started by dist_exchange_start.
+int dist_exchange_finish(mg_dist* h, DistPlan& p) {
+  if (!p.set || !p.active) return MG_OK;
+  if (h->comm) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_landed, 0));
+  return MG_OK;
+}
+
+int dist_apply(mg_dist* h, mg_operator* op, long long kernel, double alpha, const double* x, double beta, double* y,
+               const double* b, const double* d, long long row_offset) {
+  if (!op) return MG_OK;
+  return mg_op_apply_rows_dev_FP64(op, kernel, alpha, x, beta, y, b, d, 1, row_offset, h->stream);
+}
+// out = b - A x / out = x + d.*(b - A x) on this rank's rows, the halo exchange overlapped with the interior rows
+int dist_apply_A(mg_dist* h, DistLevel& L, long long kernel, double* x, double* out, const double* b) {
+  MG_TRY(dist_exchange_start(h, L.planA, x));
+  MG_TRY(dist_apply(h, L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, 0));
+  MG_TRY(dist_exchange_finish(h, L.planA));
+  MG_TRY(dist_apply(h, L.A_bnd, kernel, 1.0, x, 0.0, out, b, L.d, L.n_int));
+  return MG_OK;
+}
+// global Frobenius norm of a sharded vector: local sum of squares + one scalar all-reduce (SolveFuncs.jl:15,20,30)
+int dist_norm(mg_dist* h, const double* v, long long n, double* out) {
+  MG_TRY(mg_vec_sumsq_dev_FP64(v, n, h->partial.p, h->scalar.p, h->stream));
+  if (h->comm) {
+    NCCL_TRY(g_rccl.AllReduce(h->scalar.p, h->scalar.p, 1, NCCL_DOUBLE, NCCL_SUM, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(spin_sync(h->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(spin_sync(h->stream));
+    if (h->world > 1) {
+      double in = *h->h_scalar, outv = 0.0;
+      if (h->plug(h->plug_user, 1, &in, nullptr, &outv, nullptr, 1) != 0) return fail(MG_ERR_HIP, "exchange plug-in failed (all_reduce)");
+      *h->h_scalar = outv;
+    }
+  }
+  *out = std::sqrt(*h->h_scalar);
+  return MG_OK;
+}
+
+// the sharded cycle: mirror of cycle_level (MGcycle.jl:1-118); returns the buffer holding x
+int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
+               bool r_valid = false) {
+  DistLevel& L = h->lev[(size_t)l];
+  double *cur = xa, *alt = xb;
+  long long npre = L.npre;
+  const long long npost = L.npost;
+  if (x_zero) {
+    MG_TRY(mg_vec_dscale_dev_FP64(L.d, b, cur, L.n_own, 1, h->stream));
+    --npre;
+  } else if (r_valid) {
+    MG_TRY(mg_vec_xpdr_dev_FP64(cur, L.d, L.r.p, alt, L.n_own, 1, h->stream));
+    std::swap(cur, alt);
+    --npre;
+  }
+  for (long long s = 0; s < npre; ++s) {
+    MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
+    std::swap(cur, alt);
+  }
+  MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
+  MG_TRY(dist_exchange_start(h, L.planR, L.r.p));
+  MG_TRY(dist_exchange_finish(h, L.planR));
+  if (l + 1 < (int)h->lev.size()) {
+    DistLevel& C = h->lev[(size_t)l + 1];
+    MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, C.b.p, nullptr, nullptr, 0));
+    double* xc = nullptr;
+    MG_TRY(dist_cycle(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
+    if (ctype == 'W' || ctype == 'F') {
+      double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
+      MG_TRY(dist_cycle(h, l + 1, C.b.p, xc, other, false, ctype == 'W' ? 'W' : 'V', &xc));
+    }
+    MG_TRY(dist_exchange_start(h, L.planP, xc));
+    MG_TRY(dist_exchange_finish(h, L.planP));
+    MG_TRY(dist_apply(h, L.P, MG_K_PROLONG, 1.0, xc, 1.0, cur, nullptr, nullptr, 0));
+  } else {
+    // restrict into this rank's rows of the first replicated level, all-gather, run the tail replicated
+    MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, h->bc_pad.p, nullptr, nullptr, 0));
+    if (h->comm) {
+      NCCL_TRY(g_rccl.AllGather(h->bc_pad.p, h->bc_all.p, (size_t)h->max_tail, NCCL_DOUBLE, h->comm, h->stream));
+    } else if (h->world > 1) {
+      MG_TRY(dist_stage(h, (size_t)h->max_tail * (size_t)(h->world + 1)));
+      HIP_TRY(hipMemcpyAsync(h->h_stage, h->bc_pad.p, sizeof(double) * (size_t)h->max_tail, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(spin_sync(h->stream));
+      if (h->plug(h->plug_user, 2, h->h_stage, nullptr, h->h_stage + h->max_tail, nullptr, h->max_tail) != 0)
+        return fail(MG_ERR_HIP, "exchange plug-in failed (all_gather)");
+      HIP_TRY(hipMemcpyAsync(h->bc_all.p, h->h_stage + h->max_tail, sizeof(double) * (size_t)(h->max_tail * h->world), hipMemcpyHostToDevice, h->stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(h->bc_all.p, h->bc_pad.p, sizeof(double) * (size_t)h->max_tail, hipMemcpyDeviceToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(dist_gather64, dim3((unsigned)((h->n_tail + 255) / 256)), dim3(256), 0, h->stream, h->bc_all.p, h->gather_index.p, h->b_tail.p, h->n_tail);
+    HIP_TRY(hipGetLastError());
+    MG_TRY(mg_set_cycle_type(h->tail, ctype));
+    MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, 1, 1));
+    if ((long long)h->lev.size() < h->nl_total - 1 && (ctype == 'W' || ctype == 'F')) {       // second visit (MGcycle.jl:79-84)
+      MG_TRY(mg_set_cycle_type(h->tail, ctype == 'W' ? 'W' : 'V'));
+      MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, 1, 0));
+    }
+    MG_TRY(dist_apply(h, L.P, MG_K_PROLONG, 1.0, h->x_tail.p, 1.0, cur, nullptr, nullptr, 0));
+  }
+  for (long long s = 0; s < npost; ++s) {
+    MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
+    std::swap(cur, alt);
+  }
+  *result = cur;
+  return MG_OK;
+}
+
+int dist_set_plan(mg_dist* h, DistPlan& p, long long n_own_src, long long n_halo, long long n_send, const long long* send_idx,
+                  const long long* send_splits, const long long* recv_splits, long long active) {
+  p.set = true;
+  p.active = active != 0;
+  p.n_own_src = n_own_src;
+  p.n_halo = n_halo;
+  p.n_send = n_send;
+  p.send_splits.assign(send_splits, send_splits + h->world);
+  p.recv_splits.assign(recv_splits, recv_splits + h->world);
+  long long ss = 0, rs = 0;
+  for (int q = 0; q < h->world; ++q) { ss += p.send_splits[(size_t)q]; rs += p.recv_splits[(size_t)q]; }
+  if (ss != n_send || rs != n_halo) return fail(MG_ERR_INVALID, "halo plan: splits do not add up (send %lld/%lld, recv %lld/%lld)", ss, n_send, rs, n_halo);
+  std::vector<int> idx((size_t)std::max<long long>(n_send, 1), 0);
+  for (long long i = 0; i < n_send; ++i) {
+    if (send_idx[i] < 0 || send_idx[i] >= n_own_src) return fail(MG_ERR_INVALID, "halo plan: send index out of range");
+    idx[(size_t)i] = (int)send_idx[i];
+  }
+  MG_TRY(p.send_idx.alloc(idx.size()));
+  MG_TRY(p.send_buf.alloc(idx.size()));
+  HIP_TRY(hipMemcpy(p.send_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!h->comm) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_send), sizeof(double) * (size_t)std::max<long long>(n_send, 1)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_recv), sizeof(double) * (size_t)std::max<long long>(n_halo, 1)));
+  }
+  return MG_OK;
+}
+void dist_free_plan(DistPlan& p) {
+  p.send_idx.release();
+  p.send_buf.release();
+  if (p.h_send) (void)hipHostFree(p.h_send);
+  if (p.h_recv) (void)hipHostFree(p.h_recv);
+  p.h_send = p.h_recv = nullptr;
+}
+}  // namespace
+
+int mg_dist_unique_id(char* id128) {
+  if (!id128) return fail(MG_ERR_INVALID, "null argument");
+  if (!g_rccl.load()) return fail(MG_ERR_HIP, "librccl.so could not be loaded");
+  Rccl::UniqueId u;
+  NCCL_TRY(g_rccl.GetUniqueId(&u));
+  std::memcpy(id128, u.internal, 128);
+  return MG_OK;
+}
+
+int mg_dist_create(long long device_id, long long rank, long long world, const char* unique_id128, long long nlevels,
+                   long long nl_total, long long cycleType, mg_dist** out) {
+  if (!out) return fail(MG_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world || nlevels < 1 || nl_total <= nlevels)
+    return fail(MG_ERR_INVALID, "bad rank/world/levels (%lld/%lld, %lld sharded of %lld)", rank, world, nlevels, nl_total);
+  if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F') return fail(MG_ERR_UNSUPPORTED, "the sharded cycle implements V, W and F");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
+  HIP_TRY(hipSetDevice((int)device_id));
+  mg_dist* h = new mg_dist();
+  h->device = (int)device_id;
+  h->rank = (int)rank;
+  h->world = (int)world;
+  h->cycle = (char)cycleType;
+  h->nl_total = nl_total;
+  h->lev.resize((size_t)nlevels);
+  auto bail = [&](int rc) { mg_dist_destroy(h); return rc; };
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_landed, hipEventDisableTiming) != hipSuccess ||
+      h->partial.alloc(1024) != MG_OK || h->scalar.alloc(1) != MG_OK || hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), sizeof(double)) != hipSuccess)
+    return bail(fail(MG_ERR_HIP, "stream / event / scratch creation failed"));
+  if (unique_id128) {
+    if (!g_rccl.load()) return bail(fail(MG_ERR_HIP, "librccl.so could not be loaded"));
+    Rccl::UniqueId u;
+    std::memcpy(u.internal, unique_id128, 128);
+    const int rc = g_rccl.CommInitRank(&h->comm, (int)world, u, (int)rank);
+    if (rc != 0) return bail(dist_nccl(rc, "ncclCommInitRank"));
+  }
+  *out = h;
+  return MG_OK;
+}
+
+int mg_dist_set_exchange_plugin(mg_dist* h, mg_exchange_fn fn, void* user) {
+  if (!h || !fn) return fail(MG_ERR_INVALID, "null argument");
+  if (h->comm) return fail(MG_ERR_STATE, "this handle was created with an RCCL communicator");
+  h->plug = fn;
+  h->plug_user = user;
+  return MG_OK;
+}
+
+int mg_dist_set_level(mg_dist* h, long long level, long long n_own, long long n_int, mg_operator* A_int, mg_operator* A_bnd,
+                      mg_operator* P, mg_operator* R, const double* d_dev, long long relaxPre, long long relaxPost) {
+  if (!h) return fail(MG_ERR_INVALID, "null handle");
+  if (level < 1 || level > (long long)h->lev.size()) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  if (n_own < 1 || n_int < 0 || n_int > n_own || !P || !R || !d_dev || (n_int > 0 && !A_int) || (n_int < n_own && !A_bnd))
+    return fail(MG_ERR_INVALID, "inconsistent level description");
+  DistLevel& L = h->lev[(size_t)level - 1];
+  L.n_own = n_own;
+  L.n_int = n_int;
+  L.A_int = A_int;
+  L.A_bnd = A_bnd;
+  L.P = P;
+  L.R = R;
+  L.d = d_dev;
+  L.npre = std::max<long long>(1, relaxPre);      // relax() always updates once (MGcycle.jl:127-134)
+  L.npost = std::max<long long>(1, relaxPost);
+  h->finalized = false;
+  return MG_OK;
+}
+
+int mg_dist_set_plan_INT64(mg_dist* h, long long level, long long which, long long n_own_src, long long n_halo, long long n_send,
+                           const long long* send_idx, const long long* send_splits, const long long* recv_splits, long long active) {
+  UploadFence upload_fence;
+  if (!h) return fail(MG_ERR_INVALID, "null handle");
+  if (level < 1 || level > (long long)h->lev.size() || which < 0 || which > 2) return fail(MG_ERR_INVALID, "bad (level, which)");
+  if (!send_splits || !recv_splits || (n_send > 0 && !send_idx) || n_halo < 0 || n_send < 0) return fail(MG_ERR_INVALID, "bad plan arrays");
+  (void)hipSetDevice(h->device);
+  DistLevel& L = h->lev[(size_t)level - 1];
+  DistPlan& p = which == MG_OP_A ? L.planA : (which == MG_OP_P ? L.planP : L.planR);
+  dist_free_plan(p);
+  h->finalized = false;
+  return dist_set_plan(h, p, n_own_src, n_halo, n_send, send_idx, send_splits, recv_splits, active);
+}
+
+int mg_dist_set_tail_INT64(mg_dist* h, mg_hierarchy* tail, long long n_tail, long long own_tail, long long max_tail,
+                           const long long* gather_index) {
+  UploadFence upload_fence;
+  if (!h || !tail || !gather_index || n_tail < 1 || max_tail < 1 || own_tail < 0 || own_tail > max_tail) return fail(MG_ERR_INVALID, "bad tail description");
+  (void)hipSetDevice(h->device);
+  h->tail = tail;
+  h->n_tail = n_tail;
+  h->own_tail = own_tail;
+  h->max_tail = max_tail;
+  MG_TRY(h->bc_pad.alloc((size_t)max_tail));
+  MG_TRY(h->bc_all.alloc((size_t)max_tail * (size_t)h->world));
+  MG_TRY(h->b_tail.alloc((size_t)n_tail));
+  MG_TRY(h->x_tail.alloc((size_t)n_tail));
+  MG_TRY(h->gather_index.alloc((size_t)n_tail));
+  for (long long i = 0; i < n_tail; ++i)
+    if (gather_index[i] < 0 || gather_index[i] >= max_tail * h->world) return fail(MG_ERR_INVALID, "gather index out of range");
+  HIP_TRY(hipMemset(h->bc_pad.p, 0, h->bc_pad.bytes()));
+  HIP_TRY(hipMemset(h->x_tail.p, 0, h->x_tail.bytes()));
+  HIP_TRY(hipMemcpy(h->gather_index.p, gather_index, (size_t)n_tail * sizeof(long long), hipMemcpyHostToDevice));
+  MG_TRY(mg_set_stream(tail, h->stream));
+  h->finalized = false;
+  return MG_OK;
+}
+
+int mg_dist_finalize(mg_dist* h) {
+  UploadFence upload_fence;
+  if (!h) return fail(MG_ERR_INVALID, "null handle");
+  (void)hipSetDevice(h->device);
+  if (!h->tail) return fail(MG_ERR_STATE, "the replicated tail was not set");
+  if (h->world > 1 && !h->comm && !h->plug) return fail(MG_ERR_STATE, "no transport: pass an RCCL unique id to mg_dist_create or set an exchange plug-in");
+  const int a = (int)h->lev.size();
+  for (int l = 0; l < a; ++l) {
+    DistLevel& L = h->lev[(size_t)l];
+    if (L.n_own < 1) return fail(MG_ERR_STATE, "sharded level %d was not set", l + 1);
+    if (!L.planA.set || !L.planR.set || (l + 1 < a && !L.planP.set)) return fail(MG_ERR_STATE, "halo plans of level %d are incomplete", l + 1);
+    long long halo_x = L.planA.n_halo;
+    if (l > 0 && h->lev[(size_t)l - 1].planP.set) halo_x = std::max(halo_x, h->lev[(size_t)l - 1].planP.n_halo);
+    L.cap_x = L.n_own + halo_x;
+    L.cap_r = L.n_own + L.planR.n_halo;
+    MG_TRY(L.x0.alloc((size_t)L.cap_x));
+    MG_TRY(L.x1.alloc((size_t)L.cap_x));
+    MG_TRY(L.r.alloc((size_t)L.cap_r));
+    HIP_TRY(hipMemset(L.x0.p, 0, L.x0.bytes()));
+    HIP_TRY(hipMemset(L.x1.p, 0, L.x1.bytes()));
+    HIP_TRY(hipMemset(L.r.p, 0, L.r.bytes()));
+    if (l > 0) {
+      MG_TRY(L.b.alloc((size_t)L.n_own));
+      HIP_TRY(hipMemset(L.b.p, 0, L.b.bytes()));
+    }
+  }
+  h->finalized = true;
+  return MG_OK;
+}
+
+int mg_dist_cycle_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long long n_own, long long x_is_zero) {
+  if (!h || !b_loc || !x_loc) return fail(MG_ERR_INVALID, "null argument");
+  if (!h->finalized) return fail(MG_ERR_STATE, "mg_dist_finalize was not called");
+  DistLevel& L = h->lev[0];
+  if (n_own != L.n_own) return fail(MG_ERR_INVALID, "n_own=%lld but this rank owns %lld fine rows", n_own, L.n_own);
+  (void)hipSetDevice(h->device);
+  HIP_TRY(hipMemcpyAsync(L.x0.p, x_loc, sizeof(double) * (size_t)n_own, hipMemcpyDeviceToDevice, h->stream));
+  double* res = nullptr;
+  MG_TRY(dist_cycle(h, 0, b_loc, L.x0.p, L.x1.p, x_is_zero != 0, h->cycle, &res));
+  HIP_TRY(hipMemcpyAsync(x_loc, res, sizeof(double) * (size_t)n_own, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(spin_sync(h->stream));
+  return MG_OK;
+}
+
+// solveMG (SolveFuncs.jl:3-39) on sharded vectors
+int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long long n_own, double tol, long long maxIter,
+                           long long* iters, double* resvec) {
+  if (!h || !b_loc || !x_loc || maxIter < 0) return fail(MG_ERR_INVALID, "null argument or maxIter < 0");
+  if (!h->finalized) return fail(MG_ERR_STATE, "mg_dist_finalize was not called");
+  DistLevel& L = h->lev[0];
+  if (n_own != L.n_own) return fail(MG_ERR_INVALID, "n_own=%lld but this rank owns %lld fine rows", n_own, L.n_own);
+  (void)hipSetDevice(h->device);
+  double *cur = L.x0.p, *alt = L.x1.p;
+  HIP_TRY(hipMemcpyAsync(cur, x_loc, sizeof(double) * (size_t)n_own, hipMemcpyDeviceToDevice, h->stream));
+  double xn = 0.0, res0 = 0.0, res = 0.0;
+  MG_TRY(dist_norm(h, cur, n_own, &xn));
+  bool x_zero = (xn == 0.0);
+  if (x_zero) {
+    MG_TRY(dist_norm(h, b_loc, n_own, &res0));
+  } else {
+    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b_loc));
+    MG_TRY(dist_norm(h, L.r.p, n_own, &res0));
+  }
+  if (resvec) resvec[0] = res0;
+  long long it = 0;
+  for (long long count = 1; count <= maxIter; ++count) {
+    double* out = nullptr;
+    MG_TRY(dist_cycle(h, 0, b_loc, cur, alt, x_zero, h->cycle, &out, count > 1 || !x_zero));
+    if (out != cur) std::swap(cur, alt);
+    x_zero = false;
+    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b_loc));
+    MG_TRY(dist_norm(h, L.r.p, n_own, &res));
+    ++it;
+    if (resvec) resvec[it] = res;
+    if (res / res0 < tol) break;
+  }
+  HIP_TRY(hipMemcpyAsync(x_loc, cur, sizeof(double) * (size_t)n_own, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(spin_sync(h->stream));
+  if (iters) *iters = it;
+  return MG_OK;
+}
+
+int mg_dist_destroy(mg_dist* h) {
+  if (!h) return MG_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)spin_sync(h->stream);
+  if (h->side) (void)spin_sync(h->side);
+  if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+  for (auto& L : h->lev) {
+    dist_free_plan(L.planA);
+    dist_free_plan(L.planR);
+    dist_free_plan(L.planP);
+    L.x0.release();
+    L.x1.release();
+    L.r.release();
+    L.b.release();
+  }
+  h->bc_pad.release();
+  h->bc_all.release();
+  h->b_tail.release();
+  h->x_tail.release();
+  h->gather_index.release();
+  h->partial.release();
+  h->scalar.release();
+  if (h->h_scalar) (void)hipHostFree(h->h_scalar);
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
+  if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
+  if (h->ev_landed) (void)hipEventDestroy(h->ev_landed);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return MG_OK;
+}
+
 // Run the hierarchy's kernels on the caller's stream (e.g. torch's current stream) instead of its own.
 int mg_set_stream(mg_hierarchy* h, void* stream) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");

@@ -96,6 +96,16 @@ SIGNATURES = {
     "mg_kaczmarz_apply_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, _ll]),
     "mg_kaczmarz_apply_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
     "mg_kaczmarz_destroy": (C.c_int, [_vp]),
+    "mg_dist_unique_id": (C.c_int, [C.c_char_p]),
+    "mg_dist_create": (C.c_int, [_ll, _ll, _ll, C.c_char_p, _ll, _ll, _ll, C.POINTER(_vp)]),
+    "mg_dist_set_exchange_plugin": (C.c_int, [_vp, _vp, _vp]),
+    "mg_dist_set_level": (C.c_int, [_vp, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _ll]),
+    "mg_dist_set_plan_INT64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _ll, _lp, _lp, _lp, _ll]),
+    "mg_dist_set_tail_INT64": (C.c_int, [_vp, _vp, _ll, _ll, _ll, _lp]),
+    "mg_dist_finalize": (C.c_int, [_vp]),
+    "mg_dist_cycle_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll]),
+    "mg_dist_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _dp]),
+    "mg_dist_destroy": (C.c_int, [_vp]),
     "mg_last_error": (C.c_char_p, []),
     "mg_version": (C.c_char_p, []),
 }

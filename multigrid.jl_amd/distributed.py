@@ -626,3 +626,120 @@ class DistributedHierarchy:
             t += 8.0 * n * (1 + 2 * k) + (L.npre - 1 + L.npost) * sweep + resid
             t += 12.0 * (L.nnzR + L.nnzP) + 8.0 * k * (3 * n)
         return t
+
+
+# ======================================================================================================
+# the native sequencer (csrc: mg_dist_*): same local operators and plans, hot loop in C++ / RCCL
+# ======================================================================================================
+class NativeDistributedHierarchy:
+    """The sharded cycle behind the C ABI (``mg_dist_*``, include/mgvcycle.h): the level schedule runs in C++, the halo
+    exchange is RCCL send/recv on a side stream overlapped with the interior rows.  Built FROM a ``DistributedHierarchy``
+    (which stays the setup helper and the checker): its device operators, relaxPrecs, halo plans and replicated tail are
+    handed over by handle; the vectors and the loop belong to the library.  One right-hand side.
+
+    transport="rccl": a communicator of its own (unique id from rank 0, broadcast with ``torch.distributed``);
+    transport="plugin": every exchange goes through ``H.comm`` on host buffers (tests, ranks sharing one GPU)."""
+
+    def __init__(self, H: DistributedHierarchy, transport: str = "rccl"):
+        import ctypes as C
+        if H.nrhs != 1:
+            raise NotImplementedError("the native sequencer handles one right-hand side")
+        self.H = H
+        self.lib = lib = D.load_library()
+        comm = H.comm
+        rank, size = comm.rank, comm.size
+        self.handle = C.c_void_p()
+        uid = None
+        if transport == "rccl":
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                D._check(lib, lib.mg_dist_unique_id(buf), "mg_dist_unique_id")
+            box = [buf.raw if rank == 0 else None]
+            if size > 1:
+                import torch.distributed as dist
+                dist.broadcast_object_list(box, src=0, group=getattr(comm, "group", None))
+            uid = C.create_string_buffer(box[0], 128)
+        nl_sh = len(H.levels)
+        D._check(lib, lib.mg_dist_create(H.be.device_id, rank, size, uid, nl_sh, H.nl, ord(H.cycleType), C.byref(self.handle)),
+                 "mg_dist_create")
+        self._cb = None
+        if uid is None and size > 1:
+            self._install_plugin(comm)
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        for l, L in enumerate(H.levels, start=1):
+            hA_int = L.A_int.handle if L.A_int is not None else None
+            hA_bnd = L.A_bnd.handle if L.A_bnd is not None else None
+            D._check(lib, lib.mg_dist_set_level(self.handle, l, L.n_own, L.n_int, hA_int, hA_bnd, L.P.handle, L.R.handle,
+                                                D._ptr(L.d), L.npre, L.npost), "mg_dist_set_level")
+            for which, plan in ((D.MG_OP_A, L.planA), (D.MG_OP_R, L.planR), (D.MG_OP_P, L.planP)):
+                if plan is None:
+                    continue
+                si, ss, rs = i64(plan.send_idx), i64(plan.send_splits), i64(plan.recv_splits)
+                D._check(lib, lib.mg_dist_set_plan_INT64(self.handle, l, which, plan.n_own_src, plan.n_halo, si.size,
+                                                         D._i64(si) if si.size else None, D._i64(ss), D._i64(rs),
+                                                         1 if plan.active else 0), "mg_dist_set_plan")
+        gi = i64(H.gather_index.cpu().numpy())
+        D._check(lib, lib.mg_dist_set_tail_INT64(self.handle, H.tail.h.handle, H.n_tail, H.own_tail, H.max_tail, D._i64(gi)),
+                 "mg_dist_set_tail")
+        D._check(lib, lib.mg_dist_finalize(self.handle), "mg_dist_finalize")
+
+    def _install_plugin(self, comm):
+        import ctypes as C
+        import torch
+        size = comm.size
+        dp, lp = C.POINTER(C.c_double), C.POINTER(C.c_longlong)
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_longlong, dp, lp, dp, lp, C.c_longlong)
+        dist = comm.dist
+
+        def cb(_user, op, send, send_splits, recv, recv_splits, count):
+            try:
+                if op == 0:
+                    ss = [int(send_splits[i]) for i in range(size)]
+                    rs = [int(recv_splits[i]) for i in range(size)]
+                    s_t = torch.from_numpy(np.ctypeslib.as_array(send, shape=(max(sum(ss), 1),))[: sum(ss)].copy())
+                    r_t = torch.zeros(sum(rs), dtype=torch.float64)
+                    dist.all_to_all_single(r_t, s_t, rs, ss, group=comm.group)
+                    if sum(rs):
+                        np.ctypeslib.as_array(recv, shape=(sum(rs),))[:] = r_t.numpy()
+                elif op == 1:
+                    t = torch.from_numpy(np.ctypeslib.as_array(send, shape=(int(count),)).copy())
+                    dist.all_reduce(t, group=comm.group)
+                    np.ctypeslib.as_array(recv, shape=(int(count),))[:] = t.numpy()
+                else:
+                    t = torch.from_numpy(np.ctypeslib.as_array(send, shape=(int(count),)).copy())
+                    o = torch.zeros(int(count) * size, dtype=torch.float64)
+                    dist.all_gather_into_tensor(o, t, group=comm.group)
+                    np.ctypeslib.as_array(recv, shape=(int(count) * size,))[:] = o.numpy()
+                return 0
+            except Exception as e:          # never unwind through the C frame
+                print("exchange plug-in error:", repr(e), flush=True)
+                return 1
+
+        self._cb = FN(cb)
+        D._check(self.lib, self.lib.mg_dist_set_exchange_plugin(self.handle, C.cast(self._cb, C.c_void_p), None),
+                 "mg_dist_set_exchange_plugin")
+
+    def cycle(self, b_loc, x_loc, x_is_zero: bool):
+        D._check(self.lib, self.lib.mg_dist_cycle_dev_FP64(self.handle, D._ptr(b_loc), D._ptr(x_loc), self.H.levels[0].n_own,
+                                                           1 if x_is_zero else 0), "mg_dist_cycle_dev")
+        return x_loc
+
+    def solve(self, b_loc, x_loc, tol: float, maxIter: int):
+        import ctypes as C
+        iters = C.c_longlong(0)
+        resvec = np.zeros(int(maxIter) + 1)
+        D._check(self.lib, self.lib.mg_dist_solve_dev_FP64(self.handle, D._ptr(b_loc), D._ptr(x_loc), self.H.levels[0].n_own,
+                                                           float(tol), int(maxIter), C.byref(iters), D._f64(resvec)),
+                 "mg_dist_solve_dev")
+        return int(iters.value), resvec[: iters.value + 1]
+
+    def close(self):
+        if self.handle:
+            self.lib.mg_dist_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -50,7 +50,7 @@ def _problem(kind, nrhs, cyc):
     return mg, A, p, b, nodes
 
 
-def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo"):
+def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", native=None):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -74,12 +74,15 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo"):
             comm = dd.TorchComm()
         H = dd.DistributedHierarchy.from_global(p, comm, be, owner, nrhs, replicate_below=200)
         assert len(H.levels) >= 2, "the test must exercise at least two sharded levels"
+        S = H
+        if native:          # the same local operators and plans, the loop in C++ (mg_dist_*): "plugin" or "rccl" transport
+            S = dd.NativeDistributedHierarchy(H, transport=native)
         b_loc = H.scatter_fine(b)
         x_loc = torch.zeros_like(b_loc)
-        it, resvec = H.solve(b_loc, x_loc, 1e-10, 6)
+        it, resvec = S.solve(b_loc, x_loc, 1e-10, 6)
         # one more single cycle from the non-zero x through the public cycle() entry
         x2 = x_loc.clone()
-        H.cycle(b_loc, x2, False)
+        S.cycle(b_loc, x2, False)
         be.synchronize()
         out = [None] * world
         dist.all_gather_object(out, (H.rows_fine, x_loc.cpu().numpy(), x2.cpu().numpy()))   # (NCCL: via cuda:0)
@@ -98,12 +101,12 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo"):
         raise
 
 
-def _run(world, kind, nrhs, cyc, use_hip=False, backend="gloo"):
+def _run(world, kind, nrhs, cyc, use_hip=False, backend="gloo", native=None):
     from oracle import mg_oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nrhs, cyc, use_hip, q, backend)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nrhs, cyc, use_hip, q, backend, native)) for r in range(world)]
     for pr in procs:
         pr.start()
     res = q.get(timeout=300)
@@ -194,6 +197,23 @@ def test_hip_distributed_rowclass_with_exception_rows(built, world, monkeypatch)
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.2")
     monkeypatch.setenv("MG_ROWCLASS_KEEP_SINGLETONS", "0")
     _run(world, "gmg3d", 1, "V", use_hip=True)
+
+
+# ---- the native sequencer behind the C ABI (mg_dist_*) ----------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,cyc", [(1, "gmg3d", "V"), (2, "gmg3d", "V"), (2, "gmg3d", "W"), (4, "gmg3d", "F"),
+                                            (2, "gmg2d", "V"), (2, "sa", "V")])
+def test_native_sequencer_plugin_transport(built, world, kind, cyc):
+    """mg_dist_* with the host-staged exchange plug-in (gloo underneath), `world` fresh processes sharing the one GPU:
+    the C++ level schedule, pack kernels, interior/boundary split and replicated tail must reproduce the oracle."""
+    _run(world, kind, 1, cyc, use_hip=True, native="plugin")
+
+
+@pytest.mark.gpu
+def test_native_sequencer_rccl_world1(built):
+    """The RCCL transport with the one rank a single-GPU box allows: ncclCommInitRank from the library's own unique id,
+    ncclAllReduce / ncclAllGather on the compute stream, side stream and events created (no peer to send to)."""
+    _run(1, "gmg3d", 1, "V", use_hip=True, backend="nccl", native="rccl")
 
 
 # ---- sharded SETUP (structured_setup.py): every rank builds only its part -------------------------------
