@@ -4168,6 +4168,16 @@ int mg_dist_destroy(mg_dist* h) {
   if (h->stream) (void)spin_sync(h->stream);
   if (h->side) (void)spin_sync(h->side);
   if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+  if (h->tail && h->tail->stream == h->stream) {   // the tail was enqueuing on this handle's stream: give it one of its own
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) {
+      h->tail->stream = s;
+      h->tail->owns_stream = true;
+    } else {
+      h->tail->stream = nullptr;
+      h->tail->owns_stream = false;
+    }
+  }
   for (auto& L : h->lev) {
     dist_free_plan(L.planA);
     dist_free_plan(L.planR);
