@@ -58,3 +58,62 @@ def test_c2_cycle_is_linear_in_b(mg, c2):
     mg.recursiveCycle(p, b, x1, 1)
     mg.recursiveCycle(p, -3.0 * b, x2, 1)
     assert np.abs(x2 + 3.0 * x1).max() <= 1e-13 * np.abs(x1).max()
+
+
+# ---- C5: block multigrid, 16 right-hand sides, 256^3 cells (BASELINE.json configs[4]) -----------------------------
+@pytest.fixture(scope="module")
+def c5(mg, built):
+    A, mesh = mg.poisson_shifted([256, 256, 256])
+    p = mg.getMGparam(np.float64, np.int64, 6, 8, 1, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p, 16)
+    b = np.asfortranarray(mg.seeded_rhs(A, 16))
+    yield A, p, b
+    mg.clear_(p)
+
+
+def test_c5_block_residual_history_matches_c_oracle(mg, c5):
+    """One solveMG step on the 16-column block (SpMM kernels, Frobenius criterion, SolveFuncs.jl:30) against the
+    C/OpenMP oracle, which streams A once per column as the reference's ParSpMatVec does."""
+    A, p, b = c5
+    x = np.zeros_like(b, order="F")
+    mg.solveMG(p, b, x)
+    co = c_oracle.COracle(p, 16)
+    xo = np.zeros_like(b, order="F")
+    it, rv = co.solveMG(b, xo, 0.0, 1, c_oracle.max_threads())
+    assert it == 1 and np.abs(rv - p.resvec).max() / rv[0] < 1e-10
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    # every column is the single-vector cycle of that column: the block path couples nothing (x0 = 0, V-cycle)
+    p1 = mg.getMGparam(np.float64, np.int64, 6, 8, 1, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    p1.As, p1.Ps, p1.Rs, p1.relaxPrecs, p1.LU, p1.Meshes = p.As, p.Ps, p.Rs, p.relaxPrecs, p.LU, p.Meshes
+    p1.levels = p.levels
+    x7 = np.zeros(A.shape[0])
+    mg.recursiveCycle(p1, np.ascontiguousarray(b[:, 7]), x7, 1)
+    assert np.abs(x7 - x[:, 7]).max() <= 1e-12 * np.abs(x7).max()
+    if p1.device is not None:
+        p1.device.close()
+        p1.device = None
+    # the reported Frobenius residual is the true one
+    assert abs(np.linalg.norm(b - A @ x) - p.resvec[-1]) <= 1e-10 * p.resvec[0]
+
+
+# ---- C3: SA-AMG on anisotropic diffusion, general CSR (BASELINE.json configs[2]) at 128^3 cells ----------------------
+def test_c3_128_sa_amg_matches_c_oracle(mg, built):
+    """The streaming formats (no repeated rows in any operator of this hierarchy) at 2.1 M rows: SA_AMGsetup on the host
+    (theta 0.4, SPAI, V(1,1); edge weights 16:4:1 x log-normal sigma - DESIGN.md section 10 says why not SURVEY's
+    1 : 1e-2 : 1e-4), two solveMG steps on the device against the C/OpenMP oracle."""
+    A, mesh = mg.anisotropic_divsiggrad([128, 128, 128], weights=(1.0, 0.25, 0.0625))
+    p = mg.getMGparam(np.float64, np.int64, 14, 8, 2, 0.0, "SPAI", 1.0, 1, 1, "V", "Julia", 0.4, 0.0)
+    mg.SA_AMGsetup(A, p, True, 1)
+    assert len(p.As) >= 4 and sum(a.nnz for a in p.As) > 5 * A.nnz          # the dense middle levels of this algorithm
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    mg.solveMG(p, b, x)
+    from multigrid_jl_amd import device as D
+    assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] == 0               # general CSR: nothing stored as row classes
+    co = c_oracle.COracle(p, 1)
+    xo = np.zeros_like(b)
+    it, rv = co.solveMG(b, xo, 0.0, 2, c_oracle.max_threads())
+    assert it == 2 and np.abs(rv - p.resvec).max() / rv[0] < 1e-10
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    assert abs(np.linalg.norm(b - A @ x) - p.resvec[-1]) <= 1e-10 * p.resvec[0]
+    mg.clear_(p)
