@@ -1497,6 +1497,94 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmm(CsrDev A, VecArgs v, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-class SpMM (nrhs > 1, vectors row-major [n][nrhs]) with a per-lane class walk: G = pow2 >= nrhs lanes own one
+// row x one right-hand-side column each (a wavefront holds 64/G rows, every lane two of them), the class dictionary
+// lives in LDS as {value, column offset} records, and a gather of x is one contiguous 8*nrhs-byte segment per row.
+// No matrix stream at all (csr_stream_spmm stages 12 B per non-zero through LDS per launch): for C5 that is 1.4 of
+// 8.1 GB per fused sweep.  Rows in stored order of their class: the summation order of the CSR row.
+// The workgroups walk the rows in the L2-tiled order of the optional schedule (first row of each 2*BLK/G-row block).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm(RowClassDev C, VecArgs v, LaneDev T, int G,
+                                                              const int* __restrict__ sched) {
+  __shared__ LaneEnt ent[RL_DCAP];
+  __shared__ int ptr[RL_NCLS + 1];
+  __shared__ int delta[RL_NCLS];
+  const int tid = threadIdx.x;
+  const int nrhs = v.nrhs;
+  const int rows_wg = 2 * (BLK / G);
+  int bid = xcd_band(blockIdx.x, T.nblocks);
+  if (sched) bid = sched[bid];
+  for (int i = tid; i < T.nent; i += BLK) {
+    LaneEnt e;
+    e.val = C.cls_val[i];
+    e.off = C.cls_off[i];
+    e.pad = 0;
+    ent[i] = e;
+  }
+  for (int i = tid; i <= T.ncls; i += BLK) ptr[i] = C.cls_ptr[i];
+  for (int i = tid; i < T.ncls; i += BLK) delta[i] = C.firstcol ? 0 : C.cls_delta[i];
+  const int grp = tid / G, c = tid - grp * G;
+  const bool cact = c < nrhs;
+  int row[2], s[2], len[2];
+  const double* xb[2];
+  double pb[2], pd[2], px[2], acc[2];
+  bool live[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    row[j] = bid * rows_wg + j * (BLK / G) + grp;
+    const bool in = row[j] < C.n_rows && cact;
+    const int rr = row[j] < C.n_rows ? row[j] : C.n_rows - 1;
+    const int cls = C.cls[rr];
+    live[j] = in && cls != 0xFFFF;
+    const int first = C.firstcol ? C.firstcol[rr] : rr;
+    const size_t o = (size_t)rr * nrhs + (cact ? c : 0);
+    pb[j] = pd[j] = px[j] = 0.0;
+    acc[j] = 0.0;
+    if (MODE == AXPBY) {
+      if (v.beta != 0.0) pb[j] = v.beta * v.y[o];
+    } else {
+      pb[j] = v.b[o];
+      if (MODE == SMOOTH) {
+        pd[j] = v.d[rr];
+        px[j] = v.xs[o];
+      }
+    }
+    s[j] = live[j] ? cls : 0;
+    xb[j] = v.x + (size_t)first * nrhs + (cact ? c : 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cq = s[j];
+    s[j] = ptr[cq];
+    len[j] = live[j] ? ptr[cq + 1] - s[j] : 0;
+    xb[j] += (long long)delta[cq] * nrhs;
+  }
+  for (int k = 0; k < T.maxlen; k += 4) {
+    double g[2][4];
+    int id[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        id[j][u] = s[j] + min(k + u, len[j] > 0 ? len[j] - 1 : 0);
+        g[j][u] = (k + u < len[j]) ? xb[j][(long long)ent[id[j][u]].off * nrhs] : 0.0;
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double t = acc[j] + ent[id[j][u]].val * g[j][u];
+        acc[j] = (k + u < len[j]) ? t : acc[j];
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (live[j]) v.y[(size_t)row[j] * nrhs + c] = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], px[j]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Element-wise helpers (grid-stride, 16 B per lane where the length allows).
 // ------------------------------------------------------------------------------------------------
 // x[i][c] = d[i] * b[i][c] : first damped-Jacobi sweep from x = 0 (MGcycle.jl:134 with r = b).

@@ -57,7 +57,7 @@ static inline hipError_t spin_sync(hipStream_t s) {
 struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
-  bool no_march = false, fuse_prolong = false, no_lane = false;
+  bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -77,7 +77,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -221,6 +221,11 @@ struct Csr {
   // csr_rowclass_lane_spmv (every lane walks its own class, dictionary in LDS) replaces the waterfall kernel when the
   // dictionary fits
   bool rc_lane() const { return has_rc && !opt.no_lane && rc_ncls <= mgk::RL_NCLS && rc_entries <= mgk::RL_DCAP; }
+  // block right-hand sides: csr_rowclass_lane_spmm when every row is in a dictionary class
+  bool rc_lane_mm() const { return rc_lane() && !opt.no_lane_mm && rc_nexc == 0; }
+  DevBuf<int> sched_ln;     // L2-tiled order of the lane SpMM's row blocks (built for the current nrhs)
+  bool has_sched_ln = false;
+  int ln_rows = 0, ln_blocks = 0;
   int rc_blocks() const {
     const long long rows = rc_lane() ? mgk::RL_ROWS : (rc_pair ? 2 * mgk::BLK : mgk::RC_ROWS);
     return (int)((n_rows + rows - 1) / rows);
@@ -615,6 +620,14 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
   } else if (v.nrhs == 1) {
     if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), v);
     else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), v);
+  } else if (M.rc_lane_mm() && M.ln_blocks > 0 && M.ln_rows == 2 * (mgk::BLK / pow2_ge(v.nrhs))) {
+    mgk::LaneDev T;
+    T.ncls = (int)M.rc_ncls;
+    T.nent = (int)M.rc_entries;
+    T.maxlen = M.rc_maxlen;
+    T.nblocks = M.ln_blocks;
+    hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm<MODE>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, pow2_ge(v.nrhs),
+                       M.has_sched_ln ? M.sched_ln.p : nullptr);
   } else {
     const int G = pow2_ge(v.nrhs);
     const dim3 grid_mm(M.nblocks_mm);
@@ -1961,6 +1974,15 @@ int build_march(Csr& A, const long long grid[3]) {
 
 int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
   MG_TRY(build_schedule_for(M, grid, nrhs, M.h_blk_row, M.nblocks, M.sched, M.has_sched));
+  M.ln_rows = M.ln_blocks = 0;
+  M.has_sched_ln = false;
+  if (nrhs > 1 && M.set && M.rc_lane_mm()) {   // uniform row blocks of the lane SpMM for this nrhs
+    M.ln_rows = 2 * (mgk::BLK / pow2_ge(nrhs));
+    M.ln_blocks = (int)((M.n_rows + M.ln_rows - 1) / M.ln_rows);
+    std::vector<int> blk((size_t)M.ln_blocks + 1);
+    for (int b = 0; b <= M.ln_blocks; ++b) blk[(size_t)b] = (int)std::min<long long>((long long)b * M.ln_rows, M.n_rows);
+    MG_TRY(build_schedule_for(M, grid, nrhs, blk, M.ln_blocks, M.sched_ln, M.has_sched_ln));
+  }
   return build_schedule_for(M, grid, nrhs, M.h_blk_row_mm, M.nblocks_mm, M.sched_mm, M.has_sched_mm);
 }
 int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const std::vector<int>& h_blk, int nb,

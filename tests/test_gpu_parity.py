@@ -722,3 +722,27 @@ def test_march_with_wrong_grid_hint_and_exception_rows(mg, built, monkeypatch):
     var, nexc = p.device.operator_kernel_info(1, D.MG_OP_A)
     assert var == 3 and 6 <= nexc <= 256, (var, nexc)        # the perturbed rows (+ the singleton corner classes) in-kernel
     mg.clear_(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nrhs", [2, 3, 16])
+def test_rowclass_lane_spmm_block_rhs(mg, built, monkeypatch, nrhs):
+    """csr_rowclass_lane_spmm (block right-hand sides on row-class operators: per-lane class walk, no matrix stream)
+    against the oracle, and bit-identical to itself under the L2-tiled block order; csr_stream_spmm (MG_NO_LANE_MM=1)
+    gives the same iterates to fp64 reassociation."""
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    runs = {}
+    for name, no_mm, budget in (("lane", "0", None), ("lane-tiled", "0", "2000"), ("stream", "1", None)):
+        monkeypatch.setenv("MG_NO_LANE_MM", no_mm)
+        if budget:
+            monkeypatch.setenv("MG_SCHED_BUDGET", budget)
+        else:
+            monkeypatch.delenv("MG_SCHED_BUDGET", raising=False)
+        A, p, b = _setup(mg, [20, 18, 16], 3, "Jac", 0.8, 2, 1, "W", 5, nrhs)
+        x, hist = _compare_solve(mg, p, b)
+        runs[name] = x.copy()
+        mg.clear_(p)
+    assert np.array_equal(runs["lane"], runs["lane-tiled"])           # scheduling changes nothing
+    assert np.abs(runs["lane"] - runs["stream"]).max() <= 1e-12 * np.abs(runs["stream"]).max()
