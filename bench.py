@@ -37,6 +37,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def emit(out):
+    """Print THE json line as the last line of stdout: native libraries (RCCL prints a version banner) write to the C
+    stdio buffer, which would otherwise be flushed after Python's line at exit."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,7 +298,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     mg.clear_(p)
     if world > 1:
         dist.destroy_process_group()
@@ -501,7 +513,7 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
                                  "traffic avoided, not a bandwidth"},
             "cpu_baseline": None,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -571,7 +583,7 @@ def bench_distributed(args, mg, torch, dist, A, mesh, p, b_host, cells, nrhs, K,
                          "traffic": None},
             "cpu_baseline": None,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     dist.barrier()
     dist.destroy_process_group()
 

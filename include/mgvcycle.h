@@ -279,6 +279,14 @@ typedef struct mg_operator mg_operator;
 int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_cols,
                             const long long* colptr, const long long* rowval, const double* nzval,
                             mg_operator** out);
+/* A rank's local A of a sharded level in BOX form: square [owned box in natural x-fastest order | halo] with empty halo
+ * rows, n1*n2*n3 == regular_cols = the owned box.  Rows that read a halo column are kept apart as exception rows; all
+ * others keep the row-class form of the global grid operator and run the staged kernels of the single-GPU path. */
+int mg_op_create_box_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
+                                const long long* rowval, const double* nzval, long long n1, long long n2, long long n3,
+                                long long regular_cols, mg_operator** out);
+/* kernel variant serving the operator at nrhs == 1 (as mg_operator_rowclass_flags) and its exception rows */
+int mg_op_kernel_variant(mg_operator* op, long long* variant, long long* exception_rows);
 int mg_op_destroy(mg_operator* op);
 int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x_dev,
                          double beta, double* y_dev, const double* b_dev, const double* d_dev,
@@ -289,6 +297,18 @@ int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const 
 int mg_op_apply_rows_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x_dev,
                               double beta, double* y_dev, const double* b_dev, const double* d_dev,
                               long long nrhs, long long row_offset, void* stream);
+/* phase 0: the whole product; 1: the rows in dictionary classes only (do not read the halo of a box operator);
+ * 2: the exception rows only.  The sharded cycle runs phase 1 while the halo is in flight and phase 2 after it landed. */
+int mg_op_apply_phase_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x_dev, double beta,
+                               double* y_dev, const double* b_dev, const double* d_dev, long long nrhs,
+                               long long row_offset, long long phase, void* stream);
+/* r = b - M x with ||r||^2 fused: one partial sum per workgroup from partials_dev on (*nparts of them); optionally
+ * xnext = x + d.*r as a second output (mg_op_can_fuse_next says whether the kernel serving the operator can write it),
+ * in which case r_dev may be NULL.  phase as above; a phase-2 call gets the pointer advanced past phase 1's partials. */
+int mg_op_residual_fused_dev_FP64(mg_operator* op, const double* x_dev, const double* b_dev, const double* d_dev,
+                                  double* r_dev, double* xnext_dev, double* partials_dev, long long phase,
+                                  long long* nparts, void* stream);
+int mg_op_can_fuse_next(mg_operator* op, const double* x_dev, long long* yes);
 int mg_op_info(mg_operator* op, long long* n_rows, long long* n_cols, long long* nnz,
                double* device_bytes);
 /* x = d.*b ; xout = x + d.*r ; out[0] = sum x^2 (workspace >= 1024 doubles) - asynchronous. */
@@ -345,6 +365,8 @@ int mg_dist_set_level(mg_dist* h, long long level, long long n_own, long long n_
                       mg_operator* P, mg_operator* R, const double* d_dev, long long relaxPre, long long relaxPost);
 /* Halo plan of one operator: the source vector is [n_own_src owned | n_halo received]; send_idx (0-based, into the owned
  * part) grouped by destination rank with send_splits[world]; recv_splits[world]; active = 0 if no rank exchanges anything. */
+/* The level's A was handed over as ONE box operator (A_int, n_int = n_own, A_bnd = NULL): phase 1 overlaps the exchange. */
+int mg_dist_set_level_box(mg_dist* h, long long level, long long on);
 int mg_dist_set_plan_INT64(mg_dist* h, long long level, long long which, long long n_own_src, long long n_halo,
                            long long n_send, const long long* send_idx, const long long* send_splits,
                            const long long* recv_splits, long long active);

@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(BLK) void csr_rows_spmv(CsrDev A, const int* __rest
       if (v.beta != 0.0) pb = v.beta * v.y[row];
     } else {
       pb = v.b[row];
-      if (MODE == SMOOTH) {
+      if (MODE == SMOOTH || (MODE == RESID && v.y2)) {
         pd = v.d[row];
         px = v.xs[row];
       }
@@ -1405,7 +1405,8 @@ __global__ __launch_bounds__(BLK) void csr_rows_spmv(CsrDev A, const int* __rest
     double acc = 0.0;
     for (int k = A.rowptr[row]; k < A.rowptr[row + 1]; ++k) acc += A.val[k] * v.x[A.colidx[k]];
     outv = epilogue<MODE>(v, row, acc, pb, pd, px);
-    v.y[row] = outv;
+    if (MODE != RESID || v.y) v.y[row] = outv;
+    if (MODE == RESID && v.y2) v.y2[row] = px + pd * outv;   // x + d.*r: the next cycle's first damped-Jacobi update
   }
   if (v.sumsq) {
     double sq = outv * outv;

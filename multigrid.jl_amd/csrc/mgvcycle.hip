@@ -249,6 +249,9 @@ struct Csr {
     return t;
   }
   int rc_maxlen = 0;        // longest class of the dictionary
+  // Local operator of a sharded level: columns >= regular_cols are halo columns (appended after the owned ones); rows
+  // that reference one are forced to be exception rows, the first regular_cols rows are the owned box in natural order
+  long long regular_cols = -1;
   mgk::TileDev tiledev() const {
     mgk::TileDev t;
     t.tile_lb = rt_lb.p;
@@ -522,16 +525,36 @@ bool march_ok(const Csr& M, const mgk::VecArgs& v) {
 
 // nparts (optional): number of per-workgroup ||out||^2 partials the launch writes to v.sumsq.
 // pro (optional, SMOOTH on a marching operator only): stage x + Pm*xc instead of x (the fused coarse-grid correction).
+// phase: 0 = the whole product; 1 = every row that is in a dictionary class; 2 = the exception rows only (the sharded
+// cycle computes the rows that read the halo - forced exception rows - after the exchange has landed).  Operators that
+// are not stored as row classes compute everything in phase 2.
 template <int MODE>
 int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* nparts = nullptr,
-               const mgk::ProDev* pro = nullptr) {
+               const mgk::ProDev* pro = nullptr, int phase = 0) {
   if (nparts) *nparts = M.nblocks;
   if (M.nblocks <= 0) return MG_OK;
   const dim3 grid(M.nblocks), blk(mgk::BLK);
   if (pro && !march_ok(M, v)) return fail(MG_ERR_STATE, "fused prolongation needs the marching kernel");
+  if (phase != 0 && !(v.nrhs == 1 && M.has_rc)) {
+    if (phase == 1) return MG_OK;
+    phase = 0;
+  }
+  if (phase == 2) {   // (v.sumsq, if set, points at the first free partial: the caller advanced it past phase 1's)
+    if (nparts) *nparts = 0;
+    if (M.rc_nexc > 0) {
+      mgk::VecArgs ve = v;
+      ve.d = v.d_full;
+      const int nbx = (M.rc_nexc + mgk::BLK - 1) / mgk::BLK;
+      hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3(nbx), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, 0);
+      HIP_TRY(hipGetLastError());
+      if (nparts) *nparts = nbx;
+    }
+    return MG_OK;
+  }
   if (v.nrhs == 1 && M.has_rc) {
     int nb_main;
-    const mgk::RowClassDev C = M.rcdev();
+    mgk::RowClassDev C = M.rcdev();
+    if (phase == 1) C.nexc_inline = 0;    // the exception rows get their own launch (phase 2)
     const bool exc = C.nexc_inline > 0;   // a short list of exception rows rides in the last workgroup
     if (march_ok(M, v)) {
       const mgk::MarchDev T = M.marchdev();
@@ -605,12 +628,12 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
         else hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, false, false>), dim3(nb_main), blk, 0, stream, C, v);
       }
     }
-    if (M.rc_nexc > mgk::BLK) {   // rows of rare classes, from the CSR arrays; their ||r||^2 partials follow the others
+    if (M.rc_nexc > mgk::BLK && phase == 0) {   // rows of rare classes, from the CSR arrays; their ||r||^2 partials follow the others
       mgk::VecArgs ve = v;
       ve.d = v.d_full;
       hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3(M.exc_blocks()), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, nb_main);
     }
-    if (nparts) *nparts = nb_main + M.exc_blocks();
+    if (nparts) *nparts = nb_main + (phase == 0 ? M.exc_blocks() : 0);
   } else if (v.nrhs == 1 && M.has_pat) {
     const bool dl = M.dict_entries <= mgk::DICT_LDS && M.npat < mgk::DICT_LDS;
     if (M.nt && dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
@@ -1878,7 +1901,7 @@ int build_tile(Csr& A, const long long grid[3]) {
   A.rc_tile = false;
   if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty()) return MG_OK;
   if (A.opt.no_tile) return MG_OK;
-  if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != A.n_rows) return MG_OK;
+  if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != (A.regular_cols >= 0 ? A.regular_cols : A.n_rows)) return MG_OK;
   const long long P = grid[0] * grid[1];
   if (P < mgk::RT_CR / 2 || A.n_rows + (mgk::RT_NP + 2) * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
   auto split = [&](long long sh, long long& dz, long long& rest) {
@@ -1927,7 +1950,8 @@ int build_tile(Csr& A, const long long grid[3]) {
 int build_march(Csr& A, const long long grid[3]) {
   A.rc_march = false;
   if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march) return MG_OK;
-  if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != A.n_rows) return MG_OK;
+  // (a padded local operator of a sharded level: the grid is the owned box = its first regular_cols rows)
+  if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != (A.regular_cols >= 0 ? A.regular_cols : A.n_rows)) return MG_OK;
   const long long P = grid[0] * grid[1];
   if (P < 64 || A.n_rows + 4 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
   auto split = [&](long long sh, long long& dz, long long& rest) {
@@ -2186,6 +2210,10 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     const int s = rp[(size_t)i], e = rp[(size_t)i + 1];
     const int f = (e > s) ? ci[(size_t)s] : 0;
     first[(size_t)i] = f;
+    if (M->regular_cols >= 0 && (i >= M->regular_cols || (e > s && ci[(size_t)e - 1] >= M->regular_cols))) {
+      rid[(size_t)i] = -1;   // halo row, or a row that reads the halo (columns are sorted): forced exception row
+      continue;
+    }
     unsigned long long hsh = 1469598103934665603ull ^ (unsigned long long)(e - s);
     const int dlt = (int)(f - i);
     if (implicit) {
@@ -2234,7 +2262,8 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   // CSR arrays.  Accepted when the kept classes cover enough rows (MG_ROWCLASS_MIN_COVER, default 0.9).
   const size_t nraw = rptr.size() - 1;
   std::vector<long long> freq(nraw, 0);
-  for (long long i = 0; i < n; ++i) freq[(size_t)rid[(size_t)i]]++;
+  for (long long i = 0; i < n; ++i)
+    if (rid[(size_t)i] >= 0) freq[(size_t)rid[(size_t)i]]++;
   std::vector<int> order(nraw);
   for (size_t c = 0; c < nraw; ++c) order[c] = (int)c;
   std::sort(order.begin(), order.end(), [&](int x, int y) { return freq[(size_t)x] != freq[(size_t)y] ? freq[(size_t)x] > freq[(size_t)y] : x < y; });
@@ -2259,14 +2288,16 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   }
   {
     const double min_cover = M->opt.rowclass_min_cover;
-    if (cptr.size() < 2 || (double)covered < min_cover * (double)n) return MG_OK;
+    const double nreg = (double)(M->regular_cols >= 0 ? M->regular_cols : n);
+    if (cptr.size() < 2 || (double)covered < min_cover * nreg) return MG_OK;
   }
   std::vector<unsigned short> cid((size_t)n, 0);
   std::vector<int> exc;
   for (long long i = 0; i < n; ++i) {
-    const int c = remap[(size_t)rid[(size_t)i]];
+    const int c = rid[(size_t)i] >= 0 ? remap[(size_t)rid[(size_t)i]] : 0xFFFF;
     cid[(size_t)i] = (unsigned short)c;
-    if (c == 0xFFFF) exc.push_back((int)i);
+    // (the empty halo rows of a padded local operator are never computed: not even exception rows)
+    if (c == 0xFFFF && !(M->regular_cols >= 0 && i >= M->regular_cols)) exc.push_back((int)i);
   }
   { std::vector<int>().swap(rid); std::vector<int>().swap(roff); std::vector<double>().swap(rval); }
   if (coff.empty()) { coff.push_back(0); cval.push_back(0.0); }
@@ -2447,7 +2478,7 @@ int refresh_rowclasses(Csr* M, const double* val) {
 // CSR (the reference's C side does the -1 per access, parRelax.h:24-27), cut the rows into row blocks
 // and upload.
 int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, const long long* colptr,
-               const long long* rowval, const double* nzval) {
+               const long long* rowval, const double* nzval, long long regular_cols = -1) {
   if (n_rows < 1 || n_cols < 1 || !colptr || !rowval || !nzval)
     return fail(MG_ERR_INVALID, "empty operator or null array");
   if (n_rows >= (1LL << 31) - 1 || n_cols >= (1LL << 31) - 1)
@@ -2471,14 +2502,16 @@ int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, c
     ci[(size_t)k] = (int)c;
   }
   // row blocks: consecutive rows, <= maxrows rows and an (even-aligned) nnz span <= chunk
+  // (a box-form local operator computes its owned rows only: the empty halo rows behind them get no row block)
+  const long long n_rows_blk = regular_cols >= 0 ? std::min(regular_cols, n_rows) : n_rows;
   auto make_blocks = [&](int maxrows, int chunk) {
     std::vector<int> bl;
     bl.push_back(0);
     long long r = 0;
-    while (r < n_rows) {
+    while (r < n_rows_blk) {
       const long long base = rp[(size_t)r] & ~1LL;
       long long e = r + 1;  // a block always holds at least one row (a longer row takes the long-row path)
-      while (e < n_rows && (e - r) < maxrows && (rp[(size_t)e + 1] - base) <= chunk) ++e;
+      while (e < n_rows_blk && (e - r) < maxrows && (rp[(size_t)e + 1] - base) <= chunk) ++e;
       bl.push_back((int)e);
       r = e;
     }
@@ -2488,6 +2521,7 @@ int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, c
   std::vector<int> blk_mm = make_blocks(mgk::MM_MAXROWS, mgk::MM_CHUNK);
   M->release();
   M->opt = opt;
+  M->regular_cols = regular_cols;
   M->n_rows = n_rows;
   M->n_cols = n_cols;
   M->nnz = nnz;
@@ -3499,6 +3533,46 @@ int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_c
   return MG_OK;
 }
 
+// A rank's local operator of a sharded level in BOX form: square, rows/columns [owned box in natural x-fastest order |
+// halo], the halo rows empty; n1 x n2 x n3 = the owned box (= regular_cols rows).  Rows that read a halo column become
+// exception rows (phase 2 of mg_op_apply_phase_dev_FP64), all others keep the row-class form of the global grid operator
+// and run the staged kernels (z-marching / plane tiles) of the single-GPU path.
+int mg_op_create_box_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
+                                const long long* rowval, const double* nzval, long long n1, long long n2, long long n3,
+                                long long regular_cols, mg_operator** out) {
+  UploadFence upload_fence;
+  if (!out) return fail(MG_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (n_rows != n_cols || regular_cols < 1 || regular_cols > n_rows || n1 * n2 * n3 != regular_cols)
+    return fail(MG_ERR_INVALID, "box operator must be square with n1*n2*n3 == regular_cols <= n_rows");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
+  HIP_TRY(hipSetDevice((int)device_id));
+  mg_operator* op = new mg_operator();
+  op->device = (int)device_id;
+  int rc = upload_csr(&op->M, Options::from_env(), n_rows, n_cols, colptr, rowval, nzval, regular_cols);
+  const long long grid[3] = {n1, n2, n3};
+  if (rc == MG_OK) rc = build_tile(op->M, grid);
+  if (rc == MG_OK) rc = build_march(op->M, grid);
+  if (rc != MG_OK) {
+    op->M.release();
+    delete op;
+    return rc;
+  }
+  *out = op;
+  return MG_OK;
+}
+
+int mg_op_kernel_variant(mg_operator* op, long long* variant, long long* exception_rows) {
+  if (!op) return fail(MG_ERR_INVALID, "null operator");
+  const Csr& M = op->M;
+  if (variant) *variant = !M.has_rc ? -1 : M.rc_march ? 3 : M.rc_tile ? 2 : M.rc_window ? 1 : M.rc_lane() ? 4 : 0;
+  if (exception_rows) *exception_rows = M.has_rc ? M.rc_nexc : 0;
+  return MG_OK;
+}
+
 int mg_op_destroy(mg_operator* op) {
   if (!op) return MG_OK;
   (void)hipSetDevice(op->device);
@@ -3515,7 +3589,14 @@ int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const 
 int mg_op_apply_rows_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
                               double* y, const double* b, const double* d, long long nrhs,
                               long long row_offset, void* stream) {
+  return mg_op_apply_phase_dev_FP64(op, kernel, alpha, x, beta, y, b, d, nrhs, row_offset, 0, stream);
+}
+
+int mg_op_apply_phase_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
+                               double* y, const double* b, const double* d, long long nrhs,
+                               long long row_offset, long long phase, void* stream) {
   if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
+  if (phase < 0 || phase > 2) return fail(MG_ERR_INVALID, "phase must be 0, 1 or 2");
   if (!x || !y || nrhs < 1 || row_offset < 0) return fail(MG_ERR_INVALID, "null vector, nrhs < 1 or negative row offset");
   if (kernel == MG_K_SMOOTH && y == x) return fail(MG_ERR_INVALID, "the Jacobi update must not alias x");
   mgk::VecArgs v{};
@@ -3533,16 +3614,56 @@ int mg_op_apply_rows_dev_FP64(mg_operator* op, long long kernel, double alpha, c
     case MG_K_SPMV:
     case MG_K_RESTRICT:
     case MG_K_PROLONG:
-      return launch_csr<mgk::AXPBY>(s, op->M, v);
+      return launch_csr<mgk::AXPBY>(s, op->M, v, nullptr, nullptr, (int)phase);
     case MG_K_RESIDUAL:
       if (!b) return fail(MG_ERR_INVALID, "residual needs b");
-      return launch_csr<mgk::RESID>(s, op->M, v);
+      return launch_csr<mgk::RESID>(s, op->M, v, nullptr, nullptr, (int)phase);
     case MG_K_SMOOTH:
       if (!b || !d) return fail(MG_ERR_INVALID, "smoother needs b and d");
-      return launch_csr<mgk::SMOOTH>(s, op->M, v);
+      return launch_csr<mgk::SMOOTH>(s, op->M, v, nullptr, nullptr, (int)phase);
     default:
       return fail(MG_ERR_INVALID, "kernel %lld is not an operator kernel", kernel);
   }
+}
+
+// r = b - M x on an operator with the squared norm of r fused (per-workgroup partials written from partials_dev on,
+// *nparts of them) and, optionally, xnext = x + d.*r as a second output (the next cycle's first damped-Jacobi update);
+// r_dev may be NULL when only the norm and xnext are wanted.  phase as mg_op_apply_phase_dev_FP64.  One right-hand side.
+int mg_op_residual_fused_dev_FP64(mg_operator* op, const double* x, const double* b, const double* d, double* r_dev,
+                                  double* xnext_dev, double* partials_dev, long long phase, long long* nparts, void* stream) {
+  if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
+  if (!x || !b || !partials_dev || !nparts || phase < 0 || phase > 2 || (xnext_dev && !d)) return fail(MG_ERR_INVALID, "bad argument");
+  const Csr& M = op->M;
+  mgk::VecArgs v{};
+  v.x = x;
+  v.xs = x;
+  v.y = r_dev;
+  v.b = b;
+  v.nrhs = 1;
+  v.sumsq = partials_dev;
+  // the staged row-class kernels (march, tile) and the exception-row kernel can write the second output
+  const bool can_y2 = M.has_rc && (M.rc_tile || march_ok(M, v)) && xnext_dev && xnext_dev != x && !(phase == 0 && M.rc_nexc > 0);
+  if (can_y2) {
+    v.y2 = xnext_dev;
+    v.d = d;
+    v.d_full = d;
+  } else if (!r_dev) {
+    return fail(MG_ERR_INVALID, "this operator's kernel cannot produce xnext: pass r_dev");
+  }
+  int np = 0;
+  MG_TRY(launch_csr<mgk::RESID>(reinterpret_cast<hipStream_t>(stream), M, v, &np, nullptr, (int)phase));
+  *nparts = np;
+  return MG_OK;
+}
+// 1 if mg_op_residual_fused_dev_FP64 can write xnext for this operator and these vectors (x 16-byte aligned etc.)
+int mg_op_can_fuse_next(mg_operator* op, const double* x, long long* yes) {
+  if (!op || !yes) return fail(MG_ERR_INVALID, "null argument");
+  mgk::VecArgs v{};
+  v.x = x;
+  v.xs = x;
+  v.nrhs = 1;
+  *yes = (op->M.has_rc && (op->M.rc_tile || march_ok(op->M, v))) ? 1 : 0;
+  return MG_OK;
 }
 
 int mg_op_info(mg_operator* op, long long* n_rows, long long* n_cols, long long* nnz, double* device_bytes) {
@@ -3764,6 +3885,7 @@ struct DistLevel {
   mg_operator *A_int = nullptr, *A_bnd = nullptr, *P = nullptr, *R = nullptr;   // borrowed handles
   const double* d = nullptr;                                                    // borrowed device vector (n_own)
   long long npre = 1, npost = 1;
+  bool box = false;   // A_int is a box operator (mg_op_create_box_FP64_INT64): phase 1 overlaps the exchange, phase 2 follows it
   DistPlan planA, planR, planP;
   long long cap_x = 0, cap_r = 0;
   DevBuf<double> x0, x1, r, b;
@@ -3797,7 +3919,7 @@ struct mg_dist {
   DevBuf<double> bc_pad, bc_all, b_tail, x_tail;
   DevBuf<long long> gather_index;
   // reductions
-  DevBuf<double> partial, scalar;
+  DevBuf<double> partial, partial2, scalar;
   double* h_scalar = nullptr;
   double* h_stage = nullptr;            // pinned staging for the plug-in collectives
   size_t h_stage_n = 0;
@@ -3865,14 +3987,26 @@ int dist_apply(mg_dist* h, mg_operator* op, long long kernel, double alpha, cons
 // out = b - A x / out = x + d.*(b - A x) on this rank's rows, the halo exchange overlapped with the interior rows
 int dist_apply_A(mg_dist* h, DistLevel& L, long long kernel, double* x, double* out, const double* b) {
   MG_TRY(dist_exchange_start(h, L.planA, x));
+  if (L.box) {   // rows of the owned box that do not read the halo (staged kernels), then - halo landed - the rest
+    MG_TRY(mg_op_apply_phase_dev_FP64(L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, 1, 0, 1, h->stream));
+    MG_TRY(dist_exchange_finish(h, L.planA));
+    MG_TRY(mg_op_apply_phase_dev_FP64(L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, 1, 0, 2, h->stream));
+    return MG_OK;
+  }
   MG_TRY(dist_apply(h, L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, 0));
   MG_TRY(dist_exchange_finish(h, L.planA));
   MG_TRY(dist_apply(h, L.A_bnd, kernel, 1.0, x, 0.0, out, b, L.d, L.n_int));
   return MG_OK;
 }
 // global Frobenius norm of a sharded vector: local sum of squares + one scalar all-reduce (SolveFuncs.jl:15,20,30)
+int dist_reduce_scalar(mg_dist* h, double* out);
 int dist_norm(mg_dist* h, const double* v, long long n, double* out) {
   MG_TRY(mg_vec_sumsq_dev_FP64(v, n, h->partial.p, h->scalar.p, h->stream));
+  return dist_reduce_scalar(h, out);
+}
+
+// all-reduce h->scalar (a local sum of squares) and return its square root on the host
+int dist_reduce_scalar(mg_dist* h, double* out) {
   if (h->comm) {
     NCCL_TRY(g_rccl.AllReduce(h->scalar.p, h->scalar.p, 1, NCCL_DOUBLE, NCCL_SUM, h->comm, h->stream));
     HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -3890,9 +4024,36 @@ int dist_norm(mg_dist* h, const double* v, long long n, double* out) {
   return MG_OK;
 }
 
+// SolveFuncs.jl:26-30 on the sharded fine level: r = b - A x and ||r|| in ONE pass over the level (per-workgroup partial
+// sums, one scalar all-reduce).  Box-form levels also get alt = x + d.*r, the next cycle's first damped-Jacobi update,
+// from the same pass (*x1_ready), and then do not store r at all - as solve_dev does on one GPU.
+int dist_residual_norm(mg_dist* h, DistLevel& L, double* x, const double* b, double* alt, double* norm, bool* x1_ready) {
+  *x1_ready = false;
+  long long can = 0;
+  if (L.box && alt) MG_TRY(mg_op_can_fuse_next(L.A_int, x, &can));
+  if (!L.box) {
+    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, x, L.r.p, b));
+    return dist_norm(h, L.r.p, L.n_own, norm);
+  }
+  long long n1 = 0, n2 = 0;
+  MG_TRY(dist_exchange_start(h, L.planA, x));
+  MG_TRY(mg_op_residual_fused_dev_FP64(L.A_int, x, b, L.d, can ? nullptr : L.r.p, can ? alt : nullptr, h->partial.p, 1, &n1, h->stream));
+  MG_TRY(dist_exchange_finish(h, L.planA));
+  MG_TRY(mg_op_residual_fused_dev_FP64(L.A_int, x, b, L.d, can ? nullptr : L.r.p, can ? alt : nullptr, h->partial.p + n1, 2, &n2, h->stream));
+  const long long nb1 = n1 + n2;
+  if ((size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small (%lld > %zu)", nb1, h->partial.n);
+  const int nb2 = (int)std::min<long long>(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
+  hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->partial2.p);
+  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
+  HIP_TRY(hipGetLastError());
+  MG_TRY(dist_reduce_scalar(h, norm));
+  *x1_ready = can != 0;
+  return MG_OK;
+}
+
 // the sharded cycle: mirror of cycle_level (MGcycle.jl:1-118); returns the buffer holding x
 int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
-               bool r_valid = false) {
+               bool r_valid = false, bool x1_ready = false) {
   DistLevel& L = h->lev[(size_t)l];
   double *cur = xa, *alt = xb;
   long long npre = L.npre;
@@ -3901,7 +4062,7 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     MG_TRY(mg_vec_dscale_dev_FP64(L.d, b, cur, L.n_own, 1, h->stream));
     --npre;
   } else if (r_valid) {
-    MG_TRY(mg_vec_xpdr_dev_FP64(cur, L.d, L.r.p, alt, L.n_own, 1, h->stream));
+    if (!x1_ready) MG_TRY(mg_vec_xpdr_dev_FP64(cur, L.d, L.r.p, alt, L.n_own, 1, h->stream));   // (else: written by the residual pass)
     std::swap(cur, alt);
     --npre;
   }
@@ -4023,7 +4184,7 @@ int mg_dist_create(long long device_id, long long rank, long long world, const c
   auto bail = [&](int rc) { mg_dist_destroy(h); return rc; };
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_landed, hipEventDisableTiming) != hipSuccess ||
-      h->partial.alloc(1024) != MG_OK || h->scalar.alloc(1) != MG_OK || hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), sizeof(double)) != hipSuccess)
+      h->partial.alloc(1024) != MG_OK || h->partial2.alloc(256) != MG_OK || h->scalar.alloc(1) != MG_OK || hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), sizeof(double)) != hipSuccess)
     return bail(fail(MG_ERR_HIP, "stream / event / scratch creation failed"));
   if (unique_id128) {
     if (!g_rccl.load()) return bail(fail(MG_ERR_HIP, "librccl.so could not be loaded"));
@@ -4060,7 +4221,16 @@ int mg_dist_set_level(mg_dist* h, long long level, long long n_own, long long n_
   L.d = d_dev;
   L.npre = std::max<long long>(1, relaxPre);      // relax() always updates once (MGcycle.jl:127-134)
   L.npost = std::max<long long>(1, relaxPost);
+  L.box = false;
   h->finalized = false;
+  return MG_OK;
+}
+
+// Level `level` holds its A as ONE box operator (mg_op_create_box_FP64_INT64, passed as A_int with n_int = n_own).
+int mg_dist_set_level_box(mg_dist* h, long long level, long long on) {
+  if (!h) return fail(MG_ERR_INVALID, "null handle");
+  if (level < 1 || level > (long long)h->lev.size()) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  h->lev[(size_t)level - 1].box = on != 0;
   return MG_OK;
 }
 
@@ -4128,6 +4298,8 @@ int mg_dist_finalize(mg_dist* h) {
       HIP_TRY(hipMemset(L.b.p, 0, L.b.bytes()));
     }
   }
+  // one ||r||^2 partial per workgroup of the fused residual pass: at most one per 256 rows, + the exception rows' blocks
+  MG_TRY(h->partial.alloc((size_t)(2 * (h->lev[0].n_own / 256 + 2) + 1024)));
   h->finalized = true;
   return MG_OK;
 }
@@ -4159,21 +4331,20 @@ int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long 
   double xn = 0.0, res0 = 0.0, res = 0.0;
   MG_TRY(dist_norm(h, cur, n_own, &xn));
   bool x_zero = (xn == 0.0);
+  bool x1_ready = false;
   if (x_zero) {
     MG_TRY(dist_norm(h, b_loc, n_own, &res0));
   } else {
-    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b_loc));
-    MG_TRY(dist_norm(h, L.r.p, n_own, &res0));
+    MG_TRY(dist_residual_norm(h, L, cur, b_loc, nullptr, &res0, &x1_ready));
   }
   if (resvec) resvec[0] = res0;
   long long it = 0;
   for (long long count = 1; count <= maxIter; ++count) {
     double* out = nullptr;
-    MG_TRY(dist_cycle(h, 0, b_loc, cur, alt, x_zero, h->cycle, &out, count > 1 || !x_zero));
+    MG_TRY(dist_cycle(h, 0, b_loc, cur, alt, x_zero, h->cycle, &out, count > 1 || !x_zero, x1_ready));
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
-    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b_loc));
-    MG_TRY(dist_norm(h, L.r.p, n_own, &res));
+    MG_TRY(dist_residual_norm(h, L, cur, b_loc, count < maxIter ? alt : nullptr, &res, &x1_ready));
     ++it;
     if (resvec) resvec[it] = res;
     if (res / res0 < tol) break;
@@ -4215,6 +4386,7 @@ int mg_dist_destroy(mg_dist* h) {
   h->x_tail.release();
   h->gather_index.release();
   h->partial.release();
+  h->partial2.release();
   h->scalar.release();
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
   if (h->h_stage) (void)hipHostFree(h->h_stage);

@@ -83,6 +83,12 @@ SIGNATURES = {
     "mg_cycle_bytes": (C.c_int, [_vp, _dp]),
     "mg_device_bytes": (C.c_int, [_vp, _dp]),
     "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
+    "mg_op_create_box_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, _ll, _ll, _ll, _ll, C.POINTER(_vp)]),
+    "mg_op_kernel_variant": (C.c_int, [_vp, _lp, _lp]),
+    "mg_op_apply_phase_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _ll, _ll, _vp]),
+    "mg_dist_set_level_box": (C.c_int, [_vp, _ll, _ll]),
+    "mg_op_residual_fused_dev_FP64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _lp, _vp]),
+    "mg_op_can_fuse_next": (C.c_int, [_vp, _vp, _lp]),
     "mg_op_destroy": (C.c_int, [_vp]),
     "mg_op_apply_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _vp]),
     "mg_op_apply_rows_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _ll, _vp]),
@@ -563,7 +569,9 @@ class DeviceOperator:
     """One CSR operator resident in HBM on its own (``mg_operator``): the building block of the multi-GPU
     cycle, where a rank holds its rows of A/P/R with halo columns appended.  Asynchronous on `stream`."""
 
-    def __init__(self, M, device_id: int = 0):
+    def __init__(self, M, device_id: int = 0, box=None, regular_cols=None):
+        """box=(n1,n2,n3), regular_cols: the BOX form of a sharded level's local A (mg_op_create_box_FP64_INT64): M is
+        square [owned box in natural order | halo] with empty halo rows."""
         self.lib = load_library()
         self.handle = _vp()
         colptr, rowval, nzval = _julia_arrays(M)
@@ -572,16 +580,29 @@ class DeviceOperator:
             nzval = np.zeros(1)
         self.shape = M.shape
         self.nnz = int(M.nnz)
-        _check(self.lib, self.lib.mg_op_create_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),
-                                                          _i64(rowval), _f64(nzval), C.byref(self.handle)),
-               "mg_op_create")
+        self.box = box is not None
+        if box is not None:
+            n1, n2, n3 = (list(box) + [1, 1])[:3]
+            _check(self.lib, self.lib.mg_op_create_box_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),
+                                                                  _i64(rowval), _f64(nzval), int(n1), int(n2), int(n3),
+                                                                  int(regular_cols), C.byref(self.handle)), "mg_op_create_box")
+        else:
+            _check(self.lib, self.lib.mg_op_create_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),
+                                                              _i64(rowval), _f64(nzval), C.byref(self.handle)),
+                   "mg_op_create")
 
-    def apply(self, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, stream=0, row_offset=0):
-        _check(self.lib, self.lib.mg_op_apply_rows_dev_FP64(self.handle, int(kernel), float(alpha), _ptr(x), float(beta),
-                                                            _ptr(y), _ptr(b) if b is not None else None,
-                                                            _ptr(d) if d is not None else None, int(nrhs),
-                                                            int(row_offset), _vp(stream)),
-               "mg_op_apply_rows_dev")
+    def kernel_variant(self):
+        """(kernel variant as DeviceHierarchy.operator_kernel_variant, number of exception rows)."""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        _check(self.lib, self.lib.mg_op_kernel_variant(self.handle, C.byref(a), C.byref(b)), "mg_op_kernel_variant")
+        return int(a.value), int(b.value)
+
+    def apply(self, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, stream=0, row_offset=0, phase=0):
+        _check(self.lib, self.lib.mg_op_apply_phase_dev_FP64(self.handle, int(kernel), float(alpha), _ptr(x), float(beta),
+                                                             _ptr(y), _ptr(b) if b is not None else None,
+                                                             _ptr(d) if d is not None else None, int(nrhs),
+                                                             int(row_offset), int(phase), _vp(stream)),
+               "mg_op_apply_phase_dev")
 
     def close(self):
         if self.handle:

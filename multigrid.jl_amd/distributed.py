@@ -21,6 +21,7 @@ xGMI; "gloo" for the CPU tests).  All arithmetic runs in the HIP kernels of libm
 """
 from __future__ import annotations
 
+import os as _os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -269,11 +270,13 @@ class HipBackend:
     def index_tensor(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(self.dev)
 
-    def operator(self, M):
-        return D.DeviceOperator(M, self.device_id)
+    supports_box = True          # box-form local operators (mg_op_create_box_FP64_INT64) with phase-split launches
 
-    def apply(self, op, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, row_offset=0):
-        op.apply(kernel, x, y, b, d, alpha, beta, nrhs, self.stream(), row_offset)
+    def operator(self, M, box=None, regular_cols=None):
+        return D.DeviceOperator(M, self.device_id, box=box, regular_cols=regular_cols)
+
+    def apply(self, op, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, row_offset=0, phase=0):
+        op.apply(kernel, x, y, b, d, alpha, beta, nrhs, self.stream(), row_offset, phase)
 
     def dscale(self, d, b, x, n, nrhs):
         D.vec_dscale(d, b, x, n, nrhs, self.stream())
@@ -330,11 +333,13 @@ def _sub_hierarchy(param: MGparam, start: int) -> MGparam:
     return sub
 
 
-def _reorder_for_overlap(local_levels, rows_fine):
+def _reorder_for_overlap(local_levels, rows_fine, keep_order: bool = False):
     """Renumber every sharded level's owned rows as [interior | boundary], interior = rows of A whose columns
     are all owned.  The interior part of an SpMV with A can then run while the halo is in flight, the boundary
     part after it arrived.  A pure local permutation: applied consistently to the rows/owned columns of every
-    local operator, to d, to the send lists and to the global ids of the owned fine rows."""
+    local operator, to d, to the send lists and to the global ids of the owned fine rows.
+    keep_order (box form): the rows stay in the natural order of the owned box and A is ONE operator whose
+    rows that read the halo are exception rows of the device format (n_int = n_own)."""
     perms, invs, nints = [], [], []
     for ld in local_levels:
         A = ld["A"]
@@ -342,6 +347,8 @@ def _reorder_for_overlap(local_levels, rows_fine):
         touches_halo = np.zeros(n, dtype=bool)
         rows_of = np.repeat(np.arange(n), np.diff(A.indptr))
         touches_halo[rows_of[A.indices >= n]] = True
+        if keep_order:
+            touches_halo[:] = False
         perm = np.concatenate([np.nonzero(~touches_halo)[0], np.nonzero(touches_halo)[0]])
         inv = np.empty(n, dtype=np.int64)
         inv[perm] = np.arange(n)
@@ -377,6 +384,18 @@ def _reorder_for_overlap(local_levels, rows_fine):
     return np.asarray(rows_fine)[perms[0]], perms[0]
 
 
+def _box_of_rows(rows, nodes):
+    """(b1,b2,b3) if the ascending global ids `rows` are exactly a box of the x-fastest grid `nodes`, else None."""
+    nodes = [int(v) for v in nodes] + [1] * (3 - len(nodes))
+    rows = np.asarray(rows, dtype=np.int64)
+    i, j, k = rows % nodes[0], (rows // nodes[0]) % nodes[1], rows // (nodes[0] * nodes[1])
+    ext = [int(v.max() - v.min() + 1) for v in (i, j, k)]
+    if ext[0] * ext[1] * ext[2] != rows.size:
+        return None
+    want = ((k - k.min()) * ext[1] + (j - j.min())) * ext[0] + (i - i.min())
+    return tuple(ext) if np.array_equal(want, np.arange(rows.size)) else None
+
+
 class DistributedHierarchy:
     """The multi-GPU counterpart of ``DeviceHierarchy``: this rank's rows of the sharded levels plus the
     replicated coarse tail.  Two builders:
@@ -398,16 +417,31 @@ class DistributedHierarchy:
         self.first_tail = len(local_levels)
         self.nl = int(nl_total)
         self.levels: List[_Level] = []
-        rows_fine, self.fine_perm = _reorder_for_overlap(local_levels, rows_fine)
+        # BOX form: every sharded level's owned rows are a box of a regular grid (ld["box"]) and the backend can hold A as
+        # one square grid operator with the halo appended - the staged single-GPU kernels then serve the sharded levels
+        self.box_form = (k == 1 and getattr(be, "supports_box", False) and all(ld.get("box") is not None for ld in local_levels)
+                         and not _os.environ.get("MG_DIST_NO_BOX"))
+        rows_fine, self.fine_perm = _reorder_for_overlap(local_levels, rows_fine, keep_order=self.box_form)
         for ld in local_levels:
             L = _Level()
             L.n_own = int(ld["n_own"])
             L.n_int = int(ld["n_int"])
             L.planA, L.planR, L.planP = ld["planA"], ld["planR"], ld["planP"]
-            # A is held as two operators: interior rows (no halo columns) and boundary rows
             A = ld["A"]
-            L.A_int = be.operator(A[: L.n_int, :]) if L.n_int > 0 else None
-            L.A_bnd = be.operator(A[L.n_int:, :]) if L.n_int < L.n_own else None
+            L.box = None
+            if self.box_form:
+                # square [owned box | halo] with empty halo rows; rows reading the halo become exception rows on the device
+                n_tot = A.shape[1]
+                Asq = sp.csr_matrix((A.data, A.indices, np.concatenate([A.indptr, np.full(n_tot - A.shape[0], A.indptr[-1],
+                                                                                           dtype=A.indptr.dtype)])),
+                                    shape=(n_tot, n_tot))
+                L.box = tuple(int(v) for v in ld["box"])
+                L.A_int = be.operator(Asq, box=L.box, regular_cols=L.n_own)
+                L.A_bnd = None
+            else:
+                # A is held as two operators: interior rows (no halo columns) and boundary rows
+                L.A_int = be.operator(A[: L.n_int, :]) if L.n_int > 0 else None
+                L.A_bnd = be.operator(A[L.n_int:, :]) if L.n_int < L.n_own else None
             L.R, L.P = be.operator(ld["R"]), be.operator(ld["P"])
             L.nnzA, L.nnzR, L.nnzP = ld["A"].nnz, ld["R"].nnz, ld["P"].nnz
             L.d = be.from_numpy(np.asarray(ld["d"], dtype=np.float64))
@@ -460,7 +494,9 @@ class DistributedHierarchy:
 
     @classmethod
     def from_global(cls, param: MGparam, comm, backend, fine_owner: np.ndarray, nrhs: int = 1,
-                    replicate_below: int = 300_000):
+                    replicate_below: int = 300_000, level_nodes=None):
+        """level_nodes (optional): nodes per dimension of every level's regular grid ([n1,n2(,n3)] per level, x fastest).
+        When a rank's rows of a sharded level are a box of that grid, the level is held in BOX form."""
         cls.check_supported(param)
         rank, size = comm.rank, comm.size
         nl = len(param.As)
@@ -487,7 +523,8 @@ class DistributedHierarchy:
             P_loc, planP = localize(param.Ps[l], part, cpart if l + 1 < a else None, rank)
             local_levels.append(dict(n_own=int(part.counts[rank]), A=A_loc, planA=planA, R=R_loc, planR=planR,
                                      P=P_loc, planP=planP, d=np.asarray(param.relaxPrecs[l])[part.rows[rank]],
-                                     npre=param.relaxPre(l + 1), npost=param.relaxPost(l + 1)))
+                                     npre=param.relaxPre(l + 1), npost=param.relaxPost(l + 1),
+                                     box=_box_of_rows(part.rows[rank], level_nodes[l]) if level_nodes is not None else None))
         H = cls(comm, backend, local_levels, _sub_hierarchy(param, a), part_tail.owner, part_tail.local_index,
                 part_tail.counts, parts[0].rows[rank], param.cycleType, nl, nrhs)
         H.parts, H.part_tail = parts, part_tail
@@ -524,6 +561,11 @@ class DistributedHierarchy:
         stream, the boundary rows once it has landed."""
         be, k = self.be, self.nrhs
         h = self.exchange_start(L.planA, x)
+        if L.box is not None:       # box form: rows in dictionary classes now, rows that read the halo after it landed
+            be.apply(L.A_int, kernel, x, out, b=b, d=L.d, nrhs=k, row_offset=0, phase=1)
+            self.comm.finish(h)
+            be.apply(L.A_int, kernel, x, out, b=b, d=L.d, nrhs=k, row_offset=0, phase=2)
+            return
         if L.A_int is not None:
             be.apply(L.A_int, kernel, x, out, b=b, d=L.d, nrhs=k, row_offset=0)
         self.comm.finish(h)
@@ -671,6 +713,8 @@ class NativeDistributedHierarchy:
             hA_bnd = L.A_bnd.handle if L.A_bnd is not None else None
             D._check(lib, lib.mg_dist_set_level(self.handle, l, L.n_own, L.n_int, hA_int, hA_bnd, L.P.handle, L.R.handle,
                                                 D._ptr(L.d), L.npre, L.npost), "mg_dist_set_level")
+            if L.box is not None:
+                D._check(lib, lib.mg_dist_set_level_box(self.handle, l, 1), "mg_dist_set_level_box")
             for which, plan in ((D.MG_OP_A, L.planA), (D.MG_OP_R, L.planR), (D.MG_OP_P, L.planP)):
                 if plan is None:
                     continue
@@ -720,6 +764,7 @@ class NativeDistributedHierarchy:
                  "mg_dist_set_exchange_plugin")
 
     def cycle(self, b_loc, x_loc, x_is_zero: bool):
+        self.H.be.synchronize()       # the library enqueues on its own streams: whatever torch still has in flight for
         D._check(self.lib, self.lib.mg_dist_cycle_dev_FP64(self.handle, D._ptr(b_loc), D._ptr(x_loc), self.H.levels[0].n_own,
                                                            1 if x_is_zero else 0), "mg_dist_cycle_dev")
         return x_loc
@@ -728,6 +773,7 @@ class NativeDistributedHierarchy:
         import ctypes as C
         iters = C.c_longlong(0)
         resvec = np.zeros(int(maxIter) + 1)
+        self.H.be.synchronize()       # b_loc / x_loc (a fill, a copy) must have landed before the library's streams read them
         D._check(self.lib, self.lib.mg_dist_solve_dev_FP64(self.handle, D._ptr(b_loc), D._ptr(x_loc), self.H.levels[0].n_own,
                                                            float(tol), int(maxIter), C.byref(iters), D._f64(resvec)),
                  "mg_dist_solve_dev")

@@ -217,9 +217,10 @@ def structured_gmg(global_cells, numDomains, comm, backend, param: MGparam, oper
         planA = _make_plan([r_.get(("A", l), {}) for r_ in req_all], g, rank, size, rsA, nhA)
         planR = _make_plan([r_.get(("R", l), {}) for r_ in req_all], g, rank, size, rsR, nhR)
         planP = _make_plan([r_.get(("P", l), {}) for r_ in req_all], gc, rank, size, rsP, nhP) if rsP is not None else None
+        from .distributed import _box_of_rows
         local_levels.append(dict(n_own=int(g.own_loc.size), A=A_loc, planA=planA, R=R_loc, planR=planR, P=P_loc,
                                  planP=planP, d=np.asarray(ds[l])[g.own_loc], npre=param.relaxPre(l + 1),
-                                 npost=param.relaxPost(l + 1)))
+                                 npost=param.relaxPost(l + 1), box=_box_of_rows(g.own_gid, g.glob_nodes)))
     # ---- the replicated tail: assemble its finest operator from everybody's rows, then plain MGsetup -----
     nt = nglob[a]
     rows_i, cols_i, vals_i = [], [], []

@@ -50,7 +50,10 @@ def _problem(kind, nrhs, cyc):
     return mg, A, p, b, nodes
 
 
-def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", native=None):
+def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", native=None, box=False):
+    if box and use_hip:       # let the small local operators of the test take the row-class / staged kernels
+        os.environ.update(MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3",
+                          MG_MARCH_MIN_WG="0", MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_MARCH_MAX_LEN="64")
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -72,8 +75,17 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", nati
             from dist_cpu_backend import CpuCheckerBackend
             be = CpuCheckerBackend()
             comm = dd.TorchComm()
-        H = dd.DistributedHierarchy.from_global(p, comm, be, owner, nrhs, replicate_below=200)
+        level_nodes = None
+        if box and nodes is not None:      # BOX form of the sharded levels: rows in natural box order, A one square operator
+            level_nodes = [((np.asarray(nodes) - 1) >> l) + 1 for l in range(len(p.As))]
+        H = dd.DistributedHierarchy.from_global(p, comm, be, owner, nrhs, replicate_below=200, level_nodes=level_nodes)
         assert len(H.levels) >= 2, "the test must exercise at least two sharded levels"
+        assert H.box_form == bool(box and nodes is not None and nrhs == 1)
+        if box and use_hip and nodes is not None and nrhs == 1:
+            var = [L.A_int.kernel_variant() for L in H.levels]
+            assert var[0][0] in (1, 2, 3) and (world == 1 or var[0][1] > 0), var   # a staged kernel + exception rows
+            if len(nodes) == 3:
+                assert var[0][0] == 3, var                                     # 3-D fine level: z-marching
         S = H
         if native:          # the same local operators and plans, the loop in C++ (mg_dist_*): "plugin" or "rccl" transport
             S = dd.NativeDistributedHierarchy(H, transport=native)
@@ -101,12 +113,12 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", nati
         raise
 
 
-def _run(world, kind, nrhs, cyc, use_hip=False, backend="gloo", native=None):
+def _run(world, kind, nrhs, cyc, use_hip=False, backend="gloo", native=None, box=False):
     from oracle import mg_oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nrhs, cyc, use_hip, q, backend, native)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nrhs, cyc, use_hip, q, backend, native, box)) for r in range(world)]
     for pr in procs:
         pr.start()
     res = q.get(timeout=300)
@@ -178,6 +190,13 @@ def test_gloo_distributed_solve_matches_oracle(built, world, kind, nrhs, cyc):
     _run(world, kind, nrhs, cyc, use_hip=False)
 
 
+@pytest.mark.parametrize("world,kind,cyc", [(2, "gmg3d", "V"), (4, "gmg3d", "W"), (2, "gmg2d", "V"), (8, "gmg3d", "V")])
+def test_gloo_distributed_box_form(built, world, kind, cyc):
+    """BOX form of the sharded levels (rows in natural box order, A one square operator [owned box | halo], rows that
+    read the halo computed after the exchange): host logic under the checker backend."""
+    _run(world, kind, 1, cyc, use_hip=False, box=True)
+
+
 # ---- GPU: the HIP kernels under the same schedule ---------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,kind,nrhs,cyc", [(1, "gmg3d", 1, "V"), (2, "gmg3d", 1, "V"), (2, "gmg3d", 4, "W"),
@@ -210,6 +229,16 @@ def test_native_sequencer_plugin_transport(built, world, kind, cyc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,cyc,native", [(1, "gmg3d", "V", "plugin"), (2, "gmg3d", "V", "plugin"), (4, "gmg3d", "F", "plugin"),
+                                                   (2, "gmg3d", "W", None), (2, "gmg2d", "V", "plugin")])
+def test_box_form_local_operators_hip(built, world, kind, cyc, native):
+    """Sharded levels in BOX form on the device: the local A is one square grid operator (z-marching / plane-tile kernels
+    for the rows of the owned box that do not read the halo, csr_rows_spmv for those that do, after the exchange), driven
+    by the native sequencer (phase-split launches around the side-stream exchange) and by the Python one."""
+    _run(world, kind, 1, cyc, use_hip=True, native=native, box=True)
+
+
+@pytest.mark.gpu
 def test_native_sequencer_rccl_world1(built):
     """The RCCL transport with the one rank a single-GPU box allows: ncclCommInitRank from the library's own unique id,
     ncclAllReduce / ncclAllGather on the compute stream, side stream and events created (no peer to send to)."""
@@ -219,6 +248,8 @@ def test_native_sequencer_rccl_world1(built):
 # ---- sharded SETUP (structured_setup.py): every rank builds only its part -------------------------------
 def _worker_structured(rank, world, port, cells, levels, cyc, nrhs, use_hip, q):
     try:
+        if not use_hip:      # the operator-by-operator comparison below is written for the [interior | boundary] form
+            os.environ["MG_DIST_NO_BOX"] = "1"
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
