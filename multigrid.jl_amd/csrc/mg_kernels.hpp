@@ -1884,6 +1884,202 @@ __global__ __launch_bounds__(1024) void sptrsv_lu(LuDev F, const double* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same solve spread over the whole chip (factors of more than a few thousand rows).  The dependency levels of
+// a fill-reducing factorisation fall into two regimes: wide levels (thousands of independent rows) at the start of
+// the elimination and, at its end, the dense trailing supernode - a CHAIN of single-row levels (2732 of the 4620
+// levels of L for a 33^3 Poisson level).  The first regime gets one launch per level, one wavefront per row over as
+// many workgroups as the level has rows/4; the chain is not substituted at all: its dense triangular block D is
+// inverted once at setup (tri_inverse) and applied as a dense product (dense_apply), so the 2732 dependent steps
+// become one bandwidth-bound kernel.  No inter-workgroup waiting anywhere.
+//   sptrsv_level<LOWER>  rows order[t0..t1) of one level
+//   sptrsv_tail_rhs      t = b[p] - L21*y1 for the rows of the trailing block of L
+//   sptrsv_scatter       x[q[r]] = y[r]
+// ------------------------------------------------------------------------------------------------
+template <bool LOWER>
+__global__ __launch_bounds__(BLK) void sptrsv_level(LuDev F, const int4* __restrict__ slots, int t0, int t1,
+                                                    const double* __restrict__ b, double* y, int nrhs) {
+  const int t = t0 + (int)(((long long)blockIdx.x * BLK + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= t1) return;  // wave-uniform
+  const int* __restrict__ col = LOWER ? F.Lcol : F.Ucol;
+  const double* __restrict__ val = LOWER ? F.Lval : F.Uval;
+  const int4 sl = slots[t];                       // one load instead of order[] -> ptr[]: the level is latency-bound
+  const int row = sl.x, s = sl.y, e = sl.z;
+  const double dg = val[sl.w];
+  for (int c0 = 0; c0 < nrhs; c0 += 4) {
+    const int nc = min(4, nrhs - c0);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = s + lane; k < e; k += 64) {
+      const double v = val[k];
+      const double* yy = y + (size_t)col[k] * nrhs + c0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < nc) acc[u] += v * yy[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
+    if (lane < nc) {
+      const double rhs = LOWER ? b[(size_t)F.p[row] * nrhs + c0 + lane] : y[(size_t)row * nrhs + c0 + lane];
+      const double a = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      y[(size_t)row * nrhs + c0 + lane] = (rhs - a) / dg;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLK) void sptrsv_tail_rhs(LuDev F, int n0, const double* __restrict__ b,
+                                                       const double* __restrict__ y, double* __restrict__ t, int nrhs) {
+  const int i = (int)(((long long)blockIdx.x * BLK + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  const int row = n0 + i;
+  if (row >= F.n) return;  // wave-uniform
+  const int s = F.Lptr[row], e = F.Lptr[row + 1] - 1;
+  for (int c0 = 0; c0 < nrhs; c0 += 4) {
+    const int nc = min(4, nrhs - c0);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = s + lane; k < e; k += 64) {
+      const int c = F.Lcol[k];
+      if (c >= n0) continue;                       // the trailing block itself is applied through its inverse
+      const double v = F.Lval[k];
+      const double* yy = y + (size_t)c * nrhs + c0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < nc) acc[u] += v * yy[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);
+    if (lane < nc) {
+      const double a = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      t[(size_t)i * nrhs + c0 + lane] = b[(size_t)F.p[row] * nrhs + c0 + lane] - a;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLK) void sptrsv_scatter(const int* __restrict__ q, const double* __restrict__ y,
+                                                      double* __restrict__ x, int n, int nrhs) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= (long long)n * nrhs) return;
+  const int r = (int)(i / nrhs), u = (int)(i - (long long)r * nrhs);
+  x[(size_t)q[r] * nrhs + u] = y[i];
+}
+
+// Dense block (row-major, leading dimension ld = M rounded up to 64, zero outside the triangle, unit diagonal in the
+// padding) of the rows/columns n0.. of a factor in CSR.
+__global__ __launch_bounds__(BLK) void tri_gather_block(const int* __restrict__ ptr, const int* __restrict__ col,
+                                                        const double* __restrict__ val, int n0, int M, int ld,
+                                                        double* __restrict__ D) {
+  const int i = (int)(((long long)blockIdx.x * BLK + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= ld) return;
+  if (i >= M) {
+    if (lane == 0) D[(size_t)i * ld + i] = 1.0;
+    return;
+  }
+  for (int k = ptr[n0 + i] + lane; k < ptr[n0 + i + 1]; k += 64) {
+    const int c = col[k] - n0;
+    if (c >= 0) D[(size_t)i * ld + c] = val[k];
+  }
+}
+
+// X = inv(D) for a dense triangular block (ld x ld, ld a multiple of 64), blocked: one 256-thread workgroup per block
+// of 64 columns of X walks the 64-row panels in substitution order; for each panel the contribution of the rows
+// already known is a 64 x K x 64 product through LDS tiles (each thread a 4 x 4 register tile), the 64 x 64 diagonal
+// block is then substituted in LDS by one wavefront (a column per lane).  Setup-time kernel, ~M^3/3 flops.
+template <bool LOWER>
+__global__ __launch_bounds__(256) void tri_inverse(const double* __restrict__ D, double* X, int ld) {
+  __shared__ double As[64][17];
+  __shared__ double Bs[16][64];
+  __shared__ double Ts[64][65];
+  __shared__ double Ds[64][65];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int C0 = blockIdx.x * 64, nP = ld / 64, cb = blockIdx.x;
+  // rows outside the triangle of this column block
+  for (int i = LOWER ? 0 : C0 + 64; i < (LOWER ? C0 : ld); i += 4) {
+    const int r = i + (tid >> 6);
+    if (r < (LOWER ? C0 : ld)) X[(size_t)r * ld + C0 + (tid & 63)] = 0.0;
+  }
+  for (int pp = 0; pp < (LOWER ? nP - cb : cb + 1); ++pp) {
+    const int p = LOWER ? cb + pp : cb - pp;
+    const int I0 = p * 64;
+    const int K0 = LOWER ? C0 : I0 + 64, K1 = LOWER ? I0 : C0 + 64;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = K0; k0 < K1; k0 += 16) {
+      // D[I0 + r][k0 + kk]: 64 x 16; X[k0 + kk][C0 + c]: 16 x 64 - four elements per thread each
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = tid + 256 * u;
+        As[e >> 4][e & 15] = D[(size_t)(I0 + (e >> 4)) * ld + k0 + (e & 15)];
+        Bs[e >> 6][e & 63] = X[(size_t)(k0 + (e >> 6)) * ld + C0 + (e & 63)];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        double a[4], bb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = As[ty * 4 + i][kk];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bb[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = ty * 4 + i, c = tx * 4 + j;
+        Ts[r][c] = ((I0 + r == C0 + c) ? 1.0 : 0.0) - acc[i][j];
+      }
+    for (int e = tid; e < 64 * 64; e += 256) Ds[e >> 6][e & 63] = D[(size_t)(I0 + (e >> 6)) * ld + I0 + (e & 63)];
+    __syncthreads();
+    if (tid < 64) {                                 // one wavefront, a column per lane: no barriers needed inside
+      const int c = tid;
+      if (LOWER) {
+        for (int r = 0; r < 64; ++r) {
+          double v = Ts[r][c];
+          for (int k = 0; k < r; ++k) v -= Ds[r][k] * Ts[k][c];
+          Ts[r][c] = v / Ds[r][r];
+        }
+      } else {
+        for (int r = 63; r >= 0; --r) {
+          double v = Ts[r][c];
+          for (int k = r + 1; k < 64; ++k) v -= Ds[r][k] * Ts[k][c];
+          Ts[r][c] = v / Ds[r][r];
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) X[(size_t)(I0 + (e >> 6)) * ld + C0 + (e & 63)] = Ts[e >> 6][e & 63];
+    __threadfence();                                // the next panel of this workgroup reads these rows back
+    __syncthreads();
+  }
+}
+
+// x = T * b for a dense TRIANGULAR M x M block (row-major, leading dimension ld): dense_apply that only reads the triangle.
+template <bool LOWER>
+__global__ __launch_bounds__(BLK) void tri_apply(const double* __restrict__ T, int ld, const double* __restrict__ b,
+                                                 double* __restrict__ x, int M, int nrhs) {
+  const int wave = (int)(((long long)blockIdx.x * BLK + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (wave >= M * nrhs) return;  // wave-uniform
+  const int row = wave / nrhs, c = wave - row * nrhs;
+  const double* __restrict__ a = T + (size_t)row * ld;
+  const int j0 = LOWER ? 0 : (row & ~63), j1 = LOWER ? row + 1 : M;
+  double acc = 0.0;
+  for (int j = j0 + lane; j < j1; j += 64) acc += a[j] * b[(size_t)j * nrhs + c];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) x[(size_t)row * nrhs + c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Numeric Galerkin product on a FIXED sparsity: C = R*(A*P) (replaceMatrixInHierarchy, MGsetup.jl:226-270:
 // `Act = Ps[l]*AT*Rs[l]` with unchanged P, R; the pattern of C is the one the host setup produced).
 // One wavefront (a 64-thread workgroup) per coarse row i.  DETERMINISTIC: the entries (i,k) of R's row and (k,j) of

@@ -63,6 +63,9 @@ struct Options {
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
   long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
   long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
+  long long lu_multi_min_rows = 4096;   // sparse coarse factors of this many rows: per-level launches + dense trailing inverse
+  long long lu_dense_tail_min = 64;
+  long long lu_dense_tail_max = 16384;  // largest trailing block kept as an explicit inverse (8*M^2 bytes each for L and U: 2 x 2.1 GB)
   double rowclass_min_cover = 0.9, sched_budget = 2.0e6;
   struct Entry { const char* env; const char* key; int kind; size_t off; };   // kind 0 bool, 1 long long, 2 double, 3 int
   static const Entry* table(size_t* n);
@@ -86,6 +89,9 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
       MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
       MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
+      MG_OPT("MG_LU_MULTI_MIN_ROWS", "lu_multi_min_rows", 1, lu_multi_min_rows),
+      MG_OPT("MG_LU_DENSE_TAIL_MAX", "lu_dense_tail_max", 1, lu_dense_tail_max),
+      MG_OPT("MG_LU_DENSE_TAIL_MIN", "lu_dense_tail_min", 1, lu_dense_tail_min),
       MG_OPT("MG_ROWCLASS_MIN_COVER", "rowclass_min_cover", 2, rowclass_min_cover),
       MG_OPT("MG_SCHED_BUDGET", "sched_budget", 2, sched_budget),
   };
@@ -393,6 +399,13 @@ struct mg_hierarchy {
   DevBuf<int> luLptr, luLcol, luUptr, luUcol, luP, luQ, luLorder, luLlvl, luUorder, luUlvl;
   DevBuf<double> luLval, luUval, luWork;
   int nLlvl = 0, nUlvl = 0;
+  // chip-wide form (factors of >= lu_multi_min_rows rows): host copies of the level pointers for the per-level
+  // launches, and the explicit inverses of the dense trailing blocks (rows n-luML.. of L, n-luMU.. of U)
+  std::vector<int> luLlvl_h, luUlvl_h;
+  DevBuf<double> luInvL, luInvU, luTail;
+  DevBuf<int> luLslot, luUslot;   // per level slot {row, first, end of the off-diagonal entries, diagonal entry}
+  int luML = 0, luMU = 0;
+  bool lu_multi = false;
   hipStream_t stream = nullptr;
   bool owns_stream = true;
   // reductions
@@ -826,7 +839,42 @@ int k_coarse(mg_hierarchy* h, int level, const double* b, double* x) {
     F.p = h->luP.p; F.q = h->luQ.p;
     F.Lorder = h->luLorder.p; F.Llvl = h->luLlvl.p; F.nLlvl = h->nLlvl;
     F.Uorder = h->luUorder.p; F.Ulvl = h->luUlvl.p; F.nUlvl = h->nUlvl;
-    hipLaunchKernelGGL(mgk::sptrsv_lu, dim3(1), dim3(1024), 0, h->stream, F, b, x, h->luWork.p, (int)h->nrhs);
+    if (!h->lu_multi) {
+      hipLaunchKernelGGL(mgk::sptrsv_lu, dim3(1), dim3(1024), 0, h->stream, F, b, x, h->luWork.p, (int)h->nrhs);
+      HIP_TRY(hipGetLastError());
+      return MG_OK;
+    }
+    const int nr = (int)h->nrhs;
+    double* y = h->luWork.p;
+    auto wave_blocks = [](long long waves) { return dim3((unsigned)((waves * 64 + mgk::BLK - 1) / mgk::BLK)); };
+    // y = L \ b[p]: the levels ahead of the trailing block one launch each, the block through its inverse
+    const int nLl = (int)h->luLlvl_h.size() - 1, nUl = (int)h->luUlvl_h.size() - 1;
+    for (int l = 0; l < nLl; ++l) {
+      const int t0 = h->luLlvl_h[(size_t)l], t1 = h->luLlvl_h[(size_t)l + 1];
+      hipLaunchKernelGGL(mgk::sptrsv_level<true>, wave_blocks(t1 - t0), dim3(mgk::BLK), 0, h->stream, F,
+                         reinterpret_cast<const int4*>(h->luLslot.p), t0, t1, b, y, nr);
+    }
+    if (h->luML > 0) {
+      const int n0 = (int)n - h->luML;
+      hipLaunchKernelGGL(mgk::sptrsv_tail_rhs, wave_blocks(h->luML), dim3(mgk::BLK), 0, h->stream, F, n0, b, y, h->luTail.p, nr);
+      hipLaunchKernelGGL(mgk::tri_apply<true>, wave_blocks((long long)h->luML * nr), dim3(mgk::BLK), 0, h->stream,
+                         h->luInvL.p, (h->luML + 63) / 64 * 64, h->luTail.p, y + (size_t)n0 * (size_t)nr, h->luML, nr);
+    }
+    // y = U \ y: the trailing block first, then the levels behind it
+    if (h->luMU > 0) {
+      const int n0 = (int)n - h->luMU;
+      HIP_TRY(hipMemcpyAsync(h->luTail.p, y + (size_t)n0 * (size_t)nr, (size_t)h->luMU * (size_t)nr * sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
+      hipLaunchKernelGGL(mgk::tri_apply<false>, wave_blocks((long long)h->luMU * nr), dim3(mgk::BLK), 0, h->stream,
+                         h->luInvU.p, (h->luMU + 63) / 64 * 64, h->luTail.p, y + (size_t)n0 * (size_t)nr, h->luMU, nr);
+    }
+    for (int l = 0; l < nUl; ++l) {
+      const int t0 = h->luUlvl_h[(size_t)l], t1 = h->luUlvl_h[(size_t)l + 1];
+      hipLaunchKernelGGL(mgk::sptrsv_level<false>, wave_blocks(t1 - t0), dim3(mgk::BLK), 0, h->stream, F,
+                         reinterpret_cast<const int4*>(h->luUslot.p), t0, t1, b, y, nr);
+    }
+    hipLaunchKernelGGL(mgk::sptrsv_scatter, dim3((unsigned)((n * nr + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0,
+                       h->stream, h->luQ.p, y, x, (int)n, nr);
     HIP_TRY(hipGetLastError());
     return MG_OK;
   }
@@ -2040,6 +2088,7 @@ int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const st
 int alloc_scratch(mg_hierarchy* h) {
   const long long k = h->nrhs;
   if (h->coarse_lu) MG_TRY(h->luWork.alloc((size_t)h->n_coarse * (size_t)k));
+  if (h->coarse_lu && std::max(h->luML, h->luMU) > 0) MG_TRY(h->luTail.alloc((size_t)std::max(h->luML, h->luMU) * (size_t)k));
   if (!h->opt.no_sched) {
     for (int l = 0; l < (int)h->nlevels; ++l) {
       Level& L = h->lev[(size_t)l];
@@ -2718,6 +2767,7 @@ int mg_destroy(mg_hierarchy* h) {
   h->luLval.release();
   h->luUval.release();
   h->luWork.release();
+  h->luInvL.release(); h->luInvU.release(); h->luTail.release(); h->luLslot.release(); h->luUslot.release();
   h->kwc.release();
   h->coarse_d.release();
   h->partial.release();
@@ -2852,6 +2902,36 @@ int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* L
     return fail(MG_ERR_UNSUPPORTED, "factors exceed int32 device indices");
   (void)hipSetDevice(h->device);
   const size_t N = (size_t)n;
+  // dependency levels of the rows [0, n-M) of a triangular factor; the trailing M rows are handled apart (for U they
+  // are solved BEFORE every level, for L after all of them), so they impose no ordering here
+  auto levels = [&](const std::vector<int>& P, const std::vector<int>& Cc, bool lower, int M, std::vector<int>& order,
+                    std::vector<int>& lvlptr) {
+    const int na = (int)n - M;
+    std::vector<int> lvl((size_t)na, 0);
+    int nl = 0;
+    if (lower) {
+      for (int i = 0; i < na; ++i) {
+        int m = 0;
+        for (int k = P[(size_t)i]; k < P[(size_t)i + 1] - 1; ++k) m = std::max(m, lvl[(size_t)Cc[(size_t)k]] + 1);
+        lvl[(size_t)i] = m;
+        nl = std::max(nl, m + 1);
+      }
+    } else {
+      for (int i = na - 1; i >= 0; --i) {
+        int m = 0;
+        for (int k = P[(size_t)i] + 1; k < P[(size_t)i + 1]; ++k)
+          if (Cc[(size_t)k] < na) m = std::max(m, lvl[(size_t)Cc[(size_t)k]] + 1);
+        lvl[(size_t)i] = m;
+        nl = std::max(nl, m + 1);
+      }
+    }
+    lvlptr.assign((size_t)nl + 1, 0);
+    for (int i = 0; i < na; ++i) lvlptr[(size_t)lvl[(size_t)i] + 1]++;
+    for (int l = 0; l < nl; ++l) lvlptr[(size_t)l + 1] += lvlptr[(size_t)l];
+    order.resize((size_t)na);
+    std::vector<int> pos(lvlptr.begin(), lvlptr.end() - 1);
+    for (int i = 0; i < na; ++i) order[(size_t)pos[(size_t)lvl[(size_t)i]]++] = i;
+  };
   auto conv = [&](const long long* ptr, const long long* col, bool lower, std::vector<int>& P, std::vector<int>& Cc,
                   std::vector<int>& order, std::vector<int>& lvlptr) -> int {
     const long long nnz = ptr[n] - 1;
@@ -2863,37 +2943,20 @@ int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* L
       if (c < 0 || c >= n) return fail(MG_ERR_INVALID, "factor column index out of range");
       Cc[(size_t)k] = (int)c;
     }
-    std::vector<int> lvl(N, 0);
-    int nl = 0;
     if (lower) {
       for (size_t i = 0; i < N; ++i) {
         if (P[i + 1] - P[i] < 1 || Cc[(size_t)P[i + 1] - 1] != (int)i) return fail(MG_ERR_INVALID, "L: the diagonal must be the last entry of row %zu", i + 1);
-        int m = 0;
-        for (int k = P[i]; k < P[i + 1] - 1; ++k) {
+        for (int k = P[i]; k < P[i + 1] - 1; ++k)
           if (Cc[(size_t)k] >= (int)i) return fail(MG_ERR_INVALID, "L is not lower triangular");
-          m = std::max(m, lvl[(size_t)Cc[(size_t)k]] + 1);
-        }
-        lvl[i] = m;
-        nl = std::max(nl, m + 1);
       }
     } else {
-      for (size_t ii = N; ii-- > 0;) {
+      for (size_t ii = 0; ii < N; ++ii) {
         if (P[ii + 1] - P[ii] < 1 || Cc[(size_t)P[ii]] != (int)ii) return fail(MG_ERR_INVALID, "U: the diagonal must be the first entry of row %zu", ii + 1);
-        int m = 0;
-        for (int k = P[ii] + 1; k < P[ii + 1]; ++k) {
+        for (int k = P[ii] + 1; k < P[ii + 1]; ++k)
           if (Cc[(size_t)k] <= (int)ii) return fail(MG_ERR_INVALID, "U is not upper triangular");
-          m = std::max(m, lvl[(size_t)Cc[(size_t)k]] + 1);
-        }
-        lvl[ii] = m;
-        nl = std::max(nl, m + 1);
       }
     }
-    lvlptr.assign((size_t)nl + 1, 0);
-    for (size_t i = 0; i < N; ++i) lvlptr[(size_t)lvl[i] + 1]++;
-    for (int l = 0; l < nl; ++l) lvlptr[(size_t)l + 1] += lvlptr[(size_t)l];
-    order.resize(N);
-    std::vector<int> pos(lvlptr.begin(), lvlptr.end() - 1);
-    for (size_t i = 0; i < N; ++i) order[(size_t)pos[(size_t)lvl[i]]++] = (int)i;
+    levels(P, Cc, lower, 0, order, lvlptr);
     return MG_OK;
   };
   std::vector<int> LP, LC, LO, LL, UP, UC, UO, UL, pp(N), qq(N);
@@ -2918,6 +2981,65 @@ int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* L
   HIP_TRY(hipMemcpy(h->luUval.p, Uval, UC.size() * sizeof(double), hipMemcpyHostToDevice));
   h->nLlvl = (int)LL.size() - 1;
   h->nUlvl = (int)UL.size() - 1;
+  // chip-wide form: the trailing chains of single-row levels (rows n-1, n-2, ... one per level: the dense last
+  // supernode) are solved through the explicit inverse of their dense block
+  h->lu_multi = n >= h->opt.lu_multi_min_rows;
+  h->luML = h->luMU = 0;
+  h->luInvL.release(); h->luInvU.release(); h->luTail.release();
+  if (h->lu_multi) {
+    // Size M of the trailing block: a level costs ~8 us of dependent latency whatever its width, the dense product
+    // 8*M^2/2 bytes of traffic per factor - take the candidate with the smallest estimate.  (33^3 Poisson level under
+    // a minimum-degree ordering: 3284 levels per factor at M = 0, 639 at M = 4096, 132 at M = 8192.)
+    const int cap = (int)std::min<long long>(h->opt.lu_dense_tail_max, n);
+    int M = 0;
+    double best = 0.0;
+    std::vector<int> o, lp;
+    for (int cand = 0; cand <= cap; cand = cand == 0 ? (int)std::max<long long>(h->opt.lu_dense_tail_min, 1) : cand * 2) {
+      levels(LP, LC, true, cand, o, lp);
+      double est = 8e-6 * (double)(lp.size() - 1);
+      levels(UP, UC, false, cand, o, lp);
+      est += 8e-6 * (double)(lp.size() - 1) + 2.0 * 4.0 * (double)cand * (double)cand / 4e12;
+      if (cand == 0 || est < best) { best = est; M = cand; }
+    }
+    auto slots = [&](const std::vector<int>& P, bool lower, const std::vector<int>& order, DevBuf<int>& d) -> int {
+      std::vector<int> sl(order.size() * 4);
+      for (size_t t = 0; t < order.size(); ++t) {
+        const int r = order[t];
+        sl[4 * t] = r;
+        sl[4 * t + 1] = lower ? P[(size_t)r] : P[(size_t)r] + 1;          // off-diagonal entries [s, e)
+        sl[4 * t + 2] = lower ? P[(size_t)r + 1] - 1 : P[(size_t)r + 1];
+        sl[4 * t + 3] = lower ? P[(size_t)r + 1] - 1 : P[(size_t)r];      // the diagonal entry
+      }
+      return up_i(d, sl);
+    };
+    levels(LP, LC, true, M, o, h->luLlvl_h);
+    MG_TRY(slots(LP, true, o, h->luLslot));
+    levels(UP, UC, false, M, o, h->luUlvl_h);
+    MG_TRY(slots(UP, false, o, h->luUslot));
+    const int ML = M, MU = M;
+    auto invert = [&](bool lower, int M, const DevBuf<int>& ptr, const DevBuf<int>& col, const DevBuf<double>& val,
+                      DevBuf<double>& inv) -> int {
+      const int ld = (M + 63) / 64 * 64;
+      DevBuf<double> D;
+      MG_TRY(D.alloc((size_t)ld * (size_t)ld));
+      MG_TRY(inv.alloc((size_t)ld * (size_t)ld));
+      HIP_TRY(hipMemsetAsync(D.p, 0, (size_t)ld * (size_t)ld * sizeof(double), h->stream));
+      hipLaunchKernelGGL(mgk::tri_gather_block, dim3((unsigned)(((long long)ld * 64 + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK),
+                         0, h->stream, ptr.p, col.p, val.p, (int)n - M, M, ld, D.p);
+      if (lower) hipLaunchKernelGGL(mgk::tri_inverse<true>, dim3((unsigned)(ld / 64)), dim3(256), 0, h->stream, D.p, inv.p, ld);
+      else hipLaunchKernelGGL(mgk::tri_inverse<false>, dim3((unsigned)(ld / 64)), dim3(256), 0, h->stream, D.p, inv.p, ld);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      return MG_OK;
+    };
+    if (ML > 0) MG_TRY(invert(true, ML, h->luLptr, h->luLcol, h->luLval, h->luInvL));
+    if (MU > 0) MG_TRY(invert(false, MU, h->luUptr, h->luUcol, h->luUval, h->luInvU));
+    h->luML = ML;
+    h->luMU = MU;
+    if (h->opt.debug_format)
+      std::fprintf(stderr, "[mgvcycle] coarse LU n=%lld: dense trailing block %d, L %zu levels ahead of it (%d in all), U %zu behind it (%d)\n",
+                   n, M, h->luLlvl_h.size() - 1, h->nLlvl, h->luUlvl_h.size() - 1, h->nUlvl);
+  }
   h->n_coarse = n;
   h->coarse_set = true;
   h->coarse_lu = true;

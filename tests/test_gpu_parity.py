@@ -339,14 +339,19 @@ def test_rediscretised_hierarchy_on_device(mg, built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels,nrhs", [([16, 16, 16], 3, 1), ([32, 32], 3, 3), ([24, 24, 24], 2, 2)])
-def test_sparse_lu_coarse_solve(mg, built, cells, levels, nrhs, monkeypatch):
+@pytest.mark.parametrize("multi", [False, True])
+@pytest.mark.parametrize("cells,levels,nrhs", [([16, 16, 16], 3, 1), ([32, 32], 3, 3), ([24, 24, 24], 2, 2), ([24, 24, 24], 2, 6)])
+def test_sparse_lu_coarse_solve(mg, built, cells, levels, nrhs, multi, monkeypatch):
     """Coarsest levels above the dense-inverse cap are solved on the device from the SPARSE factors in the layout of
     the reference's native applier (mg_set_coarse_lu_FP64_INT64 <-> deps/src/parLU.cpp:120-190).  Forced here on small
     hierarchies: the whole solve must match the oracle exactly as the dense-inverse path does, and (where the
     reference binary was built) the coarse solve alone must match applyLUsolve_FP64_INT64."""
     from multigrid_jl_amd import device as D
     monkeypatch.setattr(D, "DENSE_COARSE_MAX", 0)
+    # multi: the chip-wide form (one launch per dependency level, the trailing chain of single-row levels through the
+    # explicit inverse of its dense block) that factors of >= 4096 rows get, forced on these small ones
+    monkeypatch.setenv("MG_LU_MULTI_MIN_ROWS", "0" if multi else "1000000000")
+    monkeypatch.setenv("MG_LU_DENSE_TAIL_MIN", "4")
     A, p, b = _setup(mg, cells, levels, nrhs=nrhs)
     _compare_solve(mg, p, b)
     # the coarse solve in isolation: a 1-level "hierarchy" is just x = LU \ b (recursiveCycle at the coarsest level)
