@@ -77,6 +77,13 @@ int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which
 int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long long n,
                       long long relaxPre, long long relaxPost);
 
+/* Launch-bound coarse sub-cycles (from the first level of at most `graph_max_rows` rows*nrhs down, option
+ * "graph_max_rows", default 300000; "no_graph" switches it off) are captured once into HIP graphs and replayed: the
+ * reference has no counterpart (its recursion is host code, MGcycle.jl:1-118).  Counters for tests and tuning:
+ * *launches = graph replays so far, *graphs = graphs currently cached.  Graphs are dropped by every call that
+ * changes the hierarchy. */
+int mg_graph_launches(mg_hierarchy* h, long long* launches, long long* graphs);
+
 /* Optional performance hint (results are unchanged): the rows of As[level] are the nodes of an x-fastest
  * n1 x n2 x n3 regular grid (param.Meshes[level].n .+ 1 for geometric multigrid, MGsetup.jl:54).  Lets the
  * library walk the row blocks in L2-sized y-tiles when three grid planes of the gathered vector do not fit

@@ -17,7 +17,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -63,6 +65,8 @@ struct Options {
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
   long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
   long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
+  bool no_graph = false;
+  long long graph_max_rows = 300000;    // sub-cycles from the first level of at most this many rows*nrhs replay as one HIP graph
   long long lu_multi_min_rows = 4096;   // sparse coarse factors of this many rows: per-level launches + dense trailing inverse
   long long lu_dense_tail_min = 64;
   long long lu_dense_tail_max = 16384;  // largest trailing block kept as an explicit inverse (8*M^2 bytes each for L and U: 2 x 2.1 GB)
@@ -89,6 +93,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
       MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
       MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
+      MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
       MG_OPT("MG_LU_MULTI_MIN_ROWS", "lu_multi_min_rows", 1, lu_multi_min_rows),
       MG_OPT("MG_LU_DENSE_TAIL_MAX", "lu_dense_tail_max", 1, lu_dense_tail_max),
       MG_OPT("MG_LU_DENSE_TAIL_MIN", "lu_dense_tail_min", 1, lu_dense_tail_min),
@@ -406,6 +411,17 @@ struct mg_hierarchy {
   DevBuf<int> luLslot, luUslot;   // per level slot {row, first, end of the off-diagonal entries, diagonal entry}
   int luML = 0, luMU = 0;
   bool lu_multi = false;
+  // launch-bound coarse sub-cycles replay as HIP graphs (captured on first use; keyed by level, buffers and cycle)
+  struct GraphKey {
+    int level; bool x_zero; char ctype; const void* b; const void* xa; const void* xb;
+    bool operator<(const GraphKey& o) const {
+      return std::tie(level, x_zero, ctype, b, xa, xb) < std::tie(o.level, o.x_zero, o.ctype, o.b, o.xa, o.xb);
+    }
+  };
+  struct GraphEntry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; double* result = nullptr; };
+  std::map<GraphKey, GraphEntry> graphs;
+  bool capturing = false;
+  long long graph_launches = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = true;
   // reductions
@@ -1024,6 +1040,7 @@ int fgmres_relax(mg_hierarchy* h, int lv, const double* r0, double* x0, long lon
 // SolveFuncs.jl:26-30, and recursiveCycle would recompute the same values, MGcycle.jl:26-31).
 // x1_ready (with r_valid): xb already holds xa + d.*r, the first pre-smoothing update (written by the residual kernel
 // of the previous solve step, k_residual_sumsq's xnext).
+int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result);
 int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero,
                 char ctype, double** result, bool r_valid = false, bool x1_ready = false) {
   const int nl = (int)h->nlevels;
@@ -1080,15 +1097,15 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     MG_TRY(fgmres_relax(h, l + 1, C.b.p, C.x0.p, 2, kprec, gmresTol, C.kZ.p, C.kAZ.p, true));
     xc = C.x0.p;
   } else {
-    MG_TRY(cycle_level(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
+    MG_TRY(cycle_sub(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
   }
   if (l + 1 < nl - 1) {  // MGcycle.jl:78-85
     if (ctype == 'W') {
       double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
-      MG_TRY(cycle_level(h, l + 1, C.b.p, xc, other, false, 'W', &xc));
+      MG_TRY(cycle_sub(h, l + 1, C.b.p, xc, other, false, 'W', &xc));
     } else if (ctype == 'F') {
       double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
-      MG_TRY(cycle_level(h, l + 1, C.b.p, xc, other, false, 'V', &xc));
+      MG_TRY(cycle_sub(h, l + 1, C.b.p, xc, other, false, 'V', &xc));
     }
   }
   // x += P xc (MGcycle.jl:90) and post-smoothing (l.92-102)
@@ -1130,12 +1147,57 @@ int check_ready(mg_hierarchy* h, long long n, long long nrhs) {
   return MG_OK;
 }
 
+void graphs_clear(mg_hierarchy* h) {
+  if (h->graphs.empty()) return;
+  if (h->stream) (void)spin_sync(h->stream);   // a replay may still be running
+  for (auto& kv : h->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
+  h->graphs.clear();
+}
+
+// The levels below a few hundred thousand rows are launch-bound (8-14 us per kernel for microseconds of work): the
+// whole sub-cycle from the first such level down - smoothers, transfers, coarsest solve, every launch with fixed
+// arguments on hierarchy-owned buffers - is captured once into a HIP graph and replayed.  Not for cycles with host
+// decisions inside (Jac-GMRES smoothing, K-cycles, GMRES coarsest solve) and not while profiling (events per launch).
+bool graph_ok(const mg_hierarchy* h, int l, char ctype) {
+  if (h->opt.no_graph || h->prof || h->capturing || h->relax_type == 1 || ctype == 'K' || h->coarse_gmres) return false;
+  if (h->lev[(size_t)l].n * h->nrhs > h->opt.graph_max_rows) return false;
+  return (int)h->nlevels - l >= 2 || (h->coarse_lu && h->lu_multi);
+}
+int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result) {
+  if (!graph_ok(h, l, ctype)) return cycle_level(h, l, b, xa, xb, x_zero, ctype, result, false, false);
+  const mg_hierarchy::GraphKey key{l, x_zero, ctype, b, xa, xb};
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    if (h->graphs.size() >= 64) graphs_clear(h);   // callers cycling through many buffers: start over
+    mg_hierarchy::GraphEntry e;
+    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    h->capturing = true;
+    const int rc = cycle_level(h, l, b, xa, xb, x_zero, ctype, &e.result, false, false);
+    h->capturing = false;
+    const hipError_t ce = hipStreamEndCapture(h->stream, &e.graph);
+    if (rc != MG_OK || ce != hipSuccess) {
+      if (e.graph) (void)hipGraphDestroy(e.graph);
+      if (rc != MG_OK) return rc;
+      HIP_TRY(ce);
+    }
+    HIP_TRY(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+    it = h->graphs.emplace(key, e).first;
+  }
+  HIP_TRY(hipGraphLaunch(it->second.exec, h->stream));
+  ++h->graph_launches;
+  *result = it->second.result;
+  return MG_OK;
+}
+
 // one cycle on device buffers; result guaranteed to be in x on return (no sync)
 int cycle_dev(mg_hierarchy* h, const double* b, double* x, bool x_zero) {
   double* res = nullptr;
   h->last_b = b;
   h->last_x = x;
-  MG_TRY(cycle_level(h, 0, b, x, h->lev[0].x1.p, x_zero, h->cycle, &res));
+  MG_TRY(cycle_sub(h, 0, b, x, h->lev[0].x1.p, x_zero, h->cycle, &res));
   if (res != x)
     HIP_TRY(hipMemcpyAsync(x, res, sizeof(double) * h->lev[0].n * h->nrhs, hipMemcpyDeviceToDevice, h->stream));
   return MG_OK;
@@ -2672,6 +2734,7 @@ int mg_create(long long nlevels, long long nrhs, long long device_id, mg_hierarc
 int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long long relaxKind,
                 const double* omega, long long* levels_done) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
   if (!fine_nzval || !omega) return fail(MG_ERR_INVALID, "null argument");
   if (relaxKind != 0 && relaxKind != 1) return fail(MG_ERR_INVALID, "relaxKind must be 0 (Jac) or 1 (SPAI)");
@@ -2746,6 +2809,7 @@ int mg_get_relax_FP64(mg_hierarchy* h, long long level, double* out, long long n
 
 int mg_destroy(mg_hierarchy* h) {
   if (!h) return MG_OK;
+  graphs_clear(h);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)spin_sync(h->stream);
   prof_collect(h);
@@ -2796,6 +2860,7 @@ int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which
                                const double* nzval) {
   UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   Csr* M = pick(h, level, which);
   if (!M) return fail(MG_ERR_INVALID, "bad (level=%lld, which=%lld)", level, which);
   if ((which == MG_OP_P || which == MG_OP_R) && level == h->nlevels)
@@ -2810,6 +2875,7 @@ int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long lo
                       long long relaxPre, long long relaxPost) {
   UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
   if (!d || n < 1) return fail(MG_ERR_INVALID, "empty relaxPrec");
   if (relaxPre < 0 || relaxPost < 0) return fail(MG_ERR_INVALID, "negative sweep count");
@@ -2830,6 +2896,7 @@ int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long lo
 // mg_finalize; call it right after mg_create.
 int mg_set_option(mg_hierarchy* h, const char* key, double value) {
   if (!h || !key) return fail(MG_ERR_INVALID, "null argument");
+  graphs_clear(h);
   if (!h->opt.set(key, value, false)) return fail(MG_ERR_INVALID, "unknown option '%s'", key);
   for (auto& L : h->lev) {
     L.A.opt = h->opt;
@@ -2840,8 +2907,16 @@ int mg_set_option(mg_hierarchy* h, const char* key, double value) {
   return MG_OK;
 }
 
+int mg_graph_launches(mg_hierarchy* h, long long* launches, long long* graphs) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (launches) *launches = h->graph_launches;
+  if (graphs) *graphs = (long long)h->graphs.size();
+  return MG_OK;
+}
+
 int mg_set_grid_hint(mg_hierarchy* h, long long level, long long n1, long long n2, long long n3) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
   if (n1 < 1 || n2 < 1 || n3 < 1) return fail(MG_ERR_INVALID, "grid dimensions must be >= 1");
   Level& L = h->lev[(size_t)level - 1];
@@ -2854,6 +2929,7 @@ int mg_set_grid_hint(mg_hierarchy* h, long long level, long long n1, long long n
 
 int mg_set_relax_type(mg_hierarchy* h, long long relaxType) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (relaxType != 0 && relaxType != 1) return fail(MG_ERR_INVALID, "relaxType must be 0 (Jac/SPAI) or 1 (Jac-GMRES)");
   h->relax_type = (int)relaxType;
   h->finalized = false;
@@ -2862,6 +2938,7 @@ int mg_set_relax_type(mg_hierarchy* h, long long relaxType) {
 
 int mg_set_cycle_type(mg_hierarchy* h, long long cycleType) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F' && cycleType != 'K')
     return fail(MG_ERR_INVALID, "cycleType must be 'V', 'W', 'F' or 'K'");
   if ((cycleType == 'K') != (h->cycle == 'K')) h->finalized = false;  // memKcycle must be (de)allocated
@@ -2872,6 +2949,7 @@ int mg_set_cycle_type(mg_hierarchy* h, long long cycleType) {
 int mg_set_coarse_dense_inverse_FP64(mg_hierarchy* h, long long n, const double* Ainv) {
   UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (n < 1 || !Ainv) return fail(MG_ERR_INVALID, "empty coarse inverse");
   if (n > 46000) return fail(MG_ERR_UNSUPPORTED, "dense coarse inverse of order %lld is too large", n);
   (void)hipSetDevice(h->device);
@@ -2897,6 +2975,7 @@ int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* L
                                 const double* Uval, const long long* p, const long long* q) {
   UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (n < 1 || !Lptr || !Lcol || !Lval || !Uptr || !Ucol || !Uval || !p || !q) return fail(MG_ERR_INVALID, "null or empty factor");
   if (n >= (1LL << 31) - 1 || Lptr[n] - 1 >= (1LL << 31) || Uptr[n] - 1 >= (1LL << 31))
     return fail(MG_ERR_UNSUPPORTED, "factors exceed int32 device indices");
@@ -3054,6 +3133,7 @@ int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* L
 int mg_set_coarse_gmres_FP64(mg_hierarchy* h, long long n, const double* d) {
   UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (n < 1 || !d) return fail(MG_ERR_INVALID, "empty preconditioner");
   (void)hipSetDevice(h->device);
   MG_TRY(h->coarse_d.alloc((size_t)n));
@@ -3070,6 +3150,7 @@ int mg_set_coarse_gmres_FP64(mg_hierarchy* h, long long n, const double* d) {
 int mg_finalize(mg_hierarchy* h) {
   UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   (void)hipSetDevice(h->device);
   const int nl = (int)h->nlevels;
   for (int l = 0; l < nl; ++l) {
@@ -3105,6 +3186,7 @@ int mg_finalize(mg_hierarchy* h) {
 int mg_set_nrhs(mg_hierarchy* h, long long nrhs) {
   UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   if (nrhs < 1) return fail(MG_ERR_INVALID, "nrhs must be >= 1");
   if (nrhs == h->nrhs) return MG_OK;
   (void)hipSetDevice(h->device);
@@ -3120,6 +3202,7 @@ int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, co
                            long long nnz) {
   UploadFence upload_fence;
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   Csr* M = pick(h, level, which);
   if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
   if (nnz != M->nnz) return fail(MG_ERR_INVALID, "nnz=%lld differs from the stored pattern (%lld)", nnz, M->nnz);
@@ -4523,6 +4606,7 @@ int mg_dist_destroy(mg_dist* h) {
 // Run the hierarchy's kernels on the caller's stream (e.g. torch's current stream) instead of its own.
 int mg_set_stream(mg_hierarchy* h, void* stream) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  graphs_clear(h);
   (void)hipSetDevice(h->device);
   (void)spin_sync(h->stream);
   if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);

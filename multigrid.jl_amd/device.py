@@ -42,6 +42,7 @@ SIGNATURES = {
     "mg_set_grid_hint": (C.c_int, [_vp, _ll, _ll, _ll, _ll]),
     "mg_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "mg_set_coarse_dense_inverse_FP64": (C.c_int, [_vp, _ll, _dp]),
+    "mg_graph_launches": (C.c_int, [_vp, _lp, _lp]),
     "mg_set_coarse_lu_FP64_INT64": (C.c_int, [_vp, _ll, _lp, _lp, _dp, _lp, _lp, _dp, _lp, _lp]),
     "mg_set_coarse_gmres_FP64": (C.c_int, [_vp, _ll, _dp]),
     "mg_finalize": (C.c_int, [_vp]),
@@ -553,6 +554,12 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_operator_rowclass_flags(self.handle, level, which, C.byref(a), C.byref(b), C.byref(c),
                                                              C.byref(e)), "mg_operator_rowclass_flags")
         return int(c.value), int(e.value)
+
+    def graph_launches(self):
+        """(replays so far, graphs cached) of the HIP graphs the launch-bound coarse sub-cycles run as."""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        _check(self.lib, self.lib.mg_graph_launches(self.handle, C.byref(a), C.byref(b)), "mg_graph_launches")
+        return int(a.value), int(b.value)
 
     def cycle_bytes(self) -> float:
         v = C.c_double(0)

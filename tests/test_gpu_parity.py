@@ -751,3 +751,26 @@ def test_rowclass_lane_spmm_block_rhs(mg, built, monkeypatch, nrhs):
         mg.clear_(p)
     assert np.array_equal(runs["lane"], runs["lane-tiled"])           # scheduling changes nothing
     assert np.abs(runs["lane"] - runs["stream"]).max() <= 1e-12 * np.abs(runs["stream"]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cycle", ["V", "W", "F"])
+def test_coarse_subcycle_graph_replay(mg, built, cycle, monkeypatch):
+    """The launch-bound coarse sub-cycle is captured into a HIP graph on first use and replayed afterwards: the solve
+    must give the same iterates, bit for bit, as the same hierarchy with graphs switched off (same kernels, same
+    order), and the graph path must actually have run."""
+    res = {}
+    for no_graph in ("0", "1"):
+        monkeypatch.setenv("MG_NO_GRAPH", no_graph)
+        A, p, b = _setup(mg, [32, 32, 32], 4, cyc=cycle, maxIter=6)
+        x = np.zeros_like(b)
+        x, p, it = mg.solveMG(p, b, x)
+        launches, graphs = p.device.graph_launches()
+        if no_graph == "0":
+            assert launches >= it and graphs >= 1
+        else:
+            assert launches == 0 and graphs == 0
+        res[no_graph] = (x.copy(), list(p.resvec[: it + 1]))
+        mg.clear_(p)
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert res["0"][1] == res["1"][1]
