@@ -65,7 +65,7 @@ struct Options {
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
   long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
   long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
-  bool no_graph = false;
+  bool no_graph = false, no_lane_pairs = false;
   long long graph_max_rows = 300000;    // sub-cycles from the first level of at most this many rows*nrhs replay as one HIP graph
   long long lu_multi_min_rows = 4096;   // sparse coarse factors of this many rows: per-level launches + dense trailing inverse
   long long lu_dense_tail_min = 64;
@@ -93,7 +93,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
       MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
       MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
-      MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
+      MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_NO_LANE_PAIRS", "no_lane_pairs", 0, no_lane_pairs), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
       MG_OPT("MG_LU_MULTI_MIN_ROWS", "lu_multi_min_rows", 1, lu_multi_min_rows),
       MG_OPT("MG_LU_DENSE_TAIL_MAX", "lu_dense_tail_max", 1, lu_dense_tail_max),
       MG_OPT("MG_LU_DENSE_TAIL_MIN", "lu_dense_tail_min", 1, lu_dense_tail_min),
@@ -557,6 +557,13 @@ bool march_ok(const Csr& M, const mgk::VecArgs& v) {
 // phase: 0 = the whole product; 1 = every row that is in a dictionary class; 2 = the exception rows only (the sharded
 // cycle computes the rows that read the halo - forced exception rows - after the exchange has landed).  Operators that
 // are not stored as row classes compute everything in phase 2.
+// Lane SpMM: lanes per row.  Even nrhs: two columns (16 bytes) per lane, G = pow2 >= nrhs/2 lanes per row.
+static inline bool lane_mm_pairs(const Csr& M, long long nrhs) { return nrhs % 2 == 0 && !M.opt.no_lane_pairs; }
+static inline int lane_mm_group(const Csr& M, long long nrhs) { return lane_mm_pairs(M, nrhs) ? pow2_ge(nrhs / 2) : pow2_ge(nrhs); }
+static inline bool aligned16(const mgk::VecArgs& v) {
+  auto ok = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  return ok(v.x) && ok(v.y) && ok(v.b) && ok(v.xs);
+}
 template <int MODE>
 int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* nparts = nullptr,
                const mgk::ProDev* pro = nullptr, int phase = 0) {
@@ -672,14 +679,20 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
   } else if (v.nrhs == 1) {
     if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), v);
     else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), v);
-  } else if (M.rc_lane_mm() && M.ln_blocks > 0 && M.ln_rows == 2 * (mgk::BLK / pow2_ge(v.nrhs))) {
+  } else if (M.rc_lane_mm() && M.ln_blocks > 0 && M.ln_rows == 2 * (mgk::BLK / lane_mm_group(M, v.nrhs)) &&
+             (!lane_mm_pairs(M, v.nrhs) || aligned16(v))) {
     mgk::LaneDev T;
     T.ncls = (int)M.rc_ncls;
     T.nent = (int)M.rc_entries;
     T.maxlen = M.rc_maxlen;
     T.nblocks = M.ln_blocks;
-    hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm<MODE>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, pow2_ge(v.nrhs),
-                       M.has_sched_ln ? M.sched_ln.p : nullptr);
+    const int G = lane_mm_group(M, v.nrhs);
+    const int* sched = M.has_sched_ln ? M.sched_ln.p : nullptr;
+    if (nparts) *nparts = lane_mm_pairs(M, v.nrhs) ? M.ln_blocks : 0;   // (only the paired form writes ||out||^2 partials)
+    if (lane_mm_pairs(M, v.nrhs))   // two columns (16 bytes) per lane
+      hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm2<MODE>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
+    else
+      hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm<MODE>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
   } else {
     const int G = pow2_ge(v.nrhs);
     const dim3 grid_mm(M.nblocks_mm);
@@ -722,15 +735,48 @@ int k_sumsq(mg_hierarchy* h, const double* x, long long len);
 int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x, double* out,
                      double* xnext = nullptr, bool* xnext_done = nullptr, bool r_dead = false) {
   if (xnext_done) *xnext_done = false;
-  if (h->nrhs != 1 || (size_t)std::max(A.blocks1(), A.nblocks) > h->partial.n) {
-    MG_TRY(k_residual(h, level, A, b, x, out));
-    return k_sumsq(h, out, A.n_rows * h->nrhs);
-  }
   mgk::VecArgs v{};
   v.x = x;
   v.y = out;
   v.b = b;
-  v.nrhs = 1;
+  v.nrhs = (int)h->nrhs;
+  if (h->nrhs != 1) {
+    // block right-hand sides: the paired-column lane SpMM writes ||r||^2 partials and, optionally, x + d.*r
+    const bool fused = A.rc_lane_mm() && A.ln_blocks > 0 && lane_mm_pairs(A, h->nrhs) &&
+                       A.ln_rows == 2 * (mgk::BLK / lane_mm_group(A, h->nrhs)) && (size_t)A.ln_blocks <= h->partial.n;
+    mgk::VecArgs t = v;
+    t.xs = x;
+    if (xnext) t.y2 = xnext;
+    if (!fused || !aligned16(t) || (xnext && (reinterpret_cast<uintptr_t>(xnext) & 15u))) {
+      MG_TRY(k_residual(h, level, A, b, x, out));
+      return k_sumsq(h, out, A.n_rows * h->nrhs);
+    }
+    v.sumsq = h->partial.p;
+    if (xnext && out != x && xnext != x && h->relax_type == 0 && &A == &h->lev[(size_t)level].A && !h->opt.no_fused_next) {
+      v.y2 = xnext;
+      if (r_dead) v.y = nullptr;
+      v.xs = x;
+      v.d = v.d_full = h->lev[(size_t)level].d.p;
+      if (xnext_done) *xnext_done = true;
+    }
+    int nb1 = 0;
+    {
+      const double vec = 8.0 * (double)A.n_rows * (double)h->nrhs;
+      ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, h->nrhs, true, false) + ((v.y2 && v.y) ? vec : 0.0),
+                   moved_bytes(A, h->nrhs, true, false) - (v.y ? 0.0 : vec) + (v.y2 ? vec : 0.0));
+      MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v, &nb1));
+    }
+    ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
+    const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
+    hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
+    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
+    HIP_TRY(hipGetLastError());
+    return MG_OK;
+  }
+  if ((size_t)std::max(A.blocks1(), A.nblocks) > h->partial.n) {
+    MG_TRY(k_residual(h, level, A, b, x, out));
+    return k_sumsq(h, out, A.n_rows * h->nrhs);
+  }
   v.sumsq = h->partial.p;
   // the LDS-staged row-class kernels (march, tile) have x, r and the class's relaxPrec at hand: second output
   if (xnext && A.has_rc && (A.rc_tile || march_ok(A, v)) && A.rc_nexc == 0 && out != x && xnext != x && h->relax_type == 0 &&
@@ -2111,7 +2157,7 @@ int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
   M.ln_rows = M.ln_blocks = 0;
   M.has_sched_ln = false;
   if (nrhs > 1 && M.set && M.rc_lane_mm()) {   // uniform row blocks of the lane SpMM for this nrhs
-    M.ln_rows = 2 * (mgk::BLK / pow2_ge(nrhs));
+    M.ln_rows = 2 * (mgk::BLK / lane_mm_group(M, nrhs));
     M.ln_blocks = (int)((M.n_rows + M.ln_rows - 1) / M.ln_rows);
     std::vector<int> blk((size_t)M.ln_blocks + 1);
     for (int b = 0; b <= M.ln_blocks; ++b) blk[(size_t)b] = (int)std::min<long long>((long long)b * M.ln_rows, M.n_rows);
@@ -2190,6 +2236,10 @@ int alloc_scratch(mg_hierarchy* h) {
       MG_TRY(L.kZ.alloc(len * 2));
       MG_TRY(L.kAZ.alloc(len * 2));
     }
+  }
+  {  // the fused residual+norm writes one partial per row block
+    const size_t need = (size_t)std::max(h->lev[0].A.nblocks, h->lev[0].A.ln_blocks);
+    if (need > h->partial.n) MG_TRY(h->partial.alloc(need));
   }
   // host-pointer API staging (fine level) + transpose scratch (any level, for mg_spmv)
   MG_TRY(h->stage_b.alloc((size_t)nmax * k));
@@ -3177,8 +3227,7 @@ int mg_finalize(mg_hierarchy* h) {
     return fail(MG_ERR_INVALID, "coarse inverse order %lld != coarsest level size %lld", h->n_coarse, h->lev[nl - 1].n);
   for (int l = 0; l < nl - 1; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));
   MG_TRY(alloc_scratch(h));
-  if ((size_t)h->lev[0].A.nblocks > h->partial.n)  // the fused residual+norm writes one partial per row block
-    MG_TRY(h->partial.alloc((size_t)h->lev[0].A.nblocks));
+
   h->finalized = true;
   return MG_OK;
 }
