@@ -321,6 +321,11 @@ def kernel_symbol(h, mg, p, l, nrhs):
     D = mg.device
     ntl = "true" if 12.0 * p.As[l - 1].nnz > 128.0e6 else "false"
     if nrhs > 1:
+        var, _ = h.operator_kernel_info(l, D.MG_OP_A)
+        if var == 6:
+            return "mgk::csr_rowclass_lane_spmm2<2>", "row classes (block right-hand sides, two columns per lane)"
+        if var == 5:
+            return "mgk::csr_rowclass_lane_spmm<2>", "row classes (block right-hand sides)"
         return f"mgk::csr_stream_spmm<2, {ntl}>", "plain CSR (block right-hand sides)"
     rc = h.operator_rowclasses(l, D.MG_OP_A)
     if rc[0] > 0:

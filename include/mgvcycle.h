@@ -267,7 +267,10 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
  * serves the operator at nrhs == 1: -1 none (streaming formats), 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv
  * (x staged in LDS per workgroup of consecutive rows), 2 csr_rowclass_tile_spmv (plane tiles from the grid hint),
  * 3 csr_rowclass_march_spmv (z-marching ring of slabs from the grid hint), 4 csr_rowclass_lane_spmv (every lane
- * walks its own row's class, dictionary in LDS: the default for operators that are not staged);
+ * walks its own row's class, dictionary in LDS: the default for operators that are not staged); with a block of
+ * right-hand sides (current nrhs > 1): 5 csr_rowclass_lane_spmm (one column per lane), 6 csr_rowclass_lane_spmm2 (even
+ * nrhs: two columns = 16 bytes per lane; its residual form also writes the ||r||^2 partials and x + d.*r), -1 the
+ * CSR-stream SpMM;
  * exception_rows = rows outside the dictionary classes (computed from the CSR arrays: in the last workgroup of the
  * row-class kernel when there are at most 256 of them - second template argument `true` - else by csr_rows_spmv). */
 int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which, long long* implicit_first,

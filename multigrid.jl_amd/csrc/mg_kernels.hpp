@@ -1589,6 +1589,10 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm(RowClassDev C, Vec
 // 16-byte load/store, a wavefront covers twice the rows, half the vector-memory instructions for the same bytes.
 // Measured on C5 (16 columns): the one-column form moves 1.02 x the compulsory bytes yet runs at 3.2 TB/s - it is bound
 // by the number of 8-byte-per-lane requests in flight, not by traffic.  G = pow2 >= nrhs/2 lanes per row.
+#ifndef MG_RL2_RPL
+#define MG_RL2_RPL 2
+#endif
+constexpr int RL2_RPL = MG_RL2_RPL;   // rows per lane of csr_rowclass_lane_spmm2
 template <int MODE>
 __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, VecArgs v, LaneDev T, int G,
                                                                const int* __restrict__ sched) {
@@ -1598,7 +1602,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, Ve
   __shared__ double red[BLK / 64];
   const int tid = threadIdx.x;
   const int nrhs = v.nrhs;
-  const int rows_wg = 2 * (BLK / G);
+  const int rows_wg = RL2_RPL * (BLK / G);
   int bid = xcd_band(blockIdx.x, T.nblocks);
   if (sched) bid = sched[bid];
   for (int i = tid; i < T.nent; i += BLK) {
@@ -1612,13 +1616,13 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, Ve
   for (int i = tid; i < T.ncls; i += BLK) delta[i] = C.firstcol ? 0 : C.cls_delta[i];
   const int grp = tid / G, c = tid - grp * G;      // c: column PAIR
   const bool cact = 2 * c < nrhs;
-  int row[2], s[2], len[2];
-  const double* xb[2];
-  double2 pb[2], px[2], acc[2];
-  double pd[2];
-  bool live[2];
+  int row[RL2_RPL], s[RL2_RPL], len[RL2_RPL];
+  const double* xb[RL2_RPL];
+  double2 pb[RL2_RPL], px[RL2_RPL], acc[RL2_RPL];
+  double pd[RL2_RPL];
+  bool live[RL2_RPL];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < RL2_RPL; ++j) {
     row[j] = bid * rows_wg + j * (BLK / G) + grp;
     const bool in = row[j] < C.n_rows && cact;
     const int rr = row[j] < C.n_rows ? row[j] : C.n_rows - 1;
@@ -1645,17 +1649,17 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, Ve
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < RL2_RPL; ++j) {
     const int cq = s[j];
     s[j] = ptr[cq];
     len[j] = live[j] ? ptr[cq + 1] - s[j] : 0;
     xb[j] += (long long)delta[cq] * nrhs;
   }
   for (int k = 0; k < T.maxlen; k += 4) {
-    double2 g[2][4];
-    int id[2][4];
+    double2 g[RL2_RPL][4];
+    int id[RL2_RPL][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < RL2_RPL; ++j)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         id[j][u] = s[j] + min(k + u, len[j] > 0 ? len[j] - 1 : 0);
@@ -1663,7 +1667,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, Ve
                                    : make_double2(0.0, 0.0);
       }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < RL2_RPL; ++j)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const double a = ent[id[j][u]].val;
@@ -1675,7 +1679,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, Ve
   }
   double sq = 0.0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < RL2_RPL; ++j)
     if (live[j]) {
       double2 out;
       out.x = epilogue<MODE>(v, row[j], acc[j].x, pb[j].x, pd[j], px[j].x);

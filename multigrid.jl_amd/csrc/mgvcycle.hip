@@ -468,7 +468,7 @@ double spmv_bytes(const Csr& M, long long nrhs, bool reads_y_or_b, bool smooth) 
 
 // Matrix-side bytes one launch of the kernel IN USE streams for M (the device format chosen at upload).
 double format_bytes(const Csr& M, long long nrhs) {
-  if (nrhs == 1 && M.has_rc)
+  if (M.has_rc && (nrhs == 1 || (M.rc_lane_mm() && M.ln_blocks > 0)))   // (block right-hand sides: the lane SpMM)
     return (M.rc_implicit ? 2.0 : 6.0) * (double)M.n_rows + 12.0 * (double)M.rc_entries;
   if (nrhs == 1 && M.has_pat)
     return 8.0 * (double)M.nnz + 4.0 * (double)M.dict_entries +
@@ -560,6 +560,7 @@ bool march_ok(const Csr& M, const mgk::VecArgs& v) {
 // Lane SpMM: lanes per row.  Even nrhs: two columns (16 bytes) per lane, G = pow2 >= nrhs/2 lanes per row.
 static inline bool lane_mm_pairs(const Csr& M, long long nrhs) { return nrhs % 2 == 0 && !M.opt.no_lane_pairs; }
 static inline int lane_mm_group(const Csr& M, long long nrhs) { return lane_mm_pairs(M, nrhs) ? pow2_ge(nrhs / 2) : pow2_ge(nrhs); }
+static inline int lane_mm_rpl(const Csr& M, long long nrhs) { return lane_mm_pairs(M, nrhs) ? mgk::RL2_RPL : 2; }
 static inline bool aligned16(const mgk::VecArgs& v) {
   auto ok = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   return ok(v.x) && ok(v.y) && ok(v.b) && ok(v.xs);
@@ -679,7 +680,7 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
   } else if (v.nrhs == 1) {
     if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), v);
     else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), v);
-  } else if (M.rc_lane_mm() && M.ln_blocks > 0 && M.ln_rows == 2 * (mgk::BLK / lane_mm_group(M, v.nrhs)) &&
+  } else if (M.rc_lane_mm() && M.ln_blocks > 0 && M.ln_rows == lane_mm_rpl(M, v.nrhs) * (mgk::BLK / lane_mm_group(M, v.nrhs)) &&
              (!lane_mm_pairs(M, v.nrhs) || aligned16(v))) {
     mgk::LaneDev T;
     T.ncls = (int)M.rc_ncls;
@@ -743,7 +744,7 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
   if (h->nrhs != 1) {
     // block right-hand sides: the paired-column lane SpMM writes ||r||^2 partials and, optionally, x + d.*r
     const bool fused = A.rc_lane_mm() && A.ln_blocks > 0 && lane_mm_pairs(A, h->nrhs) &&
-                       A.ln_rows == 2 * (mgk::BLK / lane_mm_group(A, h->nrhs)) && (size_t)A.ln_blocks <= h->partial.n;
+                       A.ln_rows == lane_mm_rpl(A, h->nrhs) * (mgk::BLK / lane_mm_group(A, h->nrhs)) && (size_t)A.ln_blocks <= h->partial.n;
     mgk::VecArgs t = v;
     t.xs = x;
     if (xnext) t.y2 = xnext;
@@ -2157,7 +2158,7 @@ int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
   M.ln_rows = M.ln_blocks = 0;
   M.has_sched_ln = false;
   if (nrhs > 1 && M.set && M.rc_lane_mm()) {   // uniform row blocks of the lane SpMM for this nrhs
-    M.ln_rows = 2 * (mgk::BLK / lane_mm_group(M, nrhs));
+    M.ln_rows = lane_mm_rpl(M, nrhs) * (mgk::BLK / lane_mm_group(M, nrhs));
     M.ln_blocks = (int)((M.n_rows + M.ln_rows - 1) / M.ln_rows);
     std::vector<int> blk((size_t)M.ln_blocks + 1);
     for (int b = 0; b <= M.ln_blocks; ++b) blk[(size_t)b] = (int)std::min<long long>((long long)b * M.ln_rows, M.n_rows);
@@ -3719,7 +3720,12 @@ int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which
   if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
   if (implicit_first) *implicit_first = (M->has_rc && M->rc_implicit) ? 1 : 0;
   if (class_relax) *class_relax = (M->has_rc && M->rc_has_d) ? 1 : 0;
-  if (kernel_variant) *kernel_variant = !M->has_rc ? -1 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : M->rc_lane() ? 4 : 0;
+  if (kernel_variant) {
+    if (h->nrhs > 1)   // block right-hand sides: 5 csr_rowclass_lane_spmm, 6 csr_rowclass_lane_spmm2, else the CSR stream
+      *kernel_variant = (M->has_rc && M->rc_lane_mm() && M->ln_blocks > 0) ? (lane_mm_pairs(*M, h->nrhs) ? 6 : 5) : -1;
+    else
+      *kernel_variant = !M->has_rc ? -1 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : M->rc_lane() ? 4 : 0;
+  }
   if (exception_rows) *exception_rows = M->has_rc ? M->rc_nexc : 0;
   return MG_OK;
 }
