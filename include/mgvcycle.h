@@ -351,6 +351,24 @@ int mg_kaczmarz_apply_dev_FP64(mg_kaczmarz* k, double* x_dev, const double* b_de
                                long long sequential);
 int mg_kaczmarz_destroy(mg_kaczmarz* k);
 
+/* ---- stand-alone sparse-factor applier -----------------------------------------------------------------------------
+ * Device counterpart of applyLUsolve_FP64_INT64 (deps/src/parLU.cpp:52-63; ccall parallelJuliaSolver.jl:214-217): the
+ * "Julia factors, native applies" back end 3 of src/ParallelJuliaSolver.  Factors exactly as setupLUFactor leaves them
+ * (parallelJuliaSolver.jl:113-148): L and U in CSR with 1-based Int64 indices, L's diagonal LAST and U's diagonal FIRST
+ * in every row, row scaling folded into L, p / q 1-based with A[p,q] = L*U.  solve: x[q] = U \ (L \ b[p])
+ * (parLU.cpp:120-190); doTranspose != 0: the system with the transposed matrix, x[p] = L' \ (U' \ b[q])
+ * (parLU.cpp:194-260) - the transposed factors are built and uploaded on first use.  b, x: n x nrhs column-major on
+ * the host (b is left untouched: the reference uses it as work space), or row-major [n][nrhs] in HBM for the _dev
+ * form.  All right-hand sides travel together (the reference: one OpenMP task per column). */
+typedef struct mg_lu mg_lu;
+int mg_lu_create_FP64_INT64(long long device_id, long long n, const long long* Lptr, const long long* Lcol,
+                            const double* Lval, const long long* Uptr, const long long* Ucol, const double* Uval,
+                            const long long* p, const long long* q, mg_lu** out);
+int mg_lu_solve_FP64(mg_lu* f, const double* b, double* x, long long n, long long nrhs, long long doTranspose);
+int mg_lu_solve_dev_FP64(mg_lu* f, const double* b_dev, double* x_dev, long long n, long long nrhs,
+                         long long doTranspose);
+int mg_lu_destroy(mg_lu* f);
+
 /* ---- native multi-GPU sequencer (one process per GPU) ---------------------------------------------------------
  * The sharded cycle of src/DomainDecomposition's partition (box rule DDIndices.jl:41-47, numbering DDService.jl:27-48;
  * worker map analogue DDParallel.jl:105,133-139) behind the C ABI: the host cuts every sharded level into local

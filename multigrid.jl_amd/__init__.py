@@ -23,3 +23,6 @@ from .dd_indices import (getIndicesOfCellsArray, getNodalIndicesOfCell, getOrigi
 from . import device
 
 __all__ = [n for n in dir() if not n.startswith("_")]
+
+# src/ParallelJuliaSolver is a sub-module of the reference package too (Multigrid.ParallelJuliaSolver)
+from . import parallel_julia_solver as ParallelJuliaSolver

@@ -1723,6 +1723,14 @@ __global__ __launch_bounds__(BLK) void dscale_kernel(const double* __restrict__ 
       reinterpret_cast<double2*>(x)[i] = make_double2(dd.x * bb.x, dd.y * bb.y);
     }
     if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[total - 1] = d[total - 1] * b[total - 1];
+  } else if ((nrhs & 1) == 0 && total < (1LL << 31) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(b)) & 15u) == 0) {
+    // even nrhs: 16 bytes per lane, 32-bit row arithmetic
+    const unsigned n2 = (unsigned)(total >> 1), h = (unsigned)nrhs >> 1;
+    for (unsigned i = blockIdx.x * BLK + threadIdx.x; i < n2; i += (unsigned)stride) {
+      const double dd = d[i / h];
+      const double2 bb = reinterpret_cast<const double2*>(b)[i];
+      reinterpret_cast<double2*>(x)[i] = make_double2(dd * bb.x, dd * bb.y);
+    }
   } else {
     for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < total; i += stride)
       x[i] = d[i / nrhs] * b[i];
@@ -1747,6 +1755,16 @@ __global__ __launch_bounds__(BLK) void xpdr_kernel(const double* __restrict__ x,
     }
     if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0)
       xout[total - 1] = x[total - 1] + d[total - 1] * r[total - 1];
+  } else if ((nrhs & 1) == 0 && total < (1LL << 31) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(r) |
+                                                        reinterpret_cast<uintptr_t>(xout)) & 15u) == 0) {
+    // even nrhs: 16 bytes per lane, 32-bit row arithmetic
+    const unsigned n2 = (unsigned)(total >> 1), h = (unsigned)nrhs >> 1;
+    for (unsigned i = blockIdx.x * BLK + threadIdx.x; i < n2; i += (unsigned)stride) {
+      const double dd = d[i / h];
+      const double2 xx = reinterpret_cast<const double2*>(x)[i];
+      const double2 rr = reinterpret_cast<const double2*>(r)[i];
+      reinterpret_cast<double2*>(xout)[i] = make_double2(xx.x + dd * rr.x, xx.y + dd * rr.y);
+    }
   } else {
     for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < total; i += stride)
       xout[i] = x[i] + d[i / nrhs] * r[i];

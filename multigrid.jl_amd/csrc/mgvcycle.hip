@@ -64,6 +64,7 @@ struct Options {
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
   long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
+  long long march_wg_per_cu = 2;   // resident workgroups per CU of the marching kernel (49 KB of LDS each)
   long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
   bool no_graph = false, no_lane_pairs = false;
   long long graph_max_rows = 300000;    // sub-cycles from the first level of at most this many rows*nrhs replay as one HIP graph
@@ -93,6 +94,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
       MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
       MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
+      MG_OPT("MG_MARCH_WG_PER_CU", "march_wg_per_cu", 1, march_wg_per_cu),
       MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_NO_LANE_PAIRS", "no_lane_pairs", 0, no_lane_pairs), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
       MG_OPT("MG_LU_MULTI_MIN_ROWS", "lu_multi_min_rows", 1, lu_multi_min_rows),
       MG_OPT("MG_LU_DENSE_TAIL_MAX", "lu_dense_tail_max", 1, lu_dense_tail_max),
@@ -411,6 +413,7 @@ struct mg_hierarchy {
   DevBuf<int> luLslot, luUslot;   // per level slot {row, first, end of the off-diagonal entries, diagonal entry}
   int luML = 0, luMU = 0;
   bool lu_multi = false;
+  bool lu_only = false;     // a stand-alone factor applier (mg_lu_*): one "level" that consists of the coarsest solve only
   // launch-bound coarse sub-cycles replay as HIP graphs (captured on first use; keyed by level, buffers and cycle)
   struct GraphKey {
     int level; bool x_zero; char ctype; const void* b; const void* xa; const void* xb;
@@ -2140,7 +2143,7 @@ int build_march(Csr& A, const long long grid[3]) {
   int dev = 0, ncu = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const long long nb = std::max<long long>(1, std::min<long long>(2LL * ncu, items / 8));
+  const long long nb = std::max<long long>(1, std::min<long long>(A.opt.march_wg_per_cu * ncu, items / 8));
   if (nb < A.opt.march_min_wg) return MG_OK;   // small levels: latency-bound, the other kernels serve them
   MG_TRY(A.rm_lb.alloc(lbs.size()));
   HIP_TRY(hipMemcpy(A.rm_lb.p, lbs.data(), lbs.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -3206,6 +3209,10 @@ int mg_finalize(mg_hierarchy* h) {
   const int nl = (int)h->nlevels;
   for (int l = 0; l < nl; ++l) {
     Level& L = h->lev[l];
+    if (h->lu_only && nl == 1 && !L.A.set) {   // mg_lu_*: no operator, only the factors
+      L.n = h->n_coarse;
+      continue;
+    }
     if (!L.A.set) return fail(MG_ERR_STATE, "As[%d] was not set", l + 1);
     if (L.A.n_rows != L.A.n_cols) return fail(MG_ERR_INVALID, "As[%d] is not square", l + 1);
     L.n = L.A.n_rows;
@@ -3537,6 +3544,133 @@ int mg_cycle_mixed_FP32(mg_hierarchy* h, const float* b32, float* z32, long long
 
 // Page-lock a long-lived host array (param.memCycle[1].x, the caller's b) so that the host-pointer entry points move it
 // at full PCIe rate: the CALLER owns the lifetime - unregister before the array is freed or resized.
+// ---- stand-alone sparse-factor applier: the device counterpart of the reference's parallelJuliaSolver backend 3 --------
+// applyLUsolve_FP64_INT64 (deps/src/parLU.cpp:52-63): x[q] = U \ (L \ b[p]) (l.120-190) and, with doTranspose, the
+// solve with the transposed matrix x[p] = L' \ (U' \ b[q]) (l.194-260), one right-hand side per OpenMP task there.
+// Here: the factors live in HBM in the form of the coarsest solve (level-scheduled, chip-wide for large factors); the
+// transposed solve uses the transposed factors (U' is lower triangular with its diagonal last, L' upper with its
+// diagonal first, the permutations swap roles), built on first use.
+struct mg_lu {
+  int device = 0;
+  long long n = 0;
+  std::vector<long long> Lptr, Lcol, Uptr, Ucol, p, q;
+  std::vector<double> Lval, Uval;
+  mg_hierarchy* fwd = nullptr;
+  mg_hierarchy* trans = nullptr;
+};
+namespace {
+// CSR (1-based) of the transpose of an n x n CSR (1-based) matrix; columns of every row come out ascending
+void transpose_csr1(long long n, const std::vector<long long>& ptr, const std::vector<long long>& col, const std::vector<double>& val,
+                    std::vector<long long>& tp, std::vector<long long>& tc, std::vector<double>& tv) {
+  const size_t nnz = col.size();
+  tp.assign((size_t)n + 1, 0);
+  tc.resize(nnz);
+  tv.resize(nnz);
+  for (size_t k = 0; k < nnz; ++k) tp[(size_t)col[k]]++;            // count of column c at index c (1-based) -> shifted prefix
+  long long run = 1;
+  for (long long c = 0; c < n; ++c) {
+    const long long cnt = tp[(size_t)c + 1];
+    tp[(size_t)c] = run;
+    run += cnt;
+  }
+  tp[(size_t)n] = run;
+  std::vector<long long> pos(tp.begin(), tp.end() - 1);
+  for (long long r = 0; r < n; ++r)
+    for (long long k = ptr[(size_t)r] - 1; k < ptr[(size_t)r + 1] - 1; ++k) {
+      const long long c = col[(size_t)k] - 1;
+      const long long w = pos[(size_t)c]++ - 1;
+      tc[(size_t)w] = r + 1;
+      tv[(size_t)w] = val[(size_t)k];
+    }
+}
+int lu_hierarchy(mg_lu* f, bool transposed, mg_hierarchy** out) {
+  mg_hierarchy*& h = transposed ? f->trans : f->fwd;
+  if (!h) {
+    MG_TRY(mg_create(1, 1, f->device, &h));
+    h->lu_only = true;
+    int rc;
+    if (!transposed) {
+      rc = mg_set_coarse_lu_FP64_INT64(h, f->n, f->Lptr.data(), f->Lcol.data(), f->Lval.data(), f->Uptr.data(), f->Ucol.data(),
+                                       f->Uval.data(), f->p.data(), f->q.data());
+    } else {
+      std::vector<long long> lp, lc, up, uc;
+      std::vector<double> lv, uv;
+      transpose_csr1(f->n, f->Uptr, f->Ucol, f->Uval, lp, lc, lv);   // U' : lower triangular, diagonal last
+      transpose_csr1(f->n, f->Lptr, f->Lcol, f->Lval, up, uc, uv);   // L' : upper triangular, diagonal first
+      rc = mg_set_coarse_lu_FP64_INT64(h, f->n, lp.data(), lc.data(), lv.data(), up.data(), uc.data(), uv.data(), f->q.data(),
+                                       f->p.data());
+    }
+    if (rc == MG_OK) rc = mg_finalize(h);
+    if (rc != MG_OK) {
+      mg_destroy(h);
+      h = nullptr;
+      return rc;
+    }
+  }
+  *out = h;
+  return MG_OK;
+}
+}  // namespace
+
+int mg_lu_create_FP64_INT64(long long device_id, long long n, const long long* Lptr, const long long* Lcol, const double* Lval,
+                            const long long* Uptr, const long long* Ucol, const double* Uval, const long long* p,
+                            const long long* q, mg_lu** out) {
+  if (!out) return fail(MG_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (n < 1 || !Lptr || !Lcol || !Lval || !Uptr || !Ucol || !Uval || !p || !q) return fail(MG_ERR_INVALID, "null or empty factor");
+  if (Lptr[0] != 1 || Uptr[0] != 1 || Lptr[n] < 1 || Uptr[n] < 1) return fail(MG_ERR_INVALID, "row pointers must be 1-based");
+  mg_lu* f = new mg_lu();
+  f->device = (int)device_id;
+  f->n = n;
+  f->Lptr.assign(Lptr, Lptr + n + 1);
+  f->Uptr.assign(Uptr, Uptr + n + 1);
+  f->Lcol.assign(Lcol, Lcol + (Lptr[n] - 1));
+  f->Lval.assign(Lval, Lval + (Lptr[n] - 1));
+  f->Ucol.assign(Ucol, Ucol + (Uptr[n] - 1));
+  f->Uval.assign(Uval, Uval + (Uptr[n] - 1));
+  f->p.assign(p, p + n);
+  f->q.assign(q, q + n);
+  mg_hierarchy* h = nullptr;
+  const int rc = lu_hierarchy(f, false, &h);   // validates and uploads the factors
+  if (rc != MG_OK) {
+    delete f;
+    return rc;
+  }
+  *out = f;
+  return MG_OK;
+}
+
+// b, x: host, n x nrhs column-major (a Julia Array{Float64,2} or Vector); b is NOT used as work space (the reference
+// overwrites it, parLU.cpp:176)
+int mg_lu_solve_FP64(mg_lu* f, const double* b, double* x, long long n, long long nrhs, long long doTranspose) {
+  if (!f) return fail(MG_ERR_INVALID, "null factor handle");
+  if (n != f->n) return fail(MG_ERR_INVALID, "n=%lld but the factors have order %lld", n, f->n);
+  if (nrhs < 1 || !b || !x) return fail(MG_ERR_INVALID, "bad argument");
+  mg_hierarchy* h = nullptr;
+  MG_TRY(lu_hierarchy(f, doTranspose != 0, &h));
+  MG_TRY(mg_set_nrhs(h, nrhs));
+  return mg_cycle_FP64(h, b, x, n, nrhs, 1);
+}
+
+// device-resident form: b_dev, x_dev row-major [n][nrhs] in HBM
+int mg_lu_solve_dev_FP64(mg_lu* f, const double* b_dev, double* x_dev, long long n, long long nrhs, long long doTranspose) {
+  if (!f) return fail(MG_ERR_INVALID, "null factor handle");
+  if (n != f->n) return fail(MG_ERR_INVALID, "n=%lld but the factors have order %lld", n, f->n);
+  if (nrhs < 1 || !b_dev || !x_dev) return fail(MG_ERR_INVALID, "bad argument");
+  mg_hierarchy* h = nullptr;
+  MG_TRY(lu_hierarchy(f, doTranspose != 0, &h));
+  MG_TRY(mg_set_nrhs(h, nrhs));
+  return mg_cycle_dev_FP64(h, b_dev, x_dev, n, nrhs, 1);
+}
+
+int mg_lu_destroy(mg_lu* f) {
+  if (!f) return MG_OK;
+  if (f->fwd) mg_destroy(f->fwd);
+  if (f->trans) mg_destroy(f->trans);
+  delete f;
+  return MG_OK;
+}
+
 int mg_host_register(void* ptr, long long bytes) {
   if (!ptr || bytes < 1) return fail(MG_ERR_INVALID, "null pointer or empty range");
   HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));

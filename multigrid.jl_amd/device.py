@@ -99,6 +99,10 @@ SIGNATURES = {
     "mg_vec_sumsq_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp]),
     "mg_set_stream": (C.c_int, [_vp, _vp]),
     "mg_cycle_async_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
+    "mg_lu_create_FP64_INT64": (C.c_int, [_ll, _ll, _lp, _lp, _dp, _lp, _lp, _dp, _lp, _lp, C.POINTER(_vp)]),
+    "mg_lu_solve_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, _ll]),
+    "mg_lu_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),
+    "mg_lu_destroy": (C.c_int, [_vp]),
     "mg_kaczmarz_create_FP64_INT64": (C.c_int, [_ll, _ll, _lp, _dp, _lp, _ll, _ll, C.POINTER(C.c_uint), _dp, C.POINTER(_vp)]),
     "mg_kaczmarz_apply_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, _ll]),
     "mg_kaczmarz_apply_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, _ll]),

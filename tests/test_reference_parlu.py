@@ -22,7 +22,7 @@ _i64p = C.POINTER(C.c_longlong)
 _f64p = C.POINTER(C.c_double)
 
 
-def _ref_lu_solve(lu, B):
+def _ref_lu_solve(lu, B, doTranspose=0):
     """Call the reference's applyLUsolve_FP64_INT64 with SuperLU's factors in the layout setupLUFactor produces
     (parallelJuliaSolver.jl:113-148, convertCSC2MyCSR)."""
     lib = C.CDLL(REF)
@@ -50,8 +50,37 @@ def _ref_lu_solve(lu, B):
     Bw = B.copy(order="F")                                      # the reference uses b as workspace
     P = lambda a: a.ctypes.data_as(_i64p)
     F = lambda a: a.ctypes.data_as(_f64p)
-    f(P(Lp), F(Lv), P(Lc), P(Up), F(Uv), P(Uc), P(p), P(q), P(nn), P(nnz), F(X), F(Bw), 1, nrhs, 1, 1, 0)
+    f(P(Lp), F(Lv), P(Lc), P(Up), F(Uv), P(Uc), P(p), P(q), P(nn), P(nnz), F(X), F(Bw), 1, nrhs, 1, 1, int(doTranspose))
     return X
+
+
+def _nonsymmetric(mg, n, seed):
+    """G'*m*G of testParallelJuliaSolver.jl:13-21 plus an unsymmetric sparse perturbation (the transposed solve is
+    only a test when A != A')."""
+    rng = np.random.default_rng(seed)
+    Mr = mg.getRegularMesh([0.0, 1.0, 0.0, 1.0], n)
+    G = mg.getNodalGradientMatrix(Mr)
+    m = sp.diags(np.exp(rng.standard_normal(G.shape[0])))
+    Ar = (G.T @ m @ G).tocsc()
+    Ar = Ar + 1e-1 * np.abs(Ar).sum(axis=0).max() * sp.identity(Ar.shape[1])
+    E = sp.random(Ar.shape[0], Ar.shape[1], density=3.0 / Ar.shape[0], random_state=seed, format="csc")
+    return (Ar + 0.05 * np.abs(Ar).max() * E).tocsc()
+
+
+@pytest.mark.parametrize("nrhs", [1, 5])
+def test_transposed_solve_of_the_reference_binary(mg, built, nrhs):
+    """doTranspose = 1 (parLU.cpp:194-260): x[p] = L' \\ (U' \\ b[q]) solves A' x = b.  Pins the layout the device
+    applier's transposed factors are derived from (mg_lu_solve_FP64)."""
+    import scipy.sparse.linalg as spla
+    A = _nonsymmetric(mg, [20, 23], 7)
+    lu = spla.splu(A, permc_spec="MMD_AT_PLUS_A")
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((A.shape[0], nrhs)) if nrhs > 1 else rng.standard_normal(A.shape[0])
+    X0 = _ref_lu_solve(lu, B, 0)
+    X1 = _ref_lu_solve(lu, B, 1)
+    assert np.abs(A @ X0 - B).max() <= 1e-10 * np.abs(B).max()
+    assert np.abs(A.T @ X1 - B).max() <= 1e-10 * np.abs(B).max()
+    assert np.abs(X1 - lu.solve(B, trans="T")).max() <= 1e-12 * np.abs(X1).max()
 
 
 @pytest.mark.parametrize("cells,levels,nrhs", [([16, 16, 16], 3, 1), ([32, 32], 4, 3)])
