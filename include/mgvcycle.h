@@ -295,6 +295,13 @@ int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_c
 int mg_op_create_box_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
                                 const long long* rowval, const double* nzval, long long n1, long long n2, long long n3,
                                 long long regular_cols, mg_operator** out);
+/* Announce the relaxPrec vector (device; one entry per row, for a box operator per owned row) the operator will be
+ * swept with.  Where it is bit-identical over every dictionary class of a row-class operator, the fused sweeps and the
+ * fused residual called with THIS pointer (nrhs = 1, row_offset = 0) read it from the dictionary instead of streaming
+ * 8 B/row - what mg_finalize does for the levels of a hierarchy (class_relax of mg_operator_rowclass_flags).  Call again
+ * after the contents change.  mg_dist_finalize binds every level's vector itself. */
+int mg_op_bind_relax_dev_FP64(mg_operator* op, const double* d_dev, long long n);
+
 /* kernel variant serving the operator at nrhs == 1 (as mg_operator_rowclass_flags) and its exception rows */
 int mg_op_kernel_variant(mg_operator* op, long long* variant, long long* exception_rows);
 int mg_op_destroy(mg_operator* op);

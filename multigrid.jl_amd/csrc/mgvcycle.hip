@@ -66,6 +66,7 @@ struct Options {
   long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
   long long march_wg_per_cu = 2;   // resident workgroups per CU of the marching kernel (49 KB of LDS each)
   long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
+  bool dist_tail_graph = false;   // replay the replicated tail of the sharded sequencer as a HIP graph (measured slower)
   bool no_graph = false, no_lane_pairs = false;
   long long graph_max_rows = 300000;    // sub-cycles from the first level of at most this many rows*nrhs replay as one HIP graph
   long long lu_multi_min_rows = 4096;   // sparse coarse factors of this many rows: per-level launches + dense trailing inverse
@@ -95,7 +96,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
       MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
       MG_OPT("MG_MARCH_WG_PER_CU", "march_wg_per_cu", 1, march_wg_per_cu),
-      MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_NO_LANE_PAIRS", "no_lane_pairs", 0, no_lane_pairs), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
+      MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_DIST_TAIL_GRAPH", "dist_tail_graph", 0, dist_tail_graph), MG_OPT("MG_NO_LANE_PAIRS", "no_lane_pairs", 0, no_lane_pairs), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
       MG_OPT("MG_LU_MULTI_MIN_ROWS", "lu_multi_min_rows", 1, lu_multi_min_rows),
       MG_OPT("MG_LU_DENSE_TAIL_MAX", "lu_dense_tail_max", 1, lu_dense_tail_max),
       MG_OPT("MG_LU_DENSE_TAIL_MIN", "lu_dense_tail_min", 1, lu_dense_tail_min),
@@ -230,6 +231,7 @@ struct Csr {
     d.nblocks = nblocks_mm;
     return d;
   }
+  const double* d_bound = nullptr;   // the relaxPrec vector rc_d was derived from (mg_op_bind_relax_dev_FP64 / mg_finalize)
   bool rc_pair = false;     // plain row-class kernel with two consecutive rows per lane (alternating classes)
   // csr_rowclass_lane_spmv (every lane walks its own class, dictionary in LDS) replaces the waterfall kernel when the
   // dictionary fits
@@ -1213,6 +1215,9 @@ void graphs_clear(mg_hierarchy* h) {
 // decisions inside (Jac-GMRES smoothing, K-cycles, GMRES coarsest solve) and not while profiling (events per launch).
 bool graph_ok(const mg_hierarchy* h, int l, char ctype) {
   if (h->opt.no_graph || h->prof || h->capturing || h->relax_type == 1 || ctype == 'K' || h->coarse_gmres) return false;
+  // a caller's stream (mg_set_stream) may be the legacy null stream, which cannot capture, or be part of a capture of
+  // the caller's own: only the hierarchy's own stream is captured, unless the caller vouches for its stream (dist tail)
+  if (!h->stream || (!h->owns_stream && !h->opt.dist_tail_graph)) return false;
   if (h->lev[(size_t)l].n * h->nrhs > h->opt.graph_max_rows) return false;
   return (int)h->nlevels - l >= 2 || (h->coarse_lu && h->lu_multi);
 }
@@ -2612,14 +2617,17 @@ int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
   return build_rowclasses_try(M, rp, ci, val, false);
 }
 // relaxPrec constant per class (d = omega/a_ii and a_ii is part of the class): keep it in the dictionary
-int derive_class_d(Level& L) {
-  Csr& A = L.A;
+// relaxPrec constant over every dictionary class (omega / a_ii is, by construction): the fused sweep can read it from the
+// dictionary instead of streaming 8 B/row.  d_dev: device vector over the operator's regular rows.
+int derive_class_d_csr(Csr& A, const double* d_dev, size_t n_d) {
   A.rc_has_d = false;
-  if (!A.has_rc || A.h_cls.size() != (size_t)A.n_rows || L.d.n != (size_t)A.n_rows) return MG_OK;
+  A.d_bound = nullptr;
+  const size_t nreg = (size_t)(A.regular_cols >= 0 ? A.regular_cols : A.n_rows);
+  if (!A.has_rc || A.h_cls.size() != (size_t)A.n_rows || n_d != nreg || !d_dev) return MG_OK;
   if (A.opt.no_class_d) return MG_OK;
-  std::vector<double> hd((size_t)A.n_rows), dc((size_t)A.rc_ncls, 0.0);
+  std::vector<double> hd(nreg), dc((size_t)A.rc_ncls, 0.0);
   std::vector<char> seen((size_t)A.rc_ncls, 0);
-  HIP_TRY(hipMemcpy(hd.data(), L.d.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hd.data(), d_dev, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < hd.size(); ++i) {
     const unsigned short c = A.h_cls[i];
     if (c == 0xFFFF) continue;   // exception rows read d from memory (csr_rows_spmv, xpdr_cls_kernel)
@@ -2629,8 +2637,10 @@ int derive_class_d(Level& L) {
   MG_TRY(A.rc_d.alloc(dc.size()));
   HIP_TRY(hipMemcpy(A.rc_d.p, dc.data(), dc.size() * sizeof(double), hipMemcpyHostToDevice));
   A.rc_has_d = true;
+  A.d_bound = d_dev;
   return MG_OK;
 }
+int derive_class_d(Level& L) { return derive_class_d_csr(L.A, L.d.p, L.d.n); }
 // New values on the stored pattern (mg_replace_values_FP64, mg_rap_FP64): the classes are re-derived from the host
 // pattern kept for that purpose; an operator that is no longer redundant falls back to the streaming kernels.
 int refresh_rowclasses(Csr* M, const double* val) {
@@ -3975,6 +3985,17 @@ int mg_op_destroy(mg_operator* op) {
   return MG_OK;
 }
 
+// Announce the relaxPrec vector (device, one entry per regular row) this operator will be swept with: when it is
+// bit-identical over every dictionary class the fused sweeps called with THIS pointer read it from the dictionary
+// instead of streaming it.  Call again after the vector's contents change.
+int mg_op_bind_relax_dev_FP64(mg_operator* op, const double* d_dev, long long n) {
+  UploadFence upload_fence;
+  if (!op || !op->M.set || !d_dev || n < 1) return fail(MG_ERR_INVALID, "bad argument");
+  (void)hipSetDevice(op->device);
+  (void)hipDeviceSynchronize();   // d may have been written on another stream
+  return derive_class_d_csr(op->M, d_dev, (size_t)n);
+}
+
 int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
                          double* y, const double* b, const double* d, long long nrhs, void* stream) {
   return mg_op_apply_rows_dev_FP64(op, kernel, alpha, x, beta, y, b, d, nrhs, 0, stream);
@@ -4000,6 +4021,8 @@ int mg_op_apply_phase_dev_FP64(mg_operator* op, long long kernel, double alpha, 
   v.b = b ? b + row_offset * nrhs : nullptr;
   v.d = d ? d + row_offset : nullptr;
   v.d_full = v.d;
+  // relaxPrec bound to this operator and constant per class: read from the dictionary (2 B/row instead of 10)
+  if (d && nrhs == 1 && row_offset == 0 && op->M.has_rc && op->M.rc_has_d && d == op->M.d_bound) v.d = nullptr;
   v.alpha = alpha;
   v.beta = beta;
   v.nrhs = (int)nrhs;
@@ -4039,7 +4062,7 @@ int mg_op_residual_fused_dev_FP64(mg_operator* op, const double* x, const double
   const bool can_y2 = M.has_rc && (M.rc_tile || march_ok(M, v)) && xnext_dev && xnext_dev != x && !(phase == 0 && M.rc_nexc > 0);
   if (can_y2) {
     v.y2 = xnext_dev;
-    v.d = d;
+    v.d = (M.rc_has_d && d == M.d_bound) ? nullptr : d;
     v.d_full = d;
   } else if (!r_dev) {
     return fail(MG_ERR_INVALID, "this operator's kernel cannot produce xnext: pass r_dev");
@@ -4662,6 +4685,10 @@ int mg_dist_set_tail_INT64(mg_dist* h, mg_hierarchy* tail, long long n_tail, lon
   HIP_TRY(hipMemset(h->x_tail.p, 0, h->x_tail.bytes()));
   HIP_TRY(hipMemcpy(h->gather_index.p, gather_index, (size_t)n_tail * sizeof(long long), hipMemcpyHostToDevice));
   MG_TRY(mg_set_stream(tail, h->stream));
+  // Measured at world size 1 on 256^3 (bench.py --force-sharded-path): replaying the tail as a HIP graph between the
+  // all-gather and the prolongation costs 40-80 us per step (0.98 -> 1.02-1.06 ms) where the single-GPU cycle gains 23:
+  // off unless the tail's handle asks for it (mg_set_option(tail, "dist_tail_graph", 1) / MG_DIST_TAIL_GRAPH=1).
+  if (!tail->opt.dist_tail_graph) tail->opt.no_graph = true;
   h->finalized = false;
   return MG_OK;
 }
@@ -4671,6 +4698,12 @@ int mg_dist_finalize(mg_dist* h) {
   if (!h) return fail(MG_ERR_INVALID, "null handle");
   (void)hipSetDevice(h->device);
   if (!h->tail) return fail(MG_ERR_STATE, "the replicated tail was not set");
+  for (DistLevel& L : h->lev)   // relaxPrec from the class dictionary where the level's A allows it
+    if (L.A_int && L.d && L.A_int->M.has_rc) {
+      const long long nreg = L.A_int->M.regular_cols >= 0 ? L.A_int->M.regular_cols : L.A_int->M.n_rows;
+      (void)hipDeviceSynchronize();
+      MG_TRY(derive_class_d_csr(L.A_int->M, L.d, (size_t)nreg));
+    }
   if (h->world > 1 && !h->comm && !h->plug) return fail(MG_ERR_STATE, "no transport: pass an RCCL unique id to mg_dist_create or set an exchange plug-in");
   const int a = (int)h->lev.size();
   for (int l = 0; l < a; ++l) {

@@ -85,6 +85,7 @@ SIGNATURES = {
     "mg_device_bytes": (C.c_int, [_vp, _dp]),
     "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
     "mg_op_create_box_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, _ll, _ll, _ll, _ll, C.POINTER(_vp)]),
+    "mg_op_bind_relax_dev_FP64": (C.c_int, [_vp, _vp, _ll]),
     "mg_op_kernel_variant": (C.c_int, [_vp, _lp, _lp]),
     "mg_op_apply_phase_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _ll, _ll, _vp]),
     "mg_dist_set_level_box": (C.c_int, [_vp, _ll, _ll]),
@@ -601,6 +602,10 @@ class DeviceOperator:
             _check(self.lib, self.lib.mg_op_create_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),
                                                               _i64(rowval), _f64(nzval), C.byref(self.handle)),
                    "mg_op_create")
+
+    def bind_relax(self, d, n: int):
+        """The relaxPrec vector (CUDA tensor) this operator is swept with: read from the class dictionary where possible."""
+        _check(self.lib, self.lib.mg_op_bind_relax_dev_FP64(self.handle, _ptr(d), int(n)), "mg_op_bind_relax_dev")
 
     def kernel_variant(self):
         """(kernel variant as DeviceHierarchy.operator_kernel_variant, number of exception rows)."""

@@ -275,6 +275,10 @@ class HipBackend:
     def operator(self, M, box=None, regular_cols=None):
         return D.DeviceOperator(M, self.device_id, box=box, regular_cols=regular_cols)
 
+    def bind_relax(self, op, d, n):
+        self.synchronize()
+        op.bind_relax(d, n)
+
     def apply(self, op, kernel, x, y, b=None, d=None, alpha=1.0, beta=0.0, nrhs=1, row_offset=0, phase=0):
         op.apply(kernel, x, y, b, d, alpha, beta, nrhs, self.stream(), row_offset, phase)
 
@@ -445,6 +449,8 @@ class DistributedHierarchy:
             L.R, L.P = be.operator(ld["R"]), be.operator(ld["P"])
             L.nnzA, L.nnzR, L.nnzP = ld["A"].nnz, ld["R"].nnz, ld["P"].nnz
             L.d = be.from_numpy(np.asarray(ld["d"], dtype=np.float64))
+            if hasattr(be, "bind_relax") and L.A_int is not None:      # relaxPrec from the class dictionary where possible
+                be.bind_relax(L.A_int, L.d, L.n_own if L.box else L.n_int)
             L.npre = max(1, int(ld["npre"]))            # relax() always updates once (MGcycle.jl:127-134)
             L.npost = max(1, int(ld["npost"]))
             self.levels.append(L)
