@@ -3355,18 +3355,33 @@ int mg_fused_dev_FP64(mg_hierarchy* h, long long level, long long kernel, const 
 }
 
 // ---- host-buffer hot path (what the Julia glue ccalls) ------------------------------------------
+// x == 0 everywhere?  Blocks of 4096 entries are OR-reduced bitwise (vectorises; the element-wise loop with its early
+// exit does not: 13 ms for 136 MB on the box's core) and only a block with a set bit - a non-zero or a -0.0 - is
+// looked at entry by entry.
+static bool host_all_zero(const double* x, long long len) {
+  const long long B = 4096;
+  for (long long i0 = 0; i0 < len; i0 += B) {
+    const long long i1 = std::min(len, i0 + B);
+    unsigned long long acc = 0;
+    for (long long i = i0; i < i1; ++i) {
+      unsigned long long bits;
+      std::memcpy(&bits, x + i, 8);
+      acc |= bits;
+    }
+    if (acc != 0)
+      for (long long i = i0; i < i1; ++i)
+        if (x[i] != 0.0) return false;
+  }
+  return true;
+}
+
 int mg_cycle_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
                   long long x_is_zero) {
   MG_TRY(check_ready(h, n, nrhs));
   if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
   (void)hipSetDevice(h->device);
   bool xz = (x_is_zero == 1);
-  if (x_is_zero < 0) {
-    xz = true;
-    const long long len = n * nrhs;
-    for (long long i = 0; i < len; ++i)
-      if (x[i] != 0.0) { xz = false; break; }
-  }
+  if (x_is_zero < 0) xz = host_all_zero(x, n * nrhs);   // norm(x) > 0.0 decides (MGcycle.jl:29)
   MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
   if (!xz) MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
   MG_TRY(cycle_dev(h, h->stage_b.p, h->stage_x.p, xz));
