@@ -465,8 +465,19 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
         f"{len(H.levels)} sharded levels + replicated tail of {H.n_tail} rows; halo A1 {H.levels[0].planA.n_halo}; "
         f"sharded setup {t_setup:.1f}s")
     Hpy = H
+    native_note = None
     if not args.python_sequencer:      # the hot loop in C++ behind the C ABI (mg_dist_*), RCCL send/recv on a side stream
-        H = dd.NativeDistributedHierarchy(Hpy, transport="plugin" if share else "rccl")
+        ok = 1.0
+        try:
+            H = dd.NativeDistributedHierarchy(Hpy, transport="plugin" if share else "rccl")
+        except Exception as e:          # (every rank must take the same path: agree on the outcome below)
+            ok, native_note = 0.0, f"{type(e).__name__}: {e}"
+            log(f"[rank {rank}] native sequencer unavailable: {native_note}")
+        flag = torch.tensor([ok], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            H = Hpy
+            native_note = native_note or "another rank could not create the native sequencer"
 
     def barrier():
         torch.cuda.synchronize()
@@ -503,7 +514,8 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
                        "parallelism": f"DomainDecomposition boxes {domains}, {len(Hpy.levels)} sharded levels, replicated "
                                       f"tail from {Hpy.n_tail} rows, " +
                                       ("Python sequencer, one all_to_all_single halo exchange per SpMV (torch.distributed)"
-                                       if args.python_sequencer else
+                                       + (f" [native sequencer unavailable: {native_note}]" if native_note else "")
+                                       if (args.python_sequencer or native_note) else
                                        "native C++ sequencer (mg_dist_*): ncclSend/ncclRecv halo exchange per SpMV on a side "
                                        "stream overlapped with the interior rows, one scalar all-reduce per step") +
                                       ", sharded host setup"},
