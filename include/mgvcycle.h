@@ -59,7 +59,8 @@ typedef struct mg_hierarchy mg_hierarchy;
 #define MG_K_COARSE 6   /* xc = LU \ bc                    (MGcycle.jl:177)            */
 #define MG_K_NORM 7     /* ||r||^2                         (SolveFuncs.jl:30)          */
 #define MG_K_SMOOTH_PROLONG 8 /* x' = xp + d.*(b - A*xp), xp = x + P*xc: MGcycle.jl:90 fused into the first post-sweep */
-#define MG_K_COUNT 9
+#define MG_K_SMOOTH_RESIDUAL 9 /* t = x + d.*(b - A*x) and r = b - A*t in one pass (MGcycle.jl:129-131 + 58-60 / SolveFuncs.jl:26-27) */
+#define MG_K_COUNT 10
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 
@@ -235,6 +236,13 @@ int mg_spmv_dev_FP64(mg_hierarchy* h, long long level, long long which, double a
  *   MG_K_RESIDUAL: out = b - A*x ;  MG_K_SMOOTH: out = x + d.*(b - A*x)   (out must not alias x). */
 int mg_fused_dev_FP64(mg_hierarchy* h, long long level, long long kernel, const double* b_dev,
                       const double* x_dev, double* out_dev, long long nrhs);
+/* Two stages in one pass over level `level` (1-based, not the coarsest): t = x + d.*(b - A*x)  (relax's sweep,
+ * MGcycle.jl:129-131) and r = b - A*t (MGcycle.jl:58-60 / SolveFuncs.jl:26-27); optionally xn = t + d.*r (the next
+ * cycle's first update) and *norm_r = ||r|| (SolveFuncs.jl:30).  r_dev, xn_dev, norm_r may be NULL.  x, t, r, xn must be
+ * four different 16-byte aligned device buffers.  MG_ERR_UNSUPPORTED when the level is not served by the two-stage
+ * marching kernel (the cycle then runs the two launches). */
+int mg_sweep_residual_dev_FP64(mg_hierarchy* h, long long level, const double* b_dev, const double* x_dev,
+                               double* t_dev, double* r_dev, double* xn_dev, double* norm_r);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Launch kernel `kernel` of `level` `reps` times back to back on the library's stream between two

@@ -1380,6 +1380,311 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two stages per marching pass (temporal blocking): one damped-Jacobi sweep and the residual of its result,
+//   t = x + d.*(b - A x)  (MGcycle.jl:129-131)   and   r = b - A t  (MGcycle.jl:58-60 / SolveFuncs.jl:26-27),
+// in ONE walk along z - the last pre-smoothing sweep with the residual the restriction needs, and the last
+// post-smoothing sweep with the solve loop's residual (||r||^2 partials and the next cycle's first update t + d.*r).
+// Two launches of csr_rowclass_march_spmv move 2 x 26 B per row for that; this one moves 34 (x, b, class id in; t and r
+// - or t and t + d.*r - out).  The price is the halo: stage 2 of a chunk needs t on the chunk's in-plane halo, so stage
+// 1 is evaluated on RM_C + 2*halo rows per plane (x staged on RM_C + 4*halo), and on one extra plane at each end of a
+// run.  Ring of 4 slabs of x and 4 slabs of t in LDS, one barrier per plane, stage 2 two planes behind stage 1:
+//   iteration z:  x plane z+2 -> ring | stage 1 on plane z (x planes z-1..z+1 -> t plane z) | stage 2 on plane z-2
+//                 (t planes z-3..z-1) | barrier
+// Same dictionary walk, same products in the same order and the same epilogue expressions as the single-stage
+// kernels: t, r and t + d.*r are bit-identical to theirs.  Operators without exception rows whose relaxPrec is
+// constant per class (host: march2_ok); one workgroup per CU (125 KB of LDS), 128 VGPRs.
+// ------------------------------------------------------------------------------------------------
+#ifndef MG_M2X
+#define MG_M2X 0   // attribution builds: 1 / 2 / 4 = skip the class walk of stage 1 core / stage 1 halo / stage 2; 8 = no x loads
+#endif
+struct March2Args {
+  const double* x;   // the iterate before the sweep                    [n_rows]
+  const double* b;   //                                                 [n_rows]
+  double* t;         // out: x + d.*(b - A x)                           [n_rows]
+  double* r;         // out (optional): b - A t                         [n_rows]
+  double* xn;        // out (optional): t + d.*r                        [n_rows]
+  double* sumsq;     // out (optional): per-workgroup sums of r.^2      [nblocks]
+};
+
+constexpr int RM2_CLEN = 7;   // longest class whose records a lane keeps in registers
+
+template <int DUMMY>
+__global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev C, March2Args a, MarchDev T) {
+  extern __shared__ double win[];
+  __shared__ double red[RM_C / 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int w = xcd_band(blockIdx.x, T.nblocks);
+  const int H = T.halo;
+  const int SLX = RM_C + 4 * H;
+  const int SLXP = SLX + 2;                            // entry k of a slab = global entry g0 + k; the pair loads overhang by <= 1
+  const int SLTP = RM_C + 2 * H;
+  const int npair = (SLX + 2) >> 1;                    // 16-byte pairs per x slab (<= 2*RM_C: host check)
+  double* xw = win;                                    // [4][SLXP]  x planes, entry 0 = in-plane index c0 - 2H
+  double* tw = win + 4 * SLXP;                         // [4][SLTP]  t planes, entry 0 = in-plane index c0 - H
+  MarchEnt* dent = reinterpret_cast<MarchEnt*>(tw + 4 * SLTP);            // [RM_DCAP]
+  double* dd = reinterpret_cast<double*>(dent + RM_DCAP);                 // [RM_NCLS] class relaxPrec
+  int* dptr = reinterpret_cast<int*>(dd + RM_NCLS);                       // [RM_NCLS + 1]
+  for (int i = tid; i < T.nent; i += RM_C) {
+    MarchEnt e;
+    e.val = C.cls_val[i];
+    e.code = T.lb[i];
+    e.pad = 0;
+    dent[i] = e;
+  }
+  for (int i = tid; i <= T.ncls; i += RM_C) dptr[i] = C.cls_ptr[i];
+  for (int i = tid; i < T.ncls; i += RM_C) dd[i] = C.cls_d[i];
+  const long long tot = (long long)T.chunks * T.nplanes;
+  long long it = tot * w / T.nblocks;
+  const long long it_end = tot * (w + 1) / T.nblocks;
+  const bool pact0 = tid < npair, pact1 = tid + RM_C < npair;
+  const bool hact = tid < 2 * H;                       // lanes that also own a halo row of stage 1
+  const int hj = tid < H ? tid : (hact ? RM_C + tid : 0);   // that row's offset from c0 - H (core rows: tid + H)
+  const bool regs = T.maxlen <= RM2_CLEN;              // class records in registers (else: per-lane walk of the LDS dictionary)
+  const int SLX8 = SLXP * 8, SLT8 = SLTP * 8, TW8 = 4 * SLXP * 8;
+  double sq = 0.0;
+
+  // x slab of plane p of chunk c: global entries g0 = p*P + c*RM_C - 2H onwards; loaded as 16-byte pairs from the even
+  // floor of g0, stored so that entry k of the slab is global entry g0 + k (a leading entry of an odd g0 is dropped)
+#define M2_G0(c, p) ((long long)(p) * T.P + (long long)(c) * RM_C - 2 * H)
+#define M2_E0(c, p, k) ((M2_G0(c, p) & ~1LL) + 2 * (tid + (k) * RM_C))
+#define M2_STAGE(slot, par, v0, v1)                                                                                    \
+  do {                                                                                                                 \
+    if (pact0) {                                                                                                       \
+      const int i_ = (slot) * SLXP + 2 * tid - (par);                                                                  \
+      if (i_ >= (slot) * SLXP) xw[i_] = (v0).x;                                                                        \
+      xw[i_ + 1] = (v0).y;                                                                                             \
+    }                                                                                                                  \
+    if (pact1) {                                                                                                       \
+      const int i_ = (slot) * SLXP + 2 * (tid + RM_C) - (par);                                                         \
+      xw[i_] = (v1).x;                                                                                                 \
+      xw[i_ + 1] = (v1).y;                                                                                             \
+    }                                                                                                                  \
+  } while (0)
+  // per-lane walk of the LDS dictionary (classes longer than RM2_CLEN): acc = sum over the entries of class cq (ascending k)
+  // of value * ring[base(dz) + code >> 2], additions predicated on k < len
+#define M2_WALK(acc, ring, bm, bz, bp, cq, livev)                                                                      \
+  do {                                                                                                                 \
+    const int s_ = dptr[cq], len_ = (livev) ? dptr[(cq) + 1] - s_ : 0;                                                 \
+    for (int k_ = 0; k_ < T.maxlen; k_ += 4) {                                                                         \
+      MarchEnt e_[4];                                                                                                  \
+      double xv_[4];                                                                                                   \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) e_[u_] = dent[s_ + min(k_ + u_, len_ - 1 < 0 ? 0 : len_ - 1)];  \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                               \
+        const int dz1_ = e_[u_].code & 3;                                                                              \
+        xv_[u_] = (ring)[(dz1_ == 0 ? (bm) : (dz1_ == 1 ? (bz) : (bp))) + (e_[u_].code >> 2)];                         \
+      }                                                                                                                \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                               \
+        const double t_ = (acc) + e_[u_].val * xv_[u_];                                                                \
+        (acc) = (k_ + u_ < len_) ? t_ : (acc);                                                                         \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+  // Class records in registers.  A lane's row keeps its in-plane position from plane to plane and with it - away from
+  // the first and the last plane - its class: the records are re-read from the LDS dictionary only when the class id
+  // changes.  Per record: the value and one int = ((column offset + the lane's slab offset) * 8) | (dz + 1), i.e. the
+  // BYTE offset of the gathered entry inside a slab with the plane shift in the two spare low bits; the slab of plane
+  // z + dz is slot (q + dz) & 3 of the ring.  Records beyond the class's length carry the value 0 at the class's first
+  // offset: they add +-0 (no predication).  A walk then costs per record 4 integer operations, one 8-byte LDS read and
+  // one FMA (the per-lane walk of the LDS dictionary: ~12 operations and 24 bytes - the walks are VALU-issue bound).
+#define M2_LOADRECS(vals, offs, cq, jx)                                                                                \
+  do {                                                                                                                 \
+    const int s_ = dptr[cq], len_ = dptr[(cq) + 1] - s_;                                                               \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM2_CLEN; ++u_) {                                                          \
+      const MarchEnt e_ = dent[s_ + (u_ < len_ ? u_ : 0)];                                                             \
+      (vals)[u_] = (u_ < len_) ? e_.val : 0.0;                                                                         \
+      (offs)[u_] = ((((e_.code >> 2) + (jx)) << 3)) | (e_.code & 3);                                                   \
+    }                                                                                                                  \
+  } while (0)
+  // qs: ring slot of plane z - 1 (so that the slot of plane z + dz is (qs + dz + 1) & 3); base8: byte offset of the ring; extra8: added
+  // to every record's byte offset (the t ring is walked with the x ring's records: other lane offset, other slab length)
+#define M2_REGWALK(acc, vals, offs, qs, sl8, base8)                                                                    \
+  do {                                                                                                                 \
+    double xv_[RM2_CLEN];                                                                                              \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM2_CLEN; ++u_) {                                                          \
+      const int o_ = (offs)[u_];                                                                                       \
+      const int slot_ = (o_ + (qs)) & 3;                                                                               \
+      xv_[u_] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(win) + (slot_ * (sl8) + (o_ & ~7) + (base8))); \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM2_CLEN; ++u_) (acc) = (acc) + (vals)[u_] * xv_[u_];                      \
+  } while (0)
+
+  __syncthreads();   // dictionaries in place
+  while (it < it_end) {
+    const int c = (int)(it / T.nplanes);
+    const int z0 = (int)(it - (long long)c * T.nplanes);
+    const int z1 = (int)((it_end - it) < (long long)(T.nplanes - z0) ? z0 + (it_end - it) : T.nplanes);
+    it += z1 - z0;
+    const int c0 = c * RM_C;
+    const int ipc = c0 + tid;                          // the lane's core row (in-plane index)
+    const bool livec = ipc < T.P;
+    const int iph = c0 - H + hj;                       // the lane's halo row of stage 1
+    const bool liveh = hact && iph >= 0 && iph < T.P;
+    // ---- fill the x ring: planes z0-2, z0-1, z0 (slots 0..2); plane z0+1 goes into registers -------------------------
+#pragma unroll 1
+    for (int pp = 0; pp < 3; ++pp) {
+      const d2_t q0 = march_load_pair(a.x, M2_E0(c, z0 - 2 + pp, 0), pact0, T.n_cols);
+      const d2_t q1 = march_load_pair(a.x, M2_E0(c, z0 - 2 + pp, 1), pact1, T.n_cols);
+      M2_STAGE(pp, (int)(M2_G0(c, z0 - 2 + pp) & 1LL), q0, q1);
+    }
+    d2_t pre0 = march_load_pair(a.x, M2_E0(c, z0 + 1, 0), pact0, T.n_cols);
+    d2_t pre1 = march_load_pair(a.x, M2_E0(c, z0 + 1, 1), pact1, T.n_cols);
+    // row operands of stage 1, plane zz: class id and b of the core row and of the halo row (a safe row when not live)
+    int nclsc, nclsh;
+    double nbc, nbh;
+#define M2_OPERANDS(zz)                                                                                                \
+  do {                                                                                                                 \
+    const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
+    const int rc_ = (pv_ && livec) ? (zz) * T.P + ipc : C.n_rows - 1;                                                  \
+    const int rh_ = (pv_ && liveh) ? (zz) * T.P + iph : C.n_rows - 1;                                                  \
+    nclsc = C.cls[rc_];                                                                                                \
+    nbc = a.b[rc_];                                                                                                    \
+    nclsh = C.cls[rh_];                                                                                                \
+    nbh = a.b[rh_];                                                                                                    \
+  } while (0)
+    M2_OPERANDS(z0 - 1);
+    __syncthreads();
+    // pending stores (issued at the top of the next iteration) and the operand pipeline of the core row for stage 2
+    double st_t = 0.0, st_r = 0.0, st_xn = 0.0;
+    int st_trow = -1, st_rrow = -1;
+    int cls1 = 0, cls2 = 0;        // class of the core row in planes z-1, z-2
+    double b1 = 0.0, b2 = 0.0;
+    // class records in registers: core row (x ring, lane offset tid + H; the t ring is walked with the same records
+    // shifted by the constant (tid - (tid + H)) * 8) and halo row (x ring, lane offset hj)
+    double cv[RM2_CLEN], hv[RM2_CLEN];
+    int co[RM2_CLEN], ho[RM2_CLEN];
+    int ccls = -1, hcls = -1;
+    for (int z = z0 - 1; z <= z1 + 1; ++z) {
+      const int q = z - z0 + 2;                        // ring index of plane z (plane z0-2 is 0)
+      d2_t cur0 = pre0, cur1 = pre1;
+      int clsc = nclsc, clsh = nclsh;
+      double bc = nbc, bh = nbh;
+      asm volatile("" : "+v"(cur0.x), "+v"(cur0.y), "+v"(cur1.x), "+v"(cur1.y), "+v"(clsc), "+v"(bc), "+v"(clsh), "+v"(bh));
+      // ---- x plane z+2 into its slot (that of plane z-2, last read before the previous barrier) -----------------------
+      if (z + 2 <= z1 + 1) M2_STAGE((q + 2) & 3, (int)(M2_G0(c, z + 2) & 1LL), cur0, cur1);
+      // ---- stores of the previous iteration, then the loads of x plane z+3 and of the operands of plane z+1 ------------
+      if (st_trow >= 0) a.t[st_trow] = st_t;
+      if (st_rrow >= 0) {
+        if (a.r) a.r[st_rrow] = st_r;
+        if (a.xn) a.xn[st_rrow] = st_xn;
+      }
+      if (z + 3 <= z1 + 1 && !(MG_M2X & 8)) {
+        pre0 = march_load_pair(a.x, M2_E0(c, z + 3, 0), pact0, T.n_cols);
+        pre1 = march_load_pair(a.x, M2_E0(c, z + 3, 1), pact1, T.n_cols);
+      }
+      if (z + 1 <= z1) M2_OPERANDS(z + 1);
+      // ---- stage 1 on plane z: t = x + d.*(b - A x) on the core row and on the halo row ---------------------------------
+      st_trow = -1;
+      if (z >= 0 && z < T.nplanes && z <= z1) {        // (uniform)
+        const int xbm = ((q - 1) & 3) * SLXP, xbz = (q & 3) * SLXP, xbp = ((q + 1) & 3) * SLXP;
+        {
+          const int cq = livec ? clsc : 0;
+          const int j = tid + H;
+          double acc = 0.0;
+#if !(MG_M2X & 1)
+          if (regs) {
+            if (cq != ccls) {
+              M2_LOADRECS(cv, co, cq, j);
+              ccls = cq;
+            }
+            M2_REGWALK(acc, cv, co, q - 1, SLX8, 0);
+          } else {
+            int w0 = xbm + j, w1 = xbz + j, w2 = xbp + j;
+            asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));   // (opaque: else the compiler branches per entry)
+            M2_WALK(acc, xw, w0, w1, w2, cq, livec);
+          }
+#endif
+          if (livec) {
+            const double own = xw[xbz + j + H];
+            const double tv = own + dd[cq] * (bc - acc);
+            tw[(q & 3) * SLTP + j] = tv;
+            if (z >= z0 && z < z1) {
+              st_trow = z * T.P + ipc;
+              st_t = tv;
+            }
+          }
+        }
+        if (hact) {
+          const int cq = liveh ? clsh : 0;
+          double acc = 0.0;
+#if !(MG_M2X & 2)
+          if (regs) {
+            if (cq != hcls) {
+              M2_LOADRECS(hv, ho, cq, hj);
+              hcls = cq;
+            }
+            M2_REGWALK(acc, hv, ho, q - 1, SLX8, 0);
+          } else {
+            int w0 = xbm + hj, w1 = xbz + hj, w2 = xbp + hj;
+            asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
+            M2_WALK(acc, xw, w0, w1, w2, cq, liveh);
+          }
+#endif
+          if (liveh) {
+            const double own = xw[xbz + hj + H];
+            tw[(q & 3) * SLTP + hj] = own + dd[cq] * (bh - acc);
+          }
+        }
+      }
+      // ---- stage 2 on plane z-2: r = b - A t from the t ring (planes z-3, z-2, z-1: written before the last barrier) ----
+      st_rrow = -1;
+      if (z - 2 >= z0 && z - 2 < z1) {                 // (uniform)
+        const int tbz = ((q - 2) & 3) * SLTP + tid;    // entry of column ip + rest: (tid + H) + rest = tid + (code >> 2)
+        const int cq = livec ? cls2 : 0;
+        double acc = 0.0;
+#if !(MG_M2X & 4)
+        if (regs) {
+          if (cq != ccls) {
+            M2_LOADRECS(cv, co, cq, tid + H);
+            ccls = cq;
+          }
+          M2_REGWALK(acc, cv, co, q - 3, SLT8, TW8 - 8 * H);   // (the records hold (off + tid + H) * 8: the t slab wants off + tid)
+        } else {
+          int w0 = ((q - 3) & 3) * SLTP + tid, w1 = tbz, w2 = ((q - 1) & 3) * SLTP + tid;
+          asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
+          M2_WALK(acc, tw, w0, w1, w2, cq, livec);
+        }
+#endif
+        if (livec) {
+          const double own = tw[tbz + H];
+          const double rv = b2 - acc;
+          st_rrow = (z - 2) * T.P + ipc;
+          st_r = rv;
+          st_xn = own + dd[cq] * rv;
+          sq += rv * rv;
+        }
+      }
+      cls2 = cls1;
+      b2 = b1;
+      cls1 = clsc;
+      b1 = bc;
+      __syncthreads();
+    }
+    if (st_trow >= 0) a.t[st_trow] = st_t;             // (not reached with the loop's last iteration being stage 2 only)
+    if (st_rrow >= 0) {
+      if (a.r) a.r[st_rrow] = st_r;
+      if (a.xn) a.xn[st_rrow] = st_xn;
+    }
+  }
+  if (a.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w2 = 0; w2 < RM_C / 64; ++w2) t += red[w2];
+      a.sumsq[w] = t;
+    }
+  }
+#undef M2_G0
+#undef M2_E0
+#undef M2_STAGE
+#undef M2_WALK
+#undef M2_LOADRECS
+#undef M2_REGWALK
+#undef M2_OPERANDS
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exception rows of a row-class operator (rows whose class was too rare for the dictionary: a few per cent next to
 // sub-domain faces or irregular boundaries): one lane per listed row, straight from the CSR arrays, same epilogues.
 // ------------------------------------------------------------------------------------------------

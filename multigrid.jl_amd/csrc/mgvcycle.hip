@@ -60,6 +60,7 @@ struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
+  bool no_march2 = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -86,7 +87,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -196,6 +197,8 @@ struct Csr {
   bool rc_march = false;    // csr_rowclass_march_spmv (z-marching ring of slabs; preferred over the tiles when set)
   DevBuf<int> rm_lb;
   int rm_P = 0, rm_nplanes = 0, rm_halo = 0, rm_chunks = 0, rm_nblocks = 0;
+  bool rc_march2 = false;   // csr_rowclass_march2_spmv can serve a sweep + residual pair on this operator
+  int rm2_nblocks = 0;
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   int rw_doubles = 0;   // x entries a workgroup of csr_rowclass_window_spmv stages in LDS
   DevBuf<unsigned short> rc_cls;
@@ -311,6 +314,7 @@ struct Csr {
     rc_nexc = 0;
     rc_tile = false;
     rc_march = false;
+    rc_march2 = false;
     h_rc_ptr.clear();
     h_rc_off.clear();
     h_rc_delta.clear();
@@ -376,6 +380,7 @@ struct Level {
   long long n = 0;
   // CYCLEmem (MGdef.jl:56-60) plus the Jacobi ping-pong partner of x
   DevBuf<double> b, r, x0, x1;
+  DevBuf<double> x2;   // fine level, solve loop: third rotating buffer of the fused last sweep + residual (allocated on first use)
   // FGMRESmem (FGMRES.jl:3-8): Z and A*Z bases, `inner` contiguous vectors of n*nrhs each.
   // relaxZ/relaxAZ: memRelax[level] (Jac-GMRES smoother); kZ/kAZ: memKcycle (K-cycle recursion INTO this level)
   DevBuf<double> relaxZ, relaxAZ, kZ, kAZ;
@@ -385,8 +390,8 @@ struct Level {
 struct ProfSlot {
   double ms = 0.0;
   long long launches = 0;
-  double bytes = 0.0;   // algorithmic (CSR-priced) bytes of one launch, SURVEY 8d
-  double moved = 0.0;   // bytes the kernel IN USE has to move for one launch (device format + each vector once)
+  double bytes = 0.0;   // algorithmic (CSR-priced) bytes, SURVEY 8d: SUM over the launches (reported per launch = / launches)
+  double moved = 0.0;   // bytes the kernel IN USE has to move (device format + each vector once): SUM over the launches
 };
 
 }  // namespace
@@ -534,8 +539,8 @@ void prof_collect(mg_hierarchy* h) {
       ProfSlot& s = h->slots[(size_t)p.level * MG_K_COUNT + p.kernel];
       s.ms += ms;
       s.launches += 1;
-      s.bytes = p.bytes;
-      s.moved = p.moved;
+      s.bytes += p.bytes;   // (launches of one slot may differ: the fused sweep + residual writes r, x + d.*r or neither)
+      s.moved += p.moved;
     }
     h->ev_pool.push_back(p.a);
     h->ev_pool.push_back(p.b);
@@ -548,6 +553,12 @@ int pow2_ge(long long v) {
   int g = 1;
   while (g < v && g < 64) g <<= 1;
   return g;
+}
+
+// dynamic LDS of csr_rowclass_march2_spmv: 4 x slabs + 4 t slabs + dictionary
+size_t march2_lds_bytes(int halo) {
+  const size_t slx = (size_t)(mgk::RM_C + 4 * halo + 2), slt = (size_t)(mgk::RM_C + 2 * halo);
+  return (4 * slx + 4 * slt) * sizeof(double) + 16 * (size_t)mgk::RM_DCAP + 8 * (size_t)mgk::RM_NCLS + 4 * (size_t)(mgk::RM_NCLS + 4);
 }
 
 // can the z-marching kernel serve this launch?  (staged variants read x workgroup-wide: never in place; its staging
@@ -825,6 +836,54 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
   ProfScope ps(h, level, MG_K_SMOOTH, spmv_bytes(A, h->nrhs, true, true), moved_bytes(A, h->nrhs, true, true, v.d == nullptr));
   return launch_csr<mgk::SMOOTH>(h->stream, A, v);
 }
+// One sweep and the residual of its result in one pass (csr_rowclass_march2_spmv):
+//   t = x + d.*(b - A x) ;  r = b - A t  [; xn = t + d.*r ; ||r||^2 partials]
+// for the level's own A with its own relaxPrec read from the class dictionary.  x, t, r, xn: four different buffers.
+bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* t, const double* r, const double* xn) {
+  const Level& L = h->lev[(size_t)level];
+  if (h->nrhs != 1 || h->relax_type != 0 || !L.A.has_rc || !L.A.rc_march || !L.A.rc_march2 || !L.A.rc_has_d || L.A.rc_nexc != 0) return false;
+  if (L.A.d_bound != L.d.p) return false;   // the dictionary's relaxPrec is this level's
+  if (x == t || x == r || x == xn || t == r || t == xn || (r && r == xn)) return false;
+  return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double* x, double* t, double* r, double* xn,
+                      bool want_sumsq) {
+  const Csr& A = h->lev[(size_t)level].A;
+  mgk::March2Args a{};
+  a.x = x;
+  a.b = b;
+  a.t = t;
+  a.r = r;
+  a.xn = xn;
+  a.sumsq = want_sumsq ? h->partial.p : nullptr;
+  mgk::MarchDev T = A.marchdev();
+  T.nblocks = A.rm2_nblocks;
+  if (want_sumsq && (size_t)T.nblocks > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
+  const size_t lds = march2_lds_bytes(A.rm_halo);
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march2_spmv<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipGetLastError();
+    lds_attr_set = true;
+  }
+  const double n8 = 8.0 * (double)A.n_rows;
+  {
+    // algorithmic: the two products; moved: class ids + x + b in, t and r (and/or xn) out
+    ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (xn && r ? n8 : 0.0),
+                 format_bytes(A, 1) + n8 * (3.0 + (r ? 1.0 : 0.0) + (xn ? 1.0 : 0.0)));
+    hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<0>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
+    HIP_TRY(hipGetLastError());
+  }
+  if (want_sumsq) {
+    const int nb1 = T.nblocks;
+    ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
+    const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
+    hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
+    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
+    HIP_TRY(hipGetLastError());
+  }
+  return MG_OK;
+}
 // Can the coarse-grid correction of level `level` ride in the staging of the first post-smoothing sweep?
 // (one right-hand side, pointwise smoother, A on the marching kernel, P in row-class form without exception rows)
 bool can_fuse_prolong(mg_hierarchy* h, int level, const double* x, const double* out) {
@@ -1093,8 +1152,10 @@ int fgmres_relax(mg_hierarchy* h, int lv, const double* r0, double* x0, long lon
 // x1_ready (with r_valid): xb already holds xa + d.*r, the first pre-smoothing update (written by the residual kernel
 // of the previous solve step, k_residual_sumsq's xnext).
 int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result);
+// defer_post (solve loop, fine level): leave the LAST post-smoothing sweep to the caller, who fuses it with the residual
+// of the stopping test (k_smooth_residual); *defer_post says whether that happened (result = x before that sweep).
 int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero,
-                char ctype, double** result, bool r_valid = false, bool x1_ready = false) {
+                char ctype, double** result, bool r_valid = false, bool x1_ready = false, bool* defer_post = nullptr) {
   const int nl = (int)h->nlevels;
   if (l == nl - 1) {  // solveCoarsest (MGcycle.jl:13-18,67-69,177): x = LU \ b
     MG_TRY(k_coarse(h, l, b, xa));
@@ -1130,12 +1191,19 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     std::swap(cur, alt);
     --npre;
   }
-  for (long long s = 0; s < npre; ++s) {
+  // the last pre-smoothing sweep and r = b - A x (MGcycle.jl:58-60) in one pass where the marching kernel allows
+  const bool fuse_pre = npre >= 1 && march2_ok(h, l, cur, alt, L.r.p, nullptr);
+  for (long long s = 0; s < npre - (fuse_pre ? 1 : 0); ++s) {
     MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
     std::swap(cur, alt);
   }
   // r = b - A x ; bc = R r ; xc = 0 (MGcycle.jl:58-66)
-  MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
+  if (fuse_pre) {
+    MG_TRY(k_smooth_residual(h, l, b, cur, alt, L.r.p, nullptr, false));
+    std::swap(cur, alt);
+  } else {
+    MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
+  }
   MG_TRY(k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, C.b.p));
   double* xc = nullptr;
   if (ctype == 'K' && l + 1 < nl - 1) {
@@ -1173,11 +1241,15 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
     MG_TRY(fgmres_relax(h, l, L.r.p, cur, L.npost, diag_prec, gmresTol, L.relaxZ.p, L.relaxAZ.p, false));
   } else {
-    for (long long s = post_done; s < npost; ++s) {
+    long long nlast = npost;
+    if (defer_post && *defer_post && post_done < npost) --nlast;   // the caller runs the last sweep (fused with its residual)
+    else if (defer_post) *defer_post = false;
+    for (long long s = post_done; s < nlast; ++s) {
       MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
       std::swap(cur, alt);
     }
   }
+  if (defer_post && h->relax_type == 1) *defer_post = false;
   *result = cur;
   return MG_OK;
 }
@@ -1282,15 +1354,39 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
   const bool dbg = h->opt.debug_timing;
   auto tprev = std::chrono::steady_clock::now();
   bool x1_ready = false;
+  // Where the marching kernel allows, the last post-smoothing sweep of the cycle is left out of cycle_level and runs
+  // fused with the residual of the stopping test: x_in -> t = x (the iterate) and xn = x + d.*r (the next cycle's first
+  // update) in one pass, rotating three buffers (cur, alt, spare).
+  double* spare = nullptr;
+  bool fuse_post = false;
+  if (h->nrhs == 1 && !h->opt.no_march2 && !h->opt.no_fused_next && L.A.rc_march2 && std::max<long long>(1, L.npost) >= 1) {
+    if (L.x2.n != (size_t)len) {
+      MG_TRY(L.x2.alloc((size_t)len));
+      HIP_TRY(hipMemsetAsync(L.x2.p, 0, L.x2.bytes(), h->stream));
+    }
+    spare = L.x2.p;
+    fuse_post = march2_ok(h, 0, cur, alt, nullptr, spare) && march2_ok(h, 0, alt, spare, nullptr, cur) && march2_ok(h, 0, spare, cur, nullptr, alt);
+  }
   for (long long count = 1; count <= maxIter; ++count) {
     double* out = nullptr;
     // from the second step on, L.r = b - A*x is the residual just computed for the stopping test
-    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero, x1_ready));
+    bool deferred = fuse_post;
+    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero, x1_ready, &deferred));
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
-    // SolveFuncs.jl:26-30: r = b - A x and ||r|| in one pass; where the kernel allows, the same pass also writes
-    // alt = x + d.*r, the first pre-smoothing update of the next cycle (unused if this was the last step)
-    MG_TRY(k_residual_sumsq(h, 0, L.A, b, cur, L.r.p, count < maxIter ? alt : nullptr, &x1_ready, /*r_dead=*/true));
+    if (deferred) {
+      // cur = x before the last sweep; alt <- the iterate; spare <- x + d.*r (unused if this was the last step)
+      MG_TRY(k_smooth_residual(h, 0, b, cur, alt, nullptr, count < maxIter ? spare : nullptr, true));
+      x1_ready = count < maxIter;
+      double* freed = cur;
+      cur = alt;
+      alt = spare;
+      spare = freed;
+    } else {
+      // SolveFuncs.jl:26-30: r = b - A x and ||r|| in one pass; where the kernel allows, the same pass also writes
+      // alt = x + d.*r, the first pre-smoothing update of the next cycle (unused if this was the last step)
+      MG_TRY(k_residual_sumsq(h, 0, L.A, b, cur, L.r.p, count < maxIter ? alt : nullptr, &x1_ready, /*r_dead=*/true));
+    }
     MG_TRY(scalar_sync(h, &res));
     ++it;
     if (dbg) {
@@ -2158,6 +2254,13 @@ int build_march(Csr& A, const long long grid[3]) {
   A.rm_chunks = (int)chunks;
   A.rm_nblocks = (int)nb;
   A.rc_march = true;
+  // two stages per pass (sweep + residual): no exception rows, x slab of RM_C + 4*halo entries in two 16-byte pairs per
+  // thread, ring of 4 x slabs + 4 t slabs + dictionary within the 160 KB of LDS; one workgroup per CU
+  A.rc_march2 = false;
+  A.rm2_nblocks = (int)std::max<long long>(1, std::min<long long>(ncu, items / 8));
+  if (!A.opt.no_march2 && A.rc_nexc == 0 && A.regular_cols < 0 && 2 * halo <= mgk::RM_C && march2_lds_bytes((int)halo) <= 160 * 1024 - 256 &&
+      A.rm2_nblocks >= std::min<long long>(A.opt.march_min_wg, ncu))
+    A.rc_march2 = true;
   return MG_OK;
 }
 
@@ -3354,6 +3457,25 @@ int mg_fused_dev_FP64(mg_hierarchy* h, long long level, long long kernel, const 
   return MG_OK;
 }
 
+// t = x + d.*(b - A x) and r = b - A t (optionally xn = t + d.*r and ||r||^2) in one pass over the level: the fused
+// form of relax's last sweep + the residual that follows it (MGcycle.jl:129-131 + 58-60; SolveFuncs.jl:26-30).
+int mg_sweep_residual_dev_FP64(mg_hierarchy* h, long long level, const double* b, const double* x, double* t, double* r,
+                               double* xn, double* norm_r) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  if (level < 1 || level >= h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  if (!b || !x || !t) return fail(MG_ERR_INVALID, "null vector");
+  (void)hipSetDevice(h->device);
+  if (!march2_ok(h, (int)level - 1, x, t, r, xn))
+    return fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the two-stage marching kernel (one right-hand side, pointwise "
+                "smoother, grid operator without exception rows, distinct 16-byte aligned buffers)", level);
+  MG_TRY(k_smooth_residual(h, (int)level - 1, b, x, t, r, xn, norm_r != nullptr));
+  if (norm_r) MG_TRY(scalar_sync(h, norm_r));
+  HIP_TRY(spin_sync(h->stream));
+  prof_collect(h);
+  return MG_OK;
+}
+
 // ---- host-buffer hot path (what the Julia glue ccalls) ------------------------------------------
 // x == 0 everywhere?  Blocks of 4096 entries are OR-reduced bitwise (vectorises; the element-wise loop with its early
 // exit does not: 13 ms for 136 MB on the box's core) and only a block with a set bit - a non-zero or a -0.0 - is
@@ -3768,6 +3890,11 @@ int mg_time_op_dev_FP64(mg_hierarchy* h, long long level, long long kernel, long
         rc = k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, h->lev[(size_t)l + 1].b.p);
         bts = spmv_bytes(L.R, nrhs, false, false);
         break;
+      case MG_K_SMOOTH_RESIDUAL:
+        if (!march2_ok(h, l, xa, xb, L.r.p, nullptr)) rc = fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the two-stage marching kernel", level);
+        else rc = k_smooth_residual(h, l, bvec, xa, xb, L.r.p, nullptr, false);
+        bts = spmv_bytes(L.A, nrhs, true, true) + spmv_bytes(L.A, nrhs, true, false);
+        break;
       case MG_K_PROLONG:
         rc = k_spmv(h, l, MG_K_PROLONG, L.P, 0.0, h->lev[(size_t)l + 1].x0.p, 1.0, xb);
         bts = spmv_bytes(L.P, nrhs, true, false);
@@ -3824,7 +3951,7 @@ int mg_profile_get(mg_hierarchy* h, long long level, long long kernel, double* t
   const ProfSlot& s = h->slots[(size_t)(level - 1) * MG_K_COUNT + (size_t)kernel];
   if (total_ms) *total_ms = s.ms;
   if (launches) *launches = s.launches;
-  if (bytes_per_launch) *bytes_per_launch = s.bytes;
+  if (bytes_per_launch) *bytes_per_launch = s.launches > 0 ? s.bytes / (double)s.launches : 0.0;
   return MG_OK;
 }
 
@@ -3832,7 +3959,8 @@ int mg_profile_get_moved(mg_hierarchy* h, long long level, long long kernel, dou
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
   if (level < 1 || level > h->nlevels || kernel < 0 || kernel >= MG_K_COUNT || !moved_bytes_per_launch)
     return fail(MG_ERR_INVALID, "bad (level=%lld, kernel=%lld)", level, kernel);
-  *moved_bytes_per_launch = h->slots[(size_t)(level - 1) * MG_K_COUNT + (size_t)kernel].moved;
+  const ProfSlot& sl = h->slots[(size_t)(level - 1) * MG_K_COUNT + (size_t)kernel];
+  *moved_bytes_per_launch = sl.launches > 0 ? sl.moved / (double)sl.launches : 0.0;
   return MG_OK;
 }
 

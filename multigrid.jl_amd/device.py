@@ -24,8 +24,8 @@ LIB_PATH = os.environ.get("MGVCYCLE_LIB") or os.path.join(_HERE, "csrc", "libmgv
 
 MG_OP_A, MG_OP_P, MG_OP_R = 0, 1, 2
 (MG_K_SPMV, MG_K_RESIDUAL, MG_K_SMOOTH, MG_K_RESTRICT, MG_K_PROLONG, MG_K_DSCALE, MG_K_COARSE,
- MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_COUNT) = range(10)
-KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm", "smooth+prolong"]
+ MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_COUNT) = range(11)
+KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm", "smooth+prolong", "smooth+residual"]
 
 _ll = C.c_longlong
 _dp = C.POINTER(C.c_double)
@@ -73,6 +73,7 @@ SIGNATURES = {
     "mg_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _dp]),
     "mg_spmv_dev_FP64": (C.c_int, [_vp, _ll, _ll, C.c_double, _vp, C.c_double, _vp, _ll]),
     "mg_fused_dev_FP64": (C.c_int, [_vp, _ll, _ll, _vp, _vp, _vp, _ll]),
+    "mg_sweep_residual_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
     "mg_time_op_dev_FP64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _dp, _dp]),
     "mg_profile_enable": (C.c_int, [_vp, _ll]),
     "mg_profile_get": (C.c_int, [_vp, _ll, _ll, _dp, _lp, _dp]),
@@ -481,6 +482,14 @@ class DeviceHierarchy:
         nrhs = self.nrhs if nrhs is None else nrhs
         _check(self.lib, self.lib.mg_fused_dev_FP64(self.handle, level, kernel, _ptr(b), _ptr(x), _ptr(out), nrhs),
                "mg_fused_dev")
+
+    def sweep_residual_dev(self, level, b, x, t, r=None, xn=None, want_norm=False):
+        """t = x + d.*(b - A x), r = b - A t [, xn = t + d.*r, ||r||] in one pass (two-stage marching kernel)."""
+        ss = C.c_double(0.0)
+        _check(self.lib, self.lib.mg_sweep_residual_dev_FP64(
+            self.handle, level, _ptr(b), _ptr(x), _ptr(t), _ptr(r) if r is not None else None,
+            _ptr(xn) if xn is not None else None, C.byref(ss) if want_norm else None), "mg_sweep_residual_dev")
+        return float(ss.value)
 
     def set_stream(self, stream: int):
         """Enqueue on the caller's HIP stream (e.g. ``torch.cuda.current_stream().cuda_stream``)."""

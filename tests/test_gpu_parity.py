@@ -696,6 +696,74 @@ def test_march_kernel_and_fused_prolongation(mg, built, monkeypatch, cells, leve
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cells,levels,cyc,pre,post", [([33, 25, 7], 2, "V", 2, 1), ([40, 30, 9], 3, "W", 1, 2), ([23, 23, 23], 3, "V", 2, 1),
+                                                       ([70, 10, 12], 2, "F", 2, 2), ([64, 64, 20], 3, "V", 2, 1), ([36, 36, 40], 3, "V", 3, 3),
+                                                       ([20, 20, 3], 2, "V", 1, 1)])
+def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, levels, cyc, pre, post):
+    """csr_rowclass_march2_spmv (temporal blocking: the last sweep of relax and the residual that follows it in one walk
+    along z): kernel-level t, r, t + d.*r against numpy and BIT-identical to the two single-stage launches; the solve
+    against the oracle and bit-identical iterates against the unfused path (MG_NO_MARCH2=1)."""
+    import torch
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    monkeypatch.setenv("MG_MARCH_MAX_LEN", "64")         # also on the 27-point coarse levels
+    rng = np.random.default_rng(sum(cells) + 7)
+    runs = {}
+    for name, no2 in (("fused", "0"), ("unfused", "1")):
+        monkeypatch.setenv("MG_NO_MARCH2", no2)
+        A, p, b = _setup(mg, cells, levels, "Jac", 0.8, pre, post, cyc, maxIter=5)
+        h = mg.to_device(p)
+        assert h.operator_kernel_variant(1, D.MG_OP_A) == 3
+        served = 0
+        for l in range(1, p.levels):
+            Al, dl = p.As[l - 1], p.relaxPrecs[l - 1]
+            xn_, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+            x, bb = torch.from_numpy(xn_).cuda(), torch.from_numpy(bn).cuda()
+            t, r, xn = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+            try:
+                nrm = h.sweep_residual_dev(l, bb, x, t, r, xn, True)
+            except D.MGDeviceError:
+                assert no2 == "1" or h.operator_kernel_variant(l, D.MG_OP_A) != 3
+                continue
+            assert no2 == "0"
+            served += 1
+            t_want = xn_ + dl * (bn - Al @ xn_)
+            r_want = bn - Al @ t_want
+            assert np.abs(t.cpu().numpy() - t_want).max() / np.abs(t_want).max() < KERNEL_TOL
+            assert np.abs(r.cpu().numpy() - r_want).max() / np.abs(r_want).max() < 10 * KERNEL_TOL
+            assert np.abs(xn.cpu().numpy() - (t_want + dl * r_want)).max() / np.abs(t_want).max() < 10 * KERNEL_TOL
+            assert abs(nrm - np.linalg.norm(r_want)) < 1e-12 * np.linalg.norm(r_want)
+            t1, r1 = torch.zeros_like(x), torch.zeros_like(x)
+            h.fused_dev(l, D.MG_K_SMOOTH, bb, x, t1)
+            h.fused_dev(l, D.MG_K_RESIDUAL, bb, t1, r1)
+            assert torch.equal(t, t1) and torch.equal(r, r1)          # same products, same order
+            # outputs that are not asked for are not written
+            t2 = torch.zeros_like(x)
+            h.sweep_residual_dev(l, bb, x, t2)
+            assert torch.equal(t2, t)
+        if no2 == "0":
+            assert served >= 1
+        x, hist = _compare_solve(mg, p, b)
+        x0 = np.random.default_rng(99).standard_normal(b.shape)
+        x1 = x0.copy()
+        mg.recursiveCycle(p, b, x1, 1)
+        xo = orc.recursiveCycle(p, b, x0.copy(), 1)
+        assert np.abs(x1 - xo).max() <= RES_TOL * np.abs(xo).max()
+        # a solve from a non-zero initial guess (first step: full residual, then the fused tail)
+        x2 = x0.copy()
+        mg.solveMG(p, b, x2)
+        runs[name] = (x.copy(), np.asarray(p.resvec).copy(), x1.copy(), x2.copy())
+        mg.clear_(p)
+    assert np.array_equal(runs["fused"][0], runs["unfused"][0])
+    assert np.array_equal(runs["fused"][2], runs["unfused"][2])
+    assert np.array_equal(runs["fused"][3], runs["unfused"][3])
+    assert np.abs(runs["fused"][1] - runs["unfused"][1]).max() <= 1e-14 * runs["unfused"][1][0]
+
+
+@pytest.mark.gpu
 def test_march_with_wrong_grid_hint_and_exception_rows(mg, built, monkeypatch):
     """The marching kernel with a hint that describes the wrong grid (unstaged shifts gather from global memory) and
     with a few perturbed rows (exception rows computed from the CSR arrays): the solve is still the oracle's."""
