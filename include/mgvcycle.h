@@ -120,7 +120,8 @@ int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* L
 
 /* coarseSolveType "GMRES" (MGcycle.jl:152-168): the coarsest level is solved by one restart of Jacobi-preconditioned
  * FGMRES(10) with tol 0.01 from x = 0; d = relaxParam ./ diag(A_c) is what defineCoarsestAinv keeps in param.LU
- * (MGsetup.jl:334).  One right-hand side (the reference's blockFGMRES branch is rejected). */
+ * (MGsetup.jl:334).  A block of right-hand sides takes the reference's blockFGMRES branch (MGcycle.jl:164-166): block
+ * flexible GMRES(10), one restart, Frobenius residual estimate <= 1e-2, same preconditioner per column. */
 int mg_set_coarse_gmres_FP64(mg_hierarchy* h, long long n, const double* d);
 
 /* Validate the hierarchy (shapes chain, every level complete), build the row-block partitions,

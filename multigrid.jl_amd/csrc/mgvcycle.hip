@@ -446,6 +446,7 @@ struct mg_hierarchy {
   double* h_blk = nullptr;             // pinned k x k readback
   double* h_blk_c = nullptr;           // pinned ring of coefficient matrices
   unsigned blk_c_next = 0;
+  DevBuf<double> kwc_blk;   // the same for a block of right-hand sides (blockFGMRES branch, MGcycle.jl:166)
   DevBuf<double> kwc, coarse_d;   // coarseSolveType "GMRES": FGMRES work space and the Jacobi preconditioner of the coarsest level
   bool coarse_gmres = false;
   // fine-level operands of the last cycle/solve (used as inputs by mg_time_op_dev_FP64)
@@ -947,14 +948,18 @@ int k_fill(mg_hierarchy* h, double* x, long long n, double val) {
 int fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>& work, const double* b,
                 double* x, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
                 double* resvec, long long* nres);
+int block_fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>* work, const double* B,
+                      double* X, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
+                      double* resvec, long long* nres);
 int k_coarse(mg_hierarchy* h, int level, const double* b, double* x) {
   const long long n = h->n_coarse;
   if (h->coarse_gmres) {
     // coarseSolveType "GMRES" (MGcycle.jl:152-168): x = 0; one restart of FGMRES(10), tol 0.01, M = d .* v with
     // d = relaxParam ./ diag(A_c) (defineCoarsestAinv, MGsetup.jl:334)
-    if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "coarseSolveType GMRES with a block of right-hand sides (blockFGMRES) is not on the device path");
     ProfScope ps(h, level, MG_K_COARSE, 0.0);
-    MG_TRY(k_fill(h, x, n, 0.0));
+    MG_TRY(k_fill(h, x, n * h->nrhs, 0.0));
+    if (h->nrhs != 1)   // MGcycle.jl:166: KrylovMethods.blockFGMRES(Afun, b, 10, tol = 0.01, maxIter = 1, M = M2, X = x)
+      return block_fgmres_core(h, level, 1, h->coarse_d.p, &h->kwc_blk, b, x, 10, 0.01, 1, nullptr, nullptr, nullptr, nullptr);
     return fgmres_core(h, level, 1, h->coarse_d.p, h->kwc, b, x, 10, 0.01, 1, nullptr, nullptr, nullptr, nullptr);
   }
   if (h->coarse_lu) {
@@ -2031,17 +2036,27 @@ int blk_cholqr(mg_hierarchy* h, double* W, long long n, int k, SmallMat& Rf) {
 }
 
 // blockFGMRES: block flexible GMRES(inner), block modified Gram-Schmidt, exact block least squares per inner step
-int block_fgmres_dev(mg_hierarchy* h, const double* B, double* X, long long inner, double tol, long long maxIter,
-                     long long* iters, long long* flag_out, double* resvec, long long* nres) {
-  Level& L = h->lev[0];
+// lv: the level whose A is solved; precond 0: Z = one cycle from x = 0 (level 0 only), 1: Z = dprec .* V (the Jacobi
+// preconditioner of the coarsest-level GMRES branch, MGcycle.jl:157-159); work: own work space (nullptr: the block drivers')
+int block_fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>* work, const double* B,
+                      double* X, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
+                      double* resvec, long long* nres) {
+  Level& L = h->lev[(size_t)lv];
   const long long n = L.n;
   const int k = (int)h->nrhs;
   if (k > mgk::BLK_KMAX) return fail(MG_ERR_UNSUPPORTED, "block Krylov drivers hold at most %d right-hand sides", mgk::BLK_KMAX);
   if (inner < 1 || inner > 64) return fail(MG_ERR_INVALID, "inner must be in [1,64]");
+  if (precond == 0 && lv != 0) return fail(MG_ERR_INVALID, "the cycle preconditions the fine level only");
   const int m = (int)inner;
   const size_t len = (size_t)n * k;
   double* w = nullptr;
-  MG_TRY(blk_work(h, (size_t)(2 * m + 2), n, k, &w));
+  if (work) {
+    const size_t need = (size_t)(2 * m + 2) * len;
+    if (work->n < need) MG_TRY(work->alloc(need));
+    w = work->p;
+  } else {
+    MG_TRY(blk_work(h, (size_t)(2 * m + 2), n, k, &w));
+  }
   double* Vb = w;                              // m+1 blocks
   double* Zb = w + (size_t)(m + 1) * len;      // m blocks
   double* R = Zb + (size_t)m * len;            // residual / W
@@ -2067,7 +2082,7 @@ int block_fgmres_dev(mg_hierarchy* h, const double* B, double* X, long long inne
     HIP_TRY(spin_sync(h->stream));
     return finish(-9);
   }
-  MG_TRY(k_residual(h, 0, L.A, B, X, R));
+  MG_TRY(k_residual(h, lv, L.A, B, X, R));
   MG_TRY(fro(R, &rn));
   if (rn / bn < tol) return finish(0);
   for (long long it = 1; it <= maxIter && flag != 0; ++it) {
@@ -2081,8 +2096,9 @@ int block_fgmres_dev(mg_hierarchy* h, const double* B, double* X, long long inne
       double* Vj = Vb + (size_t)j * len;
       double* Zj = Zb + (size_t)j * len;
       double* W = Vb + (size_t)(j + 1) * len;
-      MG_TRY(cycle_dev(h, Vj, Zj, true));                          // Z_j = M(V_j)
-      MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, Zj, 0.0, W));       // W = A Z_j
+      if (precond == 0) MG_TRY(cycle_dev(h, Vj, Zj, true));        // Z_j = M(V_j)
+      else MG_TRY(k_dscale(h, lv, dprec, Vj, Zj, n));
+      MG_TRY(k_spmv(h, lv, MG_K_SPMV, L.A, 1.0, Zj, 0.0, W));      // W = A Z_j
       for (int i = 0; i <= j; ++i) {                               // block modified Gram-Schmidt
         SmallMat Hij;
         MG_TRY(blk_gram(h, Vb + (size_t)i * len, W, n, k, Hij));
@@ -2114,12 +2130,16 @@ int block_fgmres_dev(mg_hierarchy* h, const double* B, double* X, long long inne
       MG_TRY(blk_comb(h, X, X, 1.0, Zb + (size_t)j * len, Yj, n, k));
     }
     if (flag == 0) break;
-    MG_TRY(k_residual(h, 0, L.A, B, X, R));
+    MG_TRY(k_residual(h, lv, L.A, B, X, R));
     MG_TRY(fro(R, &rn));
     if (rn / bn <= tol) { flag = 0; break; }
   }
   HIP_TRY(spin_sync(h->stream));
   return finish(flag);
+}
+int block_fgmres_dev(mg_hierarchy* h, const double* B, double* X, long long inner, double tol, long long maxIter,
+                     long long* iters, long long* flag_out, double* resvec, long long* nres) {
+  return block_fgmres_core(h, 0, 0, nullptr, nullptr, B, X, inner, tol, maxIter, iters, flag_out, resvec, nres);
 }
 
 // ---- host <-> device block transfer (column-major host <-> row-major device) --------------------

@@ -101,13 +101,16 @@ def FGMRES_relaxation(Afun, r0, x0, inner, prec, TOL):
 def solveCoarsest(param, b, x):
     """Default branch: z = param.LU \\ b ; x[:] = z  (MGcycle.jl:177-178).  coarseSolveType "GMRES" (l.152-168): x = 0, one
     restart of KrylovMethods.fgmres(Afun, b, 10, tol=0.01, maxIter=1) preconditioned by M2(v) = d .* v with
-    d = param.LU = relaxParam ./ diag(AT) (MGsetup.jl:334); blocks of right-hand sides go to blockFGMRES there (not restated)."""
+    d = param.LU = relaxParam ./ diag(AT) (MGsetup.jl:334); blocks of right-hand sides go to blockFGMRES (l.164-166)."""
     if getattr(param, "coarseSolveType", "") == "GMRES":
         b = np.asarray(b)
-        if b.ndim == 2 and b.shape[1] > 1:
-            raise NotImplementedError("blockFGMRES (MGcycle.jl:166) is not restated")
         A = param.As[-1]
         d = np.asarray(param.LU, dtype=np.float64)
+        if b.ndim == 2 and b.shape[1] > 1:     # MGcycle.jl:164-166: blockFGMRES(Afun, b, 10, tol = 0.01, maxIter = 1, M = M2, X = x)
+            Z = blockFGMRES(lambda V: A @ V, b, 10, tol=0.01, maxIter=1, M=lambda V: d[:, None] * V,
+                            X=np.zeros((A.shape[0], b.shape[1])))[0]
+            x[...] = Z.reshape(x.shape)
+            return x
         z = fgmres(lambda v: A @ v, b.reshape(-1), 10, tol=0.01, maxIter=1, M=lambda v: d * v, x=np.zeros(A.shape[0]))[0]
         x[...] = z.reshape(x.shape)
         return x

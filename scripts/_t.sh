@@ -1,3 +1,3 @@
 set -o pipefail
 mkdir -p gpurun_out
-MGVCYCLE_LIB=$PWD/multigrid.jl_amd/csrc/libmgvcycle.so timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "march2" 2>&1 | tail -5 | tee gpurun_out/march2_test.log && timeout -k 10 800 python scripts/march2_ab.py 2>&1 | grep -v Warning | tee gpurun_out/march2_ab.log
+timeout -k 10 1100 python -m pytest tests -q -x -m gpu --durations=8 2>&1 | tail -25 | tee gpurun_out/gpu_suite.log

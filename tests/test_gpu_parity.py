@@ -603,19 +603,20 @@ def test_rowclass_variants_on_odd_grids(mg, built, cells, levels, monkeypatch):
 @pytest.mark.parametrize("cyc,cells,levels", [("V", [16, 16, 16], 3), ("W", [24, 20], 3), ("V", [32, 32, 32], 2)])
 def test_gmres_coarse_solve(mg, built, cyc, cells, levels):
     """coarseSolveType "GMRES": Jacobi-preconditioned FGMRES(10), one restart, tol 1e-2, on the coarsest level
-    (mg_set_coarse_gmres_FP64 <-> MGcycle.jl:152-168) against the oracle's restatement; blocks are rejected as the
-    reference's blockFGMRES branch is not on the device path."""
+    (mg_set_coarse_gmres_FP64 <-> MGcycle.jl:152-168) against the oracle's restatement, one right-hand side (fgmres) and
+    blocks (blockFGMRES, l.164-166)."""
     A, mesh = mg.poisson_shifted(cells)
     p = mg.getMGparam(np.float64, np.int64, levels, 8, 8, 1e-10, "Jac", 0.8, 2, 1, cyc, "GMRES", 0.5, 0.0)
     mg.MGsetup(A, mesh, p, 1)
     b = mg.seeded_rhs(A, 1)
     _compare_solve(mg, p, b)
     mg.clear_(p)
-    mg.MGsetup(A, mesh, p, 2)
-    b2 = mg.seeded_rhs(A, 2)
-    with pytest.raises(mg.device.MGDeviceError):
-        mg.solveMG(p, b2, np.zeros_like(b2))
-    mg.clear_(p)
+    # a block of right-hand sides takes the blockFGMRES branch (MGcycle.jl:164-166)
+    for nrhs in (2, 3):
+        mg.MGsetup(A, mesh, p, nrhs)
+        b2 = mg.seeded_rhs(A, nrhs)
+        _compare_solve(mg, p, b2)
+        mg.clear_(p)
 
 
 @pytest.mark.gpu

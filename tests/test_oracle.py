@@ -253,3 +253,21 @@ def test_gmres_coarse_solve_oracle():
         hist[cst] = h["resvec"]
     assert hist["GMRES"][-1] < 1e-4 * hist["GMRES"][0]
     assert hist["GMRES"][-1] >= hist["NoMUMPS"][-1] * 0.5                # never better than the exact coarse solve by much
+
+
+def test_gmres_coarse_solve_oracle_block_branch():
+    """The same with a block of right-hand sides: the coarsest level goes through blockFGMRES (MGcycle.jl:164-166); the block
+    solve contracts like the single-vector one and its coarsest solve meets the branch's own tolerance (1e-2, Frobenius)."""
+    import multigrid_jl_amd as mg
+    A, mesh = mg.poisson_shifted([16, 16, 16])
+    p = mg.getMGparam(np.float64, np.int64, 3, 8, 10, 1e-8, "Jac", 0.8, 2, 1, "V", "GMRES", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p, 3)
+    b = mg.seeded_rhs(A, 3)
+    x = np.zeros_like(b)
+    h = {}
+    orc.solveMG(p, b, x, False, h)
+    assert h["resvec"][-1] < 1e-4 * h["resvec"][0]
+    Ac = p.As[-1]
+    bc = np.random.default_rng(5).standard_normal((Ac.shape[0], 3))
+    xc = orc.solveCoarsest(p, bc, np.zeros_like(bc))
+    assert np.linalg.norm(Ac @ xc - bc) <= 1.5e-2 * np.linalg.norm(bc)
