@@ -926,6 +926,18 @@ struct TileDev {
   int chunks;           // ceil(P / RT_CR)
   int nblocks;          // ceil(nplanes / RT_NP) * chunks
   int n_cols;
+  // per-lane walk (round 2): every lane walks the records of its own rows' class once for its RT_NP rows - the planes of
+  // a lane share the in-plane position and, away from the first and last plane, the class - from a dictionary padded to
+  // maxlen records per class in LDS (value 0 beyond a class's length: no predication).  Set by the host when every
+  // dictionary entry is a staged shift and ncls * maxlen <= RT_LCAP.
+  int lane;
+  int ncls, maxlen;
+};
+constexpr int RT_LCAP = 1024;   // records of the padded dictionary (16 B each)
+struct TileRec {
+  double val;
+  int off8;   // byte offset of the gathered entry relative to (slot 0, lane 0)
+  int pad;
 };
 
 template <int MODE, bool EXC>
@@ -966,11 +978,70 @@ __global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_til
       win[q * SL + i] = v.x[gi];
     }
   }
+  TileRec* drec = reinterpret_cast<TileRec*>(win + (RT_NP + 2) * SL);     // [ncls][maxlen] (T.lane only)
+  double* ddl = reinterpret_cast<double*>(drec + (T.lane ? T.ncls * T.maxlen : 0));
+  const bool class_dl = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
+  if (T.lane) {
+    for (int i = tid; i < T.ncls * T.maxlen; i += RT_CR) {
+      const int cc = i / T.maxlen, k = i - cc * T.maxlen;
+      const int s = C.cls_ptr[cc], len = C.cls_ptr[cc + 1] - s;
+      TileRec r;
+      r.val = k < len ? C.cls_val[s + k] : 0.0;
+      r.off8 = T.tile_lb[s + (k < len ? k : 0)] * 8;
+      r.pad = 0;
+      drec[i] = r;
+    }
+    for (int i = tid; i < T.ncls; i += RT_CR) ddl[i] = class_dl ? C.cls_d[i] : 0.0;
+  }
   __syncthreads();
   const unsigned long long lanebit = 1ull << lane;
   unsigned long long todo[RT_NP];
 #pragma unroll
   for (int j = 0; j < RT_NP; ++j) todo[j] = __ballot(live[j]);
+  if (T.lane) {
+    // the class of the lane's first live row; do all its live rows share it?
+    int cref = 0;
+    bool anylive = false, mixed = false;
+#pragma unroll
+    for (int j = RT_NP - 1; j >= 0; --j)
+      if (live[j]) {
+        cref = cls[j];
+        anylive = true;
+      }
+#pragma unroll
+    for (int j = 0; j < RT_NP; ++j) mixed = mixed || (live[j] && cls[j] != cref);
+    const char* wb = reinterpret_cast<const char*>(win) + tid * 8;
+    const int SL8 = SL * 8;
+    if (__ballot(mixed) == 0ull) {
+      if (__ballot(anylive) != 0ull) {
+        const TileRec* rp = drec + cref * T.maxlen;
+#pragma unroll 3
+        for (int k = 0; k < T.maxlen; ++k) {
+          const TileRec r = rp[k];
+          const char* a0 = wb + r.off8;
+#pragma unroll
+          for (int j = 0; j < RT_NP; ++j) acc[j] = acc[j] + r.val * *reinterpret_cast<const double*>(a0 + j * SL8);
+        }
+      }
+    } else {   // (a tile that holds the first or the last plane: the rows of a lane differ in class)
+#pragma unroll
+      for (int j = 0; j < RT_NP; ++j) {
+        const TileRec* rp = drec + (live[j] ? cls[j] : 0) * T.maxlen;
+        const char* a0 = wb + j * SL8;
+        for (int k = 0; k < T.maxlen; ++k) {
+          const TileRec r = rp[k];
+          acc[j] = acc[j] + r.val * *reinterpret_cast<const double*>(a0 + r.off8);
+        }
+      }
+    }
+    if (class_dl) {
+#pragma unroll
+      for (int j = 0; j < RT_NP; ++j)
+        if (live[j]) pd[j] = ddl[cls[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < RT_NP; ++j) todo[j] = 0ull;
+  }
   for (;;) {
     int cc = 0, lead = 0;
     bool any = false;

@@ -60,7 +60,7 @@ struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
-  bool no_march2 = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_march2 = false, no_tile_lane = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -87,7 +87,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -200,6 +200,7 @@ struct Csr {
   bool rc_march2 = false;   // csr_rowclass_march2_spmv can serve a sweep + residual pair on this operator
   int rm2_nblocks = 0;
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
+  bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
   int rw_doubles = 0;   // x entries a workgroup of csr_rowclass_window_spmv stages in LDS
   DevBuf<unsigned short> rc_cls;
   DevBuf<double> rc_val, rc_d;
@@ -279,7 +280,14 @@ struct Csr {
     t.chunks = rt_chunks;
     t.nblocks = rt_nblocks;
     t.n_cols = (int)n_cols;
+    t.lane = rt_lane ? 1 : 0;
+    t.ncls = (int)rc_ncls;
+    t.maxlen = rc_maxlen;
     return t;
+  }
+  size_t tile_lds_bytes() const {
+    return (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * rt_halo) * sizeof(double) +
+           (rt_lane ? (size_t)rc_ncls * (size_t)rc_maxlen * 16 + (size_t)rc_ncls * 8 : 0);
   }
   mgk::RowClassDev rcdev() const {
     mgk::RowClassDev c;
@@ -636,7 +644,7 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
         else hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<MODE, false, false>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
       }
     } else if (M.rc_tile && v.y != v.x) {   // (the staged variants read x workgroup-wide: never in place)
-      const size_t lds = (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * M.rt_halo) * sizeof(double);
+      const size_t lds = M.tile_lds_bytes();
       nb_main = M.rt_nblocks;
       static bool lds_attr_set[3] = {false, false, false};   // up to 80 KiB of dynamic LDS: lift the 64 KiB default once
       if (!lds_attr_set[MODE]) {
@@ -2215,6 +2223,9 @@ int build_tile(Csr& A, const long long grid[3]) {
   A.rt_P = (int)P;
   A.rt_nplanes = (int)grid[2];
   A.rt_halo = (int)halo;
+  A.rt_lane = !A.opt.no_tile_lane && std::all_of(lbs.begin(), lbs.end(), [](int v) { return v >= 0; }) &&
+              A.rc_ncls * (long long)A.rc_maxlen <= mgk::RT_LCAP &&
+              (mgk::RT_NP + 2) * SL * 8 + A.rc_ncls * (long long)A.rc_maxlen * 16 + A.rc_ncls * 8 <= 80 * 1024;
   A.rt_chunks = (int)((P + mgk::RT_CR - 1) / mgk::RT_CR);
   A.rt_nblocks = (int)(((grid[2] + mgk::RT_NP - 1) / mgk::RT_NP) * A.rt_chunks);
   {
