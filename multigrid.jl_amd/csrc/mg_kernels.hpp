@@ -752,6 +752,99 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
 }
 
 // ------------------------------------------------------------------------------------------------
+// Prolongation-shaped row-class product with the SOURCE staged in LDS (round 2): y = alpha*M*x + beta*y for an operator
+// whose rows are a fine grid (PF rows per plane) and whose columns are a coarse grid (PC columns per plane), every row
+// gathering from at most two consecutive coarse planes inside a narrow in-plane window - a prolongation: x += P*xc
+// (MGcycle.jl:90).  csr_rowclass_lane_spmv spends its time waiting for 1..8 gathers of xc per fine row (L2 / Infinity
+// Cache).  Here a workgroup owns WP_ROWS consecutive rows of ONE fine plane, stages the two coarse-plane windows its rows
+// read (2*W doubles, coalesced loads) in LDS, and the per-lane class walk reads LDS; the per-row first column is replaced
+// by its 16-bit index inside the window (wf).  All tables are derived from the DATA by the host (build_winp), which also
+// checks that every column of every row falls inside the staged windows; nothing here knows what a prolongation is.
+// Same products in the same order and the same epilogue as the lane kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int WP_ROWS = 4 * BLK;   // rows of one fine plane per workgroup (lane t: rows t, t + 256, t + 512, t + 768)
+struct WinPDev {
+  const unsigned short* wf;   // per row: index of the row's first column inside the first staged window
+  const int* cz0;             // per fine plane: the coarse plane of its rows' first columns, bit 30 set when the plane's rows read ONLY that coarse plane
+  const int* wlo;             // per chunk: in-plane index of the first staged coarse entry
+  const int* code;            // per dictionary entry: dzc*W + rest (column offset = dzc*PC + rest)
+  int PF, nplanes, PC, W, chunks, nblocks, n_cols, ncls, nent, maxlen;
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(BLK) void csr_rowclass_winp_spmv(RowClassDev C, VecArgs v, WinPDev T) {
+  extern __shared__ double win[];                                  // [2*W] coarse windows | dictionary
+  LaneEnt* ent = reinterpret_cast<LaneEnt*>(win + 2 * T.W);        // [ncls][maxlen] {value or 0, BYTE code}: padded dictionary
+  const int tid = threadIdx.x;
+  const int bid = xcd_band(blockIdx.x, T.nblocks);
+  const int z = bid / T.chunks, c = bid - z * T.chunks;
+  int row[4], cq[4], wfi[4];
+  bool in[4];
+  double pb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = c * WP_ROWS + j * BLK + tid;
+    in[j] = p < T.PF;
+    row[j] = z * T.PF + p;
+    const int rr = in[j] ? row[j] : C.n_rows - 1;
+    cq[j] = C.cls[rr];
+    wfi[j] = T.wf[rr];
+    pb[j] = (v.beta != 0.0) ? v.beta * v.y[rr] : 0.0;
+  }
+  {
+    const int czz = T.cz0[z];
+    const long long base0 = (long long)(czz & 0x3FFFFFFF) * T.PC + T.wlo[c];
+    const int nstage = (czz & 0x40000000) ? T.W : 2 * T.W;   // (a plane whose rows read one coarse plane: one window)
+    for (int i = tid; i < nstage; i += BLK) {
+      const bool second = i >= T.W;
+      long long col = base0 + (second ? (long long)T.PC + (i - T.W) : (long long)i);
+      col = col < 0 ? 0 : (col > T.n_cols - 1 ? T.n_cols - 1 : col);
+      win[i] = v.x[col];
+    }
+  }
+  // records beyond a class's length: value 0 at the class's first entry (they add +-0: no clamps, no predicated additions)
+  for (int i = tid; i < T.ncls * T.maxlen; i += BLK) {
+    const int cc = i / T.maxlen, k = i - cc * T.maxlen;
+    const int s0 = C.cls_ptr[cc], ln = C.cls_ptr[cc + 1] - s0;
+    LaneEnt e;
+    e.val = k < ln ? C.cls_val[s0 + k] : 0.0;
+    e.off = T.code[s0 + (k < ln ? k : 0)] * 8;
+    e.pad = ln;   // (the class's length rides in every record)
+    ent[i] = e;
+  }
+  __syncthreads();
+  const LaneEnt* rp[4];
+  const char* wb[4];
+  double acc[4];
+  int lenmax = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    rp[j] = ent + cq[j] * T.maxlen;
+    wb[j] = reinterpret_cast<const char*>(win) + wfi[j] * 8;
+    acc[j] = 0.0;
+    if (in[j]) lenmax = max(lenmax, rp[j][0].pad);
+  }
+  for (int k = 0; k < T.maxlen; k += 4) {
+    if (k > 0 && __ballot(lenmax > k) == 0ull) break;   // no row of this wavefront is longer (padded records would add 0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      LaneEnt e[4];
+      double g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) e[u] = rp[j][min(k + u, T.maxlen - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const double*>(wb[j] + e[u].off);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + u < T.maxlen) acc[j] = acc[j] + e[u].val * g[u];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (in[j]) v.y[row[j]] = epilogue<AXPBY>(v, row[j], acc[j], pb[j], 0.0, 0.0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row-class SpMV with LDS windows (square operators in the implicit-first form).
 // The plain row-class kernel above is bound by L2->L1 line traffic: every dictionary entry is its own gather and
 // the y+-1 / z+-1 neighbours of a grid row arrive as separate, unaligned 512-byte requests (~25 cache lines of x

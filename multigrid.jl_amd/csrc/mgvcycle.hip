@@ -60,12 +60,13 @@ struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
-  bool no_march2 = false, no_tile_lane = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_march2 = false, no_tile_lane = false, no_winp = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
   long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
   long long march_wg_per_cu = 2;   // resident workgroups per CU of the marching kernel (49 KB of LDS each)
+  long long winp_min_rows = 100000;   // smallest prolongation-shaped operator served by csr_rowclass_winp_spmv
   long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
   bool dist_tail_graph = false;   // replay the replicated tail of the sharded sequencer as a HIP graph (measured slower)
   bool no_graph = false, no_lane_pairs = false;
@@ -87,7 +88,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -96,7 +97,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
       MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
       MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
-      MG_OPT("MG_MARCH_WG_PER_CU", "march_wg_per_cu", 1, march_wg_per_cu),
+      MG_OPT("MG_MARCH_WG_PER_CU", "march_wg_per_cu", 1, march_wg_per_cu), MG_OPT("MG_WINP_MIN_ROWS", "winp_min_rows", 1, winp_min_rows),
       MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_DIST_TAIL_GRAPH", "dist_tail_graph", 0, dist_tail_graph), MG_OPT("MG_NO_LANE_PAIRS", "no_lane_pairs", 0, no_lane_pairs), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
       MG_OPT("MG_LU_MULTI_MIN_ROWS", "lu_multi_min_rows", 1, lu_multi_min_rows),
       MG_OPT("MG_LU_DENSE_TAIL_MAX", "lu_dense_tail_max", 1, lu_dense_tail_max),
@@ -201,6 +202,30 @@ struct Csr {
   int rm2_nblocks = 0;
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
+  // csr_rowclass_winp_spmv (prolongation-shaped operators: the source windows of a workgroup's rows staged in LDS)
+  bool rp_ok = false;
+  DevBuf<unsigned short> rp_wf;
+  DevBuf<int> rp_cz0, rp_wlo, rp_code;
+  int rp_PF = 0, rp_nplanes = 0, rp_PC = 0, rp_W = 0, rp_chunks = 0;
+  mgk::WinPDev winpdev() const {
+    mgk::WinPDev t;
+    t.wf = rp_wf.p;
+    t.cz0 = rp_cz0.p;
+    t.wlo = rp_wlo.p;
+    t.code = rp_code.p;
+    t.PF = rp_PF;
+    t.nplanes = rp_nplanes;
+    t.PC = rp_PC;
+    t.W = rp_W;
+    t.chunks = rp_chunks;
+    t.nblocks = rp_chunks * rp_nplanes;
+    t.n_cols = (int)n_cols;
+    t.ncls = (int)rc_ncls;
+    t.nent = (int)rc_entries;
+    t.maxlen = rc_maxlen;
+    return t;
+  }
+  size_t winp_lds_bytes() const { return (size_t)2 * rp_W * 8 + (size_t)rc_ncls * (size_t)rc_maxlen * 16; }
   int rw_doubles = 0;   // x entries a workgroup of csr_rowclass_window_spmv stages in LDS
   DevBuf<unsigned short> rc_cls;
   DevBuf<double> rc_val, rc_d;
@@ -323,6 +348,8 @@ struct Csr {
     rc_tile = false;
     rc_march = false;
     rc_march2 = false;
+    rp_ok = false;
+    rp_wf.release();
     h_rc_ptr.clear();
     h_rc_off.clear();
     h_rc_delta.clear();
@@ -662,6 +689,11 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
       const size_t lds = (size_t)M.rw_doubles * sizeof(double);
       if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, true>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
       else hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, false>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
+    } else if (MODE == mgk::AXPBY && M.rp_ok && phase == 0 && v.y != v.x) {
+      // a prolongation-shaped operator: the coarse windows of a workgroup's rows staged in LDS (no exception rows)
+      const mgk::WinPDev T = M.winpdev();
+      nb_main = T.nblocks;
+      hipLaunchKernelGGL((mgk::csr_rowclass_winp_spmv<0>), dim3(nb_main), blk, M.winp_lds_bytes(), stream, C, v, T);
     } else if (M.rc_lane()) {
       nb_main = M.rc_blocks();
       mgk::LaneDev T;
@@ -2295,6 +2327,98 @@ int build_march(Csr& A, const long long grid[3]) {
   return MG_OK;
 }
 
+// Prolongation-shaped operators (csr_rowclass_winp_spmv): rows = a fine grid gf, columns = a coarse grid gc, explicit
+// first columns.  Everything is derived from the stored pattern and checked against it: the coarse plane of each fine
+// plane's first columns (cz0), the split of every dictionary offset into plane shift (0 or 1) + in-plane rest, per chunk
+// of WP_ROWS in-plane rows the window [wlo, wlo + W) of coarse in-plane indices its rows read in any plane, and per row
+// the 16-bit index of its first column inside that window.  Any row that does not fit drops the operator back to the
+// lane kernel.
+int build_winp(Csr& M, const long long gf[3], const long long gc[3]) {
+  if (M.rp_ok && M.rp_PF == gf[0] * gf[1] && M.rp_nplanes == gf[2] && M.rp_PC == gc[0] * gc[1]) return MG_OK;   // (same pattern, same hints)
+  M.rp_ok = false;
+  if (!M.has_rc || M.rc_implicit || M.rc_nexc != 0 || M.opt.no_winp || M.regular_cols >= 0) return MG_OK;
+  if (gf[0] < 1 || gf[1] < 1 || gf[2] < 1 || gc[0] < 1 || gc[1] < 1 || gc[2] < 1) return MG_OK;
+  if (gf[0] * gf[1] * gf[2] != M.n_rows || gc[0] * gc[1] * gc[2] != M.n_cols) return MG_OK;
+  if (M.h_rp.size() != (size_t)M.n_rows + 1 || M.h_cls.size() != (size_t)M.n_rows || M.h_rc_ptr.empty()) return MG_OK;
+  if (M.rc_ncls * (long long)M.rc_maxlen > 1024 || M.n_rows < M.opt.winp_min_rows) return MG_OK;   // the padded dictionary lives in LDS (16 KB)
+  const long long PF = gf[0] * gf[1], PC = gc[0] * gc[1], nz = gf[2];
+  if (PF >= (1LL << 30) || PC < 4) return MG_OK;
+  const size_t ncls = M.h_rc_ptr.size() - 1;
+  std::vector<long long> rest(M.h_rc_off.size());
+  std::vector<int> dzc(M.h_rc_off.size());
+  std::vector<long long> cmin(ncls, 0), cmax(ncls, 0);   // per class: smallest / largest in-plane rest, second plane shifted by 0
+  std::vector<char> csecond(ncls, 0);
+  for (size_t c = 0; c < ncls; ++c)
+    for (int k = M.h_rc_ptr[c]; k < M.h_rc_ptr[c + 1]; ++k) {
+      const long long off = M.h_rc_off[(size_t)k];
+      if (off < 0) return MG_OK;
+      const long long d = (off + PC / 2) / PC;
+      if (d > 1) return MG_OK;
+      dzc[(size_t)k] = (int)d;
+      rest[(size_t)k] = off - d * PC;
+      cmin[c] = std::min(cmin[c], rest[(size_t)k]);
+      cmax[c] = std::max(cmax[c], rest[(size_t)k]);
+      if (d) csecond[c] = 1;
+    }
+  std::vector<int> cz0((size_t)nz, INT_MAX);
+  for (long long z = 0; z < nz; ++z)
+    for (long long p = 0; p < PF; ++p) {
+      const long long i = z * PF + p;
+      if (M.h_rp[(size_t)i + 1] == M.h_rp[(size_t)i]) return MG_OK;   // an empty row has no first column
+      cz0[(size_t)z] = std::min<long long>(cz0[(size_t)z], M.h_ci[(size_t)M.h_rp[(size_t)i]] / PC);
+    }
+  const long long chunks = (PF + mgk::WP_ROWS - 1) / mgk::WP_ROWS;
+  std::vector<long long> lo((size_t)chunks, LLONG_MAX), hi((size_t)chunks, LLONG_MIN);
+  std::vector<char> two((size_t)nz, 0);   // does any row of the plane read the second coarse plane?
+  for (long long z = 0; z < nz; ++z)
+    for (long long p = 0; p < PF; ++p) {
+      const long long i = z * PF + p;
+      const long long fi = (long long)M.h_ci[(size_t)M.h_rp[(size_t)i]] - (long long)cz0[(size_t)z] * PC;   // in-plane index of the first column
+      if (fi < 0 || fi >= PC) return MG_OK;
+      const unsigned short c = M.h_cls[(size_t)i];
+      if (c >= ncls) return MG_OK;
+      if (csecond[c] && (long long)cz0[(size_t)z] + 1 >= gc[2]) return MG_OK;   // would read past the last coarse plane
+      if (csecond[c]) two[(size_t)z] = 1;
+      const size_t ch = (size_t)(p / mgk::WP_ROWS);
+      lo[ch] = std::min(lo[ch], fi + cmin[c]);
+      hi[ch] = std::max(hi[ch], fi + cmax[c]);
+    }
+  long long W = 1;
+  for (size_t ch = 0; ch < (size_t)chunks; ++ch) W = std::max(W, hi[ch] - lo[ch] + 1);
+  W = (W + 1) & ~1LL;   // (the dictionary behind the windows stays 16-byte aligned)
+  if (W > 2048) return MG_OK;   // 32 KB of windows per workgroup at most (+ <= 16 KB of dictionary: below the 64 KB default)
+  std::vector<unsigned short> wf((size_t)M.n_rows);
+  for (long long z = 0; z < nz; ++z)
+    for (long long p = 0; p < PF; ++p) {
+      const long long i = z * PF + p;
+      const long long fi = (long long)M.h_ci[(size_t)M.h_rp[(size_t)i]] - (long long)cz0[(size_t)z] * PC;
+      const long long w = fi - lo[(size_t)(p / mgk::WP_ROWS)];
+      if (w < 0 || w >= W) return MG_OK;
+      wf[(size_t)i] = (unsigned short)w;
+    }
+  std::vector<int> code(M.h_rc_off.size()), wlo((size_t)chunks);
+  for (size_t k = 0; k < code.size(); ++k) code[k] = (int)(dzc[k] * W + rest[k]);
+  for (size_t ch = 0; ch < (size_t)chunks; ++ch) wlo[ch] = (int)lo[ch];
+  for (long long z = 0; z < nz; ++z)
+    if (!two[(size_t)z]) cz0[(size_t)z] |= 0x40000000;   // one window suffices for this plane
+  MG_TRY(M.rp_wf.alloc(wf.size()));
+  MG_TRY(M.rp_cz0.alloc(cz0.size()));
+  MG_TRY(M.rp_wlo.alloc(wlo.size()));
+  MG_TRY(M.rp_code.alloc(code.size()));
+  HIP_TRY(hipMemcpy(M.rp_wf.p, wf.data(), wf.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M.rp_cz0.p, cz0.data(), cz0.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M.rp_wlo.p, wlo.data(), wlo.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(M.rp_code.p, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
+  M.rp_PF = (int)PF;
+  M.rp_nplanes = (int)nz;
+  M.rp_PC = (int)PC;
+  M.rp_W = (int)W;
+  M.rp_chunks = (int)chunks;
+  M.rp_ok = true;
+  if (M.opt.debug_format) std::fprintf(stderr, "[mgvcycle] prolongation-shaped operator %lld x %lld: windows of %lld coarse entries per %d rows\n", M.n_rows, M.n_cols, W, mgk::WP_ROWS);
+  return MG_OK;
+}
+
 int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
   MG_TRY(build_schedule_for(M, grid, nrhs, M.h_blk_row, M.nblocks, M.sched, M.has_sched));
   M.ln_rows = M.ln_blocks = 0;
@@ -2348,6 +2472,7 @@ int alloc_scratch(mg_hierarchy* h) {
       MG_TRY(build_march(L.A, L.grid));
       MG_TRY(build_schedule(L.P, L.grid, k));
       if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
+      if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_winp(L.P, L.grid, h->lev[(size_t)l + 1].grid));
     }
   }
   long long nmax = 0;

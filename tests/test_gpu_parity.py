@@ -765,6 +765,48 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cells,levels", [([32, 32, 32], 3), ([33, 25, 7], 2), ([40, 30, 9], 3), ([23, 23, 23], 3), ([31, 16, 12], 2),
+                                          ([64, 64, 20], 3), ([70, 10, 12], 2)])
+def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, levels):
+    """csr_rowclass_winp_spmv (x += P*xc with the coarse windows of a workgroup's rows staged in LDS, tables derived from
+    P's pattern at upload): products against scipy for several (alpha, beta), bit-identical to the lane kernel's
+    (MG_NO_WINP=1), and the solve against the oracle - on odd and even node counts (the even-count variants of
+    getFWInterp, GeometricTransferOperators.jl:35-36, either fit the windows or fall back)."""
+    import torch
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    monkeypatch.setenv("MG_WINP_MIN_ROWS", "0")
+    outs = {}
+    for name, no in (("windows", "0"), ("lane", "1")):
+        rng = np.random.default_rng(sum(cells) + 3)           # the same vectors for both runs
+        monkeypatch.setenv("MG_NO_WINP", no)
+        A, p, b = _setup(mg, cells, levels, maxIter=5)
+        h = mg.to_device(p)
+        res = []
+        for l in range(1, p.levels):
+            P = p.Ps[l - 1]
+            Pm = P if P.shape[0] == p.As[l - 1].shape[0] else P.T          # fine x coarse
+            xc = rng.standard_normal(Pm.shape[1])
+            y0 = rng.standard_normal(Pm.shape[0])
+            for alpha, beta in ((1.0, 1.0), (1.0, 0.0), (-0.5, 2.0)):
+                y = torch.from_numpy(y0.copy()).cuda()
+                h.spmv_dev(l, D.MG_OP_P, alpha, torch.from_numpy(xc).cuda(), beta, y)
+                want = alpha * (Pm @ xc) + beta * y0
+                got = y.cpu().numpy()
+                assert np.abs(got - want).max() / np.abs(want).max() < KERNEL_TOL
+                res.append(got)
+        x, hist = _compare_solve(mg, p, b)
+        outs[name] = (res, x.copy(), np.asarray(p.resvec).copy())
+        mg.clear_(p)
+    for a, bb in zip(outs["windows"][0], outs["lane"][0]):
+        assert np.array_equal(a, bb)
+    assert np.array_equal(outs["windows"][1], outs["lane"][1])
+    assert np.array_equal(outs["windows"][2], outs["lane"][2])
+
+
+@pytest.mark.gpu
 def test_march_with_wrong_grid_hint_and_exception_rows(mg, built, monkeypatch):
     """The marching kernel with a hint that describes the wrong grid (unstaged shifts gather from global memory) and
     with a few perturbed rows (exception rows computed from the CSR arrays): the solve is still the oracle's."""
