@@ -1558,9 +1558,6 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
 // kernels: t, r and t + d.*r are bit-identical to theirs.  Operators without exception rows whose relaxPrec is
 // constant per class (host: march2_ok); one workgroup per CU (125 KB of LDS), 128 VGPRs.
 // ------------------------------------------------------------------------------------------------
-#ifndef MG_M2X
-#define MG_M2X 0   // attribution builds: 1 / 2 / 4 = skip the class walk of stage 1 core / stage 1 halo / stage 2; 8 = no x loads
-#endif
 struct March2Args {
   const double* x;   // the iterate before the sweep                    [n_rows]
   const double* b;   //                                                 [n_rows]
@@ -1731,7 +1728,7 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
         if (a.r) a.r[st_rrow] = st_r;
         if (a.xn) a.xn[st_rrow] = st_xn;
       }
-      if (z + 3 <= z1 + 1 && !(MG_M2X & 8)) {
+      if (z + 3 <= z1 + 1) {
         pre0 = march_load_pair(a.x, M2_E0(c, z + 3, 0), pact0, T.n_cols);
         pre1 = march_load_pair(a.x, M2_E0(c, z + 3, 1), pact1, T.n_cols);
       }
@@ -1744,7 +1741,6 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
           const int cq = livec ? clsc : 0;
           const int j = tid + H;
           double acc = 0.0;
-#if !(MG_M2X & 1)
           if (regs) {
             if (cq != ccls) {
               M2_LOADRECS(cv, co, cq, j);
@@ -1756,7 +1752,6 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
             asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));   // (opaque: else the compiler branches per entry)
             M2_WALK(acc, xw, w0, w1, w2, cq, livec);
           }
-#endif
           if (livec) {
             const double own = xw[xbz + j + H];
             const double tv = own + dd[cq] * (bc - acc);
@@ -1770,7 +1765,6 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
         if (hact) {
           const int cq = liveh ? clsh : 0;
           double acc = 0.0;
-#if !(MG_M2X & 2)
           if (regs) {
             if (cq != hcls) {
               M2_LOADRECS(hv, ho, cq, hj);
@@ -1782,7 +1776,6 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
             asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
             M2_WALK(acc, xw, w0, w1, w2, cq, liveh);
           }
-#endif
           if (liveh) {
             const double own = xw[xbz + hj + H];
             tw[(q & 3) * SLTP + hj] = own + dd[cq] * (bh - acc);
@@ -1795,7 +1788,6 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
         const int tbz = ((q - 2) & 3) * SLTP + tid;    // entry of column ip + rest: (tid + H) + rest = tid + (code >> 2)
         const int cq = livec ? cls2 : 0;
         double acc = 0.0;
-#if !(MG_M2X & 4)
         if (regs) {
           if (cq != ccls) {
             M2_LOADRECS(cv, co, cq, tid + H);
@@ -1807,7 +1799,6 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
           asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
           M2_WALK(acc, tw, w0, w1, w2, cq, livec);
         }
-#endif
         if (livec) {
           const double own = tw[tbz + H];
           const double rv = b2 - acc;

@@ -514,6 +514,8 @@ double spmv_bytes(const Csr& M, long long nrhs, bool reads_y_or_b, bool smooth) 
 
 // Matrix-side bytes one launch of the kernel IN USE streams for M (the device format chosen at upload).
 double format_bytes(const Csr& M, long long nrhs) {
+  if (M.has_rc && nrhs == 1 && M.rp_ok)   // LDS-staged prolongation: class id + 16-bit window index per row
+    return 4.0 * (double)M.n_rows + 12.0 * (double)M.rc_entries;
   if (M.has_rc && (nrhs == 1 || (M.rc_lane_mm() && M.ln_blocks > 0)))   // (block right-hand sides: the lane SpMM)
     return (M.rc_implicit ? 2.0 : 6.0) * (double)M.n_rows + 12.0 * (double)M.rc_entries;
   if (nrhs == 1 && M.has_pat)
