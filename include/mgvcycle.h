@@ -348,6 +348,10 @@ int mg_vec_sumsq_dev_FP64(const double* x_dev, long long len, double* workspace_
 int mg_set_stream(mg_hierarchy* h, void* stream);
 int mg_cycle_async_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n,
                             long long nrhs, long long x_is_zero);
+/* The K-cycle's step INTO the hierarchy's first level (MGcycle.jl:72-76): x = 2 steps of FGMRES_relaxation on A_1 x = b
+ * from x = 0, preconditioned by the K-cycle of level 1.  Used by the sharded sequencer when the level above the
+ * replicated tail runs a K-cycle; one right-hand side; enqueues on the handle's stream (the FGMRES dots synchronise). */
+int mg_kcycle_step_async_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n);
 
 /* ---- hybrid Kaczmarz relaxation --------------------------------------------------------------------------
  * Replaces the reference's native applyHybridKaczmarz_FP64_INT64 (deps/src/parRelax.h:7-43; ccall at
@@ -410,6 +414,11 @@ int mg_dist_set_level(mg_dist* h, long long level, long long n_own, long long n_
 /* Halo plan of one operator: the source vector is [n_own_src owned | n_halo received]; send_idx (0-based, into the owned
  * part) grouped by destination rank with send_splits[world]; recv_splits[world]; active = 0 if no rank exchanges anything. */
 /* The level's A was handed over as ONE box operator (A_int, n_int = n_own, A_bnd = NULL): phase 1 overlaps the exchange. */
+/* Smoother of the sharded levels: 0 = pointwise (Jac / SPAI: the relaxPrec vectors), 1 = Jac-GMRES (FGMRES_relaxation
+ * preconditioned by the relaxPrec vector, relaxPre / relaxPost = its inner dimensions: MGcycle.jl:48-50,96-98).  The
+ * replicated tail carries its own setting (mg_set_relax_type).  cycleType 'K' (mg_dist_create) runs the K-cycle's FGMRES
+ * steps on sharded levels with all-reduced dots (MGcycle.jl:72-76). */
+int mg_dist_set_relax_type(mg_dist* h, long long relax_type);
 int mg_dist_set_level_box(mg_dist* h, long long level, long long on);
 int mg_dist_set_plan_INT64(mg_dist* h, long long level, long long which, long long n_own_src, long long n_halo,
                            long long n_send, const long long* send_idx, const long long* send_splits,

@@ -482,6 +482,7 @@ struct mg_hierarchy {
   double* h_blk_c = nullptr;           // pinned ring of coefficient matrices
   unsigned blk_c_next = 0;
   DevBuf<double> kwc_blk;   // the same for a block of right-hand sides (blockFGMRES branch, MGcycle.jl:166)
+  DevBuf<double> kstepZ, kstepAZ, kstepX;   // mg_kcycle_step_async_dev_FP64: the K-step INTO this hierarchy's first level
   DevBuf<double> kwc, coarse_d;   // coarseSolveType "GMRES": FGMRES work space and the Jacobi preconditioner of the coarsest level
   bool coarse_gmres = false;
   // fine-level operands of the last cycle/solve (used as inputs by mg_time_op_dev_FP64)
@@ -4603,6 +4604,9 @@ struct DistLevel {
   mg_operator *A_int = nullptr, *A_bnd = nullptr, *P = nullptr, *R = nullptr;   // borrowed handles
   const double* d = nullptr;                                                    // borrowed device vector (n_own)
   long long npre = 1, npost = 1;
+  long long npre_raw = 1, npost_raw = 1;   // relaxPre/relaxPost(level) as given: the inner dimension of a Jac-GMRES relaxation
+  DevBuf<double> relZ, relAZ;              // FGMRESmem (FGMRES.jl:3-8) of the Jac-GMRES smoother: Z (with halo tail each), A*Z
+  DevBuf<double> kZ, kAZ;                  // memKcycle: the 2-step FGMRES of a K-cycle INTO this level
   bool box = false;   // A_int is a box operator (mg_op_create_box_FP64_INT64): phase 1 overlaps the exchange, phase 2 follows it
   DistPlan planA, planR, planP;
   long long cap_x = 0, cap_r = 0;
@@ -4630,6 +4634,7 @@ struct mg_dist {
   hipEvent_t ev_packed = nullptr, ev_landed = nullptr;
   std::vector<DistLevel> lev;
   char cycle = 'V';
+  int relax_type = 0;                   // 0: pointwise (Jac / SPAI), 1: Jac-GMRES (MGcycle.jl:48-50,96-98)
   bool finalized = false;
   // replicated tail
   mg_hierarchy* tail = nullptr;
@@ -4769,6 +4774,85 @@ int dist_residual_norm(mg_dist* h, DistLevel& L, double* x, const double* b, dou
   return MG_OK;
 }
 
+// dot(x, y) over all ranks (local partial sums + one scalar all-reduce); the same bits on every rank
+int dist_dot(mg_dist* h, const double* x, const double* y, long long n, double* out) {
+  const int nb = (int)std::max<long long>(1, std::min<long long>((long long)h->partial.n, (n / 2 + mgk::BLK - 1) / mgk::BLK));
+  hipLaunchKernelGGL(mgk::dot_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, x, y, n, h->partial.p);
+  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb, h->scalar.p);
+  HIP_TRY(hipGetLastError());
+  double nrm = 0.0;
+  MG_TRY(dist_reduce_scalar(h, &nrm));   // sqrt of the all-reduced sum ...
+  *out = *h->h_scalar;                   // ... whose raw value stays in the pinned scalar
+  return MG_OK;
+}
+int dist_axpby(mg_dist* h, double a, const double* x, double b, double* y, long long n) {
+  hipLaunchKernelGGL(mgk::axpby_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, a, x, b, y, n);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+int dist_fill(mg_dist* h, double* x, long long n, double val) {
+  hipLaunchKernelGGL(mgk::fill_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, x, n, val);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+// FGMRES_relaxation (FGMRES.jl:48-126) on a sharded level - the mirror of fgmres_relax: x0 += Z*t where t minimises
+// ||r0 - A Z t|| over the `inner` directions z_1 = M r0, z_j = M (A z_{j-1}).  Products with A exchange the halo of z (the
+// vectors of Z are cap_x long: owned rows + halo tail), dots are all-reduced, so the small pseudo-inverse and the
+// data-dependent exit (l.114-117) come out identical on every rank.
+extern "C++" {
+template <class Prec>
+int dist_fgmres_relax(mg_dist* h, DistLevel& L, const double* r0, double* x0, long long inner, Prec prec, double TOL,
+                      DevBuf<double>& Zbuf, DevBuf<double>& AZbuf, bool x0_is_zero) {
+  const long long n = L.n_own;
+  if (inner <= 0) {
+    if (x0_is_zero) MG_TRY(dist_fill(h, x0, n, 0.0));
+    return MG_OK;  // w = Z*t with no columns: x0 unchanged (FGMRES.jl:119-121)
+  }
+  const int k = (int)inner;
+  if (Zbuf.n < (size_t)k * (size_t)L.cap_x) {
+    MG_TRY(Zbuf.alloc((size_t)k * (size_t)L.cap_x));
+    HIP_TRY(hipMemsetAsync(Zbuf.p, 0, Zbuf.bytes(), h->stream));
+  }
+  if (AZbuf.n < (size_t)k * (size_t)n) MG_TRY(AZbuf.alloc((size_t)k * (size_t)n));
+  double rnorm0 = 0.0;
+  MG_TRY(dist_norm(h, r0, n, &rnorm0));
+  std::vector<double> H((size_t)k * k, 0.0), xi((size_t)k, 0.0), t((size_t)k, 0.0), Pinv;
+  int used = 0;
+  for (int j = 0; j < k; ++j) {
+    double* z = Zbuf.p + (size_t)j * (size_t)L.cap_x;
+    double* w = AZbuf.p + (size_t)j * (size_t)n;
+    MG_TRY(prec(j == 0 ? r0 : AZbuf.p + (size_t)(j - 1) * (size_t)n, z));   // z = prec(r0) / prec(w)   (l.83-87)
+    MG_TRY(dist_apply_A(h, L, MG_K_SPMV, z, w, nullptr));                    // w = A z                  (l.91)
+    used = j + 1;
+    for (int i = 0; i <= j; ++i) {                                           // t = AZ' * w              (l.95)
+      double d = 0.0;
+      MG_TRY(dist_dot(h, AZbuf.p + (size_t)i * (size_t)n, w, n, &d));
+      H[(size_t)i * k + j] = d;
+      H[(size_t)j * k + i] = d;
+    }
+    MG_TRY(dist_dot(h, w, r0, n, &xi[(size_t)j]));                           // xi[j] = dot(w, r0)       (l.97)
+    pinv_sym(H, k, Pinv);                                                    // t = pinv(H)*xi           (l.102)
+    double tHt = 0.0, txi = 0.0;
+    for (int a = 0; a < k; ++a) {
+      double sacc = 0.0;
+      for (int b = 0; b < k; ++b) sacc += Pinv[(size_t)a * k + b] * xi[(size_t)b];
+      t[(size_t)a] = sacc;
+    }
+    for (int a = 0; a < k; ++a) {
+      double sacc = 0.0;
+      for (int b = 0; b < k; ++b) sacc += H[(size_t)a * k + b] * t[(size_t)b];
+      tHt += t[(size_t)a] * sacc;
+      txi += t[(size_t)a] * xi[(size_t)a];
+    }
+    const double rn = std::sqrt(std::fabs(tHt - 2.0 * txi + rnorm0 * rnorm0));   // l.104
+    if (rn < TOL) break;                                                          // l.114-117
+  }
+  for (int j = 0; j < used; ++j)                                             // x0 += Z*t                (l.121-123)
+    MG_TRY(dist_axpby(h, t[(size_t)j], Zbuf.p + (size_t)j * (size_t)L.cap_x, (j == 0 && x0_is_zero) ? 0.0 : 1.0, x0, n));
+  return MG_OK;
+}
+}  // extern "C++"
+
 // the sharded cycle: mirror of cycle_level (MGcycle.jl:1-118); returns the buffer holding x
 int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
                bool r_valid = false, bool x1_ready = false) {
@@ -4776,7 +4860,19 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
   double *cur = xa, *alt = xb;
   long long npre = L.npre;
   const long long npost = L.npost;
-  if (x_zero) {
+  const double gmresTol = 1e-5;  // MGcycle.jl:5
+  auto diag_prec = [&](const double* v, double* z) { return mg_vec_dscale_dev_FP64(L.d, v, z, L.n_own, 1, h->stream); };   // MM (l.36-38)
+  if (h->relax_type == 1) {      // Jac-GMRES (MGcycle.jl:48-50): FGMRES on the residual, preconditioned by D
+    const double* r0 = b;
+    if (x_zero) {
+      MG_TRY(dist_fill(h, cur, L.n_own, 0.0));
+    } else {
+      if (!r_valid) MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
+      r0 = L.r.p;
+    }
+    MG_TRY(dist_fgmres_relax(h, L, r0, cur, L.npre_raw, diag_prec, gmresTol, L.relZ, L.relAZ, false));
+    npre = 0;
+  } else if (x_zero) {
     MG_TRY(mg_vec_dscale_dev_FP64(L.d, b, cur, L.n_own, 1, h->stream));
     --npre;
   } else if (r_valid) {
@@ -4795,7 +4891,20 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     DistLevel& C = h->lev[(size_t)l + 1];
     MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, C.b.p, nullptr, nullptr, 0));
     double* xc = nullptr;
-    MG_TRY(dist_cycle(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
+    if (ctype == 'K') {
+      // K-cycle (MGcycle.jl:72-76): 2 steps of FGMRES on A_{l+1} xc = bc, preconditioned by the K-cycle of level l+1
+      // (level l+1 is sharded, hence never the coarsest).  C.x0 doubles as scratch of the inner cycles (xc = 0 on entry).
+      auto kprec = [&](const double* v, double* z) {
+        double* res = nullptr;
+        MG_TRY(dist_cycle(h, l + 1, v, C.x0.p, C.x1.p, true, 'K', &res));
+        HIP_TRY(hipMemcpyAsync(z, res, sizeof(double) * (size_t)C.n_own, hipMemcpyDeviceToDevice, h->stream));
+        return (int)MG_OK;
+      };
+      MG_TRY(dist_fgmres_relax(h, C, C.b.p, C.x0.p, 2, kprec, gmresTol, C.kZ, C.kAZ, true));
+      xc = C.x0.p;
+    } else {
+      MG_TRY(dist_cycle(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
+    }
     if (ctype == 'W' || ctype == 'F') {
       double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
       MG_TRY(dist_cycle(h, l + 1, C.b.p, xc, other, false, ctype == 'W' ? 'W' : 'V', &xc));
@@ -4821,6 +4930,10 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     hipLaunchKernelGGL(dist_gather64, dim3((unsigned)((h->n_tail + 255) / 256)), dim3(256), 0, h->stream, h->bc_all.p, h->gather_index.p, h->b_tail.p, h->n_tail);
     HIP_TRY(hipGetLastError());
     MG_TRY(mg_set_cycle_type(h->tail, ctype));
+    if (ctype == 'K' && (long long)h->lev.size() < h->nl_total - 1) {
+      // the first replicated level is not the coarsest: its K-step runs replicated, identically on every rank
+      MG_TRY(mg_kcycle_step_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail));
+    } else
     MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, 1, 1));
     if ((long long)h->lev.size() < h->nl_total - 1 && (ctype == 'W' || ctype == 'F')) {       // second visit (MGcycle.jl:79-84)
       MG_TRY(mg_set_cycle_type(h->tail, ctype == 'W' ? 'W' : 'V'));
@@ -4828,9 +4941,14 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     }
     MG_TRY(dist_apply(h, L.P, MG_K_PROLONG, 1.0, h->x_tail.p, 1.0, cur, nullptr, nullptr, 0));
   }
-  for (long long s = 0; s < npost; ++s) {
-    MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
-    std::swap(cur, alt);
+  if (h->relax_type == 1) {      // MGcycle.jl:96-98
+    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
+    MG_TRY(dist_fgmres_relax(h, L, L.r.p, cur, L.npost_raw, diag_prec, gmresTol, L.relZ, L.relAZ, false));
+  } else {
+    for (long long s = 0; s < npost; ++s) {
+      MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
+      std::swap(cur, alt);
+    }
   }
   *result = cur;
   return MG_OK;
@@ -4886,7 +5004,7 @@ int mg_dist_create(long long device_id, long long rank, long long world, const c
   *out = nullptr;
   if (world < 1 || rank < 0 || rank >= world || nlevels < 1 || nl_total <= nlevels)
     return fail(MG_ERR_INVALID, "bad rank/world/levels (%lld/%lld, %lld sharded of %lld)", rank, world, nlevels, nl_total);
-  if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F') return fail(MG_ERR_UNSUPPORTED, "the sharded cycle implements V, W and F");
+  if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F' && cycleType != 'K') return fail(MG_ERR_UNSUPPORTED, "the sharded cycle implements V, W, F and K");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
@@ -4939,8 +5057,19 @@ int mg_dist_set_level(mg_dist* h, long long level, long long n_own, long long n_
   L.d = d_dev;
   L.npre = std::max<long long>(1, relaxPre);      // relax() always updates once (MGcycle.jl:127-134)
   L.npost = std::max<long long>(1, relaxPost);
+  L.npre_raw = relaxPre;
+  L.npost_raw = relaxPost;
   L.box = false;
   h->finalized = false;
+  return MG_OK;
+}
+
+// 0: pointwise smoothers (Jac / SPAI, the relaxPrec vectors), 1: Jac-GMRES (FGMRES_relaxation preconditioned by the
+// relaxPrec vector; relaxPre/relaxPost are its inner dimensions).  The replicated tail carries its own setting.
+int mg_dist_set_relax_type(mg_dist* h, long long relax_type) {
+  if (!h) return fail(MG_ERR_INVALID, "null handle");
+  if (relax_type != 0 && relax_type != 1) return fail(MG_ERR_INVALID, "relax_type must be 0 (pointwise) or 1 (Jac-GMRES)");
+  h->relax_type = (int)relax_type;
   return MG_OK;
 }
 
@@ -5072,7 +5201,7 @@ int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long 
     MG_TRY(dist_cycle(h, 0, b_loc, cur, alt, x_zero, h->cycle, &out, count > 1 || !x_zero, x1_ready));
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
-    MG_TRY(dist_residual_norm(h, L, cur, b_loc, count < maxIter ? alt : nullptr, &res, &x1_ready));
+    MG_TRY(dist_residual_norm(h, L, cur, b_loc, (count < maxIter && h->relax_type == 0) ? alt : nullptr, &res, &x1_ready));
     ++it;
     if (resvec) resvec[it] = res;
     if (res / res0 < tol) break;
@@ -5146,6 +5275,30 @@ int mg_cycle_async_dev_FP64(mg_hierarchy* h, const double* b, double* x, long lo
   if (x_is_zero != 0 && x_is_zero != 1) return fail(MG_ERR_INVALID, "x_is_zero must be 0 or 1 for the asynchronous cycle");
   (void)hipSetDevice(h->device);
   return cycle_dev(h, b, x, x_is_zero == 1);
+}
+
+// The K-cycle's step INTO this hierarchy's first level (MGcycle.jl:72-76): x = 2 steps of FGMRES on A_1 x = b from x = 0,
+// preconditioned by the K-cycle of level 1.  For a hierarchy that is the replicated tail of a sharded one (mg_dist_*): the
+// level above it is sharded and its K-branch lands here.  A one-level hierarchy just solves.  Asynchronous like
+// mg_cycle_async_dev_FP64 as far as the stream goes (the FGMRES dots are host-visible, as everywhere in a K-cycle).
+int mg_kcycle_step_async_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n) {
+  MG_TRY(check_ready(h, n, 1));
+  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
+  (void)hipSetDevice(h->device);
+  if (h->nlevels < 2) return cycle_dev(h, b, x, true);
+  Level& L = h->lev[0];
+  if (h->kstepZ.n != (size_t)(2 * n)) {
+    MG_TRY(h->kstepZ.alloc((size_t)(2 * n)));
+    MG_TRY(h->kstepAZ.alloc((size_t)(2 * n)));
+    MG_TRY(h->kstepX.alloc((size_t)n));
+  }
+  auto kprec = [&](const double* v, double* z) {
+    double* res = nullptr;
+    MG_TRY(cycle_level(h, 0, v, h->kstepX.p, L.x1.p, true, 'K', &res));
+    HIP_TRY(hipMemcpyAsync(z, res, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    return (int)MG_OK;
+  };
+  return fgmres_relax(h, 0, b, x, 2, kprec, 1e-5, h->kstepZ.p, h->kstepAZ.p, true);
 }
 
 }  // extern "C"

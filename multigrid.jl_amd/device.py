@@ -90,6 +90,8 @@ SIGNATURES = {
     "mg_op_kernel_variant": (C.c_int, [_vp, _lp, _lp]),
     "mg_op_apply_phase_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _ll, _ll, _vp]),
     "mg_dist_set_level_box": (C.c_int, [_vp, _ll, _ll]),
+    "mg_dist_set_relax_type": (C.c_int, [_vp, _ll]),
+    "mg_kcycle_step_async_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll]),
     "mg_op_residual_fused_dev_FP64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _lp, _vp]),
     "mg_op_can_fuse_next": (C.c_int, [_vp, _vp, _lp]),
     "mg_op_destroy": (C.c_int, [_vp]),

@@ -417,6 +417,7 @@ class DistributedHierarchy:
         self.be = be = backend
         self.nrhs = k = int(nrhs)
         self.cycleType = cycleType
+        self.relaxType = getattr(tail_param, "relaxType", "Jac")
         rank, size = comm.rank, comm.size
         self.first_tail = len(local_levels)
         self.nl = int(nl_total)
@@ -490,20 +491,26 @@ class DistributedHierarchy:
         self.rows_fine = np.asarray(rows_fine)
 
     @staticmethod
-    def check_supported(param: MGparam):
-        """The sharded schedule implements the pointwise smoothers and V/W/F cycles; anything else must fail loudly
-        rather than silently run a different method."""
-        if param.relaxType not in ("Jac", "SPAI"):
-            raise NotImplementedError(f"relaxType={param.relaxType!r} is not implemented in the multi-GPU cycle")
-        if param.cycleType not in ("V", "W", "F"):
-            raise NotImplementedError(f"cycleType={param.cycleType!r} is not implemented in the multi-GPU cycle")
+    def check_supported(param: MGparam, native: bool = False):
+        """The Python-sequenced schedule implements the pointwise smoothers and V/W/F cycles; the native sequencer
+        (mg_dist_*) also the Jac-GMRES smoother and the K-cycle (all-reduced dots).  Anything else must fail loudly rather
+        than silently run a different method."""
+        relax_ok = ("Jac", "SPAI", "Jac-GMRES") if native else ("Jac", "SPAI")
+        cycle_ok = ("V", "W", "F", "K") if native else ("V", "W", "F")
+        if param.relaxType not in relax_ok:
+            raise NotImplementedError(f"relaxType={param.relaxType!r} is not implemented in the multi-GPU cycle"
+                                      + ("" if native else " of the Python sequencer (the native one, mg_dist_*, has Jac-GMRES)"))
+        if param.cycleType not in cycle_ok:
+            raise NotImplementedError(f"cycleType={param.cycleType!r} is not implemented in the multi-GPU cycle"
+                                      + ("" if native else " of the Python sequencer (the native one, mg_dist_*, has the K-cycle)"))
 
     @classmethod
     def from_global(cls, param: MGparam, comm, backend, fine_owner: np.ndarray, nrhs: int = 1,
-                    replicate_below: int = 300_000, level_nodes=None):
+                    replicate_below: int = 300_000, level_nodes=None, native_only: bool = False):
         """level_nodes (optional): nodes per dimension of every level's regular grid ([n1,n2(,n3)] per level, x fastest).
-        When a rank's rows of a sharded level are a box of that grid, the level is held in BOX form."""
-        cls.check_supported(param)
+        When a rank's rows of a sharded level are a box of that grid, the level is held in BOX form.
+        native_only: the hierarchy will be driven by NativeDistributedHierarchy only (Jac-GMRES / K-cycle allowed)."""
+        cls.check_supported(param, native=native_only)
         rank, size = comm.rank, comm.size
         nl = len(param.As)
         if nl < 2:
@@ -630,12 +637,18 @@ class DistributedHierarchy:
         """One cycle; b_loc/x_loc hold this rank's fine rows (length n_own [x nrhs]); x_loc updated in place."""
         L = self.levels[0]
         L.x0[: L.n_own].copy_(x_loc)
+        self._python_sequencer_supported()
         res = self._cycle(0, b_loc, L.x0, L.x1, bool(x_is_zero), self.cycleType)
         x_loc.copy_(res[: L.n_own])
         return x_loc
 
+    def _python_sequencer_supported(self):
+        if self.relaxType not in ("Jac", "SPAI") or self.cycleType not in ("V", "W", "F"):
+            raise NotImplementedError("Jac-GMRES smoothing and the K-cycle run in the native sequencer only (NativeDistributedHierarchy)")
+
     def solve(self, b_loc, x_loc, tol: float, maxIter: int):
         """solveMG (SolveFuncs.jl:3-39) on sharded vectors; returns (iters, resvec)."""
+        self._python_sequencer_supported()
         be, k = self.be, self.nrhs
         L = self.levels[0]
         cur, alt = L.x0, L.x1
@@ -710,6 +723,7 @@ class NativeDistributedHierarchy:
         nl_sh = len(H.levels)
         D._check(lib, lib.mg_dist_create(H.be.device_id, rank, size, uid, nl_sh, H.nl, ord(H.cycleType), C.byref(self.handle)),
                  "mg_dist_create")
+        D._check(lib, lib.mg_dist_set_relax_type(self.handle, 1 if H.relaxType == "Jac-GMRES" else 0), "mg_dist_set_relax_type")
         self._cb = None
         if uid is None and size > 1:
             self._install_plugin(comm)

@@ -1,3 +1,3 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "prolongation_with_staged or gmres_coarse or march2" 2>&1 | tail -8 | tee gpurun_out/winp_test.log
+timeout -k 10 900 python -m pytest tests/test_distributed.py -q -x -m gpu -k "kcycle_and_jac_gmres or native_sequencer_plugin" 2>&1 | tail -15 | tee gpurun_out/dist_test.log

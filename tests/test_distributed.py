@@ -41,6 +41,11 @@ def _problem(kind, nrhs, cyc):
         p = mg.getMGparam(np.float64, np.int64, 3, 8, 6, 1e-10, "SPAI", 1.0, 1, 1, cyc, "NoMUMPS", 0.5, 0.0)
         mg.MGsetup(A, mesh, p, nrhs)
         nodes = mesh.n + 1
+    elif kind == "gmg3d-jacgmres":   # Jac-GMRES smoother (FGMRES_relaxation, MGcycle.jl:48-50,96-98): native sequencer only
+        A, mesh = mg.poisson_shifted([16, 16, 16])
+        p = mg.getMGparam(np.float64, np.int64, 4, 8, 6, 1e-10, "Jac-GMRES", 0.75, 2, 2, cyc, "NoMUMPS", 0.5, 0.0)
+        mg.MGsetup(A, mesh, p, nrhs)
+        nodes = mesh.n + 1
     else:  # "sa": general CSR, contiguous row blocks
         A, _ = mg.anisotropic_divsiggrad([12, 12, 12], weights=(1, 0.5, 0.25))
         p = mg.getMGparam(np.float64, np.int64, 4, 8, 6, 1e-10, "SPAI", 1.0, 1, 1, cyc, "Julia", 0.4)
@@ -78,7 +83,8 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", nati
         level_nodes = None
         if box and nodes is not None:      # BOX form of the sharded levels: rows in natural box order, A one square operator
             level_nodes = [((np.asarray(nodes) - 1) >> l) + 1 for l in range(len(p.As))]
-        H = dd.DistributedHierarchy.from_global(p, comm, be, owner, nrhs, replicate_below=200, level_nodes=level_nodes)
+        H = dd.DistributedHierarchy.from_global(p, comm, be, owner, nrhs, replicate_below=200, level_nodes=level_nodes,
+                                                native_only=bool(native) and (cyc == "K" or p.relaxType == "Jac-GMRES"))
         assert len(H.levels) >= 2, "the test must exercise at least two sharded levels"
         assert H.box_form == bool(box and nodes is not None and nrhs == 1)
         if box and use_hip and nodes is not None and nrhs == 1:
@@ -236,6 +242,18 @@ def test_box_form_local_operators_hip(built, world, kind, cyc, native):
     for the rows of the owned box that do not read the halo, csr_rows_spmv for those that do, after the exchange), driven
     by the native sequencer (phase-split launches around the side-stream exchange) and by the Python one."""
     _run(world, kind, 1, cyc, use_hip=True, native=native, box=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,cyc,box", [(1, "gmg3d", "K", False), (2, "gmg3d", "K", False), (4, "gmg3d", "K", True),
+                                                (2, "gmg3d-jacgmres", "V", False), (2, "gmg3d-jacgmres", "K", True),
+                                                (4, "gmg3d-jacgmres", "W", False)])
+def test_native_sequencer_kcycle_and_jac_gmres(built, world, kind, cyc, box):
+    """The K-cycle (2 FGMRES steps per level preconditioned by the next level's K-cycle, MGcycle.jl:72-76) and the Jac-GMRES
+    smoother (FGMRES.jl:48-126) in the native sharded sequencer: products with the halo exchanged, dots all-reduced, the
+    data-dependent exits identical on every rank; the level above the replicated tail lands in mg_kcycle_step_async_dev_FP64.
+    Against the oracle (1e-10).  The Python sequencer refuses both (loudly)."""
+    _run(world, kind, 1, cyc, use_hip=True, native="plugin", box=box)
 
 
 @pytest.mark.gpu
