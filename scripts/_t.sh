@@ -1,3 +1,3 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_distributed.py -q -x -m gpu -k "kcycle_and_jac_gmres or native_sequencer_plugin" 2>&1 | tail -15 | tee gpurun_out/dist_test.log
+timeout -k 10 1000 python -m pytest tests -q -x -m gpu 2>&1 | tail -6 | tee gpurun_out/gpu_suite.log && python bench.py --steps 20 --warmup 5 > gpurun_out/c2_bench_final.json 2> gpurun_out/c2_bench_final.err; tail -c 600 gpurun_out/c2_bench_final.json
