@@ -203,7 +203,7 @@ def main():
     dom = max((k for k in ((1, "smooth"), (1, "smooth+residual")) if k in prof), key=lambda k: prof[k][0])
     kdesc = "fine-level fused damped-Jacobi sweep x' = x + d.*(b - A x), level 1"
     if dom[1] == "smooth+residual":
-        kname = "mgk::csr_rowclass_march2_spmv<0>"
+        kname = "mgk::csr_rowclass_march2_spmv<false>"
         kdesc = ("fine-level damped-Jacobi sweep t = x + d.*(b - A x) AND the residual r = b - A t (with ||r||^2 and the "
                  "next cycle's first update in the solve loop) in one pass, level 1")
     ms_s, cnt_s, bts_s = prof[dom]

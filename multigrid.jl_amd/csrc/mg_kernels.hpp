@@ -1569,7 +1569,25 @@ struct March2Args {
 
 constexpr int RM2_CLEN = 7;   // longest class whose records a lane keeps in registers
 
-template <int DUMMY>
+// class ids of the rows e0, e0 + 1 (e0 even: one aligned 32-bit word; the class array is padded) packed lo | hi << 16;
+// rows outside the operator get class 0
+__device__ __forceinline__ unsigned int march_load_clspair(const unsigned short* __restrict__ cls, long long e0, bool act, int n_rows) {
+  unsigned int r = 0u;
+  if (act) {
+    if (e0 >= 0 && e0 + 1 < n_rows) {
+      r = *reinterpret_cast<const unsigned int*>(cls + e0);
+    } else {
+      if (e0 >= 0 && e0 < n_rows) r = cls[e0];
+      if (e0 + 1 >= 0 && e0 + 1 < n_rows) r |= (unsigned int)cls[e0 + 1] << 16;
+    }
+  }
+  return r;
+}
+
+// ZERO: the sweep starts from x = 0, i.e. its input is x1 = d.*b (relax's first update, MGcycle.jl:134 with r = b): the
+// staged vector is computed from b and the class ids while the slab passes through registers, and the dscale launch with
+// its write and re-read of x1 disappears (a.x is not read).  The product is dscale_kernel's (one multiply).
+template <bool ZERO>
 __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev C, March2Args a, MarchDev T) {
   extern __shared__ double win[];
   __shared__ double red[RM_C / 64];
@@ -1669,6 +1687,15 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
     _Pragma("unroll") for (int u_ = 0; u_ < RM2_CLEN; ++u_) (acc) = (acc) + (vals)[u_] * xv_[u_];                      \
   } while (0)
 
+  // the source of the slabs: x, or (ZERO) b with the class ids of the same entries
+  const double* src = ZERO ? a.b : a.x;
+#define M2_X1(v, cc)                                                                                                   \
+  do {                                                                                                                 \
+    if (ZERO) {                                                                                                        \
+      (v).x = dd[(cc) & 0xFFFFu] * (v).x;                                                                              \
+      (v).y = dd[(cc) >> 16] * (v).y;                                                                                  \
+    }                                                                                                                  \
+  } while (0)
   __syncthreads();   // dictionaries in place
   while (it < it_end) {
     const int c = (int)(it / T.nplanes);
@@ -1683,12 +1710,23 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
     // ---- fill the x ring: planes z0-2, z0-1, z0 (slots 0..2); plane z0+1 goes into registers -------------------------
 #pragma unroll 1
     for (int pp = 0; pp < 3; ++pp) {
-      const d2_t q0 = march_load_pair(a.x, M2_E0(c, z0 - 2 + pp, 0), pact0, T.n_cols);
-      const d2_t q1 = march_load_pair(a.x, M2_E0(c, z0 - 2 + pp, 1), pact1, T.n_cols);
+      d2_t q0 = march_load_pair(src, M2_E0(c, z0 - 2 + pp, 0), pact0, T.n_cols);
+      d2_t q1 = march_load_pair(src, M2_E0(c, z0 - 2 + pp, 1), pact1, T.n_cols);
+      if (ZERO) {
+        const unsigned int k0 = march_load_clspair(C.cls, M2_E0(c, z0 - 2 + pp, 0), pact0, C.n_rows);
+        const unsigned int k1 = march_load_clspair(C.cls, M2_E0(c, z0 - 2 + pp, 1), pact1, C.n_rows);
+        M2_X1(q0, k0);
+        M2_X1(q1, k1);
+      }
       M2_STAGE(pp, (int)(M2_G0(c, z0 - 2 + pp) & 1LL), q0, q1);
     }
-    d2_t pre0 = march_load_pair(a.x, M2_E0(c, z0 + 1, 0), pact0, T.n_cols);
-    d2_t pre1 = march_load_pair(a.x, M2_E0(c, z0 + 1, 1), pact1, T.n_cols);
+    d2_t pre0 = march_load_pair(src, M2_E0(c, z0 + 1, 0), pact0, T.n_cols);
+    d2_t pre1 = march_load_pair(src, M2_E0(c, z0 + 1, 1), pact1, T.n_cols);
+    unsigned int cpre0 = 0u, cpre1 = 0u;
+    if (ZERO) {
+      cpre0 = march_load_clspair(C.cls, M2_E0(c, z0 + 1, 0), pact0, C.n_rows);
+      cpre1 = march_load_clspair(C.cls, M2_E0(c, z0 + 1, 1), pact1, C.n_rows);
+    }
     // row operands of stage 1, plane zz: class id and b of the core row and of the halo row (a safe row when not live)
     int nclsc, nclsh;
     double nbc, nbh;
@@ -1717,9 +1755,15 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
     for (int z = z0 - 1; z <= z1 + 1; ++z) {
       const int q = z - z0 + 2;                        // ring index of plane z (plane z0-2 is 0)
       d2_t cur0 = pre0, cur1 = pre1;
+      unsigned int ccur0 = cpre0, ccur1 = cpre1;
       int clsc = nclsc, clsh = nclsh;
       double bc = nbc, bh = nbh;
       asm volatile("" : "+v"(cur0.x), "+v"(cur0.y), "+v"(cur1.x), "+v"(cur1.y), "+v"(clsc), "+v"(bc), "+v"(clsh), "+v"(bh));
+      if (ZERO) {
+        asm volatile("" : "+v"(ccur0), "+v"(ccur1));
+        M2_X1(cur0, ccur0);
+        M2_X1(cur1, ccur1);
+      }
       // ---- x plane z+2 into its slot (that of plane z-2, last read before the previous barrier) -----------------------
       if (z + 2 <= z1 + 1) M2_STAGE((q + 2) & 3, (int)(M2_G0(c, z + 2) & 1LL), cur0, cur1);
       // ---- stores of the previous iteration, then the loads of x plane z+3 and of the operands of plane z+1 ------------
@@ -1729,8 +1773,12 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
         if (a.xn) a.xn[st_rrow] = st_xn;
       }
       if (z + 3 <= z1 + 1) {
-        pre0 = march_load_pair(a.x, M2_E0(c, z + 3, 0), pact0, T.n_cols);
-        pre1 = march_load_pair(a.x, M2_E0(c, z + 3, 1), pact1, T.n_cols);
+        pre0 = march_load_pair(src, M2_E0(c, z + 3, 0), pact0, T.n_cols);
+        pre1 = march_load_pair(src, M2_E0(c, z + 3, 1), pact1, T.n_cols);
+        if (ZERO) {
+          cpre0 = march_load_clspair(C.cls, M2_E0(c, z + 3, 0), pact0, C.n_rows);
+          cpre1 = march_load_clspair(C.cls, M2_E0(c, z + 3, 1), pact1, C.n_rows);
+        }
       }
       if (z + 1 <= z1) M2_OPERANDS(z + 1);
       // ---- stage 1 on plane z: t = x + d.*(b - A x) on the core row and on the halo row ---------------------------------
@@ -1833,6 +1881,7 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
 #undef M2_G0
 #undef M2_E0
 #undef M2_STAGE
+#undef M2_X1
 #undef M2_WALK
 #undef M2_LOADRECS
 #undef M2_REGWALK

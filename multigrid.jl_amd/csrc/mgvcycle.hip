@@ -60,7 +60,7 @@ struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
-  bool no_march2 = false, no_tile_lane = false, no_winp = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -88,7 +88,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -890,8 +890,9 @@ bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* 
   if (x == t || x == r || x == xn || t == r || t == xn || (r && r == xn)) return false;
   return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
+// from_zero: the sweep's input is x1 = d.*b (the level is entered with x = 0): x is not read, no dscale launch is needed
 int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double* x, double* t, double* r, double* xn,
-                      bool want_sumsq) {
+                      bool want_sumsq, bool from_zero = false) {
   const Csr& A = h->lev[(size_t)level].A;
   mgk::March2Args a{};
   a.x = x;
@@ -906,7 +907,8 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
   const size_t lds = march2_lds_bytes(A.rm_halo);
   static bool lds_attr_set = false;
   if (!lds_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march2_spmv<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march2_spmv<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march2_spmv<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void)hipGetLastError();
     lds_attr_set = true;
   }
@@ -915,7 +917,8 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
     // algorithmic: the two products; moved: class ids + x + b in, t and r (and/or xn) out
     ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (xn && r ? n8 : 0.0),
                  format_bytes(A, 1) + n8 * (3.0 + (r ? 1.0 : 0.0) + (xn ? 1.0 : 0.0)));
-    hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<0>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
+    if (from_zero) hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<true>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
+    else hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<false>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
     HIP_TRY(hipGetLastError());
   }
   if (want_sumsq) {
@@ -1220,6 +1223,7 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   // relax() always performs at least one update: `for i=1:numit-1 ... end; x .+= d.*r` (MGcycle.jl:127-134)
   long long npre = std::max<long long>(1, L.npre);
   const long long npost = std::max<long long>(1, L.npost);
+  bool from_zero = false;
   // pre-smoothing (MGcycle.jl:26-31,54).  x == 0: r = b, so the first sweep is x = d.*b.
   if (h->relax_type == 1) {  // Jac-GMRES (MGcycle.jl:48-50): FGMRES on the residual, preconditioned by D
     const double* r0 = b;
@@ -1232,7 +1236,9 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     MG_TRY(fgmres_relax(h, l, r0, cur, L.npre, diag_prec, gmresTol, L.relaxZ.p, L.relaxAZ.p, false));
     npre = 0;
   } else if (x_zero) {
-    MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
+    // two sweeps from x = 0 on a level the two-stage pass serves: x1 = d.*b is formed inside that pass
+    from_zero = npre == 2 && !h->opt.no_march2_zero && march2_ok(h, l, cur, alt, L.r.p, nullptr);
+    if (!from_zero) MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
     --npre;
   } else if (r_valid) {
     if (!x1_ready) MG_TRY(k_xpdr(h, l, cur, L.d.p, L.r.p, alt, L.n));
@@ -1247,7 +1253,7 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   }
   // r = b - A x ; bc = R r ; xc = 0 (MGcycle.jl:58-66)
   if (fuse_pre) {
-    MG_TRY(k_smooth_residual(h, l, b, cur, alt, L.r.p, nullptr, false));
+    MG_TRY(k_smooth_residual(h, l, b, cur, alt, L.r.p, nullptr, false, from_zero));
     std::swap(cur, alt);
   } else {
     MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));

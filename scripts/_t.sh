@@ -1,3 +1,3 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -q -x -m gpu 2>&1 | tail -6 | tee gpurun_out/gpu_suite.log && python bench.py --steps 20 --warmup 5 > gpurun_out/c2_bench_final.json 2> gpurun_out/c2_bench_final.err; tail -c 600 gpurun_out/c2_bench_final.json
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_krylov.py -q -x -m gpu -k "march2 or pcg or golden or nonzero_initial or krylov or solveMG" 2>&1 | tail -5 | tee gpurun_out/zero_test.log && (python scripts/diag_pcg.py 2>&1 | grep -v Warn; MG_NO_MARCH2_ZERO=1 python scripts/diag_pcg.py 2>&1 | grep -v Warn; MG_NO_MARCH2=1 MG_NO_TILE_LANE=1 MG_NO_WINP=1 python scripts/diag_pcg.py 2>&1 | grep -v Warn) | tee gpurun_out/diag_pcg.txt

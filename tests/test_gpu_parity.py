@@ -713,8 +713,9 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
     monkeypatch.setenv("MG_MARCH_MAX_LEN", "64")         # also on the 27-point coarse levels
     rng = np.random.default_rng(sum(cells) + 7)
     runs = {}
-    for name, no2 in (("fused", "0"), ("unfused", "1")):
+    for name, no2, nozero in (("fused", "0", "0"), ("unfused", "1", "0"), ("fused, dscale launched", "0", "1")):
         monkeypatch.setenv("MG_NO_MARCH2", no2)
+        monkeypatch.setenv("MG_NO_MARCH2_ZERO", nozero)   # two sweeps from x = 0: x1 = d.*b formed inside the pass, or by dscale
         A, p, b = _setup(mg, cells, levels, "Jac", 0.8, pre, post, cyc, maxIter=5)
         h = mg.to_device(p)
         assert h.operator_kernel_variant(1, D.MG_OP_A) == 3
@@ -758,10 +759,11 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
         mg.solveMG(p, b, x2)
         runs[name] = (x.copy(), np.asarray(p.resvec).copy(), x1.copy(), x2.copy())
         mg.clear_(p)
-    assert np.array_equal(runs["fused"][0], runs["unfused"][0])
-    assert np.array_equal(runs["fused"][2], runs["unfused"][2])
-    assert np.array_equal(runs["fused"][3], runs["unfused"][3])
-    assert np.abs(runs["fused"][1] - runs["unfused"][1]).max() <= 1e-14 * runs["unfused"][1][0]
+    for other in ("unfused", "fused, dscale launched"):
+        assert np.array_equal(runs["fused"][0], runs[other][0]), other
+        assert np.array_equal(runs["fused"][2], runs[other][2]), other
+        assert np.array_equal(runs["fused"][3], runs[other][3]), other
+        assert np.abs(runs["fused"][1] - runs[other][1]).max() <= 1e-14 * runs[other][1][0], other
 
 
 @pytest.mark.gpu
