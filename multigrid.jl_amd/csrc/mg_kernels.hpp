@@ -84,6 +84,7 @@ struct VecArgs {
   double alpha;     // AXPBY
   double beta;      // AXPBY
   int nrhs;
+  int dotx;         // csr_rowclass_march_spmv only: the partials in `sumsq` are of x[row]*out[row] (p'Ap of CG) instead of out^2
 };
 
 // Each XCD gets a contiguous band of logical blocks (workgroups are dealt round-robin over the 8 XCDs:
@@ -1517,7 +1518,7 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
         st_row = row;
         st_out = outv;
         if (MODE == RESID && v.y2) st_out2 = own + pd * outv;   // x + d.*r
-        sq += outv * outv;
+        sq += (MODE == AXPBY && v.dotx) ? own * outv : outv * outv;
       }
       __syncthreads();
     }
@@ -2405,6 +2406,23 @@ __global__ __launch_bounds__(BLK) void cg_update_xr(double alpha, const double* 
     x[i] += alpha * p[i];
     r[i] -= alpha * Ap[i];
   }
+}
+
+// the same with the per-workgroup sums of squares of the new r (||r|| of the stopping test without another pass)
+__global__ __launch_bounds__(BLK) void cg_update_xr_norm(double alpha, const double* __restrict__ p,
+                                                         const double* __restrict__ Ap, double* __restrict__ x,
+                                                         double* __restrict__ r, long long n, double* __restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const long long stride = (long long)gridDim.x * BLK;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+    x[i] += alpha * p[i];
+    const double rn = r[i] - alpha * Ap[i];
+    r[i] = rn;
+    acc += rn * rn;
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 // y = a*x + b*y

@@ -1471,6 +1471,34 @@ int dot_sync(mg_hierarchy* h, const double* x, const double* y, long long len, d
   return MG_OK;
 }
 
+// y = A x on level `level` and *out = x'y: where the marching kernel serves the product its per-workgroup partials are of
+// x[row]*y[row] (VecArgs::dotx), else the product and a dot pass.  Synchronises the stream.
+int k_spmv_dot(mg_hierarchy* h, int level, const Csr& A, const double* x, double* y, double* out) {
+  mgk::VecArgs v{};
+  v.x = x;
+  v.y = y;
+  v.alpha = 1.0;
+  v.beta = 0.0;
+  v.nrhs = (int)h->nrhs;
+  if (h->nrhs == 1 && march_ok(A, v) && A.rc_nexc == 0 && (size_t)A.rm_nblocks <= h->partial.n) {
+    v.sumsq = h->partial.p;
+    v.dotx = 1;
+    int nb1 = 0;
+    {
+      ProfScope ps(h, level, MG_K_SPMV, spmv_bytes(A, 1, false, false), moved_bytes(A, 1, false, false));
+      MG_TRY(launch_csr<mgk::AXPBY>(h->stream, A, v, &nb1));
+    }
+    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->scalar.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(spin_sync(h->stream));
+    *out = *h->h_scalar;
+    return MG_OK;
+  }
+  MG_TRY(k_spmv(h, level, MG_K_SPMV, A, 1.0, x, 0.0, y));
+  return dot_sync(h, x, y, (long long)A.n_rows * h->nrhs, out);
+}
+
 // Preconditioned CG with one multigrid cycle (x = 0 on entry) as M: solveCG_MG (SolveFuncs.jl:104-116) ->
 // KrylovMethods.cg (v0.6.0, un-vendored: Manifest.toml:35-41), restated from its published algorithm:
 //   r = b - A x0 ; z = M r ; p = z ; nr0 = ||b||
@@ -1505,23 +1533,29 @@ int pcg_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long m
   MG_TRY(k_residual(h, 0, L.A, b, x, r));                              // r = b - A(x)
   MG_TRY(cycle_dev(h, r, z, true));                                    // z = M(r), x = 0 on entry
   HIP_TRY(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
+  // Three passes of the textbook loop are folded into their neighbours (same values, fewer sweeps over the vectors and one
+  // host synchronisation less per iteration): gamma = r'z of iteration k+1 IS z'r of iteration k (computed once); p'Ap comes
+  // out of the product kernel where the marching kernel serves A (partials of p[row]*Ap[row]); ||r||^2 out of the update.
+  double gamma = 0.0;
+  MG_TRY(dot_sync(h, r, z, n, &gamma));
+  const int nb_upd = (int)std::min<long long>(grid_for(n), (long long)h->partial.n);
   for (long long k = 1; k <= maxIter; ++k) {
     it = k;
-    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, p, 0.0, Ap));             // Ap = A(p)
-    double gamma = 0.0, pAp = 0.0, rn = 0.0;
-    MG_TRY(dot_sync(h, r, z, n, &gamma));
-    MG_TRY(dot_sync(h, p, Ap, n, &pAp));
+    double pAp = 0.0, rn = 0.0;
+    MG_TRY(k_spmv_dot(h, 0, L.A, p, Ap, &pAp));                        // Ap = A(p), p'Ap
     const double alpha = gamma / pAp;
     if (std::isinf(alpha) || alpha < 0.0) { flag = -2; break; }
-    hipLaunchKernelGGL(mgk::cg_update_xr, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, alpha, p, Ap, x, r, n);
+    hipLaunchKernelGGL(mgk::cg_update_xr_norm, dim3(nb_upd), dim3(mgk::BLK), 0, h->stream, alpha, p, Ap, x, r, n, h->partial.p);
+    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb_upd, h->scalar.p);
     HIP_TRY(hipGetLastError());
-    MG_TRY(norm_sync(h, r, n, &rn));
+    MG_TRY(scalar_sync(h, &rn));
     if (resvec) resvec[k - 1] = rn / nr0;
     if (rn / nr0 <= tol) { flag = 0; break; }
     MG_TRY(cycle_dev(h, r, z, true));
     double zr = 0.0;
     MG_TRY(dot_sync(h, z, r, n, &zr));
     const double beta = zr / gamma;
+    gamma = zr;                                                        // = r'z at the top of the next iteration
     hipLaunchKernelGGL(mgk::cg_update_p, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, beta, z, p, n);
     HIP_TRY(hipGetLastError());
   }

@@ -41,5 +41,5 @@ for name, fn in (("cycle from x = 0 (preconditioner call)", None), ("solveCG_MG 
         out = h.pcg_dev(b, x, 0.0, K)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / K
-        print(f"{name}: {dt*1e3:.4f} ms per iteration (cycle + A*p + 4 reductions), {K} iterations: {out[:2] if isinstance(out, tuple) else out}", flush=True)
+        print(f"{name}: {dt*1e3:.4f} ms per iteration (cycle from x = 0 + A*p with p'Ap + update with ||r|| + z'r + update of p), {K} iterations: {out[:2] if isinstance(out, tuple) else out}", flush=True)
 h.close()
