@@ -13,6 +13,7 @@ python scripts/lu_coarse_time.py > $out/lu_coarse.txt 2>&1
 MG_NO_MARCH2=1 MG_NO_TILE_LANE=1 MG_NO_WINP=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass > $out/c2_bench_single_stage.json 2> $out/c2_bench_single_stage.err
 python bench.py --workload c3 --cells 128 --steps 10 --warmup 2 --no-cpu-baseline > $out/c3_128_bench.json 2> $out/c3_128_bench.err
 python scripts/diag_host_api.py 2>&1 | grep "host API" > $out/host_api.txt
+python scripts/diag_pcg.py 2>&1 | grep "ms per" > $out/krylov.txt
 # rocprofv3: the program itself after "--"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass > $out/prof_c2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c5 -- python3 bench.py --workload c5 --steps 10 --warmup 2 --no-cpu-baseline > $out/prof_c5.log 2>&1
