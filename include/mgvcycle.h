@@ -184,6 +184,9 @@ int mg_bicgstab_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, lo
  * estimate after every inner step, *nres their number, *iters the total number of inner steps.  nrhs = 1. */
 int mg_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long inner, double tol,
                    long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres);
+/* the same with b and x in HBM (device pointers), like mg_pcg_dev_FP64 / mg_bicgstab_dev_FP64 */
+int mg_fgmres_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n, long long inner, double tol,
+                       long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres);
 
 /* The block branches of the same three drivers (size(b,2) > 1: KrylovMethods.blockCG / blockBiCGSTB / blockFGMRES,
  * SolveFuncs.jl:95,113,130), nrhs <= 16, every n x nrhs block resident in HBM across iterations.  The package is not

@@ -2425,6 +2425,33 @@ __global__ __launch_bounds__(BLK) void cg_update_xr_norm(double alpha, const dou
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// One step of modified Gram-Schmidt with the coefficient on the device: w -= (*hk) * v, and the per-workgroup partial sums
+// of the NEXT dot in the same pass - w_new . u (u = the next basis vector) or, with u == nullptr, w_new . w_new (the norm
+// that ends the orthogonalisation).  The chain dot -> update -> dot never leaves the device (FGMRES Arnoldi loop).
+__global__ __launch_bounds__(BLK) void mgs_step(const double* __restrict__ hk, const double* __restrict__ v,
+                                                double* __restrict__ w, const double* __restrict__ u, long long n,
+                                                double* __restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const double a = -hk[0];
+  const long long stride = (long long)gridDim.x * BLK;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+    const double wn = a * v[i] + 1.0 * w[i];
+    w[i] = wn;
+    acc += wn * (u ? u[i] : wn);
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// w *= 1/sqrt(*wn2) unless *wn2 == 0 (the new basis vector of the Arnoldi loop)
+__global__ __launch_bounds__(BLK) void scale_rsqrt(const double* __restrict__ wn2, double* __restrict__ w, long long n) {
+  const double nrm = sqrt(wn2[0]);
+  if (nrm == 0.0) return;
+  const double a = 1.0 / nrm;
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) w[i] = a * w[i];
+}
+
 // y = a*x + b*y
 __global__ __launch_bounds__(BLK) void axpby_kernel(double a, const double* __restrict__ x, double b,
                                                     double* __restrict__ y, long long n) {

@@ -60,7 +60,7 @@ struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
-  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -88,7 +88,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -482,6 +482,8 @@ struct mg_hierarchy {
   double* h_blk_c = nullptr;           // pinned ring of coefficient matrices
   unsigned blk_c_next = 0;
   DevBuf<double> kwc_blk;   // the same for a block of right-hand sides (blockFGMRES branch, MGcycle.jl:166)
+  DevBuf<double> kscal;     // FGMRES: the Hessenberg column of an inner step, on the device
+  double* h_kscal = nullptr;   // ... and its pinned readback (66 doubles)
   DevBuf<double> kstepZ, kstepAZ, kstepX;   // mg_kcycle_step_async_dev_FP64: the K-step INTO this hierarchy's first level
   DevBuf<double> kwc, coarse_d;   // coarseSolveType "GMRES": FGMRES work space and the Jacobi preconditioner of the coarsest level
   bool coarse_gmres = false;
@@ -1716,16 +1718,39 @@ int fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBu
       if (precond == 0) MG_TRY(cycle_dev(h, vi, zi, true));               // z = M(V[:,i])
       else MG_TRY(k_dscale(h, lv, dprec, vi, zi, n));
       MG_TRY(k_spmv(h, lv, MG_K_SPMV, L.A, 1.0, zi, 0.0, w));             // w = A z
-      for (int k = 0; k <= i; ++k) {                                      // modified Gram-Schmidt
-        double hk = 0.0;
-        MG_TRY(dot_sync(h, w, V + (size_t)k * n, n, &hk));
-        Hat(k, i) = hk;
-        MG_TRY(k_axpby(h, -hk, V + (size_t)k * n, 1.0, w, n));
+      // modified Gram-Schmidt with the chain dot -> update -> dot on the device: h_k = w.V_k stays in HBM, the update
+      // w -= h_k V_k reads it there and produces the partials of the next dot (or of ||w||^2) in the same pass; the i+2
+      // scalars come back in ONE readback per inner step (round 2: one host synchronisation instead of i+2)
+      if (h->opt.no_mgs_chain) {   // (A/B: one dot, one host synchronisation and one update per basis vector)
+        for (int k = 0; k <= i; ++k) {
+          double hk = 0.0;
+          MG_TRY(dot_sync(h, w, V + (size_t)k * n, n, &hk));
+          Hat(k, i) = hk;
+          MG_TRY(k_axpby(h, -hk, V + (size_t)k * n, 1.0, w, n));
+        }
+        double wn = 0.0;
+        MG_TRY(norm_sync(h, w, n, &wn));
+        Hat(i + 1, i) = wn;
+        if (wn != 0.0) MG_TRY(k_axpby(h, 1.0 / wn, w, 0.0, w, n));
+      } else {
+        if (h->kscal.n < (size_t)m + 2) MG_TRY(h->kscal.alloc((size_t)m + 2));
+        if (!h->h_kscal) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_kscal), sizeof(double) * 66));
+        const int nb = (int)std::min<long long>(h->nred_blocks, std::max<long long>(1, (n / 2 + mgk::BLK - 1) / mgk::BLK));
+        double* hd = h->kscal.p;
+        hipLaunchKernelGGL(mgk::dot_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, w, V, n, h->partial.p);
+        hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb, hd);
+        for (int k = 0; k <= i; ++k) {
+          hipLaunchKernelGGL(mgk::mgs_step, dim3(nb), dim3(mgk::BLK), 0, h->stream, hd + k, V + (size_t)k * n, w,
+                             k < i ? V + (size_t)(k + 1) * n : (const double*)nullptr, n, h->partial.p);
+          hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb, hd + k + 1);
+        }
+        hipLaunchKernelGGL(mgk::scale_rsqrt, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, hd + i + 1, w, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->h_kscal, hd, sizeof(double) * (size_t)(i + 2), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(spin_sync(h->stream));
+        for (int k = 0; k <= i; ++k) Hat(k, i) = h->h_kscal[k];
+        Hat(i + 1, i) = std::sqrt(h->h_kscal[i + 1]);
       }
-      double wn = 0.0;
-      MG_TRY(norm_sync(h, w, n, &wn));
-      Hat(i + 1, i) = wn;
-      if (wn != 0.0) MG_TRY(k_axpby(h, 1.0 / wn, w, 0.0, w, n));
       for (int k = 0; k < i; ++k) {                                       // previous rotations
         const double t = cs[(size_t)k] * Hat(k, i) + sn[(size_t)k] * Hat(k + 1, i);
         Hat(k + 1, i) = -sn[(size_t)k] * Hat(k, i) + cs[(size_t)k] * Hat(k + 1, i);
@@ -3213,6 +3238,7 @@ int mg_destroy(mg_hierarchy* h) {
   h->kw.release();
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
   if (h->h_blk) (void)hipHostFree(h->h_blk);
+  if (h->h_kscal) (void)hipHostFree(h->h_kscal);
   if (h->h_blk_c) (void)hipHostFree(h->h_blk_c);
   h->blk_partial.release();
   h->blk_c.release();
@@ -3764,6 +3790,16 @@ int mg_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, lon
   MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
   MG_TRY(fgmres_dev(h, h->stage_b.p, h->stage_x.p, inner, tol, maxIter, iters, flag, resvec, nres));
   MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
+  prof_collect(h);
+  return MG_OK;
+}
+
+int mg_fgmres_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long inner, double tol,
+                       long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
+  MG_TRY(check_ready(h, n, 1));
+  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
+  (void)hipSetDevice(h->device);
+  MG_TRY(fgmres_dev(h, b, x, inner, tol, maxIter, iters, flag, resvec, nres));
   prof_collect(h);
   return MG_OK;
 }

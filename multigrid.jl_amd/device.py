@@ -59,6 +59,7 @@ SIGNATURES = {
     "mg_bicgstab_FP64": (C.c_int, [_vp, _dp, _dp, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
     "mg_bicgstab_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
     "mg_fgmres_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
+    "mg_fgmres_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
     "mg_block_pcg_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp]),
     "mg_block_pcg_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp]),
     "mg_block_bicgstab_FP64": (C.c_int, [_vp, _dp, _dp, _ll, _ll, C.c_double, _ll, _lp, _lp, _dp, _lp]),
@@ -452,6 +453,14 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_pcg_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, float(tol), int(maxIter),
                                                   C.byref(iters), C.byref(flag), _f64(resvec)), "mg_pcg_dev")
         return int(flag.value), int(iters.value), resvec[: iters.value]
+
+    def fgmres_dev(self, b, x, inner: int, tol: float, maxIter: int):
+        """solveGMRES_MG on device tensors (one right-hand side); returns (flag, inner steps, resvec)."""
+        iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        resvec = np.zeros(max(int(inner) * int(maxIter), 1))
+        _check(self.lib, self.lib.mg_fgmres_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, int(inner), float(tol), int(maxIter),
+                                                     C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)), "mg_fgmres_dev")
+        return int(flag.value), int(iters.value), resvec[: nres.value]
 
     def spmv(self, level: int, which: int, alpha: float, x, beta: float, y):
         x = self._host_block(x)

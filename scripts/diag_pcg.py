@@ -19,7 +19,7 @@ _x = torch.zeros_like(b)
 _t0 = time.perf_counter()
 while time.perf_counter() - _t0 < 0.6:
     h.cycle_dev(b, _x, 1)
-for name, fn in (("cycle from x = 0 (preconditioner call)", None), ("solveCG_MG (mg_pcg_dev)", "pcg")):
+for name, fn in (("cycle from x = 0 (preconditioner call)", None), ("solveCG_MG (mg_pcg_dev)", "pcg"), ("solveGMRES_MG (mg_fgmres_dev, inner 5)", "fgmres")):
     x = torch.zeros_like(b)
     if fn is None:
         for _ in range(3):
@@ -32,6 +32,16 @@ for name, fn in (("cycle from x = 0 (preconditioner call)", None), ("solveCG_MG 
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / K
         print(f"{name}: {dt*1e3:.4f} ms per cycle = {n/dt/1e9:.2f} G DoF-updates/s", flush=True)
+    elif fn == "fgmres":
+        h.fgmres_dev(b, x, 5, 0.0, 1)
+        x.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        R = 3
+        out = h.fgmres_dev(b, x, 5, 0.0, R)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (5 * R)
+        print(f"{name}: {dt*1e3:.4f} ms per inner step (cycle from x = 0 + A*z + modified Gram-Schmidt), {5 * R} inner steps", flush=True)
     else:
         h.pcg_dev(b, x, 0.0, 3)
         x.zero_()
