@@ -3722,6 +3722,17 @@ static bool host_all_zero(const double* x, long long len) {
   return true;
 }
 
+// the caller's initial guess into the staging buffer: x == 0 (the usual call) is a device memset instead of n*nrhs*8
+// bytes over PCIe (the scan of a zero vector runs at memory speed: host_all_zero)
+static int upload_x_or_zero(mg_hierarchy* h, const double* x, long long n, long long nrhs) {
+  const long long len = n * nrhs;
+  if (host_all_zero(x, len)) {
+    HIP_TRY(hipMemsetAsync(h->stage_x.p, 0, sizeof(double) * (size_t)len, h->stream));
+    return MG_OK;
+  }
+  return upload_block(h, x, h->stage_x.p, n, nrhs);
+}
+
 int mg_cycle_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
                   long long x_is_zero) {
   MG_TRY(check_ready(h, n, nrhs));
@@ -3744,14 +3755,7 @@ int mg_solve_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long
   if (maxIter < 0) return fail(MG_ERR_INVALID, "maxIter < 0");
   (void)hipSetDevice(h->device);
   MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  {  // x == 0 (the usual call): a device memset instead of n*nrhs*8 bytes over PCIe
-    bool xz = true;
-    const long long len = n * nrhs;
-    for (long long i = 0; i < len; ++i)
-      if (x[i] != 0.0) { xz = false; break; }
-    if (xz) HIP_TRY(hipMemsetAsync(h->stage_x.p, 0, sizeof(double) * (size_t)len, h->stream));
-    else MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
-  }
+  MG_TRY(upload_x_or_zero(h, x, n, nrhs));
   MG_TRY(solve_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, resvec));
   MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
   prof_collect(h);
@@ -3774,7 +3778,7 @@ int mg_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double
   if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
   (void)hipSetDevice(h->device);
   MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
-  MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
+  MG_TRY(upload_x_or_zero(h, x, n, 1));
   MG_TRY(pcg_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec));
   MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
   prof_collect(h);
@@ -3787,7 +3791,7 @@ int mg_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, lon
   if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
   (void)hipSetDevice(h->device);
   MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
-  MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
+  MG_TRY(upload_x_or_zero(h, x, n, 1));
   MG_TRY(fgmres_dev(h, h->stage_b.p, h->stage_x.p, inner, tol, maxIter, iters, flag, resvec, nres));
   MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
   prof_collect(h);
@@ -3820,7 +3824,7 @@ int mg_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long long n, d
   if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
   (void)hipSetDevice(h->device);
   MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
-  MG_TRY(upload_block(h, x, h->stage_x.p, n, 1));
+  MG_TRY(upload_x_or_zero(h, x, n, 1));
   MG_TRY(bicgstab_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec, nres));
   MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
   prof_collect(h);
@@ -3843,7 +3847,7 @@ int mg_block_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, 
   if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
   (void)hipSetDevice(h->device);
   MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
+  MG_TRY(upload_x_or_zero(h, x, n, nrhs));
   MG_TRY(block_pcg_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resmat));
   MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
   prof_collect(h);
@@ -3864,7 +3868,7 @@ int mg_block_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long lon
   if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
   (void)hipSetDevice(h->device);
   MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
+  MG_TRY(upload_x_or_zero(h, x, n, nrhs));
   MG_TRY(block_bicgstab_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec, nres));
   MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
   prof_collect(h);
@@ -3887,7 +3891,7 @@ int mg_block_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long 
   if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
   (void)hipSetDevice(h->device);
   MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
+  MG_TRY(upload_x_or_zero(h, x, n, nrhs));
   MG_TRY(block_fgmres_dev(h, h->stage_b.p, h->stage_x.p, inner, tol, maxIter, iters, flag, resvec, nres));
   MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
   prof_collect(h);

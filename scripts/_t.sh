@@ -1,2 +1,3 @@
+set -o pipefail
 mkdir -p gpurun_out
-(python scripts/diag_pcg.py 2>&1 | grep "GMRES"; MG_NO_MGS_CHAIN=1 python scripts/diag_pcg.py 2>&1 | grep "GMRES") | tee gpurun_out/diag_fgmres_ab.txt
+timeout -k 10 900 python -m pytest tests/test_krylov.py tests/test_gpu_parity.py -q -x -m gpu -k "krylov or wrapper or nonzero or solveMG or block" 2>&1 | tail -4 | tee gpurun_out/host_test.log && python scripts/diag_host_api.py 2>&1 | grep "host API" | tee gpurun_out/host_api.txt
