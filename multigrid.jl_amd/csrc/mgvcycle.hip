@@ -923,12 +923,10 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
     else hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<false>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
     HIP_TRY(hipGetLastError());
   }
-  if (want_sumsq) {
+  if (want_sumsq) {   // one partial per workgroup (<= one per CU): a single-workgroup final sum
     const int nb1 = T.nblocks;
     ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-    const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
-    hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
-    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
+    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->scalar.p);
     HIP_TRY(hipGetLastError());
   }
   return MG_OK;
