@@ -723,12 +723,19 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
         acc[j] = (k + u < len[j]) ? t : acc[j];
       }
   }
+  // AXPBY with v.y2: also write d[row]*out - the restriction bc = R r hands the coarse level its first update x = d.*bc
+  // (relax from x = 0: MGcycle.jl:134 with r = b), so that level needs no dscale launch
+  const bool scale2 = (MODE == AXPBY) && v.y2 != nullptr;
   double sq = 0.0;
   if (both && live[0] && live[1]) {
     d2_t o;
     o.x = epilogue<MODE>(v, row[0], acc[0], pb[0], pd[0], px[0]);
     o.y = epilogue<MODE>(v, row[1], acc[1], pb[1], pd[1], px[1]);
     *reinterpret_cast<d2_t*>(v.y + r0) = o;
+    if (scale2) {
+      v.y2[r0] = v.d_full[r0] * o.x;
+      v.y2[r0 + 1] = v.d_full[r0 + 1] * o.y;
+    }
     sq = o.x * o.x + o.y * o.y;
   } else {
 #pragma unroll
@@ -736,6 +743,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
       if (live[j]) {
         const double outv = epilogue<MODE>(v, row[j], acc[j], pb[j], pd[j], px[j]);
         v.y[row[j]] = outv;
+        if (scale2) v.y2[row[j]] = v.d_full[row[j]] * outv;
         sq += outv * outv;
       }
   }

@@ -60,7 +60,7 @@ struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
-  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -88,7 +88,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -458,9 +458,9 @@ struct mg_hierarchy {
   bool lu_only = false;     // a stand-alone factor applier (mg_lu_*): one "level" that consists of the coarsest solve only
   // launch-bound coarse sub-cycles replay as HIP graphs (captured on first use; keyed by level, buffers and cycle)
   struct GraphKey {
-    int level; bool x_zero; char ctype; const void* b; const void* xa; const void* xb;
+    int level; bool x_zero; char ctype; const void* b; const void* xa; const void* xb; bool x1_given;
     bool operator<(const GraphKey& o) const {
-      return std::tie(level, x_zero, ctype, b, xa, xb) < std::tie(o.level, o.x_zero, o.ctype, o.b, o.xa, o.xb);
+      return std::tie(level, x_zero, ctype, b, xa, xb, x1_given) < std::tie(o.level, o.x_zero, o.ctype, o.b, o.xa, o.xb, o.x1_given);
     }
   };
   struct GraphEntry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; double* result = nullptr; };
@@ -767,16 +767,24 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
 }
 
 // y = alpha*M*x + beta*y
+// d2 / y2 (optional, both or none; only where restrict_can_scale(M)): also y2 = d2 .* y
 int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, const double* x,
-           double beta, double* y) {
+           double beta, double* y, const double* d2 = nullptr, double* y2 = nullptr) {
   mgk::VecArgs v{};
   v.x = x;
   v.y = y;
   v.alpha = alpha;
   v.beta = beta;
   v.nrhs = (int)h->nrhs;
-  ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false), moved_bytes(M, h->nrhs, beta != 0.0, false));
+  v.d_full = d2;
+  v.y2 = y2;
+  const double extra = y2 ? 16.0 * (double)M.n_rows : 0.0;
+  ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false) + extra, moved_bytes(M, h->nrhs, beta != 0.0, false) + extra);
   return launch_csr<mgk::AXPBY>(h->stream, M, v);
+}
+// Is the product with M served by csr_rowclass_lane_spmv for one right-hand side (the kernel that can write d.*out too)?
+bool restrict_can_scale(const mg_hierarchy* h, const Csr& M) {
+  return h->nrhs == 1 && !h->opt.no_restrict_scale && M.has_rc && M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && M.rc_lane();
 }
 // out = b - A*x
 int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x,
@@ -1202,11 +1210,14 @@ int fgmres_relax(mg_hierarchy* h, int lv, const double* r0, double* x0, long lon
 // SolveFuncs.jl:26-30, and recursiveCycle would recompute the same values, MGcycle.jl:26-31).
 // x1_ready (with r_valid): xb already holds xa + d.*r, the first pre-smoothing update (written by the residual kernel
 // of the previous solve step, k_residual_sumsq's xnext).
-int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result);
+int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
+              bool x1_given = false);
+// x1_given (with x_zero): xa already holds d.*b, the first update from x = 0 (written by the restriction that produced b).
 // defer_post (solve loop, fine level): leave the LAST post-smoothing sweep to the caller, who fuses it with the residual
 // of the stopping test (k_smooth_residual); *defer_post says whether that happened (result = x before that sweep).
 int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero,
-                char ctype, double** result, bool r_valid = false, bool x1_ready = false, bool* defer_post = nullptr) {
+                char ctype, double** result, bool r_valid = false, bool x1_ready = false, bool* defer_post = nullptr,
+                bool x1_given = false) {
   const int nl = (int)h->nlevels;
   if (l == nl - 1) {  // solveCoarsest (MGcycle.jl:13-18,67-69,177): x = LU \ b
     MG_TRY(k_coarse(h, l, b, xa));
@@ -1237,8 +1248,8 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     npre = 0;
   } else if (x_zero) {
     // two sweeps from x = 0 on a level the two-stage pass serves: x1 = d.*b is formed inside that pass
-    from_zero = npre == 2 && !h->opt.no_march2_zero && march2_ok(h, l, cur, alt, L.r.p, nullptr);
-    if (!from_zero) MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
+    from_zero = !x1_given && npre == 2 && !h->opt.no_march2_zero && march2_ok(h, l, cur, alt, L.r.p, nullptr);
+    if (!from_zero && !x1_given) MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
     --npre;
   } else if (r_valid) {
     if (!x1_ready) MG_TRY(k_xpdr(h, l, cur, L.d.p, L.r.p, alt, L.n));
@@ -1258,7 +1269,9 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   } else {
     MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
   }
-  MG_TRY(k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, C.b.p));
+  // the restriction also writes the coarse level's first update x = d.*bc where its kernel can (no dscale launch there)
+  const bool give_x1 = h->relax_type == 0 && !(ctype == 'K') && l + 1 < nl - 1 && C.relax_set && restrict_can_scale(h, L.R);
+  MG_TRY(k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, C.b.p, give_x1 ? C.d.p : nullptr, give_x1 ? C.x0.p : nullptr));
   double* xc = nullptr;
   if (ctype == 'K' && l + 1 < nl - 1) {
     // K-cycle (MGcycle.jl:72-76): 2 steps of FGMRES on A_{l+1} xc = bc, preconditioned by the K-cycle of level l+1
@@ -1271,7 +1284,7 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     MG_TRY(fgmres_relax(h, l + 1, C.b.p, C.x0.p, 2, kprec, gmresTol, C.kZ.p, C.kAZ.p, true));
     xc = C.x0.p;
   } else {
-    MG_TRY(cycle_sub(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
+    MG_TRY(cycle_sub(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc, give_x1));
   }
   if (l + 1 < nl - 1) {  // MGcycle.jl:78-85
     if (ctype == 'W') {
@@ -1347,16 +1360,17 @@ bool graph_ok(const mg_hierarchy* h, int l, char ctype) {
   if (h->lev[(size_t)l].n * h->nrhs > h->opt.graph_max_rows) return false;
   return (int)h->nlevels - l >= 2 || (h->coarse_lu && h->lu_multi);
 }
-int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result) {
-  if (!graph_ok(h, l, ctype)) return cycle_level(h, l, b, xa, xb, x_zero, ctype, result, false, false);
-  const mg_hierarchy::GraphKey key{l, x_zero, ctype, b, xa, xb};
+int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
+              bool x1_given) {
+  if (!graph_ok(h, l, ctype)) return cycle_level(h, l, b, xa, xb, x_zero, ctype, result, false, false, nullptr, x1_given);
+  const mg_hierarchy::GraphKey key{l, x_zero, ctype, b, xa, xb, x1_given};
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     if (h->graphs.size() >= 64) graphs_clear(h);   // callers cycling through many buffers: start over
     mg_hierarchy::GraphEntry e;
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->capturing = true;
-    const int rc = cycle_level(h, l, b, xa, xb, x_zero, ctype, &e.result, false, false);
+    const int rc = cycle_level(h, l, b, xa, xb, x_zero, ctype, &e.result, false, false, nullptr, x1_given);
     h->capturing = false;
     const hipError_t ce = hipStreamEndCapture(h->stream, &e.graph);
     if (rc != MG_OK || ce != hipSuccess) {

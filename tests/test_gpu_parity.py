@@ -716,6 +716,7 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
     for name, no2, nozero in (("fused", "0", "0"), ("unfused", "1", "0"), ("fused, dscale launched", "0", "1")):
         monkeypatch.setenv("MG_NO_MARCH2", no2)
         monkeypatch.setenv("MG_NO_MARCH2_ZERO", nozero)   # two sweeps from x = 0: x1 = d.*b formed inside the pass, or by dscale
+        monkeypatch.setenv("MG_NO_RESTRICT_SCALE", nozero)   # the restriction also writes the coarse level's d.*bc, or dscale does
         A, p, b = _setup(mg, cells, levels, "Jac", 0.8, pre, post, cyc, maxIter=5)
         h = mg.to_device(p)
         assert h.operator_kernel_variant(1, D.MG_OP_A) == 3
