@@ -791,15 +791,18 @@ def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, 
         for l in range(1, p.levels):
             P = p.Ps[l - 1]
             Pm = P if P.shape[0] == p.As[l - 1].shape[0] else P.T          # fine x coarse
-            xc = rng.standard_normal(Pm.shape[1])
-            y0 = rng.standard_normal(Pm.shape[0])
-            for alpha, beta in ((1.0, 1.0), (1.0, 0.0), (-0.5, 2.0)):
-                y = torch.from_numpy(y0.copy()).cuda()
-                h.spmv_dev(l, D.MG_OP_P, alpha, torch.from_numpy(xc).cuda(), beta, y)
-                want = alpha * (Pm @ xc) + beta * y0
-                got = y.cpu().numpy()
-                assert np.abs(got - want).max() / np.abs(want).max() < KERNEL_TOL
-                res.append(got)
+            R = p.Rs[l - 1]
+            Rm = R if R.shape[1] == p.As[l - 1].shape[0] else R.T          # coarse x fine
+            for which, M in ((D.MG_OP_P, Pm), (D.MG_OP_R, Rm)):
+                xin = rng.standard_normal(M.shape[1])
+                y0 = rng.standard_normal(M.shape[0])
+                for alpha, beta in ((1.0, 1.0), (1.0, 0.0), (-0.5, 2.0)):
+                    y = torch.from_numpy(y0.copy()).cuda()
+                    h.spmv_dev(l, which, alpha, torch.from_numpy(xin).cuda(), beta, y)
+                    want = alpha * (M @ xin) + beta * y0
+                    got = y.cpu().numpy()
+                    assert np.abs(got - want).max() / np.abs(want).max() < KERNEL_TOL
+                    res.append(got)
         x, hist = _compare_solve(mg, p, b)
         outs[name] = (res, x.copy(), np.asarray(p.resvec).copy())
         mg.clear_(p)
