@@ -1024,8 +1024,8 @@ struct TileDev {
   const int* tile_lb;   // per dictionary entry: LDS index of (slot 0, lane 0) or -1
   int P;                // rows per plane
   int nplanes;          // n_rows == nplanes * P
-  int halo;             // slab = RT_CR + 2*halo entries of x
-  int chunks;           // ceil(P / RT_CR)
+  int halo;             // slab = CR + 2*halo entries of x
+  int chunks;           // ceil(P / CR)
   int nblocks;          // ceil(nplanes / RT_NP) * chunks
   int n_cols;
   // per-lane walk (round 2): every lane walks the records of its own rows' class once for its RT_NP rows - the planes of
@@ -1042,16 +1042,17 @@ struct TileRec {
   int pad;
 };
 
-template <int MODE, bool EXC>
-__global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_tile_spmv(RowClassDev C, VecArgs v, TileDev T) {
+// CR: rows of a plane per workgroup = threads per workgroup (1024; 256 for levels whose 1024-row tiles would not fill the chip)
+template <int MODE, bool EXC, int CR>
+__global__ __launch_bounds__(CR, CR >= 1024 ? 8 : 4) void csr_rowclass_tile_spmv(RowClassDev C, VecArgs v, TileDev T) {
   extern __shared__ double win[];
-  __shared__ double red[RT_CR / 64];
+  __shared__ double red[CR / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int bid = xcd_band(blockIdx.x, T.nblocks);
   const int g = bid / T.chunks, c = bid - g * T.chunks;
-  const int SL = RT_CR + 2 * T.halo;
+  const int SL = CR + 2 * T.halo;
   const int pl0 = g * RT_NP;                           // first plane of the tile
-  const int inplane = c * RT_CR + tid;                 // position of the lane's rows inside their planes
+  const int inplane = c * CR + tid;                 // position of the lane's rows inside their planes
   int row[RT_NP], cls[RT_NP];
   double pb[RT_NP], pd[RT_NP], acc[RT_NP];   // (the row's own x is read from LDS in the epilogue: registers are tight)
   bool live[RT_NP];
@@ -1071,10 +1072,10 @@ __global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_til
       if ((MODE == SMOOTH || (MODE == RESID && v.y2)) && v.d) pd[j] = v.d[rr];
     }
   }
-  // stage slabs q = 0 .. RT_NP+1 <-> planes pl0-1 .. pl0+RT_NP, rows [c*RT_CR - halo, c*RT_CR + RT_CR + halo)
+  // stage slabs q = 0 .. RT_NP+1 <-> planes pl0-1 .. pl0+RT_NP, rows [c*CR - halo, c*CR + CR + halo)
   for (int q = 0; q < RT_NP + 2; ++q) {
-    const long long g0 = (long long)(pl0 + q - 1) * T.P + c * RT_CR - T.halo;
-    for (int i = tid; i < SL; i += RT_CR) {
+    const long long g0 = (long long)(pl0 + q - 1) * T.P + c * CR - T.halo;
+    for (int i = tid; i < SL; i += CR) {
       long long gi = g0 + i;
       gi = gi < 0 ? 0 : (gi > T.n_cols - 1 ? T.n_cols - 1 : gi);
       win[q * SL + i] = v.x[gi];
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_til
   double* ddl = reinterpret_cast<double*>(drec + (T.lane ? T.ncls * T.maxlen : 0));
   const bool class_dl = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
   if (T.lane) {
-    for (int i = tid; i < T.ncls * T.maxlen; i += RT_CR) {
+    for (int i = tid; i < T.ncls * T.maxlen; i += CR) {
       const int cc = i / T.maxlen, k = i - cc * T.maxlen;
       const int s = C.cls_ptr[cc], len = C.cls_ptr[cc + 1] - s;
       TileRec r;
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_til
       r.pad = 0;
       drec[i] = r;
     }
-    for (int i = tid; i < T.ncls; i += RT_CR) ddl[i] = class_dl ? C.cls_d[i] : 0.0;
+    for (int i = tid; i < T.ncls; i += CR) ddl[i] = class_dl ? C.cls_d[i] : 0.0;
   }
   __syncthreads();
   const unsigned long long lanebit = 1ull << lane;
@@ -1207,7 +1208,7 @@ __global__ __launch_bounds__(RT_CR, RT_CR >= 1024 ? 8 : 6) void csr_rowclass_til
     __syncthreads();
     if (tid == 0) {
       double t = 0.0;
-      for (int w = 0; w < RT_CR / 64; ++w) t += red[w];
+      for (int w = 0; w < CR / 64; ++w) t += red[w];
       v.sumsq[bid] = t;
     }
   }

@@ -60,6 +60,7 @@ struct Options {
   bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
+  bool no_tile_small = false;
   bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
@@ -88,7 +89,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -202,6 +203,7 @@ struct Csr {
   int rm2_nblocks = 0;
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
+  int rt_cr = mgk::RT_CR;   // rows of a plane per workgroup: 1024, or 256 on levels too small to fill the chip with 1024-row tiles
   // csr_rowclass_winp_spmv (prolongation-shaped operators: the source windows of a workgroup's rows staged in LDS)
   bool rp_ok = false;
   DevBuf<unsigned short> rp_wf;
@@ -311,7 +313,7 @@ struct Csr {
     return t;
   }
   size_t tile_lds_bytes() const {
-    return (size_t)(mgk::RT_NP + 2) * (size_t)(mgk::RT_CR + 2 * rt_halo) * sizeof(double) +
+    return (size_t)(mgk::RT_NP + 2) * (size_t)(rt_cr + 2 * rt_halo) * sizeof(double) +
            (rt_lane ? (size_t)rc_ncls * (size_t)rc_maxlen * 16 + (size_t)rc_ncls * 8 : 0);
   }
   mgk::RowClassDev rcdev() const {
@@ -680,15 +682,20 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
       nb_main = M.rt_nblocks;
       static bool lds_attr_set[3] = {false, false, false};   // up to 80 KiB of dynamic LDS: lift the 64 KiB default once
       if (!lds_attr_set[MODE]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE, false, mgk::RT_CR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE, true, mgk::RT_CR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipGetLastError();
         lds_attr_set[MODE] = true;
       }
-      if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, true>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, C, v, M.tiledev());
-      else hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, false>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, C, v, M.tiledev());
+      if (M.rt_cr == 256) {
+        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, true, 256>), dim3(nb_main), dim3(256), lds, stream, C, v, M.tiledev());
+        else hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, false, 256>), dim3(nb_main), dim3(256), lds, stream, C, v, M.tiledev());
+      } else {
+        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, true, mgk::RT_CR>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, C, v, M.tiledev());
+        else hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, false, mgk::RT_CR>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, C, v, M.tiledev());
+      }
     } else if (M.rc_window && v.y != v.x) {
       nb_main = M.rw_blocks();
       const size_t lds = (size_t)M.rw_doubles * sizeof(double);
@@ -2305,6 +2312,13 @@ int build_tile(Csr& A, const long long grid[3]) {
   if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != (A.regular_cols >= 0 ? A.regular_cols : A.n_rows)) return MG_OK;
   const long long P = grid[0] * grid[1];
   if (P < mgk::RT_CR / 2 || A.n_rows + (mgk::RT_NP + 2) * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
+  // 1024 rows of a plane per workgroup; levels whose 1024-row tiles number fewer than tile_min_wg take 256-row tiles (4 x
+  // the workgroups, a quarter of the threads each) if THOSE fill the chip - else the lane kernel serves the level
+  long long CRt = mgk::RT_CR;
+  {
+    const long long groups = (grid[2] + mgk::RT_NP - 1) / mgk::RT_NP;
+    if (((P + CRt - 1) / CRt) * groups < A.opt.tile_min_wg && !A.opt.no_tile_small && ((P + 255) / 256) * groups >= A.opt.tile_min_wg) CRt = 256;
+  }
   auto split = [&](long long sh, long long& dz, long long& rest) {
     dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
     rest = sh - dz * P;
@@ -2321,7 +2335,7 @@ int build_tile(Csr& A, const long long grid[3]) {
     if (dz < -1 || dz > 1) return MG_OK;
     halo = std::max(halo, rest < 0 ? -rest : rest);
   }
-  const long long SL = mgk::RT_CR + 2 * halo;
+  const long long SL = CRt + 2 * halo;
   if ((mgk::RT_NP + 2) * SL * 8 > 80 * 1024) return MG_OK;   // two workgroups per CU
   std::vector<int> lbs(A.h_rc_off.size(), -1);
   for (size_t c = 0; c + 1 < A.h_rc_ptr.size(); ++c)
@@ -2338,7 +2352,8 @@ int build_tile(Csr& A, const long long grid[3]) {
   A.rt_lane = !A.opt.no_tile_lane && std::all_of(lbs.begin(), lbs.end(), [](int v) { return v >= 0; }) &&
               A.rc_ncls * (long long)A.rc_maxlen <= mgk::RT_LCAP &&
               (mgk::RT_NP + 2) * SL * 8 + A.rc_ncls * (long long)A.rc_maxlen * 16 + A.rc_ncls * 8 <= 80 * 1024;
-  A.rt_chunks = (int)((P + mgk::RT_CR - 1) / mgk::RT_CR);
+  A.rt_cr = (int)CRt;
+  A.rt_chunks = (int)((P + CRt - 1) / CRt);
   A.rt_nblocks = (int)(((grid[2] + mgk::RT_NP - 1) / mgk::RT_NP) * A.rt_chunks);
   {
     // 4096 rows per workgroup: a level that yields fewer workgroups than the chip has CUs is latency-bound and runs

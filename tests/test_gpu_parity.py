@@ -813,6 +813,32 @@ def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cells,levels", [([64, 64, 20], 3), ([48, 40, 20], 2), ([33, 65, 12], 2)])
+def test_plane_tiles_of_256_rows_for_small_levels(mg, built, monkeypatch, cells, levels):
+    """csr_rowclass_tile_spmv<..., 256>: a level whose 1024-row tiles would be too few for the chip takes 256-row tiles
+    (same kernel, a quarter of the threads per workgroup).  Forced here by the workgroup threshold; bit-identical to the
+    lane kernel that serves the level otherwise, and to the oracle within the solve tolerance."""
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    monkeypatch.setenv("MG_NO_MARCH", "1")
+    monkeypatch.setenv("MG_TILE_MIN_WG", "32")
+    runs = {}
+    for name, no_small in (("tiles256", "0"), ("lane", "1")):
+        monkeypatch.setenv("MG_NO_TILE_SMALL", no_small)
+        A, p, b = _setup(mg, cells, levels, maxIter=5)
+        h = mg.to_device(p)
+        var = h.operator_kernel_variant(1, D.MG_OP_A)
+        assert var == (2 if no_small == "0" else 4), var          # plane tiles / lane kernel
+        x, hist = _compare_solve(mg, p, b)
+        runs[name] = (x.copy(), np.asarray(p.resvec).copy())
+        mg.clear_(p)
+    assert np.array_equal(runs["tiles256"][0], runs["lane"][0])
+    assert np.abs(runs["tiles256"][1] - runs["lane"][1]).max() <= 1e-14 * runs["lane"][1][0]
+
+
+@pytest.mark.gpu
 def test_march_with_wrong_grid_hint_and_exception_rows(mg, built, monkeypatch):
     """The marching kernel with a hint that describes the wrong grid (unstaged shifts gather from global memory) and
     with a few perturbed rows (exception rows computed from the CSR arrays): the solve is still the oracle's."""
