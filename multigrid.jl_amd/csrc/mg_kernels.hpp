@@ -771,7 +771,11 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
 // checks that every column of every row falls inside the staged windows; nothing here knows what a prolongation is.
 // Same products in the same order and the same epilogue as the lane kernel.
 // ------------------------------------------------------------------------------------------------
-constexpr int WP_ROWS = 4 * BLK;   // rows of one fine plane per workgroup (lane t: rows t, t + 256, t + 512, t + 768)
+#ifndef MG_WP_T
+#define MG_WP_T 512
+#endif
+constexpr int WP_T = MG_WP_T;        // threads per workgroup
+constexpr int WP_ROWS = 4 * WP_T;   // rows of one fine plane per workgroup (lane t: rows t, t + WP_T, t + 2 WP_T, t + 3 WP_T)
 struct WinPDev {
   const unsigned short* wf;   // per row: index of the row's first column inside the first staged window
   const int* cz0;             // per fine plane: the coarse plane of its rows' first columns, bit 30 set when the plane's rows read ONLY that coarse plane
@@ -781,7 +785,7 @@ struct WinPDev {
 };
 
 template <int DUMMY>
-__global__ __launch_bounds__(BLK) void csr_rowclass_winp_spmv(RowClassDev C, VecArgs v, WinPDev T) {
+__global__ __launch_bounds__(WP_T) void csr_rowclass_winp_spmv(RowClassDev C, VecArgs v, WinPDev T) {
   extern __shared__ double win[];                                  // [2*W] coarse windows | dictionary
   LaneEnt* ent = reinterpret_cast<LaneEnt*>(win + 2 * T.W);        // [ncls][maxlen] {value or 0, BYTE code}: padded dictionary
   const int tid = threadIdx.x;
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_winp_spmv(RowClassDev C, Vec
   double pb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int p = c * WP_ROWS + j * BLK + tid;
+    const int p = c * WP_ROWS + j * WP_T + tid;
     in[j] = p < T.PF;
     row[j] = z * T.PF + p;
     const int rr = in[j] ? row[j] : C.n_rows - 1;
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_winp_spmv(RowClassDev C, Vec
     const int czz = T.cz0[z];
     const long long base0 = (long long)(czz & 0x3FFFFFFF) * T.PC + T.wlo[c];
     const int nstage = (czz & 0x40000000) ? T.W : 2 * T.W;   // (a plane whose rows read one coarse plane: one window)
-    for (int i = tid; i < nstage; i += BLK) {
+    for (int i = tid; i < nstage; i += WP_T) {
       const bool second = i >= T.W;
       long long col = base0 + (second ? (long long)T.PC + (i - T.W) : (long long)i);
       col = col < 0 ? 0 : (col > T.n_cols - 1 ? T.n_cols - 1 : col);
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_winp_spmv(RowClassDev C, Vec
     }
   }
   // records beyond a class's length: value 0 at the class's first entry (they add +-0: no clamps, no predicated additions)
-  for (int i = tid; i < T.ncls * T.maxlen; i += BLK) {
+  for (int i = tid; i < T.ncls * T.maxlen; i += WP_T) {
     const int cc = i / T.maxlen, k = i - cc * T.maxlen;
     const int s0 = C.cls_ptr[cc], ln = C.cls_ptr[cc + 1] - s0;
     LaneEnt e;

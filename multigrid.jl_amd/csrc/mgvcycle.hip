@@ -705,7 +705,7 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
       // a prolongation-shaped operator: the coarse windows of a workgroup's rows staged in LDS (no exception rows)
       const mgk::WinPDev T = M.winpdev();
       nb_main = T.nblocks;
-      hipLaunchKernelGGL((mgk::csr_rowclass_winp_spmv<0>), dim3(nb_main), blk, M.winp_lds_bytes(), stream, C, v, T);
+      hipLaunchKernelGGL((mgk::csr_rowclass_winp_spmv<0>), dim3(nb_main), dim3(mgk::WP_T), M.winp_lds_bytes(), stream, C, v, T);
     } else if (M.rc_lane()) {
       nb_main = M.rc_blocks();
       mgk::LaneDev T;

@@ -1,3 +1,3 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_distributed.py -q -x -m gpu -k "tiles_of_256 or rowclass or march or golden or box or tiled" 2>&1 | tail -12 | tee gpurun_out/t256_test.log && rm -f gpurun_out/bench_env_ab.log && bash scripts/bench_env_ab.sh base MG_NO_TILE_SMALL=1
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "staged_coarse or spmatmul" 2>&1 | tail -3 && rm -f gpurun_out/bench_ab.log && bash scripts/bench_ab.sh base wp256 wp1024
