@@ -69,7 +69,121 @@ def parse():
                     help="N>1: sequence the sharded cycle from Python (torch.distributed) instead of the native mg_dist_* path")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; the median is reported")
     ap.add_argument("--no-generic-pass", action="store_true", help="skip the second pass with the streaming formats forced")
+    ap.add_argument("--n1-reference", default="auto", choices=["auto", "on", "off"],
+                    help="--gpus N > 1 started without a launcher: also run the per-GPU workload on one GPU first and report "
+                         "parallel_efficiency_vs_n1 (auto: weak scaling only - a strong-scaling N = 1 run of 512^3 is its own job)")
     return ap.parse_args()
+
+
+def visible_gpus():
+    """GPUs this process tree may use, WITHOUT initialising HIP (the launcher must stay GPU-free: it starts the ranks)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(base):
+            for line in open(os.path.join(base, node, "properties")):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except Exception:
+        n = 0
+    if n == 0:
+        try:
+            import torch
+            n = torch.cuda.device_count()      # (counting devices does not initialise the GPU on this image)
+        except Exception:
+            n = 0
+    return n
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_ranks(argv, n, extra_env=None, tag=""):
+    """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set - the fan-out the
+    reference does with its worker map, DDParallel.jl:87-105,133-139), wait for all of them and return
+    (exit code, parsed JSON line of rank 0 or None).  The parent never touches the GPU and never execs."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "MG_BENCH_CHILD": "1",
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    line = None
+    for ln in (out0 or b"").decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                line = json.loads(ln)
+            except Exception:
+                pass
+    rc = next((c for c in rcs if c != 0), 0)
+    if rc != 0:
+        log(f"[launcher{tag}] rank exit codes {rcs}")
+    return rc, line
+
+
+def launch(args):
+    """`python bench.py --gpus N` with no launcher around it: be the launcher.  Parses, starts N ranks, relays rank 0's
+    single JSON line (plus what only the launcher knows: the N = 1 reference of the same per-GPU workload and the
+    parallel efficiency against it), exits non-zero if any rank did."""
+    n = args.gpus
+    argv = [a for a in sys.argv[1:]]
+    have = visible_gpus()
+    extra = {}
+    if have < n:
+        if os.environ.get("MG_BENCH_SHARE_GPU") == "1" or os.environ.get("MG_BENCH_ALLOW_SHARE") == "1":
+            extra["MG_BENCH_SHARE_GPU"] = "1"
+            log(f"[launcher] {n} ranks requested, {have} GPU(s) visible: the ranks SHARE cuda:0 through the host-staged "
+                f"transport (functional run; its numbers mean nothing)")
+        else:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (set MG_BENCH_ALLOW_SHARE=1 for a functional "
+                             f"run with all ranks on one GPU)")
+    ref = None
+    if args.n1_reference == "on" or (args.n1_reference == "auto" and args.scaling == "weak"):
+        # the same per-GPU workload on ONE GPU through the single-GPU path (== the default `--gpus 1` line, minus the
+        # CPU baseline and the generic-CSR pass): the denominator of parallel_efficiency_vs_n1
+        a1 = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+              "--no-generic-pass", "--workload", args.workload]
+        if args.cells:
+            a1 += ["--cells", str(args.cells)]
+        if args.levels:
+            a1 += ["--levels", str(args.levels)]
+        rc1, ref = run_ranks(a1, 1, {"MG_BENCH_N1_REFERENCE": "1"}, " n1")
+        if rc1 != 0 or ref is None:
+            log("[launcher] the N = 1 reference run failed; parallel_efficiency_vs_n1 stays null")
+            ref = None
+    rc, line = run_ranks(argv, n, extra)
+    if rc != 0 or line is None:
+        raise SystemExit(rc or 1)
+    line["launcher"] = {"ranks_started": n, "gpus_visible": have, "shared_gpu": bool(extra),
+                        "how": "bench.py started the ranks itself (fresh processes, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set)"}
+    if ref is not None:
+        v1 = float(ref["value"])
+        line["n1_reference"] = {"value": v1, "ms_per_step": ref.get("ms_per_step"), "workload": ref["config"]["workload"],
+                                "path": "single-GPU path, same box, same run"}
+        # weak: N x the work in the same time; strong: the same work N x faster - value(N) / (N * value(1)) either way,
+        # given that the N = 1 run holds the per-GPU workload (weak) or the whole problem (strong)
+        line["parallel_efficiency_vs_n1"] = round(float(line["value"]) / (n * v1), 4)
+    else:
+        line["parallel_efficiency_vs_n1"] = None
+    emit(line)
 
 
 def levels_for(cells):
@@ -84,6 +198,12 @@ def levels_for(cells):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch(args)          # no torchrun around us: start the ranks ourselves (this process stays GPU-free)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus and not args.force_sharded_path:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={os.environ['WORLD_SIZE']}")
     import torch
     import multigrid_jl_amd as mg
 
@@ -320,7 +440,7 @@ def main():
         out = {
             "metric": "V-cycle DoF-updates/s", "value": round(dof_per_s, 1), "unit": "DoF-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{desc} ({n} nodal DoF), {p.levels} levels, nrhs={nrhs}, fp64, "
                                    f"solveMG step = cycle + residual + norm",
@@ -512,6 +632,8 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
         flag = torch.tensor([ok], device=red_dev, dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if float(flag.item()) < 1.0:
+            if H is not Hpy:
+                H.close()      # (gives the tail hierarchy back to the Python sequencer's stream)
             H = Hpy
             native_note = native_note or "another rank could not create the native sequencer"
 
@@ -537,6 +659,7 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
     dt = float(tt.item())
     lb = torch.tensor([Hpy.local_algorithmic_bytes()], device=red_dev, dtype=torch.float64)
     dist.all_reduce(lb, op=dist.ReduceOp.MAX)
+    rccl_ranks = H.comm_count() if hasattr(H, "comm_count") else None
     if rank == 0:
         ach = float(lb.item()) / (dt / K) / 1e9
         out = {
@@ -556,6 +679,8 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
                                        "stream overlapped with the interior rows, one scalar all-reduce per step") +
                                       ", sharded host setup"},
             "relres_after_steps": float(resvec[-1] / resvec[0]),
+            "rccl_comm_ranks": rccl_ranks,      # ncclCommCount of the sequencer's communicator (None/0: host-staged transport)
+            "transport": ("plug-in (host-staged, ranks share one GPU)" if share else "RCCL") if not (args.python_sequencer or native_note) else "torch.distributed",
             "setup_s": {"sharded_setup_incl_upload": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "kernel": "sharded levels of one V-cycle, per GPU (max over ranks)",
                          "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,

@@ -436,6 +436,13 @@ int mg_dist_finalize(mg_dist* h);
 int mg_dist_cycle_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long long n_own, long long x_is_zero);
 int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long long n_own, double tol, long long maxIter,
                            long long* iters, double* resvec);
+/* Number of ranks of the handle's RCCL communicator as the library itself reports it (ncclCommCount); 0 for the
+ * host-staged plug-in transport. */
+int mg_dist_comm_count(mg_dist* h, long long* count);
+/* Hand the tail's mg_hierarchy back to its owner (stream and graph option as before mg_dist_set_tail_INT64).  Needed
+ * only when the tail's handle is to be used or destroyed while this sequencer still exists; mg_dist_destroy does it
+ * itself otherwise, so the tail must outlive the sequencer or be released first. */
+int mg_dist_release_tail(mg_dist* h);
 int mg_dist_destroy(mg_dist* h);
 
 const char* mg_last_error(void);

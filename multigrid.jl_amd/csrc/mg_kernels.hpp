@@ -2842,10 +2842,19 @@ __global__ __launch_bounds__(BLK) void relax_jacobi(CsrDev A, double omega, doub
     if (A.colidx[k] == i) diag = A.val[k];
   d[i] = omega / diag;
 }
-__global__ __launch_bounds__(BLK) void colsumsq_kernel(CsrDev A, double* __restrict__ s) {
-  const int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= A.n_rows) return;
-  for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) atomicAdd(&s[A.colidx[k]], A.val[k] * A.val[k]);
+// s[j] = sum over the entries of COLUMN j of a_ij^2 in ascending row order - the order in which Julia's
+// sum(AT.^2, dims=2) (MGsetup.jl:360) and a row-major pass over A accumulate them: no atomics, the same bits on every run.
+// tptr / tperm: the transposed pattern (entries of column j are tperm[tptr[j] .. tptr[j+1]), ascending rows).
+__global__ __launch_bounds__(BLK) void colsumsq_kernel(const double* __restrict__ val, const int* __restrict__ tptr,
+                                                       const int* __restrict__ tperm, int n_cols, double* __restrict__ s) {
+  const int j = blockIdx.x * BLK + threadIdx.x;
+  if (j >= n_cols) return;
+  double acc = 0.0;
+  for (int k = tptr[j]; k < tptr[j + 1]; ++k) {
+    const double a = val[tperm[k]];
+    acc += a * a;
+  }
+  s[j] = acc;
 }
 __global__ __launch_bounds__(BLK) void relax_spai(CsrDev A, double omega, const double* __restrict__ s,
                                                   double* __restrict__ d) {
@@ -2854,7 +2863,7 @@ __global__ __launch_bounds__(BLK) void relax_spai(CsrDev A, double omega, const 
   double diag = 0.0;
   for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
     if (A.colidx[k] == i) diag = A.val[k];
-  d[i] = omega * diag / s[i];
+  d[i] = omega * (diag / s[i]);   // relaxParam * getSPAIprec(AT) (MGsetup.jl:148, 361): the quotient first
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -7,6 +7,8 @@
 //   solveMG         src/Multigrid/SolveFuncs.jl:3-39
 // The hierarchy is resident in HBM; the host only sequences kernel launches on one HIP stream.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // declarations only: librccl is dlopen'ed by mg_dist_* (single-GPU users do not depend on it)
 
 #include <algorithm>
 #include <cmath>
@@ -269,6 +271,8 @@ struct Csr {
   bool rc_lane() const { return has_rc && !opt.no_lane && rc_ncls <= mgk::RL_NCLS && rc_entries <= mgk::RL_DCAP; }
   // block right-hand sides: csr_rowclass_lane_spmm when every row is in a dictionary class
   bool rc_lane_mm() const { return rc_lane() && !opt.no_lane_mm && rc_nexc == 0; }
+  DevBuf<int> t_ptr, t_perm;   // transposed pattern (column -> entries in ascending row order): SPAI relaxPrec on the device
+  bool has_t = false;
   DevBuf<int> sched_ln;     // L2-tiled order of the lane SpMM's row blocks (built for the current nrhs)
   bool has_sched_ln = false;
   int ln_rows = 0, ln_blocks = 0;
@@ -391,6 +395,9 @@ struct Csr {
     pat_off.release();
     pat.release();
     has_pat = false;
+    t_ptr.release();
+    t_perm.release();
+    has_t = false;
     rowptr.release();
     colidx.release();
     blk_row.release();
@@ -632,7 +639,10 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
   const dim3 grid(M.nblocks), blk(mgk::BLK);
   if (pro && !march_ok(M, v)) return fail(MG_ERR_STATE, "fused prolongation needs the marching kernel");
   if (phase != 0 && !(v.nrhs == 1 && M.has_rc)) {
-    if (phase == 1) return MG_OK;
+    if (phase == 1) {   // nothing is launched: no partial is written either (phase 2 computes the whole product)
+      if (nparts) *nparts = 0;
+      return MG_OK;
+    }
     phase = 0;
   }
   if (phase == 2) {   // (v.sumsq, if set, points at the first free partial: the caller advanced it past phase 1's)
@@ -3095,6 +3105,26 @@ int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, c
   return MG_OK;
 }
 
+// column -> entries in ascending row order (stable counting sort of the stored pattern), for colsumsq_kernel
+int build_transposed_pattern(Csr& A) {
+  if (A.has_t) return MG_OK;
+  std::vector<int> rp((size_t)A.n_rows + 1), ci((size_t)A.nnz);
+  HIP_TRY(hipMemcpy(rp.data(), A.rowptr.p, rp.size() * sizeof(int), hipMemcpyDeviceToHost));
+  if (A.nnz > 0) HIP_TRY(hipMemcpy(ci.data(), A.colidx.p, ci.size() * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> tp((size_t)A.n_cols + 1, 0), perm((size_t)std::max<long long>(A.nnz, 1));
+  for (long long k = 0; k < A.nnz; ++k) ++tp[(size_t)ci[(size_t)k] + 1];
+  for (long long j = 0; j < A.n_cols; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
+  std::vector<int> next(tp.begin(), tp.end() - 1);
+  for (long long i = 0; i < A.n_rows; ++i)
+    for (int k = rp[(size_t)i]; k < rp[(size_t)i + 1]; ++k) perm[(size_t)next[(size_t)ci[(size_t)k]]++] = k;
+  MG_TRY(A.t_ptr.alloc(tp.size()));
+  MG_TRY(A.t_perm.alloc(perm.size()));
+  HIP_TRY(hipMemcpy(A.t_ptr.p, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(A.t_perm.p, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice));
+  A.has_t = true;
+  return MG_OK;
+}
+
 Csr* pick(mg_hierarchy* h, long long level, long long which) {
   if (level < 1 || level > h->nlevels) return nullptr;
   Level& L = h->lev[level - 1];
@@ -3175,8 +3205,9 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
     if (relaxKind == 0) {
       hipLaunchKernelGGL(mgk::relax_jacobi, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), omega[l], L.d.p);
     } else {
-      HIP_TRY(hipMemsetAsync(L.r.p, 0, sizeof(double) * (size_t)L.n, h->stream));  // L.r as scratch for the column sums
-      hipLaunchKernelGGL(mgk::colsumsq_kernel, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), L.r.p);
+      MG_TRY(build_transposed_pattern(L.A));   // (first SPAI re-setup of this level only)
+      hipLaunchKernelGGL(mgk::colsumsq_kernel, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.val.p, L.A.t_ptr.p, L.A.t_perm.p,
+                         (int)L.A.n_cols, L.r.p);   // L.r as scratch for the column sums
       hipLaunchKernelGGL(mgk::relax_spai, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), omega[l], L.r.p, L.d.p);
     }
     hipLaunchKernelGGL(mgk::rap_numeric, dim3((unsigned)C.n), dim3(64), 0, h->stream, L.R.dev(), L.A.dev(), L.P.dev(),
@@ -3357,9 +3388,10 @@ int mg_set_relax_type(mg_hierarchy* h, long long relaxType) {
 
 int mg_set_cycle_type(mg_hierarchy* h, long long cycleType) {
   if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
   if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F' && cycleType != 'K')
     return fail(MG_ERR_INVALID, "cycleType must be 'V', 'W', 'F' or 'K'");
+  if (h->cycle == (char)cycleType) return MG_OK;   // (the cycle type is part of the graph key: nothing to drop)
+  graphs_clear(h);
   if ((cycleType == 'K') != (h->cycle == 'K')) h->finalized = false;  // memKcycle must be (de)allocated
   h->cycle = (char)cycleType;
   return MG_OK;
@@ -4657,22 +4689,24 @@ int mg_kaczmarz_apply_FP64(mg_kaczmarz* k, double* x, const double* b, long long
 // DDParallel.jl:105,133-139.  The host (multigrid.jl_amd/distributed.py, or the Julia glue) cuts the hierarchy into
 // local operators [owned | halo] and send lists; this code owns the vectors and the hot loop.
 // =================================================================================================================
-#include <dlfcn.h>
 namespace {
 // RCCL is loaded lazily (dlopen) so that single-GPU users of the library do not depend on it.
+// Prototypes, handle types and enumerators come from the RCCL header this library is built against (rccl/rccl.h):
+// decltype(&ncclSend) etc. - if the ABI moves, the build follows it or fails, it cannot go silently wrong.
 struct Rccl {
-  typedef struct { char internal[128]; } UniqueId;
+  typedef ncclUniqueId UniqueId;
   void* lib = nullptr;
-  int (*GetUniqueId)(UniqueId*) = nullptr;
-  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool load() {
     if (lib) return true;
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
@@ -4685,6 +4719,7 @@ struct Rccl {
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
     GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
     Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
@@ -4696,7 +4731,10 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
-constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;   // ncclFloat64, ncclSum (rccl.h)
+constexpr ncclDataType_t NCCL_DOUBLE = ncclFloat64;
+constexpr ncclRedOp_t NCCL_SUM = ncclSum;
+static_assert(sizeof(ncclUniqueId) == 128, "mg_dist_unique_id / mg_dist_create exchange the RCCL id as 128 bytes");
+static_assert(ncclFloat64 == 8 && ncclSum == 0, "RCCL enumerators moved: check the glue in INTEGRATION.md");
 
 struct DistPlan {
   bool set = false, active = false;
@@ -4734,7 +4772,7 @@ __global__ __launch_bounds__(256) void dist_gather64(const double* __restrict__ 
 
 struct mg_dist {
   int device = 0, rank = 0, world = 1;
-  void* comm = nullptr;                 // ncclComm_t (RCCL transport)
+  ncclComm_t comm = nullptr;            // RCCL transport
   mg_exchange_fn plug = nullptr;        // host-staged transport (tests / one shared GPU)
   void* plug_user = nullptr;
   hipStream_t stream = nullptr, side = nullptr;
@@ -4745,6 +4783,9 @@ struct mg_dist {
   bool finalized = false;
   // replicated tail
   mg_hierarchy* tail = nullptr;
+  // what the tail's handle looked like before this sequencer borrowed it (restored by mg_dist_release_tail / destroy)
+  hipStream_t tail_prev_stream = nullptr;
+  bool tail_prev_owns = false, tail_prev_no_graph = false, tail_borrowed = false;
   long long n_tail = 0, own_tail = 0, max_tail = 0, nl_total = 0;
   DevBuf<double> bc_pad, bc_all, b_tail, x_tail;
   DevBuf<long long> gather_index;
@@ -4756,8 +4797,8 @@ struct mg_dist {
 };
 
 namespace {
-int dist_nccl(int rc, const char* what) {
-  if (rc == 0) return MG_OK;
+int dist_nccl(ncclResult_t rc, const char* what) {
+  if (rc == ncclSuccess) return MG_OK;
   return fail(MG_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
 }
 #define NCCL_TRY(expr) MG_TRY(dist_nccl((expr), #expr))
@@ -4866,12 +4907,17 @@ int dist_residual_norm(mg_dist* h, DistLevel& L, double* x, const double* b, dou
     return dist_norm(h, L.r.p, L.n_own, norm);
   }
   long long n1 = 0, n2 = 0;
+  {   // capacity before anything is written: every launch form of this operator writes at most this many partials
+    const Csr& M = L.A_int->M;
+    const size_t need = (size_t)std::max(M.blocks1(), M.nblocks) + (size_t)(M.rc_nexc + mgk::BLK - 1) / mgk::BLK + 1;
+    if (need > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small (%zu > %zu)", need, h->partial.n);
+  }
   MG_TRY(dist_exchange_start(h, L.planA, x));
   MG_TRY(mg_op_residual_fused_dev_FP64(L.A_int, x, b, L.d, can ? nullptr : L.r.p, can ? alt : nullptr, h->partial.p, 1, &n1, h->stream));
   MG_TRY(dist_exchange_finish(h, L.planA));
   MG_TRY(mg_op_residual_fused_dev_FP64(L.A_int, x, b, L.d, can ? nullptr : L.r.p, can ? alt : nullptr, h->partial.p + n1, 2, &n2, h->stream));
   const long long nb1 = n1 + n2;
-  if ((size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small (%lld > %zu)", nb1, h->partial.n);
+  if (nb1 <= 0) return fail(MG_ERR_STATE, "the fused residual wrote no partial sums");
   const int nb2 = (int)std::min<long long>(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
   hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->partial2.p);
   hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
@@ -5133,10 +5179,22 @@ int mg_dist_create(long long device_id, long long rank, long long world, const c
     if (!g_rccl.load()) return bail(fail(MG_ERR_HIP, "librccl.so could not be loaded"));
     Rccl::UniqueId u;
     std::memcpy(u.internal, unique_id128, 128);
-    const int rc = g_rccl.CommInitRank(&h->comm, (int)world, u, (int)rank);
-    if (rc != 0) return bail(dist_nccl(rc, "ncclCommInitRank"));
+    const ncclResult_t rc = g_rccl.CommInitRank(&h->comm, (int)world, u, (int)rank);
+    if (rc != ncclSuccess) return bail(dist_nccl(rc, "ncclCommInitRank"));
   }
   *out = h;
+  return MG_OK;
+}
+
+// Ranks of this handle's communicator AS RCCL REPORTS THEM (ncclCommCount); 0 when the handle uses the plug-in transport.
+int mg_dist_comm_count(mg_dist* h, long long* count) {
+  if (!h || !count) return fail(MG_ERR_INVALID, "null argument");
+  *count = 0;
+  if (!h->comm) return MG_OK;
+  if (!g_rccl.CommCount) return fail(MG_ERR_UNSUPPORTED, "this librccl has no ncclCommCount");
+  int c = 0;
+  NCCL_TRY(g_rccl.CommCount(h->comm, &c));
+  *count = c;
   return MG_OK;
 }
 
@@ -5221,7 +5279,16 @@ int mg_dist_set_tail_INT64(mg_dist* h, mg_hierarchy* tail, long long n_tail, lon
   HIP_TRY(hipMemset(h->bc_pad.p, 0, h->bc_pad.bytes()));
   HIP_TRY(hipMemset(h->x_tail.p, 0, h->x_tail.bytes()));
   HIP_TRY(hipMemcpy(h->gather_index.p, gather_index, (size_t)n_tail * sizeof(long long), hipMemcpyHostToDevice));
-  MG_TRY(mg_set_stream(tail, h->stream));
+  // The tail enqueues on this sequencer's stream from now on.  Its own stream (if it owns one) is parked, not destroyed,
+  // and comes back with mg_dist_release_tail / mg_dist_destroy - the handle stays usable by its owner afterwards.
+  graphs_clear(tail);
+  (void)spin_sync(tail->stream);
+  h->tail_prev_stream = tail->stream;
+  h->tail_prev_owns = tail->owns_stream;
+  h->tail_prev_no_graph = tail->opt.no_graph;
+  h->tail_borrowed = true;
+  tail->stream = h->stream;
+  tail->owns_stream = false;
   // Measured at world size 1 on 256^3 (bench.py --force-sharded-path): replaying the tail as a HIP graph between the
   // all-gather and the prolongation costs 40-80 us per step (0.98 -> 1.02-1.06 ms) where the single-GPU cycle gains 23:
   // off unless the tail's handle asks for it (mg_set_option(tail, "dist_tail_graph", 1) / MG_DIST_TAIL_GRAPH=1).
@@ -5263,7 +5330,14 @@ int mg_dist_finalize(mg_dist* h) {
     }
   }
   // one ||r||^2 partial per workgroup of the fused residual pass: at most one per 256 rows, + the exception rows' blocks
-  MG_TRY(h->partial.alloc((size_t)(2 * (h->lev[0].n_own / 256 + 2) + 1024)));
+  {
+    size_t need = (size_t)(2 * (h->lev[0].n_own / 256 + 2) + 1024);
+    if (h->lev[0].A_int) {
+      const Csr& M = h->lev[0].A_int->M;
+      need = std::max(need, (size_t)std::max(M.blocks1(), M.nblocks) + (size_t)(M.rc_nexc + mgk::BLK - 1) / mgk::BLK + 2);
+    }
+    MG_TRY(h->partial.alloc(need));
+  }
   h->finalized = true;
   return MG_OK;
 }
@@ -5319,22 +5393,32 @@ int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long 
   return MG_OK;
 }
 
+// Hand the replicated tail's hierarchy back to its owner: its stream and graph option as they were before
+// mg_dist_set_tail_INT64.  Call it BEFORE destroying the tail's handle when that happens first; mg_dist_destroy calls it
+// otherwise.  The sequencer cannot cycle afterwards (mg_dist_set_tail_INT64 again to re-attach).
+int mg_dist_release_tail(mg_dist* h) {
+  if (!h) return fail(MG_ERR_INVALID, "null handle");
+  if (h->tail && h->tail_borrowed) {
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)spin_sync(h->stream);
+    graphs_clear(h->tail);
+    h->tail->stream = h->tail_prev_stream;
+    h->tail->owns_stream = h->tail_prev_owns;
+    h->tail->opt.no_graph = h->tail_prev_no_graph;
+  }
+  h->tail = nullptr;
+  h->tail_borrowed = false;
+  h->finalized = false;
+  return MG_OK;
+}
+
 int mg_dist_destroy(mg_dist* h) {
   if (!h) return MG_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)spin_sync(h->stream);
   if (h->side) (void)spin_sync(h->side);
   if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
-  if (h->tail && h->tail->stream == h->stream) {   // the tail was enqueuing on this handle's stream: give it one of its own
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) {
-      h->tail->stream = s;
-      h->tail->owns_stream = true;
-    } else {
-      h->tail->stream = nullptr;
-      h->tail->owns_stream = false;
-    }
-  }
+  (void)mg_dist_release_tail(h);
   for (auto& L : h->lev) {
     dist_free_plan(L.planA);
     dist_free_plan(L.planR);

@@ -799,7 +799,15 @@ class NativeDistributedHierarchy:
                  "mg_dist_solve_dev")
         return int(iters.value), resvec[: iters.value + 1]
 
+    def comm_count(self) -> int:
+        """Ranks of the sequencer's RCCL communicator as the library reports them (0: plug-in transport)."""
+        import ctypes as C
+        c = C.c_longlong(0)
+        D._check(self.lib, self.lib.mg_dist_comm_count(self.handle, C.byref(c)), "mg_dist_comm_count")
+        return int(c.value)
+
     def close(self):
+        """Destroy the native sequencer; the tail hierarchy goes back to the Python sequencer's stream first."""
         if self.handle:
             self.lib.mg_dist_destroy(self.handle)
             self.handle = None

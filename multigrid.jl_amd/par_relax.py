@@ -67,8 +67,17 @@ def setupHybridKaczmarz(param: hybridKaczmarz, AT, mesh):
     return param
 
 
+def _matrix_key(A):
+    """Identity of the VALUES as well as of the object: the reference passes AT.nzval on every call (parRelax.jl:61-64), so
+    a matrix modified in place, or a new one allocated at a recycled id, must not hit the uploaded copy."""
+    import zlib
+    A = A if sp.isspmatrix_csr(A) else sp.csr_matrix(A)
+    data = np.ascontiguousarray(A.data)
+    return (A.nnz, A.shape, zlib.crc32(data.view(np.uint8)), zlib.crc32(np.ascontiguousarray(A.indices).view(np.uint8)))
+
+
 def _device_handle(param: hybridKaczmarz, A):
-    key = (id(A), A.nnz, A.shape)
+    key = _matrix_key(A)
     if param._handle is not None and param._key == key:
         return param._handle
     param.close()

@@ -65,8 +65,28 @@ def clear_(param: parallelJuliaSolver):
     return param
 
 
+def _upload_factors(param: "parallelJuliaSolver") -> None:
+    """(Re)create the device applier from param.L / U / p / q (the layout of setupLUFactor)."""
+    lib = D.load_library()
+    L, U = param.L, param.U
+    a64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    Lp, Lc, Lv = a64(L.indptr) + 1, a64(L.indices) + 1, np.ascontiguousarray(L.data, dtype=np.float64)
+    Up, Uc, Uv = a64(U.indptr) + 1, a64(U.indices) + 1, np.ascontiguousarray(U.data, dtype=np.float64)
+    param.close()
+    h = C.c_void_p()
+    D._check(lib, lib.mg_lu_create_FP64_INT64(0, L.shape[0], D._i64(Lp), D._i64(Lc), D._f64(Lv), D._i64(Up), D._i64(Uc),
+                                              D._f64(Uv), D._i64(param.p), D._i64(param.q), C.byref(h)), "mg_lu_create")
+    param._handle = h
+
+
 def copySolver(param: parallelJuliaSolver) -> parallelJuliaSolver:
-    return getParallelJuliaSolver(param.VAL, param.IND, numCores=param.numCores, backend=param.backend)
+    """``copySolver`` (parallelJuliaSolver.jl:257-260): copies of L, U, p, q, the settings, counters reset to zero.  The
+    copy gets a device applier of its own (created on its first solve) - a set-up solver stays set up."""
+    new = getParallelJuliaSolver(param.VAL, param.IND, numCores=param.numCores, backend=param.backend)
+    if param.L is not None:
+        new.L, new.U = param.L.copy(), param.U.copy()
+        new.p, new.q = param.p.copy(), param.q.copy()
+    return new
 
 
 def setupLUFactor(AI, param: parallelJuliaSolver) -> parallelJuliaSolver:
@@ -79,15 +99,7 @@ def setupLUFactor(AI, param: parallelJuliaSolver) -> parallelJuliaSolver:
     param.L, param.U = L, U
     param.p = (np.argsort(lu.perm_r) + 1).astype(np.int64)
     param.q = (np.argsort(lu.perm_c) + 1).astype(np.int64)
-    lib = D.load_library()
-    a64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
-    Lp, Lc, Lv = a64(L.indptr) + 1, a64(L.indices) + 1, np.ascontiguousarray(L.data, dtype=np.float64)
-    Up, Uc, Uv = a64(U.indptr) + 1, a64(U.indices) + 1, np.ascontiguousarray(U.data, dtype=np.float64)
-    param.close()
-    h = C.c_void_p()
-    D._check(lib, lib.mg_lu_create_FP64_INT64(0, L.shape[0], D._i64(Lp), D._i64(Lc), D._f64(Lv), D._i64(Up), D._i64(Uc),
-                                              D._f64(Uv), D._i64(param.p), D._i64(param.q), C.byref(h)), "mg_lu_create")
-    param._handle = h
+    _upload_factors(param)
     return param
 
 
@@ -100,7 +112,9 @@ def solve(b: np.ndarray, x: np.ndarray, LU: parallelJuliaSolver, doTranspose: in
     """x[q] = U \\ (L \\ b[p]), or with doTranspose x[p] = L' \\ (U' \\ b[q]) (parallelJuliaSolver.jl:151-207); x is
     written in place (column-major, as Julia holds it)."""
     if LU._handle is None:
-        raise RuntimeError("the factors were not set up")
+        if LU.L is None:
+            raise RuntimeError("the factors were not set up")
+        _upload_factors(LU)          # a copySolver() copy: factors present, device applier not yet created
     lib = D.load_library()
     bb = np.asfortranarray(b, dtype=np.float64)
     if x.dtype != np.float64 or (x.ndim == 2 and not x.flags.f_contiguous) or not x.flags.writeable:

@@ -56,7 +56,7 @@ def _problem(kind, nrhs, cyc):
 
 
 def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", native=None, box=False):
-    if box and use_hip:       # let the small local operators of the test take the row-class / staged kernels
+    if box and box != "plain" and use_hip:       # let the small local operators of the test take the row-class / staged kernels
         os.environ.update(MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3",
                           MG_MARCH_MIN_WG="0", MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_MARCH_MAX_LEN="64")
     try:
@@ -87,7 +87,7 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", nati
                                                 native_only=bool(native) and (cyc == "K" or p.relaxType == "Jac-GMRES"))
         assert len(H.levels) >= 2, "the test must exercise at least two sharded levels"
         assert H.box_form == bool(box and nodes is not None and nrhs == 1)
-        if box and use_hip and nodes is not None and nrhs == 1:
+        if box and box != "plain" and use_hip and nodes is not None and nrhs == 1:
             var = [L.A_int.kernel_variant() for L in H.levels]
             assert var[0][0] in (1, 2, 3) and (world == 1 or var[0][1] > 0), var   # a staged kernel + exception rows
             if len(nodes) == 3:
@@ -242,6 +242,16 @@ def test_box_form_local_operators_hip(built, world, kind, cyc, native):
     for the rows of the owned box that do not read the halo, csr_rows_spmv for those that do, after the exchange), driven
     by the native sequencer (phase-split launches around the side-stream exchange) and by the Python one."""
     _run(world, kind, 1, cyc, use_hip=True, native=native, box=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_native_box_form_default_thresholds(built, world):
+    """Box-form levels WITHOUT the row-class overrides of the tests above: local operators of fewer than
+    `rowclass_min_rows` rows (and every variable-coefficient operator) are not stored as row classes, so phase 1 of the
+    phase-split launches computes nothing and phase 2 the whole product.  The fused residual + norm of the native solve
+    loop must then sum phase 2's partials only (round-2 ADVICE: it added stale partials of the previous reduction)."""
+    _run(world, "gmg3d", 1, "V", use_hip=True, native="plugin", box="plain")
 
 
 @pytest.mark.gpu

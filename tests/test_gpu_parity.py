@@ -287,9 +287,16 @@ def test_replace_matrix_on_device(mg, built, relaxType, omega, cells):
     _compare_solve(mg, p, b2)
     # the device product is deterministic (no atomics): a second pass over the same values gives the same bits
     first = [M.data.copy() for M in p.As[1:]]
+    first_d = [np.array(d, copy=True) for d in p.relaxPrecs[:len(p.As) - 1]]
     mg.replaceMatrixInHierarchy(p, A2)
     for v0, M in zip(first, p.As[1:]):
         assert np.array_equal(v0, M.data)
+    # ... and so are the relaxPrecs: SPAI's column sums of squares are ordered sums (ascending rows, the order of Julia's
+    # sum(AT.^2, dims=2) and of the host's bincount), not atomics - the same bits as the host's
+    for l, d0 in enumerate(first_d):
+        assert np.array_equal(d0, p.relaxPrecs[l])
+    if relaxType == "SPAI":
+        assert np.array_equal(p.relaxPrecs[0], mg.getRelaxPrec(A2, relaxType, omega))
     mg.clear_(p)
 
 
