@@ -322,8 +322,14 @@ def main():
     # level - the sweep + residual pass (csr_rowclass_march2_spmv), whichever takes more of the step
     dom = max((k for k in ((1, "smooth"), (1, "smooth+residual")) if k in prof), key=lambda k: prof[k][0])
     kdesc = "fine-level fused damped-Jacobi sweep x' = x + d.*(b - A x), level 1"
+    tile_geo = None
     if dom[1] == "smooth+residual":
+        form, geo = h.sweep_residual_form(1)
         kname = "mgk::csr_rowclass_march2_spmv<false>"
+        if form == 3:
+            kname = f"mgk::csr_rowclass_march3_spmv<ZERO, OUT, 1024, {geo[4]}, 2>"
+            tile_geo = {"tiles_per_line": geo[0], "tiles_per_column": geo[1], "TX": geo[2], "TY": geo[3], "rows_per_lane": geo[4],
+                        "workgroups": geo[5], "lds_bytes": geo[6], "estimated_fill_bytes_per_row": geo[7] / 100.0}
         kdesc = ("fine-level damped-Jacobi sweep t = x + d.*(b - A x) AND the residual r = b - A t (with ||r||^2 and the "
                  "next cycle's first update in the solve loop) in one pass, level 1")
     ms_s, cnt_s, bts_s = prof[dom]
@@ -366,6 +372,8 @@ def main():
                 "step_moved_GB": round(step_moved / 1e9, 4), "step_moved_gbs": round(step_moved / (dt / K) / 1e9, 1),
                 "step_csr_equivalent_GB": round(step_bytes / 1e9, 4),
                 "kernels": kern_table}
+    if tile_geo:
+        roofline["inplane_tiles"] = tile_geo
     if dom[1] == "smooth+residual":
         # Temporal blocking lowers the COMPULSORY bytes (34 B/row instead of 2 x 26 for the two launches it replaces), so
         # its fraction of the peak is not comparable with a single-stage kernel's: report, next to it, (a) the same time

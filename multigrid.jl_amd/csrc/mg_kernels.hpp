@@ -1903,6 +1903,387 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two stages per pass on 2-D IN-PLANE TILES (round 3): the same pair as csr_rowclass_march2_spmv,
+//   t = x + d.*(b - A x)  (MGcycle.jl:129-131)   and   r = b - A t  (MGcycle.jl:58-60 / SolveFuncs.jl:26-27),
+// for operators whose classes are "z-stars": at most one entry in plane z-1 and one in plane z+1, both at the row's own
+// in-plane position, and up to RM3_NIP in-plane entries (dy, dx) with |dy|, |dx| <= 1 - the 7-point operator and its
+// boundary classes.  What changes against the 1-D chunks of march2:
+//  * a workgroup owns a TX x TY tile of the plane (x fastest) and walks a run of planes; stage 1 is evaluated on the tile
+//    + one ring of rows, from x staged on the tile + two rings: (TX+4)(TY+4) / (TX TY) of x instead of (C + 4 n1) / C -
+//    the halo no longer grows with the line length (a 513-node line is served like a 257-node one);
+//  * the entries in planes z-1 / z+1 read the row's OWN position only, so they come from registers: a lane keeps x of its
+//    rows for planes z-1, z (carried) and reads z+1 once; t of planes z-2, z-1, z likewise.  LDS then holds 3 slabs of x
+//    (z: in-plane reads, z+1: own read, z+2: being written) and 2 of t instead of 4 + 4, which is what lets the tile grow,
+//    and stage 2 runs ONE plane behind stage 1:
+//      iteration z:  x plane z+2 -> ring | stage 1 on plane z | stage 2 on plane z-1 | barrier
+//  * lane (xx, j) of the (TX+2)-wide stage-1 region owns rows (xx, j + s*SY), s < K1: its rows share the x position, hence
+//    (away from the first/last line of the grid and the first/last plane) the class - ONE set of class records per lane, in
+//    registers: {value of the z-1 entry, value of the z+1 entry, RM3_NIP x (value, byte offset inside a slab)}; classes
+//    with fewer entries are padded with value 0 at their first in-plane offset (adds +-0).
+// Same products in the same order (z-1 entry, in-plane entries in stored order, z+1 entry = ascending columns), same
+// epilogue expressions as march2 / the single-stage kernels.  Loads are consumed one iteration after their issue, stores
+// issued one iteration late (as there).  OUT: bit 0 = r is written, bit 1 = t + d.*r is written.
+// ------------------------------------------------------------------------------------------------
+constexpr int RM3_NIP = 5;      // in-plane entries of a class
+constexpr int RM3_NCLS = 128;   // classes of the operator
+struct M3Class {                // 80 bytes per class; built on the host (build_march3), copied to LDS by every workgroup
+  double v_lo, v_hi;            // value of the entry in plane z-1 / z+1 (0: the class has none)
+  double v[RM3_NIP];            // in-plane values in stored order, 0 beyond the class's length
+  int off[RM3_NIP];             // byte offset (dy*pitch + dx)*8 of each; padding repeats the first one
+  int flags;                    // bit 0: stage 2 of such a row is not computed by this kernel
+};
+static_assert(sizeof(M3Class) == 80, "M3Class is read with 16-byte LDS loads");
+struct March3Dev {
+  const M3Class* cls;           // [ncls]
+  int n1, n2, nplanes, P;       // grid (x fastest), P = n1*n2
+  int TX, TY;                   // core tile
+  int tiles_x, tiles_y;
+  int WX, SY;                   // width of the stage-1 region (TX + 2); lines of it per slot pass (NT / WX)
+  int pitch;                    // doubles per slab line (2*NPL, even)
+  int LY, NPL;                  // lines of an x slab (TY + 4); 16-byte pairs per line
+  int nblocks;
+  int n_cols, ncls;
+};
+
+template <bool ZERO, int OUT, int NT, int K1, int NPM>
+__global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, March2Args a, March3Dev T) {
+  extern __shared__ double win[];
+  __shared__ double red[NT / 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int w = xcd_band(blockIdx.x, T.nblocks);
+  const int pitch = T.pitch;
+  const int XS = T.LY * pitch;                  // doubles per x slab
+  const int TS = (T.TY + 2) * pitch;            // doubles per t slab (same pitch: one set of record offsets serves both)
+  double* xw = win;                             // [3][XS]
+  double* tw = win + 3 * XS;                    // [2][TS]
+  M3Class* dcl = reinterpret_cast<M3Class*>(tw + 2 * TS);    // [ncls]
+  double* dd = reinterpret_cast<double*>(dcl + T.ncls);      // [ncls] class relaxPrec
+  {
+    const int nw = T.ncls * (int)(sizeof(M3Class) / 8);
+    const double* srcd = reinterpret_cast<const double*>(T.cls);
+    double* dstd = reinterpret_cast<double*>(dcl);
+    for (int i = tid; i < nw; i += NT) dstd[i] = srcd[i];
+    for (int i = tid; i < T.ncls; i += NT) dd[i] = C.cls_d[i];
+  }
+  // ---- the lane's place: column xx of the stage-1 region, lines j + s*SY ---------------------------------------------
+  const int xx = tid % T.WX, j = tid / T.WX;
+  const bool lane_ok = j < T.SY;
+  const int own8 = ((j + 1) * pitch + xx + 1) * 8;      // byte offset of slot 0's own entry inside an x slab
+  const int tdelta8 = -(pitch + 1) * 8;                 // ... and of the same row inside a t slab, relative to it
+  const int sstride8 = T.SY * pitch * 8;                // from slot s to slot s + 1
+  // ---- the lane's 16-byte pairs of a slab: pair pid = tid + m*NT is pair i of line l ---------------------------------
+  int pl_line[NPM], pl_i[NPM];
+  bool pl_ok[NPM];
+#pragma unroll
+  for (int m = 0; m < NPM; ++m) {
+    const int pid = tid + m * NT;
+    pl_ok[m] = pid < T.LY * T.NPL;
+    pl_line[m] = pid / T.NPL;
+    pl_i[m] = pid - pl_line[m] * T.NPL;
+  }
+  const long long tot = (long long)T.tiles_x * T.tiles_y * T.nplanes;
+  long long it = tot * w / T.nblocks;
+  const long long it_end = tot * (w + 1) / T.nblocks;
+  const double* src = ZERO ? a.b : a.x;
+  double sq = 0.0;
+  // class records of the lane (registers)
+  double rlo = 0.0, rhi = 0.0, rv[RM3_NIP];
+  int ro[RM3_NIP], rflag = 0, rcls = -1;
+#pragma unroll
+  for (int u = 0; u < RM3_NIP; ++u) {
+    rv[u] = 0.0;
+    ro[u] = 0;
+  }
+#define M3_LOADRECS(cq)                                                                                                \
+  do {                                                                                                                 \
+    const M3Class* q_ = dcl + (cq);                                                                                    \
+    rlo = q_->v_lo;                                                                                                    \
+    rhi = q_->v_hi;                                                                                                    \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) {                                                           \
+      rv[u_] = q_->v[u_];                                                                                              \
+      ro[u_] = q_->off[u_];                                                                                            \
+    }                                                                                                                  \
+    rflag = q_->flags;                                                                                                 \
+    rcls = (cq);                                                                                                       \
+  } while (0)
+  // acc = (z-1 entry) + in-plane entries in stored order + (z+1 entry); base8: byte address of the row's own entry in the slab
+#define M3_WALK(acc, lo_, hi_, slab, base8)                                                                            \
+  do {                                                                                                                 \
+    double xv_[RM3_NIP];                                                                                               \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_)                                                             \
+      xv_[u_] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(slab) + ((base8) + ro[u_]));            \
+    (acc) = (acc) + rlo * (lo_);                                                                                       \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) (acc) = (acc) + rv[u_] * xv_[u_];                           \
+    (acc) = (acc) + rhi * (hi_);                                                                                       \
+  } while (0)
+#define M3_X1(v, cc)                                                                                                   \
+  do {                                                                                                                 \
+    if (ZERO) {                                                                                                        \
+      (v).x = dd[(cc) & 0xFFFFu] * (v).x;                                                                              \
+      (v).y = dd[(cc) >> 16] * (v).y;                                                                                  \
+    }                                                                                                                  \
+  } while (0)
+  __syncthreads();   // dictionaries in place
+  while (it < it_end) {
+    const int c = (int)(it / T.nplanes);
+    const int z0 = (int)(it - (long long)c * T.nplanes);
+    const int z1 = (int)((it_end - it) < (long long)(T.nplanes - z0) ? z0 + (it_end - it) : T.nplanes);
+    it += z1 - z0;
+    const int ty = c / T.tiles_x, tx = c - ty * T.tiles_x;
+    const int x0 = tx * T.TX, y0 = ty * T.TY;
+    // ---- per-tile lane state -------------------------------------------------------------------------------------------
+    int lo[NPM];          // in-plane index of the first entry of the lane's slab line (may be negative)
+    bool lv[NPM];
+#pragma unroll
+    for (int m = 0; m < NPM; ++m) {
+      const int yl = y0 - 2 + pl_line[m];
+      lv[m] = pl_ok[m] && yl >= 0 && yl < T.n2;
+      lo[m] = yl * T.n1 + x0 - 2;
+    }
+    const int gx = x0 - 1 + xx;
+    const bool xin = lane_ok && gx >= 0 && gx < T.n1;
+    const bool xcore = xx >= 1 && xx <= T.TX;
+    const int ip0 = (y0 - 1 + j) * T.n1 + gx;           // in-plane index of slot 0's row; slot s: + s*SY*n1
+    const int ipstride = T.SY * T.n1;
+    unsigned live1 = 0u, core = 0u;                     // per slot: stage 1 is computed / the row belongs to the core tile
+#pragma unroll
+    for (int s = 0; s < K1; ++s) {
+      const int yy = j + s * T.SY, gy = y0 - 1 + yy;
+      const bool l1 = xin && yy < T.TY + 2 && gy >= 0 && gy < T.n2;
+      live1 |= (l1 ? 1u : 0u) << s;
+      core |= ((l1 && xcore && yy >= 1 && yy <= T.TY) ? 1u : 0u) << s;
+    }
+#define M3_G(p, m) ((long long)(p) * T.P + lo[m])
+#define M3_LOADPAIR(dst, p, m)                                                                                         \
+  do {                                                                                                                 \
+    const bool act_ = lv[m] && (p) >= 0 && (p) < T.nplanes;                                                            \
+    const long long e0_ = (M3_G(p, m) & ~1LL) + 2 * pl_i[m];                                                           \
+    (dst) = march_load_pair(src, e0_, act_, T.n_cols);                                                                 \
+  } while (0)
+#define M3_LOADCLSPAIR(dst, p, m)                                                                                      \
+  do {                                                                                                                 \
+    const bool act_ = lv[m] && (p) >= 0 && (p) < T.nplanes;                                                            \
+    const long long e0_ = (M3_G(p, m) & ~1LL) + 2 * pl_i[m];                                                           \
+    (dst) = march_load_clspair(C.cls, e0_, act_, C.n_rows);                                                            \
+  } while (0)
+  // entry k of a slab line = in-plane index lo + k: a leading entry of an odd line start is dropped
+#define M3_STAGE(slot, p, m, v)                                                                                        \
+  do {                                                                                                                 \
+    if (pl_ok[m]) {                                                                                                    \
+      const int k_ = 2 * pl_i[m] - (int)(M3_G(p, m) & 1LL);                                                            \
+      double* q_ = xw + ((slot) * XS + pl_line[m] * pitch + k_);                                                       \
+      if (k_ >= 0) q_[0] = (v).x;                                                                                      \
+      q_[1] = (v).y;                                                                                                   \
+    }                                                                                                                  \
+  } while (0)
+    // ---- fill the ring: planes z0-1 (slot 0) and z0 (slot 1); plane z0+1 goes into registers ----------------------------
+#pragma unroll 1
+    for (int pp = 0; pp < 2; ++pp) {
+      d2_t q[NPM];
+#pragma unroll
+      for (int m = 0; m < NPM; ++m) M3_LOADPAIR(q[m], z0 - 1 + pp, m);
+      if (ZERO) {
+#pragma unroll
+        for (int m = 0; m < NPM; ++m) {
+          unsigned int k;
+          M3_LOADCLSPAIR(k, z0 - 1 + pp, m);
+          M3_X1(q[m], k);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < NPM; ++m) M3_STAGE(pp, z0 - 1 + pp, m, q[m]);
+    }
+    d2_t pre[NPM];
+    unsigned int cpre[NPM];
+#pragma unroll
+    for (int m = 0; m < NPM; ++m) {
+      M3_LOADPAIR(pre[m], z0 + 1, m);
+      cpre[m] = 0u;
+      if (ZERO) M3_LOADCLSPAIR(cpre[m], z0 + 1, m);
+    }
+    // row operands of plane zz: class id and b of every slot's row (a safe row where the slot is not live)
+    int ncls_[K1];
+    double nb_[K1];
+#define M3_OPERANDS(zz)                                                                                                \
+  do {                                                                                                                 \
+    const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
+      const int r_ = (pv_ && ((live1 >> s_) & 1u)) ? (zz) * T.P + ip0 + s_ * ipstride : C.n_rows - 1;                  \
+      ncls_[s_] = C.cls[r_];                                                                                           \
+      nb_[s_] = a.b[r_];                                                                                               \
+    }                                                                                                                  \
+  } while (0)
+    M3_OPERANDS(z0 - 1);
+    // own x of plane z0-2 (the z-1 entry of stage 1 on plane z0-1), straight from global memory
+    double xm[K1], xc[K1];
+#pragma unroll
+    for (int s = 0; s < K1; ++s) {
+      xm[s] = 0.0;
+      if (z0 - 2 >= 0 && ((live1 >> s) & 1u)) {
+        const int r_ = (z0 - 2) * T.P + ip0 + s * ipstride;
+        xm[s] = ZERO ? dd[C.cls[r_]] * a.b[r_] : a.x[r_];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < K1; ++s)   // own x of plane z0-1 from its slab (slot 0)
+      xc[s] = ((live1 >> s) & 1u) ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xw) + (own8 + s * sstride8)) : 0.0;
+    double t1[K1], t2[K1];         // own t of planes z-1, z-2
+    double b1[K1];                 // b of plane z-1 (stage 2)
+    int cls1[K1];
+    double st_t[K1], st_r[K1];     // pending stores (issued at the top of the next iteration); st_r: r, or t + d.*r
+    double st_x[K1];
+    unsigned pend_r = 0u;          // slots with a pending stage-2 store
+    int pend_tz = -1, pend_rz = -1;
+#pragma unroll
+    for (int s = 0; s < K1; ++s) {
+      t1[s] = t2[s] = b1[s] = st_t[s] = st_r[s] = st_x[s] = 0.0;
+      cls1[s] = 0;
+    }
+    int qz = 0;                    // ring slot of plane z (plane z0-1 is slot 0)
+    for (int z = z0 - 1; z <= z1; ++z) {
+      d2_t cur[NPM];
+      unsigned int ccur[NPM];
+      int cls0[K1];
+      double b0[K1];
+#pragma unroll
+      for (int m = 0; m < NPM; ++m) {
+        cur[m] = pre[m];
+        ccur[m] = cpre[m];
+        asm volatile("" : "+v"(cur[m].x), "+v"(cur[m].y));     // the wait of this iteration
+        if (ZERO) asm volatile("" : "+v"(ccur[m]));
+      }
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        cls0[s] = ncls_[s];
+        b0[s] = nb_[s];
+        asm volatile("" : "+v"(cls0[s]), "+v"(b0[s]));
+      }
+      const int q1 = qz == 2 ? 0 : qz + 1, q2 = q1 == 2 ? 0 : q1 + 1;   // slots of planes z+1, z+2
+      // ---- x plane z+2 into its slot (that of plane z-1, last read before the previous barrier) ------------------------
+      if (z + 2 <= z1 + 1) {
+#pragma unroll
+        for (int m = 0; m < NPM; ++m) {
+          M3_X1(cur[m], ccur[m]);
+          M3_STAGE(q2, z + 2, m, cur[m]);
+        }
+      }
+      // ---- stores of the previous iteration, then the loads of x plane z+3 and of the operands of plane z+1 ------------
+      if (pend_tz >= 0) {
+#pragma unroll
+        for (int s = 0; s < K1; ++s)
+          if ((core >> s) & 1u) a.t[pend_tz * T.P + ip0 + s * ipstride] = st_t[s];
+      }
+      if (pend_rz >= 0) {
+#pragma unroll
+        for (int s = 0; s < K1; ++s)
+          if ((pend_r >> s) & 1u) {
+            const int r_ = pend_rz * T.P + ip0 + s * ipstride;
+            if (OUT & 1) a.r[r_] = st_r[s];
+            if (OUT & 2) a.xn[r_] = st_x[s];
+          }
+      }
+      if (z + 3 <= z1 + 1) {
+#pragma unroll
+        for (int m = 0; m < NPM; ++m) {
+          M3_LOADPAIR(pre[m], z + 3, m);
+          if (ZERO) M3_LOADCLSPAIR(cpre[m], z + 3, m);
+        }
+      }
+      if (z + 1 <= z1) M3_OPERANDS(z + 1);
+      // ---- stage 1 on plane z: t = x + d.*(b - A x) on every live row of the lane ----------------------------------------
+      const bool s1 = z >= 0 && z < T.nplanes;          // (uniform)
+      double tc[K1];
+      pend_tz = (s1 && z >= z0 && z < z1) ? z : -1;
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        tc[s] = 0.0;
+        if ((live1 >> s) & 1u) {
+          const int o8 = own8 + s * sstride8;
+          const double xp = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xw) + (q1 * XS * 8 + o8));
+          if (s1) {
+            const int cq = cls0[s];
+            if (cq != rcls) M3_LOADRECS(cq);
+            double acc = 0.0;
+            M3_WALK(acc, xm[s], xp, xw, qz * XS * 8 + o8);
+            const double tv = xc[s] + dd[cq] * (b0[s] - acc);
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(tw) + ((z & 1) * TS * 8 + o8 + tdelta8)) = tv;
+            tc[s] = tv;
+            st_t[s] = tv;
+          }
+          xm[s] = xc[s];
+          xc[s] = xp;
+        }
+      }
+      // ---- stage 2 on plane z-1: r = b - A t (in-plane neighbours from the t slab written before the last barrier) -----------
+      pend_r = 0u;
+      pend_rz = -1;
+      if (z - 1 >= z0 && z - 1 < z1) {                  // (uniform)
+        pend_rz = z - 1;
+#pragma unroll
+        for (int s = 0; s < K1; ++s) {
+          if ((core >> s) & 1u) {
+            const int cq = cls1[s];
+            if (cq != rcls) M3_LOADRECS(cq);
+            if (!(rflag & 1)) {
+              const int o8 = own8 + s * sstride8 + tdelta8;
+              double acc = 0.0;
+              M3_WALK(acc, t2[s], tc[s], tw, ((z - 1) & 1) * TS * 8 + o8);
+              const double rr = b1[s] - acc;
+              st_r[s] = rr;
+              st_x[s] = t1[s] + dd[cq] * rr;
+              sq += rr * rr;
+              pend_r |= 1u << s;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        t2[s] = t1[s];
+        t1[s] = tc[s];
+        b1[s] = b0[s];
+        cls1[s] = cls0[s];
+      }
+      qz = q1;
+      __syncthreads();
+    }
+    if (pend_tz >= 0) {
+#pragma unroll
+      for (int s = 0; s < K1; ++s)
+        if ((core >> s) & 1u) a.t[pend_tz * T.P + ip0 + s * ipstride] = st_t[s];
+    }
+    if (pend_rz >= 0) {
+#pragma unroll
+      for (int s = 0; s < K1; ++s)
+        if ((pend_r >> s) & 1u) {
+          const int r_ = pend_rz * T.P + ip0 + s * ipstride;
+          if (OUT & 1) a.r[r_] = st_r[s];
+          if (OUT & 2) a.xn[r_] = st_x[s];
+        }
+    }
+  }
+  if (a.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w2 = 0; w2 < NT / 64; ++w2) t += red[w2];
+      a.sumsq[w] = t;
+    }
+  }
+#undef M3_LOADRECS
+#undef M3_WALK
+#undef M3_X1
+#undef M3_G
+#undef M3_LOADPAIR
+#undef M3_LOADCLSPAIR
+#undef M3_STAGE
+#undef M3_OPERANDS
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exception rows of a row-class operator (rows whose class was too rare for the dictionary: a few per cent next to
 // sub-domain faces or irregular boundaries): one lane per listed row, straight from the CSR arrays, same epilogues.
 // ------------------------------------------------------------------------------------------------
@@ -2852,7 +3233,7 @@ __global__ __launch_bounds__(BLK) void colsumsq_kernel(const double* __restrict_
   double acc = 0.0;
   for (int k = tptr[j]; k < tptr[j + 1]; ++k) {
     const double a = val[tperm[k]];
-    acc += a * a;
+    acc = __dadd_rn(acc, __dmul_rn(a, a));   // squares rounded, then summed (no fused multiply-add): AT.^2 is an array in the reference
   }
   s[j] = acc;
 }

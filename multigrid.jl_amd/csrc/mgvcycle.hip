@@ -64,6 +64,9 @@ struct Options {
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
   bool no_tile_small = false;
   bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_march3 = false;          // never use the 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv)
+  long long march3_k1 = 2;         // rows of the stage-1 region per lane (2 or 3): tile height = K1 * (1024 / (TX + 2)) - 2
+  long long march3_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -92,6 +95,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -203,6 +207,12 @@ struct Csr {
   int rm_P = 0, rm_nplanes = 0, rm_halo = 0, rm_chunks = 0, rm_nblocks = 0;
   bool rc_march2 = false;   // csr_rowclass_march2_spmv can serve a sweep + residual pair on this operator
   int rm2_nblocks = 0;
+  bool rc_march3 = false;   // ... and so can csr_rowclass_march3_spmv (2-D in-plane tiles, z-star classes): preferred
+  DevBuf<mgk::M3Class> rm3_cls;
+  mgk::March3Dev rm3{};     // tile geometry (cls pointer filled in at launch)
+  size_t rm3_lds = 0;
+  int rm3_k1 = 3;
+  double rm3_fill = 0.0;    // estimated L1 fills + stores per row (bytes) of the chosen geometry
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
   int rt_cr = mgk::RT_CR;   // rows of a plane per workgroup: 1024, or 256 on levels too small to fill the chip with 1024-row tiles
@@ -354,6 +364,8 @@ struct Csr {
     rc_tile = false;
     rc_march = false;
     rc_march2 = false;
+    rc_march3 = false;
+    rm3_cls.release();
     rp_ok = false;
     rp_wf.release();
     h_rc_ptr.clear();
@@ -605,6 +617,8 @@ int pow2_ge(long long v) {
   return g;
 }
 
+// csr_rowclass_march3_spmv: threads per workgroup, 16-byte pairs of a slab per lane
+constexpr int RM3_NT = 1024, RM3_NPM = 2;
 // dynamic LDS of csr_rowclass_march2_spmv: 4 x slabs + 4 t slabs + dictionary
 size_t march2_lds_bytes(int halo) {
   const size_t slx = (size_t)(mgk::RM_C + 4 * halo + 2), slt = (size_t)(mgk::RM_C + 2 * halo);
@@ -912,10 +926,49 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
 // for the level's own A with its own relaxPrec read from the class dictionary.  x, t, r, xn: four different buffers.
 bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* t, const double* r, const double* xn) {
   const Level& L = h->lev[(size_t)level];
-  if (h->nrhs != 1 || h->relax_type != 0 || !L.A.has_rc || !L.A.rc_march || !L.A.rc_march2 || !L.A.rc_has_d || L.A.rc_nexc != 0) return false;
+  if (h->nrhs != 1 || h->relax_type != 0 || !L.A.has_rc || !L.A.rc_has_d || L.A.rc_nexc != 0) return false;
+  if (!(L.A.rc_march && L.A.rc_march2) && !L.A.rc_march3) return false;
   if (L.A.d_bound != L.d.p) return false;   // the dictionary's relaxPrec is this level's
   if (x == t || x == r || x == xn || t == r || t == xn || (r && r == xn)) return false;
   return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+// the 2-D tile form (csr_rowclass_march3_spmv): template arguments from what is wanted
+template <bool ZERO, int OUT, int K1>
+int launch_march3(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
+  auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, RM3_NT, K1, RM3_NPM>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm3.nblocks), dim3(RM3_NT), A.rm3_lds, stream, A.rcdev(), a, A.rm3);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+template <bool ZERO, int OUT>
+int launch_march3_k(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
+  return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 2>(stream, A, a) : launch_march3<ZERO, OUT, 3>(stream, A, a);
+}
+int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::March2Args& a, bool from_zero) {
+  const int nb1 = A.rm3.nblocks;
+  if (a.sumsq && (size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
+  const double n8 = 8.0 * (double)A.n_rows;
+  {
+    ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (a.xn && a.r ? n8 : 0.0),
+                 format_bytes(A, 1) + n8 * (3.0 + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
+    const int out = (a.r ? 1 : 0) | (a.xn ? 2 : 0);
+    int rc = MG_OK;
+    if (from_zero) rc = out == 1 ? launch_march3_k<true, 1>(h->stream, A, a) : out == 2 ? launch_march3_k<true, 2>(h->stream, A, a) : out == 3 ? launch_march3_k<true, 3>(h->stream, A, a) : launch_march3_k<true, 0>(h->stream, A, a);
+    else rc = out == 1 ? launch_march3_k<false, 1>(h->stream, A, a) : out == 2 ? launch_march3_k<false, 2>(h->stream, A, a) : out == 3 ? launch_march3_k<false, 3>(h->stream, A, a) : launch_march3_k<false, 0>(h->stream, A, a);
+    MG_TRY(rc);
+  }
+  if (a.sumsq) {
+    ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
+    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->scalar.p);
+    HIP_TRY(hipGetLastError());
+  }
+  return MG_OK;
 }
 // from_zero: the sweep's input is x1 = d.*b (the level is entered with x = 0): x is not read, no dscale launch is needed
 int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double* x, double* t, double* r, double* xn,
@@ -928,6 +981,7 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
   a.r = r;
   a.xn = xn;
   a.sumsq = want_sumsq ? h->partial.p : nullptr;
+  if (A.rc_march3) return k_smooth_residual3(h, level, A, a, from_zero);
   mgk::MarchDev T = A.marchdev();
   T.nblocks = A.rm2_nblocks;
   if (want_sumsq && (size_t)T.nblocks > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
@@ -2431,6 +2485,143 @@ int build_march(Csr& A, const long long grid[3]) {
     A.rc_march2 = true;
   return MG_OK;
 }
+int build_march3(Csr& A, const long long grid[3]);
+// every staged form of a level's A that depends on the grid hint and on the classes
+int build_staged(Csr& A, const long long grid[3]) {
+  MG_TRY(build_tile(A, grid));
+  MG_TRY(build_march(A, grid));
+  return build_march3(A, grid);
+}
+
+// 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv): the operator must be a grid operator of z-star classes -
+// per class at most one entry in plane z-1 (the first) and one in plane z+1 (the last), both at the row's own in-plane
+// position, and at most RM3_NIP in-plane entries (dy, dx), |dy|, |dx| <= 1.  Tile geometry: the stage-1 region is
+// WX = TX + 2 columns wide, a 1024-thread workgroup holds SY = 1024 / WX lines of it per slot pass and K1 passes, so
+// TY = K1*SY - 2; tiles per line and K1 are chosen by an estimate of the L1 fills per row (halo + run ends), within the
+// LDS (3 x slabs + 2 t slabs + class records <= 160 KB) and the two 16-byte pairs a lane loads per slab.
+int build_march3(Csr& A, const long long grid[3]) {
+  A.rc_march3 = false;
+  if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march3 || A.opt.no_march2 || A.opt.no_march) return MG_OK;
+  if (A.rc_nexc != 0 || A.regular_cols >= 0) return MG_OK;
+  const long long n1 = grid[0], n2 = grid[1], n3 = grid[2];
+  if (n1 < 4 || n2 < 4 || n3 < 3 || n1 * n2 * n3 != A.n_rows) return MG_OK;
+  const long long P = n1 * n2;
+  if (A.n_rows + 4 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
+  const size_t ncls = A.h_rc_ptr.size() - 1;
+  if (ncls > (size_t)mgk::RM3_NCLS) return MG_OK;
+  // ---- classes: decompose every column shift into (dz, dy, dx) ------------------------------------------------------------
+  struct Ent { int dz, dy, dx; };
+  std::vector<std::vector<Ent>> ents(ncls);
+  for (size_t c = 0; c < ncls; ++c) {
+    int nip = 0;
+    const int k0 = A.h_rc_ptr[c], k1 = A.h_rc_ptr[c + 1];
+    for (int k = k0; k < k1; ++k) {
+      const long long sh = (long long)A.h_rc_delta[c] + A.h_rc_off[(size_t)k];
+      const long long dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
+      const long long rest = sh - dz * P;
+      const long long dy = (rest >= 0) ? (rest + n1 / 2) / n1 : -((-rest + n1 / 2) / n1);
+      const long long dx = rest - dy * n1;
+      if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) return MG_OK;
+      if (dz != 0 && (dy != 0 || dx != 0)) return MG_OK;           // not a z-star
+      if (dz == -1 && k != k0) return MG_OK;                       // the z-1 entry comes first ...
+      if (dz == 1 && k != k1 - 1) return MG_OK;                    // ... the z+1 entry last (ascending columns)
+      if (dz == 0 && ++nip > mgk::RM3_NIP) return MG_OK;
+      ents[c].push_back({(int)dz, (int)dy, (int)dx});
+    }
+  }
+  // ---- tile geometry ------------------------------------------------------------------------------------------------------
+  int dev = 0, ncu = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const long long lds_cap = 160 * 1024 - 1024;
+  const size_t dict_bytes = ncls * (sizeof(mgk::M3Class) + 8);
+  struct Geo { long long tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, K1, nb; size_t lds; double fill; };
+  Geo best{};
+  bool have = false;
+  for (long long K1 = 2; K1 <= 3; ++K1) {
+    if (A.opt.march3_k1 >= 2 && A.opt.march3_k1 <= 3 && K1 != A.opt.march3_k1) continue;
+    for (long long tilesx = 1; tilesx <= std::max<long long>(1, n1 / 16); ++tilesx) {
+      if (A.opt.march3_tiles_x > 0 && tilesx != A.opt.march3_tiles_x) continue;
+      Geo g{};
+      g.K1 = K1;
+      g.tilesx = tilesx;
+      g.TX = (n1 + tilesx - 1) / tilesx;
+      g.WX = g.TX + 2;
+      if (g.WX > RM3_NT / 2) continue;
+      g.SY = RM3_NT / g.WX;
+      g.TY = std::min<long long>(K1 * g.SY - 2, n2);
+      if (g.TY < 2) continue;
+      g.tilesy = (n2 + g.TY - 1) / g.TY;
+      g.TY = (n2 + g.tilesy - 1) / g.tilesy;                        // equal tiles
+      g.NPL = (g.TX + 6) / 2;
+      g.pitch = 2 * g.NPL;
+      g.LY = g.TY + 4;
+      if (g.LY * g.NPL > (long long)RM3_NPM * RM3_NT) continue;
+      g.lds = (size_t)(3 * g.LY + 2 * (g.TY + 2)) * (size_t)g.pitch * 8 + dict_bytes;
+      if ((long long)g.lds > lds_cap) continue;
+      const long long wg_per_cu = (long long)g.lds * 2 <= lds_cap ? 2 : 1;
+      const long long items = g.tilesx * g.tilesy * n3;
+      g.nb = std::max<long long>(1, std::min<long long>(wg_per_cu * ncu, items / 4));
+      const double R = (double)items / (double)g.nb;                // planes per run
+      const double core = (double)g.TX * (double)g.TY;
+      // fills per row of the grid: tiles are equal, so partial tiles at the far edges are charged through tiles*core / P
+      const double waste = (double)(g.tilesx * g.TX) * (double)(g.tilesy * g.TY) / (double)P;
+      g.fill = waste * (8.0 * (double)((g.TX + 4) * (g.TY + 4)) / core * (1.0 + 3.0 / R) +
+                        10.0 * (double)((g.TX + 2) * (g.TY + 2)) / core * (1.0 + 2.0 / R)) + 16.0;
+      if (!have || g.fill < best.fill) {
+        best = g;
+        have = true;
+      }
+    }
+  }
+  if (!have) return MG_OK;
+  if (best.nb < std::min<long long>(A.opt.march_min_wg, ncu)) return MG_OK;   // small levels: latency-bound, other kernels
+  // ---- class records with byte offsets in the chosen pitch ------------------------------------------------------------------
+  std::vector<mgk::M3Class> recs(ncls);
+  for (size_t c = 0; c < ncls; ++c) {
+    mgk::M3Class q{};
+    int nip = 0, first_off = 0;
+    const int k0 = A.h_rc_ptr[c];
+    std::vector<double> vals((size_t)(A.h_rc_ptr[c + 1] - k0));
+    HIP_TRY(hipMemcpy(vals.data(), A.rc_val.p + k0, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < ents[c].size(); ++e) {
+      const Ent& t = ents[c][e];
+      if (t.dz == -1) q.v_lo = vals[e];
+      else if (t.dz == 1) q.v_hi = vals[e];
+      else {
+        const int off = (int)((t.dy * best.pitch + t.dx) * 8);
+        if (nip == 0) first_off = off;
+        q.v[nip] = vals[e];
+        q.off[nip] = off;
+        ++nip;
+      }
+    }
+    for (int u = nip; u < mgk::RM3_NIP; ++u) {
+      q.v[u] = 0.0;
+      q.off[u] = first_off;
+    }
+    q.flags = 0;
+    recs[c] = q;
+  }
+  MG_TRY(A.rm3_cls.alloc(ncls));
+  HIP_TRY(hipMemcpy(A.rm3_cls.p, recs.data(), ncls * sizeof(mgk::M3Class), hipMemcpyHostToDevice));
+  mgk::March3Dev T{};
+  T.cls = A.rm3_cls.p;
+  T.n1 = (int)n1; T.n2 = (int)n2; T.nplanes = (int)n3; T.P = (int)P;
+  T.TX = (int)best.TX; T.TY = (int)best.TY; T.tiles_x = (int)best.tilesx; T.tiles_y = (int)best.tilesy;
+  T.WX = (int)best.WX; T.SY = (int)best.SY; T.pitch = (int)best.pitch; T.LY = (int)best.LY; T.NPL = (int)best.NPL;
+  T.nblocks = (int)best.nb;
+  T.n_cols = (int)A.n_cols; T.ncls = (int)ncls;
+  A.rm3 = T;
+  A.rm3_lds = best.lds;
+  A.rm3_k1 = (int)best.K1;
+  A.rm3_fill = best.fill;
+  A.rc_march3 = true;
+  if (A.opt.debug_format)
+    std::fprintf(stderr, "[mg] march3: grid %lldx%lldx%lld tiles %lldx%lld of %lldx%lld (K1 %lld, SY %lld), %lld workgroups, LDS %zu B, est. %.1f B/row\n",
+                 n1, n2, n3, best.tilesx, best.tilesy, best.TX, best.TY, best.K1, best.SY, best.nb, best.lds, best.fill);
+  return MG_OK;
+}
 
 // Prolongation-shaped operators (csr_rowclass_winp_spmv): rows = a fine grid gf, columns = a coarse grid gc, explicit
 // first columns.  Everything is derived from the stored pattern and checked against it: the coarse plane of each fine
@@ -2573,8 +2764,7 @@ int alloc_scratch(mg_hierarchy* h) {
     for (int l = 0; l < (int)h->nlevels; ++l) {
       Level& L = h->lev[(size_t)l];
       MG_TRY(build_schedule(L.A, L.grid, k));
-      MG_TRY(build_tile(L.A, L.grid));
-      MG_TRY(build_march(L.A, L.grid));
+      MG_TRY(build_staged(L.A, L.grid));
       MG_TRY(build_schedule(L.P, L.grid, k));
       if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
       if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_winp(L.P, L.grid, h->lev[(size_t)l + 1].grid));
@@ -3227,8 +3417,7 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
   }
   for (int l = 0; l + 1 < nl; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));   // relaxPrecs were recomputed above
   for (int l = 0; l < nl; ++l) {   // tile / march tables follow the new classes
-    MG_TRY(build_tile(h->lev[(size_t)l].A, h->lev[(size_t)l].grid));
-    MG_TRY(build_march(h->lev[(size_t)l].A, h->lev[(size_t)l].grid));
+    MG_TRY(build_staged(h->lev[(size_t)l].A, h->lev[(size_t)l].grid));
   }
   if (levels_done) *levels_done = nl - 1;
   return MG_OK;
@@ -3667,8 +3856,7 @@ int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, co
   if (which == MG_OP_A) {
     Level& L = h->lev[(size_t)level - 1];
     if (L.relax_set) MG_TRY(derive_class_d(L));
-    MG_TRY(build_tile(L.A, L.grid));
-    MG_TRY(build_march(L.A, L.grid));
+    MG_TRY(build_staged(L.A, L.grid));
   }
   return MG_OK;
 }
@@ -4315,6 +4503,29 @@ int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which
   return MG_OK;
 }
 
+// Which kernel fuses a sweep with the residual that follows it on this level's A (one right-hand side): *form = 0 none
+// (two launches), 2 csr_rowclass_march2_spmv (1-D chunks), 3 csr_rowclass_march3_spmv (2-D in-plane tiles).  geometry
+// (optional, 8 entries, form 3): tiles per line, tiles per column, TX, TY, rows of the stage-1 region per lane (K1),
+// workgroups, dynamic LDS bytes, estimated L1 fills + stores per row in hundredths of a byte.
+int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, long long* geometry) {
+  if (!h || !form) return fail(MG_ERR_INVALID, "null argument");
+  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  const Csr& A = h->lev[(size_t)level - 1].A;
+  *form = 0;
+  if (!A.set || !A.has_rc || !A.rc_has_d || A.rc_nexc != 0 || h->nrhs != 1) return MG_OK;
+  if (A.rc_march3) {
+    *form = 3;
+    if (geometry) {
+      const long long g[8] = {A.rm3.tiles_x, A.rm3.tiles_y, A.rm3.TX, A.rm3.TY, A.rm3_k1, A.rm3.nblocks, (long long)A.rm3_lds,
+                              (long long)(A.rm3_fill * 100.0)};
+      std::copy(g, g + 8, geometry);
+    }
+  } else if (A.rc_march && A.rc_march2) {
+    *form = 2;
+  }
+  return MG_OK;
+}
+
 int mg_cycle_bytes(mg_hierarchy* h, double* bytes) {
   if (!h || !bytes) return fail(MG_ERR_INVALID, "null argument");
   if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
@@ -4399,8 +4610,7 @@ int mg_op_create_box_FP64_INT64(long long device_id, long long n_rows, long long
   op->device = (int)device_id;
   int rc = upload_csr(&op->M, Options::from_env(), n_rows, n_cols, colptr, rowval, nzval, regular_cols);
   const long long grid[3] = {n1, n2, n3};
-  if (rc == MG_OK) rc = build_tile(op->M, grid);
-  if (rc == MG_OK) rc = build_march(op->M, grid);
+  if (rc == MG_OK) rc = build_staged(op->M, grid);
   if (rc != MG_OK) {
     op->M.release();
     delete op;

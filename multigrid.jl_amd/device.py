@@ -83,6 +83,7 @@ SIGNATURES = {
     "mg_operator_format": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
     "mg_operator_rowclasses": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _dp]),
     "mg_operator_rowclass_flags": (C.c_int, [_vp, _ll, _ll, _lp, _lp, _lp, _lp]),
+    "mg_sweep_residual_form": (C.c_int, [_vp, _ll, _lp, _lp]),
     "mg_cycle_bytes": (C.c_int, [_vp, _dp]),
     "mg_device_bytes": (C.c_int, [_vp, _dp]),
     "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
@@ -570,6 +571,14 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_operator_rowclass_flags(self.handle, level, which, C.byref(a), C.byref(b), C.byref(c),
                                                              C.byref(e)), "mg_operator_rowclass_flags")
         return bool(a.value), bool(b.value)
+
+    def sweep_residual_form(self, level: int):
+        """(form, geometry): 0 two launches, 2 csr_rowclass_march2_spmv, 3 csr_rowclass_march3_spmv with its tile geometry
+        [tiles per line, tiles per column, TX, TY, rows per lane, workgroups, LDS bytes, est. fill bytes per row x 100]."""
+        f = C.c_longlong(0)
+        g = (C.c_longlong * 8)()
+        _check(self.lib, self.lib.mg_sweep_residual_form(self.handle, level, C.byref(f), g), "mg_sweep_residual_form")
+        return int(f.value), [int(v) for v in g]
 
     def operator_kernel_variant(self, level: int, which: int) -> int:
         """-1 streaming formats, 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv, 2 csr_rowclass_tile_spmv."""

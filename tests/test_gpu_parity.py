@@ -775,6 +775,77 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cells,k1,tiles_x", [([33, 25, 7], 2, 0), ([33, 25, 7], 3, 2), ([40, 30, 9], 2, 3), ([23, 23, 23], 3, 1),
+                                              ([70, 10, 12], 2, 0), ([64, 64, 20], 3, 0), ([64, 64, 20], 2, 4), ([36, 36, 40], 2, 2),
+                                              ([20, 20, 3], 2, 1), ([130, 18, 5], 2, 0), ([257, 9, 4], 3, 0)])
+def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k1, tiles_x):
+    """csr_rowclass_march3_spmv (sweep + residual in one pass on 2-D in-plane tiles; the z-1 / z+1 entries from registers):
+    t, r, t + d.*r and ||r|| against numpy, BIT-identical to the 1-D chunk form (MG_NO_MARCH3=1) and to the two
+    single-stage launches, from a given x and from x = 0 (x1 = d.*b formed inside the pass); the solve against the oracle
+    with bit-identical iterates.  Tile geometries forced through the options: partial tiles at both far edges, one tile
+    per line, tiles narrower than a wavefront's worth of lanes, two and three rows per lane."""
+    import torch
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    monkeypatch.setenv("MG_MARCH_MAX_LEN", "64")
+    monkeypatch.setenv("MG_MARCH3_K1", str(k1))
+    monkeypatch.setenv("MG_MARCH3_TILES_X", str(tiles_x))
+    rng = np.random.default_rng(sum(cells) + 11)
+    xn_ = bn = None
+    runs, outs = {}, {}
+    for name, no3 in (("tiles", "0"), ("chunks", "1")):
+        monkeypatch.setenv("MG_NO_MARCH3", no3)
+        A, p, b = _setup(mg, cells, 2, "Jac", 0.8, 2, 1, "V", maxIter=5)
+        h = mg.to_device(p)
+        form, geo = h.sweep_residual_form(1)
+        assert form == (3 if no3 == "0" else 2), (form, geo)
+        if no3 == "0":
+            assert geo[4] == k1 and (tiles_x == 0 or geo[0] == tiles_x), geo
+        Al, dl = p.As[0], p.relaxPrecs[0]
+        if xn_ is None:
+            xn_, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+        x, bb = torch.from_numpy(xn_).cuda(), torch.from_numpy(bn).cuda()
+        t, r, xn = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+        nrm = h.sweep_residual_dev(1, bb, x, t, r, xn, True)
+        t_want = xn_ + dl * (bn - Al @ xn_)
+        r_want = bn - Al @ t_want
+        assert np.abs(t.cpu().numpy() - t_want).max() / np.abs(t_want).max() < KERNEL_TOL
+        assert np.abs(r.cpu().numpy() - r_want).max() / np.abs(r_want).max() < 10 * KERNEL_TOL
+        assert np.abs(xn.cpu().numpy() - (t_want + dl * r_want)).max() / np.abs(t_want).max() < 10 * KERNEL_TOL
+        assert abs(nrm - np.linalg.norm(r_want)) < 1e-12 * np.linalg.norm(r_want)
+        t1, r1 = torch.zeros_like(x), torch.zeros_like(x)
+        h.fused_dev(1, D.MG_K_SMOOTH, bb, x, t1)
+        h.fused_dev(1, D.MG_K_RESIDUAL, bb, t1, r1)
+        assert torch.equal(t, t1) and torch.equal(r, r1)          # same products, same order
+        # single outputs (the template variants that keep only one pending store per row)
+        t2, r2 = torch.zeros_like(x), torch.zeros_like(x)
+        h.sweep_residual_dev(1, bb, x, t2, r2)
+        assert torch.equal(t2, t) and torch.equal(r2, r)
+        t3, x3 = torch.zeros_like(x), torch.zeros_like(x)
+        h.sweep_residual_dev(1, bb, x, t3, None, x3)
+        assert torch.equal(t3, t) and torch.equal(x3, xn)
+        outs[name] = (t.cpu().numpy(), r.cpu().numpy(), xn.cpu().numpy())
+        x_, hist = _compare_solve(mg, p, b)
+        x0 = np.random.default_rng(99).standard_normal(b.shape)
+        x1 = x0.copy()
+        mg.recursiveCycle(p, b, x1, 1)
+        xo = orc.recursiveCycle(p, b, x0.copy(), 1)
+        assert np.abs(x1 - xo).max() <= RES_TOL * np.abs(xo).max()
+        x2 = x0.copy()
+        mg.solveMG(p, b, x2)
+        runs[name] = (x_.copy(), np.asarray(p.resvec).copy(), x1.copy(), x2.copy())
+        mg.clear_(p)
+    for k in range(3):
+        assert np.array_equal(outs["tiles"][k], outs["chunks"][k]), k
+    for k in (0, 2, 3):
+        assert np.array_equal(runs["tiles"][k], runs["chunks"][k]), k
+    assert np.abs(runs["tiles"][1] - runs["chunks"][1]).max() <= 1e-14 * runs["chunks"][1][0]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cells,levels", [([32, 32, 32], 3), ([33, 25, 7], 2), ([40, 30, 9], 3), ([23, 23, 23], 3), ([31, 16, 12], 2),
                                           ([64, 64, 20], 3), ([70, 10, 12], 2)])
 def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, levels):
