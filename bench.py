@@ -327,9 +327,11 @@ def main():
         form, geo = h.sweep_residual_form(1)
         kname = "mgk::csr_rowclass_march2_spmv<false>"
         if form == 3:
-            kname = f"mgk::csr_rowclass_march3_spmv<ZERO, OUT, 1024, {geo[4]}, 2>"
+            kname = f"mgk::csr_rowclass_march3_spmv<ZERO, OUT, {geo[8]}, {geo[4]}, 2>"
             tile_geo = {"tiles_per_line": geo[0], "tiles_per_column": geo[1], "TX": geo[2], "TY": geo[3], "rows_per_lane": geo[4],
-                        "workgroups": geo[5], "lds_bytes": geo[6], "estimated_fill_bytes_per_row": geo[7] / 100.0}
+                        "threads_per_workgroup": geo[8], "workgroups": geo[5], "lds_bytes": geo[6],
+                        "schedule": (f"lockstep: {geo[9]} segments of {geo[10]} planes per tile" if geo[9] else "balanced ranges"),
+                        "class_table_entries": geo[11], "estimated_fill_bytes_per_row": geo[7] / 100.0}
         kdesc = ("fine-level damped-Jacobi sweep t = x + d.*(b - A x) AND the residual r = b - A t (with ||r||^2 and the "
                  "next cycle's first update in the solve loop) in one pass, level 1")
     ms_s, cnt_s, bts_s = prof[dom]

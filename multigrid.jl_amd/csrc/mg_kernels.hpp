@@ -1575,10 +1575,11 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
 struct March2Args {
   const double* x;   // the iterate before the sweep                    [n_rows]
   const double* b;   //                                                 [n_rows]
-  double* t;         // out: x + d.*(b - A x)                           [n_rows]
+  double* t;         // out (optional): x + d.*(b - A x)                [n_rows]
   double* r;         // out (optional): b - A t                         [n_rows]
   double* xn;        // out (optional): t + d.*r                        [n_rows]
   double* sumsq;     // out (optional): per-workgroup sums of r.^2      [nblocks]
+  double* sink;      // march3: scratch [12 * nblocks * threads] that takes the stores of lanes / planes with nothing to store
 };
 
 constexpr int RM2_CLEN = 7;   // longest class whose records a lane keeps in registers
@@ -1781,7 +1782,7 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
       // ---- x plane z+2 into its slot (that of plane z-2, last read before the previous barrier) -----------------------
       if (z + 2 <= z1 + 1) M2_STAGE((q + 2) & 3, (int)(M2_G0(c, z + 2) & 1LL), cur0, cur1);
       // ---- stores of the previous iteration, then the loads of x plane z+3 and of the operands of plane z+1 ------------
-      if (st_trow >= 0) a.t[st_trow] = st_t;
+      if (st_trow >= 0 && a.t) a.t[st_trow] = st_t;
       if (st_rrow >= 0) {
         if (a.r) a.r[st_rrow] = st_r;
         if (a.xn) a.xn[st_rrow] = st_xn;
@@ -1876,7 +1877,7 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
       b1 = bc;
       __syncthreads();
     }
-    if (st_trow >= 0) a.t[st_trow] = st_t;             // (not reached with the loop's last iteration being stage 2 only)
+    if (st_trow >= 0 && a.t) a.t[st_trow] = st_t;      // (not reached with the loop's last iteration being stage 2 only)
     if (st_rrow >= 0) {
       if (a.r) a.r[st_rrow] = st_r;
       if (a.xn) a.xn[st_rrow] = st_xn;
@@ -1919,13 +1920,21 @@ __global__ __launch_bounds__(RM_C, 4) void csr_rowclass_march2_spmv(RowClassDev 
 //  * lane (xx, j) of the (TX+2)-wide stage-1 region owns rows (xx, j + s*SY), s < K1: its rows share the x position, hence
 //    (away from the first/last line of the grid and the first/last plane) the class - ONE set of class records per lane, in
 //    registers: {value of the z-1 entry, value of the z+1 entry, RM3_NIP x (value, byte offset inside a slab)}; classes
-//    with fewer entries are padded with value 0 at their first in-plane offset (adds +-0).
+//    with fewer entries are padded with value 0 at their first in-plane offset (adds +-0);
+//  * NO class-id stream: the host has verified that cls(x, y, z) = tab[cz[z]][cy[y]][cx[x]] for small index maps cx, cy,
+//    cz (true for every grid operator: the class says which neighbours exist) - the maps live in LDS and the 2 bytes per
+//    row (3.7 with the halo and the partial cache lines of a tile's short segments) are not read at all;
+//  * schedule: either equal contiguous ranges of the (tile, plane) list (as march), or LOCKSTEP - every workgroup one
+//    segment of one tile, all tiles of a segment side by side on one XCD, so that the halo lines two neighbouring tiles
+//    both stage are fetched from HBM once and hit that XCD's L2 the second time.
 // Same products in the same order (z-1 entry, in-plane entries in stored order, z+1 entry = ascending columns), same
 // epilogue expressions as march2 / the single-stage kernels.  Loads are consumed one iteration after their issue, stores
-// issued one iteration late (as there).  OUT: bit 0 = r is written, bit 1 = t + d.*r is written.
+// not waited for (every lane issues every store instruction, so the wait counts them).  OUT: bit 0 = r is written,
+// bit 1 = t + d.*r, bit 2 = t.
 // ------------------------------------------------------------------------------------------------
 constexpr int RM3_NIP = 5;      // in-plane entries of a class
 constexpr int RM3_NCLS = 128;   // classes of the operator
+constexpr int RM3_TAB = 1024;   // entries of the class table tab[cz][cy][cx]
 struct M3Class {                // 80 bytes per class; built on the host (build_march3), copied to LDS by every workgroup
   double v_lo, v_hi;            // value of the entry in plane z-1 / z+1 (0: the class has none)
   double v[RM3_NIP];            // in-plane values in stored order, 0 beyond the class's length
@@ -1935,6 +1944,8 @@ struct M3Class {                // 80 bytes per class; built on the host (build_
 static_assert(sizeof(M3Class) == 80, "M3Class is read with 16-byte LDS loads");
 struct March3Dev {
   const M3Class* cls;           // [ncls]
+  const unsigned short* cmap;   // cx[n1] | cy[n2] | cz[nplanes] | tab[ncz*ncy*ncx]  (class = tab[(cz*ncy + cy)*ncx + cx])
+  int ncx, ncy, ntab;
   int n1, n2, nplanes, P;       // grid (x fastest), P = n1*n2
   int TX, TY;                   // core tile
   int tiles_x, tiles_y;
@@ -1942,9 +1953,16 @@ struct March3Dev {
   int pitch;                    // doubles per slab line (2*NPL, even)
   int LY, NPL;                  // lines of an x slab (TY + 4); 16-byte pairs per line
   int nblocks;
+  int segs, seglen;             // lockstep schedule: segs > 0: workgroup w = segment (w / tiles) of tile (w % tiles)
   int n_cols, ncls;
 };
 
+#ifndef MG_M3_PD
+#define MG_M3_PD 1    // x planes in flight in registers (1 or 2)
+#endif
+#ifndef MG_M3_EXP
+#define MG_M3_EXP 0   // attribution builds (make variant): 1 no class walks, 2 no slab/operand loads, 3 no stores
+#endif
 template <bool ZERO, int OUT, int NT, int K1, int NPM>
 __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, March2Args a, March3Dev T) {
   extern __shared__ double win[];
@@ -1958,13 +1976,20 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   double* tw = win + 3 * XS;                    // [2][TS]
   M3Class* dcl = reinterpret_cast<M3Class*>(tw + 2 * TS);    // [ncls]
   double* dd = reinterpret_cast<double*>(dcl + T.ncls);      // [ncls] class relaxPrec
+  unsigned short* cxL = reinterpret_cast<unsigned short*>(dd + T.ncls);   // cx | cy | cz | tab
+  unsigned short* cyL = cxL + T.n1;
+  unsigned short* czL = cyL + T.n2;
+  unsigned short* tabL = czL + T.nplanes;
   {
     const int nw = T.ncls * (int)(sizeof(M3Class) / 8);
     const double* srcd = reinterpret_cast<const double*>(T.cls);
     double* dstd = reinterpret_cast<double*>(dcl);
     for (int i = tid; i < nw; i += NT) dstd[i] = srcd[i];
     for (int i = tid; i < T.ncls; i += NT) dd[i] = C.cls_d[i];
+    const int nm = T.n1 + T.n2 + T.nplanes + T.ntab;
+    for (int i = tid; i < nm; i += NT) cxL[i] = T.cmap[i];
   }
+  const int zstride = T.ncy * T.ncx;            // class = tabL[cz[z]*zstride + (cy[y]*ncx + cx[x])]
   // ---- the lane's place: column xx of the stage-1 region, lines j + s*SY ---------------------------------------------
   const int xx = tid % T.WX, j = tid / T.WX;
   const bool lane_ok = j < T.SY;
@@ -1972,19 +1997,32 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   const int tdelta8 = -(pitch + 1) * 8;                 // ... and of the same row inside a t slab, relative to it
   const int sstride8 = T.SY * pitch * 8;                // from slot s to slot s + 1
   // ---- the lane's 16-byte pairs of a slab: pair pid = tid + m*NT is pair i of line l ---------------------------------
-  int pl_line[NPM], pl_i[NPM];
-  bool pl_ok[NPM];
+  int pofs[NPM];        // element index of the pair inside a slab (line*pitch + 2*i)
+  int pline[NPM];       // its line
+  unsigned pflag = 0u;  // per m: bit 4m = the pair exists, bit 4m+1 = first pair of its line, bit 4m+2 = its line is inside the grid
 #pragma unroll
   for (int m = 0; m < NPM; ++m) {
     const int pid = tid + m * NT;
-    pl_ok[m] = pid < T.LY * T.NPL;
-    pl_line[m] = pid / T.NPL;
-    pl_i[m] = pid - pl_line[m] * T.NPL;
+    const int l = pid / T.NPL, i = pid - l * T.NPL;
+    pline[m] = l;
+    pofs[m] = l * pitch + 2 * i;
+    if (pid < T.LY * T.NPL) pflag |= 1u << (4 * m);
+    if (i == 0) pflag |= 2u << (4 * m);
   }
-  const long long tot = (long long)T.tiles_x * T.tiles_y * T.nplanes;
-  long long it = tot * w / T.nblocks;
-  const long long it_end = tot * (w + 1) / T.nblocks;
+  const int ntiles = T.tiles_x * T.tiles_y;
+  long long it, it_end;
+  if (T.segs > 0) {     // lockstep: one segment of one tile
+    const int seg = w / ntiles, c = w - seg * ntiles;
+    const int zs = seg * T.seglen, ze = zs + T.seglen < T.nplanes ? zs + T.seglen : T.nplanes;
+    it = (long long)c * T.nplanes + zs;
+    it_end = (long long)c * T.nplanes + (ze > zs ? ze : zs);
+  } else {
+    const long long tot = (long long)ntiles * T.nplanes;
+    it = tot * w / T.nblocks;
+    it_end = tot * (w + 1) / T.nblocks;
+  }
   const double* src = ZERO ? a.b : a.x;
+  double* sk = a.sink + ((size_t)w * NT + tid);   // this lane's slot of the sink
   double sq = 0.0;
   // class records of the lane (registers)
   double rlo = 0.0, rhi = 0.0, rv[RM3_NIP];
@@ -2008,20 +2046,13 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   } while (0)
   // acc = (z-1 entry) + in-plane entries in stored order + (z+1 entry); base8: byte address of the row's own entry in the slab
 #define M3_WALK(acc, lo_, hi_, slab, base8)                                                                            \
-  do {                                                                                                                 \
+  if (MG_M3_EXP != 1) do {                                                                                             \
     double xv_[RM3_NIP];                                                                                               \
     _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_)                                                             \
       xv_[u_] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(slab) + ((base8) + ro[u_]));            \
     (acc) = (acc) + rlo * (lo_);                                                                                       \
     _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) (acc) = (acc) + rv[u_] * xv_[u_];                           \
     (acc) = (acc) + rhi * (hi_);                                                                                       \
-  } while (0)
-#define M3_X1(v, cc)                                                                                                   \
-  do {                                                                                                                 \
-    if (ZERO) {                                                                                                        \
-      (v).x = dd[(cc) & 0xFFFFu] * (v).x;                                                                              \
-      (v).y = dd[(cc) >> 16] * (v).y;                                                                                  \
-    }                                                                                                                  \
   } while (0)
   __syncthreads();   // dictionaries in place
   while (it < it_end) {
@@ -2032,13 +2063,16 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     const int ty = c / T.tiles_x, tx = c - ty * T.tiles_x;
     const int x0 = tx * T.TX, y0 = ty * T.TY;
     // ---- per-tile lane state -------------------------------------------------------------------------------------------
-    int lo[NPM];          // in-plane index of the first entry of the lane's slab line (may be negative)
-    bool lv[NPM];
+    int pg[NPM];          // in-plane index of the pair's first element (before the even floor; may be negative)
+    int pr0[NPM], pr1[NPM];   // ZERO: cy*ncx + cx of the pair's two elements as they land in the slab (clamped into the grid)
+    pflag &= ~0x4444u;
 #pragma unroll
     for (int m = 0; m < NPM; ++m) {
-      const int yl = y0 - 2 + pl_line[m];
-      lv[m] = pl_ok[m] && yl >= 0 && yl < T.n2;
-      lo[m] = yl * T.n1 + x0 - 2;
+      const int yl = y0 - 2 + pline[m];
+      const int i2 = pofs[m] - pline[m] * pitch;        // 2*i
+      if (yl >= 0 && yl < T.n2) pflag |= 4u << (4 * m);
+      pg[m] = yl * T.n1 + x0 - 2 + i2;
+      pr0[m] = pr1[m] = 0;
     }
     const int gx = x0 - 1 + xx;
     const bool xin = lane_ok && gx >= 0 && gx < T.n1;
@@ -2046,34 +2080,54 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     const int ip0 = (y0 - 1 + j) * T.n1 + gx;           // in-plane index of slot 0's row; slot s: + s*SY*n1
     const int ipstride = T.SY * T.n1;
     unsigned live1 = 0u, core = 0u;                     // per slot: stage 1 is computed / the row belongs to the core tile
+    int rp[K1];                                         // cy*ncx + cx of the slot's row (class = tab[cz*zstride + rp])
+    const int cxo = xin ? (int)cxL[gx] : 0;
 #pragma unroll
     for (int s = 0; s < K1; ++s) {
       const int yy = j + s * T.SY, gy = y0 - 1 + yy;
       const bool l1 = xin && yy < T.TY + 2 && gy >= 0 && gy < T.n2;
       live1 |= (l1 ? 1u : 0u) << s;
       core |= ((l1 && xcore && yy >= 1 && yy <= T.TY) ? 1u : 0u) << s;
+      rp[s] = l1 ? (int)cyL[gy] * T.ncx + cxo : 0;
     }
-#define M3_G(p, m) ((long long)(p) * T.P + lo[m])
+#define M3_PAR(p, m) ((int)(((long long)(p) * T.P + pg[m]) & 1LL))
 #define M3_LOADPAIR(dst, p, m)                                                                                         \
   do {                                                                                                                 \
-    const bool act_ = lv[m] && (p) >= 0 && (p) < T.nplanes;                                                            \
-    const long long e0_ = (M3_G(p, m) & ~1LL) + 2 * pl_i[m];                                                           \
-    (dst) = march_load_pair(src, e0_, act_, T.n_cols);                                                                 \
+    const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u && (p) >= 0 && (p) < T.nplanes;                                \
+    const long long e0_ = ((long long)(p) * T.P + pg[m]) & ~1LL;                                                       \
+    (dst) = march_load_pair(src, e0_, act_ && MG_M3_EXP != 2, T.n_cols);                                               \
   } while (0)
-#define M3_LOADCLSPAIR(dst, p, m)                                                                                      \
-  do {                                                                                                                 \
-    const bool act_ = lv[m] && (p) >= 0 && (p) < T.nplanes;                                                            \
-    const long long e0_ = (M3_G(p, m) & ~1LL) + 2 * pl_i[m];                                                           \
-    (dst) = march_load_clspair(C.cls, e0_, act_, C.n_rows);                                                            \
-  } while (0)
-  // entry k of a slab line = in-plane index lo + k: a leading entry of an odd line start is dropped
+  // entry k of a slab line = in-plane index (line start) + k: a leading entry of an odd line start is dropped
 #define M3_STAGE(slot, p, m, v)                                                                                        \
   do {                                                                                                                 \
-    if (pl_ok[m]) {                                                                                                    \
-      const int k_ = 2 * pl_i[m] - (int)(M3_G(p, m) & 1LL);                                                            \
-      double* q_ = xw + ((slot) * XS + pl_line[m] * pitch + k_);                                                       \
-      if (k_ >= 0) q_[0] = (v).x;                                                                                      \
+    if ((pflag >> (4 * (m))) & 1u) {                                                                                   \
+      const int par_ = M3_PAR(p, m);                                                                                   \
+      double* q_ = xw + ((slot) * XS + pofs[m] - par_);                                                                \
+      if (!(par_ && ((pflag >> (4 * (m))) & 2u))) q_[0] = (v).x;                                                       \
       q_[1] = (v).y;                                                                                                   \
+    }                                                                                                                  \
+  } while (0)
+    if (ZERO) {   // x1 = d.*b at the slab positions: the classes of the two elements a pair stores (positions, not loads)
+#pragma unroll
+      for (int m = 0; m < NPM; ++m) {
+        const int yl = y0 - 2 + pline[m];
+        const int i2 = pofs[m] - pline[m] * pitch;
+        const int yc = yl < 0 ? 0 : (yl >= T.n2 ? T.n2 - 1 : yl);
+        const int base = (int)cyL[yc] * T.ncx;
+        pr0[m] = base;    // completed per plane: the parity shifts which two columns the pair holds
+        pr1[m] = x0 - 2 + i2;
+      }
+    }
+    // class of the slab element at column col (clamped into the line) of pair m's line
+#define M3_PAIRCLS(m, col, zb) ((int)tabL[(zb) + pr0[m] + (int)cxL[(col) < 0 ? 0 : ((col) >= T.n1 ? T.n1 - 1 : (col))]])
+#define M3_X1(v, p, m)                                                                                                 \
+  do {                                                                                                                 \
+    if (ZERO) {                                                                                                        \
+      const int zc_ = (p) < 0 ? 0 : ((p) >= T.nplanes ? T.nplanes - 1 : (p));                                          \
+      const int zb_ = (int)czL[zc_] * zstride;                                                                         \
+      const int c0_ = pr1[m] - M3_PAR(p, m);                                                                           \
+      (v).x = dd[M3_PAIRCLS(m, c0_, zb_)] * (v).x;                                                                     \
+      (v).y = dd[M3_PAIRCLS(m, c0_ + 1, zb_)] * (v).y;                                                                 \
     }                                                                                                                  \
   } while (0)
     // ---- fill the ring: planes z0-1 (slot 0) and z0 (slot 1); plane z0+1 goes into registers ----------------------------
@@ -2082,35 +2136,28 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       d2_t q[NPM];
 #pragma unroll
       for (int m = 0; m < NPM; ++m) M3_LOADPAIR(q[m], z0 - 1 + pp, m);
-      if (ZERO) {
 #pragma unroll
-        for (int m = 0; m < NPM; ++m) {
-          unsigned int k;
-          M3_LOADCLSPAIR(k, z0 - 1 + pp, m);
-          M3_X1(q[m], k);
-        }
+      for (int m = 0; m < NPM; ++m) {
+        M3_X1(q[m], z0 - 1 + pp, m);
+        M3_STAGE(pp, z0 - 1 + pp, m, q[m]);
       }
-#pragma unroll
-      for (int m = 0; m < NPM; ++m) M3_STAGE(pp, z0 - 1 + pp, m, q[m]);
     }
-    d2_t pre[NPM];
-    unsigned int cpre[NPM];
+    d2_t pre[NPM], pre2[NPM];     // x planes z+2 and (MG_M3_PD == 2) z+3, in flight
+#pragma unroll
+    for (int m = 0; m < NPM; ++m) M3_LOADPAIR(pre[m], z0 + 1, m);
 #pragma unroll
     for (int m = 0; m < NPM; ++m) {
-      M3_LOADPAIR(pre[m], z0 + 1, m);
-      cpre[m] = 0u;
-      if (ZERO) M3_LOADCLSPAIR(cpre[m], z0 + 1, m);
+      pre2[m] = d2_t{0.0, 0.0};
+      if (MG_M3_PD == 2) M3_LOADPAIR(pre2[m], z0 + 2, m);
     }
-    // row operands of plane zz: class id and b of every slot's row (a safe row where the slot is not live)
-    int ncls_[K1];
+    // b of plane zz for every slot's row (a safe row where the slot is not live)
     double nb_[K1];
 #define M3_OPERANDS(zz)                                                                                                \
   do {                                                                                                                 \
     const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
     _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
       const int r_ = (pv_ && ((live1 >> s_) & 1u)) ? (zz) * T.P + ip0 + s_ * ipstride : C.n_rows - 1;                  \
-      ncls_[s_] = C.cls[r_];                                                                                           \
-      nb_[s_] = a.b[r_];                                                                                               \
+      nb_[s_] = MG_M3_EXP == 2 ? 1.0 : a.b[r_];                                                                        \
     }                                                                                                                  \
   } while (0)
     M3_OPERANDS(z0 - 1);
@@ -2121,8 +2168,14 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       xm[s] = 0.0;
       if (z0 - 2 >= 0 && ((live1 >> s) & 1u)) {
         const int r_ = (z0 - 2) * T.P + ip0 + s * ipstride;
-        xm[s] = ZERO ? dd[C.cls[r_]] * a.b[r_] : a.x[r_];
+        xm[s] = ZERO ? dd[tabL[(int)czL[z0 - 2] * zstride + rp[s]]] * a.b[r_] : a.x[r_];
       }
+    }
+    // As many stores as an iteration of the loop below issues, BEHIND the loads above: the compiler's wait for those loads
+    // at the top of the loop is then s_waitcnt vmcnt(number of stores) on the entry path as well as on the back edge
+    if (MG_M3_EXP != 3) {
+#pragma unroll
+      for (int i = 0; i < K1 * (((OUT >> 2) & 1) + ((OUT >> 1) & 1) + (OUT & 1)); ++i) sk[(size_t)i * T.nblocks * NT] = 0.0;   // (distinct slots: distinct instructions)
     }
     __syncthreads();
 #pragma unroll
@@ -2130,71 +2183,49 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       xc[s] = ((live1 >> s) & 1u) ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xw) + (own8 + s * sstride8)) : 0.0;
     double t1[K1], t2[K1];         // own t of planes z-1, z-2
     double b1[K1];                 // b of plane z-1 (stage 2)
-    int cls1[K1];
-    double st_t[K1], st_r[K1];     // pending stores (issued at the top of the next iteration); st_r: r, or t + d.*r
-    double st_x[K1];
-    unsigned pend_r = 0u;          // slots with a pending stage-2 store
-    int pend_tz = -1, pend_rz = -1;
 #pragma unroll
-    for (int s = 0; s < K1; ++s) {
-      t1[s] = t2[s] = b1[s] = st_t[s] = st_r[s] = st_x[s] = 0.0;
-      cls1[s] = 0;
-    }
+    for (int s = 0; s < K1; ++s) t1[s] = t2[s] = b1[s] = 0.0;
     int qz = 0;                    // ring slot of plane z (plane z0-1 is slot 0)
     for (int z = z0 - 1; z <= z1; ++z) {
       d2_t cur[NPM];
-      unsigned int ccur[NPM];
-      int cls0[K1];
       double b0[K1];
 #pragma unroll
       for (int m = 0; m < NPM; ++m) {
         cur[m] = pre[m];
-        ccur[m] = cpre[m];
-        asm volatile("" : "+v"(cur[m].x), "+v"(cur[m].y));     // the wait of this iteration
-        if (ZERO) asm volatile("" : "+v"(ccur[m]));
+        asm volatile("" : "+v"(cur[m].x), "+v"(cur[m].y));     // the wait of this iteration: the loads, not the stores behind them
       }
 #pragma unroll
       for (int s = 0; s < K1; ++s) {
-        cls0[s] = ncls_[s];
         b0[s] = nb_[s];
-        asm volatile("" : "+v"(cls0[s]), "+v"(b0[s]));
+        asm volatile("" : "+v"(b0[s]));
       }
       const int q1 = qz == 2 ? 0 : qz + 1, q2 = q1 == 2 ? 0 : q1 + 1;   // slots of planes z+1, z+2
       // ---- x plane z+2 into its slot (that of plane z-1, last read before the previous barrier) ------------------------
       if (z + 2 <= z1 + 1) {
 #pragma unroll
         for (int m = 0; m < NPM; ++m) {
-          M3_X1(cur[m], ccur[m]);
+          M3_X1(cur[m], z + 2, m);
           M3_STAGE(q2, z + 2, m, cur[m]);
         }
       }
-      // ---- stores of the previous iteration, then the loads of x plane z+3 and of the operands of plane z+1 ------------
-      if (pend_tz >= 0) {
+      // ---- the loads of x plane z+3 (z+4: two planes in flight) and of b of plane z+1, in flight while this plane is computed
+      if (MG_M3_PD == 2) {
 #pragma unroll
-        for (int s = 0; s < K1; ++s)
-          if ((core >> s) & 1u) a.t[pend_tz * T.P + ip0 + s * ipstride] = st_t[s];
-      }
-      if (pend_rz >= 0) {
+        for (int m = 0; m < NPM; ++m) pre[m] = pre2[m];
+        if (z + 4 <= z1 + 1) {
 #pragma unroll
-        for (int s = 0; s < K1; ++s)
-          if ((pend_r >> s) & 1u) {
-            const int r_ = pend_rz * T.P + ip0 + s * ipstride;
-            if (OUT & 1) a.r[r_] = st_r[s];
-            if (OUT & 2) a.xn[r_] = st_x[s];
-          }
-      }
-      if (z + 3 <= z1 + 1) {
-#pragma unroll
-        for (int m = 0; m < NPM; ++m) {
-          M3_LOADPAIR(pre[m], z + 3, m);
-          if (ZERO) M3_LOADCLSPAIR(cpre[m], z + 3, m);
+          for (int m = 0; m < NPM; ++m) M3_LOADPAIR(pre2[m], z + 4, m);
         }
+      } else if (z + 3 <= z1 + 1) {
+#pragma unroll
+        for (int m = 0; m < NPM; ++m) M3_LOADPAIR(pre[m], z + 3, m);
       }
       if (z + 1 <= z1) M3_OPERANDS(z + 1);
       // ---- stage 1 on plane z: t = x + d.*(b - A x) on every live row of the lane ----------------------------------------
       const bool s1 = z >= 0 && z < T.nplanes;          // (uniform)
+      const int zb0 = s1 ? (int)czL[z] * zstride : 0;   // class table rows of planes z and z-1
+      const int zb1 = (z - 1 >= 0 && z - 1 < T.nplanes) ? (int)czL[z - 1] * zstride : 0;
       double tc[K1];
-      pend_tz = (s1 && z >= z0 && z < z1) ? z : -1;
 #pragma unroll
       for (int s = 0; s < K1; ++s) {
         tc[s] = 0.0;
@@ -2202,39 +2233,59 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
           const int o8 = own8 + s * sstride8;
           const double xp = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xw) + (q1 * XS * 8 + o8));
           if (s1) {
-            const int cq = cls0[s];
+            const int cq = (int)tabL[zb0 + rp[s]];
             if (cq != rcls) M3_LOADRECS(cq);
             double acc = 0.0;
             M3_WALK(acc, xm[s], xp, xw, qz * XS * 8 + o8);
             const double tv = xc[s] + dd[cq] * (b0[s] - acc);
             *reinterpret_cast<double*>(reinterpret_cast<char*>(tw) + ((z & 1) * TS * 8 + o8 + tdelta8)) = tv;
             tc[s] = tv;
-            st_t[s] = tv;
           }
           xm[s] = xc[s];
           xc[s] = xp;
         }
       }
       // ---- stage 2 on plane z-1: r = b - A t (in-plane neighbours from the t slab written before the last barrier) -----------
-      pend_r = 0u;
-      pend_rz = -1;
-      if (z - 1 >= z0 && z - 1 < z1) {                  // (uniform)
-        pend_rz = z - 1;
+      double st_r[K1], st_x[K1];
+      unsigned done2 = 0u;
+      const bool s2 = z - 1 >= z0 && z - 1 < z1;        // (uniform)
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        st_r[s] = st_x[s] = 0.0;
+        if (s2 && ((core >> s) & 1u)) {
+          const int cq = (int)tabL[zb1 + rp[s]];
+          if (cq != rcls) M3_LOADRECS(cq);
+          if (!(rflag & 1)) {
+            const int o8 = own8 + s * sstride8 + tdelta8;
+            double acc = 0.0;
+            M3_WALK(acc, t2[s], tc[s], tw, ((z - 1) & 1) * TS * 8 + o8);
+            const double rr = b1[s] - acc;
+            st_r[s] = rr;
+            st_x[s] = t1[s] + dd[cq] * rr;
+            sq += rr * rr;
+            done2 |= 1u << s;
+          }
+        }
+      }
+      // ---- the stores of this iteration: EVERY lane issues every store instruction (lanes / planes with nothing to store
+      // write to their slot of the sink), so their number is fixed and the wait at the top of the next iteration can be
+      // for the loads alone (s_waitcnt vmcnt(number of stores)): a store's acknowledgement is not on the critical path ------
+      if (MG_M3_EXP != 3) {
+        const bool wt = s1 && z >= z0 && z < z1;        // (uniform) plane z belongs to this run: its t is stored
 #pragma unroll
         for (int s = 0; s < K1; ++s) {
-          if ((core >> s) & 1u) {
-            const int cq = cls1[s];
-            if (cq != rcls) M3_LOADRECS(cq);
-            if (!(rflag & 1)) {
-              const int o8 = own8 + s * sstride8 + tdelta8;
-              double acc = 0.0;
-              M3_WALK(acc, t2[s], tc[s], tw, ((z - 1) & 1) * TS * 8 + o8);
-              const double rr = b1[s] - acc;
-              st_r[s] = rr;
-              st_x[s] = t1[s] + dd[cq] * rr;
-              sq += rr * rr;
-              pend_r |= 1u << s;
-            }
+          const int rowt = z * T.P + ip0 + s * ipstride, rowr = rowt - T.P;
+          if (OUT & 4) {
+            double* q_ = (wt && ((core >> s) & 1u)) ? a.t + rowt : sk;
+            *q_ = tc[s];
+          }
+          if (OUT & 1) {
+            double* q_ = ((done2 >> s) & 1u) ? a.r + rowr : sk;
+            *q_ = st_r[s];
+          }
+          if (OUT & 2) {
+            double* q_ = ((done2 >> s) & 1u) ? a.xn + rowr : sk;
+            *q_ = st_x[s];
           }
         }
       }
@@ -2243,24 +2294,9 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
         t2[s] = t1[s];
         t1[s] = tc[s];
         b1[s] = b0[s];
-        cls1[s] = cls0[s];
       }
       qz = q1;
       __syncthreads();
-    }
-    if (pend_tz >= 0) {
-#pragma unroll
-      for (int s = 0; s < K1; ++s)
-        if ((core >> s) & 1u) a.t[pend_tz * T.P + ip0 + s * ipstride] = st_t[s];
-    }
-    if (pend_rz >= 0) {
-#pragma unroll
-      for (int s = 0; s < K1; ++s)
-        if ((pend_r >> s) & 1u) {
-          const int r_ = pend_rz * T.P + ip0 + s * ipstride;
-          if (OUT & 1) a.r[r_] = st_r[s];
-          if (OUT & 2) a.xn[r_] = st_x[s];
-        }
     }
   }
   if (a.sumsq) {
@@ -2276,9 +2312,9 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
 #undef M3_LOADRECS
 #undef M3_WALK
 #undef M3_X1
-#undef M3_G
+#undef M3_PAR
+#undef M3_PAIRCLS
 #undef M3_LOADPAIR
-#undef M3_LOADCLSPAIR
 #undef M3_STAGE
 #undef M3_OPERANDS
 }
@@ -3228,12 +3264,14 @@ __global__ __launch_bounds__(BLK) void relax_jacobi(CsrDev A, double omega, doub
 // tptr / tperm: the transposed pattern (entries of column j are tperm[tptr[j] .. tptr[j+1]), ascending rows).
 __global__ __launch_bounds__(BLK) void colsumsq_kernel(const double* __restrict__ val, const int* __restrict__ tptr,
                                                        const int* __restrict__ tperm, int n_cols, double* __restrict__ s) {
+#pragma clang fp contract(off)   // squares rounded, then summed (no fused multiply-add): AT.^2 is an array in the reference
   const int j = blockIdx.x * BLK + threadIdx.x;
   if (j >= n_cols) return;
   double acc = 0.0;
   for (int k = tptr[j]; k < tptr[j + 1]; ++k) {
     const double a = val[tperm[k]];
-    acc = __dadd_rn(acc, __dmul_rn(a, a));   // squares rounded, then summed (no fused multiply-add): AT.^2 is an array in the reference
+    const double sq = a * a;
+    acc = acc + sq;
   }
   s[j] = acc;
 }

@@ -64,9 +64,12 @@ struct Options {
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
   bool no_tile_small = false;
   bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_dead_t = false;          // solve loop: store the iterate of every step (A/B, bit-identity tests)
   bool no_march3 = false;          // never use the 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv)
-  long long march3_k1 = 2;         // rows of the stage-1 region per lane (2 or 3): tile height = K1 * (1024 / (TX + 2)) - 2
+  long long march3_k1 = 0;         // rows of the stage-1 region per lane (0: by the fill estimate; 2..4): tile height = K1 * (NT / (TX + 2)) - 2
+  long long march3_nt = 0;         // threads per workgroup (0: by the fill estimate; 1024 or 768)
   long long march3_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
+  bool no_march3_lockstep = false, march3_lockstep_force = false;   // schedule of the 2-D tile form
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -95,7 +98,8 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
-      MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x),
+      MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
+      MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -209,9 +213,10 @@ struct Csr {
   int rm2_nblocks = 0;
   bool rc_march3 = false;   // ... and so can csr_rowclass_march3_spmv (2-D in-plane tiles, z-star classes): preferred
   DevBuf<mgk::M3Class> rm3_cls;
-  mgk::March3Dev rm3{};     // tile geometry (cls pointer filled in at launch)
+  DevBuf<unsigned short> rm3_cmap;   // cx | cy | cz | tab: class id = tab[cz[z]][cy[y]][cx[x]]
+  mgk::March3Dev rm3{};     // tile geometry
   size_t rm3_lds = 0;
-  int rm3_k1 = 3;
+  int rm3_k1 = 3, rm3_nt = 1024;
   double rm3_fill = 0.0;    // estimated L1 fills + stores per row (bytes) of the chosen geometry
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
@@ -366,6 +371,7 @@ struct Csr {
     rc_march2 = false;
     rc_march3 = false;
     rm3_cls.release();
+    rm3_cmap.release();
     rp_ok = false;
     rp_wf.release();
     h_rc_ptr.clear();
@@ -437,6 +443,7 @@ struct Level {
   // CYCLEmem (MGdef.jl:56-60) plus the Jacobi ping-pong partner of x
   DevBuf<double> b, r, x0, x1;
   DevBuf<double> x2;   // fine level, solve loop: third rotating buffer of the fused last sweep + residual (allocated on first use)
+  DevBuf<double> x3;   // scratch for outputs of the fused sweep + residual nobody asked for (test entry point only)
   // FGMRESmem (FGMRES.jl:3-8): Z and A*Z bases, `inner` contiguous vectors of n*nrhs each.
   // relaxZ/relaxAZ: memRelax[level] (Jac-GMRES smoother); kZ/kAZ: memKcycle (K-cycle recursion INTO this level)
   DevBuf<double> relaxZ, relaxAZ, kZ, kAZ;
@@ -492,6 +499,7 @@ struct mg_hierarchy {
   bool owns_stream = true;
   // reductions
   DevBuf<double> partial, partial2, scalar;
+  DevBuf<double> m3sink;       // csr_rowclass_march3_spmv: one slot per lane for the stores of lanes with nothing to store
   double* h_scalar = nullptr;  // pinned
   int nred_blocks = 1024;
   // staging for the host-pointer API
@@ -617,8 +625,8 @@ int pow2_ge(long long v) {
   return g;
 }
 
-// csr_rowclass_march3_spmv: threads per workgroup, 16-byte pairs of a slab per lane
-constexpr int RM3_NT = 1024, RM3_NPM = 2;
+// csr_rowclass_march3_spmv: 16-byte pairs of a slab per lane
+constexpr int RM3_NPM = 2;
 // dynamic LDS of csr_rowclass_march2_spmv: 4 x slabs + 4 t slabs + dictionary
 size_t march2_lds_bytes(int halo) {
   const size_t slx = (size_t)(mgk::RM_C + 4 * halo + 2), slt = (size_t)(mgk::RM_C + 2 * halo);
@@ -929,38 +937,57 @@ bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* 
   if (h->nrhs != 1 || h->relax_type != 0 || !L.A.has_rc || !L.A.rc_has_d || L.A.rc_nexc != 0) return false;
   if (!(L.A.rc_march && L.A.rc_march2) && !L.A.rc_march3) return false;
   if (L.A.d_bound != L.d.p) return false;   // the dictionary's relaxPrec is this level's
-  if (x == t || x == r || x == xn || t == r || t == xn || (r && r == xn)) return false;
+  if ((t && (x == t || t == r || t == xn)) || x == r || x == xn || (r && r == xn)) return false;   // (t, r, xn: each optional)
   return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
 // the 2-D tile form (csr_rowclass_march3_spmv): template arguments from what is wanted
-template <bool ZERO, int OUT, int K1>
+template <bool ZERO, int OUT, int NT, int K1>
 int launch_march3(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
-  auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, RM3_NT, K1, RM3_NPM>;
+  auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, NT, K1, RM3_NPM>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm3.nblocks), dim3(RM3_NT), A.rm3_lds, stream, A.rcdev(), a, A.rm3);
+  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm3.nblocks), dim3(NT), A.rm3_lds, stream, A.rcdev(), a, A.rm3);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
 template <bool ZERO, int OUT>
 int launch_march3_k(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
-  return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 2>(stream, A, a) : launch_march3<ZERO, OUT, 3>(stream, A, a);
+  if (A.rm3_nt == 768) return A.rm3_k1 == 3 ? launch_march3<ZERO, OUT, 768, 3>(stream, A, a) : launch_march3<ZERO, OUT, 768, 4>(stream, A, a);
+  return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 1024, 2>(stream, A, a) : launch_march3<ZERO, OUT, 1024, 3>(stream, A, a);
 }
-int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::March2Args& a, bool from_zero) {
+int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::March2Args& a_in, bool from_zero) {
+  mgk::March2Args a = a_in;
   const int nb1 = A.rm3.nblocks;
+  {
+    const size_t need = (size_t)12 * (size_t)nb1 * (size_t)A.rm3_nt;   // (12 >= stores per lane and iteration: K1 <= 4 rows x 3 outputs)
+    if (h->m3sink.n < need) MG_TRY(h->m3sink.alloc(need));
+  }
+  a.sink = h->m3sink.p;
   if (a.sumsq && (size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
   const double n8 = 8.0 * (double)A.n_rows;
   {
     ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (a.xn && a.r ? n8 : 0.0),
-                 format_bytes(A, 1) + n8 * (3.0 + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
-    const int out = (a.r ? 1 : 0) | (a.xn ? 2 : 0);
+                 format_bytes(A, 1) + n8 * (2.0 + (a.t ? 1.0 : 0.0) + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
+    const int out = (a.r ? 1 : 0) | (a.xn ? 2 : 0) | (a.t ? 4 : 0);
     int rc = MG_OK;
-    if (from_zero) rc = out == 1 ? launch_march3_k<true, 1>(h->stream, A, a) : out == 2 ? launch_march3_k<true, 2>(h->stream, A, a) : out == 3 ? launch_march3_k<true, 3>(h->stream, A, a) : launch_march3_k<true, 0>(h->stream, A, a);
-    else rc = out == 1 ? launch_march3_k<false, 1>(h->stream, A, a) : out == 2 ? launch_march3_k<false, 2>(h->stream, A, a) : out == 3 ? launch_march3_k<false, 3>(h->stream, A, a) : launch_march3_k<false, 0>(h->stream, A, a);
+    // the combinations the cycle and the solve loop use are instantiated exactly; anything else (the test entry point) runs
+    // the all-outputs kernel with the missing vectors pointed at the sink... no: at a scratch vector of the level
+    mgk::March2Args b2 = a;
+    int o = out;
+    if (!(o == 5 || o == 2 || o == 6 || o == 7)) {   // (t, r) cycle; (xn) solve loop, iterate dead; (t, xn) its last step; all
+      Level& L = h->lev[(size_t)level];
+      if (L.x3.n != (size_t)A.n_rows) MG_TRY(L.x3.alloc((size_t)A.n_rows));
+      if (!b2.t) b2.t = L.x3.p;      // (one scratch vector takes every output nobody asked for: written, never read)
+      if (!b2.r) b2.r = L.x3.p;
+      if (!b2.xn) b2.xn = L.x3.p;
+      o = 7;
+    }
+    if (from_zero) rc = o == 5 ? launch_march3_k<true, 5>(h->stream, A, b2) : o == 2 ? launch_march3_k<true, 2>(h->stream, A, b2) : o == 6 ? launch_march3_k<true, 6>(h->stream, A, b2) : launch_march3_k<true, 7>(h->stream, A, b2);
+    else rc = o == 5 ? launch_march3_k<false, 5>(h->stream, A, b2) : o == 2 ? launch_march3_k<false, 2>(h->stream, A, b2) : o == 6 ? launch_march3_k<false, 6>(h->stream, A, b2) : launch_march3_k<false, 7>(h->stream, A, b2);
     MG_TRY(rc);
   }
   if (a.sumsq) {
@@ -997,7 +1024,7 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
   {
     // algorithmic: the two products; moved: class ids + x + b in, t and r (and/or xn) out
     ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (xn && r ? n8 : 0.0),
-                 format_bytes(A, 1) + n8 * (3.0 + (r ? 1.0 : 0.0) + (xn ? 1.0 : 0.0)));
+                 format_bytes(A, 1) + n8 * (2.0 + (t ? 1.0 : 0.0) + (r ? 1.0 : 0.0) + (xn ? 1.0 : 0.0)));
     if (from_zero) hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<true>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
     else hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<false>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
     HIP_TRY(hipGetLastError());
@@ -1493,12 +1520,13 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
   const bool dbg = h->opt.debug_timing;
   auto tprev = std::chrono::steady_clock::now();
   bool x1_ready = false;
+  bool t_missing = false;
   // Where the marching kernel allows, the last post-smoothing sweep of the cycle is left out of cycle_level and runs
   // fused with the residual of the stopping test: x_in -> t = x (the iterate) and xn = x + d.*r (the next cycle's first
   // update) in one pass, rotating three buffers (cur, alt, spare).
   double* spare = nullptr;
   bool fuse_post = false;
-  if (h->nrhs == 1 && !h->opt.no_march2 && !h->opt.no_fused_next && L.A.rc_march2 && std::max<long long>(1, L.npost) >= 1) {
+  if (h->nrhs == 1 && !h->opt.no_march2 && !h->opt.no_fused_next && (L.A.rc_march2 || L.A.rc_march3) && std::max<long long>(1, L.npost) >= 1) {
     if (L.x2.n != (size_t)len) {
       MG_TRY(L.x2.alloc((size_t)len));
       HIP_TRY(hipMemsetAsync(L.x2.p, 0, L.x2.bytes(), h->stream));
@@ -1514,13 +1542,18 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
     if (deferred) {
-      // cur = x before the last sweep; alt <- the iterate; spare <- x + d.*r (unused if this was the last step)
-      MG_TRY(k_smooth_residual(h, 0, b, cur, alt, nullptr, count < maxIter ? spare : nullptr, true));
+      // cur = x before the last sweep; alt <- the iterate; spare <- x + d.*r (unused if this was the last step).
+      // The iterate itself is DEAD while the loop goes on (the next cycle starts from x + d.*r and recomputes its own
+      // residual): unless this is the last step by count it is not stored (8 of the pass's 34 bytes per row); should the
+      // stopping test end the loop here after all, one single-stage sweep of the same input reproduces it bit for bit.
+      const bool last = count == maxIter || h->opt.no_dead_t;
+      MG_TRY(k_smooth_residual(h, 0, b, cur, last ? alt : nullptr, nullptr, count < maxIter ? spare : nullptr, true));
       x1_ready = count < maxIter;
       double* freed = cur;
       cur = alt;
       alt = spare;
       spare = freed;
+      t_missing = !last;
     } else {
       // SolveFuncs.jl:26-30: r = b - A x and ||r|| in one pass; where the kernel allows, the same pass also writes
       // alt = x + d.*r, the first pre-smoothing update of the next cycle (unused if this was the last step)
@@ -1535,7 +1568,9 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
     }
     if (resvec) resvec[it] = res;
     if (res / res0 < tol) break;  // SolveFuncs.jl:34-36
+    t_missing = false;            // (the loop goes on: the iterate of this step is never read)
   }
+  if (t_missing) MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, spare, cur));   // spare: the input of the last pass; cur: the iterate
   if (cur != x) {
     HIP_TRY(hipMemcpyAsync(x, cur, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(spin_sync(h->stream));
@@ -2495,16 +2530,21 @@ int build_staged(Csr& A, const long long grid[3]) {
 
 // 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv): the operator must be a grid operator of z-star classes -
 // per class at most one entry in plane z-1 (the first) and one in plane z+1 (the last), both at the row's own in-plane
-// position, and at most RM3_NIP in-plane entries (dy, dx), |dy|, |dx| <= 1.  Tile geometry: the stage-1 region is
-// WX = TX + 2 columns wide, a 1024-thread workgroup holds SY = 1024 / WX lines of it per slot pass and K1 passes, so
-// TY = K1*SY - 2; tiles per line and K1 are chosen by an estimate of the L1 fills per row (halo + run ends), within the
-// LDS (3 x slabs + 2 t slabs + class records <= 160 KB) and the two 16-byte pairs a lane loads per slab.
+// position, and at most RM3_NIP in-plane entries (dy, dx), |dy|, |dx| <= 1 - whose class ids factor as
+// cls(x, y, z) = tab[cz[z]][cy[y]][cx[x]] (found by hashing the three families of grid slices, then VERIFIED row by row).
+// Tile geometry: the stage-1 region is WX = TX + 2 columns wide, an NT-thread workgroup holds SY = NT / WX lines of it per
+// slot pass and K1 passes, so TY = K1*SY - 2; threads per workgroup (1024 with K1 <= 3: 128 registers per lane; 768 with
+// K1 <= 4: 168), tiles per line and K1 are chosen by an estimate of the bytes filled per row (halo, run ends, the partial
+// cache lines at both ends of a tile's line segments), within the LDS (3 x slabs + 2 t slabs + tables <= 160 KB) and the
+// 16-byte pairs a lane can load per slab.  Schedule: lockstep (tiles x segments of planes = about one workgroup per CU, all
+// tiles of a segment on one XCD) when that keeps >= 85 % of the balanced schedule's parallel efficiency.
 int build_march3(Csr& A, const long long grid[3]) {
   A.rc_march3 = false;
   if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march3 || A.opt.no_march2 || A.opt.no_march) return MG_OK;
   if (A.rc_nexc != 0 || A.regular_cols >= 0) return MG_OK;
   const long long n1 = grid[0], n2 = grid[1], n3 = grid[2];
   if (n1 < 4 || n2 < 4 || n3 < 3 || n1 * n2 * n3 != A.n_rows) return MG_OK;
+  if (n1 > 65535 || n2 > 65535 || n3 > 65535 || A.h_cls.size() != (size_t)A.n_rows) return MG_OK;
   const long long P = n1 * n2;
   if (A.n_rows + 4 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
   const size_t ncls = A.h_rc_ptr.size() - 1;
@@ -2529,53 +2569,144 @@ int build_march3(Csr& A, const long long grid[3]) {
       ents[c].push_back({(int)dz, (int)dy, (int)dx});
     }
   }
+  // ---- class ids as a product of three index maps --------------------------------------------------------------------------
+  // hash of every x-slice / y-slice / z-slice of the class array; equal hashes = same index; then the exact check
+  std::vector<unsigned short> cmap;
+  int ncx = 0, ncy = 0, ncz = 0;
+  {
+    const unsigned short* cl = A.h_cls.data();
+    std::vector<unsigned long long> hx((size_t)n1, 0), hy((size_t)n2, 0), hz((size_t)n3, 0);
+    auto mix = [](unsigned long long v) {
+      v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
+      return v;
+    };
+    for (long long z = 0; z < n3; ++z)
+      for (long long y = 0; y < n2; ++y) {
+        const unsigned short* line = cl + (z * n2 + y) * n1;
+        unsigned long long hl = 0;
+        for (long long x = 0; x < n1; ++x) {
+          const unsigned long long v = (unsigned long long)line[x] + 1;
+          hx[(size_t)x] += mix(v * 0x9E3779B97F4A7C15ULL + (unsigned long long)(z * n2 + y));
+          hl += mix(v * 0xD6E8FEB86659FD93ULL + (unsigned long long)x);
+        }
+        hy[(size_t)y] += mix(hl + (unsigned long long)z * 0x9E3779B97F4A7C15ULL);
+        hz[(size_t)z] += mix(hl + (unsigned long long)y * 0xC2B2AE3D27D4EB4FULL);
+      }
+    auto index_of = [](const std::vector<unsigned long long>& hv, std::vector<unsigned short>& idx, std::vector<long long>& rep) {
+      std::unordered_map<unsigned long long, int> seen;
+      idx.resize(hv.size());
+      for (size_t i = 0; i < hv.size(); ++i) {
+        auto itf = seen.find(hv[i]);
+        if (itf == seen.end()) {
+          itf = seen.emplace(hv[i], (int)rep.size()).first;
+          rep.push_back((long long)i);
+        }
+        idx[i] = (unsigned short)itf->second;
+      }
+    };
+    std::vector<unsigned short> cx, cy, cz;
+    std::vector<long long> rx, ry, rz;
+    index_of(hx, cx, rx);
+    index_of(hy, cy, ry);
+    index_of(hz, cz, rz);
+    ncx = (int)rx.size(); ncy = (int)ry.size(); ncz = (int)rz.size();
+    if ((long long)ncx * ncy * ncz > mgk::RM3_TAB) return MG_OK;
+    std::vector<unsigned short> tab((size_t)ncx * ncy * ncz);
+    for (int iz = 0; iz < ncz; ++iz)
+      for (int iy = 0; iy < ncy; ++iy)
+        for (int ix = 0; ix < ncx; ++ix) tab[((size_t)iz * ncy + iy) * ncx + ix] = cl[(rz[(size_t)iz] * n2 + ry[(size_t)iy]) * n1 + rx[(size_t)ix]];
+    bool okmap = true;
+#pragma omp parallel for schedule(static) reduction(&& : okmap)
+    for (long long z = 0; z < n3; ++z) {
+      for (long long y = 0; y < n2 && okmap; ++y) {
+        const unsigned short* line = cl + (z * n2 + y) * n1;
+        const unsigned short* trow = tab.data() + ((size_t)cz[(size_t)z] * ncy + cy[(size_t)y]) * ncx;
+        for (long long x = 0; x < n1; ++x)
+          if (line[x] != trow[cx[(size_t)x]]) { okmap = false; break; }
+      }
+    }
+    if (!okmap) return MG_OK;     // the classes are not a product of coordinate classes: the 1-D chunk form serves the level
+    for (unsigned short v : tab) if (v >= ncls) return MG_OK;
+    cmap.insert(cmap.end(), cx.begin(), cx.end());
+    cmap.insert(cmap.end(), cy.begin(), cy.end());
+    cmap.insert(cmap.end(), cz.begin(), cz.end());
+    cmap.insert(cmap.end(), tab.begin(), tab.end());
+  }
   // ---- tile geometry ------------------------------------------------------------------------------------------------------
   int dev = 0, ncu = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   const long long lds_cap = 160 * 1024 - 1024;
-  const size_t dict_bytes = ncls * (sizeof(mgk::M3Class) + 8);
-  struct Geo { long long tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, K1, nb; size_t lds; double fill; };
+  const size_t dict_bytes = ncls * (sizeof(mgk::M3Class) + 8) + ((cmap.size() * 2 + 15) & ~(size_t)15);
+  struct Geo { long long NT, tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, K1, nb, segs, seglen; size_t lds; double fill; };
   Geo best{};
   bool have = false;
-  for (long long K1 = 2; K1 <= 3; ++K1) {
-    if (A.opt.march3_k1 >= 2 && A.opt.march3_k1 <= 3 && K1 != A.opt.march3_k1) continue;
-    for (long long tilesx = 1; tilesx <= std::max<long long>(1, n1 / 16); ++tilesx) {
-      if (A.opt.march3_tiles_x > 0 && tilesx != A.opt.march3_tiles_x) continue;
-      Geo g{};
-      g.K1 = K1;
-      g.tilesx = tilesx;
-      g.TX = (n1 + tilesx - 1) / tilesx;
-      g.WX = g.TX + 2;
-      if (g.WX > RM3_NT / 2) continue;
-      g.SY = RM3_NT / g.WX;
-      g.TY = std::min<long long>(K1 * g.SY - 2, n2);
-      if (g.TY < 2) continue;
-      g.tilesy = (n2 + g.TY - 1) / g.TY;
-      g.TY = (n2 + g.tilesy - 1) / g.tilesy;                        // equal tiles
-      g.NPL = (g.TX + 6) / 2;
-      g.pitch = 2 * g.NPL;
-      g.LY = g.TY + 4;
-      if (g.LY * g.NPL > (long long)RM3_NPM * RM3_NT) continue;
-      g.lds = (size_t)(3 * g.LY + 2 * (g.TY + 2)) * (size_t)g.pitch * 8 + dict_bytes;
-      if ((long long)g.lds > lds_cap) continue;
-      const long long wg_per_cu = (long long)g.lds * 2 <= lds_cap ? 2 : 1;
-      const long long items = g.tilesx * g.tilesy * n3;
-      g.nb = std::max<long long>(1, std::min<long long>(wg_per_cu * ncu, items / 4));
-      const double R = (double)items / (double)g.nb;                // planes per run
-      const double core = (double)g.TX * (double)g.TY;
-      // fills per row of the grid: tiles are equal, so partial tiles at the far edges are charged through tiles*core / P
-      const double waste = (double)(g.tilesx * g.TX) * (double)(g.tilesy * g.TY) / (double)P;
-      g.fill = waste * (8.0 * (double)((g.TX + 4) * (g.TY + 4)) / core * (1.0 + 3.0 / R) +
-                        10.0 * (double)((g.TX + 2) * (g.TY + 2)) / core * (1.0 + 2.0 / R)) + 16.0;
-      if (!have || g.fill < best.fill) {
-        best = g;
-        have = true;
+  for (long long NT : {1024LL, 768LL}) {
+    if (A.opt.march3_nt != 0 && A.opt.march3_nt != NT) continue;
+    for (long long K1 = 2; K1 <= (NT == 768 ? 4 : 3); ++K1) {
+      if (A.opt.march3_k1 != 0 && K1 != A.opt.march3_k1) continue;
+      if (NT == 768 && K1 < 3) continue;
+      for (long long tilesx = 1; tilesx <= std::max<long long>({1, n1 / 16, A.opt.march3_tiles_x}); ++tilesx) {
+        if (A.opt.march3_tiles_x > 0 && tilesx != A.opt.march3_tiles_x) continue;
+        Geo g{};
+        g.NT = NT;
+        g.K1 = K1;
+        g.tilesx = tilesx;
+        g.TX = (n1 + tilesx - 1) / tilesx;
+        g.WX = g.TX + 2;
+        if (g.WX > NT / 2) continue;
+        g.SY = NT / g.WX;
+        g.TY = std::min<long long>(K1 * g.SY - 2, n2);
+        if (g.TY < 2) continue;
+        g.tilesy = (n2 + g.TY - 1) / g.TY;
+        g.TY = (n2 + g.tilesy - 1) / g.tilesy;                        // equal tiles
+        g.NPL = (g.TX + 6) / 2;
+        g.pitch = 2 * g.NPL;
+        g.LY = g.TY + 4;
+        if (g.LY * g.NPL > (long long)RM3_NPM * NT) continue;
+        g.lds = (size_t)(3 * g.LY + 2 * (g.TY + 2)) * (size_t)g.pitch * 8 + dict_bytes;
+        if ((long long)g.lds > lds_cap) continue;
+        const long long wg_per_cu = 1;   // (> 100 registers per lane: one workgroup of 12-16 waves per CU whatever the LDS)
+        const long long tiles = g.tilesx * g.tilesy, items = tiles * n3, slots = wg_per_cu * ncu;
+        // balanced: equal contiguous ranges of the (tile, plane) list; lockstep: tiles x segments
+        g.nb = std::max<long long>(1, std::min<long long>(slots, items / 4));
+        double R = (double)items / (double)g.nb, eff = 1.0;
+        g.segs = 0;
+        g.seglen = 0;
+        if (!A.opt.no_march3_lockstep && tiles <= slots) {
+          const long long S = std::min<long long>(slots / tiles, n3 / 4);
+          if (S >= 1) {
+            const long long Lz = (n3 + S - 1) / S;
+            const double e = ((double)n3 / (double)(S * Lz)) * ((double)(tiles * S) / (double)slots);
+            if (e >= 0.85 || A.opt.march3_lockstep_force) {
+              g.segs = S;
+              g.seglen = Lz;
+              g.nb = tiles * S;
+              R = (double)Lz;
+              eff = e;
+            }
+          }
+        }
+        const double core = (double)g.TX * (double)g.TY;
+        // fills per row of the grid: tiles are equal, so partial tiles at the far edges are charged through tiles*core / P;
+        // a line segment of W doubles at an arbitrary alignment touches W/16 + 15/16 cache lines of 128 bytes
+        const double waste = (double)(g.tilesx * g.TX) * (double)(g.tilesy * g.TY) / (double)P;
+        auto lines = [](double W) { return 1.0 + 15.0 / W; };
+        // (lockstep: neighbouring tiles stage their common halo lines at the same time on one XCD - measured on 257^3: the
+        // fabric traffic falls to 1.02 x compulsory, the pass gains 5 %: the halo excess is charged at half)
+        const double share = g.segs > 0 ? 0.5 : 1.0;
+        const double fx = 8.0 * (double)((g.TX + 4) * (g.TY + 4)) / core * (1.0 + 3.0 / R) * lines((double)(g.TX + 4));
+        const double fb = 8.0 * (double)((g.TX + 2) * (g.TY + 2)) / core * (1.0 + 2.0 / R) * lines((double)(g.TX + 2));
+        g.fill = (waste * (8.0 + share * (fx - 8.0) + 8.0 + share * (fb - 8.0)) + 16.0) / eff;
+        if (!have || g.fill < best.fill) {
+          best = g;
+          have = true;
+        }
       }
     }
   }
   if (!have) return MG_OK;
-  if (best.nb < std::min<long long>(A.opt.march_min_wg, ncu)) return MG_OK;   // small levels: latency-bound, other kernels
+  if (best.nb < std::min<long long>(A.opt.march_min_wg, (long long)ncu * 3 / 4)) return MG_OK;   // small levels: latency-bound, other kernels
   // ---- class records with byte offsets in the chosen pitch ------------------------------------------------------------------
   std::vector<mgk::M3Class> recs(ncls);
   for (size_t c = 0; c < ncls; ++c) {
@@ -2583,7 +2714,7 @@ int build_march3(Csr& A, const long long grid[3]) {
     int nip = 0, first_off = 0;
     const int k0 = A.h_rc_ptr[c];
     std::vector<double> vals((size_t)(A.h_rc_ptr[c + 1] - k0));
-    HIP_TRY(hipMemcpy(vals.data(), A.rc_val.p + k0, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (!vals.empty()) HIP_TRY(hipMemcpy(vals.data(), A.rc_val.p + k0, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t e = 0; e < ents[c].size(); ++e) {
       const Ent& t = ents[c][e];
       if (t.dz == -1) q.v_lo = vals[e];
@@ -2605,21 +2736,28 @@ int build_march3(Csr& A, const long long grid[3]) {
   }
   MG_TRY(A.rm3_cls.alloc(ncls));
   HIP_TRY(hipMemcpy(A.rm3_cls.p, recs.data(), ncls * sizeof(mgk::M3Class), hipMemcpyHostToDevice));
+  MG_TRY(A.rm3_cmap.alloc(cmap.size()));
+  HIP_TRY(hipMemcpy(A.rm3_cmap.p, cmap.data(), cmap.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   mgk::March3Dev T{};
   T.cls = A.rm3_cls.p;
+  T.cmap = A.rm3_cmap.p;
+  T.ncx = ncx; T.ncy = ncy; T.ntab = ncx * ncy * ncz;
   T.n1 = (int)n1; T.n2 = (int)n2; T.nplanes = (int)n3; T.P = (int)P;
   T.TX = (int)best.TX; T.TY = (int)best.TY; T.tiles_x = (int)best.tilesx; T.tiles_y = (int)best.tilesy;
   T.WX = (int)best.WX; T.SY = (int)best.SY; T.pitch = (int)best.pitch; T.LY = (int)best.LY; T.NPL = (int)best.NPL;
   T.nblocks = (int)best.nb;
+  T.segs = (int)best.segs; T.seglen = (int)best.seglen;
   T.n_cols = (int)A.n_cols; T.ncls = (int)ncls;
   A.rm3 = T;
   A.rm3_lds = best.lds;
   A.rm3_k1 = (int)best.K1;
+  A.rm3_nt = (int)best.NT;
   A.rm3_fill = best.fill;
   A.rc_march3 = true;
   if (A.opt.debug_format)
-    std::fprintf(stderr, "[mg] march3: grid %lldx%lldx%lld tiles %lldx%lld of %lldx%lld (K1 %lld, SY %lld), %lld workgroups, LDS %zu B, est. %.1f B/row\n",
-                 n1, n2, n3, best.tilesx, best.tilesy, best.TX, best.TY, best.K1, best.SY, best.nb, best.lds, best.fill);
+    std::fprintf(stderr, "[mg] march3: grid %lldx%lldx%lld tiles %lldx%lld of %lldx%lld (%lld threads, K1 %lld, SY %lld), %lld workgroups%s, class maps %dx%dx%d, LDS %zu B, est. %.1f B/row\n",
+                 n1, n2, n3, best.tilesx, best.tilesy, best.TX, best.TY, best.NT, best.K1, best.SY, best.nb,
+                 best.segs ? " (lockstep)" : "", ncx, ncy, ncz, best.lds, best.fill);
   return MG_OK;
 }
 
@@ -3461,7 +3599,10 @@ int mg_destroy(mg_hierarchy* h) {
     L.r.release();
     L.x0.release();
     L.x1.release();
+    L.x2.release();
+    L.x3.release();
   }
+  h->m3sink.release();
   h->Ainv.release();
   for (DevBuf<int>* d : {&h->luLptr, &h->luLcol, &h->luUptr, &h->luUcol, &h->luP, &h->luQ, &h->luLorder, &h->luLlvl,
                          &h->luUorder, &h->luUlvl})
@@ -4505,8 +4646,9 @@ int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which
 
 // Which kernel fuses a sweep with the residual that follows it on this level's A (one right-hand side): *form = 0 none
 // (two launches), 2 csr_rowclass_march2_spmv (1-D chunks), 3 csr_rowclass_march3_spmv (2-D in-plane tiles).  geometry
-// (optional, 8 entries, form 3): tiles per line, tiles per column, TX, TY, rows of the stage-1 region per lane (K1),
-// workgroups, dynamic LDS bytes, estimated L1 fills + stores per row in hundredths of a byte.
+// (optional, 12 entries, form 3): tiles per line, tiles per column, TX, TY, rows of the stage-1 region per lane (K1),
+// workgroups, dynamic LDS bytes, estimated bytes filled + stored per row x 100, threads per workgroup, segments of the
+// lockstep schedule (0: balanced ranges), planes per segment, entries of the class table.
 int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, long long* geometry) {
   if (!h || !form) return fail(MG_ERR_INVALID, "null argument");
   if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
@@ -4516,9 +4658,9 @@ int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, lo
   if (A.rc_march3) {
     *form = 3;
     if (geometry) {
-      const long long g[8] = {A.rm3.tiles_x, A.rm3.tiles_y, A.rm3.TX, A.rm3.TY, A.rm3_k1, A.rm3.nblocks, (long long)A.rm3_lds,
-                              (long long)(A.rm3_fill * 100.0)};
-      std::copy(g, g + 8, geometry);
+      const long long g[12] = {A.rm3.tiles_x, A.rm3.tiles_y, A.rm3.TX, A.rm3.TY, A.rm3_k1, A.rm3.nblocks, (long long)A.rm3_lds,
+                               (long long)(A.rm3_fill * 100.0), A.rm3_nt, A.rm3.segs, A.rm3.seglen, A.rm3.ntab};
+      std::copy(g, g + 12, geometry);
     }
   } else if (A.rc_march && A.rc_march2) {
     *form = 2;

@@ -775,15 +775,17 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,k1,tiles_x", [([33, 25, 7], 2, 0), ([33, 25, 7], 3, 2), ([40, 30, 9], 2, 3), ([23, 23, 23], 3, 1),
-                                              ([70, 10, 12], 2, 0), ([64, 64, 20], 3, 0), ([64, 64, 20], 2, 4), ([36, 36, 40], 2, 2),
-                                              ([20, 20, 3], 2, 1), ([130, 18, 5], 2, 0), ([257, 9, 4], 3, 0)])
-def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k1, tiles_x):
+@pytest.mark.parametrize("cells,k1,nt,tiles_x,lockstep", [([33, 25, 7], 2, 1024, 0, 0), ([33, 25, 7], 3, 768, 2, 1), ([40, 30, 9], 4, 768, 3, 0),
+                                                          ([23, 23, 23], 3, 1024, 1, 1), ([70, 10, 12], 2, 1024, 0, 0), ([64, 64, 20], 4, 768, 0, 1),
+                                                          ([64, 64, 20], 2, 1024, 4, 1), ([36, 36, 40], 3, 768, 2, 0), ([20, 20, 3], 2, 1024, 1, 1),
+                                                          ([130, 18, 5], 4, 768, 0, 0), ([257, 9, 4], 3, 1024, 0, 1)])
+def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k1, nt, tiles_x, lockstep):
     """csr_rowclass_march3_spmv (sweep + residual in one pass on 2-D in-plane tiles; the z-1 / z+1 entries from registers):
     t, r, t + d.*r and ||r|| against numpy, BIT-identical to the 1-D chunk form (MG_NO_MARCH3=1) and to the two
     single-stage launches, from a given x and from x = 0 (x1 = d.*b formed inside the pass); the solve against the oracle
     with bit-identical iterates.  Tile geometries forced through the options: partial tiles at both far edges, one tile
-    per line, tiles narrower than a wavefront's worth of lanes, two and three rows per lane."""
+    per line, tiles narrower than a wavefront's worth of lanes, two to four rows per lane, 768 and 1024 threads, the
+    lockstep and the balanced schedule.  The class ids come from the verified product map, never from a stream."""
     import torch
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
@@ -792,7 +794,10 @@ def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
     monkeypatch.setenv("MG_MARCH_MAX_LEN", "64")
     monkeypatch.setenv("MG_MARCH3_K1", str(k1))
+    monkeypatch.setenv("MG_MARCH3_NT", str(nt))
     monkeypatch.setenv("MG_MARCH3_TILES_X", str(tiles_x))
+    monkeypatch.setenv("MG_NO_MARCH3_LOCKSTEP", "0" if lockstep else "1")
+    monkeypatch.setenv("MG_MARCH3_LOCKSTEP_FORCE", "1" if lockstep else "0")
     rng = np.random.default_rng(sum(cells) + 11)
     xn_ = bn = None
     runs, outs = {}, {}
@@ -803,7 +808,7 @@ def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k
         form, geo = h.sweep_residual_form(1)
         assert form == (3 if no3 == "0" else 2), (form, geo)
         if no3 == "0":
-            assert geo[4] == k1 and (tiles_x == 0 or geo[0] == tiles_x), geo
+            assert geo[4] == k1 and geo[8] == nt and (tiles_x == 0 or geo[0] == tiles_x) and (geo[9] > 0) == bool(lockstep), geo
         Al, dl = p.As[0], p.relaxPrecs[0]
         if xn_ is None:
             xn_, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
