@@ -343,6 +343,21 @@ int mg_op_residual_fused_dev_FP64(mg_operator* op, const double* x_dev, const do
                                   double* r_dev, double* xnext_dev, double* partials_dev, long long phase,
                                   long long* nparts, void* stream);
 int mg_op_can_fuse_next(mg_operator* op, const double* x_dev, long long* yes);
+/* The two-stage pass on a stand-alone operator (csr_rowclass_march3_spmv; what the sharded sequencer calls on the box-form
+ * levels): t = x + d.*(b - M x) on every row that has a row class and r = b - M t [xn = t + d.*r, ||r||^2 partials] on every
+ * such row that is not next to a row without one - the last sweep of relax and the residual that follows it
+ * (MGcycle.jl:129-131 + 58-60; SolveFuncs.jl:26-30) in one pass.  The rows it leaves out are computed from the CSR arrays
+ * by mg_op_apply_list_dev_FP64: list 1 = rows without a class (a box operator's rows that read the halo: t and r), list 2 =
+ * rows next to them (r).  d: the vector bound with mg_op_bind_relax_dev_FP64; t, r, xn: each optional, all distinct. */
+int mg_op_can_sweep_residual(mg_operator* op, const double* x_dev, const double* d_dev, long long* yes, long long* list1_rows,
+                             long long* list2_rows);
+int mg_op_sweep_residual_dev_FP64(mg_operator* op, const double* x_dev, const double* b_dev, const double* d_dev, double* t_dev,
+                                  double* r_dev, double* xn_dev, double* partials_dev, long long* nparts, void* stream);
+/* kernel: MG_K_SMOOTH (y = x + d.*(b - M x)) or MG_K_RESIDUAL (y = b - M x; y2, if given, = x + d.*y; partials_dev, if
+ * given, receives *nparts partial sums of y.^2).  y or y2 may be NULL for MG_K_RESIDUAL. */
+int mg_op_apply_list_dev_FP64(mg_operator* op, long long list, long long kernel, const double* x_dev, double* y_dev,
+                              const double* b_dev, const double* d_dev, double* y2_dev, double* partials_dev, long long* nparts,
+                              void* stream);
 int mg_op_info(mg_operator* op, long long* n_rows, long long* n_cols, long long* nnz,
                double* device_bytes);
 /* x = d.*b ; xout = x + d.*r ; out[0] = sum x^2 (workspace >= 1024 doubles) - asynchronous. */

@@ -64,6 +64,7 @@ struct Options {
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
   bool no_tile_small = false;
   bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_rmarch = false;          // restriction: lane kernel (gathers from L2) instead of the fine slabs staged in LDS
   bool no_dead_t = false;          // solve loop: store the iterate of every step (A/B, bit-identity tests)
   bool no_march3 = false;          // never use the 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv)
   long long march3_k1 = 0;         // rows of the stage-1 region per lane (0: by the fill estimate; 2..4): tile height = K1 * (NT / (TX + 2)) - 2
@@ -98,7 +99,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
-      MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
+      MG_OPT("MG_NO_RMARCH", "no_rmarch", 0, no_rmarch), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
@@ -212,6 +213,8 @@ struct Csr {
   bool rc_march2 = false;   // csr_rowclass_march2_spmv can serve a sweep + residual pair on this operator
   int rm2_nblocks = 0;
   bool rc_march3 = false;   // ... and so can csr_rowclass_march3_spmv (2-D in-plane tiles, z-star classes): preferred
+  DevBuf<int> rc_exc2;      // box operators on the 2-D tile form: rows whose stage 2 is left to csr_rows_spmv (the layer behind the faces)
+  int rc_nexc2 = 0;
   DevBuf<mgk::M3Class> rm3_cls;
   DevBuf<unsigned short> rm3_cmap;   // cx | cy | cz | tab: class id = tab[cz[z]][cy[y]][cx[x]]
   mgk::March3Dev rm3{};     // tile geometry
@@ -221,6 +224,11 @@ struct Csr {
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
   int rt_cr = mgk::RT_CR;   // rows of a plane per workgroup: 1024, or 256 on levels too small to fill the chip with 1024-row tiles
+  // csr_rowclass_rmarch_spmv (restriction-shaped operators: rows a coarse grid, columns a fine grid; fine slabs staged in LDS)
+  bool rr_ok = false;
+  DevBuf<int> rr_code;
+  mgk::RMarchDev rr{};
+  size_t rr_lds = 0;
   // csr_rowclass_winp_spmv (prolongation-shaped operators: the source windows of a workgroup's rows staged in LDS)
   bool rp_ok = false;
   DevBuf<unsigned short> rp_wf;
@@ -372,7 +380,11 @@ struct Csr {
     rc_march3 = false;
     rm3_cls.release();
     rm3_cmap.release();
+    rc_exc2.release();
+    rc_nexc2 = 0;
     rp_ok = false;
+    rr_ok = false;
+    rr_code.release();
     rp_wf.release();
     h_rc_ptr.clear();
     h_rc_off.clear();
@@ -733,6 +745,21 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
       const size_t lds = (size_t)M.rw_doubles * sizeof(double);
       if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, true>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
       else hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, false>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
+    } else if (MODE == mgk::AXPBY && M.rr_ok && phase == 0 && v.beta == 0.0 && v.y != v.x && !v.dotx && (reinterpret_cast<uintptr_t>(v.x) & 15) == 0) {
+      // a restriction-shaped operator: fine slabs staged in LDS, marched along the coarse z (no exception rows)
+      nb_main = M.rr.nblocks;
+      static bool rr_attr = false;
+      if (!rr_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_rmarch_spmv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipGetLastError();
+        rr_attr = true;
+      }
+      mgk::RMarchDev T = M.rr;
+      T.code = M.rr_code.p;
+      hipLaunchKernelGGL(mgk::csr_rowclass_rmarch_spmv, dim3(nb_main), dim3(mgk::RR_NT), M.rr_lds, stream, C, v, T);
+      if (nparts) *nparts = 0;
+      HIP_TRY(hipGetLastError());
+      return MG_OK;
     } else if (MODE == mgk::AXPBY && M.rp_ok && phase == 0 && v.y != v.x) {
       // a prolongation-shaped operator: the coarse windows of a workgroup's rows staged in LDS (no exception rows)
       const mgk::WinPDev T = M.winpdev();
@@ -823,7 +850,7 @@ int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, con
 }
 // Is the product with M served by csr_rowclass_lane_spmv for one right-hand side (the kernel that can write d.*out too)?
 bool restrict_can_scale(const mg_hierarchy* h, const Csr& M) {
-  return h->nrhs == 1 && !h->opt.no_restrict_scale && M.has_rc && M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && M.rc_lane();
+  return h->nrhs == 1 && !h->opt.no_restrict_scale && M.has_rc && M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && (M.rc_lane() || M.rr_ok);
 }
 // out = b - A*x
 int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x,
@@ -959,6 +986,20 @@ int launch_march3_k(hipStream_t stream, const Csr& A, const mgk::March2Args& a) 
   if (A.rm3_nt == 768) return A.rm3_k1 == 3 ? launch_march3<ZERO, OUT, 768, 3>(stream, A, a) : launch_march3<ZERO, OUT, 768, 4>(stream, A, a);
   return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 1024, 2>(stream, A, a) : launch_march3<ZERO, OUT, 1024, 3>(stream, A, a);
 }
+// dispatch on (from_zero, outputs); `scratch` (n_rows doubles, may be null when t and one of r / xn are given in one of the
+// instantiated combinations) takes the outputs nobody asked for
+int launch_march3_any(hipStream_t stream, const Csr& A, mgk::March2Args a, bool from_zero, double* scratch) {
+  int o = (a.r ? 1 : 0) | (a.xn ? 2 : 0) | (a.t ? 4 : 0);
+  if (!(o == 5 || o == 2 || o == 6 || o == 7)) {   // (t, r) cycle; (xn) solve loop, iterate dead; (t, xn) its last step; all
+    if (!scratch) return fail(MG_ERR_STATE, "this combination of outputs needs a scratch vector");
+    if (!a.t) a.t = scratch;      // (one scratch vector takes every output nobody asked for: written, never read)
+    if (!a.r) a.r = scratch;
+    if (!a.xn) a.xn = scratch;
+    o = 7;
+  }
+  if (from_zero) return o == 5 ? launch_march3_k<true, 5>(stream, A, a) : o == 2 ? launch_march3_k<true, 2>(stream, A, a) : o == 6 ? launch_march3_k<true, 6>(stream, A, a) : launch_march3_k<true, 7>(stream, A, a);
+  return o == 5 ? launch_march3_k<false, 5>(stream, A, a) : o == 2 ? launch_march3_k<false, 2>(stream, A, a) : o == 6 ? launch_march3_k<false, 6>(stream, A, a) : launch_march3_k<false, 7>(stream, A, a);
+}
 int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::March2Args& a_in, bool from_zero) {
   mgk::March2Args a = a_in;
   const int nb1 = A.rm3.nblocks;
@@ -967,28 +1008,22 @@ int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::Marc
     if (h->m3sink.n < need) MG_TRY(h->m3sink.alloc(need));
   }
   a.sink = h->m3sink.p;
+  a.d = h->lev[(size_t)level].d.p;
   if (a.sumsq && (size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
   const double n8 = 8.0 * (double)A.n_rows;
   {
     ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (a.xn && a.r ? n8 : 0.0),
                  format_bytes(A, 1) + n8 * (2.0 + (a.t ? 1.0 : 0.0) + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
-    const int out = (a.r ? 1 : 0) | (a.xn ? 2 : 0) | (a.t ? 4 : 0);
-    int rc = MG_OK;
     // the combinations the cycle and the solve loop use are instantiated exactly; anything else (the test entry point) runs
-    // the all-outputs kernel with the missing vectors pointed at the sink... no: at a scratch vector of the level
-    mgk::March2Args b2 = a;
-    int o = out;
-    if (!(o == 5 || o == 2 || o == 6 || o == 7)) {   // (t, r) cycle; (xn) solve loop, iterate dead; (t, xn) its last step; all
+    // the all-outputs kernel with the missing vectors pointed at a scratch vector of the level
+    const int o = (a.r ? 1 : 0) | (a.xn ? 2 : 0) | (a.t ? 4 : 0);
+    double* scratch = nullptr;
+    if (!(o == 5 || o == 2 || o == 6 || o == 7)) {
       Level& L = h->lev[(size_t)level];
       if (L.x3.n != (size_t)A.n_rows) MG_TRY(L.x3.alloc((size_t)A.n_rows));
-      if (!b2.t) b2.t = L.x3.p;      // (one scratch vector takes every output nobody asked for: written, never read)
-      if (!b2.r) b2.r = L.x3.p;
-      if (!b2.xn) b2.xn = L.x3.p;
-      o = 7;
+      scratch = L.x3.p;
     }
-    if (from_zero) rc = o == 5 ? launch_march3_k<true, 5>(h->stream, A, b2) : o == 2 ? launch_march3_k<true, 2>(h->stream, A, b2) : o == 6 ? launch_march3_k<true, 6>(h->stream, A, b2) : launch_march3_k<true, 7>(h->stream, A, b2);
-    else rc = o == 5 ? launch_march3_k<false, 5>(h->stream, A, b2) : o == 2 ? launch_march3_k<false, 2>(h->stream, A, b2) : o == 6 ? launch_march3_k<false, 6>(h->stream, A, b2) : launch_march3_k<false, 7>(h->stream, A, b2);
-    MG_TRY(rc);
+    MG_TRY(launch_march3_any(h->stream, A, a, from_zero, scratch));
   }
   if (a.sumsq) {
     ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
@@ -2541,9 +2576,15 @@ int build_staged(Csr& A, const long long grid[3]) {
 int build_march3(Csr& A, const long long grid[3]) {
   A.rc_march3 = false;
   if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march3 || A.opt.no_march2 || A.opt.no_march) return MG_OK;
-  if (A.rc_nexc != 0 || A.regular_cols >= 0) return MG_OK;
+  // a box operator of a sharded level (regular_cols >= 0): the grid is the owned box = its first regular_cols rows; the rows
+  // that read the halo are exception rows (class 0xFFFF) and stay so here
+  const bool box = A.regular_cols >= 0;
+  const long long nreg = box ? A.regular_cols : A.n_rows;
+  if (A.rc_nexc != 0 && !box) return MG_OK;
+  A.rc_exc2.release();
+  A.rc_nexc2 = 0;
   const long long n1 = grid[0], n2 = grid[1], n3 = grid[2];
-  if (n1 < 4 || n2 < 4 || n3 < 3 || n1 * n2 * n3 != A.n_rows) return MG_OK;
+  if (n1 < 4 || n2 < 4 || n3 < 3 || n1 * n2 * n3 != nreg) return MG_OK;
   if (n1 > 65535 || n2 > 65535 || n3 > 65535 || A.h_cls.size() != (size_t)A.n_rows) return MG_OK;
   const long long P = n1 * n2;
   if (A.n_rows + 4 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
@@ -2626,11 +2667,51 @@ int build_march3(Csr& A, const long long grid[3]) {
       }
     }
     if (!okmap) return MG_OK;     // the classes are not a product of coordinate classes: the 1-D chunk form serves the level
-    for (unsigned short v : tab) if (v >= ncls) return MG_OK;
+    for (unsigned short v : tab) if (v >= ncls && !(box && v == 0xFFFF)) return MG_OK;
     cmap.insert(cmap.end(), cx.begin(), cx.end());
     cmap.insert(cmap.end(), cy.begin(), cy.end());
     cmap.insert(cmap.end(), cz.begin(), cz.end());
     cmap.insert(cmap.end(), tab.begin(), tab.end());
+    if (box && A.rc_nexc > 0) {
+      // Stage 2 (r = b - A t) of a row next to an exception row needs that row's t, which exists only after the exchange:
+      // such rows (the layer behind the faces) are left to csr_rows_spmv as well.  Their set must be sx[x] | sy[y] | sz[z].
+      std::vector<unsigned char> near((size_t)nreg, 0);
+#pragma omp parallel for schedule(static)
+      for (long long i = 0; i < nreg; ++i) {
+        const unsigned short c = cl[i];
+        if (c == 0xFFFF) continue;
+        for (int k = A.h_rc_ptr[c]; k < A.h_rc_ptr[(size_t)c + 1]; ++k) {
+          const long long col = i + A.h_rc_delta[c] + A.h_rc_off[(size_t)k];
+          if (col >= 0 && col < nreg && cl[col] == 0xFFFF) { near[(size_t)i] = 1; break; }
+        }
+      }
+      std::vector<unsigned short> sx((size_t)n1, 1), sy((size_t)n2, 1), sz((size_t)n3, 1);
+      for (long long z = 0; z < n3; ++z)
+        for (long long y = 0; y < n2; ++y)
+          for (long long x = 0; x < n1; ++x) {
+            const long long i = (z * n2 + y) * n1 + x;
+            if (cl[i] == 0xFFFF || near[(size_t)i]) continue;
+            sx[(size_t)x] = 0; sy[(size_t)y] = 0; sz[(size_t)z] = 0;     // a row computed in full: none of its coordinates is flagged
+          }
+      std::vector<int> list2;
+      for (long long z = 0; z < n3; ++z)
+        for (long long y = 0; y < n2; ++y)
+          for (long long x = 0; x < n1; ++x) {
+            const long long i = (z * n2 + y) * n1 + x;
+            if (cl[i] == 0xFFFF) continue;
+            const bool flag = sx[(size_t)x] | sy[(size_t)y] | sz[(size_t)z];
+            if (near[(size_t)i] && !flag) return MG_OK;                 // not a union of coordinate layers: two launches per pair
+            if (flag) list2.push_back((int)i);                          // (a superset of `near` is harmless: computed by the list kernel)
+          }
+      cmap.insert(cmap.end(), sx.begin(), sx.end());
+      cmap.insert(cmap.end(), sy.begin(), sy.end());
+      cmap.insert(cmap.end(), sz.begin(), sz.end());
+      A.rc_nexc2 = (int)list2.size();
+      if (!list2.empty()) {
+        MG_TRY(A.rc_exc2.alloc(list2.size()));
+        HIP_TRY(hipMemcpy(A.rc_exc2.p, list2.data(), list2.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
+    }
   }
   // ---- tile geometry ------------------------------------------------------------------------------------------------------
   int dev = 0, ncu = 256;
@@ -2748,6 +2829,7 @@ int build_march3(Csr& A, const long long grid[3]) {
   T.nblocks = (int)best.nb;
   T.segs = (int)best.segs; T.seglen = (int)best.seglen;
   T.n_cols = (int)A.n_cols; T.ncls = (int)ncls;
+  T.has_exc = (box && A.rc_nexc > 0) ? 1 : 0;
   A.rm3 = T;
   A.rm3_lds = best.lds;
   A.rm3_k1 = (int)best.K1;
@@ -2758,6 +2840,101 @@ int build_march3(Csr& A, const long long grid[3]) {
     std::fprintf(stderr, "[mg] march3: grid %lldx%lldx%lld tiles %lldx%lld of %lldx%lld (%lld threads, K1 %lld, SY %lld), %lld workgroups%s, class maps %dx%dx%d, LDS %zu B, est. %.1f B/row\n",
                  n1, n2, n3, best.tilesx, best.tilesy, best.TX, best.TY, best.NT, best.K1, best.SY, best.nb,
                  best.segs ? " (lockstep)" : "", ncx, ncy, ncz, best.lds, best.fill);
+  return MG_OK;
+}
+
+// Restriction-shaped operators (csr_rowclass_rmarch_spmv): rows = a coarse grid gc, columns = a fine grid gf, coarse node
+// (X, Y, Z) reading only fine nodes (2X+dx, 2Y+dy, 2Z+dz), |d| <= 1.  Verified row by row against the stored pattern: the
+// first column of a row relative to its centre (2X, 2Y, 2Z) must be the same for all rows of a class, every dictionary entry
+// must decompose into (dz, dy, dx) within +-1.  Geometry: 512 threads = a CX x CY coarse tile, fine slab (2CX+1) x (2CY+1).
+int build_rmarch(Csr& M, const long long gc[3], const long long gf[3]) {
+  M.rr_ok = false;
+  if (!M.has_rc || M.rc_implicit || M.rc_nexc != 0 || M.opt.no_rmarch || M.regular_cols >= 0) return MG_OK;
+  if (gc[0] < 2 || gc[1] < 2 || gc[2] < 2 || gf[0] < 3 || gf[1] < 3 || gf[2] < 3) return MG_OK;
+  if (gc[0] * gc[1] * gc[2] != M.n_rows || gf[0] * gf[1] * gf[2] != M.n_cols) return MG_OK;
+  if (M.h_rp.size() != (size_t)M.n_rows + 1 || M.h_cls.size() != (size_t)M.n_rows || M.h_rc_ptr.empty()) return MG_OK;
+  if (M.n_rows < M.opt.winp_min_rows / 8) return MG_OK;      // small levels: launch-bound either way
+  const size_t ncls = M.h_rc_ptr.size() - 1;
+  if (ncls > (size_t)mgk::RR_NCLS || M.h_rc_off.size() > (size_t)mgk::RR_DCAP) return MG_OK;
+  const long long c1 = gc[0], c2 = gc[1], c3 = gc[2], f1 = gf[0], f2 = gf[1], f3 = gf[2];
+  if (2 * (c1 - 1) > f1 - 1 || 2 * (c2 - 1) > f2 - 1 || 2 * (c3 - 1) > f3 - 1) return MG_OK;   // every centre inside the fine grid
+  if (M.n_cols + 4 * f1 * f2 >= (1LL << 31) - 1) return MG_OK;
+  const long long FP = f1 * f2;
+  std::vector<long long> cdelta(ncls, LLONG_MIN);
+  bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+  for (long long Z = 0; Z < c3; ++Z) {
+    for (long long Y = 0; Y < c2 && ok; ++Y)
+      for (long long X = 0; X < c1; ++X) {
+        const long long i = (Z * c2 + Y) * c1 + X;
+        const unsigned short c = M.h_cls[(size_t)i];
+        if (M.h_rp[(size_t)i + 1] == M.h_rp[(size_t)i]) { ok = false; break; }
+        const long long centre = (2 * Z * f2 + 2 * Y) * f1 + 2 * X;
+        const long long d = (long long)M.h_ci[(size_t)M.h_rp[(size_t)i]] - centre;
+        long long seen;
+#pragma omp atomic read
+        seen = cdelta[c];
+        if (seen == LLONG_MIN) {
+#pragma omp critical
+          { if (cdelta[c] == LLONG_MIN) cdelta[c] = d; seen = cdelta[c]; }
+        }
+        if (seen != d) { ok = false; break; }
+      }
+  }
+  if (!ok) return MG_OK;
+  std::vector<int> dzv(M.h_rc_off.size()), dyv(M.h_rc_off.size()), dxv(M.h_rc_off.size());
+  int maxlen = 0;
+  for (size_t c = 0; c < ncls; ++c) {
+    if (cdelta[c] == LLONG_MIN) cdelta[c] = 0;       // (a class without rows)
+    maxlen = std::max(maxlen, M.h_rc_ptr[c + 1] - M.h_rc_ptr[c]);
+    for (int k = M.h_rc_ptr[c]; k < M.h_rc_ptr[c + 1]; ++k) {
+      const long long sh = cdelta[c] + M.h_rc_off[(size_t)k];
+      const long long dz = (sh >= 0) ? (sh + FP / 2) / FP : -((-sh + FP / 2) / FP);
+      const long long rest = sh - dz * FP;
+      const long long dy = (rest >= 0) ? (rest + f1 / 2) / f1 : -((-rest + f1 / 2) / f1);
+      const long long dx = rest - dy * f1;
+      if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) return MG_OK;
+      dzv[(size_t)k] = (int)dz; dyv[(size_t)k] = (int)dy; dxv[(size_t)k] = (int)dx;
+    }
+  }
+  // geometry
+  int dev = 0, ncu = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const size_t dict_bytes = M.h_rc_off.size() * 16 + (ncls + 1) * 4 + 16;
+  mgk::RMarchDev T{};
+  bool have = false;
+  for (long long tilesx = (c1 + 63) / 64; tilesx <= c1 && !have; ++tilesx) {
+    const long long CX = (c1 + tilesx - 1) / tilesx;
+    long long CY = std::min<long long>(mgk::RR_NT / CX, c2);
+    if (CY < 1) continue;
+    const long long tilesy = (c2 + CY - 1) / CY;
+    CY = (c2 + tilesy - 1) / tilesy;
+    const long long W = 2 * CX + 1, NPL = (W + 2) / 2, LY = 2 * CY + 1;
+    if (LY * NPL > (long long)mgk::RR_NPM * mgk::RR_NT) continue;
+    const size_t lds = (size_t)(3 * LY * 2 * NPL) * 8 + dict_bytes;
+    if (lds > 80 * 1024) continue;
+    T.CX = (int)CX; T.CY = (int)CY; T.tiles_x = (int)tilesx; T.tiles_y = (int)tilesy;
+    T.pitch = (int)(2 * NPL); T.LY = (int)LY; T.NPL = (int)NPL;
+    M.rr_lds = lds;
+    have = true;
+  }
+  if (!have) return MG_OK;
+  const long long items = (long long)T.tiles_x * T.tiles_y * c3;
+  const long long per_cu = std::max<long long>(1, std::min<long long>(3, (160 * 1024 - 1024) / (long long)M.rr_lds));
+  T.nblocks = (int)std::max<long long>(1, std::min<long long>(per_cu * ncu, items / 4));
+  if (T.nblocks < std::min<long long>(M.opt.march_min_wg, ncu)) return MG_OK;
+  std::vector<int> code(M.h_rc_off.size());
+  for (size_t k = 0; k < code.size(); ++k) code[k] = ((dyv[k] * T.pitch + dxv[k] + T.pitch + 1) << 2) | (dzv[k] + 1);
+  MG_TRY(M.rr_code.alloc(std::max<size_t>(code.size(), 1)));
+  HIP_TRY(hipMemcpy(M.rr_code.p, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
+  T.c1 = (int)c1; T.c2 = (int)c2; T.c3 = (int)c3; T.f1 = (int)f1; T.f2 = (int)f2; T.f3 = (int)f3;
+  T.n_cols = (int)M.n_cols; T.ncls = (int)ncls; T.nent = (int)M.h_rc_off.size(); T.maxlen = maxlen;
+  M.rr = T;
+  M.rr_ok = true;
+  if (M.opt.debug_format)
+    std::fprintf(stderr, "[mg] rmarch: coarse %lldx%lldx%lld <- fine %lldx%lldx%lld, tiles %dx%d of %dx%d, %d workgroups, LDS %zu B\n",
+                 c1, c2, c3, f1, f2, f3, T.tiles_x, T.tiles_y, T.CX, T.CY, T.nblocks, M.rr_lds);
   return MG_OK;
 }
 
@@ -2906,6 +3083,7 @@ int alloc_scratch(mg_hierarchy* h) {
       MG_TRY(build_schedule(L.P, L.grid, k));
       if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
       if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_winp(L.P, L.grid, h->lev[(size_t)l + 1].grid));
+      if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_rmarch(L.R, h->lev[(size_t)l + 1].grid, L.grid));
     }
   }
   long long nmax = 0;
@@ -4638,7 +4816,7 @@ int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which
     if (h->nrhs > 1)   // block right-hand sides: 5 csr_rowclass_lane_spmm, 6 csr_rowclass_lane_spmm2, else the CSR stream
       *kernel_variant = (M->has_rc && M->rc_lane_mm() && M->ln_blocks > 0) ? (lane_mm_pairs(*M, h->nrhs) ? 6 : 5) : -1;
     else
-      *kernel_variant = !M->has_rc ? -1 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : M->rc_lane() ? 4 : 0;
+      *kernel_variant = !M->has_rc ? -1 : M->rr_ok ? 7 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : M->rc_lane() ? 4 : 0;   // (7: csr_rowclass_rmarch_spmv for beta == 0, else the lane kernel)
   }
   if (exception_rows) *exception_rows = M->has_rc ? M->rc_nexc : 0;
   return MG_OK;
@@ -4706,6 +4884,7 @@ int mg_device_bytes(mg_hierarchy* h, double* bytes) {
 struct mg_operator {
   int device = 0;
   Csr M;
+  DevBuf<double> m3sink, m3scratch;   // csr_rowclass_march3_spmv: store sink; outputs nobody asked for
 };
 
 int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_cols,
@@ -4774,6 +4953,8 @@ int mg_op_destroy(mg_operator* op) {
   if (!op) return MG_OK;
   (void)hipSetDevice(op->device);
   op->M.release();
+  op->m3sink.release();
+  op->m3scratch.release();
   delete op;
   return MG_OK;
 }
@@ -4873,6 +5054,83 @@ int mg_op_can_fuse_next(mg_operator* op, const double* x, long long* yes) {
   v.xs = x;
   v.nrhs = 1;
   *yes = (op->M.has_rc && (op->M.rc_tile || march_ok(op->M, v))) ? 1 : 0;
+  return MG_OK;
+}
+
+// Can mg_op_sweep_residual_dev_FP64 serve this operator with these vectors?  (2-D tile form of the two-stage pass: grid
+// operator of z-star classes, relaxPrec bound to the operator and constant per class, x 16-byte aligned.)  *lists: rows the
+// pass leaves to mg_op_apply_list_dev_FP64 - list 1 (rows that read the halo: neither t nor r), list 2 (rows next to them: r).
+int mg_op_can_sweep_residual(mg_operator* op, const double* x, const double* d, long long* yes, long long* list1, long long* list2) {
+  if (!op || !yes) return fail(MG_ERR_INVALID, "null argument");
+  const Csr& M = op->M;
+  *yes = (M.set && M.has_rc && M.rc_march3 && M.rc_has_d && d && d == M.d_bound && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
+  if (list1) *list1 = M.rc_nexc;
+  if (list2) *list2 = M.rc_nexc2;
+  return MG_OK;
+}
+
+// One damped-Jacobi sweep and the residual of its result in ONE pass (csr_rowclass_march3_spmv) over an operator:
+//   t = x + d.*(b - M x) on every row that has a class;  r = b - M t [xn = t + d.*r, ||r||^2 partials] on every such row
+//   that is not in list 2.  t, r, xn: each optional; d: the relaxPrec bound with mg_op_bind_relax_dev_FP64.
+int mg_op_sweep_residual_dev_FP64(mg_operator* op, const double* x, const double* b, const double* d, double* t, double* r,
+                                  double* xn, double* partials_dev, long long* nparts, void* stream) {
+  if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
+  if (!x || !b || !d || (partials_dev && !nparts)) return fail(MG_ERR_INVALID, "bad argument");
+  long long yes = 0;
+  MG_TRY(mg_op_can_sweep_residual(op, x, d, &yes, nullptr, nullptr));
+  if (!yes) return fail(MG_ERR_UNSUPPORTED, "this operator is not served by the two-stage pass");
+  if ((t && (x == t || t == r || t == xn)) || x == r || x == xn || (r && r == xn)) return fail(MG_ERR_INVALID, "x, t, r, xn must be distinct buffers");
+  (void)hipSetDevice(op->device);
+  const Csr& M = op->M;
+  const size_t need = (size_t)12 * (size_t)M.rm3.nblocks * (size_t)M.rm3_nt;
+  if (op->m3sink.n < need) MG_TRY(op->m3sink.alloc(need));
+  const int o = (r ? 1 : 0) | (xn ? 2 : 0) | (t ? 4 : 0);
+  if (!(o == 5 || o == 2 || o == 6 || o == 7) && op->m3scratch.n < (size_t)M.n_rows) MG_TRY(op->m3scratch.alloc((size_t)M.n_rows));
+  mgk::March2Args a{};
+  a.x = x;
+  a.b = b;
+  a.t = t;
+  a.r = r;
+  a.xn = xn;
+  a.sumsq = partials_dev;
+  a.sink = op->m3sink.p;
+  a.d = d;
+  MG_TRY(launch_march3_any(reinterpret_cast<hipStream_t>(stream), M, a, false, op->m3scratch.p));
+  if (nparts) *nparts = partials_dev ? M.rm3.nblocks : 0;
+  return MG_OK;
+}
+
+// The rows mg_op_sweep_residual_dev_FP64 leaves out, from the CSR arrays (csr_rows_spmv): list 1 = the rows that read the
+// halo, list 2 = the rows next to them.  kernel: MG_K_SMOOTH (y = x + d.*(b - M x)) or MG_K_RESIDUAL (y = b - M x; y2, if
+// given, = xs + d.*y with xs = x; partials_dev, if given, receives ||y||^2 partials, *nparts of them).
+int mg_op_apply_list_dev_FP64(mg_operator* op, long long list, long long kernel, const double* x, double* y, const double* b,
+                              const double* d, double* y2, double* partials_dev, long long* nparts, void* stream) {
+  if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
+  if ((list != 1 && list != 2) || !x || !b || (!y && !y2) || (partials_dev && !nparts)) return fail(MG_ERR_INVALID, "bad argument");
+  if ((kernel == MG_K_SMOOTH || y2) && !d) return fail(MG_ERR_INVALID, "this kernel needs d");
+  const Csr& M = op->M;
+  const int n = list == 1 ? M.rc_nexc : M.rc_nexc2;
+  const int* rows = list == 1 ? M.rc_exc.p : M.rc_exc2.p;
+  if (nparts) *nparts = 0;
+  if (n <= 0) return MG_OK;
+  (void)hipSetDevice(op->device);
+  mgk::VecArgs v{};
+  v.x = x;
+  v.xs = x;
+  v.y = y;
+  v.b = b;
+  v.d = d;
+  v.d_full = d;
+  v.y2 = y2;
+  v.nrhs = 1;
+  v.sumsq = partials_dev;
+  const int nb = (n + mgk::BLK - 1) / mgk::BLK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (kernel == MG_K_SMOOTH) hipLaunchKernelGGL((mgk::csr_rows_spmv<mgk::SMOOTH>), dim3(nb), dim3(mgk::BLK), 0, s, M.dev(), rows, n, v, 0);
+  else if (kernel == MG_K_RESIDUAL) hipLaunchKernelGGL((mgk::csr_rows_spmv<mgk::RESID>), dim3(nb), dim3(mgk::BLK), 0, s, M.dev(), rows, n, v, 0);
+  else return fail(MG_ERR_INVALID, "kernel %lld is not a list kernel", kernel);
+  HIP_TRY(hipGetLastError());
+  if (nparts && partials_dev) *nparts = nb;
   return MG_OK;
 }
 
@@ -5108,6 +5366,7 @@ struct DistLevel {
   DistPlan planA, planR, planP;
   long long cap_x = 0, cap_r = 0;
   DevBuf<double> x0, x1, r, b;
+  DevBuf<double> x2;   // fine level, solve loop: third rotating buffer of the fused last sweep + residual (allocated on first use)
 };
 }  // namespace
 
@@ -5133,6 +5392,7 @@ struct mg_dist {
   char cycle = 'V';
   int relax_type = 0;                   // 0: pointwise (Jac / SPAI), 1: Jac-GMRES (MGcycle.jl:48-50,96-98)
   bool finalized = false;
+  bool no_pair = false;                 // MG_DIST_NO_PAIR=1: never fuse a sweep with the residual that follows it (A/B, tests)
   // replicated tail
   mg_hierarchy* tail = nullptr;
   // what the tail's handle looked like before this sequencer borrowed it (restored by mg_dist_release_tail / destroy)
@@ -5244,6 +5504,46 @@ int dist_reduce_scalar(mg_dist* h, double* out) {
     }
   }
   *out = std::sqrt(*h->h_scalar);
+  return MG_OK;
+}
+
+// Can the sweep + residual pair of this level run as one two-stage pass (box-form level whose A is on the 2-D tile form)?
+bool dist_pair_ok(mg_dist* h, DistLevel& L, const double* x) {
+  if (!L.box || h->relax_type != 0 || h->no_pair || !L.A_int) return false;
+  long long yes = 0;
+  if (mg_op_can_sweep_residual(L.A_int, x, L.d, &yes, nullptr, nullptr) != MG_OK) return false;
+  return yes != 0;
+}
+// One sweep and the residual of its result on a sharded box-form level (MGcycle.jl:54-60; SolveFuncs.jl:26-30 with the last
+// post-smoothing sweep): t = x + d.*(b - A x), r = b - A t [, xn = t + d.*r, ||r|| over all ranks].  Two exchanges as for
+// the two launches it replaces, one pass over the level instead of two:
+//   exchange(x) || two-stage pass: t everywhere but on the rows that read the halo, r two layers in
+//   -> t on those rows -> exchange(t) || r of the layer behind them -> r on them.
+// t: a buffer with a halo tail (cap_x).  r / xn: each optional.
+int dist_sweep_residual(mg_dist* h, DistLevel& L, double* x, double* t, double* r, double* xn, const double* b, double* norm) {
+  long long n0 = 0, n1 = 0, n2 = 0;
+  double* part = norm ? h->partial.p : nullptr;
+  if (norm) {
+    const Csr& M = L.A_int->M;
+    const size_t need = (size_t)M.rm3.nblocks + (size_t)(M.rc_nexc + M.rc_nexc2) / mgk::BLK + 4;
+    if (need > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small (%zu > %zu)", need, h->partial.n);
+  }
+  MG_TRY(dist_exchange_start(h, L.planA, x));
+  MG_TRY(mg_op_sweep_residual_dev_FP64(L.A_int, x, b, L.d, t, r, xn, part, &n0, h->stream));
+  MG_TRY(dist_exchange_finish(h, L.planA));
+  MG_TRY(mg_op_apply_list_dev_FP64(L.A_int, 1, MG_K_SMOOTH, x, t, b, L.d, nullptr, nullptr, nullptr, h->stream));
+  MG_TRY(dist_exchange_start(h, L.planA, t));
+  MG_TRY(mg_op_apply_list_dev_FP64(L.A_int, 2, MG_K_RESIDUAL, t, r, b, L.d, xn, part ? part + n0 : nullptr, &n1, h->stream));
+  MG_TRY(dist_exchange_finish(h, L.planA));
+  MG_TRY(mg_op_apply_list_dev_FP64(L.A_int, 1, MG_K_RESIDUAL, t, r, b, L.d, xn, part ? part + n0 + n1 : nullptr, &n2, h->stream));
+  if (norm) {
+    const long long nb1 = n0 + n1 + n2;
+    const int nb2 = (int)std::min<long long>(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
+    hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->partial2.p);
+    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
+    HIP_TRY(hipGetLastError());
+    MG_TRY(dist_reduce_scalar(h, norm));
+  }
   return MG_OK;
 }
 
@@ -5359,8 +5659,10 @@ int dist_fgmres_relax(mg_dist* h, DistLevel& L, const double* r0, double* x0, lo
 }  // extern "C++"
 
 // the sharded cycle: mirror of cycle_level (MGcycle.jl:1-118); returns the buffer holding x
+// defer_post (optional, in/out): asked with true, the LAST post-smoothing sweep is left out where it can run fused with the
+// residual that follows the cycle (dist_sweep_residual) - *defer_post tells whether it was.
 int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
-               bool r_valid = false, bool x1_ready = false) {
+               bool r_valid = false, bool x1_ready = false, bool* defer_post = nullptr) {
   DistLevel& L = h->lev[(size_t)l];
   double *cur = xa, *alt = xb;
   long long npre = L.npre;
@@ -5385,11 +5687,22 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     std::swap(cur, alt);
     --npre;
   }
-  for (long long s = 0; s < npre; ++s) {
+  // the last pre-smoothing sweep and the residual for the restriction as ONE pass where the level allows (MGcycle.jl:54-60)
+  const bool pair_pre = npre >= 1 && dist_pair_ok(h, L, cur);
+  for (long long s = 0; s < npre - (pair_pre ? 1 : 0); ++s) {
     MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
     std::swap(cur, alt);
   }
-  MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
+  if (pair_pre && dist_pair_ok(h, L, cur)) {
+    MG_TRY(dist_sweep_residual(h, L, cur, alt, L.r.p, nullptr, b, nullptr));
+    std::swap(cur, alt);
+  } else {
+    if (pair_pre) {   // (the buffer the remaining sweep starts from is not aligned for the pass: two launches)
+      MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
+      std::swap(cur, alt);
+    }
+    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
+  }
   MG_TRY(dist_exchange_start(h, L.planR, L.r.p));
   MG_TRY(dist_exchange_finish(h, L.planR));
   if (l + 1 < (int)h->lev.size()) {
@@ -5450,11 +5763,18 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
     MG_TRY(dist_fgmres_relax(h, L, L.r.p, cur, L.npost_raw, diag_prec, gmresTol, L.relZ, L.relAZ, false));
   } else {
-    for (long long s = 0; s < npost; ++s) {
+    const bool defer = defer_post && *defer_post && npost >= 1;
+    for (long long s = 0; s < npost - (defer ? 1 : 0); ++s) {
+      MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
+      std::swap(cur, alt);
+    }
+    if (defer_post) *defer_post = defer && dist_pair_ok(h, L, cur);
+    if (defer && !*defer_post) {   // (not fusable from this buffer after all: the sweep runs here)
       MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
       std::swap(cur, alt);
     }
   }
+  if (h->relax_type == 1 && defer_post) *defer_post = false;
   *result = cur;
   return MG_OK;
 }
@@ -5522,6 +5842,7 @@ int mg_dist_create(long long device_id, long long rank, long long world, const c
   h->cycle = (char)cycleType;
   h->nl_total = nl_total;
   h->lev.resize((size_t)nlevels);
+  if (const char* e = std::getenv("MG_DIST_NO_PAIR")) h->no_pair = e[0] == '1';   // (read once, here: nothing on the launch path reads the environment)
   auto bail = [&](int rc) { mg_dist_destroy(h); return rc; };
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_landed, hipEventDisableTiming) != hipSuccess ||
@@ -5729,12 +6050,36 @@ int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long 
   }
   if (resvec) resvec[0] = res0;
   long long it = 0;
+  // Where the fine level's A allows, the last post-smoothing sweep is left out of the cycle and runs fused with the residual of
+  // the stopping test (SolveFuncs.jl:26-30): x -> the iterate t, ||r||, and xn = t + d.*r, the next cycle's first update;
+  // three buffers rotate (as solve_dev does on one GPU)
+  double* spare = nullptr;
+  bool fuse_post = false;
+  if (h->relax_type == 0 && L.npost >= 1 && dist_pair_ok(h, L, cur)) {
+    if (L.x2.n != (size_t)L.cap_x) {
+      MG_TRY(L.x2.alloc((size_t)L.cap_x));
+      HIP_TRY(hipMemsetAsync(L.x2.p, 0, L.x2.bytes(), h->stream));
+    }
+    spare = L.x2.p;
+    fuse_post = dist_pair_ok(h, L, alt) && dist_pair_ok(h, L, spare);
+  }
   for (long long count = 1; count <= maxIter; ++count) {
     double* out = nullptr;
-    MG_TRY(dist_cycle(h, 0, b_loc, cur, alt, x_zero, h->cycle, &out, count > 1 || !x_zero, x1_ready));
+    bool deferred = fuse_post;
+    MG_TRY(dist_cycle(h, 0, b_loc, cur, alt, x_zero, h->cycle, &out, count > 1 || !x_zero, x1_ready, fuse_post ? &deferred : nullptr));
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
-    MG_TRY(dist_residual_norm(h, L, cur, b_loc, (count < maxIter && h->relax_type == 0) ? alt : nullptr, &res, &x1_ready));
+    if (fuse_post && deferred) {
+      // cur = x before the last sweep; alt <- the iterate; spare <- t + d.*r (not written on the last step)
+      MG_TRY(dist_sweep_residual(h, L, cur, alt, nullptr, count < maxIter ? spare : nullptr, b_loc, &res));
+      x1_ready = count < maxIter;
+      double* freed = cur;
+      cur = alt;
+      alt = spare;
+      spare = freed;
+    } else {
+      MG_TRY(dist_residual_norm(h, L, cur, b_loc, (count < maxIter && h->relax_type == 0) ? alt : nullptr, &res, &x1_ready));
+    }
     ++it;
     if (resvec) resvec[it] = res;
     if (res / res0 < tol) break;
@@ -5777,6 +6122,7 @@ int mg_dist_destroy(mg_dist* h) {
     dist_free_plan(L.planP);
     L.x0.release();
     L.x1.release();
+    L.x2.release();
     L.r.release();
     L.b.release();
   }

@@ -96,6 +96,9 @@ SIGNATURES = {
     "mg_kcycle_step_async_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll]),
     "mg_op_residual_fused_dev_FP64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _lp, _vp]),
     "mg_op_can_fuse_next": (C.c_int, [_vp, _vp, _lp]),
+    "mg_op_can_sweep_residual": (C.c_int, [_vp, _vp, _vp, _lp, _lp, _lp]),
+    "mg_op_sweep_residual_dev_FP64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _lp, _vp]),
+    "mg_op_apply_list_dev_FP64": (C.c_int, [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _lp, _vp]),
     "mg_op_destroy": (C.c_int, [_vp]),
     "mg_op_apply_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _vp]),
     "mg_op_apply_rows_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _ll, _vp]),

@@ -776,9 +776,8 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cells,k1,nt,tiles_x,lockstep", [([33, 25, 7], 2, 1024, 0, 0), ([33, 25, 7], 3, 768, 2, 1), ([40, 30, 9], 4, 768, 3, 0),
-                                                          ([23, 23, 23], 3, 1024, 1, 1), ([70, 10, 12], 2, 1024, 0, 0), ([64, 64, 20], 4, 768, 0, 1),
-                                                          ([64, 64, 20], 2, 1024, 4, 1), ([36, 36, 40], 3, 768, 2, 0), ([20, 20, 3], 2, 1024, 1, 1),
-                                                          ([130, 18, 5], 4, 768, 0, 0), ([257, 9, 4], 3, 1024, 0, 1)])
+                                                          ([23, 23, 23], 3, 1024, 1, 1), ([48, 40, 12], 4, 768, 0, 1), ([20, 20, 3], 2, 1024, 1, 1),
+                                                          ([257, 9, 4], 3, 1024, 0, 1)])
 def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k1, nt, tiles_x, lockstep):
     """csr_rowclass_march3_spmv (sweep + residual in one pass on 2-D in-plane tiles; the z-1 / z+1 entries from registers):
     t, r, t + d.*r and ||r|| against numpy, BIT-identical to the 1-D chunk form (MG_NO_MARCH3=1) and to the two
@@ -893,6 +892,55 @@ def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, 
         assert np.array_equal(a, bb)
     assert np.array_equal(outs["windows"][1], outs["lane"][1])
     assert np.array_equal(outs["windows"][2], outs["lane"][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells,levels,expect", [([32, 32, 32], 3, True), ([40, 30, 10], 2, True), ([22, 70, 12], 2, True),
+                                                 ([130, 12, 8], 2, True), ([31, 16, 12], 2, False), ([23, 23, 23], 2, False)])
+def test_restriction_with_staged_fine_slabs(mg, built, monkeypatch, cells, levels, expect):
+    """csr_rowclass_rmarch_spmv (bc = R r with the fine vector staged in LDS, a ring of three fine slabs marched along the
+    coarse z; tables derived from R's pattern at upload and verified row by row): products against scipy, bit-identical
+    to the lane kernel's (MG_NO_RMARCH=1) including the fused second output d.*bc, and the solve against the oracle.  Odd
+    cell counts (even node counts: the non-geometric variants of getFWInterp, GeometricTransferOperators.jl:35-36) do not
+    have the 2X-1..2X+1 shape everywhere and must fall back to the lane kernel."""
+    import torch
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    monkeypatch.setenv("MG_WINP_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    outs = {}
+    for name, no in (("slabs", "0"), ("lane", "1")):
+        rng = np.random.default_rng(sum(cells) + 5)           # the same vectors for both runs
+        monkeypatch.setenv("MG_NO_RMARCH", no)
+        A, p, b = _setup(mg, cells, levels, maxIter=5)
+        h = mg.to_device(p)
+        var = h.operator_kernel_variant(1, D.MG_OP_R)
+        assert (var == 7) == (no == "0" and expect), var
+        res = []
+        for l in range(1, p.levels):
+            R = p.Rs[l - 1]
+            Rm = R if R.shape[1] == p.As[l - 1].shape[0] else R.T          # coarse x fine
+            xin = rng.standard_normal(Rm.shape[1])
+            y0 = rng.standard_normal(Rm.shape[0])
+            for alpha, beta in ((1.0, 0.0), (-0.75, 0.0), (1.0, 1.0)):
+                y = torch.from_numpy(y0.copy()).cuda()
+                h.spmv_dev(l, D.MG_OP_R, alpha, torch.from_numpy(xin).cuda(), beta, y)
+                want = alpha * (Rm @ xin) + beta * y0
+                got = y.cpu().numpy()
+                assert np.abs(got - want).max() / np.abs(want).max() < KERNEL_TOL
+                res.append(got)
+        x, hist = _compare_solve(mg, p, b)
+        x0 = np.random.default_rng(99).standard_normal(b.shape)
+        x1 = x0.copy()
+        mg.recursiveCycle(p, b, x1, 1)
+        outs[name] = (res, x.copy(), np.asarray(p.resvec).copy(), x1.copy())
+        mg.clear_(p)
+    for a, bb in zip(outs["slabs"][0], outs["lane"][0]):
+        assert np.array_equal(a, bb)
+    for k in (1, 2, 3):
+        assert np.array_equal(outs["slabs"][k], outs["lane"][k]), k
 
 
 @pytest.mark.gpu
