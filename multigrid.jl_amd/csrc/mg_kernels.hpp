@@ -2340,181 +2340,6 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
 }
 
 // ------------------------------------------------------------------------------------------------
-// Restriction with the fine vector staged in LDS (round 3): y = alpha*M*x [; y2 = d2.*y] for an operator whose rows are a
-// COARSE grid and whose columns are a FINE grid with coarse node (X, Y, Z) reading only fine nodes (2X+dx, 2Y+dy, 2Z+dz),
-// |d| <= 1 - the full-weighting restriction bc = R r (MGcycle.jl:66) with its 27 gathers per row.  The lane kernel takes
-// those gathers from L2 (27 x 8 bytes per coarse row through the L1 for 8 bytes of compulsory traffic per fine row);
-// here a workgroup owns a CX x CY tile of the coarse plane and walks a run of coarse planes with a ring of THREE fine slabs
-// ((2CX+1) x (2CY+1) entries each): coarse plane Z reads fine planes 2Z-1, 2Z, 2Z+1, plane Z+1 keeps 2Z+1 and replaces
-// the other two, so every fine plane is staged once per tile:
-//   iteration Z:  wait for the planes 2Z, 2Z+1 in registers | barrier | -> ring | loads of 2Z+2, 2Z+3 | barrier |
-//                 every lane walks the dictionary entries of its coarse row's class (ascending k: the row's stored order)
-// The host (build_rmarch) verifies row by row that the pattern has this shape and derives per dictionary entry the code
-// ((dy*pitch + dx + pitch + 1) << 2) | (dz + 1); anything else keeps the lane kernel.  Same products in the same order, same
-// epilogue expressions: bit-identical to the lane kernel.
-// ------------------------------------------------------------------------------------------------
-constexpr int RR_NT = 512;      // threads per workgroup (one coarse row per lane and plane)
-constexpr int RR_NPM = 2;       // 16-byte pairs per lane and fine plane
-constexpr int RR_DCAP = 1024;   // dictionary entries
-constexpr int RR_NCLS = 128;
-struct RMarchDev {
-  const int* code;              // per dictionary entry (see above)
-  int c1, c2, c3;               // coarse grid (rows), x fastest
-  int f1, f2, f3;               // fine grid (columns)
-  int CX, CY, tiles_x, tiles_y;
-  int pitch, LY, NPL;           // fine slab: 2*CY + 1 lines of pitch doubles (2*NPL), 16-byte pairs per line
-  int nblocks;
-  int n_cols, ncls, nent, maxlen;
-};
-
-__global__ __launch_bounds__(RR_NT) void csr_rowclass_rmarch_spmv(RowClassDev C, VecArgs v, RMarchDev T) {
-  extern __shared__ double win[];
-  const int tid = threadIdx.x;
-  const int w = xcd_band(blockIdx.x, T.nblocks);
-  const int pitch = T.pitch;
-  const int FS = T.LY * pitch;                          // doubles per fine slab
-  double* fw = win;                                     // [3][FS]
-  MarchEnt* dent = reinterpret_cast<MarchEnt*>(fw + 3 * FS);    // [nent]
-  int* dptr = reinterpret_cast<int*>(dent + T.nent);            // [ncls + 1]
-  for (int i = tid; i < T.nent; i += RR_NT) {
-    MarchEnt e;
-    e.val = C.cls_val[i];
-    e.code = T.code[i];
-    e.pad = 0;
-    dent[i] = e;
-  }
-  for (int i = tid; i <= T.ncls; i += RR_NT) dptr[i] = C.cls_ptr[i];
-  const long long FP = (long long)T.f1 * T.f2;          // fine rows per plane
-  const int CP = T.c1 * T.c2;
-  // the lane's coarse row of the tile, and its pairs of a fine slab
-  const int cxx = tid % T.CX, cyy = tid / T.CX;
-  const bool lane_ok = cyy < T.CY;
-  const int cen = (2 * cyy + 1) * pitch + 2 * cxx + 1 - (pitch + 1);   // slab index of the centre minus the bias of the codes
-  int pofs[RR_NPM], pline[RR_NPM];
-  unsigned pflag = 0u;                                  // per m: bit 4m the pair exists, 4m+1 first pair of its line, 4m+2 line inside the grid
-#pragma unroll
-  for (int m = 0; m < RR_NPM; ++m) {
-    const int pid = tid + m * RR_NT;
-    const int l = pid / T.NPL, i = pid - l * T.NPL;
-    pline[m] = l;
-    pofs[m] = l * pitch + 2 * i;
-    if (pid < T.LY * T.NPL) pflag |= 1u << (4 * m);
-    if (i == 0) pflag |= 2u << (4 * m);
-  }
-  const int ntiles = T.tiles_x * T.tiles_y;
-  const long long tot = (long long)ntiles * T.c3;
-  long long it = tot * w / T.nblocks;
-  const long long it_end = tot * (w + 1) / T.nblocks;
-  const bool scale2 = v.y2 != nullptr;
-#define RR_LOADPAIR(dst, p, m)                                                                                         \
-  do {                                                                                                                 \
-    const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u && (p) >= 0 && (p) < T.f3;                                     \
-    const long long e0_ = ((long long)(p) * FP + pg[m]) & ~1LL;                                                        \
-    (dst) = march_load_pair(v.x, e0_, act_, T.n_cols);                                                                 \
-  } while (0)
-#define RR_STAGE(p, m, val)                                                                                            \
-  do {                                                                                                                 \
-    if (((pflag >> (4 * (m))) & 1u) && (p) >= 0) {                                                                     \
-      const int par_ = (int)(((long long)(p) * FP + pg[m]) & 1LL);                                                     \
-      double* q_ = fw + (((p) % 3) * FS + pofs[m] - par_);                                                             \
-      if (!(par_ && ((pflag >> (4 * (m))) & 2u))) q_[0] = (val).x;                                                     \
-      q_[1] = (val).y;                                                                                                 \
-    }                                                                                                                  \
-  } while (0)
-  __syncthreads();   // dictionary in place
-  while (it < it_end) {
-    const int c = (int)(it / T.c3);
-    const int z0 = (int)(it - (long long)c * T.c3);
-    const int z1 = (int)((it_end - it) < (long long)(T.c3 - z0) ? z0 + (it_end - it) : T.c3);
-    it += z1 - z0;
-    const int ty = c / T.tiles_x, tx = c - ty * T.tiles_x;
-    const int X0 = tx * T.CX, Y0 = ty * T.CY;
-    int pg[RR_NPM];     // fine in-plane index of the pair's first element (before the even floor; may be negative)
-    pflag &= ~0x4444u;
-#pragma unroll
-    for (int m = 0; m < RR_NPM; ++m) {
-      const int yl = 2 * Y0 - 1 + pline[m];
-      const int i2 = pofs[m] - pline[m] * pitch;
-      if (yl >= 0 && yl < T.f2) pflag |= 4u << (4 * m);
-      pg[m] = yl * T.f1 + 2 * X0 - 1 + i2;
-    }
-    const int X = X0 + cxx, Y = Y0 + cyy;
-    const bool live = lane_ok && X < T.c1 && Y < T.c2;
-    const int crow0 = Y * T.c1 + X;                     // in-plane index of the lane's coarse row
-    // ---- fine plane 2*z0 - 1 straight into the ring; planes 2*z0, 2*z0 + 1 into registers -----------------------------------
-    __syncthreads();                                    // (the previous run's last reads of the ring)
-    {
-      d2_t q[RR_NPM];
-#pragma unroll
-      for (int m = 0; m < RR_NPM; ++m) RR_LOADPAIR(q[m], 2 * z0 - 1, m);
-#pragma unroll
-      for (int m = 0; m < RR_NPM; ++m) RR_STAGE(2 * z0 - 1, m, q[m]);
-    }
-    d2_t pa[RR_NPM], pb[RR_NPM];
-#pragma unroll
-    for (int m = 0; m < RR_NPM; ++m) {
-      RR_LOADPAIR(pa[m], 2 * z0, m);
-      RR_LOADPAIR(pb[m], 2 * z0 + 1, m);
-    }
-    int ncls_ = live ? (int)C.cls[z0 * CP + crow0] : 0;
-    for (int z = z0; z < z1; ++z) {
-      d2_t ca[RR_NPM], cb[RR_NPM];
-      int cq = ncls_;
-#pragma unroll
-      for (int m = 0; m < RR_NPM; ++m) {
-        ca[m] = pa[m];
-        cb[m] = pb[m];
-        asm volatile("" : "+v"(ca[m].x), "+v"(ca[m].y), "+v"(cb[m].x), "+v"(cb[m].y));   // the wait of this iteration
-      }
-      asm volatile("" : "+v"(cq));
-      __syncthreads();                                  // everyone has finished plane z-1: its two older slabs are free
-#pragma unroll
-      for (int m = 0; m < RR_NPM; ++m) {
-        RR_STAGE(2 * z, m, ca[m]);
-        RR_STAGE(2 * z + 1, m, cb[m]);
-      }
-      if (z + 1 < z1) {
-#pragma unroll
-        for (int m = 0; m < RR_NPM; ++m) {
-          RR_LOADPAIR(pa[m], 2 * z + 2, m);
-          RR_LOADPAIR(pb[m], 2 * z + 3, m);
-        }
-        ncls_ = live ? (int)C.cls[(z + 1) * CP + crow0] : 0;
-      }
-      __syncthreads();                                  // the slabs of planes 2z-1, 2z, 2z+1 are in place
-      if (live) {
-        const int row = z * CP + crow0;
-        const int s0 = dptr[cq], len = dptr[cq + 1] - s0;
-        // slab of fine plane 2z + dz: slot (2z + dz) mod 3 (plane -1 of the first coarse plane: slot 2, never read)
-        const int bm = ((2 * z + 2) % 3) * FS + cen, bz = ((2 * z) % 3) * FS + cen, bp = ((2 * z + 1) % 3) * FS + cen;
-        double acc = 0.0;
-        for (int k = 0; k < T.maxlen; k += 4) {
-          MarchEnt e[4];
-          double xv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) e[u] = dent[s0 + min(k + u, len > 0 ? len - 1 : 0)];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int dz1 = e[u].code & 3;
-            xv[u] = fw[(dz1 == 0 ? bm : (dz1 == 1 ? bz : bp)) + (e[u].code >> 2)];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double t = acc + e[u].val * xv[u];
-            acc = (k + u < len) ? t : acc;
-          }
-        }
-        const double outv = epilogue<AXPBY>(v, row, acc, 0.0, 0.0, 0.0);
-        v.y[row] = outv;
-        if (scale2) v.y2[row] = v.d_full[row] * outv;
-      }
-    }
-  }
-#undef RR_LOADPAIR
-#undef RR_STAGE
-}
-
-// ------------------------------------------------------------------------------------------------
 // Exception rows of a row-class operator (rows whose class was too rare for the dictionary: a few per cent next to
 // sub-domain faces or irregular boundaries): one lane per listed row, straight from the CSR arrays, same epilogues.
 // ------------------------------------------------------------------------------------------------

@@ -64,7 +64,6 @@ struct Options {
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
   bool no_tile_small = false;
   bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
-  bool no_rmarch = false;          // restriction: lane kernel (gathers from L2) instead of the fine slabs staged in LDS
   bool no_dead_t = false;          // solve loop: store the iterate of every step (A/B, bit-identity tests)
   bool no_march3 = false;          // never use the 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv)
   long long march3_k1 = 0;         // rows of the stage-1 region per lane (0: by the fill estimate; 2..4): tile height = K1 * (NT / (TX + 2)) - 2
@@ -99,7 +98,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
-      MG_OPT("MG_NO_RMARCH", "no_rmarch", 0, no_rmarch), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
+      MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
@@ -224,11 +223,6 @@ struct Csr {
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
   int rt_cr = mgk::RT_CR;   // rows of a plane per workgroup: 1024, or 256 on levels too small to fill the chip with 1024-row tiles
-  // csr_rowclass_rmarch_spmv (restriction-shaped operators: rows a coarse grid, columns a fine grid; fine slabs staged in LDS)
-  bool rr_ok = false;
-  DevBuf<int> rr_code;
-  mgk::RMarchDev rr{};
-  size_t rr_lds = 0;
   // csr_rowclass_winp_spmv (prolongation-shaped operators: the source windows of a workgroup's rows staged in LDS)
   bool rp_ok = false;
   DevBuf<unsigned short> rp_wf;
@@ -383,8 +377,6 @@ struct Csr {
     rc_exc2.release();
     rc_nexc2 = 0;
     rp_ok = false;
-    rr_ok = false;
-    rr_code.release();
     rp_wf.release();
     h_rc_ptr.clear();
     h_rc_off.clear();
@@ -745,21 +737,6 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
       const size_t lds = (size_t)M.rw_doubles * sizeof(double);
       if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, true>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
       else hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, false>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
-    } else if (MODE == mgk::AXPBY && M.rr_ok && phase == 0 && v.beta == 0.0 && v.y != v.x && !v.dotx && (reinterpret_cast<uintptr_t>(v.x) & 15) == 0) {
-      // a restriction-shaped operator: fine slabs staged in LDS, marched along the coarse z (no exception rows)
-      nb_main = M.rr.nblocks;
-      static bool rr_attr = false;
-      if (!rr_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_rmarch_spmv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        (void)hipGetLastError();
-        rr_attr = true;
-      }
-      mgk::RMarchDev T = M.rr;
-      T.code = M.rr_code.p;
-      hipLaunchKernelGGL(mgk::csr_rowclass_rmarch_spmv, dim3(nb_main), dim3(mgk::RR_NT), M.rr_lds, stream, C, v, T);
-      if (nparts) *nparts = 0;
-      HIP_TRY(hipGetLastError());
-      return MG_OK;
     } else if (MODE == mgk::AXPBY && M.rp_ok && phase == 0 && v.y != v.x) {
       // a prolongation-shaped operator: the coarse windows of a workgroup's rows staged in LDS (no exception rows)
       const mgk::WinPDev T = M.winpdev();
@@ -850,7 +827,7 @@ int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, con
 }
 // Is the product with M served by csr_rowclass_lane_spmv for one right-hand side (the kernel that can write d.*out too)?
 bool restrict_can_scale(const mg_hierarchy* h, const Csr& M) {
-  return h->nrhs == 1 && !h->opt.no_restrict_scale && M.has_rc && M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && (M.rc_lane() || M.rr_ok);
+  return h->nrhs == 1 && !h->opt.no_restrict_scale && M.has_rc && M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && M.rc_lane();
 }
 // out = b - A*x
 int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x,
@@ -2843,101 +2820,6 @@ int build_march3(Csr& A, const long long grid[3]) {
   return MG_OK;
 }
 
-// Restriction-shaped operators (csr_rowclass_rmarch_spmv): rows = a coarse grid gc, columns = a fine grid gf, coarse node
-// (X, Y, Z) reading only fine nodes (2X+dx, 2Y+dy, 2Z+dz), |d| <= 1.  Verified row by row against the stored pattern: the
-// first column of a row relative to its centre (2X, 2Y, 2Z) must be the same for all rows of a class, every dictionary entry
-// must decompose into (dz, dy, dx) within +-1.  Geometry: 512 threads = a CX x CY coarse tile, fine slab (2CX+1) x (2CY+1).
-int build_rmarch(Csr& M, const long long gc[3], const long long gf[3]) {
-  M.rr_ok = false;
-  if (!M.has_rc || M.rc_implicit || M.rc_nexc != 0 || M.opt.no_rmarch || M.regular_cols >= 0) return MG_OK;
-  if (gc[0] < 2 || gc[1] < 2 || gc[2] < 2 || gf[0] < 3 || gf[1] < 3 || gf[2] < 3) return MG_OK;
-  if (gc[0] * gc[1] * gc[2] != M.n_rows || gf[0] * gf[1] * gf[2] != M.n_cols) return MG_OK;
-  if (M.h_rp.size() != (size_t)M.n_rows + 1 || M.h_cls.size() != (size_t)M.n_rows || M.h_rc_ptr.empty()) return MG_OK;
-  if (M.n_rows < M.opt.winp_min_rows / 8) return MG_OK;      // small levels: launch-bound either way
-  const size_t ncls = M.h_rc_ptr.size() - 1;
-  if (ncls > (size_t)mgk::RR_NCLS || M.h_rc_off.size() > (size_t)mgk::RR_DCAP) return MG_OK;
-  const long long c1 = gc[0], c2 = gc[1], c3 = gc[2], f1 = gf[0], f2 = gf[1], f3 = gf[2];
-  if (2 * (c1 - 1) > f1 - 1 || 2 * (c2 - 1) > f2 - 1 || 2 * (c3 - 1) > f3 - 1) return MG_OK;   // every centre inside the fine grid
-  if (M.n_cols + 4 * f1 * f2 >= (1LL << 31) - 1) return MG_OK;
-  const long long FP = f1 * f2;
-  std::vector<long long> cdelta(ncls, LLONG_MIN);
-  bool ok = true;
-#pragma omp parallel for schedule(static) reduction(&& : ok)
-  for (long long Z = 0; Z < c3; ++Z) {
-    for (long long Y = 0; Y < c2 && ok; ++Y)
-      for (long long X = 0; X < c1; ++X) {
-        const long long i = (Z * c2 + Y) * c1 + X;
-        const unsigned short c = M.h_cls[(size_t)i];
-        if (M.h_rp[(size_t)i + 1] == M.h_rp[(size_t)i]) { ok = false; break; }
-        const long long centre = (2 * Z * f2 + 2 * Y) * f1 + 2 * X;
-        const long long d = (long long)M.h_ci[(size_t)M.h_rp[(size_t)i]] - centre;
-        long long seen;
-#pragma omp atomic read
-        seen = cdelta[c];
-        if (seen == LLONG_MIN) {
-#pragma omp critical
-          { if (cdelta[c] == LLONG_MIN) cdelta[c] = d; seen = cdelta[c]; }
-        }
-        if (seen != d) { ok = false; break; }
-      }
-  }
-  if (!ok) return MG_OK;
-  std::vector<int> dzv(M.h_rc_off.size()), dyv(M.h_rc_off.size()), dxv(M.h_rc_off.size());
-  int maxlen = 0;
-  for (size_t c = 0; c < ncls; ++c) {
-    if (cdelta[c] == LLONG_MIN) cdelta[c] = 0;       // (a class without rows)
-    maxlen = std::max(maxlen, M.h_rc_ptr[c + 1] - M.h_rc_ptr[c]);
-    for (int k = M.h_rc_ptr[c]; k < M.h_rc_ptr[c + 1]; ++k) {
-      const long long sh = cdelta[c] + M.h_rc_off[(size_t)k];
-      const long long dz = (sh >= 0) ? (sh + FP / 2) / FP : -((-sh + FP / 2) / FP);
-      const long long rest = sh - dz * FP;
-      const long long dy = (rest >= 0) ? (rest + f1 / 2) / f1 : -((-rest + f1 / 2) / f1);
-      const long long dx = rest - dy * f1;
-      if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) return MG_OK;
-      dzv[(size_t)k] = (int)dz; dyv[(size_t)k] = (int)dy; dxv[(size_t)k] = (int)dx;
-    }
-  }
-  // geometry
-  int dev = 0, ncu = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const size_t dict_bytes = M.h_rc_off.size() * 16 + (ncls + 1) * 4 + 16;
-  mgk::RMarchDev T{};
-  bool have = false;
-  for (long long tilesx = (c1 + 63) / 64; tilesx <= c1 && !have; ++tilesx) {
-    const long long CX = (c1 + tilesx - 1) / tilesx;
-    long long CY = std::min<long long>(mgk::RR_NT / CX, c2);
-    if (CY < 1) continue;
-    const long long tilesy = (c2 + CY - 1) / CY;
-    CY = (c2 + tilesy - 1) / tilesy;
-    const long long W = 2 * CX + 1, NPL = (W + 2) / 2, LY = 2 * CY + 1;
-    if (LY * NPL > (long long)mgk::RR_NPM * mgk::RR_NT) continue;
-    const size_t lds = (size_t)(3 * LY * 2 * NPL) * 8 + dict_bytes;
-    if (lds > 80 * 1024) continue;
-    T.CX = (int)CX; T.CY = (int)CY; T.tiles_x = (int)tilesx; T.tiles_y = (int)tilesy;
-    T.pitch = (int)(2 * NPL); T.LY = (int)LY; T.NPL = (int)NPL;
-    M.rr_lds = lds;
-    have = true;
-  }
-  if (!have) return MG_OK;
-  const long long items = (long long)T.tiles_x * T.tiles_y * c3;
-  const long long per_cu = std::max<long long>(1, std::min<long long>(3, (160 * 1024 - 1024) / (long long)M.rr_lds));
-  T.nblocks = (int)std::max<long long>(1, std::min<long long>(per_cu * ncu, items / 4));
-  if (T.nblocks < std::min<long long>(M.opt.march_min_wg, ncu)) return MG_OK;
-  std::vector<int> code(M.h_rc_off.size());
-  for (size_t k = 0; k < code.size(); ++k) code[k] = ((dyv[k] * T.pitch + dxv[k] + T.pitch + 1) << 2) | (dzv[k] + 1);
-  MG_TRY(M.rr_code.alloc(std::max<size_t>(code.size(), 1)));
-  HIP_TRY(hipMemcpy(M.rr_code.p, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
-  T.c1 = (int)c1; T.c2 = (int)c2; T.c3 = (int)c3; T.f1 = (int)f1; T.f2 = (int)f2; T.f3 = (int)f3;
-  T.n_cols = (int)M.n_cols; T.ncls = (int)ncls; T.nent = (int)M.h_rc_off.size(); T.maxlen = maxlen;
-  M.rr = T;
-  M.rr_ok = true;
-  if (M.opt.debug_format)
-    std::fprintf(stderr, "[mg] rmarch: coarse %lldx%lldx%lld <- fine %lldx%lldx%lld, tiles %dx%d of %dx%d, %d workgroups, LDS %zu B\n",
-                 c1, c2, c3, f1, f2, f3, T.tiles_x, T.tiles_y, T.CX, T.CY, T.nblocks, M.rr_lds);
-  return MG_OK;
-}
-
 // Prolongation-shaped operators (csr_rowclass_winp_spmv): rows = a fine grid gf, columns = a coarse grid gc, explicit
 // first columns.  Everything is derived from the stored pattern and checked against it: the coarse plane of each fine
 // plane's first columns (cz0), the split of every dictionary offset into plane shift (0 or 1) + in-plane rest, per chunk
@@ -3083,7 +2965,6 @@ int alloc_scratch(mg_hierarchy* h) {
       MG_TRY(build_schedule(L.P, L.grid, k));
       if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
       if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_winp(L.P, L.grid, h->lev[(size_t)l + 1].grid));
-      if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_rmarch(L.R, h->lev[(size_t)l + 1].grid, L.grid));
     }
   }
   long long nmax = 0;
@@ -4816,7 +4697,7 @@ int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which
     if (h->nrhs > 1)   // block right-hand sides: 5 csr_rowclass_lane_spmm, 6 csr_rowclass_lane_spmm2, else the CSR stream
       *kernel_variant = (M->has_rc && M->rc_lane_mm() && M->ln_blocks > 0) ? (lane_mm_pairs(*M, h->nrhs) ? 6 : 5) : -1;
     else
-      *kernel_variant = !M->has_rc ? -1 : M->rr_ok ? 7 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : M->rc_lane() ? 4 : 0;   // (7: csr_rowclass_rmarch_spmv for beta == 0, else the lane kernel)
+      *kernel_variant = !M->has_rc ? -1 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : M->rc_lane() ? 4 : 0;
   }
   if (exception_rows) *exception_rows = M->has_rc ? M->rc_nexc : 0;
   return MG_OK;
@@ -5106,7 +4987,7 @@ int mg_op_sweep_residual_dev_FP64(mg_operator* op, const double* x, const double
 int mg_op_apply_list_dev_FP64(mg_operator* op, long long list, long long kernel, const double* x, double* y, const double* b,
                               const double* d, double* y2, double* partials_dev, long long* nparts, void* stream) {
   if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
-  if ((list != 1 && list != 2) || !x || !b || (!y && !y2) || (partials_dev && !nparts)) return fail(MG_ERR_INVALID, "bad argument");
+  if ((list != 1 && list != 2) || !x || !b || (!y && !y2 && !partials_dev) || (partials_dev && !nparts)) return fail(MG_ERR_INVALID, "bad argument");
   if ((kernel == MG_K_SMOOTH || y2) && !d) return fail(MG_ERR_INVALID, "this kernel needs d");
   const Csr& M = op->M;
   const int n = list == 1 ? M.rc_nexc : M.rc_nexc2;

@@ -895,55 +895,6 @@ def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels,expect", [([32, 32, 32], 3, True), ([40, 30, 10], 2, True), ([22, 70, 12], 2, True),
-                                                 ([130, 12, 8], 2, True), ([31, 16, 12], 2, False), ([23, 23, 23], 2, False)])
-def test_restriction_with_staged_fine_slabs(mg, built, monkeypatch, cells, levels, expect):
-    """csr_rowclass_rmarch_spmv (bc = R r with the fine vector staged in LDS, a ring of three fine slabs marched along the
-    coarse z; tables derived from R's pattern at upload and verified row by row): products against scipy, bit-identical
-    to the lane kernel's (MG_NO_RMARCH=1) including the fused second output d.*bc, and the solve against the oracle.  Odd
-    cell counts (even node counts: the non-geometric variants of getFWInterp, GeometricTransferOperators.jl:35-36) do not
-    have the 2X-1..2X+1 shape everywhere and must fall back to the lane kernel."""
-    import torch
-    from multigrid_jl_amd import device as D
-    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
-    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
-    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
-    monkeypatch.setenv("MG_WINP_MIN_ROWS", "0")
-    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
-    outs = {}
-    for name, no in (("slabs", "0"), ("lane", "1")):
-        rng = np.random.default_rng(sum(cells) + 5)           # the same vectors for both runs
-        monkeypatch.setenv("MG_NO_RMARCH", no)
-        A, p, b = _setup(mg, cells, levels, maxIter=5)
-        h = mg.to_device(p)
-        var = h.operator_kernel_variant(1, D.MG_OP_R)
-        assert (var == 7) == (no == "0" and expect), var
-        res = []
-        for l in range(1, p.levels):
-            R = p.Rs[l - 1]
-            Rm = R if R.shape[1] == p.As[l - 1].shape[0] else R.T          # coarse x fine
-            xin = rng.standard_normal(Rm.shape[1])
-            y0 = rng.standard_normal(Rm.shape[0])
-            for alpha, beta in ((1.0, 0.0), (-0.75, 0.0), (1.0, 1.0)):
-                y = torch.from_numpy(y0.copy()).cuda()
-                h.spmv_dev(l, D.MG_OP_R, alpha, torch.from_numpy(xin).cuda(), beta, y)
-                want = alpha * (Rm @ xin) + beta * y0
-                got = y.cpu().numpy()
-                assert np.abs(got - want).max() / np.abs(want).max() < KERNEL_TOL
-                res.append(got)
-        x, hist = _compare_solve(mg, p, b)
-        x0 = np.random.default_rng(99).standard_normal(b.shape)
-        x1 = x0.copy()
-        mg.recursiveCycle(p, b, x1, 1)
-        outs[name] = (res, x.copy(), np.asarray(p.resvec).copy(), x1.copy())
-        mg.clear_(p)
-    for a, bb in zip(outs["slabs"][0], outs["lane"][0]):
-        assert np.array_equal(a, bb)
-    for k in (1, 2, 3):
-        assert np.array_equal(outs["slabs"][k], outs["lane"][k]), k
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("cells,levels", [([64, 64, 20], 3), ([48, 40, 20], 2), ([33, 65, 12], 2)])
 def test_plane_tiles_of_256_rows_for_small_levels(mg, built, monkeypatch, cells, levels):
     """csr_rowclass_tile_spmv<..., 256>: a level whose 1024-row tiles would be too few for the chip takes 256-row tiles
