@@ -989,8 +989,11 @@ int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::Marc
   if (a.sumsq && (size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
   const double n8 = 8.0 * (double)A.n_rows;
   {
+    // moved: no class-id stream in this form (the ids come from the product map) - the class records, the index maps, x and b
+    // in, the outputs asked for out
+    const double tables = (double)A.rc_ncls * 88.0 + 2.0 * (double)(A.rm3.n1 + A.rm3.n2 + A.rm3.nplanes + A.rm3.ntab);
     ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (a.xn && a.r ? n8 : 0.0),
-                 format_bytes(A, 1) + n8 * (2.0 + (a.t ? 1.0 : 0.0) + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
+                 tables + n8 * (2.0 + (a.t ? 1.0 : 0.0) + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
     // the combinations the cycle and the solve loop use are instantiated exactly; anything else (the test entry point) runs
     // the all-outputs kernel with the missing vectors pointed at a scratch vector of the level
     const int o = (a.r ? 1 : 0) | (a.xn ? 2 : 0) | (a.t ? 4 : 0);

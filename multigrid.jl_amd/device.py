@@ -655,6 +655,30 @@ class DeviceOperator:
                                                              int(row_offset), int(phase), _vp(stream)),
                "mg_op_apply_phase_dev")
 
+    def can_sweep_residual(self, x, d):
+        """(yes, rows of list 1, rows of list 2): can the two-stage pass serve this operator with these vectors, and how
+        many rows does it leave to ``apply_list``?"""
+        y, a, b = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        _check(self.lib, self.lib.mg_op_can_sweep_residual(self.handle, _ptr(x), _ptr(d), C.byref(y), C.byref(a), C.byref(b)),
+               "mg_op_can_sweep_residual")
+        return bool(y.value), int(a.value), int(b.value)
+
+    def sweep_residual(self, x, b, d, t=None, r=None, xn=None, partials=None, stream=0):
+        """t = x + d.*(b - M x) and r = b - M t [xn = t + d.*r, ||r||^2 partials] in one pass; returns the number of partials."""
+        n = C.c_longlong(0)
+        opt = lambda v: _ptr(v) if v is not None else None
+        _check(self.lib, self.lib.mg_op_sweep_residual_dev_FP64(self.handle, _ptr(x), _ptr(b), _ptr(d), opt(t), opt(r), opt(xn),
+                                                                opt(partials), C.byref(n), _vp(stream)), "mg_op_sweep_residual_dev")
+        return int(n.value)
+
+    def apply_list(self, which, kernel, x, y, b, d=None, y2=None, partials=None, stream=0):
+        """The rows the two-stage pass leaves out (list 1: rows without a class; list 2: rows next to them), from the CSR arrays."""
+        n = C.c_longlong(0)
+        opt = lambda v: _ptr(v) if v is not None else None
+        _check(self.lib, self.lib.mg_op_apply_list_dev_FP64(self.handle, int(which), int(kernel), _ptr(x), opt(y), _ptr(b), opt(d),
+                                                            opt(y2), opt(partials), C.byref(n), _vp(stream)), "mg_op_apply_list_dev")
+        return int(n.value)
+
     def close(self):
         if self.handle:
             self.lib.mg_op_destroy(self.handle)

@@ -850,6 +850,36 @@ def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k
 
 
 @pytest.mark.gpu
+def test_march3_serves_513_node_lines(mg, built):
+    """A 512^3-cell grid on ONE GPU has 513-node lines: the 1-D chunk form of the two-stage pass cannot stage them (its halo
+    is a whole line: LDS) and round 2 fell back to two launches of the lane kernel there.  The 2-D tile form cuts the line
+    into tiles, so the same kernel serves it - checked on a 512 x 512 x 8 slab of such a grid with DEFAULT thresholds: the
+    fused pass is selected, t and r agree with scipy and are bit-identical to the two single-stage launches."""
+    import torch
+    from multigrid_jl_amd import device as D
+    A, p, b = _setup(mg, [512, 512, 8], 5, "Jac", 0.8, 2, 1, "V", maxIter=2)      # (coarsest: 33 x 33 x 2 nodes)
+    h = mg.to_device(p)
+    form, geo = h.sweep_residual_form(1)
+    assert form == 3 and geo[0] >= 4 and geo[2] <= 160, (form, geo)         # >= 4 tiles per 513-node line
+    Al, dl = p.As[0], p.relaxPrecs[0]
+    rng = np.random.default_rng(5)
+    xn_, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+    x, bb = torch.from_numpy(xn_).cuda(), torch.from_numpy(bn).cuda()
+    t, r = torch.zeros_like(x), torch.zeros_like(x)
+    nrm = h.sweep_residual_dev(1, bb, x, t, r, None, True)
+    t_want = xn_ + dl * (bn - Al @ xn_)
+    r_want = bn - Al @ t_want
+    assert np.abs(t.cpu().numpy() - t_want).max() / np.abs(t_want).max() < KERNEL_TOL
+    assert np.abs(r.cpu().numpy() - r_want).max() / np.abs(r_want).max() < 10 * KERNEL_TOL
+    assert abs(nrm - np.linalg.norm(r_want)) < 1e-12 * np.linalg.norm(r_want)
+    t1, r1 = torch.zeros_like(x), torch.zeros_like(x)
+    h.fused_dev(1, D.MG_K_SMOOTH, bb, x, t1)
+    h.fused_dev(1, D.MG_K_RESIDUAL, bb, t1, r1)
+    assert torch.equal(t, t1) and torch.equal(r, r1)
+    mg.clear_(p)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cells,levels", [([32, 32, 32], 3), ([33, 25, 7], 2), ([40, 30, 9], 3), ([23, 23, 23], 3), ([31, 16, 12], 2),
                                           ([64, 64, 20], 3), ([70, 10, 12], 2)])
 def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, levels):
