@@ -332,8 +332,8 @@ def main():
                         "threads_per_workgroup": geo[8], "workgroups": geo[5], "lds_bytes": geo[6],
                         "schedule": (f"lockstep: {geo[9]} segments of {geo[10]} planes per tile" if geo[9] else "balanced ranges"),
                         "class_table_entries": geo[11], "estimated_fill_bytes_per_row": geo[7] / 100.0}
-        kdesc = ("fine-level damped-Jacobi sweep t = x + d.*(b - A x) AND the residual r = b - A t (with ||r||^2 and the "
-                 "next cycle's first update in the solve loop) in one pass, level 1")
+        kdesc = ("fine-level damped-Jacobi sweep t = x + d.*(b - A x) AND the residual r = b - A t in one pass, level 1: the "
+                 "last pre-smoothing sweep with the residual the restriction needs (x, b in; t, r out)")
     ms_s, cnt_s, bts_s = prof[dom]
     avg_s = ms_s / cnt_s
     mv_s = moved[dom]
@@ -376,6 +376,15 @@ def main():
                 "kernels": kern_table}
     if tile_geo:
         roofline["inplane_tiles"] = tile_geo
+    if (1, "smooth+residual+norm") in prof:
+        # the same kernel as the solve loop runs it: last post-smoothing sweep + the residual of the stopping test; x and b
+        # in, t + d.*r (the next cycle's first update) and ||r||^2 partials out - the iterate itself is a dead store unless
+        # the loop stops (26 B/row instead of 34)
+        ms2, cnt2, _ = prof[(1, "smooth+residual+norm")]
+        mv2 = moved[(1, "smooth+residual+norm")]
+        roofline["solve_loop_variant"] = {"avg_launch_ms": round(ms2 / cnt2, 5), "launches": cnt2, "bytes_per_launch": mv2,
+                                          "achieved": round(mv2 / (ms2 / cnt2) / 1e6, 1),
+                                          "frac": round(mv2 / (ms2 / cnt2) / 1e6 / HBM_PEAK_GBS, 4)}
     if dom[1] == "smooth+residual":
         # Temporal blocking lowers the COMPULSORY bytes (34 B/row instead of 2 x 26 for the two launches it replaces), so
         # its fraction of the peak is not comparable with a single-stage kernel's: report, next to it, (a) the same time

@@ -60,7 +60,8 @@ typedef struct mg_hierarchy mg_hierarchy;
 #define MG_K_NORM 7     /* ||r||^2                         (SolveFuncs.jl:30)          */
 #define MG_K_SMOOTH_PROLONG 8 /* x' = xp + d.*(b - A*xp), xp = x + P*xc: MGcycle.jl:90 fused into the first post-sweep */
 #define MG_K_SMOOTH_RESIDUAL 9 /* t = x + d.*(b - A*x) and r = b - A*t in one pass (MGcycle.jl:129-131 + 58-60 / SolveFuncs.jl:26-27) */
-#define MG_K_COUNT 10
+#define MG_K_SMOOTH_RESIDUAL_NORM 10 /* the same pass in the solve loop: last post-smoothing sweep + the stopping test's residual: ||r||^2 and t + d.*r out (SolveFuncs.jl:26-30); profile slot only */
+#define MG_K_COUNT 11
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 

@@ -992,7 +992,7 @@ int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::Marc
     // moved: no class-id stream in this form (the ids come from the product map) - the class records, the index maps, x and b
     // in, the outputs asked for out
     const double tables = (double)A.rc_ncls * 88.0 + 2.0 * (double)(A.rm3.n1 + A.rm3.n2 + A.rm3.nplanes + A.rm3.ntab);
-    ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (a.xn && a.r ? n8 : 0.0),
+    ProfScope ps(h, level, a.sumsq ? MG_K_SMOOTH_RESIDUAL_NORM : MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (a.xn && a.r ? n8 : 0.0),
                  tables + n8 * (2.0 + (a.t ? 1.0 : 0.0) + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
     // the combinations the cycle and the solve loop use are instantiated exactly; anything else (the test entry point) runs
     // the all-outputs kernel with the missing vectors pointed at a scratch vector of the level
@@ -1038,7 +1038,7 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
   const double n8 = 8.0 * (double)A.n_rows;
   {
     // algorithmic: the two products; moved: class ids + x + b in, t and r (and/or xn) out
-    ProfScope ps(h, level, MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (xn && r ? n8 : 0.0),
+    ProfScope ps(h, level, want_sumsq ? MG_K_SMOOTH_RESIDUAL_NORM : MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (xn && r ? n8 : 0.0),
                  format_bytes(A, 1) + n8 * (2.0 + (t ? 1.0 : 0.0) + (r ? 1.0 : 0.0) + (xn ? 1.0 : 0.0)));
     if (from_zero) hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<true>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
     else hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<false>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);

@@ -24,8 +24,9 @@ LIB_PATH = os.environ.get("MGVCYCLE_LIB") or os.path.join(_HERE, "csrc", "libmgv
 
 MG_OP_A, MG_OP_P, MG_OP_R = 0, 1, 2
 (MG_K_SPMV, MG_K_RESIDUAL, MG_K_SMOOTH, MG_K_RESTRICT, MG_K_PROLONG, MG_K_DSCALE, MG_K_COARSE,
- MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_COUNT) = range(11)
-KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm", "smooth+prolong", "smooth+residual"]
+ MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_SMOOTH_RESIDUAL_NORM, MG_K_COUNT) = range(12)
+KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm", "smooth+prolong", "smooth+residual",
+                "smooth+residual+norm"]
 
 _ll = C.c_longlong
 _dp = C.POINTER(C.c_double)
