@@ -1961,41 +1961,14 @@ struct March3Dev {
                                 // row (x, y, z) is left out where sx[x] | sy[y] | sz[z] (a neighbour is such a row)
 };
 
-// The restriction bc = R r (MGcycle.jl:66) fused behind stage 2 (lockstep schedule only): r of the core tile also goes into a
-// ring of three slabs in LDS, and every coarse node whose fine neighbourhood (2X+-1, 2Y+-1, 2Z+-1, as far as it exists)
-// lies inside the tile's core and the segment's planes is computed from that ring by the lane that owns its centre - the
-// dictionary walk of R's class in stored order, as the lane kernel does it.  The other coarse nodes (those next to a tile or
-// segment boundary: m3_restrict_inside() false) are computed from r in memory by csr_rows_spmv on a list the host builds
-// with the same predicate.  R's class ids come from a verified product map, like A's.
-struct M3Restrict {
-  const MarchEnt* ent;          // R's dictionary: value, code = ((dy*pitch + dx + pitch + 1) << 2) | (dz + 1)   [nent]
-  const int* ptr;               // [ncls + 1]
-  const unsigned short* cmap;   // cx[c1] | cy[c2] | cz[c3] | tab[ncz*ncy*ncx]
-  int ncx, ncy, ntab, ncls, nent, maxlen;
-  int c1, c2, c3;               // coarse grid
-  double alpha;
-  double* bc;                   // out [c1*c2*c3]
-  const double* d2;             // optional: the coarse level's relaxPrec ...
-  double* y2;                   // ... and d2.*bc, its first update (MGcycle.jl:134 with r = b)
-};
-// Is coarse node (X, Y, Z) computed inside the marching pass?  (gx, gy, gz) = (2X, 2Y, 2Z) its centre; the tile owns fine
-// columns [x0, x0 + TX) and lines [y0, y0 + TY), the segment fine planes [zs, ze); n1, n2, n3 the fine grid.
-__host__ __device__ inline bool m3_restrict_inside(int gx, int gy, int gz, int x0, int y0, int TX, int TY, int zs, int ze, int n1, int n2,
-                                                   int n3) {
-  const bool xin = gx >= x0 && gx < x0 + TX && (gx - 1 >= x0 || gx == 0) && (gx + 1 < x0 + TX || gx == n1 - 1);
-  const bool yin = gy >= y0 && gy < y0 + TY && (gy - 1 >= y0 || gy == 0) && (gy + 1 < y0 + TY || gy == n2 - 1);
-  const bool zin = gz >= zs && gz < ze && (gz - 1 >= zs || gz == 0) && (gz + 1 < ze || gz == n3 - 1);
-  return xin && yin && zin;
-}
-
 #ifndef MG_M3_PD
 #define MG_M3_PD 1    // x planes in flight in registers (1 or 2)
 #endif
 #ifndef MG_M3_EXP
 #define MG_M3_EXP 0   // attribution builds (make variant): 1 no class walks, 2 no slab/operand loads, 3 no stores
 #endif
-template <bool ZERO, int OUT, int NT, int K1, int NPM, bool RES>
-__global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, March2Args a, March3Dev T, M3Restrict Q) {
+template <bool ZERO, int OUT, int NT, int K1, int NPM>
+__global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, March2Args a, March3Dev T) {
   extern __shared__ double win[];
   __shared__ double red[NT / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -2014,22 +1987,6 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   unsigned short* sxL = tabL + T.ntab;          // (has_exc only)
   unsigned short* syL = sxL + T.n1;
   unsigned short* szL = syL + T.n2;
-  // RES: ring of three r slabs (t-slab geometry), R's dictionary and class maps - behind everything else
-  const int nmapA = (T.n1 + T.n2 + T.nplanes) * (T.has_exc ? 2 : 1) + T.ntab;
-  double* rw = reinterpret_cast<double*>(reinterpret_cast<char*>(win) +
-                                         (((reinterpret_cast<char*>(cxL + nmapA) - reinterpret_cast<char*>(win)) + 15) & ~15));   // [3][TS], 16-byte aligned
-  MarchEnt* rent = reinterpret_cast<MarchEnt*>(rw + 3 * TS);                  // [Q.nent]
-  int* rptr = reinterpret_cast<int*>(rent + (RES ? Q.nent : 0));              // [Q.ncls + 1] (+ pad to even)
-  unsigned short* rcxL = reinterpret_cast<unsigned short*>(rptr + (RES ? ((Q.ncls + 2) & ~1) : 0));   // cx | cy | cz | tab of R
-  unsigned short* rcyL = rcxL + (RES ? Q.c1 : 0);
-  unsigned short* rczL = rcyL + (RES ? Q.c2 : 0);
-  unsigned short* rtabL = rczL + (RES ? Q.c3 : 0);
-  if (RES) {
-    for (int i = tid; i < Q.nent; i += NT) rent[i] = Q.ent[i];
-    for (int i = tid; i <= Q.ncls; i += NT) rptr[i] = Q.ptr[i];
-    const int nm = Q.c1 + Q.c2 + Q.c3 + Q.ntab;
-    for (int i = tid; i < nm; i += NT) rcxL[i] = Q.cmap[i];
-  }
   {
     const int nw = T.ncls * (int)(sizeof(M3Class) / 8);
     const double* srcd = reinterpret_cast<const double*>(T.cls);
@@ -2142,59 +2099,6 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       rp[s] = l1 ? (int)cyL[gy] * T.ncx + cxo : 0;
       if (T.has_exc && l1 && (sxL[gx] | syL[gy])) skip2 |= 1u << s;
     }
-    // RES: the slots whose row is the centre of a coarse node this tile computes (in-plane part of m3_restrict_inside)
-    unsigned rmask = 0u;
-    int crp[K1];                                        // cy*ncx + cx of that coarse node in R's class table
-    int cip0 = 0;                                       // coarse in-plane index of slot 0's node; slot s: + s*(SY/2)*c1 (SY even: host)
-    if (RES) {
-#pragma unroll
-      for (int s = 0; s < K1; ++s) {
-        const int yy = j + s * T.SY, gy = y0 - 1 + yy;
-        crp[s] = 0;
-        if (((core >> s) & 1u) && !(gx & 1) && !(gy & 1) &&
-            m3_restrict_inside(gx, gy, 0, x0, y0, T.TX, T.TY, 0, 1, T.n1, T.n2, 1) && (gx >> 1) < Q.c1 && (gy >> 1) < Q.c2) {
-          rmask |= 1u << s;
-          crp[s] = (int)rcyL[gy >> 1] * Q.ncx + (int)rcxL[gx >> 1];
-        }
-      }
-      cip0 = ((y0 - 1 + j) >> 1) * Q.c1 + (gx >> 1);    // (used only for slots in rmask: even gy, even gx)
-    }
-    const int rzstride = RES ? Q.ncy * Q.ncx : 0;
-    // coarse plane Z whose top fine plane (2Z+1, or 2Z when that is the last plane) is zr: the rows in rmask walk R's class
-#define M3_RESTRICT(zr)                                                                                                \
-  do {                                                                                                                 \
-    const int Z_ = (zr) >> 1;                                                                                          \
-    const int zb_ = (int)rczL[Z_] * rzstride;                                                                          \
-    const int bm_ = ((2 * Z_ + 2) % 3) * TS, bz_ = ((2 * Z_) % 3) * TS, bp_ = ((2 * Z_ + 1) % 3) * TS;                 \
-    _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
-      if ((rmask >> s_) & 1u) {                                                                                        \
-        const int cq_ = (int)rtabL[zb_ + crp[s_]];                                                                     \
-        const int s0_ = rptr[cq_], len_ = rptr[cq_ + 1] - s0_;                                                         \
-        const int own_ = (own8 + s_ * sstride8 + tdelta8) / 8 - (pitch + 1);                                           \
-        double acc_ = 0.0;                                                                                             \
-        for (int k_ = 0; k_ < Q.maxlen; k_ += 4) {                                                                     \
-          MarchEnt e_[4];                                                                                              \
-          double xv_[4];                                                                                               \
-          _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) e_[u_] = rent[s0_ + min(k_ + u_, len_ > 0 ? len_ - 1 : 0)]; \
-          _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                           \
-            const int dz1_ = e_[u_].code & 3;                                                                          \
-            xv_[u_] = rw[(dz1_ == 0 ? bm_ : (dz1_ == 1 ? bz_ : bp_)) + own_ + (e_[u_].code >> 2)];                     \
-          }                                                                                                            \
-          _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                           \
-            const double t_ = acc_ + e_[u_].val * xv_[u_];                                                             \
-            acc_ = (k_ + u_ < len_) ? t_ : acc_;                                                                       \
-          }                                                                                                            \
-        }                                                                                                              \
-        const int crow_ = Z_ * Q.c1 * Q.c2 + ((y0 - 1 + j + s_ * T.SY) >> 1) * Q.c1 + (gx >> 1);                       \
-        const double out_ = Q.alpha * acc_ + 0.0;                                                                      \
-        Q.bc[crow_] = out_;                                                                                            \
-        if (Q.y2) Q.y2[crow_] = Q.d2[crow_] * out_;                                                                    \
-      }                                                                                                                \
-    }                                                                                                                  \
-  } while (0)
-    // does the run [z0, z1) compute the coarse plane whose top fine plane is zr?  (the z part of m3_restrict_inside)
-#define M3_RESTRICT_PLANE(zr) ((zr) >= z0 && (zr) < z1 && (((zr) & 1) || (zr) == T.nplanes - 1) &&                       \
-                               m3_restrict_inside(0, 0, ((zr) >> 1) << 1, 0, 0, 1, 1, z0, z1, 1, 1, T.nplanes))
 #define M3_PAR(p, m) ((int)(((long long)(p) * T.P + pg[m]) & 1LL))
 #define M3_LOADPAIR(dst, p, m)                                                                                         \
   do {                                                                                                                 \
@@ -2335,12 +2239,6 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
         for (int m = 0; m < NPM; ++m) M3_LOADPAIR(pre[m], z + 3, m);
       }
       if (z + 1 <= z1) M3_OPERANDS(z + 1);
-      // ---- RES: the coarse plane whose last fine plane of r (z-2) was written before the last barrier; then a barrier of its own:
-      // stage 2 below overwrites the oldest r slab ---------------------------------------------------------------------------
-      if (RES && M3_RESTRICT_PLANE(z - 2)) {            // (uniform)
-        M3_RESTRICT(z - 2);
-        __syncthreads();
-      }
       // ---- stage 1 on plane z: t = x + d.*(b - A x) on every live row of the lane ----------------------------------------
       const bool s1 = z >= 0 && z < T.nplanes;          // (uniform)
       const int zb0 = s1 ? (int)czL[z] * zstride : 0;   // class table rows of planes z and z-1
@@ -2381,7 +2279,6 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
             double acc = 0.0;
             M3_WALK(acc, t2[s], tc[s], tw, ((z - 1) & 1) * TS * 8 + o8);
             const double rr = b1[s] - acc;
-            if (RES) *reinterpret_cast<double*>(reinterpret_cast<char*>(rw) + (((z - 1) % 3) * TS * 8 + o8)) = rr;
             st_r[s] = rr;
             st_x[s] = t1[s] + dd[cq] * rr;
             sq += rr * rr;
@@ -2420,9 +2317,6 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       qz = q1;
       __syncthreads();
     }
-    if (RES && M3_RESTRICT_PLANE(z1 - 1)) M3_RESTRICT(z1 - 1);   // (the run's last plane of r: written before the loop's last barrier)
-#undef M3_RESTRICT
-#undef M3_RESTRICT_PLANE
   }
   if (a.sumsq) {
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -2473,7 +2367,6 @@ __global__ __launch_bounds__(BLK) void csr_rows_spmv(CsrDev A, const int* __rest
     outv = epilogue<MODE>(v, row, acc, pb, pd, px);
     if (MODE != RESID || v.y) v.y[row] = outv;
     if (MODE == RESID && v.y2) v.y2[row] = px + pd * outv;   // x + d.*r: the next cycle's first damped-Jacobi update
-    if (MODE == AXPBY && v.y2) v.y2[row] = v.d_full[row] * outv;   // d.*(R r): the coarse level's first update (as the lane kernel)
   }
   if (v.sumsq) {
     double sq = outv * outv;

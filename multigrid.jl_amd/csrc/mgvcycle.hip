@@ -70,7 +70,6 @@ struct Options {
   long long march3_nt = 0;         // threads per workgroup (0: by the fill estimate; 1024 or 768)
   long long march3_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
   bool no_march3_lockstep = false, march3_lockstep_force = false;   // schedule of the 2-D tile form
-  bool no_march3_restrict = false;   // never fuse the restriction behind stage 2 of the 2-D tile form
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -100,7 +99,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
-      MG_OPT("MG_NO_MARCH3_RESTRICT", "no_march3_restrict", 0, no_march3_restrict), MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
+      MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
       MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
@@ -215,15 +214,6 @@ struct Csr {
   bool rc_march3 = false;   // ... and so can csr_rowclass_march3_spmv (2-D in-plane tiles, z-star classes): preferred
   DevBuf<int> rc_exc2;      // box operators on the 2-D tile form: rows whose stage 2 is left to csr_rows_spmv (the layer behind the faces)
   int rc_nexc2 = 0;
-  // the restriction fused behind stage 2 of the 2-D tile form (this A's level, its R): R's dictionary with slab offsets, R's
-  // class map, the coarse rows left to csr_rows_spmv (those next to a tile or segment boundary)
-  bool rm3r_ok = false;
-  DevBuf<mgk::MarchEnt> rm3r_ent;
-  DevBuf<int> rm3r_ptr, rm3r_list;
-  DevBuf<unsigned short> rm3r_cmap;
-  int rm3r_nlist = 0;
-  mgk::M3Restrict rm3r{};
-  size_t rm3r_lds = 0;      // dynamic LDS of the launch with the restriction fused
   DevBuf<mgk::M3Class> rm3_cls;
   DevBuf<unsigned short> rm3_cmap;   // cx | cy | cz | tab: class id = tab[cz[z]][cy[y]][cx[x]]
   mgk::March3Dev rm3{};     // tile geometry
@@ -382,11 +372,6 @@ struct Csr {
     rc_march = false;
     rc_march2 = false;
     rc_march3 = false;
-    rm3r_ok = false;
-    rm3r_ent.release();
-    rm3r_ptr.release();
-    rm3r_list.release();
-    rm3r_cmap.release();
     rm3_cls.release();
     rm3_cmap.release();
     rc_exc2.release();
@@ -960,33 +945,28 @@ bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* 
   return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
 // the 2-D tile form (csr_rowclass_march3_spmv): template arguments from what is wanted
-template <bool ZERO, int OUT, int NT, int K1, bool RES>
-int launch_march3(hipStream_t stream, const Csr& A, const mgk::March2Args& a, const mgk::M3Restrict& q) {
-  auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, NT, K1, RM3_NPM, RES>;
+template <bool ZERO, int OUT, int NT, int K1>
+int launch_march3(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
+  auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, NT, K1, RM3_NPM>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm3.nblocks), dim3(NT), RES ? A.rm3r_lds : A.rm3_lds, stream, A.rcdev(), a, A.rm3, q);
+  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm3.nblocks), dim3(NT), A.rm3_lds, stream, A.rcdev(), a, A.rm3);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
-template <bool ZERO, int OUT, bool RES = false>
-int launch_march3_k(hipStream_t stream, const Csr& A, const mgk::March2Args& a, const mgk::M3Restrict& q = mgk::M3Restrict{}) {
-  if (A.rm3_nt == 768) return A.rm3_k1 == 3 ? launch_march3<ZERO, OUT, 768, 3, RES>(stream, A, a, q) : launch_march3<ZERO, OUT, 768, 4, RES>(stream, A, a, q);
-  return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 1024, 2, RES>(stream, A, a, q) : launch_march3<ZERO, OUT, 1024, 3, RES>(stream, A, a, q);
+template <bool ZERO, int OUT>
+int launch_march3_k(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
+  if (A.rm3_nt == 768) return A.rm3_k1 == 3 ? launch_march3<ZERO, OUT, 768, 3>(stream, A, a) : launch_march3<ZERO, OUT, 768, 4>(stream, A, a);
+  return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 1024, 2>(stream, A, a) : launch_march3<ZERO, OUT, 1024, 3>(stream, A, a);
 }
 // dispatch on (from_zero, outputs); `scratch` (n_rows doubles, may be null when t and one of r / xn are given in one of the
 // instantiated combinations) takes the outputs nobody asked for
-int launch_march3_any(hipStream_t stream, const Csr& A, mgk::March2Args a, bool from_zero, double* scratch,
-                      const mgk::M3Restrict* q = nullptr) {
+int launch_march3_any(hipStream_t stream, const Csr& A, mgk::March2Args a, bool from_zero, double* scratch) {
   int o = (a.r ? 1 : 0) | (a.xn ? 2 : 0) | (a.t ? 4 : 0);
-  if (q) {   // the cycle's pair (t, r out) with the restriction fused behind stage 2
-    if (o != 5 || !A.rm3r_ok) return fail(MG_ERR_STATE, "the fused restriction needs the (t, r) form of the pass");
-    return from_zero ? launch_march3_k<true, 5, true>(stream, A, a, *q) : launch_march3_k<false, 5, true>(stream, A, a, *q);
-  }
   if (!(o == 5 || o == 2 || o == 6 || o == 7)) {   // (t, r) cycle; (xn) solve loop, iterate dead; (t, xn) its last step; all
     if (!scratch) return fail(MG_ERR_STATE, "this combination of outputs needs a scratch vector");
     if (!a.t) a.t = scratch;      // (one scratch vector takes every output nobody asked for: written, never read)
@@ -997,8 +977,7 @@ int launch_march3_any(hipStream_t stream, const Csr& A, mgk::March2Args a, bool 
   if (from_zero) return o == 5 ? launch_march3_k<true, 5>(stream, A, a) : o == 2 ? launch_march3_k<true, 2>(stream, A, a) : o == 6 ? launch_march3_k<true, 6>(stream, A, a) : launch_march3_k<true, 7>(stream, A, a);
   return o == 5 ? launch_march3_k<false, 5>(stream, A, a) : o == 2 ? launch_march3_k<false, 2>(stream, A, a) : o == 6 ? launch_march3_k<false, 6>(stream, A, a) : launch_march3_k<false, 7>(stream, A, a);
 }
-int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::March2Args& a_in, bool from_zero,
-                       const mgk::M3Restrict* q = nullptr) {
+int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::March2Args& a_in, bool from_zero) {
   mgk::March2Args a = a_in;
   const int nb1 = A.rm3.nblocks;
   {
@@ -1024,7 +1003,7 @@ int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::Marc
       if (L.x3.n != (size_t)A.n_rows) MG_TRY(L.x3.alloc((size_t)A.n_rows));
       scratch = L.x3.p;
     }
-    MG_TRY(launch_march3_any(h->stream, A, a, from_zero, scratch, q));
+    MG_TRY(launch_march3_any(h->stream, A, a, from_zero, scratch));
   }
   if (a.sumsq) {
     ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
@@ -1034,10 +1013,8 @@ int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::Marc
   return MG_OK;
 }
 // from_zero: the sweep's input is x1 = d.*b (the level is entered with x = 0): x is not read, no dscale launch is needed
-// q (optional): also bc = R r (MGcycle.jl:66), fused behind stage 2 for the coarse nodes inside a tile and a segment
-// (Csr::rm3r_ok); the caller computes the rest with k_restrict_list.
 int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double* x, double* t, double* r, double* xn,
-                      bool want_sumsq, bool from_zero = false, const mgk::M3Restrict* q = nullptr) {
+                      bool want_sumsq, bool from_zero = false) {
   const Csr& A = h->lev[(size_t)level].A;
   mgk::March2Args a{};
   a.x = x;
@@ -1046,8 +1023,7 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
   a.r = r;
   a.xn = xn;
   a.sumsq = want_sumsq ? h->partial.p : nullptr;
-  if (A.rc_march3) return k_smooth_residual3(h, level, A, a, from_zero, q);
-  if (q) return fail(MG_ERR_STATE, "the fused restriction needs the 2-D tile form");
+  if (A.rc_march3) return k_smooth_residual3(h, level, A, a, from_zero);
   mgk::MarchDev T = A.marchdev();
   T.nblocks = A.rm2_nblocks;
   if (want_sumsq && (size_t)T.nblocks > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
@@ -1347,28 +1323,6 @@ int fgmres_relax(mg_hierarchy* h, int lv, const double* r0, double* x0, long lon
 // SolveFuncs.jl:26-30, and recursiveCycle would recompute the same values, MGcycle.jl:26-31).
 // x1_ready (with r_valid): xb already holds xa + d.*r, the first pre-smoothing update (written by the residual kernel
 // of the previous solve step, k_residual_sumsq's xnext).
-// bc = R r on the coarse rows the fused pass left out (next to a tile or segment boundary), from r in memory
-int k_restrict_list(mg_hierarchy* h, int level, const Csr& A, const Csr& R, const double* r, double* bc, const double* d2, double* y2) {
-  const int n = A.rm3r_nlist;
-  if (n <= 0) return MG_OK;
-  mgk::VecArgs v{};
-  v.x = r;
-  v.y = bc;
-  v.alpha = 1.0;
-  v.beta = 0.0;
-  v.nrhs = 1;
-  v.d_full = d2;
-  v.y2 = y2;
-  // moved: the listed rows' entries of r (a cold read: written by the pass before), their class-free CSR rows, bc [and d2, y2]
-  const double nnz_rows = (double)n * (double)R.nnz / (double)std::max<long long>(1, R.n_rows);
-  const double bytes = 12.0 * nnz_rows + 8.0 * nnz_rows / 3.0 + (double)n * (12.0 + (y2 ? 16.0 : 0.0));
-  ProfScope ps(h, level, MG_K_RESTRICT, bytes, bytes);
-  hipLaunchKernelGGL((mgk::csr_rows_spmv<mgk::AXPBY>), dim3((unsigned)((n + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, h->stream, R.dev(),
-                     A.rm3r_list.p, n, v, 0);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-
 int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
               bool x1_given = false);
 // x1_given (with x_zero): xa already holds d.*b, the first update from x = 0 (written by the restriction that produced b).
@@ -1422,26 +1376,15 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     std::swap(cur, alt);
   }
   // r = b - A x ; bc = R r ; xc = 0 (MGcycle.jl:58-66)
-  // ... and bc = R r behind it where the level's A and R allow (most coarse nodes from r in LDS; the rest from a list)
-  const bool fuse_res = fuse_pre && L.A.rc_march3 && L.A.rm3r_ok && !h->opt.no_march3_restrict;
-  // the restriction also writes the coarse level's first update x = d.*bc where its kernel can (no dscale launch there)
-  const bool give_x1 = h->relax_type == 0 && !(ctype == 'K') && l + 1 < nl - 1 && C.relax_set && (restrict_can_scale(h, L.R) || fuse_res);
   if (fuse_pre) {
-    mgk::M3Restrict q = L.A.rm3r;
-    q.alpha = 1.0;
-    q.bc = C.b.p;
-    q.d2 = give_x1 ? C.d.p : nullptr;
-    q.y2 = give_x1 ? C.x0.p : nullptr;
-    MG_TRY(k_smooth_residual(h, l, b, cur, alt, L.r.p, nullptr, false, from_zero, fuse_res ? &q : nullptr));
+    MG_TRY(k_smooth_residual(h, l, b, cur, alt, L.r.p, nullptr, false, from_zero));
     std::swap(cur, alt);
   } else {
     MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
   }
-  if (fuse_res) {
-    MG_TRY(k_restrict_list(h, l, L.A, L.R, L.r.p, C.b.p, give_x1 ? C.d.p : nullptr, give_x1 ? C.x0.p : nullptr));
-  } else {
-    MG_TRY(k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, C.b.p, give_x1 ? C.d.p : nullptr, give_x1 ? C.x0.p : nullptr));
-  }
+  // the restriction also writes the coarse level's first update x = d.*bc where its kernel can (no dscale launch there)
+  const bool give_x1 = h->relax_type == 0 && !(ctype == 'K') && l + 1 < nl - 1 && C.relax_set && restrict_can_scale(h, L.R);
+  MG_TRY(k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, C.b.p, give_x1 ? C.d.p : nullptr, give_x1 ? C.x0.p : nullptr));
   double* xc = nullptr;
   if (ctype == 'K' && l + 1 < nl - 1) {
     // K-cycle (MGcycle.jl:72-76): 2 steps of FGMRES on A_{l+1} xc = bc, preconditioned by the K-cycle of level l+1
@@ -2610,60 +2553,6 @@ int build_staged(Csr& A, const long long grid[3]) {
 // cache lines at both ends of a tile's line segments), within the LDS (3 x slabs + 2 t slabs + tables <= 160 KB) and the
 // 16-byte pairs a lane can load per slab.  Schedule: lockstep (tiles x segments of planes = about one workgroup per CU, all
 // tiles of a segment on one XCD) when that keeps >= 85 % of the balanced schedule's parallel efficiency.
-// Do the class ids of an n1 x n2 x n3 grid of rows (x fastest) factor as cls(x, y, z) = tab[cz[z]][cy[y]][cx[x]]?  Index maps
-// from hashes of the three families of grid slices (equal slices = same index), the table from one representative of every
-// index triple, then the EXACT check over all rows.  True for every grid operator: the class says which neighbours exist.
-bool factor_class_ids(const unsigned short* cl, long long n1, long long n2, long long n3, long long max_tab, std::vector<unsigned short>& cx,
-                      std::vector<unsigned short>& cy, std::vector<unsigned short>& cz, std::vector<unsigned short>& tab) {
-  std::vector<unsigned long long> hx((size_t)n1, 0), hy((size_t)n2, 0), hz((size_t)n3, 0);
-  auto mix = [](unsigned long long v) {
-    v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
-    return v;
-  };
-  for (long long z = 0; z < n3; ++z)
-    for (long long y = 0; y < n2; ++y) {
-      const unsigned short* line = cl + (z * n2 + y) * n1;
-      unsigned long long hl = 0;
-      for (long long x = 0; x < n1; ++x) {
-        const unsigned long long v = (unsigned long long)line[x] + 1;
-        hx[(size_t)x] += mix(v * 0x9E3779B97F4A7C15ULL + (unsigned long long)(z * n2 + y));
-        hl += mix(v * 0xD6E8FEB86659FD93ULL + (unsigned long long)x);
-      }
-      hy[(size_t)y] += mix(hl + (unsigned long long)z * 0x9E3779B97F4A7C15ULL);
-      hz[(size_t)z] += mix(hl + (unsigned long long)y * 0xC2B2AE3D27D4EB4FULL);
-    }
-  auto index_of = [](const std::vector<unsigned long long>& hv, std::vector<unsigned short>& idx, std::vector<long long>& rep) {
-    std::unordered_map<unsigned long long, int> seen;
-    idx.resize(hv.size());
-    for (size_t i = 0; i < hv.size(); ++i) {
-      auto itf = seen.find(hv[i]);
-      if (itf == seen.end()) {
-        itf = seen.emplace(hv[i], (int)rep.size()).first;
-        rep.push_back((long long)i);
-      }
-      idx[i] = (unsigned short)itf->second;
-    }
-  };
-  std::vector<long long> rx, ry, rz;
-  index_of(hx, cx, rx);
-  index_of(hy, cy, ry);
-  index_of(hz, cz, rz);
-  const size_t ncx = rx.size(), ncy = ry.size(), ncz = rz.size();
-  if ((long long)(ncx * ncy * ncz) > max_tab) return false;
-  tab.assign(ncx * ncy * ncz, 0);
-  for (size_t iz = 0; iz < ncz; ++iz)
-    for (size_t iy = 0; iy < ncy; ++iy)
-      for (size_t ix = 0; ix < ncx; ++ix) tab[(iz * ncy + iy) * ncx + ix] = cl[(rz[iz] * n2 + ry[iy]) * n1 + rx[ix]];
-  for (long long z = 0; z < n3; ++z)
-    for (long long y = 0; y < n2; ++y) {
-      const unsigned short* line = cl + (z * n2 + y) * n1;
-      const unsigned short* trow = tab.data() + ((size_t)cz[(size_t)z] * ncy + cy[(size_t)y]) * ncx;
-      for (long long x = 0; x < n1; ++x)
-        if (line[x] != trow[cx[(size_t)x]]) return false;
-    }
-  return true;
-}
-
 int build_march3(Csr& A, const long long grid[3]) {
   A.rc_march3 = false;
   if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march3 || A.opt.no_march2 || A.opt.no_march) return MG_OK;
@@ -2702,15 +2591,62 @@ int build_march3(Csr& A, const long long grid[3]) {
     }
   }
   // ---- class ids as a product of three index maps --------------------------------------------------------------------------
+  // hash of every x-slice / y-slice / z-slice of the class array; equal hashes = same index; then the exact check
   std::vector<unsigned short> cmap;
   int ncx = 0, ncy = 0, ncz = 0;
   {
     const unsigned short* cl = A.h_cls.data();
-    std::vector<unsigned short> cx, cy, cz, tab;
-    if (!factor_class_ids(cl, n1, n2, n3, mgk::RM3_TAB, cx, cy, cz, tab)) return MG_OK;   // not a product of coordinate classes: the 1-D chunk form serves the level
-    ncx = (int)(*std::max_element(cx.begin(), cx.end())) + 1;
-    ncy = (int)(*std::max_element(cy.begin(), cy.end())) + 1;
-    ncz = (int)(*std::max_element(cz.begin(), cz.end())) + 1;
+    std::vector<unsigned long long> hx((size_t)n1, 0), hy((size_t)n2, 0), hz((size_t)n3, 0);
+    auto mix = [](unsigned long long v) {
+      v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
+      return v;
+    };
+    for (long long z = 0; z < n3; ++z)
+      for (long long y = 0; y < n2; ++y) {
+        const unsigned short* line = cl + (z * n2 + y) * n1;
+        unsigned long long hl = 0;
+        for (long long x = 0; x < n1; ++x) {
+          const unsigned long long v = (unsigned long long)line[x] + 1;
+          hx[(size_t)x] += mix(v * 0x9E3779B97F4A7C15ULL + (unsigned long long)(z * n2 + y));
+          hl += mix(v * 0xD6E8FEB86659FD93ULL + (unsigned long long)x);
+        }
+        hy[(size_t)y] += mix(hl + (unsigned long long)z * 0x9E3779B97F4A7C15ULL);
+        hz[(size_t)z] += mix(hl + (unsigned long long)y * 0xC2B2AE3D27D4EB4FULL);
+      }
+    auto index_of = [](const std::vector<unsigned long long>& hv, std::vector<unsigned short>& idx, std::vector<long long>& rep) {
+      std::unordered_map<unsigned long long, int> seen;
+      idx.resize(hv.size());
+      for (size_t i = 0; i < hv.size(); ++i) {
+        auto itf = seen.find(hv[i]);
+        if (itf == seen.end()) {
+          itf = seen.emplace(hv[i], (int)rep.size()).first;
+          rep.push_back((long long)i);
+        }
+        idx[i] = (unsigned short)itf->second;
+      }
+    };
+    std::vector<unsigned short> cx, cy, cz;
+    std::vector<long long> rx, ry, rz;
+    index_of(hx, cx, rx);
+    index_of(hy, cy, ry);
+    index_of(hz, cz, rz);
+    ncx = (int)rx.size(); ncy = (int)ry.size(); ncz = (int)rz.size();
+    if ((long long)ncx * ncy * ncz > mgk::RM3_TAB) return MG_OK;
+    std::vector<unsigned short> tab((size_t)ncx * ncy * ncz);
+    for (int iz = 0; iz < ncz; ++iz)
+      for (int iy = 0; iy < ncy; ++iy)
+        for (int ix = 0; ix < ncx; ++ix) tab[((size_t)iz * ncy + iy) * ncx + ix] = cl[(rz[(size_t)iz] * n2 + ry[(size_t)iy]) * n1 + rx[(size_t)ix]];
+    bool okmap = true;
+#pragma omp parallel for schedule(static) reduction(&& : okmap)
+    for (long long z = 0; z < n3; ++z) {
+      for (long long y = 0; y < n2 && okmap; ++y) {
+        const unsigned short* line = cl + (z * n2 + y) * n1;
+        const unsigned short* trow = tab.data() + ((size_t)cz[(size_t)z] * ncy + cy[(size_t)y]) * ncx;
+        for (long long x = 0; x < n1; ++x)
+          if (line[x] != trow[cx[(size_t)x]]) { okmap = false; break; }
+      }
+    }
+    if (!okmap) return MG_OK;     // the classes are not a product of coordinate classes: the 1-D chunk form serves the level
     for (unsigned short v : tab) if (v >= ncls && !(box && v == 0xFFFF)) return MG_OK;
     cmap.insert(cmap.end(), cx.begin(), cx.end());
     cmap.insert(cmap.end(), cy.begin(), cy.end());
@@ -2887,111 +2823,6 @@ int build_march3(Csr& A, const long long grid[3]) {
   return MG_OK;
 }
 
-// The restriction fused behind stage 2 of the 2-D tile form (M3Restrict): A = the fine level's operator (geometry chosen, lockstep
-// schedule), R = its restriction with rows a coarse grid gc whose node (X, Y, Z) reads only fine nodes (2X+dx, 2Y+dy, 2Z+dz),
-// |d| <= 1 - verified row by row: the first column of a row relative to its centre (2X, 2Y, 2Z) is the same for all rows of a
-// class, every dictionary entry decomposes into (dz, dy, dx) within +-1, the class ids factor over the coarse coordinates.
-int build_march3_restrict(Csr& A, Csr& R, const long long gc[3]) {
-  A.rm3r_ok = false;
-  if (!A.rc_march3 || A.rm3.segs <= 0 || A.rm3.has_exc || A.opt.no_march3_restrict) return MG_OK;
-  if (!R.has_rc || R.rc_implicit || R.rc_nexc != 0 || R.regular_cols >= 0 || R.h_rc_ptr.empty()) return MG_OK;
-  const long long c1 = gc[0], c2 = gc[1], c3 = gc[2], f1 = A.rm3.n1, f2 = A.rm3.n2, f3 = A.rm3.nplanes;
-  if (c1 < 2 || c2 < 2 || c3 < 2 || c1 * c2 * c3 != R.n_rows || f1 * f2 * f3 != R.n_cols) return MG_OK;
-  if (c1 > 65535 || c2 > 65535 || c3 > 65535) return MG_OK;
-  if (R.h_rp.size() != (size_t)R.n_rows + 1 || R.h_cls.size() != (size_t)R.n_rows) return MG_OK;
-  if (2 * (c1 - 1) > f1 - 1 || 2 * (c2 - 1) > f2 - 1 || 2 * (c3 - 1) > f3 - 1) return MG_OK;   // every centre inside the fine grid
-  const size_t ncls = R.h_rc_ptr.size() - 1;
-  if (ncls > 256 || R.h_rc_off.size() > 2048) return MG_OK;
-  const long long FP = f1 * f2;
-  std::vector<long long> cdelta(ncls, LLONG_MIN);
-  for (long long Z = 0; Z < c3; ++Z)
-    for (long long Y = 0; Y < c2; ++Y)
-      for (long long X = 0; X < c1; ++X) {
-        const long long i = (Z * c2 + Y) * c1 + X;
-        const unsigned short c = R.h_cls[(size_t)i];
-        if (c >= ncls || R.h_rp[(size_t)i + 1] == R.h_rp[(size_t)i]) return MG_OK;
-        const long long d = (long long)R.h_ci[(size_t)R.h_rp[(size_t)i]] - ((2 * Z * f2 + 2 * Y) * f1 + 2 * X);
-        if (cdelta[c] == LLONG_MIN) cdelta[c] = d;
-        else if (cdelta[c] != d) return MG_OK;
-      }
-  const int pitch = A.rm3.pitch;
-  std::vector<mgk::MarchEnt> ent(R.h_rc_off.size());
-  std::vector<double> vals(R.h_rc_off.size());
-  if (!vals.empty()) HIP_TRY(hipMemcpy(vals.data(), R.rc_val.p, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
-  int maxlen = 0;
-  for (size_t c = 0; c < ncls; ++c) {
-    if (cdelta[c] == LLONG_MIN) cdelta[c] = 0;       // (a class without rows)
-    maxlen = std::max(maxlen, R.h_rc_ptr[c + 1] - R.h_rc_ptr[c]);
-    for (int k = R.h_rc_ptr[c]; k < R.h_rc_ptr[c + 1]; ++k) {
-      const long long sh = cdelta[c] + R.h_rc_off[(size_t)k];
-      const long long dz = (sh >= 0) ? (sh + FP / 2) / FP : -((-sh + FP / 2) / FP);
-      const long long rest = sh - dz * FP;
-      const long long dy = (rest >= 0) ? (rest + f1 / 2) / f1 : -((-rest + f1 / 2) / f1);
-      const long long dx = rest - dy * f1;
-      if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) return MG_OK;
-      mgk::MarchEnt e;
-      e.val = vals[(size_t)k];
-      e.code = (int)(((dy * pitch + dx + pitch + 1) << 2) | (dz + 1));
-      e.pad = 0;
-      ent[(size_t)k] = e;
-    }
-  }
-  std::vector<unsigned short> cx, cy, cz, tab;
-  if (!factor_class_ids(R.h_cls.data(), c1, c2, c3, 4096, cx, cy, cz, tab)) return MG_OK;
-  const int ncx = (int)(*std::max_element(cx.begin(), cx.end())) + 1, ncy = (int)(*std::max_element(cy.begin(), cy.end())) + 1;
-  for (unsigned short v : tab) if (v >= ncls) return MG_OK;
-  std::vector<unsigned short> cmap;
-  cmap.insert(cmap.end(), cx.begin(), cx.end());
-  cmap.insert(cmap.end(), cy.begin(), cy.end());
-  cmap.insert(cmap.end(), cz.begin(), cz.end());
-  cmap.insert(cmap.end(), tab.begin(), tab.end());
-  // dynamic LDS with the three r slabs, R's dictionary and maps behind everything the plain launch holds
-  const mgk::March3Dev& T = A.rm3;
-  const size_t TS = (size_t)(T.TY + 2) * (size_t)T.pitch;
-  const size_t slabs = (size_t)(3 * T.LY + 2 * (T.TY + 2)) * (size_t)T.pitch * 8;
-  const size_t mapsA = ((size_t)(T.n1 + T.n2 + T.nplanes) * (T.has_exc ? 2 : 1) + (size_t)T.ntab) * 2;
-  size_t lds = slabs + (size_t)T.ncls * 88 + mapsA;
-  lds = (lds + 15) & ~(size_t)15;
-  lds += 3 * TS * 8 + ent.size() * 16 + (size_t)((ncls + 2) & ~(size_t)1) * 4 + cmap.size() * 2 + 16;
-  if (lds > 160 * 1024 - 1024) return MG_OK;
-  // the coarse rows the pass does not compute: same predicate as the kernel, tile and segment of the node's centre
-  std::vector<int> list;
-  for (long long Z = 0; Z < c3; ++Z) {
-    const int seg = (int)(2 * Z / T.seglen), zs = seg * T.seglen, ze = std::min<int>(T.nplanes, zs + T.seglen);
-    for (long long Y = 0; Y < c2; ++Y) {
-      const int y0 = (int)(2 * Y / T.TY) * T.TY;
-      for (long long X = 0; X < c1; ++X) {
-        const int x0 = (int)(2 * X / T.TX) * T.TX;
-        if (!mgk::m3_restrict_inside((int)(2 * X), (int)(2 * Y), (int)(2 * Z), x0, y0, T.TX, T.TY, zs, ze, T.n1, T.n2, T.nplanes))
-          list.push_back((int)((Z * c2 + Y) * c1 + X));
-      }
-    }
-  }
-  MG_TRY(A.rm3r_ent.alloc(std::max<size_t>(ent.size(), 1)));
-  MG_TRY(A.rm3r_ptr.alloc(ncls + 1));
-  MG_TRY(A.rm3r_cmap.alloc(cmap.size()));
-  MG_TRY(A.rm3r_list.alloc(std::max<size_t>(list.size(), 1)));
-  HIP_TRY(hipMemcpy(A.rm3r_ent.p, ent.data(), ent.size() * sizeof(mgk::MarchEnt), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(A.rm3r_ptr.p, R.h_rc_ptr.data(), (ncls + 1) * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(A.rm3r_cmap.p, cmap.data(), cmap.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  if (!list.empty()) HIP_TRY(hipMemcpy(A.rm3r_list.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
-  mgk::M3Restrict q{};
-  q.ent = A.rm3r_ent.p;
-  q.ptr = A.rm3r_ptr.p;
-  q.cmap = A.rm3r_cmap.p;
-  q.ncx = ncx; q.ncy = ncy; q.ntab = (int)tab.size(); q.ncls = (int)ncls; q.nent = (int)ent.size(); q.maxlen = maxlen;
-  q.c1 = (int)c1; q.c2 = (int)c2; q.c3 = (int)c3;
-  q.alpha = 1.0;
-  A.rm3r = q;
-  A.rm3r_nlist = (int)list.size();
-  A.rm3r_lds = lds;
-  A.rm3r_ok = true;
-  if (A.opt.debug_format)
-    std::fprintf(stderr, "[mg] march3: restriction fused (coarse %lldx%lldx%lld, %zu classes, %zu entries): %zu of %lld coarse rows left to the list kernel, LDS %zu B\n",
-                 c1, c2, c3, ncls, ent.size(), list.size(), R.n_rows, lds);
-  return MG_OK;
-}
-
 // Prolongation-shaped operators (csr_rowclass_winp_spmv): rows = a fine grid gf, columns = a coarse grid gc, explicit
 // first columns.  Everything is derived from the stored pattern and checked against it: the coarse plane of each fine
 // plane's first columns (cz0), the split of every dictionary offset into plane shift (0 or 1) + in-plane rest, per chunk
@@ -3137,7 +2968,6 @@ int alloc_scratch(mg_hierarchy* h) {
       MG_TRY(build_schedule(L.P, L.grid, k));
       if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
       if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_winp(L.P, L.grid, h->lev[(size_t)l + 1].grid));
-      if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_march3_restrict(L.A, L.R, h->lev[(size_t)l + 1].grid));
     }
   }
   long long nmax = 0;
@@ -4878,10 +4708,9 @@ int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which
 
 // Which kernel fuses a sweep with the residual that follows it on this level's A (one right-hand side): *form = 0 none
 // (two launches), 2 csr_rowclass_march2_spmv (1-D chunks), 3 csr_rowclass_march3_spmv (2-D in-plane tiles).  geometry
-// (optional, 14 entries, form 3): tiles per line, tiles per column, TX, TY, rows of the stage-1 region per lane (K1),
+// (optional, 12 entries, form 3): tiles per line, tiles per column, TX, TY, rows of the stage-1 region per lane (K1),
 // workgroups, dynamic LDS bytes, estimated bytes filled + stored per row x 100, threads per workgroup, segments of the
-// lockstep schedule (0: balanced ranges), planes per segment, entries of the class table, 1 if the restriction is fused behind
-// stage 2 in the cycle, coarse rows that fused restriction leaves to the list kernel.
+// lockstep schedule (0: balanced ranges), planes per segment, entries of the class table.
 int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, long long* geometry) {
   if (!h || !form) return fail(MG_ERR_INVALID, "null argument");
   if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
@@ -4891,10 +4720,9 @@ int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, lo
   if (A.rc_march3) {
     *form = 3;
     if (geometry) {
-      const long long g[14] = {A.rm3.tiles_x, A.rm3.tiles_y, A.rm3.TX, A.rm3.TY, A.rm3_k1, A.rm3.nblocks, (long long)A.rm3_lds,
-                               (long long)(A.rm3_fill * 100.0), A.rm3_nt, A.rm3.segs, A.rm3.seglen, A.rm3.ntab,
-                               (A.rm3r_ok && !A.opt.no_march3_restrict) ? 1 : 0, A.rm3r_ok ? A.rm3r_nlist : 0};
-      std::copy(g, g + 14, geometry);
+      const long long g[12] = {A.rm3.tiles_x, A.rm3.tiles_y, A.rm3.TX, A.rm3.TY, A.rm3_k1, A.rm3.nblocks, (long long)A.rm3_lds,
+                               (long long)(A.rm3_fill * 100.0), A.rm3_nt, A.rm3.segs, A.rm3.seglen, A.rm3.ntab};
+      std::copy(g, g + 12, geometry);
     }
   } else if (A.rc_march && A.rc_march2) {
     *form = 2;

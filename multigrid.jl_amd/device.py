@@ -579,10 +579,9 @@ class DeviceHierarchy:
     def sweep_residual_form(self, level: int):
         """(form, geometry): 0 two launches, 2 csr_rowclass_march2_spmv, 3 csr_rowclass_march3_spmv with its tile geometry
         [tiles per line, tiles per column, TX, TY, rows per lane, workgroups, LDS bytes, est. fill bytes per row x 100,
-        threads per workgroup, lockstep segments (0: balanced ranges), planes per segment, class-table entries,
-        restriction fused (0/1), coarse rows left to the list kernel]."""
+        threads per workgroup, lockstep segments (0: balanced ranges), planes per segment, class-table entries]."""
         f = C.c_longlong(0)
-        g = (C.c_longlong * 14)()
+        g = (C.c_longlong * 12)()
         _check(self.lib, self.lib.mg_sweep_residual_form(self.handle, level, C.byref(f), g), "mg_sweep_residual_form")
         return int(f.value), [int(v) for v in g]
 

@@ -850,52 +850,6 @@ def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels,k1,nt,tiles_x,cyc", [([32, 32, 32], 3, 3, 768, 0, "V"), ([40, 24, 20], 2, 2, 1024, 2, "W"),
-                                                            ([24, 40, 36], 2, 4, 768, 1, "V"), ([64, 16, 8], 2, 3, 1024, 3, "F"),
-                                                            ([33, 25, 7], 2, 2, 1024, 0, "V")])
-def test_march3_restriction_fused_behind_stage_two(mg, built, monkeypatch, cells, levels, k1, nt, tiles_x, cyc):
-    """bc = R r (MGcycle.jl:66) fused behind stage 2 of the marching pass: r of the core tile stays in a ring of three slabs
-    in LDS and the coarse nodes whose fine neighbourhood lies inside the tile and the segment are computed there, the rest by
-    the list kernel from r in memory.  Iterates and residual histories must be BIT-identical to the unfused path
-    (MG_NO_MARCH3_RESTRICT=1: same pass without the restriction, then the lane kernel) and match the oracle; odd node
-    counts in every direction are required (else R does not have the 2X-1..2X+1 shape and nothing is fused)."""
-    import torch
-    from multigrid_jl_amd import device as D
-    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
-    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
-    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
-    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
-    monkeypatch.setenv("MG_MARCH_MAX_LEN", "64")
-    monkeypatch.setenv("MG_MARCH3_K1", str(k1))
-    monkeypatch.setenv("MG_MARCH3_NT", str(nt))
-    monkeypatch.setenv("MG_MARCH3_TILES_X", str(tiles_x))
-    monkeypatch.setenv("MG_MARCH3_LOCKSTEP_FORCE", "1")
-    odd_nodes = all(c % 2 == 0 for c in cells)
-    runs = {}
-    for name, no in (("fused", "0"), ("separate", "1")):
-        monkeypatch.setenv("MG_NO_MARCH3_RESTRICT", no)
-        A, p, b = _setup(mg, cells, levels, "Jac", 0.8, 2, 1, cyc, maxIter=5)
-        h = mg.to_device(p)
-        form, geo = h.sweep_residual_form(1)
-        assert form == 3 and geo[9] > 0, (form, geo)
-        assert geo[12] == (1 if (no == "0" and odd_nodes) else 0), geo
-        if geo[12]:
-            assert 0 < geo[13] < p.As[1].shape[0], geo            # some coarse rows inside, some on the list
-        x_, hist = _compare_solve(mg, p, b)
-        x0 = np.random.default_rng(99).standard_normal(b.shape)
-        x1 = x0.copy()
-        mg.recursiveCycle(p, b, x1, 1)
-        xo = orc.recursiveCycle(p, b, x0.copy(), 1)
-        assert np.abs(x1 - xo).max() <= RES_TOL * np.abs(xo).max()
-        x2 = x0.copy()
-        mg.solveMG(p, b, x2)
-        runs[name] = (x_.copy(), np.asarray(p.resvec).copy(), x1.copy(), x2.copy())
-        mg.clear_(p)
-    for k in range(4):
-        assert np.array_equal(runs["fused"][k], runs["separate"][k]), k
-
-
-@pytest.mark.gpu
 def test_march3_serves_513_node_lines(mg, built):
     """A 512^3-cell grid on ONE GPU has 513-node lines: the 1-D chunk form of the two-stage pass cannot stage them (its halo
     is a whole line: LDS) and round 2 fell back to two launches of the lane kernel there.  The 2-D tile form cuts the line
