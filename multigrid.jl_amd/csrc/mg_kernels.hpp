@@ -2343,33 +2343,55 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
 // Exception rows of a row-class operator (rows whose class was too rare for the dictionary: a few per cent next to
 // sub-domain faces or irregular boundaries): one lane per listed row, straight from the CSR arrays, same epilogues.
 // ------------------------------------------------------------------------------------------------
+// (round 3) EIGHT lanes per listed row: they load eight consecutive entries of the row at once (one or two cache lines of the
+// CSR arrays per row instead of one scattered 8/4-byte access per lane and entry - the face layers of a sharded box are
+// hundreds of thousands of rows, and with one lane per row the uncoalesced walk took ~1 us per 1000 rows), then every lane of
+// the group adds the products in stored order through shuffles: the same fused multiply-adds in the same order as before.
 template <int MODE>
 __global__ __launch_bounds__(BLK) void csr_rows_spmv(CsrDev A, const int* __restrict__ rows, int nrows, VecArgs v,
                                                      int sumsq_off) {
   __shared__ double red[BLK / 64];
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * BLK + tid;
-  double outv = 0.0;
-  if (i < nrows) {
-    const int row = rows[i];
-    double pb = 0.0, pd = 0.0, px = 0.0;
-    if (MODE == AXPBY) {
-      if (v.beta != 0.0) pb = v.beta * v.y[row];
-    } else {
-      pb = v.b[row];
-      if (MODE == SMOOTH || (MODE == RESID && v.y2)) {
-        pd = v.d[row];
-        px = v.xs[row];
+  const int tid = threadIdx.x, g = tid & 7, grp = tid >> 3;
+  double sq = 0.0;
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {                 // BLK rows per workgroup (one ||.||^2 partial each), 32 at a time
+    const int i = blockIdx.x * BLK + pass * (BLK / 8) + grp;
+    if (i < nrows) {
+      const int row = rows[i];
+      const int s = A.rowptr[row], e = A.rowptr[row + 1];
+      double acc = 0.0;
+      for (int base = s; base < e; base += 8) {
+        const int k = base + g;
+        double val = 0.0, xv = 0.0;
+        if (k < e) {
+          val = A.val[k];
+          xv = v.x[A.colidx[k]];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double vu = __shfl(val, u, 8), xu = __shfl(xv, u, 8);
+          if (base + u < e) acc += vu * xu;
+        }
+      }
+      if (g == 0) {
+        double pb = 0.0, pd = 0.0, px = 0.0;
+        if (MODE == AXPBY) {
+          if (v.beta != 0.0) pb = v.beta * v.y[row];
+        } else {
+          pb = v.b[row];
+          if (MODE == SMOOTH || (MODE == RESID && v.y2)) {
+            pd = v.d[row];
+            px = v.xs[row];
+          }
+        }
+        const double outv = epilogue<MODE>(v, row, acc, pb, pd, px);
+        if (MODE != RESID || v.y) v.y[row] = outv;
+        if (MODE == RESID && v.y2) v.y2[row] = px + pd * outv;   // x + d.*r: the next cycle's first damped-Jacobi update
+        sq += outv * outv;
       }
     }
-    double acc = 0.0;
-    for (int k = A.rowptr[row]; k < A.rowptr[row + 1]; ++k) acc += A.val[k] * v.x[A.colidx[k]];
-    outv = epilogue<MODE>(v, row, acc, pb, pd, px);
-    if (MODE != RESID || v.y) v.y[row] = outv;
-    if (MODE == RESID && v.y2) v.y2[row] = px + pd * outv;   // x + d.*r: the next cycle's first damped-Jacobi update
   }
   if (v.sumsq) {
-    double sq = outv * outv;
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
