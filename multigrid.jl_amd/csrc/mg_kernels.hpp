@@ -2852,6 +2852,20 @@ __global__ __launch_bounds__(BLK) void sum_final(const double* __restrict__ part
   if (threadIdx.x == 0) out[0] = s;
 }
 
+// the same, with the sum also stored straight into pinned host memory: the solve loop's stopping test reads it there once the
+// stream has drained - no 8-byte copy (a blit kernel of its own, ~4 us on the critical path of every step)
+__global__ __launch_bounds__(BLK) void sum_final_mirror(const double* __restrict__ partial, int np, double* __restrict__ out,
+                                                        double* __restrict__ host_mirror) {
+  __shared__ double red[BLK / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < np; i += BLK) acc += partial[i];
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    host_mirror[0] = s;
+  }
+}
+
 // dot(x, y), first stage (second stage: sum_final)
 __global__ __launch_bounds__(BLK) void dot_partial(const double* __restrict__ x, const double* __restrict__ y,
                                                    long long n, double* __restrict__ partial) {

@@ -505,6 +505,7 @@ struct mg_hierarchy {
   DevBuf<double> partial, partial2, scalar;
   DevBuf<double> m3sink;       // csr_rowclass_march3_spmv: one slot per lane for the stores of lanes with nothing to store
   double* h_scalar = nullptr;  // pinned
+  bool scalar_mirrored = false;   // the kernel that produced h->scalar also stored it into h_scalar (sum_final_mirror)
   int nred_blocks = 1024;
   // staging for the host-pointer API
   DevBuf<double> stage_b, stage_x, stage_t;
@@ -585,6 +586,11 @@ hipEvent_t get_event(mg_hierarchy* h) {
   return e;
 }
 
+// h->scalar = sum of np partials, also stored straight into the pinned h_scalar (scalar_sync then needs no copy)
+void launch_sum_final(mg_hierarchy* h, const double* partial, int np) {
+  hipLaunchKernelGGL(mgk::sum_final_mirror, dim3(1), dim3(mgk::BLK), 0, h->stream, partial, np, h->scalar.p, h->h_scalar);
+  h->scalar_mirrored = !h->capturing;
+}
 struct ProfScope {
   mg_hierarchy* h;
   bool on;
@@ -883,7 +889,7 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
     ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
     const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
     hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
-    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
+    launch_sum_final(h, h->partial2.p, nb2);
     HIP_TRY(hipGetLastError());
     return MG_OK;
   }
@@ -911,11 +917,12 @@ int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, 
   ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
   const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
   hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
-  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
+  launch_sum_final(h, h->partial2.p, nb2);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
 int scalar_sync(mg_hierarchy* h, double* out);
+int scalar_wait(mg_hierarchy* h);
 
 // out = x + d.*(b - A*x)
 int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const double* b,
@@ -1007,7 +1014,7 @@ int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::Marc
   }
   if (a.sumsq) {
     ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->scalar.p);
+    launch_sum_final(h, h->partial.p, nb1);
     HIP_TRY(hipGetLastError());
   }
   return MG_OK;
@@ -1047,7 +1054,7 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
   if (want_sumsq) {   // one partial per workgroup (<= one per CU): a single-workgroup final sum
     const int nb1 = T.nblocks;
     ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->scalar.p);
+    launch_sum_final(h, h->partial.p, nb1);
     HIP_TRY(hipGetLastError());
   }
   return MG_OK;
@@ -1192,15 +1199,20 @@ int k_sumsq(mg_hierarchy* h, const double* x, long long len) {
   const int nb = std::min<long long>(h->nred_blocks, std::max<long long>(1, (len / 2 + mgk::BLK - 1) / mgk::BLK));
   hipLaunchKernelGGL(mgk::sumsq_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, x, len,
                      h->partial.p);
-  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb,
-                     h->scalar.p);
+  launch_sum_final(h, h->partial.p, nb);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
 // host value of sqrt(h->scalar); synchronises the stream
-int scalar_sync(mg_hierarchy* h, double* out) {
-  HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+// h->scalar on the host (*h->h_scalar) once the stream has drained
+int scalar_wait(mg_hierarchy* h) {
+  if (!h->scalar_mirrored) HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  h->scalar_mirrored = false;
   HIP_TRY(spin_sync(h->stream));
+  return MG_OK;
+}
+int scalar_sync(mg_hierarchy* h, double* out) {
+  MG_TRY(scalar_wait(h));
   *out = std::sqrt(*h->h_scalar);
   return MG_OK;
 }
@@ -1598,10 +1610,9 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
 int dot_sync(mg_hierarchy* h, const double* x, const double* y, long long len, double* out) {
   const int nb = (int)std::min<long long>(h->nred_blocks, std::max<long long>(1, (len / 2 + mgk::BLK - 1) / mgk::BLK));
   hipLaunchKernelGGL(mgk::dot_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, x, y, len, h->partial.p);
-  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb, h->scalar.p);
+  launch_sum_final(h, h->partial.p, nb);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(spin_sync(h->stream));
+  MG_TRY(scalar_wait(h));
   *out = *h->h_scalar;
   return MG_OK;
 }
@@ -1623,10 +1634,9 @@ int k_spmv_dot(mg_hierarchy* h, int level, const Csr& A, const double* x, double
       ProfScope ps(h, level, MG_K_SPMV, spmv_bytes(A, 1, false, false), moved_bytes(A, 1, false, false));
       MG_TRY(launch_csr<mgk::AXPBY>(h->stream, A, v, &nb1));
     }
-    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->scalar.p);
+    launch_sum_final(h, h->partial.p, nb1);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(spin_sync(h->stream));
+    MG_TRY(scalar_wait(h));
     *out = *h->h_scalar;
     return MG_OK;
   }
@@ -1681,7 +1691,7 @@ int pcg_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long m
     const double alpha = gamma / pAp;
     if (std::isinf(alpha) || alpha < 0.0) { flag = -2; break; }
     hipLaunchKernelGGL(mgk::cg_update_xr_norm, dim3(nb_upd), dim3(mgk::BLK), 0, h->stream, alpha, p, Ap, x, r, n, h->partial.p);
-    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb_upd, h->scalar.p);
+    launch_sum_final(h, h->partial.p, nb_upd);
     HIP_TRY(hipGetLastError());
     MG_TRY(scalar_sync(h, &rn));
     if (resvec) resvec[k - 1] = rn / nr0;

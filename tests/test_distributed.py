@@ -383,6 +383,75 @@ def test_structured_setup_hip(built):
     _run_structured(2, [32, 32, 32], 4, "V", 1, use_hip=True)
 
 
+def _worker_c4box(rank, world, port, cells, levels, q):
+    """One rank of the C4-sized run: sharded host setup of its 257^3 box, native sequencer, plug-in transport."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["MG_HOST_THREADS"] = str(max(1, (os.cpu_count() or 2) // world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import multigrid_jl_amd as mg
+        from multigrid_jl_amd import distributed as dd, structured_setup as ss
+        be, comm = dd.HipBackend(0), dd.TorchComm(stage_through_host=True)
+        doms = dd.default_domains(world, 3)
+        p = mg.getMGparam(np.float64, np.int64, levels, 8, 2, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+        H, info = ss.structured_gmg(cells, doms, comm, be, p, ss.poisson_operator(cells), nrhs=1)
+        assert H.box_form and len(H.levels) >= 2
+        b_own, ss2 = ss.local_rhs(info, 1)
+        tot = torch.tensor([ss2], dtype=torch.float64)
+        dist.all_reduce(tot)
+        b_loc = be.from_numpy(H.order_fine(b_own) / float(tot.item()) ** 0.5)
+        x_loc = torch.zeros_like(b_loc)
+        S = dd.NativeDistributedHierarchy(H, transport="plugin")
+        yes, l1, l2 = H.levels[0].A_int.can_sweep_residual(H.levels[0].x0, H.levels[0].d)
+        it, resvec = S.solve(b_loc, x_loc, 0.0, 2)
+        be.synchronize()
+        sums = torch.tensor([float(x_loc.sum().item()), float((x_loc * x_loc).sum().item())], dtype=torch.float64)
+        dist.all_reduce(sums)
+        if rank == 0:
+            q.put(("ok", it, resvec, sums.numpy(), (bool(yes), l1, l2, H.levels[0].n_own)))
+        dist.barrier()
+        S.close()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+@pytest.mark.gpu
+def test_c4_per_gpu_box_size_two_ranks_vs_c_oracle(built):
+    """BASELINE.json configs[3] (512^3 cells over 8 GPUs) puts a 257^3-node box on every GPU.  Two such boxes - 256 x 256 x 512
+    cells, 33.9 M rows - on two ranks sharing this box's one GPU (host-staged plug-in transport): sharded host setup, box-form
+    levels, the fused sweep + residual pairs with their face-layer list kernels, replicated tail; two solveMG steps against the
+    C/OpenMP oracle on the global hierarchy (residual history to 1e-10, sum and norm of the iterate)."""
+    from oracle import c_oracle
+    import multigrid_jl_amd as mg
+    cells, levels, world = [256, 256, 512], 6, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c4box, args=(r, world, port, cells, levels, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    A, mesh = mg.poisson_shifted(cells)                      # (the checker's hierarchy, while the ranks set up theirs)
+    p = mg.getMGparam(np.float64, np.int64, levels, 8, 2, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p, 1)
+    b = mg.seeded_rhs(A)
+    co = c_oracle.COracle(p, 1)
+    xo = np.zeros_like(b)
+    ito, rv = co.solveMG(b, xo, 0.0, 2, c_oracle.max_threads())
+    res = q.get(timeout=900)
+    for pr in procs:
+        pr.join(timeout=300)
+    assert res[0] == "ok", res[1]
+    _, it, resvec, sums, info = res
+    assert info[0] and info[1] > 60000 and info[2] > 60000, info      # the two-stage pass with a real face layer on each rank
+    assert it == ito == 2
+    assert np.abs(np.asarray(resvec) - rv).max() / rv[0] < 1e-10
+    assert abs(sums[0] - xo.sum()) <= 1e-9 * np.abs(xo).sum() and abs(sums[1] - xo @ xo) <= 1e-10 * (xo @ xo)
+
+
 def test_unsupported_settings_fail_loudly():
     import multigrid_jl_amd as mg
     from multigrid_jl_amd import distributed as dd
