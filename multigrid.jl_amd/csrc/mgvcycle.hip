@@ -352,7 +352,9 @@ struct Csr {
     c.cls_off = rc_off.p;
     c.cls_val = rc_val.p;
     c.nblocks = rc_blocks();
-    c.n_rows = (int)n_rows;
+    // a box operator's rows beyond the owned box are empty halo rows: no kernel may touch them - the row operands (b, d, y)
+    // are only n_own long, and "a safe row" for idle lanes must be one of the owned rows
+    c.n_rows = (int)(regular_cols >= 0 ? std::min(regular_cols, n_rows) : n_rows);
     return c;
   }
   void drop_rc() {
