@@ -443,6 +443,9 @@ int mg_dist_set_level(mg_dist* h, long long level, long long n_own, long long n_
  * replicated tail carries its own setting (mg_set_relax_type).  cycleType 'K' (mg_dist_create) runs the K-cycle's FGMRES
  * steps on sharded levels with all-reduced dots (MGcycle.jl:72-76). */
 int mg_dist_set_relax_type(mg_dist* h, long long relax_type);
+/* Right-hand sides per call (default 1; row-major [n][nrhs] blocks; MGdef.jl:163-176, SolveFuncs.jl:30): right after
+ * mg_dist_create.  b_loc / x_loc of the cycle and solve entry points are then n_own x nrhs blocks. */
+int mg_dist_set_nrhs(mg_dist* h, long long nrhs);
 int mg_dist_set_level_box(mg_dist* h, long long level, long long on);
 int mg_dist_set_plan_INT64(mg_dist* h, long long level, long long which, long long n_own_src, long long n_halo,
                            long long n_send, const long long* send_idx, const long long* send_splits,

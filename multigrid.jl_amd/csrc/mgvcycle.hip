@@ -5266,15 +5266,22 @@ struct DistLevel {
 };
 }  // namespace
 
+// rows of a row-major block [n][k]: dst row i = src row idx[i]
 __global__ __launch_bounds__(256) void dist_pack(const double* __restrict__ src, const int* __restrict__ idx,
-                                                 double* __restrict__ dst, long long n) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
+                                                 double* __restrict__ dst, long long n, int k) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n * k) {
+    const long long i = e / k;
+    dst[e] = src[(long long)idx[i] * k + (e - i * k)];
+  }
 }
 __global__ __launch_bounds__(256) void dist_gather64(const double* __restrict__ src, const long long* __restrict__ idx,
-                                                     double* __restrict__ dst, long long n) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
+                                                     double* __restrict__ dst, long long n, int k) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n * k) {
+    const long long i = e / k;
+    dst[e] = src[idx[i] * k + (e - i * k)];
+  }
 }
 
 struct mg_dist {
@@ -5288,6 +5295,7 @@ struct mg_dist {
   char cycle = 'V';
   int relax_type = 0;                   // 0: pointwise (Jac / SPAI), 1: Jac-GMRES (MGcycle.jl:48-50,96-98)
   bool finalized = false;
+  long long nrhs = 1;                   // right-hand sides per call (blocks are row-major [n][nrhs], as in mg_hierarchy)
   bool no_pair = false;                 // MG_DIST_NO_PAIR=1: never fuse a sweep with the residual that follows it (A/B, tests)
   // replicated tail
   mg_hierarchy* tail = nullptr;
@@ -5323,17 +5331,18 @@ int dist_stage(mg_dist* h, size_t n) {
 // RCCL: pack on the compute stream, send/recv on the side stream; the compute stream goes on.  Plug-in: done on return.
 int dist_exchange_start(mg_dist* h, DistPlan& p, double* buf) {
   if (!p.set || !p.active) return MG_OK;
+  const long long k = h->nrhs;
   if (p.n_send > 0)
-    hipLaunchKernelGGL(dist_pack, dim3((unsigned)((p.n_send + 255) / 256)), dim3(256), 0, h->stream, buf, p.send_idx.p, p.send_buf.p, p.n_send);
+    hipLaunchKernelGGL(dist_pack, dim3((unsigned)((p.n_send * k + 255) / 256)), dim3(256), 0, h->stream, buf, p.send_idx.p, p.send_buf.p, p.n_send, (int)k);
   HIP_TRY(hipGetLastError());
-  double* recv = buf + p.n_own_src;
+  double* recv = buf + p.n_own_src * k;
   if (h->comm) {
     HIP_TRY(hipEventRecord(h->ev_packed, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_packed, 0));
     NCCL_TRY(g_rccl.GroupStart());
     long long so = 0, ro = 0;
     for (int peer = 0; peer < h->world; ++peer) {
-      const long long ns = p.send_splits[(size_t)peer], nr = p.recv_splits[(size_t)peer];
+      const long long ns = p.send_splits[(size_t)peer] * k, nr = p.recv_splits[(size_t)peer] * k;
       if (ns > 0) NCCL_TRY(g_rccl.Send(p.send_buf.p + so, (size_t)ns, NCCL_DOUBLE, peer, h->comm, h->side));
       if (nr > 0) NCCL_TRY(g_rccl.Recv(recv + ro, (size_t)nr, NCCL_DOUBLE, peer, h->comm, h->side));
       so += ns;
@@ -5344,11 +5353,14 @@ int dist_exchange_start(mg_dist* h, DistPlan& p, double* buf) {
     return MG_OK;
   }
   // host-staged transport
-  if (p.n_send > 0) HIP_TRY(hipMemcpyAsync(p.h_send, p.send_buf.p, sizeof(double) * (size_t)p.n_send, hipMemcpyDeviceToHost, h->stream));
+  if (p.n_send > 0) HIP_TRY(hipMemcpyAsync(p.h_send, p.send_buf.p, sizeof(double) * (size_t)(p.n_send * k), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(spin_sync(h->stream));
-  if (h->plug(h->plug_user, 0, p.h_send, p.send_splits.data(), p.h_recv, p.recv_splits.data(), 0) != 0)
+  std::vector<long long> ssk(p.send_splits), rsk(p.recv_splits);     // (counts in doubles: rows x right-hand sides)
+  for (auto& c : ssk) c *= k;
+  for (auto& c : rsk) c *= k;
+  if (h->plug(h->plug_user, 0, p.h_send, ssk.data(), p.h_recv, rsk.data(), 0) != 0)
     return fail(MG_ERR_HIP, "exchange plug-in failed (all_to_all)");
-  if (p.n_halo > 0) HIP_TRY(hipMemcpyAsync(recv, p.h_recv, sizeof(double) * (size_t)p.n_halo, hipMemcpyHostToDevice, h->stream));
+  if (p.n_halo > 0) HIP_TRY(hipMemcpyAsync(recv, p.h_recv, sizeof(double) * (size_t)(p.n_halo * k), hipMemcpyHostToDevice, h->stream));
   return MG_OK;
 }
 // Make the compute stream wait for the halo started by dist_exchange_start.
@@ -5361,15 +5373,15 @@ int dist_exchange_finish(mg_dist* h, DistPlan& p) {
 int dist_apply(mg_dist* h, mg_operator* op, long long kernel, double alpha, const double* x, double beta, double* y,
                const double* b, const double* d, long long row_offset) {
   if (!op) return MG_OK;
-  return mg_op_apply_rows_dev_FP64(op, kernel, alpha, x, beta, y, b, d, 1, row_offset, h->stream);
+  return mg_op_apply_rows_dev_FP64(op, kernel, alpha, x, beta, y, b, d, h->nrhs, row_offset, h->stream);
 }
 // out = b - A x / out = x + d.*(b - A x) on this rank's rows, the halo exchange overlapped with the interior rows
 int dist_apply_A(mg_dist* h, DistLevel& L, long long kernel, double* x, double* out, const double* b) {
   MG_TRY(dist_exchange_start(h, L.planA, x));
   if (L.box) {   // rows of the owned box that do not read the halo (staged kernels), then - halo landed - the rest
-    MG_TRY(mg_op_apply_phase_dev_FP64(L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, 1, 0, 1, h->stream));
+    MG_TRY(mg_op_apply_phase_dev_FP64(L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, h->nrhs, 0, 1, h->stream));
     MG_TRY(dist_exchange_finish(h, L.planA));
-    MG_TRY(mg_op_apply_phase_dev_FP64(L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, 1, 0, 2, h->stream));
+    MG_TRY(mg_op_apply_phase_dev_FP64(L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, h->nrhs, 0, 2, h->stream));
     return MG_OK;
   }
   MG_TRY(dist_apply(h, L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, 0));
@@ -5405,7 +5417,7 @@ int dist_reduce_scalar(mg_dist* h, double* out) {
 
 // Can the sweep + residual pair of this level run as one two-stage pass (box-form level whose A is on the 2-D tile form)?
 bool dist_pair_ok(mg_dist* h, DistLevel& L, const double* x) {
-  if (!L.box || h->relax_type != 0 || h->no_pair || !L.A_int) return false;
+  if (!L.box || h->relax_type != 0 || h->no_pair || !L.A_int || h->nrhs != 1) return false;
   long long yes = 0;
   if (mg_op_can_sweep_residual(L.A_int, x, L.d, &yes, nullptr, nullptr) != MG_OK) return false;
   return yes != 0;
@@ -5449,10 +5461,10 @@ int dist_sweep_residual(mg_dist* h, DistLevel& L, double* x, double* t, double* 
 int dist_residual_norm(mg_dist* h, DistLevel& L, double* x, const double* b, double* alt, double* norm, bool* x1_ready) {
   *x1_ready = false;
   long long can = 0;
-  if (L.box && alt) MG_TRY(mg_op_can_fuse_next(L.A_int, x, &can));
-  if (!L.box) {
+  if (L.box && alt && h->nrhs == 1) MG_TRY(mg_op_can_fuse_next(L.A_int, x, &can));
+  if (!L.box || h->nrhs != 1) {     // (blocks: the Frobenius norm over the whole n x nrhs block, SolveFuncs.jl:30)
     MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, x, L.r.p, b));
-    return dist_norm(h, L.r.p, L.n_own, norm);
+    return dist_norm(h, L.r.p, L.n_own * h->nrhs, norm);
   }
   long long n1 = 0, n2 = 0;
   {   // capacity before anything is written: every launch form of this operator writes at most this many partials
@@ -5564,7 +5576,7 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
   long long npre = L.npre;
   const long long npost = L.npost;
   const double gmresTol = 1e-5;  // MGcycle.jl:5
-  auto diag_prec = [&](const double* v, double* z) { return mg_vec_dscale_dev_FP64(L.d, v, z, L.n_own, 1, h->stream); };   // MM (l.36-38)
+  auto diag_prec = [&](const double* v, double* z) { return mg_vec_dscale_dev_FP64(L.d, v, z, L.n_own, h->nrhs, h->stream); };   // MM (l.36-38)
   if (h->relax_type == 1) {      // Jac-GMRES (MGcycle.jl:48-50): FGMRES on the residual, preconditioned by D
     const double* r0 = b;
     if (x_zero) {
@@ -5576,10 +5588,10 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     MG_TRY(dist_fgmres_relax(h, L, r0, cur, L.npre_raw, diag_prec, gmresTol, L.relZ, L.relAZ, false));
     npre = 0;
   } else if (x_zero) {
-    MG_TRY(mg_vec_dscale_dev_FP64(L.d, b, cur, L.n_own, 1, h->stream));
+    MG_TRY(mg_vec_dscale_dev_FP64(L.d, b, cur, L.n_own, h->nrhs, h->stream));
     --npre;
   } else if (r_valid) {
-    if (!x1_ready) MG_TRY(mg_vec_xpdr_dev_FP64(cur, L.d, L.r.p, alt, L.n_own, 1, h->stream));   // (else: written by the residual pass)
+    if (!x1_ready) MG_TRY(mg_vec_xpdr_dev_FP64(cur, L.d, L.r.p, alt, L.n_own, h->nrhs, h->stream));   // (else: written by the residual pass)
     std::swap(cur, alt);
     --npre;
   }
@@ -5630,28 +5642,29 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     // restrict into this rank's rows of the first replicated level, all-gather, run the tail replicated
     MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, h->bc_pad.p, nullptr, nullptr, 0));
     if (h->comm) {
-      NCCL_TRY(g_rccl.AllGather(h->bc_pad.p, h->bc_all.p, (size_t)h->max_tail, NCCL_DOUBLE, h->comm, h->stream));
+      NCCL_TRY(g_rccl.AllGather(h->bc_pad.p, h->bc_all.p, (size_t)(h->max_tail * h->nrhs), NCCL_DOUBLE, h->comm, h->stream));
     } else if (h->world > 1) {
-      MG_TRY(dist_stage(h, (size_t)h->max_tail * (size_t)(h->world + 1)));
-      HIP_TRY(hipMemcpyAsync(h->h_stage, h->bc_pad.p, sizeof(double) * (size_t)h->max_tail, hipMemcpyDeviceToHost, h->stream));
+      const long long mt = h->max_tail * h->nrhs;      // doubles per rank: padded share x right-hand sides
+      MG_TRY(dist_stage(h, (size_t)mt * (size_t)(h->world + 1)));
+      HIP_TRY(hipMemcpyAsync(h->h_stage, h->bc_pad.p, sizeof(double) * (size_t)mt, hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(spin_sync(h->stream));
-      if (h->plug(h->plug_user, 2, h->h_stage, nullptr, h->h_stage + h->max_tail, nullptr, h->max_tail) != 0)
+      if (h->plug(h->plug_user, 2, h->h_stage, nullptr, h->h_stage + mt, nullptr, mt) != 0)
         return fail(MG_ERR_HIP, "exchange plug-in failed (all_gather)");
-      HIP_TRY(hipMemcpyAsync(h->bc_all.p, h->h_stage + h->max_tail, sizeof(double) * (size_t)(h->max_tail * h->world), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->bc_all.p, h->h_stage + mt, sizeof(double) * (size_t)(mt * h->world), hipMemcpyHostToDevice, h->stream));
     } else {
-      HIP_TRY(hipMemcpyAsync(h->bc_all.p, h->bc_pad.p, sizeof(double) * (size_t)h->max_tail, hipMemcpyDeviceToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->bc_all.p, h->bc_pad.p, sizeof(double) * (size_t)(h->max_tail * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
     }
-    hipLaunchKernelGGL(dist_gather64, dim3((unsigned)((h->n_tail + 255) / 256)), dim3(256), 0, h->stream, h->bc_all.p, h->gather_index.p, h->b_tail.p, h->n_tail);
+    hipLaunchKernelGGL(dist_gather64, dim3((unsigned)((h->n_tail * h->nrhs + 255) / 256)), dim3(256), 0, h->stream, h->bc_all.p, h->gather_index.p, h->b_tail.p, h->n_tail, (int)h->nrhs);
     HIP_TRY(hipGetLastError());
     MG_TRY(mg_set_cycle_type(h->tail, ctype));
     if (ctype == 'K' && (long long)h->lev.size() < h->nl_total - 1) {
       // the first replicated level is not the coarsest: its K-step runs replicated, identically on every rank
       MG_TRY(mg_kcycle_step_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail));
     } else
-    MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, 1, 1));
+    MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, h->nrhs, 1));
     if ((long long)h->lev.size() < h->nl_total - 1 && (ctype == 'W' || ctype == 'F')) {       // second visit (MGcycle.jl:79-84)
       MG_TRY(mg_set_cycle_type(h->tail, ctype == 'W' ? 'W' : 'V'));
-      MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, 1, 0));
+      MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, h->nrhs, 0));
     }
     MG_TRY(dist_apply(h, L.P, MG_K_PROLONG, 1.0, h->x_tail.p, 1.0, cur, nullptr, nullptr, 0));
   }
@@ -5693,11 +5706,11 @@ int dist_set_plan(mg_dist* h, DistPlan& p, long long n_own_src, long long n_halo
     idx[(size_t)i] = (int)send_idx[i];
   }
   MG_TRY(p.send_idx.alloc(idx.size()));
-  MG_TRY(p.send_buf.alloc(idx.size()));
+  MG_TRY(p.send_buf.alloc(idx.size() * (size_t)h->nrhs));
   HIP_TRY(hipMemcpy(p.send_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
   if (!h->comm) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_send), sizeof(double) * (size_t)std::max<long long>(n_send, 1)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_recv), sizeof(double) * (size_t)std::max<long long>(n_halo, 1)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_send), sizeof(double) * (size_t)(std::max<long long>(n_send, 1) * h->nrhs)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_recv), sizeof(double) * (size_t)(std::max<long long>(n_halo, 1) * h->nrhs)));
   }
   return MG_OK;
 }
@@ -5764,6 +5777,21 @@ int mg_dist_comm_count(mg_dist* h, long long* count) {
   int c = 0;
   NCCL_TRY(g_rccl.CommCount(h->comm, &c));
   *count = c;
+  return MG_OK;
+}
+
+// Right-hand sides per call (default 1): blocks are row-major [n][nrhs] everywhere, as in mg_hierarchy (MGdef.jl:163-176: the
+// reference is block-capable everywhere; one Frobenius stopping criterion for the block, SolveFuncs.jl:30).  Call it right
+// after mg_dist_create - the plans, the tail and the level vectors are sized with it.  Blocks run the pointwise smoothers and
+// the V / W / F cycles (the K-cycle's and Jac-GMRES's small systems are per right-hand side in the reference: refused here).
+int mg_dist_set_nrhs(mg_dist* h, long long nrhs) {
+  if (!h || nrhs < 1) return fail(MG_ERR_INVALID, "null handle or nrhs < 1");
+  for (const DistLevel& L : h->lev)
+    if (L.planA.set || L.n_own > 0) return fail(MG_ERR_STATE, "mg_dist_set_nrhs must precede the levels and plans");
+  if (h->tail) return fail(MG_ERR_STATE, "mg_dist_set_nrhs must precede mg_dist_set_tail_INT64");
+  if (nrhs > 1 && (h->cycle == 'K' || h->relax_type == 1)) return fail(MG_ERR_UNSUPPORTED, "blocks of right-hand sides: V, W, F cycles with pointwise smoothers");
+  h->nrhs = nrhs;
+  h->finalized = false;
   return MG_OK;
 }
 
@@ -5838,10 +5866,12 @@ int mg_dist_set_tail_INT64(mg_dist* h, mg_hierarchy* tail, long long n_tail, lon
   h->n_tail = n_tail;
   h->own_tail = own_tail;
   h->max_tail = max_tail;
-  MG_TRY(h->bc_pad.alloc((size_t)max_tail));
-  MG_TRY(h->bc_all.alloc((size_t)max_tail * (size_t)h->world));
-  MG_TRY(h->b_tail.alloc((size_t)n_tail));
-  MG_TRY(h->x_tail.alloc((size_t)n_tail));
+  const size_t kk = (size_t)h->nrhs;
+  MG_TRY(h->bc_pad.alloc((size_t)max_tail * kk));
+  MG_TRY(h->bc_all.alloc((size_t)max_tail * (size_t)h->world * kk));
+  MG_TRY(h->b_tail.alloc((size_t)n_tail * kk));
+  MG_TRY(h->x_tail.alloc((size_t)n_tail * kk));
+  if (tail->nrhs != h->nrhs) return fail(MG_ERR_INVALID, "the tail hierarchy is set up for %lld right-hand sides, the sequencer for %lld", tail->nrhs, h->nrhs);
   MG_TRY(h->gather_index.alloc((size_t)n_tail));
   for (long long i = 0; i < n_tail; ++i)
     if (gather_index[i] < 0 || gather_index[i] >= max_tail * h->world) return fail(MG_ERR_INVALID, "gather index out of range");
@@ -5887,14 +5917,14 @@ int mg_dist_finalize(mg_dist* h) {
     if (l > 0 && h->lev[(size_t)l - 1].planP.set) halo_x = std::max(halo_x, h->lev[(size_t)l - 1].planP.n_halo);
     L.cap_x = L.n_own + halo_x;
     L.cap_r = L.n_own + L.planR.n_halo;
-    MG_TRY(L.x0.alloc((size_t)L.cap_x));
-    MG_TRY(L.x1.alloc((size_t)L.cap_x));
-    MG_TRY(L.r.alloc((size_t)L.cap_r));
+    MG_TRY(L.x0.alloc((size_t)(L.cap_x * h->nrhs)));
+    MG_TRY(L.x1.alloc((size_t)(L.cap_x * h->nrhs)));
+    MG_TRY(L.r.alloc((size_t)(L.cap_r * h->nrhs)));
     HIP_TRY(hipMemset(L.x0.p, 0, L.x0.bytes()));
     HIP_TRY(hipMemset(L.x1.p, 0, L.x1.bytes()));
     HIP_TRY(hipMemset(L.r.p, 0, L.r.bytes()));
     if (l > 0) {
-      MG_TRY(L.b.alloc((size_t)L.n_own));
+      MG_TRY(L.b.alloc((size_t)(L.n_own * h->nrhs)));
       HIP_TRY(hipMemset(L.b.p, 0, L.b.bytes()));
     }
   }
@@ -5917,10 +5947,10 @@ int mg_dist_cycle_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long 
   DistLevel& L = h->lev[0];
   if (n_own != L.n_own) return fail(MG_ERR_INVALID, "n_own=%lld but this rank owns %lld fine rows", n_own, L.n_own);
   (void)hipSetDevice(h->device);
-  HIP_TRY(hipMemcpyAsync(L.x0.p, x_loc, sizeof(double) * (size_t)n_own, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(L.x0.p, x_loc, sizeof(double) * (size_t)(n_own * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
   double* res = nullptr;
   MG_TRY(dist_cycle(h, 0, b_loc, L.x0.p, L.x1.p, x_is_zero != 0, h->cycle, &res));
-  HIP_TRY(hipMemcpyAsync(x_loc, res, sizeof(double) * (size_t)n_own, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(x_loc, res, sizeof(double) * (size_t)(n_own * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(spin_sync(h->stream));
   return MG_OK;
 }
@@ -5934,13 +5964,13 @@ int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long 
   if (n_own != L.n_own) return fail(MG_ERR_INVALID, "n_own=%lld but this rank owns %lld fine rows", n_own, L.n_own);
   (void)hipSetDevice(h->device);
   double *cur = L.x0.p, *alt = L.x1.p;
-  HIP_TRY(hipMemcpyAsync(cur, x_loc, sizeof(double) * (size_t)n_own, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(cur, x_loc, sizeof(double) * (size_t)(n_own * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
   double xn = 0.0, res0 = 0.0, res = 0.0;
-  MG_TRY(dist_norm(h, cur, n_own, &xn));
+  MG_TRY(dist_norm(h, cur, n_own * h->nrhs, &xn));
   bool x_zero = (xn == 0.0);
   bool x1_ready = false;
   if (x_zero) {
-    MG_TRY(dist_norm(h, b_loc, n_own, &res0));
+    MG_TRY(dist_norm(h, b_loc, n_own * h->nrhs, &res0));
   } else {
     MG_TRY(dist_residual_norm(h, L, cur, b_loc, nullptr, &res0, &x1_ready));
   }
@@ -5980,7 +6010,7 @@ int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long 
     if (resvec) resvec[it] = res;
     if (res / res0 < tol) break;
   }
-  HIP_TRY(hipMemcpyAsync(x_loc, cur, sizeof(double) * (size_t)n_own, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(x_loc, cur, sizeof(double) * (size_t)(n_own * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(spin_sync(h->stream));
   if (iters) *iters = it;
   return MG_OK;

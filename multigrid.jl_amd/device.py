@@ -126,6 +126,7 @@ SIGNATURES = {
     "mg_dist_finalize": (C.c_int, [_vp]),
     "mg_dist_cycle_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, _ll]),
     "mg_dist_solve_dev_FP64": (C.c_int, [_vp, _vp, _vp, _ll, C.c_double, _ll, _lp, _dp]),
+    "mg_dist_set_nrhs": (C.c_int, [_vp, _ll]),
     "mg_dist_release_tail": (C.c_int, [_vp]),
     "mg_dist_comm_count": (C.c_int, [_vp, _lp]),
     "mg_dist_destroy": (C.c_int, [_vp]),

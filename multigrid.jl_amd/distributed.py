@@ -703,8 +703,8 @@ class NativeDistributedHierarchy:
 
     def __init__(self, H: DistributedHierarchy, transport: str = "rccl"):
         import ctypes as C
-        if H.nrhs != 1:
-            raise NotImplementedError("the native sequencer handles one right-hand side")
+        if H.nrhs != 1 and (H.cycleType == "K" or H.relaxType == "Jac-GMRES"):
+            raise NotImplementedError("blocks of right-hand sides: V, W, F cycles with the pointwise smoothers")
         self.H = H
         self.lib = lib = D.load_library()
         comm = H.comm
@@ -724,6 +724,8 @@ class NativeDistributedHierarchy:
         D._check(lib, lib.mg_dist_create(H.be.device_id, rank, size, uid, nl_sh, H.nl, ord(H.cycleType), C.byref(self.handle)),
                  "mg_dist_create")
         D._check(lib, lib.mg_dist_set_relax_type(self.handle, 1 if H.relaxType == "Jac-GMRES" else 0), "mg_dist_set_relax_type")
+        if H.nrhs != 1:
+            D._check(lib, lib.mg_dist_set_nrhs(self.handle, int(H.nrhs)), "mg_dist_set_nrhs")
         self._cb = None
         if uid is None and size > 1:
             self._install_plugin(comm)

@@ -235,6 +235,17 @@ def test_native_sequencer_plugin_transport(built, world, kind, cyc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,nrhs,cyc", [(2, "gmg3d", 3, "V"), (2, "sa", 2, "V"), (4, "gmg3d", 4, "W"), (1, "gmg2d", 2, "F"),
+                                                 (2, "gmg3d", 16, "V")])
+def test_native_sequencer_blocks_of_right_hand_sides(built, world, kind, nrhs, cyc):
+    """mg_dist_* with nrhs > 1 (MGdef.jl:163-176: the reference is block-capable everywhere; one Frobenius criterion for the
+    block, SolveFuncs.jl:30): row-major [n][nrhs] blocks through the pack kernels, the halo exchange, the SpMM kernels, the
+    padded all-gather into the replicated tail - GMG and SA-AMG (general CSR, contiguous row blocks) hierarchies, against the
+    oracle's block solve."""
+    _run(world, kind, nrhs, cyc, use_hip=True, native="plugin")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,kind,cyc,native", [(1, "gmg3d", "V", "plugin"), (2, "gmg3d", "V", "plugin"), (4, "gmg3d", "F", "plugin"),
                                                    (2, "gmg3d", "W", None), (2, "gmg2d", "V", "plugin")])
 def test_box_form_local_operators_hip(built, world, kind, cyc, native):
