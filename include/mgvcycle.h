@@ -138,8 +138,8 @@ int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which,
 
 /* replaceMatrixInHierarchy on the device (MGsetup.jl:226-270): new fine values on the unchanged sparsity, then
  * per level relaxPrecs[l] (relaxKind 0: Jac omega/diag, 1: SPAI omega*diag/colnorm^2; omega[l] per level) and the
- * Galerkin product As[l+1] = Ps[l]*As[l]*Rs[l] on the fixed patterns (rows of As[l+1] up to 1024 entries; otherwise
- * MG_ERR_UNSUPPORTED and the host path applies).  The coarsest factorisation stays on the host: fetch the
+ * Galerkin product As[l+1] = Ps[l]*As[l]*Rs[l] on the fixed patterns (rows of As[l+1] of any length: 2048 target columns
+ * at a time; deterministic - the same sums in the same order on every run).  The coarsest factorisation stays on the host: fetch the
  * coarsest values (mg_get_values_FP64), factor, mg_set_coarse_dense_inverse_FP64, mg_finalize. */
 int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long long relaxKind,
                 const double* omega, long long* levels_done);

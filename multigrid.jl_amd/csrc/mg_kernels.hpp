@@ -3265,23 +3265,28 @@ __global__ __launch_bounds__(BLK) void tri_apply(const double* __restrict__ T, i
 // A's rows are walked one after the other in stored order; only the entries (j,c) of ONE row of P - distinct target
 // columns - are spread over the lanes, each lane finds its column in C's (sorted) row by binary search in LDS and adds
 // there without atomics.  Every entry of C is therefore the same sum in the same order on every run.
-// Rows of C longer than RAP_CAP are left to the host path.
 // ------------------------------------------------------------------------------------------------
-constexpr int RAP_CAP = 1024;
+constexpr int RAP_CAP = 2048;
 __global__ __launch_bounds__(64) void rap_numeric(CsrDev R, CsrDev A, CsrDev P, const int* __restrict__ Crowptr,
-                                                  const int* __restrict__ Ccol, double* __restrict__ Cval) {
+                                                  const int* __restrict__ Ccol, double* __restrict__ Cval, int chunk) {
   __shared__ int scol[RAP_CAP];
   __shared__ double sacc[RAP_CAP];
   const int i = blockIdx.x;
   const int lane = threadIdx.x;
   const int c0 = Crowptr[i];
   const int len = Crowptr[i + 1] - c0;
-  for (int t = lane; t < len; t += 64) {
-    scol[t] = Ccol[c0 + t];
-    sacc[t] = 0.0;
-  }
-  __syncthreads();
-  if (len > 0) {
+  // Rows of C longer than RAP_CAP (SA-AMG middle levels: thousands of entries per row) are accumulated RAP_CAP target
+  // columns at a time: the same walk per chunk, contributions to columns outside the chunk skipped - every entry of C is
+  // still the same sum in the same order, at (number of chunks) times the walk.
+  for (int t0 = 0; t0 < len; t0 += chunk) {          // chunk <= RAP_CAP (host)
+    const int clen = len - t0 < chunk ? len - t0 : chunk;
+    __syncthreads();
+    for (int t = lane; t < clen; t += 64) {
+      scol[t] = Ccol[c0 + t0 + t];
+      sacc[t] = 0.0;
+    }
+    __syncthreads();
+    const int cmin = scol[0], cmax = scol[clen - 1];
     for (int kk = R.rowptr[i]; kk < R.rowptr[i + 1]; ++kk) {        // wave-uniform, stored order
       const int k = R.colidx[kk];
       const double rv = R.val[kk];
@@ -3290,7 +3295,8 @@ __global__ __launch_bounds__(64) void rap_numeric(CsrDev R, CsrDev A, CsrDev P, 
         const double ra = rv * A.val[jj];
         for (int pp = P.rowptr[j] + lane; pp < P.rowptr[j + 1]; pp += 64) {   // distinct columns: one lane each
           const int c = P.colidx[pp];
-          int lo = 0, hi = len - 1;
+          if (c < cmin || c > cmax) continue;                       // (another chunk's column)
+          int lo = 0, hi = clen - 1;
           while (lo < hi) {  // the pattern of C contains every reachable column by construction
             const int mid = (lo + hi) >> 1;
             if (scol[mid] < c) lo = mid + 1;
@@ -3301,9 +3307,9 @@ __global__ __launch_bounds__(64) void rap_numeric(CsrDev R, CsrDev A, CsrDev P, 
         __builtin_amdgcn_wave_barrier();   // one wavefront: LDS accesses of the next row of P follow in program order
       }
     }
+    __syncthreads();
+    for (int t = lane; t < clen; t += 64) Cval[c0 + t0 + t] = sacc[t];
   }
-  __syncthreads();
-  for (int t = lane; t < len; t += 64) Cval[c0 + t] = sacc[t];
 }
 
 // d[i] = omega / a_ii  (getRelaxPrec "Jac", MGsetup.jl:145-147); s[j] += a_ij^2 (getSPAIprec, MGsetup.jl:359-362)

@@ -64,6 +64,7 @@ struct Options {
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
   bool no_tile_small = false;
   bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  long long rap_chunk = 2048;      // target columns of a coarse row the numeric Galerkin product accumulates at a time (<= 2048; tests)
   bool no_dead_t = false;          // solve loop: store the iterate of every step (A/B, bit-identity tests)
   bool no_march3 = false;          // never use the 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv)
   long long march3_k1 = 0;         // rows of the stage-1 region per lane (0: by the fill estimate; 2..4): tile height = K1 * (NT / (TX + 2)) - 2
@@ -98,7 +99,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
-      MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
+      MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
@@ -3592,12 +3593,6 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
   if (nnz != L0.A.nnz) return fail(MG_ERR_INVALID, "nnz=%lld differs from the stored fine pattern (%lld)", nnz, L0.A.nnz);
   (void)hipSetDevice(h->device);
   const int nl = (int)h->nlevels;
-  for (int l = 0; l + 1 < nl; ++l)
-    if (h->lev[(size_t)l + 1].A.max_row_nnz > mgk::RAP_CAP) {
-      if (levels_done) *levels_done = 0;
-      return fail(MG_ERR_UNSUPPORTED, "As[%d] has rows with %d entries (> %d): use the host path", l + 2,
-                  h->lev[(size_t)l + 1].A.max_row_nnz, mgk::RAP_CAP);
-    }
   HIP_TRY(spin_sync(h->stream));
   HIP_TRY(hipMemcpyAsync(L0.A.val.p, fine_nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
   for (int l = 0; l + 1 < nl; ++l) {
@@ -3613,7 +3608,7 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
       hipLaunchKernelGGL(mgk::relax_spai, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), omega[l], L.r.p, L.d.p);
     }
     hipLaunchKernelGGL(mgk::rap_numeric, dim3((unsigned)C.n), dim3(64), 0, h->stream, L.R.dev(), L.A.dev(), L.P.dev(),
-                       C.A.rowptr.p, C.A.colidx.p, C.A.val.p);
+                       C.A.rowptr.p, C.A.colidx.p, C.A.val.p, (int)std::max<long long>(1, std::min<long long>(h->opt.rap_chunk, mgk::RAP_CAP)));
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(spin_sync(h->stream));

@@ -253,13 +253,15 @@ def test_pattern_coded_kernel_paths(mg, built, monkeypatch):
             assert np.abs(got1 - w).max() / scale < KERNEL_TOL
 
 
-@pytest.mark.parametrize("relaxType,omega,cells", [("Jac", 0.8, [16, 16, 16]), ("SPAI", 1.0, [24, 20])])
-def test_replace_matrix_on_device(mg, built, relaxType, omega, cells):
+@pytest.mark.parametrize("relaxType,omega,cells,chunk", [("Jac", 0.8, [16, 16, 16], 0), ("SPAI", 1.0, [24, 20], 0), ("Jac", 0.8, [12, 12, 12], 10)])
+def test_replace_matrix_on_device(mg, built, monkeypatch, relaxType, omega, cells, chunk):
     """replaceMatrixInHierarchy (MGsetup.jl:226-270) with a resident hierarchy: the numeric Galerkin products and
     relaxPrecs are recomputed on the device (mg_rap_FP64) and must equal the host products; the following solve must
     match the oracle on the refreshed host hierarchy."""
     import scipy.sparse as sp
     from multigrid_jl_amd.mgsetup import galerkin
+    if chunk:      # coarse rows longer than the accumulator (SA-AMG middle levels: thousands of entries): 27-entry rows, 10 at a time
+        monkeypatch.setenv("MG_RAP_CHUNK", str(chunk))
     A, mesh = mg.poisson_shifted(cells)
     p = mg.getMGparam(np.float64, np.int64, 3, 8, 6, 1e-10, relaxType, omega, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
     mg.MGsetup(A, mesh, p)
