@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import multigrid_jl_amd as mg
 from multigrid_jl_amd import device as D
+if os.environ.get("AB_LIB"):
+    D._lib = D.load_library(os.path.join(os.path.dirname(D.LIB_PATH), os.environ["AB_LIB"]))
+    print("library:", os.environ["AB_LIB"], flush=True)
 cells = int(sys.argv[1])
 kern = {"restrict": D.MG_K_RESTRICT, "prolong": D.MG_K_PROLONG, "smooth": D.MG_K_SMOOTH, "residual": D.MG_K_RESIDUAL,
         "pair": D.MG_K_SMOOTH_RESIDUAL}[sys.argv[2]]
