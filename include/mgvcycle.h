@@ -308,6 +308,14 @@ int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_c
 int mg_op_create_box_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
                                 const long long* rowval, const double* nzval, long long n1, long long n2, long long n3,
                                 long long regular_cols, mg_operator** out);
+/* A rank's local P of a sharded level with grid hints: rows = the owned fine box f1 x f2 x f3 (== n_rows, natural
+ * x-fastest order), columns = [owned coarse box c1 x c2 x c3 (== regular_cols) | halo].  Rows that read a halo column are
+ * kept apart as exception rows; the others take the LDS-staged prolongation kernel of the single-GPU path where the
+ * pattern fits it (checked on the data).  mg_op_apply_phase_dev_FP64: phase 1 = the rows that read owned coarse entries
+ * only, phase 2 = the exception rows (ParSpMatVec.jl:49-71 semantics unchanged: y = alpha*P*x + beta*y). */
+int mg_op_create_grid_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
+                                 const long long* rowval, const double* nzval, long long regular_cols, long long f1,
+                                 long long f2, long long f3, long long c1, long long c2, long long c3, mg_operator** out);
 /* Announce the relaxPrec vector (device; one entry per row, for a box operator per owned row) the operator will be
  * swept with.  Where it is bit-identical over every dictionary class of a row-class operator, the fused sweeps and the
  * fused residual called with THIS pointer (nrhs = 1, row_offset = 0) read it from the dictionary instead of streaming

@@ -803,6 +803,10 @@ __global__ __launch_bounds__(WP_T) void csr_rowclass_winp_spmv(RowClassDev C, Ve
     cq[j] = C.cls[rr];
     wfi[j] = T.wf[rr];
     pb[j] = (v.beta != 0.0) ? v.beta * v.y[rr] : 0.0;
+    if (cq[j] == 0xFFFF) {   // an exception row (reads halo columns): csr_rows_spmv computes it
+      in[j] = false;
+      cq[j] = 0;
+    }
   }
   {
     const int czz = T.cz0[z];

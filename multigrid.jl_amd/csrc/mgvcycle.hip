@@ -320,6 +320,10 @@ struct Csr {
   // Local operator of a sharded level: columns >= regular_cols are halo columns (appended after the owned ones); rows
   // that reference one are forced to be exception rows, the first regular_cols rows are the owned box in natural order
   long long regular_cols = -1;
+  // rows >= regular_rows are empty halo rows (-1: the square box form, regular_rows == regular_cols; a prolongation over
+  // [owned coarse | halo] columns has all its rows regular)
+  long long regular_rows = -1;
+  long long reg_rows() const { return regular_cols < 0 ? n_rows : (regular_rows >= 0 ? regular_rows : std::min(regular_cols, n_rows)); }
   mgk::TileDev tiledev() const {
     mgk::TileDev t;
     t.tile_lb = rt_lb.p;
@@ -355,7 +359,7 @@ struct Csr {
     c.nblocks = rc_blocks();
     // a box operator's rows beyond the owned box are empty halo rows: no kernel may touch them - the row operands (b, d, y)
     // are only n_own long, and "a safe row" for idle lanes must be one of the owned rows
-    c.n_rows = (int)(regular_cols >= 0 ? std::min(regular_cols, n_rows) : n_rows);
+    c.n_rows = (int)reg_rows();
     return c;
   }
   void drop_rc() {
@@ -746,11 +750,20 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
       const size_t lds = (size_t)M.rw_doubles * sizeof(double);
       if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, true>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
       else hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, false>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
-    } else if (MODE == mgk::AXPBY && M.rp_ok && phase == 0 && v.y != v.x) {
-      // a prolongation-shaped operator: the coarse windows of a workgroup's rows staged in LDS (no exception rows)
+    } else if (MODE == mgk::AXPBY && M.rp_ok && v.y != v.x) {
+      // a prolongation-shaped operator: the coarse windows of a workgroup's rows staged in LDS; exception rows (a sharded
+      // level's rows that read halo columns) from the CSR arrays - behind it here, or as phase 2 behind the exchange
       const mgk::WinPDev T = M.winpdev();
       nb_main = T.nblocks;
       hipLaunchKernelGGL((mgk::csr_rowclass_winp_spmv<0>), dim3(nb_main), dim3(mgk::WP_T), M.winp_lds_bytes(), stream, C, v, T);
+      if (M.rc_nexc > 0 && phase == 0) {
+        mgk::VecArgs ve = v;
+        ve.d = v.d_full;
+        hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3((M.rc_nexc + mgk::BLK - 1) / mgk::BLK), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, 0);
+      }
+      if (nparts) *nparts = 0;
+      HIP_TRY(hipGetLastError());
+      return MG_OK;
     } else if (M.rc_lane()) {
       nb_main = M.rc_blocks();
       mgk::LaneDev T;
@@ -2845,9 +2858,12 @@ int build_march3(Csr& A, const long long grid[3]) {
 int build_winp(Csr& M, const long long gf[3], const long long gc[3]) {
   if (M.rp_ok && M.rp_PF == gf[0] * gf[1] && M.rp_nplanes == gf[2] && M.rp_PC == gc[0] * gc[1]) return MG_OK;   // (same pattern, same hints)
   M.rp_ok = false;
-  if (!M.has_rc || M.rc_implicit || M.rc_nexc != 0 || M.opt.no_winp || M.regular_cols >= 0) return MG_OK;
+  // (a prolongation of a sharded level: columns [owned coarse box | halo]; the rows that read the halo are exception rows,
+  // computed by csr_rows_spmv behind the exchange - they take no part in the windows)
+  const bool boxp = M.regular_cols >= 0;
+  if (!M.has_rc || M.rc_implicit || (M.rc_nexc != 0 && !boxp) || M.opt.no_winp || (boxp && M.reg_rows() != M.n_rows)) return MG_OK;
   if (gf[0] < 1 || gf[1] < 1 || gf[2] < 1 || gc[0] < 1 || gc[1] < 1 || gc[2] < 1) return MG_OK;
-  if (gf[0] * gf[1] * gf[2] != M.n_rows || gc[0] * gc[1] * gc[2] != M.n_cols) return MG_OK;
+  if (gf[0] * gf[1] * gf[2] != M.n_rows || gc[0] * gc[1] * gc[2] != (boxp ? M.regular_cols : M.n_cols)) return MG_OK;
   if (M.h_rp.size() != (size_t)M.n_rows + 1 || M.h_cls.size() != (size_t)M.n_rows || M.h_rc_ptr.empty()) return MG_OK;
   if (M.rc_ncls * (long long)M.rc_maxlen > 1024 || M.n_rows < M.opt.winp_min_rows) return MG_OK;   // the padded dictionary lives in LDS (16 KB)
   const long long PF = gf[0] * gf[1], PC = gc[0] * gc[1], nz = gf[2];
@@ -2873,18 +2889,22 @@ int build_winp(Csr& M, const long long gf[3], const long long gc[3]) {
   for (long long z = 0; z < nz; ++z)
     for (long long p = 0; p < PF; ++p) {
       const long long i = z * PF + p;
+      if (M.h_cls[(size_t)i] == 0xFFFF) continue;                      // (exception row: not served by the windows)
       if (M.h_rp[(size_t)i + 1] == M.h_rp[(size_t)i]) return MG_OK;   // an empty row has no first column
       cz0[(size_t)z] = std::min<long long>(cz0[(size_t)z], M.h_ci[(size_t)M.h_rp[(size_t)i]] / PC);
     }
+  for (long long z = 0; z < nz; ++z)
+    if (cz0[(size_t)z] == INT_MAX) cz0[(size_t)z] = 0;                 // (a plane of exception rows only)
   const long long chunks = (PF + mgk::WP_ROWS - 1) / mgk::WP_ROWS;
   std::vector<long long> lo((size_t)chunks, LLONG_MAX), hi((size_t)chunks, LLONG_MIN);
   std::vector<char> two((size_t)nz, 0);   // does any row of the plane read the second coarse plane?
   for (long long z = 0; z < nz; ++z)
     for (long long p = 0; p < PF; ++p) {
       const long long i = z * PF + p;
+      const unsigned short c = M.h_cls[(size_t)i];
+      if (c == 0xFFFF) continue;
       const long long fi = (long long)M.h_ci[(size_t)M.h_rp[(size_t)i]] - (long long)cz0[(size_t)z] * PC;   // in-plane index of the first column
       if (fi < 0 || fi >= PC) return MG_OK;
-      const unsigned short c = M.h_cls[(size_t)i];
       if (c >= ncls) return MG_OK;
       if (csecond[c] && (long long)cz0[(size_t)z] + 1 >= gc[2]) return MG_OK;   // would read past the last coarse plane
       if (csecond[c]) two[(size_t)z] = 1;
@@ -2893,13 +2913,17 @@ int build_winp(Csr& M, const long long gf[3], const long long gc[3]) {
       hi[ch] = std::max(hi[ch], fi + cmax[c]);
     }
   long long W = 1;
-  for (size_t ch = 0; ch < (size_t)chunks; ++ch) W = std::max(W, hi[ch] - lo[ch] + 1);
+  for (size_t ch = 0; ch < (size_t)chunks; ++ch) {
+    if (lo[ch] == LLONG_MAX) { lo[ch] = 0; hi[ch] = 0; }              // (a chunk of exception rows only)
+    W = std::max(W, hi[ch] - lo[ch] + 1);
+  }
   W = (W + 1) & ~1LL;   // (the dictionary behind the windows stays 16-byte aligned)
   if (W > 2048) return MG_OK;   // 32 KB of windows per workgroup at most (+ <= 16 KB of dictionary: below the 64 KB default)
   std::vector<unsigned short> wf((size_t)M.n_rows);
   for (long long z = 0; z < nz; ++z)
     for (long long p = 0; p < PF; ++p) {
       const long long i = z * PF + p;
+      if (M.h_cls[(size_t)i] == 0xFFFF) { wf[(size_t)i] = 0; continue; }
       const long long fi = (long long)M.h_ci[(size_t)M.h_rp[(size_t)i]] - (long long)cz0[(size_t)z] * PC;
       const long long w = fi - lo[(size_t)(p / mgk::WP_ROWS)];
       if (w < 0 || w >= W) return MG_OK;
@@ -3147,7 +3171,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     const int s = rp[(size_t)i], e = rp[(size_t)i + 1];
     const int f = (e > s) ? ci[(size_t)s] : 0;
     first[(size_t)i] = f;
-    if (M->regular_cols >= 0 && (i >= M->regular_cols || (e > s && ci[(size_t)e - 1] >= M->regular_cols))) {
+    if (M->regular_cols >= 0 && (i >= M->reg_rows() || (e > s && ci[(size_t)e - 1] >= M->regular_cols))) {
       rid[(size_t)i] = -1;   // halo row, or a row that reads the halo (columns are sorted): forced exception row
       continue;
     }
@@ -3225,7 +3249,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   }
   {
     const double min_cover = M->opt.rowclass_min_cover;
-    const double nreg = (double)(M->regular_cols >= 0 ? M->regular_cols : n);
+    const double nreg = (double)M->reg_rows();
     if (cptr.size() < 2 || (double)covered < min_cover * nreg) return MG_OK;
   }
   std::vector<unsigned short> cid((size_t)n, 0);
@@ -3234,7 +3258,7 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
     const int c = rid[(size_t)i] >= 0 ? remap[(size_t)rid[(size_t)i]] : 0xFFFF;
     cid[(size_t)i] = (unsigned short)c;
     // (the empty halo rows of a padded local operator are never computed: not even exception rows)
-    if (c == 0xFFFF && !(M->regular_cols >= 0 && i >= M->regular_cols)) exc.push_back((int)i);
+    if (c == 0xFFFF && i < M->reg_rows()) exc.push_back((int)i);
   }
   { std::vector<int>().swap(rid); std::vector<int>().swap(roff); std::vector<double>().swap(rval); }
   if (coff.empty()) { coff.push_back(0); cval.push_back(0.0); }
@@ -3420,7 +3444,7 @@ int refresh_rowclasses(Csr* M, const double* val) {
 // CSR (the reference's C side does the -1 per access, parRelax.h:24-27), cut the rows into row blocks
 // and upload.
 int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, const long long* colptr,
-               const long long* rowval, const double* nzval, long long regular_cols = -1) {
+               const long long* rowval, const double* nzval, long long regular_cols = -1, long long regular_rows = -1) {
   if (n_rows < 1 || n_cols < 1 || !colptr || !rowval || !nzval)
     return fail(MG_ERR_INVALID, "empty operator or null array");
   if (n_rows >= (1LL << 31) - 1 || n_cols >= (1LL << 31) - 1)
@@ -3445,7 +3469,7 @@ int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, c
   }
   // row blocks: consecutive rows, <= maxrows rows and an (even-aligned) nnz span <= chunk
   // (a box-form local operator computes its owned rows only: the empty halo rows behind them get no row block)
-  const long long n_rows_blk = regular_cols >= 0 ? std::min(regular_cols, n_rows) : n_rows;
+  const long long n_rows_blk = regular_cols >= 0 ? (regular_rows >= 0 ? regular_rows : std::min(regular_cols, n_rows)) : n_rows;
   auto make_blocks = [&](int maxrows, int chunk) {
     std::vector<int> bl;
     bl.push_back(0);
@@ -3464,6 +3488,7 @@ int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, c
   M->release();
   M->opt = opt;
   M->regular_cols = regular_cols;
+  M->regular_rows = regular_rows;
   M->n_rows = n_rows;
   M->n_cols = n_cols;
   M->nnz = nnz;
@@ -4832,10 +4857,41 @@ int mg_op_create_box_FP64_INT64(long long device_id, long long n_rows, long long
   return MG_OK;
 }
 
+// A transfer operator of a sharded level with grid hints: rows = a fine box f1 x f2 x f3 (n_rows, natural order), columns =
+// [owned coarse box c1 x c2 x c3 (regular_cols) | halo].  The rows that read a halo column become exception rows; the others
+// take the LDS-staged prolongation kernel (csr_rowclass_winp_spmv) when the pattern fits it, with the same phase split as box
+// operators: phase 1 overlaps the exchange of the coarse vector, phase 2 follows it.
+int mg_op_create_grid_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
+                                 const long long* rowval, const double* nzval, long long regular_cols, long long f1, long long f2,
+                                 long long f3, long long c1, long long c2, long long c3, mg_operator** out) {
+  UploadFence upload_fence;
+  if (!out) return fail(MG_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (regular_cols < 1 || regular_cols > n_cols || f1 * f2 * f3 != n_rows || c1 * c2 * c3 != regular_cols)
+    return fail(MG_ERR_INVALID, "grid operator: f1*f2*f3 must equal n_rows and c1*c2*c3 regular_cols <= n_cols");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
+  HIP_TRY(hipSetDevice((int)device_id));
+  mg_operator* op = new mg_operator();
+  op->device = (int)device_id;
+  int rc = upload_csr(&op->M, Options::from_env(), n_rows, n_cols, colptr, rowval, nzval, regular_cols, n_rows);
+  const long long gf[3] = {f1, f2, f3}, gc[3] = {c1, c2, c3};
+  if (rc == MG_OK) rc = build_winp(op->M, gf, gc);
+  if (rc != MG_OK) {
+    op->M.release();
+    delete op;
+    return rc;
+  }
+  *out = op;
+  return MG_OK;
+}
+
 int mg_op_kernel_variant(mg_operator* op, long long* variant, long long* exception_rows) {
   if (!op) return fail(MG_ERR_INVALID, "null operator");
   const Csr& M = op->M;
-  if (variant) *variant = !M.has_rc ? -1 : M.rc_march ? 3 : M.rc_tile ? 2 : M.rc_window ? 1 : M.rc_lane() ? 4 : 0;
+  if (variant) *variant = !M.has_rc ? -1 : M.rc_march ? 3 : M.rc_tile ? 2 : M.rc_window ? 1 : M.rp_ok ? 5 : M.rc_lane() ? 4 : 0;
   if (exception_rows) *exception_rows = M.has_rc ? M.rc_nexc : 0;
   return MG_OK;
 }
@@ -5631,8 +5687,14 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
       MG_TRY(dist_cycle(h, l + 1, C.b.p, xc, other, false, ctype == 'W' ? 'W' : 'V', &xc));
     }
     MG_TRY(dist_exchange_start(h, L.planP, xc));
-    MG_TRY(dist_exchange_finish(h, L.planP));
-    MG_TRY(dist_apply(h, L.P, MG_K_PROLONG, 1.0, xc, 1.0, cur, nullptr, nullptr, 0));
+    if (L.P && L.P->M.regular_cols >= 0) {   // grid form: the rows that read owned coarse entries only run beside the exchange
+      MG_TRY(mg_op_apply_phase_dev_FP64(L.P, MG_K_PROLONG, 1.0, xc, 1.0, cur, nullptr, nullptr, h->nrhs, 0, 1, h->stream));
+      MG_TRY(dist_exchange_finish(h, L.planP));
+      MG_TRY(mg_op_apply_phase_dev_FP64(L.P, MG_K_PROLONG, 1.0, xc, 1.0, cur, nullptr, nullptr, h->nrhs, 0, 2, h->stream));
+    } else {
+      MG_TRY(dist_exchange_finish(h, L.planP));
+      MG_TRY(dist_apply(h, L.P, MG_K_PROLONG, 1.0, xc, 1.0, cur, nullptr, nullptr, 0));
+    }
   } else {
     // restrict into this rank's rows of the first replicated level, all-gather, run the tail replicated
     MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, h->bc_pad.p, nullptr, nullptr, 0));

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mg_device_bytes": (C.c_int, [_vp, _dp]),
     "mg_op_create_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, C.POINTER(_vp)]),
     "mg_op_create_box_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, _ll, _ll, _ll, _ll, C.POINTER(_vp)]),
+    "mg_op_create_grid_FP64_INT64": (C.c_int, [_ll, _ll, _ll, _lp, _lp, _dp, _ll, _ll, _ll, _ll, _ll, _ll, _ll,
+                                               C.POINTER(_vp)]),
     "mg_op_bind_relax_dev_FP64": (C.c_int, [_vp, _vp, _ll]),
     "mg_op_kernel_variant": (C.c_int, [_vp, _lp, _lp]),
     "mg_op_apply_phase_dev_FP64": (C.c_int, [_vp, _ll, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _ll, _ll, _ll, _vp]),
@@ -618,9 +620,10 @@ class DeviceOperator:
     """One CSR operator resident in HBM on its own (``mg_operator``): the building block of the multi-GPU
     cycle, where a rank holds its rows of A/P/R with halo columns appended.  Asynchronous on `stream`."""
 
-    def __init__(self, M, device_id: int = 0, box=None, regular_cols=None):
+    def __init__(self, M, device_id: int = 0, box=None, regular_cols=None, coarse_box=None):
         """box=(n1,n2,n3), regular_cols: the BOX form of a sharded level's local A (mg_op_create_box_FP64_INT64): M is
-        square [owned box in natural order | halo] with empty halo rows."""
+        square [owned box in natural order | halo] with empty halo rows.  With coarse_box=(c1,c2,c3) as well: the grid form
+        of a local P (mg_op_create_grid_FP64_INT64): rows = the owned fine box `box`, columns = [owned coarse box | halo]."""
         self.lib = load_library()
         self.handle = _vp()
         colptr, rowval, nzval = _julia_arrays(M)
@@ -630,7 +633,14 @@ class DeviceOperator:
         self.shape = M.shape
         self.nnz = int(M.nnz)
         self.box = box is not None
-        if box is not None:
+        if box is not None and coarse_box is not None:
+            f = (list(box) + [1, 1])[:3]
+            c = (list(coarse_box) + [1, 1])[:3]
+            _check(self.lib, self.lib.mg_op_create_grid_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),
+                                                                   _i64(rowval), _f64(nzval), int(regular_cols),
+                                                                   int(f[0]), int(f[1]), int(f[2]), int(c[0]), int(c[1]),
+                                                                   int(c[2]), C.byref(self.handle)), "mg_op_create_grid")
+        elif box is not None:
             n1, n2, n3 = (list(box) + [1, 1])[:3]
             _check(self.lib, self.lib.mg_op_create_box_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),
                                                                   _i64(rowval), _f64(nzval), int(n1), int(n2), int(n3),

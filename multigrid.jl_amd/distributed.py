@@ -272,8 +272,8 @@ class HipBackend:
 
     supports_box = True          # box-form local operators (mg_op_create_box_FP64_INT64) with phase-split launches
 
-    def operator(self, M, box=None, regular_cols=None):
-        return D.DeviceOperator(M, self.device_id, box=box, regular_cols=regular_cols)
+    def operator(self, M, box=None, regular_cols=None, coarse_box=None):
+        return D.DeviceOperator(M, self.device_id, box=box, regular_cols=regular_cols, coarse_box=coarse_box)
 
     def bind_relax(self, op, d, n):
         self.synchronize()
@@ -447,7 +447,13 @@ class DistributedHierarchy:
                 # A is held as two operators: interior rows (no halo columns) and boundary rows
                 L.A_int = be.operator(A[: L.n_int, :]) if L.n_int > 0 else None
                 L.A_bnd = be.operator(A[L.n_int:, :]) if L.n_int < L.n_own else None
-            L.R, L.P = be.operator(ld["R"]), be.operator(ld["P"])
+            L.R = be.operator(ld["R"])
+            if self.box_form and ld.get("cbox") is not None and not _os.environ.get("MG_DIST_NO_GRID_P"):
+                # grid form of P: rows = the owned fine box, columns = [owned coarse box | halo] (or the whole replicated
+                # coarse grid): the LDS-staged prolongation kernel serves the rows that read no halo column
+                L.P = be.operator(ld["P"], box=L.box, regular_cols=int(ld["cbox_cols"]), coarse_box=tuple(int(v) for v in ld["cbox"]))
+            else:
+                L.P = be.operator(ld["P"])
             L.nnzA, L.nnzR, L.nnzP = ld["A"].nnz, ld["R"].nnz, ld["P"].nnz
             L.d = be.from_numpy(np.asarray(ld["d"], dtype=np.float64))
             if hasattr(be, "bind_relax") and L.A_int is not None:      # relaxPrec from the class dictionary where possible
@@ -534,10 +540,19 @@ class DistributedHierarchy:
             R_loc, planR = localize(param.Rs[l], cpart, part, rank)
             # the prolongation gathers the sharded x_{l+1}, or the replicated tail solution (no halo)
             P_loc, planP = localize(param.Ps[l], part, cpart if l + 1 < a else None, rank)
+            cbox, cbox_cols = None, 0
+            if level_nodes is not None and l + 1 < len(level_nodes):
+                if l + 1 < a:       # columns of P: [this rank's box of the next sharded level | halo]
+                    cbox, cbox_cols = _box_of_rows(cpart.rows[rank], level_nodes[l + 1]), int(cpart.counts[rank])
+                else:               # the replicated tail: the whole coarse grid
+                    cbox, cbox_cols = tuple(int(v) for v in level_nodes[l + 1]), int(P_loc.shape[1])
+                    if int(np.prod(cbox)) != cbox_cols:
+                        cbox = None
             local_levels.append(dict(n_own=int(part.counts[rank]), A=A_loc, planA=planA, R=R_loc, planR=planR,
                                      P=P_loc, planP=planP, d=np.asarray(param.relaxPrecs[l])[part.rows[rank]],
                                      npre=param.relaxPre(l + 1), npost=param.relaxPost(l + 1),
-                                     box=_box_of_rows(part.rows[rank], level_nodes[l]) if level_nodes is not None else None))
+                                     box=_box_of_rows(part.rows[rank], level_nodes[l]) if level_nodes is not None else None,
+                                     cbox=cbox, cbox_cols=cbox_cols))
         H = cls(comm, backend, local_levels, _sub_hierarchy(param, a), part_tail.owner, part_tail.local_index,
                 part_tail.counts, parts[0].rows[rank], param.cycleType, nl, nrhs)
         H.parts, H.part_tail = parts, part_tail

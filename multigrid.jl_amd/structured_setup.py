@@ -218,9 +218,16 @@ def structured_gmg(global_cells, numDomains, comm, backend, param: MGparam, oper
         planR = _make_plan([r_.get(("R", l), {}) for r_ in req_all], g, rank, size, rsR, nhR)
         planP = _make_plan([r_.get(("P", l), {}) for r_ in req_all], gc, rank, size, rsP, nhP) if rsP is not None else None
         from .distributed import _box_of_rows
+        if l + 1 < a:       # columns of P: [this rank's box of the next sharded level | halo]
+            cbox, cbox_cols = _box_of_rows(gc.own_gid, gc.glob_nodes), int(gc.own_loc.size)
+        else:               # the replicated tail: the whole coarse grid
+            cbox, cbox_cols = tuple(int(v) for v in gc.glob_nodes), int(P_loc.shape[1])
+            if int(np.prod(cbox)) != cbox_cols:
+                cbox = None
         local_levels.append(dict(n_own=int(g.own_loc.size), A=A_loc, planA=planA, R=R_loc, planR=planR, P=P_loc,
                                  planP=planP, d=np.asarray(ds[l])[g.own_loc], npre=param.relaxPre(l + 1),
-                                 npost=param.relaxPost(l + 1), box=_box_of_rows(g.own_gid, g.glob_nodes)))
+                                 npost=param.relaxPost(l + 1), box=_box_of_rows(g.own_gid, g.glob_nodes),
+                                 cbox=cbox, cbox_cols=cbox_cols))
     # ---- the replicated tail: assemble its finest operator from everybody's rows, then plain MGsetup -----
     nt = nglob[a]
     rows_i, cols_i, vals_i = [], [], []

@@ -26,8 +26,10 @@ class CpuCheckerBackend:
 
     supports_box = True
 
-    def operator(self, M, box=None, regular_cols=None):
+    def operator(self, M, box=None, regular_cols=None, coarse_box=None):
         M = M.tocsr()
+        if coarse_box is not None:     # grid form of P: every row is computed, the hints only pick a kernel on the device
+            return M
         if box is not None:            # box form: square [owned box | halo], only the owned rows are ever computed
             M = M[: int(regular_cols), :].tocsr()
             M._mg_box = True

@@ -58,7 +58,8 @@ def _problem(kind, nrhs, cyc):
 def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", native=None, box=False):
     if box and box != "plain" and use_hip:       # let the small local operators of the test take the row-class / staged kernels
         os.environ.update(MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3",
-                          MG_MARCH_MIN_WG="0", MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_MARCH_MAX_LEN="64")
+                          MG_MARCH_MIN_WG="0", MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_MARCH_MAX_LEN="64",
+                          MG_WINP_MIN_ROWS="0")
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -92,6 +93,10 @@ def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", nati
             assert var[0][0] in (1, 2, 3) and (world == 1 or var[0][1] > 0), var   # a staged kernel + exception rows
             if len(nodes) == 3:
                 assert var[0][0] == 3, var                                     # 3-D fine level: z-marching
+            pv = [L.P.kernel_variant() for L in H.levels]
+            assert pv[0][0] == 5, pv                  # grid form of P: coarse windows staged in LDS ...
+            assert world == 1 or rank != 0 or pv[0][1] > 0, pv   # ... + the rows that read halo columns (the interface nodes
+                                                                 # belong to the upper box: rank 0 reads them), behind the exchange
         S = H
         if native:          # the same local operators and plans, the loop in C++ (mg_dist_*): "plugin" or "rccl" transport
             S = dd.NativeDistributedHierarchy(H, transport=native)
