@@ -423,32 +423,58 @@ def main():
     # ---- the same K steps with the STREAMING formats forced for this handle (mg_set_option no_rowclass = 1): what
     # an operator without repeated rows gets (variable coefficients, SA-AMG); its SURVEY 8d fraction ------------------
     if nrhs == 1 and roofline.get("row_classes_L1") and not args.no_generic_pass:
-        hg = mg.device.DeviceHierarchy(p, device_id=local_rank, nrhs=nrhs, options={"no_rowclass": 1})
-        xg = torch.zeros_like(b)
-        hg.solve_dev(b, xg, 0.0, max(1, W))
-        xg.zero_()
-        barrier()
-        t0 = time.perf_counter()
-        itg, resg = hg.solve_dev(b, xg, 0.0, K)
-        barrier()
-        dtg = time.perf_counter() - t0
-        profg, movedg, totg = profiled_pass(hg, b, xg, K, torch)
-        kg, fg = kernel_symbol(hg, mg, p, 1, nrhs)
-        msg, cntg, btsg = profg[(1, "smooth")]
-        ag = msg / cntg
-        roofline["generic_csr"] = {
-            "kernel": kg, "device_format": fg, "avg_launch_ms": round(ag, 5), "launches": cntg,
-            "algorithmic_bytes_per_launch": btsg, "achieved": round(btsg / ag / 1e6, 1),
-            "frac": round(btsg / ag / 1e6 / HBM_PEAK_GBS, 4),
-            "moved_bytes_per_launch": movedg[(1, "smooth")],
-            "moved_frac": round(movedg[(1, "smooth")] / ag / 1e6 / HBM_PEAK_GBS, 4),
-            "ms_per_step": round(dtg / K * 1e3, 4), "dof_updates_per_s": round(n * nrhs * K / dtg, 1),
-            "resvec_rel_diff_vs_default": float(np.abs(resg - resvec).max() / resvec[0]),
-            "note": "fine-level fused sweep of the same workload with row classes disabled through the API for a second "
-                    "handle; `frac` is SURVEY 8d's ALGORITHMIC CSR bytes / time / peak (the north_star's 60 % target), "
-                    "`moved_frac` uses the bytes the pattern-coded kernel streams"}
-        hg.close()
-        del xg
+        def generic_pass(opts):
+            hg = mg.device.DeviceHierarchy(p, device_id=local_rank, nrhs=nrhs, options=opts)
+            xg = torch.zeros_like(b)
+            hg.solve_dev(b, xg, 0.0, max(1, W))
+            xg.zero_()
+            barrier()
+            t0 = time.perf_counter()
+            itg, resg = hg.solve_dev(b, xg, 0.0, K)
+            barrier()
+            dtg = time.perf_counter() - t0
+            profg, movedg, totg = profiled_pass(hg, b, xg, K, torch)
+            formg, _ = hg.sweep_residual_form(1)
+            kg, fg = kernel_symbol(hg, mg, p, 1, nrhs)
+            hg.close()
+            del xg
+            return dtg, resg, profg, movedg, formg, kg, fg
+
+        def launch_line(prof_, moved_, key):
+            if key not in prof_ or prof_[key][1] == 0:
+                return None
+            ms_, cnt_, bts_ = prof_[key]
+            a_ = ms_ / cnt_
+            return {"avg_launch_ms": round(a_, 5), "launches": cnt_, "algorithmic_bytes_per_launch": bts_,
+                    "achieved": round(bts_ / a_ / 1e6, 1), "frac": round(bts_ / a_ / 1e6 / HBM_PEAK_GBS, 4),
+                    "moved_bytes_per_launch": moved_[key], "moved_frac": round(moved_[key] / a_ / 1e6 / HBM_PEAK_GBS, 4)}
+
+        dtg, resg, profg, movedg, formg, kg, fg = generic_pass({"no_rowclass": 1})
+        gen = {"ms_per_step": round(dtg / K * 1e3, 4), "dof_updates_per_s": round(n * nrhs * K / dtg, 1),
+               "resvec_rel_diff_vs_default": float(np.abs(resg - resvec).max() / resvec[0]),
+               "note": "the same workload with row classes disabled through the API for a second handle: what an operator "
+                       "without repeated rows gets (variable coefficients; jInv's div sigma grad).  `frac` is SURVEY 8d's "
+                       "ALGORITHMIC CSR bytes / time / peak (the north_star's 60 % target), `moved_frac` the bytes the kernel streams"}
+        if formg == 4:      # band form: sweep + residual in one pass, the values streamed once from planar arrays
+            pair = launch_line(profg, movedg, (1, "smooth+residual"))
+            pairn = launch_line(profg, movedg, (1, "smooth+residual+norm"))
+            gen.update({"kernel": "mgk::csr_rowclass_march3_spmv<false, 5, 512, K1, 2, true>", "device_format": "band form (structure "
+                        "classes as a product map + 7 planar value arrays), fine level; pattern-coded CSR below", "sweep_residual_pair": pair,
+                        "sweep_residual_norm_pair": pairn})
+            if pair:
+                gen.update({k: pair[k] for k in ("avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "achieved", "frac",
+                                                 "moved_bytes_per_launch", "moved_frac")})
+            # the CSR kernels alone (round 2's path for such operators), for comparison
+            dt0, res0, prof0, moved0, _, k0, f0 = generic_pass({"no_rowclass": 1, "no_band": 1})
+            line0 = launch_line(prof0, moved0, (1, "smooth")) or {}
+            line0.update({"kernel": k0, "device_format": f0, "ms_per_step": round(dt0 / K * 1e3, 4),
+                          "resvec_rel_diff_vs_default": float(np.abs(res0 - resvec).max() / resvec[0])})
+            gen["without_band"] = line0
+        else:
+            line = launch_line(profg, movedg, (1, "smooth")) or {}
+            gen.update(line)
+            gen.update({"kernel": kg, "device_format": fg})
+        roofline["generic_csr"] = gen
 
     # ---- CPU baseline: the C/OpenMP oracle ("port") on a bounded sample of the same workload ----
     cpu = None

@@ -1960,6 +1960,8 @@ struct March3Dev {
   int nblocks;
   int segs, seglen;             // lockstep schedule: segs > 0: workgroup w = segment (w / tiles) of tile (w % tiles)
   int n_cols, ncls;
+  const double* vband;          // VAR (coefficients differ from row to row): 7 planar arrays of n_rows values, slot k at
+  long long vstride;            // vband + k*vstride: k = 0 the z-1 entry, 1..5 the in-plane entries in stored order, 6 the z+1 entry
   int has_exc;                  // box operator of a sharded level: the table holds 0xFFFF for rows that read the halo (neither
                                 // stage is computed here) and cmap continues with sx[n1] | sy[n2] | sz[nplanes]: stage 2 of
                                 // row (x, y, z) is left out where sx[x] | sy[y] | sz[z] (a neighbour is such a row)
@@ -1971,7 +1973,14 @@ struct March3Dev {
 #ifndef MG_M3_EXP
 #define MG_M3_EXP 0   // attribution builds (make variant): 1 no class walks, 2 no slab/operand loads, 3 no stores
 #endif
-template <bool ZERO, int OUT, int NT, int K1, int NPM>
+// VAR (round 3): the same pass for grid operators whose COEFFICIENTS differ from row to row (div sigma grad - what jInv feeds
+// this package; MGsetup.jl:226-270 exists because sigma changes every outer iteration).  The classes then describe the
+// STRUCTURE only (which neighbours a row has: offsets, no values), still as a verified product map; the values are streamed
+// from 7 planar arrays (T.vband: coalesced 8-byte loads along x, 0 where a row has no such entry) and relaxPrec from the
+// level's vector, both one plane ahead like b.  Stage 2 of plane z-1 reuses the values stage 1 of that plane loaded one
+// iteration earlier (registers): the pair streams the matrix ONCE - 56 + 8 B/row instead of 2 x (56 + 4 + 8) through the
+// pattern-coded CSR kernels.
+template <bool ZERO, int OUT, int NT, int K1, int NPM, bool VAR = false>
 __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, March2Args a, March3Dev T) {
   extern __shared__ double win[];
   __shared__ double red[NT / 64];
@@ -1996,7 +2005,8 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     const double* srcd = reinterpret_cast<const double*>(T.cls);
     double* dstd = reinterpret_cast<double*>(dcl);
     for (int i = tid; i < nw; i += NT) dstd[i] = srcd[i];
-    for (int i = tid; i < T.ncls; i += NT) dd[i] = C.cls_d[i];
+    if (!VAR)
+      for (int i = tid; i < T.ncls; i += NT) dd[i] = C.cls_d[i];
     const int nm = (T.n1 + T.n2 + T.nplanes) * (T.has_exc ? 2 : 1) + T.ntab;
     for (int i = tid; i < nm; i += NT) cxL[i] = T.cmap[i];
   }
@@ -2037,7 +2047,8 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   double sq = 0.0;
   // class records of the lane (registers)
   double rlo = 0.0, rhi = 0.0, rv[RM3_NIP];
-  int ro[RM3_NIP], rflag = 0, rcls = -1;
+  int ro[RM3_NIP], rcls = -1;
+  [[maybe_unused]] int rflag = 0;
 #pragma unroll
   for (int u = 0; u < RM3_NIP; ++u) {
     rv[u] = 0.0;
@@ -2065,6 +2076,18 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) (acc) = (acc) + rv[u_] * xv_[u_];                           \
     (acc) = (acc) + rhi * (hi_);                                                                                       \
   } while (0)
+  // VAR: the same walk with the row's own values vv_[0..6] (z-1, in-plane x RM3_NIP, z+1); the record gives the offsets
+#define M3_WALKV(acc, lo_, hi_, slab, base8, vv_)                                                                      \
+  if (MG_M3_EXP != 1) do {                                                                                             \
+    double xv_[RM3_NIP];                                                                                               \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_)                                                             \
+      xv_[u_] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(slab) + ((base8) + ro[u_]));            \
+    (acc) = (acc) + (vv_)[0] * (lo_);                                                                                  \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) (acc) = (acc) + (vv_)[1 + u_] * xv_[u_];                    \
+    (acc) = (acc) + (vv_)[RM3_NIP + 1] * (hi_);                                                                        \
+  } while (0)
+  constexpr int NV = VAR ? RM3_NIP + 2 : 1;   // values per row kept in registers
+  constexpr int KV = VAR ? K1 : 1;
   __syncthreads();   // dictionaries in place
   while (it < it_end) {
     const int c = (int)(it / T.nplanes);
@@ -2143,8 +2166,8 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       const int c0_ = pr1[m] - M3_PAR(p, m);                                                                           \
       const int k0_ = M3_PAIRCLS(m, c0_, zb_), k1_ = M3_PAIRCLS(m, c0_ + 1, zb_);                                      \
       const long long e_ = (((long long)(p) * T.P + pg[m]) & ~1LL);                                                    \
-      (v).x = (k0_ == 0xFFFF ? M3_DROW(e_) : dd[k0_]) * (v).x;                                                         \
-      (v).y = (k1_ == 0xFFFF ? M3_DROW(e_ + 1) : dd[k1_]) * (v).y;                                                     \
+      (v).x = ((VAR || k0_ == 0xFFFF) ? M3_DROW(e_) : dd[k0_]) * (v).x;                                                \
+      (v).y = ((VAR || k1_ == 0xFFFF) ? M3_DROW(e_ + 1) : dd[k1_]) * (v).y;                                            \
     }                                                                                                                  \
   } while (0)
     // ---- fill the ring: planes z0-1 (slot 0) and z0 (slot 1); plane z0+1 goes into registers ----------------------------
@@ -2169,12 +2192,18 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     }
     // b of plane zz for every slot's row (a safe row where the slot is not live)
     double nb_[K1];
+    double nv_[KV][NV], nd_[KV];   // VAR: the rows' values and relaxPrec, in flight with b
 #define M3_OPERANDS(zz)                                                                                                \
   do {                                                                                                                 \
     const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
     _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
       const int r_ = (pv_ && ((live1 >> s_) & 1u)) ? (zz) * T.P + ip0 + s_ * ipstride : C.n_rows - 1;                  \
       nb_[s_] = MG_M3_EXP == 2 ? 1.0 : a.b[r_];                                                                        \
+      if (VAR) {                                                                                                       \
+        _Pragma("unroll") for (int k_ = 0; k_ < NV; ++k_)                                                              \
+          nv_[s_ % KV][k_] = MG_M3_EXP == 2 ? 1.0 : __builtin_nontemporal_load(T.vband + ((size_t)k_ * (size_t)T.vstride + (size_t)r_)); \
+        nd_[s_ % KV] = MG_M3_EXP == 2 ? 1.0 : a.d[r_];                                                                 \
+      }                                                                                                                \
     }                                                                                                                  \
   } while (0)
     M3_OPERANDS(z0 - 1);
@@ -2187,7 +2216,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
         const int r_ = (z0 - 2) * T.P + ip0 + s * ipstride;
         if (ZERO) {
           const int k_ = (int)tabL[(int)czL[z0 - 2] * zstride + rp[s]];
-          xm[s] = (k_ == 0xFFFF ? a.d[r_] : dd[k_]) * a.b[r_];
+          xm[s] = ((VAR || k_ == 0xFFFF) ? a.d[r_] : dd[k_]) * a.b[r_];
         } else {
           xm[s] = a.x[r_];
         }
@@ -2205,8 +2234,15 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       xc[s] = ((live1 >> s) & 1u) ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xw) + (own8 + s * sstride8)) : 0.0;
     double t1[K1], t2[K1];         // own t of planes z-1, z-2
     double b1[K1];                 // b of plane z-1 (stage 2)
+    double v1[KV][NV], d1[KV];     // VAR: values and relaxPrec of the rows of plane z-1 (stage 2)
 #pragma unroll
     for (int s = 0; s < K1; ++s) t1[s] = t2[s] = b1[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < KV; ++s) {
+      d1[s] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v1[s][k] = 0.0;
+    }
     int qz = 0;                    // ring slot of plane z (plane z0-1 is slot 0)
     for (int z = z0 - 1; z <= z1; ++z) {
       d2_t cur[NPM];
@@ -2220,6 +2256,19 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       for (int s = 0; s < K1; ++s) {
         b0[s] = nb_[s];
         asm volatile("" : "+v"(b0[s]));
+      }
+      double v0[KV][NV], d0[KV];
+      if (VAR) {
+#pragma unroll
+        for (int s = 0; s < KV; ++s) {
+          d0[s] = nd_[s];
+          asm volatile("" : "+v"(d0[s]));
+#pragma unroll
+          for (int k = 0; k < NV; ++k) {
+            v0[s][k] = nv_[s][k];
+            asm volatile("" : "+v"(v0[s][k]));
+          }
+        }
       }
       const int q1 = qz == 2 ? 0 : qz + 1, q2 = q1 == 2 ? 0 : q1 + 1;   // slots of planes z+1, z+2
       // ---- x plane z+2 into its slot (that of plane z-1, last read before the previous barrier) ------------------------
@@ -2258,8 +2307,12 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
           if (cq != 0xFFFF) {                           // (0xFFFF: a row that reads the halo - computed after the exchange)
             if (cq != rcls) M3_LOADRECS(cq);
             double acc = 0.0;
-            M3_WALK(acc, xm[s], xp, xw, qz * XS * 8 + o8);
-            const double tv = xc[s] + dd[cq] * (b0[s] - acc);
+            if (VAR) {
+              M3_WALKV(acc, xm[s], xp, xw, qz * XS * 8 + o8, v0[s % KV]);
+            } else {
+              M3_WALK(acc, xm[s], xp, xw, qz * XS * 8 + o8);
+            }
+            const double tv = xc[s] + (VAR ? d0[s % KV] : dd[cq]) * (b0[s] - acc);
             *reinterpret_cast<double*>(reinterpret_cast<char*>(tw) + ((z & 1) * TS * 8 + o8 + tdelta8)) = tv;
             tc[s] = tv;
           }
@@ -2281,10 +2334,14 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
             if (cq != rcls) M3_LOADRECS(cq);
             const int o8 = own8 + s * sstride8 + tdelta8;
             double acc = 0.0;
-            M3_WALK(acc, t2[s], tc[s], tw, ((z - 1) & 1) * TS * 8 + o8);
+            if (VAR) {
+              M3_WALKV(acc, t2[s], tc[s], tw, ((z - 1) & 1) * TS * 8 + o8, v1[s % KV]);
+            } else {
+              M3_WALK(acc, t2[s], tc[s], tw, ((z - 1) & 1) * TS * 8 + o8);
+            }
             const double rr = b1[s] - acc;
             st_r[s] = rr;
-            st_x[s] = t1[s] + dd[cq] * rr;
+            st_x[s] = t1[s] + (VAR ? d1[s % KV] : dd[cq]) * rr;
             sq += rr * rr;
             done2 |= 1u << s;
           }
@@ -2318,6 +2375,14 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
         t1[s] = tc[s];
         b1[s] = b0[s];
       }
+      if (VAR) {
+#pragma unroll
+        for (int s = 0; s < KV; ++s) {
+          d1[s] = d0[s];
+#pragma unroll
+          for (int k = 0; k < NV; ++k) v1[s][k] = v0[s][k];
+        }
+      }
       qz = q1;
       __syncthreads();
     }
@@ -2334,6 +2399,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   }
 #undef M3_LOADRECS
 #undef M3_WALK
+#undef M3_WALKV
 #undef M3_X1
 #undef M3_PAR
 #undef M3_PAIRCLS

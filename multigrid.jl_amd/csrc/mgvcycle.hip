@@ -63,7 +63,7 @@ struct Options {
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
   bool no_tile_small = false;
-  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_band = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   long long rap_chunk = 2048;      // target columns of a coarse row the numeric Galerkin product accumulates at a time (<= 2048; tests)
   bool no_dead_t = false;          // solve loop: store the iterate of every step (A/B, bit-identity tests)
   bool no_march3 = false;          // never use the 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv)
@@ -77,6 +77,7 @@ struct Options {
   long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
   long long march_wg_per_cu = 2;   // resident workgroups per CU of the marching kernel (49 KB of LDS each)
   long long winp_min_rows = 100000;   // smallest prolongation-shaped operator served by csr_rowclass_winp_spmv
+  long long band_min_rows = 100000;   // smallest variable-coefficient grid operator held in band form (build_band)
   long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
   bool dist_tail_graph = false;   // replay the replicated tail of the sharded sequencer as a HIP graph (measured slower)
   bool no_graph = false, no_lane_pairs = false;
@@ -98,7 +99,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
@@ -109,7 +110,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
       MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
       MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
-      MG_OPT("MG_MARCH_WG_PER_CU", "march_wg_per_cu", 1, march_wg_per_cu), MG_OPT("MG_WINP_MIN_ROWS", "winp_min_rows", 1, winp_min_rows),
+      MG_OPT("MG_MARCH_WG_PER_CU", "march_wg_per_cu", 1, march_wg_per_cu), MG_OPT("MG_WINP_MIN_ROWS", "winp_min_rows", 1, winp_min_rows), MG_OPT("MG_BAND_MIN_ROWS", "band_min_rows", 1, band_min_rows),
       MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_DIST_TAIL_GRAPH", "dist_tail_graph", 0, dist_tail_graph), MG_OPT("MG_NO_LANE_PAIRS", "no_lane_pairs", 0, no_lane_pairs), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
       MG_OPT("MG_LU_MULTI_MIN_ROWS", "lu_multi_min_rows", 1, lu_multi_min_rows),
       MG_OPT("MG_LU_DENSE_TAIL_MAX", "lu_dense_tail_max", 1, lu_dense_tail_max),
@@ -221,6 +222,12 @@ struct Csr {
   size_t rm3_lds = 0;
   int rm3_k1 = 3, rm3_nt = 1024;
   double rm3_fill = 0.0;    // estimated L1 fills + stores per row (bytes) of the chosen geometry
+  // the same pass for a grid operator WITHOUT row classes (coefficients differ from row to row): structure classes + the
+  // values in 7 planar arrays (build_band)
+  bool rm3_var = false;
+  DevBuf<double> vband;
+  long long vstride = 0;
+  long long band_ncls = 0;
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
   bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
   int rt_cr = mgk::RT_CR;   // rows of a plane per workgroup: 1024, or 256 on levels too small to fill the chip with 1024-row tiles
@@ -379,6 +386,8 @@ struct Csr {
     rc_march = false;
     rc_march2 = false;
     rc_march3 = false;
+    rm3_var = false;
+    vband.release();
     rm3_cls.release();
     rm3_cmap.release();
     rc_exc2.release();
@@ -961,28 +970,39 @@ int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const do
 // for the level's own A with its own relaxPrec read from the class dictionary.  x, t, r, xn: four different buffers.
 bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* t, const double* r, const double* xn) {
   const Level& L = h->lev[(size_t)level];
-  if (h->nrhs != 1 || h->relax_type != 0 || !L.A.has_rc || !L.A.rc_has_d || L.A.rc_nexc != 0) return false;
-  if (!(L.A.rc_march && L.A.rc_march2) && !L.A.rc_march3) return false;
-  if (L.A.d_bound != L.d.p) return false;   // the dictionary's relaxPrec is this level's
+  if (h->nrhs != 1 || h->relax_type != 0) return false;
+  if (L.A.rm3_var && L.A.rc_march3) {        // band form: values and relaxPrec are streamed per row
+    if (!L.relax_set) return false;
+  } else {
+    if (!L.A.has_rc || !L.A.rc_has_d || L.A.rc_nexc != 0) return false;
+    if (!(L.A.rc_march && L.A.rc_march2) && !L.A.rc_march3) return false;
+    if (L.A.d_bound != L.d.p) return false;   // the dictionary's relaxPrec is this level's
+  }
   if ((t && (x == t || t == r || t == xn)) || x == r || x == xn || (r && r == xn)) return false;   // (t, r, xn: each optional)
   return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
 // the 2-D tile form (csr_rowclass_march3_spmv): template arguments from what is wanted
-template <bool ZERO, int OUT, int NT, int K1>
+template <bool ZERO, int OUT, int NT, int K1, bool VAR = false>
 int launch_march3(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
-  auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, NT, K1, RM3_NPM>;
+  auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, NT, K1, RM3_NPM, VAR>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm3.nblocks), dim3(NT), A.rm3_lds, stream, A.rcdev(), a, A.rm3);
+  mgk::RowClassDev C = A.rcdev();
+  if (VAR) {
+    C = mgk::RowClassDev{};
+    C.n_rows = (int)A.n_rows;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm3.nblocks), dim3(NT), A.rm3_lds, stream, C, a, A.rm3);
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
 template <bool ZERO, int OUT>
 int launch_march3_k(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
+  if (A.rm3_var) return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 512, 2, true>(stream, A, a) : launch_march3<ZERO, OUT, 512, 3, true>(stream, A, a);
   if (A.rm3_nt == 768) return A.rm3_k1 == 3 ? launch_march3<ZERO, OUT, 768, 3>(stream, A, a) : launch_march3<ZERO, OUT, 768, 4>(stream, A, a);
   return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 1024, 2>(stream, A, a) : launch_march3<ZERO, OUT, 1024, 3>(stream, A, a);
 }
@@ -1014,7 +1034,9 @@ int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::Marc
   {
     // moved: no class-id stream in this form (the ids come from the product map) - the class records, the index maps, x and b
     // in, the outputs asked for out
-    const double tables = (double)A.rc_ncls * 88.0 + 2.0 * (double)(A.rm3.n1 + A.rm3.n2 + A.rm3.nplanes + A.rm3.ntab);
+    // (band form: + the 7 planar value arrays and relaxPrec, once for both stages)
+    const double tables = (double)(A.rm3_var ? A.band_ncls : A.rc_ncls) * 88.0 + 2.0 * (double)(A.rm3.n1 + A.rm3.n2 + A.rm3.nplanes + A.rm3.ntab) +
+                          (A.rm3_var ? 8.0 * (double)(mgk::RM3_NIP + 3) * (double)A.n_rows : 0.0);
     ProfScope ps(h, level, a.sumsq ? MG_K_SMOOTH_RESIDUAL_NORM : MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (a.xn && a.r ? n8 : 0.0),
                  tables + n8 * (2.0 + (a.t ? 1.0 : 0.0) + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
     // the combinations the cycle and the solve loop use are instantiated exactly; anything else (the test entry point) runs
@@ -2579,8 +2601,15 @@ int build_staged(Csr& A, const long long grid[3]) {
 // cache lines at both ends of a tile's line segments), within the LDS (3 x slabs + 2 t slabs + tables <= 160 KB) and the
 // 16-byte pairs a lane can load per slab.  Schedule: lockstep (tiles x segments of planes = about one workgroup per CU, all
 // tiles of a segment on one XCD) when that keeps >= 85 % of the balanced schedule's parallel efficiency.
+struct M3Ent { int dz, dy, dx; };
+int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl, size_t ncls,
+                      const std::vector<std::vector<M3Ent>>& ents, bool var);
+int build_band(Csr& A, const long long grid[3]);
 int build_march3(Csr& A, const long long grid[3]) {
   A.rc_march3 = false;
+  A.rm3_var = false;
+  A.vband.release();
+  if (!A.has_rc) return build_band(A, grid);
   if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march3 || A.opt.no_march2 || A.opt.no_march) return MG_OK;
   // a box operator of a sharded level (regular_cols >= 0): the grid is the owned box = its first regular_cols rows; the rows
   // that read the halo are exception rows (class 0xFFFF) and stay so here
@@ -2597,7 +2626,7 @@ int build_march3(Csr& A, const long long grid[3]) {
   const size_t ncls = A.h_rc_ptr.size() - 1;
   if (ncls > (size_t)mgk::RM3_NCLS) return MG_OK;
   // ---- classes: decompose every column shift into (dz, dy, dx) ------------------------------------------------------------
-  struct Ent { int dz, dy, dx; };
+  using Ent = M3Ent;
   std::vector<std::vector<Ent>> ents(ncls);
   for (size_t c = 0; c < ncls; ++c) {
     int nip = 0;
@@ -2616,12 +2645,113 @@ int build_march3(Csr& A, const long long grid[3]) {
       ents[c].push_back({(int)dz, (int)dy, (int)dx});
     }
   }
+  return build_march3_impl(A, grid, A.h_cls.data(), ncls, ents, false);
+}
+
+// Band form (csr_rowclass_march3_spmv<..., VAR = true>) of a grid operator that has NO row classes because its coefficients
+// differ from row to row: classes of the STRUCTURE (the sorted list of column shifts of a row), which must be z-stars and
+// factor as a product map exactly like the value classes of build_march3, and the values re-laid as 7 planar arrays
+// (slot 0 the z-1 entry, 1..5 the in-plane entries in stored order, 6 the z+1 entry; 0 where a row has none).  Built from the
+// device's CSR arrays (copied back once), re-built whenever build_staged runs again (new values: replaceMatrixInHierarchy).
+int build_band(Csr& A, const long long grid[3]) {
+  if (A.opt.no_band || A.opt.no_march3 || A.opt.no_march2 || A.opt.no_march || A.regular_cols >= 0) return MG_OK;
+  const long long n1 = grid[0], n2 = grid[1], n3 = grid[2];
+  if (n1 < 4 || n2 < 4 || n3 < 3 || n1 * n2 * n3 != A.n_rows || A.n_cols != A.n_rows) return MG_OK;
+  if (A.n_rows < A.opt.band_min_rows || A.max_row_nnz > mgk::RM3_NIP + 2) return MG_OK;
+  const long long P = n1 * n2, n = A.n_rows;
+  std::vector<int> rp((size_t)n + 1), ci((size_t)std::max<long long>(A.nnz, 1));
+  HIP_TRY(hipMemcpy(rp.data(), A.rowptr.p, rp.size() * sizeof(int), hipMemcpyDeviceToHost));
+  if (A.nnz > 0) HIP_TRY(hipMemcpy(ci.data(), A.colidx.p, (size_t)A.nnz * sizeof(int), hipMemcpyDeviceToHost));
+  // ---- structure classes: rows with the same list of shifts --------------------------------------------------------------
+  std::vector<unsigned short> cl((size_t)n);
+  std::vector<std::vector<long long>> shifts;          // per class
+  std::unordered_map<unsigned long long, std::vector<int>> byhash;
+  for (long long i = 0; i < n; ++i) {
+    const int k0 = rp[(size_t)i], k1 = rp[(size_t)i + 1];
+    unsigned long long hsh = 0x9E3779B97F4A7C15ULL * (unsigned long long)(k1 - k0 + 1);
+    for (int k = k0; k < k1; ++k) {
+      hsh ^= (unsigned long long)((long long)ci[(size_t)k] - i) + 0x9E3779B97F4A7C15ULL + (hsh << 6) + (hsh >> 2);
+    }
+    std::vector<int>& cand = byhash[hsh];
+    int found = -1;
+    for (int c : cand) {
+      const std::vector<long long>& sh = shifts[(size_t)c];
+      if ((int)sh.size() != k1 - k0) continue;
+      bool same = true;
+      for (int k = k0; k < k1 && same; ++k) same = sh[(size_t)(k - k0)] == (long long)ci[(size_t)k] - i;
+      if (same) { found = c; break; }
+    }
+    if (found < 0) {
+      if (shifts.size() >= (size_t)mgk::RM3_NCLS) return MG_OK;
+      std::vector<long long> sh((size_t)(k1 - k0));
+      for (int k = k0; k < k1; ++k) sh[(size_t)(k - k0)] = (long long)ci[(size_t)k] - i;
+      found = (int)shifts.size();
+      shifts.push_back(sh);
+      cand.push_back(found);
+    }
+    cl[(size_t)i] = (unsigned short)found;
+  }
+  const size_t ncls = shifts.size();
+  std::vector<std::vector<M3Ent>> ents(ncls);
+  for (size_t c = 0; c < ncls; ++c) {
+    int nip = 0;
+    const size_t len = shifts[c].size();
+    for (size_t k = 0; k < len; ++k) {
+      const long long sh = shifts[c][k];
+      if (k > 0 && sh <= shifts[c][k - 1]) return MG_OK;             // (ascending columns)
+      const long long dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
+      const long long rest = sh - dz * P;
+      const long long dy = (rest >= 0) ? (rest + n1 / 2) / n1 : -((-rest + n1 / 2) / n1);
+      const long long dx = rest - dy * n1;
+      if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) return MG_OK;
+      if (dz != 0 && (dy != 0 || dx != 0)) return MG_OK;             // not a z-star
+      if (dz == -1 && k != 0) return MG_OK;
+      if (dz == 1 && k != len - 1) return MG_OK;
+      if (dz == 0 && ++nip > mgk::RM3_NIP) return MG_OK;
+      ents[c].push_back({(int)dz, (int)dy, (int)dx});
+    }
+  }
+  MG_TRY(build_march3_impl(A, grid, cl.data(), ncls, ents, true));
+  if (!A.rc_march3) return MG_OK;
+  // ---- the values as planar slots -------------------------------------------------------------------------------------------
+  std::vector<double> val((size_t)std::max<long long>(A.nnz, 1));
+  if (A.nnz > 0) HIP_TRY(hipMemcpy(val.data(), A.val.p, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost));
+  const long long vstride = (n + 15) & ~15LL;
+  const int NS = mgk::RM3_NIP + 2;
+  std::vector<double> band((size_t)NS * (size_t)vstride, 0.0);
+  std::vector<std::vector<int>> slot(ncls);
+  for (size_t c = 0; c < ncls; ++c) {
+    int nip = 0;
+    for (const M3Ent& t : ents[c]) slot[c].push_back(t.dz == -1 ? 0 : t.dz == 1 ? NS - 1 : 1 + nip++);
+  }
+  for (long long i = 0; i < n; ++i) {
+    const std::vector<int>& sl = slot[(size_t)cl[(size_t)i]];
+    const int k0 = rp[(size_t)i];
+    for (size_t e = 0; e < sl.size(); ++e) band[(size_t)sl[e] * (size_t)vstride + (size_t)i] = val[(size_t)k0 + e];
+  }
+  MG_TRY(A.vband.alloc(band.size()));
+  HIP_TRY(hipMemcpy(A.vband.p, band.data(), band.size() * sizeof(double), hipMemcpyHostToDevice));
+  A.vstride = vstride;
+  A.rm3.vband = A.vband.p;
+  A.rm3.vstride = vstride;
+  A.rm3_var = true;
+  A.band_ncls = (long long)ncls;
+  return MG_OK;
+}
+
+int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl_in, size_t ncls,
+                      const std::vector<std::vector<M3Ent>>& ents, bool var) {
+  using Ent = M3Ent;
+  const bool box = A.regular_cols >= 0;
+  const long long nreg = box ? A.regular_cols : A.n_rows;
+  const long long n1 = grid[0], n2 = grid[1], n3 = grid[2];
+  const long long P = n1 * n2;
   // ---- class ids as a product of three index maps --------------------------------------------------------------------------
   // hash of every x-slice / y-slice / z-slice of the class array; equal hashes = same index; then the exact check
   std::vector<unsigned short> cmap;
   int ncx = 0, ncy = 0, ncz = 0;
   {
-    const unsigned short* cl = A.h_cls.data();
+    const unsigned short* cl = cl_in;
     std::vector<unsigned long long> hx((size_t)n1, 0), hy((size_t)n2, 0), hz((size_t)n3, 0);
     auto mix = [](unsigned long long v) {
       v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
@@ -2728,10 +2858,12 @@ int build_march3(Csr& A, const long long grid[3]) {
   struct Geo { long long NT, tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, K1, nb, segs, seglen; size_t lds; double fill; };
   Geo best{};
   bool have = false;
-  for (long long NT : {1024LL, 768LL}) {
-    if (A.opt.march3_nt != 0 && A.opt.march3_nt != NT) continue;
+  // (VAR: 3 x 8 more doubles per row and lane in registers - 512 threads, 256 registers per lane, two or three rows per lane)
+  for (long long NT : {1024LL, 768LL, 512LL}) {
+    if (var != (NT == 512)) continue;
+    if (!var && A.opt.march3_nt != 0 && A.opt.march3_nt != NT) continue;
     for (long long K1 = 2; K1 <= (NT == 768 ? 4 : 3); ++K1) {
-      if (A.opt.march3_k1 != 0 && K1 != A.opt.march3_k1) continue;
+      if (A.opt.march3_k1 != 0 && K1 != A.opt.march3_k1 && !(var && A.opt.march3_k1 > 3)) continue;
       if (NT == 768 && K1 < 3) continue;
       for (long long tilesx = 1; tilesx <= std::max<long long>({1, n1 / 16, A.opt.march3_tiles_x}); ++tilesx) {
         if (A.opt.march3_tiles_x > 0 && tilesx != A.opt.march3_tiles_x) continue;
@@ -2799,9 +2931,12 @@ int build_march3(Csr& A, const long long grid[3]) {
   for (size_t c = 0; c < ncls; ++c) {
     mgk::M3Class q{};
     int nip = 0, first_off = 0;
-    const int k0 = A.h_rc_ptr[c];
-    std::vector<double> vals((size_t)(A.h_rc_ptr[c + 1] - k0));
-    if (!vals.empty()) HIP_TRY(hipMemcpy(vals.data(), A.rc_val.p + k0, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> vals(ents[c].size(), 1.0);   // (VAR: the records carry the structure only)
+    if (!var) {
+      const int k0 = A.h_rc_ptr[c];
+      vals.resize((size_t)(A.h_rc_ptr[c + 1] - k0));
+      if (!vals.empty()) HIP_TRY(hipMemcpy(vals.data(), A.rc_val.p + k0, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
     for (size_t e = 0; e < ents[c].size(); ++e) {
       const Ent& t = ents[c][e];
       if (t.dz == -1) q.v_lo = vals[e];
@@ -4748,9 +4883,11 @@ int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, lo
   if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
   const Csr& A = h->lev[(size_t)level - 1].A;
   *form = 0;
-  if (!A.set || !A.has_rc || !A.rc_has_d || A.rc_nexc != 0 || h->nrhs != 1) return MG_OK;
+  if (!A.set || h->nrhs != 1) return MG_OK;
+  const bool band = A.rm3_var && A.rc_march3;
+  if (!band && (!A.has_rc || !A.rc_has_d || A.rc_nexc != 0)) return MG_OK;
   if (A.rc_march3) {
-    *form = 3;
+    *form = band ? 4 : 3;
     if (geometry) {
       const long long g[12] = {A.rm3.tiles_x, A.rm3.tiles_y, A.rm3.TX, A.rm3.TY, A.rm3_k1, A.rm3.nblocks, (long long)A.rm3_lds,
                                (long long)(A.rm3_fill * 100.0), A.rm3_nt, A.rm3.segs, A.rm3.seglen, A.rm3.ntab};

@@ -851,6 +851,86 @@ def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k
     assert np.abs(runs["tiles"][1] - runs["chunks"][1]).max() <= 1e-14 * runs["chunks"][1][0]
 
 
+def _setup_divsiggrad(mg, cells, levels, relaxType="Jac", omega=0.8, pre=2, post=1, cyc="V", maxIter=6, seed=5):
+    """Nodal div sigma grad with a log-normal cell coefficient (testGMG.jl:57-75 / testSAforDivSigGrad.jl:96-100 idiom) + a
+    small shift: every row of the 7-point operator has its own values - no row classes."""
+    import scipy.sparse as sp
+    mesh = mg.getRegularMesh([0.0, 1.0] * len(cells), cells)
+    sigma = np.exp(np.random.default_rng(seed).standard_normal(int(np.prod(cells))))
+    A = mg.getNodalDivSigGradMatrix(mesh, sigma)
+    A = (A + 1e-3 * abs(A).sum(axis=0).max() * sp.identity(A.shape[0], format="csr")).tocsr()
+    A.sort_indices()
+    p = mg.getMGparam(np.float64, np.int64, levels, 8, maxIter, 1e-10, relaxType, omega, pre, post, cyc, "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p, 1)
+    return A, p, mg.seeded_rhs(A, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells,k1,tiles_x,lockstep,relax", [([33, 25, 7], 2, 0, 0, "Jac"), ([40, 30, 9], 3, 2, 1, "Jac"), ([23, 23, 23], 2, 1, 1, "SPAI"),
+                                                             ([48, 40, 12], 3, 0, 1, "Jac"), ([130, 9, 5], 2, 0, 0, "Jac")])
+def test_band_form_variable_coefficients(mg, built, monkeypatch, cells, k1, tiles_x, lockstep, relax):
+    """Grid operators whose coefficients differ from row to row (div sigma grad: what jInv feeds the package) have no row
+    classes; round 2 ran them through the pattern-coded CSR kernels only.  Band form: structure classes as a verified product
+    map, the values in 7 planar arrays, relaxPrec per row, sweep + residual in ONE pass of csr_rowclass_march3_spmv<VAR>
+    (the matrix is streamed once for both stages).  t, r, t + d.*r and ||r|| against numpy and against the CSR kernels
+    (MG_NO_BAND=1; those add rounded products, this one fused multiply-adds: 1e-13, not bits); solve and cycle against the
+    oracle, from x = 0 (x1 = d.*b formed inside the pass) and from a given x."""
+    import torch
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_BAND_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    monkeypatch.setenv("MG_MARCH3_K1", str(k1))
+    monkeypatch.setenv("MG_MARCH3_TILES_X", str(tiles_x))
+    monkeypatch.setenv("MG_NO_MARCH3_LOCKSTEP", "0" if lockstep else "1")
+    monkeypatch.setenv("MG_MARCH3_LOCKSTEP_FORCE", "1" if lockstep else "0")
+    rng = np.random.default_rng(sum(cells) + 3)
+    outs, runs = {}, {}
+    xn_ = bn = None
+    for name, off in (("band", "0"), ("csr", "1")):
+        monkeypatch.setenv("MG_NO_BAND", off)
+        A, p, b = _setup_divsiggrad(mg, cells, 2, relax, 0.8 if relax == "Jac" else 1.0)
+        h = mg.to_device(p)
+        form, geo = h.sweep_residual_form(1)
+        assert form == (4 if off == "0" else 0), (form, geo)
+        assert h.operator_rowclasses(1, D.MG_OP_A)[0] == 0          # really no row classes
+        Al, dl = p.As[0], p.relaxPrecs[0]
+        if xn_ is None:
+            xn_, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+        t_want = xn_ + dl * (bn - Al @ xn_)
+        r_want = bn - Al @ t_want
+        if off == "0":
+            assert geo[4] == k1 and geo[8] == 512 and (tiles_x == 0 or geo[0] == tiles_x) and (geo[9] > 0) == bool(lockstep), geo
+            x, bb = torch.from_numpy(xn_).cuda(), torch.from_numpy(bn).cuda()
+            t, r, xn = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+            nrm = h.sweep_residual_dev(1, bb, x, t, r, xn, True)
+            assert np.abs(t.cpu().numpy() - t_want).max() / np.abs(t_want).max() < KERNEL_TOL
+            assert np.abs(r.cpu().numpy() - r_want).max() / np.abs(r_want).max() < 10 * KERNEL_TOL
+            assert np.abs(xn.cpu().numpy() - (t_want + dl * r_want)).max() / np.abs(t_want).max() < 10 * KERNEL_TOL
+            assert abs(nrm - np.linalg.norm(r_want)) < 1e-12 * np.linalg.norm(r_want)
+            t1, r1 = torch.zeros_like(x), torch.zeros_like(x)
+            h.fused_dev(1, D.MG_K_SMOOTH, bb, x, t1)
+            h.fused_dev(1, D.MG_K_RESIDUAL, bb, t1, r1)
+            assert (t - t1).abs().max().item() <= KERNEL_TOL * np.abs(t_want).max()
+            assert (r - r1).abs().max().item() <= 10 * KERNEL_TOL * np.abs(r_want).max()
+            t2, r2 = torch.zeros_like(x), torch.zeros_like(x)
+            h.sweep_residual_dev(1, bb, x, t2, r2)
+            assert torch.equal(t2, t) and torch.equal(r2, r)
+            t3, x3 = torch.zeros_like(x), torch.zeros_like(x)
+            h.sweep_residual_dev(1, bb, x, t3, None, x3)
+            assert torch.equal(t3, t) and torch.equal(x3, xn)
+        x_, hist = _compare_solve(mg, p, b)
+        x0 = np.random.default_rng(99).standard_normal(b.shape)
+        x1 = x0.copy()
+        mg.recursiveCycle(p, b, x1, 1)
+        xo = orc.recursiveCycle(p, b, x0.copy(), 1)
+        assert np.abs(x1 - xo).max() <= RES_TOL * np.abs(xo).max()
+        runs[name] = (x_.copy(), np.asarray(p.resvec).copy(), x1.copy())
+        mg.clear_(p)
+    assert np.abs(runs["band"][0] - runs["csr"][0]).max() <= 1e-11 * np.abs(runs["csr"][0]).max()
+    assert np.abs(runs["band"][1] - runs["csr"][1]).max() <= 1e-11 * runs["csr"][1][0]
+    assert np.abs(runs["band"][2] - runs["csr"][2]).max() <= 1e-11 * np.abs(runs["csr"][2]).max()
+
+
 @pytest.mark.gpu
 def test_march3_serves_513_node_lines(mg, built):
     """A 512^3-cell grid on ONE GPU has 513-node lines: the 1-D chunk form of the two-stage pass cannot stage them (its halo
