@@ -312,7 +312,9 @@ int mg_op_create_box_FP64_INT64(long long device_id, long long n_rows, long long
  * x-fastest order), columns = [owned coarse box c1 x c2 x c3 (== regular_cols) | halo].  Rows that read a halo column are
  * kept apart as exception rows; the others take the LDS-staged prolongation kernel of the single-GPU path where the
  * pattern fits it (checked on the data).  mg_op_apply_phase_dev_FP64: phase 1 = the rows that read owned coarse entries
- * only, phase 2 = the exception rows (ParSpMatVec.jl:49-71 semantics unchanged: y = alpha*P*x + beta*y). */
+ * only, phase 2 = the exception rows (ParSpMatVec.jl:49-71 semantics unchanged: y = alpha*P*x + beta*y).
+ * With f1 = ... = c3 = 0 only the owned | halo split is made (any local operator, e.g. a restriction: rows that read a
+ * halo column in phase 2, the others in phase 1, whatever kernel serves them). */
 int mg_op_create_grid_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
                                  const long long* rowval, const double* nzval, long long regular_cols, long long f1,
                                  long long f2, long long f3, long long c1, long long c2, long long c3, mg_operator** out);

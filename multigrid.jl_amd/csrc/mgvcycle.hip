@@ -5004,7 +5004,8 @@ int mg_op_create_grid_FP64_INT64(long long device_id, long long n_rows, long lon
   UploadFence upload_fence;
   if (!out) return fail(MG_ERR_INVALID, "out is null");
   *out = nullptr;
-  if (regular_cols < 1 || regular_cols > n_cols || f1 * f2 * f3 != n_rows || c1 * c2 * c3 != regular_cols)
+  const bool hints = f1 != 0 || f2 != 0 || f3 != 0 || c1 != 0 || c2 != 0 || c3 != 0;   // (all zero: only the owned | halo split)
+  if (regular_cols < 1 || regular_cols > n_cols || (hints && (f1 * f2 * f3 != n_rows || c1 * c2 * c3 != regular_cols)))
     return fail(MG_ERR_INVALID, "grid operator: f1*f2*f3 must equal n_rows and c1*c2*c3 regular_cols <= n_cols");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -5015,7 +5016,7 @@ int mg_op_create_grid_FP64_INT64(long long device_id, long long n_rows, long lon
   op->device = (int)device_id;
   int rc = upload_csr(&op->M, Options::from_env(), n_rows, n_cols, colptr, rowval, nzval, regular_cols, n_rows);
   const long long gf[3] = {f1, f2, f3}, gc[3] = {c1, c2, c3};
-  if (rc == MG_OK) rc = build_winp(op->M, gf, gc);
+  if (rc == MG_OK && hints) rc = build_winp(op->M, gf, gc);
   if (rc != MG_OK) {
     op->M.release();
     delete op;
@@ -5800,10 +5801,21 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
   }
   MG_TRY(dist_exchange_start(h, L.planR, L.r.p));
-  MG_TRY(dist_exchange_finish(h, L.planR));
+  // R held with the owned | halo column split: the coarse rows that read owned residuals only run beside the exchange
+  auto restrict_to = [&](double* bc) {
+    if (L.R && L.R->M.regular_cols >= 0) {
+      MG_TRY(mg_op_apply_phase_dev_FP64(L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, bc, nullptr, nullptr, h->nrhs, 0, 1, h->stream));
+      MG_TRY(dist_exchange_finish(h, L.planR));
+      MG_TRY(mg_op_apply_phase_dev_FP64(L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, bc, nullptr, nullptr, h->nrhs, 0, 2, h->stream));
+    } else {
+      MG_TRY(dist_exchange_finish(h, L.planR));
+      MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, bc, nullptr, nullptr, 0));
+    }
+    return (int)MG_OK;
+  };
   if (l + 1 < (int)h->lev.size()) {
     DistLevel& C = h->lev[(size_t)l + 1];
-    MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, C.b.p, nullptr, nullptr, 0));
+    MG_TRY(restrict_to(C.b.p));
     double* xc = nullptr;
     if (ctype == 'K') {
       // K-cycle (MGcycle.jl:72-76): 2 steps of FGMRES on A_{l+1} xc = bc, preconditioned by the K-cycle of level l+1
@@ -5834,7 +5846,7 @@ int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool 
     }
   } else {
     // restrict into this rank's rows of the first replicated level, all-gather, run the tail replicated
-    MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, h->bc_pad.p, nullptr, nullptr, 0));
+    MG_TRY(restrict_to(h->bc_pad.p));
     if (h->comm) {
       NCCL_TRY(g_rccl.AllGather(h->bc_pad.p, h->bc_all.p, (size_t)(h->max_tail * h->nrhs), NCCL_DOUBLE, h->comm, h->stream));
     } else if (h->world > 1) {

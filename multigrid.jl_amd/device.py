@@ -633,7 +633,12 @@ class DeviceOperator:
         self.shape = M.shape
         self.nnz = int(M.nnz)
         self.box = box is not None
-        if box is not None and coarse_box is not None:
+        if regular_cols is not None and box is None and coarse_box is None:
+            # only the owned | halo column split (a local restriction): rows reading a halo column go to phase 2
+            _check(self.lib, self.lib.mg_op_create_grid_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),
+                                                                   _i64(rowval), _f64(nzval), int(regular_cols),
+                                                                   0, 0, 0, 0, 0, 0, C.byref(self.handle)), "mg_op_create_grid")
+        elif box is not None and coarse_box is not None:
             f = (list(box) + [1, 1])[:3]
             c = (list(coarse_box) + [1, 1])[:3]
             _check(self.lib, self.lib.mg_op_create_grid_FP64_INT64(int(device_id), M.shape[0], M.shape[1], _i64(colptr),

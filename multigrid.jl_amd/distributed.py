@@ -447,7 +447,12 @@ class DistributedHierarchy:
                 # A is held as two operators: interior rows (no halo columns) and boundary rows
                 L.A_int = be.operator(A[: L.n_int, :]) if L.n_int > 0 else None
                 L.A_bnd = be.operator(A[L.n_int:, :]) if L.n_int < L.n_own else None
-            L.R = be.operator(ld["R"])
+            if self.box_form and not _os.environ.get("MG_DIST_NO_GRID_P") and L.n_own < ld["R"].shape[1]:
+                # R with the owned | halo split of its columns: the coarse rows that read owned residuals only run beside
+                # the exchange of r (phase 1), the others behind it (phase 2)
+                L.R = be.operator(ld["R"], regular_cols=L.n_own)
+            else:
+                L.R = be.operator(ld["R"])
             if self.box_form and ld.get("cbox") is not None and not _os.environ.get("MG_DIST_NO_GRID_P"):
                 # grid form of P: rows = the owned fine box, columns = [owned coarse box | halo] (or the whole replicated
                 # coarse grid): the LDS-staged prolongation kernel serves the rows that read no halo column

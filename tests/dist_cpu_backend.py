@@ -28,7 +28,7 @@ class CpuCheckerBackend:
 
     def operator(self, M, box=None, regular_cols=None, coarse_box=None):
         M = M.tocsr()
-        if coarse_box is not None:     # grid form of P: every row is computed, the hints only pick a kernel on the device
+        if coarse_box is not None or box is None:   # grid form of P / split R: every row is computed, the hints only pick kernels
             return M
         if box is not None:            # box form: square [owned box | halo], only the owned rows are ever computed
             M = M[: int(regular_cols), :].tocsr()
