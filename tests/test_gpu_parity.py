@@ -876,6 +876,7 @@ def test_band_form_variable_coefficients(mg, built, monkeypatch, cells, k1, tile
     (MG_NO_BAND=1; those add rounded products, this one fused multiply-adds: 1e-13, not bits); solve and cycle against the
     oracle, from x = 0 (x1 = d.*b formed inside the pass) and from a given x."""
     import torch
+    import scipy.sparse as sp
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_BAND_MIN_ROWS", "0")
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
@@ -925,6 +926,18 @@ def test_band_form_variable_coefficients(mg, built, monkeypatch, cells, k1, tile
         xo = orc.recursiveCycle(p, b, x0.copy(), 1)
         assert np.abs(x1 - xo).max() <= RES_TOL * np.abs(xo).max()
         runs[name] = (x_.copy(), np.asarray(p.resvec).copy(), x1.copy())
+        if off == "0":
+            # sigma changes (what replaceMatrixInHierarchy exists for, MGsetup.jl:226-270): same pattern, new values - the
+            # planar value arrays of the resident hierarchy must follow
+            mesh = mg.getRegularMesh([0.0, 1.0] * len(cells), cells)
+            A2 = mg.getNodalDivSigGradMatrix(mesh, np.exp(np.random.default_rng(77).standard_normal(int(np.prod(cells)))))
+            A2 = (A2 + 1e-3 * abs(A2).sum(axis=0).max() * sp.identity(A2.shape[0], format="csr")).tocsr()
+            A2.sort_indices()
+            assert np.array_equal(A2.indices, A.indices)
+            dev_before = p.device
+            mg.replaceMatrixInHierarchy(p, A2)
+            assert p.device is dev_before and p.device.sweep_residual_form(1)[0] == 4
+            _compare_solve(mg, p, mg.seeded_rhs(A2, 1))
         mg.clear_(p)
     assert np.abs(runs["band"][0] - runs["csr"][0]).max() <= 1e-11 * np.abs(runs["csr"][0]).max()
     assert np.abs(runs["band"][1] - runs["csr"][1]).max() <= 1e-11 * runs["csr"][1][0]
