@@ -18,6 +18,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c2 -- python3 
 f=$(find $out/prof_c2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/c2_kernel_stats.csv
 t=$(find $out/prof_c2 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python3 profiles/summarize_trace.py $t > $out/c2_kernel_by_grid.md
 echo "kernel trace done" >> $out/progress.txt
+# the band form (grid operator without row classes): the whole bench on the generic formats, kernel stats + PMC of its pass
+export MG_NO_ROWCLASS=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c2g -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-generic-pass > $out/prof_c2g.log 2>&1
+f=$(find $out/prof_c2g -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/c2_generic_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  lc=$(echo $c | tr A-Z a-z)
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_256g_$lc -- python3 scripts/pmc_probe.py 256 > $out/pmc_256g_$lc.log 2>&1
+  f=$(find $out/pmc_256g_$lc -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 profiles/summarize_pmc.py $f > $out/pmc_256_generic_$lc.txt
+done
+unset MG_NO_ROWCLASS
+echo "generic done" >> $out/progress.txt
 for cells in 256 400; do
 for c in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $c | tr A-Z a-z)
