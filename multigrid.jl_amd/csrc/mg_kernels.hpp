@@ -2043,7 +2043,10 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     it_end = tot * (w + 1) / T.nblocks;
   }
   const double* src = ZERO ? a.b : a.x;
-  double* sk = a.sink + ((size_t)w * NT + tid);   // this lane's slot of the sink
+  // this lane's slot of the sink: 32 workgroup-sized slabs shared by all workgroups (what lands there is never read) - small
+  // enough to stay in L2: one slab per workgroup (12 doubles x 250 000 lanes = 19 MB) was written back to HBM once or twice per
+  // launch (PMC: +30 MB of writes on the 272 MB of t and r)
+  double* sk = a.sink + ((size_t)(w & 31) * NT + tid);
   double sq = 0.0;
   // class records of the lane (registers)
   double rlo = 0.0, rhi = 0.0, rv[RM3_NIP];
@@ -2201,7 +2204,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       nb_[s_] = MG_M3_EXP == 2 ? 1.0 : a.b[r_];                                                                        \
       if (VAR) {                                                                                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < NV; ++k_)                                                              \
-          nv_[s_ % KV][k_] = MG_M3_EXP == 2 ? 1.0 : __builtin_nontemporal_load(T.vband + ((size_t)k_ * (size_t)T.vstride + (size_t)r_)); \
+          nv_[s_ % KV][k_] = MG_M3_EXP == 2 ? 1.0 : T.vband[(size_t)k_ * (size_t)T.vstride + (size_t)r_];                            \
         nd_[s_ % KV] = MG_M3_EXP == 2 ? 1.0 : a.d[r_];                                                                 \
       }                                                                                                                \
     }                                                                                                                  \
@@ -2226,7 +2229,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     // at the top of the loop is then s_waitcnt vmcnt(number of stores) on the entry path as well as on the back edge
     if (MG_M3_EXP != 3) {
 #pragma unroll
-      for (int i = 0; i < K1 * (((OUT >> 2) & 1) + ((OUT >> 1) & 1) + (OUT & 1)); ++i) sk[(size_t)i * T.nblocks * NT] = 0.0;   // (distinct slots: distinct instructions)
+      for (int i = 0; i < K1 * (((OUT >> 2) & 1) + ((OUT >> 1) & 1) + (OUT & 1)); ++i) sk[(size_t)i * 32 * NT] = 0.0;   // (distinct slots: distinct instructions)
     }
     __syncthreads();
 #pragma unroll

@@ -1024,7 +1024,7 @@ int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::Marc
   mgk::March2Args a = a_in;
   const int nb1 = A.rm3.nblocks;
   {
-    const size_t need = (size_t)12 * (size_t)nb1 * (size_t)A.rm3_nt;   // (12 >= stores per lane and iteration: K1 <= 4 rows x 3 outputs)
+    const size_t need = (size_t)12 * 32 * (size_t)A.rm3_nt;   // (12 >= stores per lane and iteration: K1 <= 4 rows x 3 outputs; 32 slabs shared by all workgroups)
     if (h->m3sink.n < need) MG_TRY(h->m3sink.alloc(need));
   }
   a.sink = h->m3sink.p;
@@ -5167,7 +5167,7 @@ int mg_op_sweep_residual_dev_FP64(mg_operator* op, const double* x, const double
   if ((t && (x == t || t == r || t == xn)) || x == r || x == xn || (r && r == xn)) return fail(MG_ERR_INVALID, "x, t, r, xn must be distinct buffers");
   (void)hipSetDevice(op->device);
   const Csr& M = op->M;
-  const size_t need = (size_t)12 * (size_t)M.rm3.nblocks * (size_t)M.rm3_nt;
+  const size_t need = (size_t)12 * 32 * (size_t)M.rm3_nt;
   if (op->m3sink.n < need) MG_TRY(op->m3sink.alloc(need));
   const int o = (r ? 1 : 0) | (xn ? 2 : 0) | (t ? 4 : 0);
   if (!(o == 5 || o == 2 || o == 6 || o == 7) && op->m3scratch.n < (size_t)M.n_rows) MG_TRY(op->m3scratch.alloc((size_t)M.n_rows));
