@@ -705,20 +705,31 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
     xb[j] += delta[cq];
     if (class_d) pd[j] = dd[cq];
   }
-  for (int k = 0; k < T.maxlen; k += 4) {
-    double g[2][4];
-    int id[2][4];
+  // gathers per row in flight.  A restriction row has 27 entries: with 4 at a time a lane waits out 7 round trips to a source
+  // that the preceding pass has just pushed out of the caches; 9 at a time (3 round trips, 40 more registers) takes the fine
+  // restriction from 73.7 to 66.0 us and the step from 0.6274 to 0.6170 ms (profiles/r03_dead_ends.md, the one positive entry);
+  // 14 at a time is slower again (occupancy)
+#ifndef MG_LANE_GROUP
+#define MG_LANE_GROUP 9
+#endif
+#ifndef MG_LANE_GROUP_A
+#define MG_LANE_GROUP_A 4
+#endif
+  constexpr int LG = (MODE == AXPBY && !PAIR) ? MG_LANE_GROUP : MG_LANE_GROUP_A;
+  for (int k = 0; k < T.maxlen; k += LG) {
+    double g[2][LG];
+    int id[2][LG];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LG; ++u) {
         id[j][u] = s[j] + min(k + u, len[j] > 0 ? len[j] - 1 : 0);
         g[j][u] = (k + u < len[j]) ? xb[j][ent[id[j][u]].off] : 0.0;
       }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LG; ++u) {
         const double t = acc[j] + ent[id[j][u]].val * g[j][u];
         acc[j] = (k + u < len[j]) ? t : acc[j];
       }
