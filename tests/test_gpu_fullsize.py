@@ -60,6 +60,40 @@ def test_c2_cycle_is_linear_in_b(mg, c2):
     assert np.abs(x2 + 3.0 * x1).max() <= 1e-13 * np.abs(x1).max()
 
 
+# ---- the C2 grid with VARIABLE coefficients (div sigma grad, log-normal sigma: what jInv feeds the package) ---------------
+def test_c2_size_variable_coefficients_band_form_matches_c_oracle(mg, built):
+    """256^3 cells, nodal div sigma grad (testGMG.jl:57-75 idiom) + a small shift, GMG V(2,1) Jacobi, DEFAULT thresholds: no
+    two rows are equal, so the fine level has no row classes and takes the two-stage pass in band form (form 4: structure
+    classes + 7 planar value arrays); its 27-point Galerkin levels run the pattern-coded CSR kernels.  Two solveMG steps
+    against the C/OpenMP oracle; the reported residual is the true one; the cycle is linear in b."""
+    import scipy.sparse as sp
+    from multigrid_jl_amd import device as D
+    cells = [256, 256, 256]
+    mesh = mg.getRegularMesh([0.0, 1.0] * 3, cells)
+    sigma = np.exp(np.random.default_rng(11).standard_normal(int(np.prod(cells))))
+    A = mg.getNodalDivSigGradMatrix(mesh, sigma)
+    A = (A + 1e-3 * abs(A).sum(axis=0).max() * sp.identity(A.shape[0], format="csr")).tocsr()
+    A.sort_indices()
+    p = mg.getMGparam(np.float64, np.int64, 6, 8, 2, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p)
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    mg.solveMG(p, b, x)
+    assert p.device.operator_rowclasses(1, D.MG_OP_A)[0] == 0 and p.device.sweep_residual_form(1)[0] == 4
+    co = c_oracle.COracle(p, 1)
+    xo = np.zeros_like(b)
+    it, rv = co.solveMG(b, xo, 0.0, 2, c_oracle.max_threads())
+    assert it == 2 and np.abs(rv - p.resvec).max() / rv[0] < 1e-10
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    assert abs(np.linalg.norm(b - A @ x) - p.resvec[-1]) <= 1e-10 * p.resvec[0]
+    x1 = np.zeros_like(b)
+    x2 = np.zeros_like(b)
+    mg.recursiveCycle(p, b, x1, 1)
+    mg.recursiveCycle(p, -3.0 * b, x2, 1)
+    assert np.abs(x2 + 3.0 * x1).max() <= 1e-13 * np.abs(x1).max()
+    mg.clear_(p)
+
+
 # ---- C5: block multigrid, 16 right-hand sides, 256^3 cells (BASELINE.json configs[4]) -----------------------------
 @pytest.fixture(scope="module")
 def c5(mg, built):
