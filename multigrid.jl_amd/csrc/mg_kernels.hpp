@@ -2423,6 +2423,17 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
 #undef M3_OPERANDS
 }
 
+// Band form: the values of a CSR operator re-laid as planar slots (build_band).  slot[c*NS + e] = the planar array entry e
+// of a row of structure class c goes to; slots a class does not fill keep the 0 they were initialised with.
+__global__ __launch_bounds__(BLK) void band_fill(const int* __restrict__ rowptr, const double* __restrict__ val,
+                                                 const unsigned short* __restrict__ cls, const int* __restrict__ slot, int ns,
+                                                 double* __restrict__ vband, long long vstride, int n) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const int c = cls[i], k0 = rowptr[i], len = rowptr[i + 1] - k0;
+  for (int e = 0; e < len && e < ns; ++e) vband[(size_t)slot[c * ns + e] * (size_t)vstride + (size_t)i] = val[k0 + e];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Exception rows of a row-class operator (rows whose class was too rare for the dictionary: a few per cent next to
 // sub-domain faces or irregular boundaries): one lane per listed row, straight from the CSR arrays, same epilogues.

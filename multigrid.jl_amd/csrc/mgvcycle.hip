@@ -226,6 +226,8 @@ struct Csr {
   // values in 7 planar arrays (build_band)
   bool rm3_var = false;
   DevBuf<double> vband;
+  DevBuf<unsigned short> vb_cls;   // structure class of every row
+  DevBuf<int> vb_slot;             // [class][entry] -> planar slot
   long long vstride = 0;
   long long band_ncls = 0;
   int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
@@ -388,6 +390,8 @@ struct Csr {
     rc_march3 = false;
     rm3_var = false;
     vband.release();
+    vb_cls.release();
+    vb_slot.release();
     rm3_cls.release();
     rm3_cmap.release();
     rc_exc2.release();
@@ -2605,7 +2609,20 @@ struct M3Ent { int dz, dy, dx; };
 int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl, size_t ncls,
                       const std::vector<std::vector<M3Ent>>& ents, bool var);
 int build_band(Csr& A, const long long grid[3]);
+int band_refill(Csr& A) {
+  const int NS = mgk::RM3_NIP + 2;
+  hipLaunchKernelGGL(mgk::band_fill, dim3((unsigned)((A.n_rows + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, nullptr, A.rowptr.p, A.val.p,
+                     A.vb_cls.p, A.vb_slot.p, NS, A.vband.p, A.vstride, (int)A.n_rows);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return MG_OK;
+}
 int build_march3(Csr& A, const long long grid[3]) {
+  // band form, same pattern (the pattern of a set operator never changes: mg_replace_values / mg_rap keep it), same grid: only
+  // the values moved - one kernel refills the planar arrays from the CSR values
+  if (!A.has_rc && A.rm3_var && A.rc_march3 && A.rm3.n1 == grid[0] && A.rm3.n2 == grid[1] && A.rm3.nplanes == grid[2] && !A.opt.no_band &&
+      !A.opt.no_march3 && !A.opt.no_march2 && !A.opt.no_march)
+    return band_refill(A);
   A.rc_march3 = false;
   A.rm3_var = false;
   A.vband.release();
@@ -2713,25 +2730,22 @@ int build_band(Csr& A, const long long grid[3]) {
   }
   MG_TRY(build_march3_impl(A, grid, cl.data(), ncls, ents, true));
   if (!A.rc_march3) return MG_OK;
-  // ---- the values as planar slots -------------------------------------------------------------------------------------------
-  std::vector<double> val((size_t)std::max<long long>(A.nnz, 1));
-  if (A.nnz > 0) HIP_TRY(hipMemcpy(val.data(), A.val.p, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost));
+  // ---- the values as planar slots: class ids + slot table to the device, one kernel fills (and later refills) the arrays ------
   const long long vstride = (n + 15) & ~15LL;
   const int NS = mgk::RM3_NIP + 2;
-  std::vector<double> band((size_t)NS * (size_t)vstride, 0.0);
-  std::vector<std::vector<int>> slot(ncls);
+  std::vector<int> slot(ncls * (size_t)NS, 0);
   for (size_t c = 0; c < ncls; ++c) {
-    int nip = 0;
-    for (const M3Ent& t : ents[c]) slot[c].push_back(t.dz == -1 ? 0 : t.dz == 1 ? NS - 1 : 1 + nip++);
+    int nip = 0, e = 0;
+    for (const M3Ent& t : ents[c]) slot[c * (size_t)NS + (size_t)e++] = t.dz == -1 ? 0 : t.dz == 1 ? NS - 1 : 1 + nip++;
   }
-  for (long long i = 0; i < n; ++i) {
-    const std::vector<int>& sl = slot[(size_t)cl[(size_t)i]];
-    const int k0 = rp[(size_t)i];
-    for (size_t e = 0; e < sl.size(); ++e) band[(size_t)sl[e] * (size_t)vstride + (size_t)i] = val[(size_t)k0 + e];
-  }
-  MG_TRY(A.vband.alloc(band.size()));
-  HIP_TRY(hipMemcpy(A.vband.p, band.data(), band.size() * sizeof(double), hipMemcpyHostToDevice));
+  MG_TRY(A.vband.alloc((size_t)NS * (size_t)vstride));
+  MG_TRY(A.vb_cls.alloc(cl.size()));
+  MG_TRY(A.vb_slot.alloc(slot.size()));
+  HIP_TRY(hipMemset(A.vband.p, 0, A.vband.bytes()));
+  HIP_TRY(hipMemcpy(A.vb_cls.p, cl.data(), cl.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(A.vb_slot.p, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
   A.vstride = vstride;
+  MG_TRY(band_refill(A));
   A.rm3.vband = A.vband.p;
   A.rm3.vstride = vstride;
   A.rm3_var = true;

@@ -13,7 +13,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 scripts/prolong_ab.py - > $out/p$i.log 2>&1
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python3 profiles/summarize_pmc.py $f | grep -E "winp|lane_spmv<0|march3" >> $out/sq.txt
+  [ -n "$f" ] && python3 profiles/summarize_pmc.py $f | grep -E "winp|lane_spmv<0|march3|tile_spmv" >> $out/sq.txt
   echo "pass $i done" >> $out/progress.txt
 done
 find $out -type d -name "p[0-9]*" -prune -exec rm -rf {} \; 2>/dev/null
