@@ -2196,31 +2196,33 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
         M3_STAGE(pp, z0 - 1 + pp, m, q[m]);
       }
     }
-    d2_t pre[NPM], pre2[NPM];     // x planes z+2 and (MG_M3_PD == 2) z+3, in flight
+    // Loads in flight.  MG_M3_PD planes ahead: with 2, iteration z consumes what iteration z-2 asked for and refills the SAME
+    // register buffer, so nothing is copied between buffers (a copy of a register whose load is in flight is a wait): the
+    // loop below is unrolled by two and each half uses its own buffer (PB = half).
+    constexpr int NBUF = MG_M3_PD == 2 ? 2 : 1;
+    d2_t preb[NBUF][NPM];         // x planes z+2 [, z+3]
 #pragma unroll
-    for (int m = 0; m < NPM; ++m) M3_LOADPAIR(pre[m], z0 + 1, m);
+    for (int q = 0; q < NBUF; ++q)
 #pragma unroll
-    for (int m = 0; m < NPM; ++m) {
-      pre2[m] = d2_t{0.0, 0.0};
-      if (MG_M3_PD == 2) M3_LOADPAIR(pre2[m], z0 + 2, m);
-    }
+      for (int m = 0; m < NPM; ++m) M3_LOADPAIR(preb[q][m], z0 + 1 + q, m);
     // b of plane zz for every slot's row (a safe row where the slot is not live)
-    double nb_[K1];
-    double nv_[KV][NV], nd_[KV];   // VAR: the rows' values and relaxPrec, in flight with b
-#define M3_OPERANDS(zz)                                                                                                \
+    double nbb[NBUF][K1];
+    double nvb[NBUF][KV][NV], ndb[NBUF][KV];   // VAR: the rows' values and relaxPrec, in flight with b
+#define M3_OPERANDS(zz, PB_)                                                                                           \
   do {                                                                                                                 \
     const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
     _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
       const int r_ = (pv_ && ((live1 >> s_) & 1u)) ? (zz) * T.P + ip0 + s_ * ipstride : C.n_rows - 1;                  \
-      nb_[s_] = MG_M3_EXP == 2 ? 1.0 : a.b[r_];                                                                        \
+      nbb[PB_][s_] = MG_M3_EXP == 2 ? 1.0 : a.b[r_];                                                                   \
       if (VAR) {                                                                                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < NV; ++k_)                                                              \
-          nv_[s_ % KV][k_] = MG_M3_EXP == 2 ? 1.0 : T.vband[(size_t)k_ * (size_t)T.vstride + (size_t)r_];                            \
-        nd_[s_ % KV] = MG_M3_EXP == 2 ? 1.0 : a.d[r_];                                                                 \
+          nvb[PB_][s_ % KV][k_] = MG_M3_EXP == 2 ? 1.0 : T.vband[(size_t)k_ * (size_t)T.vstride + (size_t)r_];        \
+        ndb[PB_][s_ % KV] = MG_M3_EXP == 2 ? 1.0 : a.d[r_];                                                            \
       }                                                                                                                \
     }                                                                                                                  \
   } while (0)
-    M3_OPERANDS(z0 - 1);
+    M3_OPERANDS(z0 - 1, 0);
+    if (NBUF == 2) M3_OPERANDS(z0, NBUF - 1);
     // own x of plane z0-2 (the z-1 entry of stage 1 on plane z0-1), straight from global memory
     double xm[K1], xc[K1];
 #pragma unroll
@@ -2258,28 +2260,33 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       for (int k = 0; k < NV; ++k) v1[s][k] = 0.0;
     }
     int qz = 0;                    // ring slot of plane z (plane z0-1 is slot 0)
-    for (int z = z0 - 1; z <= z1; ++z) {
+    for (int zz = z0 - 1; zz <= z1; zz += NBUF) {
+#pragma unroll
+     for (int half = 0; half < NBUF; ++half) {
+      const int z = zz + half;
+      if (z > z1) break;                                       // (uniform)
+      const int PB = half;                                     // (a constant after the unroll: the buffers stay in registers)
       d2_t cur[NPM];
       double b0[K1];
 #pragma unroll
       for (int m = 0; m < NPM; ++m) {
-        cur[m] = pre[m];
+        cur[m] = preb[PB][m];
         asm volatile("" : "+v"(cur[m].x), "+v"(cur[m].y));     // the wait of this iteration: the loads, not the stores behind them
       }
 #pragma unroll
       for (int s = 0; s < K1; ++s) {
-        b0[s] = nb_[s];
+        b0[s] = nbb[PB][s];
         asm volatile("" : "+v"(b0[s]));
       }
       double v0[KV][NV], d0[KV];
       if (VAR) {
 #pragma unroll
         for (int s = 0; s < KV; ++s) {
-          d0[s] = nd_[s];
+          d0[s] = ndb[PB][s];
           asm volatile("" : "+v"(d0[s]));
 #pragma unroll
           for (int k = 0; k < NV; ++k) {
-            v0[s][k] = nv_[s][k];
+            v0[s][k] = nvb[PB][s][k];
             asm volatile("" : "+v"(v0[s][k]));
           }
         }
@@ -2293,19 +2300,13 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
           M3_STAGE(q2, z + 2, m, cur[m]);
         }
       }
-      // ---- the loads of x plane z+3 (z+4: two planes in flight) and of b of plane z+1, in flight while this plane is computed
-      if (MG_M3_PD == 2) {
+      // ---- the loads of x plane z+2+NBUF and of b of plane z+NBUF into the buffer just consumed, in flight while this plane
+      // (and with two buffers the next one) is computed
+      if (z + 2 + NBUF <= z1 + 1) {
 #pragma unroll
-        for (int m = 0; m < NPM; ++m) pre[m] = pre2[m];
-        if (z + 4 <= z1 + 1) {
-#pragma unroll
-          for (int m = 0; m < NPM; ++m) M3_LOADPAIR(pre2[m], z + 4, m);
-        }
-      } else if (z + 3 <= z1 + 1) {
-#pragma unroll
-        for (int m = 0; m < NPM; ++m) M3_LOADPAIR(pre[m], z + 3, m);
+        for (int m = 0; m < NPM; ++m) M3_LOADPAIR(preb[PB][m], z + 2 + NBUF, m);
       }
-      if (z + 1 <= z1) M3_OPERANDS(z + 1);
+      if (z + NBUF <= z1) M3_OPERANDS(z + NBUF, PB);
       // ---- stage 1 on plane z: t = x + d.*(b - A x) on every live row of the lane ----------------------------------------
       const bool s1 = z >= 0 && z < T.nplanes;          // (uniform)
       const int zb0 = s1 ? (int)czL[z] * zstride : 0;   // class table rows of planes z and z-1
@@ -2399,6 +2400,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       }
       qz = q1;
       __syncthreads();
+     }
     }
   }
   if (a.sumsq) {
