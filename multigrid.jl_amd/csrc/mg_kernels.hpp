@@ -593,6 +593,7 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_spmv(RowClassDev C, VecArgs 
 constexpr int RL_DCAP = 512;
 constexpr int RL_NCLS = 128;
 constexpr int RL_ROWS = 2 * BLK;   // rows per workgroup (lane t: rows t and t + BLK)
+static_assert(BLK > RL_NCLS && RL_DCAP % BLK == 0, "the lane kernels stage their dictionary with one pass over the classes");
 struct LaneDev {
   int ncls, nent, maxlen, nblocks;
 };
@@ -614,18 +615,6 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
   const int tid = threadIdx.x;
   const int bid = xcd_band(blockIdx.x, T.nblocks);
   const bool class_d = (MODE == SMOOTH) && !v.d;
-  for (int i = tid; i < T.nent; i += BLK) {
-    LaneEnt e;
-    e.val = C.cls_val[i];
-    e.off = C.cls_off[i];
-    e.pad = 0;
-    ent[i] = e;
-  }
-  for (int i = tid; i <= T.ncls; i += BLK) ptr[i] = C.cls_ptr[i];
-  for (int i = tid; i < T.ncls; i += BLK) {
-    delta[i] = C.firstcol ? 0 : C.cls_delta[i];
-    dd[i] = class_d ? C.cls_d[i] : 0.0;
-  }
   int row[2], s[2], len[2];
   const double* xb[2];
   double pb[2], pd[2], px[2], acc[2];
@@ -694,6 +683,34 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmv(RowClassDev C, Vec
       }
       s[j] = live[j] ? cls : 0;                               // (class id for now; resolved after the barrier)
       xb[j] = v.x + first;
+    }
+  }
+  // the dictionary into LDS - BEHIND the loads of the row operands above (all in flight together) and with every load issued
+  // before the first LDS write (round 3; as three load-store loops in front of the row loads this was a chain of 4-5 round trips)
+  {
+    constexpr int ND = RL_DCAP / BLK;                          // nent <= RL_DCAP, ncls <= RL_NCLS < BLK
+    LaneEnt e[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * BLK;
+      const int ii = i < T.nent ? i : 0;
+      e[u].val = C.cls_val[ii];
+      e[u].off = C.cls_off[ii];
+      e[u].pad = 0;
+    }
+    const int pi = tid <= T.ncls ? tid : 0, ci = tid < T.ncls ? tid : 0;
+    const int pv = C.cls_ptr[pi];
+    const int dv = C.firstcol ? 0 : C.cls_delta[ci];
+    const double ddv = class_d ? C.cls_d[ci] : 0.0;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * BLK;
+      if (i < T.nent) ent[i] = e[u];
+    }
+    if (tid <= T.ncls) ptr[tid] = pv;
+    if (tid < T.ncls) {
+      delta[tid] = dv;
+      dd[tid] = ddv;
     }
   }
   __syncthreads();
@@ -819,26 +836,51 @@ __global__ __launch_bounds__(WP_T) void csr_rowclass_winp_spmv(RowClassDev C, Ve
       cq[j] = 0;
     }
   }
+  // Both staging loops issue ALL their loads before the first LDS write (round 3): as load-store loops every load was waited
+  // for before its ds_write - a chain of up to 8 + 2 x 2 round trips per workgroup.
   {
     const int czz = T.cz0[z];
     const long long base0 = (long long)(czz & 0x3FFFFFFF) * T.PC + T.wlo[c];
     const int nstage = (czz & 0x40000000) ? T.W : 2 * T.W;   // (a plane whose rows read one coarse plane: one window)
-    for (int i = tid; i < nstage; i += WP_T) {
+    constexpr int NU = (4096 + WP_T - 1) / WP_T;               // (W <= 2048: build_winp)
+    double st[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = tid + u * WP_T;
       const bool second = i >= T.W;
       long long col = base0 + (second ? (long long)T.PC + (i - T.W) : (long long)i);
       col = col < 0 ? 0 : (col > T.n_cols - 1 ? T.n_cols - 1 : col);
-      win[i] = v.x[col];
+      st[u] = (i < nstage) ? v.x[col] : 0.0;
     }
-  }
-  // records beyond a class's length: value 0 at the class's first entry (they add +-0: no clamps, no predicated additions)
-  for (int i = tid; i < T.ncls * T.maxlen; i += WP_T) {
-    const int cc = i / T.maxlen, k = i - cc * T.maxlen;
-    const int s0 = C.cls_ptr[cc], ln = C.cls_ptr[cc + 1] - s0;
-    LaneEnt e;
-    e.val = k < ln ? C.cls_val[s0 + k] : 0.0;
-    e.off = T.code[s0 + (k < ln ? k : 0)] * 8;
-    e.pad = ln;   // (the class's length rides in every record)
-    ent[i] = e;
+    // records beyond a class's length: value 0 at the class's first entry (they add +-0: no clamps, no predicated additions)
+    constexpr int ND = (1024 + WP_T - 1) / WP_T;               // (ncls * maxlen <= 1024: build_winp)
+    int s0[ND], ln[ND], kk[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * WP_T;
+      const bool on = i < T.ncls * T.maxlen;
+      const int cc = on ? i / T.maxlen : 0;
+      kk[u] = on ? i - cc * T.maxlen : 0;
+      s0[u] = C.cls_ptr[cc];
+      ln[u] = C.cls_ptr[cc + 1] - s0[u];
+    }
+    LaneEnt e[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      e[u].val = kk[u] < ln[u] ? C.cls_val[s0[u] + kk[u]] : 0.0;
+      e[u].off = T.code[s0[u] + (kk[u] < ln[u] ? kk[u] : 0)] * 8;
+      e[u].pad = ln[u];   // (the class's length rides in every record)
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = tid + u * WP_T;
+      if (i < nstage) win[i] = st[u];
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * WP_T;
+      if (i < T.ncls * T.maxlen) ent[i] = e[u];
+    }
   }
   __syncthreads();
   const LaneEnt* rp[4];
@@ -1091,30 +1133,76 @@ __global__ __launch_bounds__(CR, CR >= 1024 ? 8 : 4) void csr_rowclass_tile_spmv
       if ((MODE == SMOOTH || (MODE == RESID && v.y2)) && v.d) pd[j] = v.d[rr];
     }
   }
-  // stage slabs q = 0 .. RT_NP+1 <-> planes pl0-1 .. pl0+RT_NP, rows [c*CR - halo, c*CR + CR + halo)
-  for (int q = 0; q < RT_NP + 2; ++q) {
-    const long long g0 = (long long)(pl0 + q - 1) * T.P + c * CR - T.halo;
-    for (int i = tid; i < SL; i += CR) {
-      long long gi = g0 + i;
-      gi = gi < 0 ? 0 : (gi > T.n_cols - 1 ? T.n_cols - 1 : gi);
-      win[q * SL + i] = v.x[gi];
+  const bool class_dl = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
+  // stage slabs q = 0 .. RT_NP+1 <-> planes pl0-1 .. pl0+RT_NP, rows [c*CR - halo, c*CR + CR + halo).  ALL loads of a lane
+  // are issued before the first LDS write (round 3): written as one load-store loop the compiler waits for every load before
+  // its ds_write - up to 12 round trips in a row per workgroup, which is what the level-2 / level-3 launches spent their
+  // time on (SQ counters: 66 % of the wave cycles waiting)
+  {
+    constexpr int NQ = RT_NP + 2, NU = 2;        // (halo <= CR/2: two entries per lane and slab; a longer slab takes the loop below)
+    double st[NQ][NU];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const long long g0 = (long long)(pl0 + q - 1) * T.P + c * CR - T.halo;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int i = tid + u * CR;
+        long long gi = g0 + i;
+        gi = gi < 0 ? 0 : (gi > T.n_cols - 1 ? T.n_cols - 1 : gi);
+        st[q][u] = (i < SL) ? v.x[gi] : 0.0;
+      }
+    }
+    // the padded dictionary (T.lane): its loads go out behind the slab loads, before any LDS write
+    TileRec* drec = reinterpret_cast<TileRec*>(win + (RT_NP + 2) * SL);     // [ncls][maxlen] (T.lane only)
+    double* ddl = reinterpret_cast<double*>(drec + (T.lane ? T.ncls * T.maxlen : 0));
+    constexpr int ND = (RT_LCAP + CR - 1) / CR;                            // ncls * maxlen <= RT_LCAP
+    TileRec dr[ND];
+    double ddv = 0.0;
+    if (T.lane) {
+      int ds[ND], dl[ND], dk[ND];
+#pragma unroll
+      for (int u = 0; u < ND; ++u) {
+        const int i = tid + u * CR;
+        const bool on = i < T.ncls * T.maxlen;
+        const int cc = on ? i / T.maxlen : 0;
+        dk[u] = on ? i - cc * T.maxlen : 0;
+        ds[u] = C.cls_ptr[cc];
+        dl[u] = C.cls_ptr[cc + 1] - ds[u];
+      }
+      if (class_dl && tid < T.ncls) ddv = C.cls_d[tid];
+#pragma unroll
+      for (int u = 0; u < ND; ++u) {
+        dr[u].val = dk[u] < dl[u] ? C.cls_val[ds[u] + dk[u]] : 0.0;
+        dr[u].off8 = T.tile_lb[ds[u] + (dk[u] < dl[u] ? dk[u] : 0)] * 8;
+        dr[u].pad = 0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int i = tid + u * CR;
+        if (i < SL) win[q * SL + i] = st[q][u];
+      }
+    for (int q = 0; q < NQ; ++q) {
+      const long long g0 = (long long)(pl0 + q - 1) * T.P + c * CR - T.halo;
+      for (int i = tid + NU * CR; i < SL; i += CR) {
+        long long gi = g0 + i;
+        gi = gi < 0 ? 0 : (gi > T.n_cols - 1 ? T.n_cols - 1 : gi);
+        win[q * SL + i] = v.x[gi];
+      }
+    }
+    if (T.lane) {
+#pragma unroll
+      for (int u = 0; u < ND; ++u) {
+        const int i = tid + u * CR;
+        if (i < T.ncls * T.maxlen) drec[i] = dr[u];
+      }
+      for (int i = tid; i < T.ncls; i += CR) ddl[i] = (i == tid) ? ddv : (class_dl ? C.cls_d[i] : 0.0);
     }
   }
   TileRec* drec = reinterpret_cast<TileRec*>(win + (RT_NP + 2) * SL);     // [ncls][maxlen] (T.lane only)
   double* ddl = reinterpret_cast<double*>(drec + (T.lane ? T.ncls * T.maxlen : 0));
-  const bool class_dl = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
-  if (T.lane) {
-    for (int i = tid; i < T.ncls * T.maxlen; i += CR) {
-      const int cc = i / T.maxlen, k = i - cc * T.maxlen;
-      const int s = C.cls_ptr[cc], len = C.cls_ptr[cc + 1] - s;
-      TileRec r;
-      r.val = k < len ? C.cls_val[s + k] : 0.0;
-      r.off8 = T.tile_lb[s + (k < len ? k : 0)] * 8;
-      r.pad = 0;
-      drec[i] = r;
-    }
-    for (int i = tid; i < T.ncls; i += CR) ddl[i] = class_dl ? C.cls_d[i] : 0.0;
-  }
   __syncthreads();
   const unsigned long long lanebit = 1ull << lane;
   unsigned long long todo[RT_NP];
@@ -2595,15 +2683,6 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm(RowClassDev C, Vec
   const int rows_wg = 2 * (BLK / G);
   int bid = xcd_band(blockIdx.x, T.nblocks);
   if (sched) bid = sched[bid];
-  for (int i = tid; i < T.nent; i += BLK) {
-    LaneEnt e;
-    e.val = C.cls_val[i];
-    e.off = C.cls_off[i];
-    e.pad = 0;
-    ent[i] = e;
-  }
-  for (int i = tid; i <= T.ncls; i += BLK) ptr[i] = C.cls_ptr[i];
-  for (int i = tid; i < T.ncls; i += BLK) delta[i] = C.firstcol ? 0 : C.cls_delta[i];
   const int grp = tid / G, c = tid - grp * G;
   const bool cact = c < nrhs;
   int row[2], s[2], len[2];
@@ -2632,6 +2711,28 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm(RowClassDev C, Vec
     }
     s[j] = live[j] ? cls : 0;
     xb[j] = v.x + (size_t)first * nrhs + (cact ? c : 0);
+  }
+  // the dictionary into LDS behind the row operands' loads, every load issued before the first LDS write (see csr_rowclass_lane_spmv)
+  {
+    constexpr int ND = RL_DCAP / BLK;
+    LaneEnt e[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * BLK;
+      const int ii = i < T.nent ? i : 0;
+      e[u].val = C.cls_val[ii];
+      e[u].off = C.cls_off[ii];
+      e[u].pad = 0;
+    }
+    const int pv = C.cls_ptr[tid <= T.ncls ? tid : 0];
+    const int dv = C.firstcol ? 0 : C.cls_delta[tid < T.ncls ? tid : 0];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * BLK;
+      if (i < T.nent) ent[i] = e[u];
+    }
+    if (tid <= T.ncls) ptr[tid] = pv;
+    if (tid < T.ncls) delta[tid] = dv;
   }
   __syncthreads();
 #pragma unroll
@@ -2684,15 +2785,6 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, Ve
   const int rows_wg = RL2_RPL * (BLK / G);
   int bid = xcd_band(blockIdx.x, T.nblocks);
   if (sched) bid = sched[bid];
-  for (int i = tid; i < T.nent; i += BLK) {
-    LaneEnt e;
-    e.val = C.cls_val[i];
-    e.off = C.cls_off[i];
-    e.pad = 0;
-    ent[i] = e;
-  }
-  for (int i = tid; i <= T.ncls; i += BLK) ptr[i] = C.cls_ptr[i];
-  for (int i = tid; i < T.ncls; i += BLK) delta[i] = C.firstcol ? 0 : C.cls_delta[i];
   const int grp = tid / G, c = tid - grp * G;      // c: column PAIR
   const bool cact = 2 * c < nrhs;
   int row[RL2_RPL], s[RL2_RPL], len[RL2_RPL];
@@ -2725,6 +2817,28 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, Ve
     }
     s[j] = live[j] ? cls : 0;
     xb[j] = v.x + (size_t)first * nrhs + (cact ? 2 * c : 0);
+  }
+  // the dictionary into LDS behind the row operands' loads, every load issued before the first LDS write (see csr_rowclass_lane_spmv)
+  {
+    constexpr int ND = RL_DCAP / BLK;
+    LaneEnt e[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * BLK;
+      const int ii = i < T.nent ? i : 0;
+      e[u].val = C.cls_val[ii];
+      e[u].off = C.cls_off[ii];
+      e[u].pad = 0;
+    }
+    const int pv = C.cls_ptr[tid <= T.ncls ? tid : 0];
+    const int dv = C.firstcol ? 0 : C.cls_delta[tid < T.ncls ? tid : 0];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * BLK;
+      if (i < T.nent) ent[i] = e[u];
+    }
+    if (tid <= T.ncls) ptr[tid] = pv;
+    if (tid < T.ncls) delta[tid] = dv;
   }
   __syncthreads();
 #pragma unroll
