@@ -307,11 +307,6 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
     if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
     if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
   }
-  if (DLDS)
-    for (int i = tid; i < DICT_LDS; i += BLK) {
-      if (i < P.dict_entries) soff[i] = P.pat_off[i];
-      if (i <= P.npat) sptr[i] = P.pat_ptr[i];
-    }
   int first = 0, po = 0;
   if (nruns == 0 && lrow < nrows) {
     first = P.firstcol[r0 + lrow];
@@ -324,6 +319,24 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
     if (MODE == AXPBY) { if (v.beta != 0.0) pb = v.beta * v.y[row]; }
     else pb = v.b[row];
     if (MODE == SMOOTH) { pd = v.d[row]; px = v.xs[row]; }
+  }
+  if (DLDS) {   // the pattern dictionary: loads behind everything above, all issued before the first LDS write
+    constexpr int ND = (DICT_LDS + BLK - 1) / BLK;
+    int so[ND], sp[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * BLK;
+      so[u] = i < P.dict_entries ? P.pat_off[i] : 0;
+      sp[u] = i <= P.npat ? P.pat_ptr[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * BLK;
+      if (i < DICT_LDS) {
+        if (i < P.dict_entries) soff[i] = so[u];
+        if (i <= P.npat) sptr[i] = sp[u];
+      }
+    }
   }
 #pragma unroll
   for (int it = 0; it < PAIRS; ++it) {

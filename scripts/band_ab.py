@@ -5,6 +5,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import multigrid_jl_amd as mg
+from multigrid_jl_amd import device as D
+if os.environ.get("AB_LIB"):
+    D._lib = D.load_library(os.path.join(os.path.dirname(D.LIB_PATH), os.environ["AB_LIB"]))
+    print("library:", os.environ["AB_LIB"], flush=True)
 
 cells = int(os.environ.get("AB_CELLS", "256"))
 A, mesh = mg.poisson_shifted([cells] * 3)
