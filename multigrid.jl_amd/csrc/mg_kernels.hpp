@@ -2782,11 +2782,9 @@ __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm(RowClassDev C, Vec
 // 16-byte load/store, a wavefront covers twice the rows, half the vector-memory instructions for the same bytes.
 // Measured on C5 (16 columns): the one-column form moves 1.02 x the compulsory bytes yet runs at 3.2 TB/s - it is bound
 // by the number of 8-byte-per-lane requests in flight, not by traffic.  G = pow2 >= nrhs/2 lanes per row.
-#ifndef MG_RL2_RPL
-#define MG_RL2_RPL 2
-#endif
-constexpr int RL2_RPL = MG_RL2_RPL;   // rows per lane of csr_rowclass_lane_spmm2
-template <int MODE>
+// RPL rows per lane: 3 for square operators (the sweeps and residuals of A: fused sweep 1.57 -> 1.46 ms on C5), 2 for the
+// transfer operators (3 would slow the prolongation from 1.01 to 1.25 ms) - chosen per operator by the host (lane_mm_rpl).
+template <int MODE, int RL2_RPL>
 __global__ __launch_bounds__(BLK) void csr_rowclass_lane_spmm2(RowClassDev C, VecArgs v, LaneDev T, int G,
                                                                const int* __restrict__ sched) {
   __shared__ LaneEnt ent[RL_DCAP];

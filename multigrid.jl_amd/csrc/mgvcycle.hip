@@ -63,7 +63,7 @@ struct Options {
   bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
   bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
   bool no_tile_small = false;
-  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_band = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
+  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_band = false, no_lane_rpl3 = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
   long long rap_chunk = 2048;      // target columns of a coarse row the numeric Galerkin product accumulates at a time (<= 2048; tests)
   bool no_dead_t = false;          // solve loop: store the iterate of every step (A/B, bit-identity tests)
   bool no_march3 = false;          // never use the 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv)
@@ -99,7 +99,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
       MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
+      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_LANE_RPL3", "no_lane_rpl3", 0, no_lane_rpl3), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
@@ -678,7 +678,8 @@ bool march_ok(const Csr& M, const mgk::VecArgs& v) {
 // Lane SpMM: lanes per row.  Even nrhs: two columns (16 bytes) per lane, G = pow2 >= nrhs/2 lanes per row.
 static inline bool lane_mm_pairs(const Csr& M, long long nrhs) { return nrhs % 2 == 0 && !M.opt.no_lane_pairs; }
 static inline int lane_mm_group(const Csr& M, long long nrhs) { return lane_mm_pairs(M, nrhs) ? pow2_ge(nrhs / 2) : pow2_ge(nrhs); }
-static inline int lane_mm_rpl(const Csr& M, long long nrhs) { return lane_mm_pairs(M, nrhs) ? mgk::RL2_RPL : 2; }
+// rows per lane of the row-class SpMM: 3 for a square operator in the paired-column form (A: sweeps, residuals), else 2
+static inline int lane_mm_rpl(const Csr& M, long long nrhs) { return (lane_mm_pairs(M, nrhs) && M.n_rows == M.n_cols && !M.opt.no_lane_rpl3) ? 3 : 2; }
 static inline bool aligned16(const mgk::VecArgs& v) {
   auto ok = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   return ok(v.x) && ok(v.y) && ok(v.b) && ok(v.xs);
@@ -831,7 +832,8 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
     const int* sched = M.has_sched_ln ? M.sched_ln.p : nullptr;
     if (nparts) *nparts = lane_mm_pairs(M, v.nrhs) ? M.ln_blocks : 0;   // (only the paired form writes ||out||^2 partials)
     if (lane_mm_pairs(M, v.nrhs))   // two columns (16 bytes) per lane
-      hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm2<MODE>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
+      if (lane_mm_rpl(M, v.nrhs) == 3) hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm2<MODE, 3>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
+      else hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm2<MODE, 2>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
     else
       hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm<MODE>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
   } else {
