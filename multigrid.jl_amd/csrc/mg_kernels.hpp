@@ -2083,9 +2083,10 @@ struct March3Dev {
 #define MG_M3_PD 1    // x planes in flight in registers (1 or 2)
 #endif
 #ifndef MG_M3_NT
-#define MG_M3_NT 1    // b is read and t written with non-temporal accesses: what stays in the Infinity Cache behind the pass is then r
-                      // (read next, by the restriction: 64.7 -> 61.1 us, step -5 us) rather than the tail of every stream; x keeps plain
-                      // loads (lockstep neighbours share their halo lines in L2)
+#define MG_M3_NT 1    // bit 0: t is WRITTEN non-temporally (it is read again only after the whole coarse cycle; what stays cached behind
+                      // the pass is then rather r, which the restriction reads next: restriction 66 -> 62 us; 400^3 step -10 us).
+                      // bit 1: b READ non-temporally as well: 4 us more at 256^3, but lockstep neighbours then fetch their common ring
+                      // rows of b from HBM twice - +33 us per step at 400^3 (PMC reads +7 %): off
 #endif
 #ifndef MG_M3_EXP
 #define MG_M3_EXP 0   // attribution builds (make variant): 1 no class walks, 2 no slab/operand loads, 3 no stores
@@ -2319,7 +2320,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
     _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
       const int r_ = (pv_ && ((live1 >> s_) & 1u)) ? (zz) * T.P + ip0 + s_ * ipstride : C.n_rows - 1;                  \
-      nbb[PB_][s_] = MG_M3_EXP == 2 ? 1.0 : (MG_M3_NT ? __builtin_nontemporal_load(a.b + r_) : a.b[r_]);               \
+      nbb[PB_][s_] = MG_M3_EXP == 2 ? 1.0 : ((MG_M3_NT & 2) ? __builtin_nontemporal_load(a.b + r_) : a.b[r_]);               \
       if (VAR) {                                                                                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < NV; ++k_)                                                              \
           nvb[PB_][s_ % KV][k_] = MG_M3_EXP == 2 ? 1.0 : T.vband[(size_t)k_ * (size_t)T.vstride + (size_t)r_];        \
@@ -2478,7 +2479,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
           const int rowt = z * T.P + ip0 + s * ipstride, rowr = rowt - T.P;
           if (OUT & 4) {
             double* q_ = (wt && ((core >> s) & 1u)) ? a.t + rowt : sk;
-            if (MG_M3_NT) __builtin_nontemporal_store(tc[s], q_);
+            if (MG_M3_NT & 1) __builtin_nontemporal_store(tc[s], q_);
             else *q_ = tc[s];
           }
           if (OUT & 1) {
