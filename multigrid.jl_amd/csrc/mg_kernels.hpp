@@ -2083,10 +2083,10 @@ struct March3Dev {
 #define MG_M3_PD 1    // x planes in flight in registers (1 or 2)
 #endif
 #ifndef MG_M3_NT
-#define MG_M3_NT 1    // bit 0: t is WRITTEN non-temporally (it is read again only after the whole coarse cycle; what stays cached behind
-                      // the pass is then rather r, which the restriction reads next: restriction 66 -> 62 us; 400^3 step -10 us).
-                      // bit 1: b READ non-temporally as well: 4 us more at 256^3, but lockstep neighbours then fetch their common ring
-                      // rows of b from HBM twice - +33 us per step at 400^3 (PMC reads +7 %): off
+#define MG_M3_NT 0    // experiment (profiles/r03_march3_ab.md section 8): bit 0 = t WRITTEN non-temporally (so that r rather than t stays cached
+                      // for the restriction: restriction 66 -> 62 us, but the pass itself 4 us slower - neutral over four alternations);
+                      // bit 1 = b READ non-temporally as well (lockstep neighbours then fetch their common ring rows of b from HBM twice:
+                      // +33 us per step at 400^3).  Off.
 #endif
 #ifndef MG_M3_EXP
 #define MG_M3_EXP 0   // attribution builds (make variant): 1 no class walks, 2 no slab/operand loads, 3 no stores
