@@ -197,6 +197,8 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
   if (owner) {
     outv = epilogue<MODE>(v, r0 + lrow, acc, pb, pd, px);
     v.y[r0 + lrow] = outv;
+    // AXPBY with v.y2: also d[row]*out - the restriction hands the coarse level its first update x = d.*bc (as the lane kernel does)
+    if (MODE == AXPBY && v.y2) v.y2[r0 + lrow] = v.d_full[r0 + lrow] * outv;
   }
   if (v.sumsq) {  // fused Frobenius norm (SolveFuncs.jl:30): deterministic per-block partial, summed by sum_final
     double sq = outv * outv;
@@ -395,6 +397,8 @@ __global__ __launch_bounds__(BLK) void csr_pattern_spmv(CsrDev A, PatDev P, VecA
   if (owner) {
     outv = epilogue<MODE>(v, r0 + lrow, acc, pb, pd, px);
     v.y[r0 + lrow] = outv;
+    // AXPBY with v.y2: also d[row]*out - the restriction hands the coarse level its first update x = d.*bc (as the lane kernel does)
+    if (MODE == AXPBY && v.y2) v.y2[r0 + lrow] = v.d_full[r0 + lrow] * outv;
   }
   if (v.sumsq) {
     double sq = outv * outv;

@@ -862,9 +862,12 @@ int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, con
   ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false) + extra, moved_bytes(M, h->nrhs, beta != 0.0, false) + extra);
   return launch_csr<mgk::AXPBY>(h->stream, M, v);
 }
-// Is the product with M served by csr_rowclass_lane_spmv for one right-hand side (the kernel that can write d.*out too)?
+// Is the product with M served, for one right-hand side, by a kernel that can write d.*out too (csr_rowclass_lane_spmv, or the
+// streaming kernels csr_pattern_spmv / csr_stream_spmv for operators without row classes)?
 bool restrict_can_scale(const mg_hierarchy* h, const Csr& M) {
-  return h->nrhs == 1 && !h->opt.no_restrict_scale && M.has_rc && M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && M.rc_lane();
+  if (h->nrhs != 1 || h->opt.no_restrict_scale) return false;
+  if (!M.has_rc) return M.max_row_nnz <= mgk::CHUNK - 2;   // the streaming kernels (pattern-coded or plain CSR), short rows: epilogue output
+  return M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && M.rc_lane();
 }
 // out = b - A*x
 int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x,
