@@ -3200,6 +3200,9 @@ __global__ __launch_bounds__(BLK) void dense_apply(const double* __restrict__ Ai
   const int c = wave - row * nrhs;
   const double* a = Ainv + (size_t)row * n;
   double acc = 0.0;
+  // (unrolled: the loads of eight steps go out together, the products are still added in the order j = lane, lane + 64, ...;
+  // as a plain loop every step waited for its own two loads - twelve round trips for the 729-row inverse of C2)
+#pragma unroll 8
   for (int j = lane; j < n; j += 64) acc += a[j] * b[(size_t)j * nrhs + c];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) x[(size_t)row * nrhs + c] = acc;
