@@ -7,6 +7,9 @@ torch.cuda.init()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multigrid_jl_amd as mg
 from multigrid_jl_amd import device as D
+if os.environ.get("AB_LIB"):
+    D._lib = D.load_library(os.path.join(os.path.dirname(D.LIB_PATH), os.environ["AB_LIB"]))
+    print("library:", os.environ["AB_LIB"], flush=True)
 
 def run(multi):
     os.environ["MG_LU_MULTI_MIN_ROWS"] = "0" if multi else "1000000000"
