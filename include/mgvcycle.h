@@ -61,7 +61,8 @@ typedef struct mg_hierarchy mg_hierarchy;
 #define MG_K_SMOOTH_PROLONG 8 /* x' = xp + d.*(b - A*xp), xp = x + P*xc: MGcycle.jl:90 fused into the first post-sweep */
 #define MG_K_SMOOTH_RESIDUAL 9 /* t = x + d.*(b - A*x) and r = b - A*t in one pass (MGcycle.jl:129-131 + 58-60 / SolveFuncs.jl:26-27) */
 #define MG_K_SMOOTH_RESIDUAL_NORM 10 /* the same pass in the solve loop: last post-smoothing sweep + the stopping test's residual: ||r||^2 and t + d.*r out (SolveFuncs.jl:26-30); profile slot only */
-#define MG_K_COUNT 11
+#define MG_K_FOUR_STAGE 11 /* solve loop, fine level: the last post-smoothing sweep + stopping-test residual of step k AND the second pre-smoothing sweep + residual of step k+1 in one pass (SolveFuncs.jl:24-37 around MGcycle.jl:26-31,54-60): x, b in; t', r' and ||r||^2 out; profile slot only */
+#define MG_K_COUNT 12
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 
@@ -248,6 +249,19 @@ int mg_fused_dev_FP64(mg_hierarchy* h, long long level, long long kernel, const 
  * marching kernel (the cycle then runs the two launches). */
 int mg_sweep_residual_dev_FP64(mg_hierarchy* h, long long level, const double* b_dev, const double* x_dev,
                                double* t_dev, double* r_dev, double* xn_dev, double* norm_r);
+
+/* The solve loop's two fine-level passes across the stopping test as ONE four-stage pass (round 4; replaces the pair
+ * SolveFuncs.jl:24-37 runs back to back: the last post-smoothing sweep + `r = b - A x`, `norm(r)` of step k, then
+ * MGcycle.jl:26-31,54-60 of step k+1 - `r[:] = b - A x`, two sweeps of relax, `r = b - A x` for the restriction):
+ *   t = x + d.*(b - A x) ; r = b - A t ; *norm_r = ||r|| ; xn = t + d.*r ; tp = xn + d.*(b - A xn) ; rp = b - A tp.
+ * x, tp, rp: three different device buffers (x 16-byte aligned); t is not stored.  MG_ERR_UNSUPPORTED when the level is not
+ * served (needs the 2-D tile form of the two-stage pass, relaxPre = 2, one right-hand side, a pointwise smoother).
+ * mg_solve*_FP64 uses it on every step but the last by count; a stopping test that ends the loop earlier re-creates the
+ * iterate with one sweep of the pass's input.  Exposed for kernel tests. */
+int mg_four_stage_dev_FP64(mg_hierarchy* h, long long level, const double* b_dev, const double* x_dev, double* tp_dev,
+                           double* rp_dev, double* norm_r);
+/* *yes = 1 when level `level` has the four-stage form; geometry[12] as mg_sweep_residual_form's tile geometry. */
+int mg_four_stage_form(mg_hierarchy* h, long long level, long long* yes, long long* geometry);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Launch kernel `kernel` of `level` `reps` times back to back on the library's stream between two

@@ -2537,6 +2537,360 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
 #undef M3_OPERANDS
 }
 
+// ------------------------------------------------------------------------------------------------
+// FOUR stages in one walk along z (round 4): the solve loop's two fine-level passes are back to back across the stopping
+// test - the last post-smoothing sweep + residual (+ ||r||^2, + the next cycle's first update) of step k writes the vector
+// the second pre-smoothing sweep + residual of step k+1 reads (SolveFuncs.jl:24-37 around MGcycle.jl:26-31,54-60,122-136):
+//     t  = x  + d.*(b - A x)        last post-smoothing sweep of step k        (the iterate of step k)
+//     r  = b - A t ;  ||r||^2       the stopping test's residual               (SolveFuncs.jl:26-30)
+//     xn = t  + d.*r                first pre-smoothing update of step k+1     (MGcycle.jl:134 with the r just computed)
+//     t' = xn + d.*(b - A xn)       second pre-smoothing sweep                 (MGcycle.jl:128-131)
+//     r' = b - A t'                 the residual the restriction needs         (MGcycle.jl:58-60)
+// x and b go in ONCE, t' and r' come out once: 32 B/row where the two passes moved 24 + 32 and ran the tile twice.  The
+// two stages across the stopping test are speculative: if the test ends the loop, the caller re-creates the iterate t with
+// one single-stage sweep of x (still in its buffer) and drops t', r'.
+// Same layout as the two-stage tile kernel above - z-star classes from a verified product map, the z+-1 entries from the
+// lane's own registers, in-plane entries from LDS slabs - with three more rings: the tile core TX x TY carries a halo of
+// 3 rows for stage 1 (x staged with 4), 2 for stage 2, 1 for stage 3; 3 slabs of x and 2 each of t, xn, t' (same pitch and
+// origin, so one set of record offsets serves all; later stages' slabs drop the lines they never touch), stage k runs k-1
+// planes behind stage 1:
+//     iteration z:  x plane z+2 -> ring | t(z) | r, xn (z-1) | t' (z-2) | r' (z-3) | barrier
+// Same products in the same order and the same epilogue expressions as march3: t', r' and ||r|| are bit-identical to the
+// two passes'.  Stores: t'(z-2) and r'(z-3) by every lane (sink for lanes / planes with nothing to store).
+// ------------------------------------------------------------------------------------------------
+struct March4Dev {
+  const M3Class* cls;           // [ncls] records with byte offsets in THIS kernel's pitch
+  const unsigned short* cmap;   // cx[n1] | cy[n2] | cz[nplanes] | tab  (shared with march3)
+  int ncx, ncy, ntab;
+  int n1, n2, nplanes, P;
+  int TX, TY;                   // core tile
+  int tiles_x, tiles_y;
+  int WX, SY;                   // width of the stage-1 region (TX + 6); lines of it per slot pass (NT / WX)
+  int pitch;                    // doubles per slab line (2*NPL)
+  int LY, NPL;                  // lines of an x slab (TY + 8); 16-byte pairs per line
+  int nblocks;
+  int segs, seglen;             // workgroup w = segment (w / tiles) of tile (w % tiles)
+  int n_cols, ncls;
+};
+constexpr int RM4_G = 4;        // halo of the staged x (stage 1 runs on core + 3 rings)
+
+template <int NT, int K1, int NPM>
+__global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, March2Args a, March4Dev T) {
+  extern __shared__ double win[];
+  __shared__ double red[NT / 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int w = xcd_band(blockIdx.x, T.nblocks);
+  const int pitch = T.pitch;
+  const int XS = T.LY * pitch;                                    // doubles per x slab
+  const int TS = (T.LY - 2) * pitch, NS = (T.LY - 4) * pitch, PS = (T.LY - 6) * pitch;   // t, xn, t' slabs
+  // byte offsets (from win) of each ring's VIRTUAL line 0: slab line ly of every ring = in-plane line y0 - 4 + ly
+  const int tB = (3 * XS - pitch) * 8;
+  const int nB = (3 * XS + 2 * TS - 2 * pitch) * 8;
+  const int pB = (3 * XS + 2 * TS + 2 * NS - 3 * pitch) * 8;
+  double* xw = win;
+  char* winb = reinterpret_cast<char*>(win);
+  M3Class* dcl = reinterpret_cast<M3Class*>(win + (3 * XS + 2 * TS + 2 * NS + 2 * PS));   // [ncls]
+  double* dd = reinterpret_cast<double*>(dcl + T.ncls);                                    // [ncls] class relaxPrec
+  unsigned short* cxL = reinterpret_cast<unsigned short*>(dd + T.ncls);                    // cx | cy | cz | tab
+  unsigned short* cyL = cxL + T.n1;
+  unsigned short* czL = cyL + T.n2;
+  unsigned short* tabL = czL + T.nplanes;
+  {
+    const int nw = T.ncls * (int)(sizeof(M3Class) / 8);
+    const double* srcd = reinterpret_cast<const double*>(T.cls);
+    double* dstd = reinterpret_cast<double*>(dcl);
+    for (int i = tid; i < nw; i += NT) dstd[i] = srcd[i];
+    for (int i = tid; i < T.ncls; i += NT) dd[i] = C.cls_d[i];
+    const int nm = T.n1 + T.n2 + T.nplanes + T.ntab;
+    for (int i = tid; i < nm; i += NT) cxL[i] = T.cmap[i];
+  }
+  const int zstride = T.ncy * T.ncx;
+  // ---- the lane's place: column xx of the stage-1 region, lines j + s*SY ---------------------------------------------
+  const int xx = tid % T.WX, j = tid / T.WX;
+  const bool lane_ok = j < T.SY;
+  const int own8 = ((j + 1) * pitch + xx + 1) * 8;      // byte offset of slot 0's own entry inside a slab (every ring)
+  const int sstride8 = T.SY * pitch * 8;                // from slot s to slot s + 1
+  // ---- the lane's 16-byte pairs of an x slab ---------------------------------------------------------------------------
+  int pofs[NPM], pline[NPM];
+  unsigned pflag = 0u;  // per m: bit 4m = the pair exists, bit 4m+1 = first pair of its line, bit 4m+2 = its line is inside the grid
+#pragma unroll
+  for (int m = 0; m < NPM; ++m) {
+    const int pid = tid + m * NT;
+    const int l = pid / T.NPL, i = pid - l * T.NPL;
+    pline[m] = l;
+    pofs[m] = l * pitch + 2 * i;
+    if (pid < T.LY * T.NPL) pflag |= 1u << (4 * m);
+    if (i == 0) pflag |= 2u << (4 * m);
+  }
+  const int ntiles = T.tiles_x * T.tiles_y;
+  const int seg = w / ntiles, c = w - seg * ntiles;
+  const int zs = seg * T.seglen, ze = zs + T.seglen < T.nplanes ? zs + T.seglen : T.nplanes;
+  double* sk = a.sink + ((size_t)(w & 31) * NT + tid);
+  double sq = 0.0;
+  double rlo = 0.0, rhi = 0.0, rv[RM3_NIP];
+  int ro[RM3_NIP], rcls = -1;
+#pragma unroll
+  for (int u = 0; u < RM3_NIP; ++u) {
+    rv[u] = 0.0;
+    ro[u] = 0;
+  }
+#define M4_LOADRECS(cq)                                                                                                \
+  do {                                                                                                                 \
+    const M3Class* q_ = dcl + (cq);                                                                                    \
+    rlo = q_->v_lo;                                                                                                    \
+    rhi = q_->v_hi;                                                                                                    \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) {                                                           \
+      rv[u_] = q_->v[u_];                                                                                              \
+      ro[u_] = q_->off[u_];                                                                                            \
+    }                                                                                                                  \
+    rcls = (cq);                                                                                                       \
+  } while (0)
+  // acc = (z-1 entry) + in-plane entries in stored order + (z+1 entry); base8: byte offset (from win) of the row's own entry
+#define M4_WALK(acc, lo_, hi_, base8)                                                                                  \
+  do {                                                                                                                 \
+    double xv_[RM3_NIP];                                                                                               \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_)                                                             \
+      xv_[u_] = *reinterpret_cast<const double*>(winb + ((base8) + ro[u_]));                                           \
+    (acc) = (acc) + rlo * (lo_);                                                                                       \
+    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) (acc) = (acc) + rv[u_] * xv_[u_];                           \
+    (acc) = (acc) + rhi * (hi_);                                                                                       \
+  } while (0)
+  __syncthreads();   // dictionaries in place
+  if (ze > zs) {
+    const int ty = c / T.tiles_x, tx = c - ty * T.tiles_x;
+    const int x0 = tx * T.TX, y0 = ty * T.TY;
+    int pg[NPM];
+#pragma unroll
+    for (int m = 0; m < NPM; ++m) {
+      const int yl = y0 - RM4_G + pline[m];
+      const int i2 = pofs[m] - pline[m] * pitch;        // 2*i
+      if (yl >= 0 && yl < T.n2) pflag |= 4u << (4 * m);
+      pg[m] = yl * T.n1 + x0 - RM4_G + i2;
+    }
+    const int gx = x0 - 3 + xx;
+    const bool xin = lane_ok && gx >= 0 && gx < T.n1;
+    const int dxo = xx < 3 ? 3 - xx : (xx > T.TX + 2 ? xx - (T.TX + 2) : 0);    // rings between the column and the core
+    const int ip0 = (y0 - 3 + j) * T.n1 + gx;           // in-plane index of slot 0's row; slot s: + s*SY*n1
+    const int ipstride = T.SY * T.n1;
+    unsigned live1 = 0u, live2 = 0u, live3 = 0u, core = 0u;     // per slot: stage k is computed on the row
+    int rp[K1];
+    const int cxo = xin ? (int)cxL[gx] : 0;
+#pragma unroll
+    for (int s = 0; s < K1; ++s) {
+      const int yy = j + s * T.SY, gy = y0 - 3 + yy;
+      const bool l1 = xin && yy < T.TY + 6 && gy >= 0 && gy < T.n2;
+      const int dyo = yy < 3 ? 3 - yy : (yy > T.TY + 2 ? yy - (T.TY + 2) : 0);
+      const int dist = dxo > dyo ? dxo : dyo;
+      live1 |= (l1 ? 1u : 0u) << s;
+      live2 |= ((l1 && dist <= 2) ? 1u : 0u) << s;
+      live3 |= ((l1 && dist <= 1) ? 1u : 0u) << s;
+      core |= ((l1 && dist == 0) ? 1u : 0u) << s;
+      rp[s] = l1 ? (int)cyL[gy] * T.ncx + cxo : 0;
+    }
+#define M4_PAR(p, m) ((int)(((long long)(p) * T.P + pg[m]) & 1LL))
+#define M4_LOADPAIR(dst, p, m)                                                                                         \
+  do {                                                                                                                 \
+    const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u && (p) >= 0 && (p) < T.nplanes;                                \
+    const long long e0_ = ((long long)(p) * T.P + pg[m]) & ~1LL;                                                       \
+    (dst) = march_load_pair(a.x, e0_, act_, T.n_cols);                                                                 \
+  } while (0)
+#define M4_STAGE(slot, p, m, v)                                                                                        \
+  do {                                                                                                                 \
+    if ((pflag >> (4 * (m))) & 1u) {                                                                                   \
+      const int par_ = M4_PAR(p, m);                                                                                   \
+      double* q_ = xw + ((slot) * XS + pofs[m] - par_);                                                                \
+      if (!(par_ && ((pflag >> (4 * (m))) & 2u))) q_[0] = (v).x;                                                       \
+      q_[1] = (v).y;                                                                                                   \
+    }                                                                                                                  \
+  } while (0)
+    const int zA = zs - 3 > 0 ? zs - 3 : 0;             // first plane of stage 1
+    const int zE = ze + 2;                              // last iteration (stage 4 on plane ze - 1)
+    // ---- fill the ring: planes zA (slot 0) and zA+1 (slot 1); plane zA+2 goes into registers ----------------------------
+#pragma unroll 1
+    for (int pp = 0; pp < 2; ++pp) {
+      d2_t q[NPM];
+#pragma unroll
+      for (int m = 0; m < NPM; ++m) M4_LOADPAIR(q[m], zA + pp, m);
+#pragma unroll
+      for (int m = 0; m < NPM; ++m) M4_STAGE(pp, zA + pp, m, q[m]);
+    }
+    d2_t preb[NPM];
+#pragma unroll
+    for (int m = 0; m < NPM; ++m) M4_LOADPAIR(preb[m], zA + 2, m);
+    double nbb[K1];
+#define M4_OPERANDS(zz)                                                                                                \
+  do {                                                                                                                 \
+    const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
+      const int r_ = (pv_ && ((live1 >> s_) & 1u)) ? (zz) * T.P + ip0 + s_ * ipstride : C.n_rows - 1;                  \
+      nbb[s_] = a.b[r_];                                                                                               \
+    }                                                                                                                  \
+  } while (0)
+    M4_OPERANDS(zA);
+    double xm[K1], xc[K1];
+#pragma unroll
+    for (int s = 0; s < K1; ++s) {
+      xm[s] = 0.0;
+      if (zA - 1 >= 0 && ((live1 >> s) & 1u)) xm[s] = a.x[(zA - 1) * T.P + ip0 + s * ipstride];
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * K1; ++i) sk[(size_t)i * 32 * NT] = 0.0;   // as many stores as an iteration issues, behind the loads (see march3)
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < K1; ++s)   // own x of plane zA from its slab (slot 0)
+      xc[s] = ((live1 >> s) & 1u) ? *reinterpret_cast<const double*>(winb + (own8 + s * sstride8)) : 0.0;
+    double t1[K1], t2[K1], n1[K1], n2[K1], p1[K1], p2[K1], b1[K1], b2[K1], b3[K1];
+#pragma unroll
+    for (int s = 0; s < K1; ++s) t1[s] = t2[s] = n1[s] = n2[s] = p1[s] = p2[s] = b1[s] = b2[s] = b3[s] = 0.0;
+    int qz = 0;                    // ring slot of x plane z
+    for (int z = zA; z <= zE; ++z) {
+      d2_t cur[NPM];
+      double b0[K1];
+#pragma unroll
+      for (int m = 0; m < NPM; ++m) {
+        cur[m] = preb[m];
+        asm volatile("" : "+v"(cur[m].x), "+v"(cur[m].y));     // the wait of this iteration: the loads, not the stores behind them
+      }
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        b0[s] = nbb[s];
+        asm volatile("" : "+v"(b0[s]));
+      }
+      const int q1 = qz == 2 ? 0 : qz + 1, q2 = q1 == 2 ? 0 : q1 + 1;   // slots of planes z+1, z+2
+      if (z + 2 <= zE + 1) {
+#pragma unroll
+        for (int m = 0; m < NPM; ++m) M4_STAGE(q2, z + 2, m, cur[m]);
+      }
+      if (z + 3 <= zE + 1) {
+#pragma unroll
+        for (int m = 0; m < NPM; ++m) M4_LOADPAIR(preb[m], z + 3, m);
+      }
+      if (z + 1 <= zE) M4_OPERANDS(z + 1);
+      const bool s1 = z < T.nplanes;                                            // (uniform; z >= zA >= 0)
+      const bool s2 = z - 1 >= 0 && z - 1 < T.nplanes && z >= zs - 1;           // plane z-1 in [zs-2, ze+1]
+      const bool s3 = z - 2 >= 0 && z - 2 < T.nplanes && z >= zs + 1;           // plane z-2 in [zs-1, ze]
+      const bool s4 = z >= zs + 3;                                              // plane z-3 in [zs, ze)
+      const int zb0 = s1 ? (int)czL[z] * zstride : 0;
+      const int zb1 = s2 ? (int)czL[z - 1] * zstride : 0;
+      const int zb2 = s3 ? (int)czL[z - 2] * zstride : 0;
+      const int zb3 = s4 ? (int)czL[z - 3] * zstride : 0;
+      const int xq8 = qz * XS * 8, xq18 = q1 * XS * 8;
+      const int tW8 = tB + (z & 1) * TS * 8, tR8 = tB + ((z - 1) & 1) * TS * 8;
+      const int nW8 = nB + ((z - 1) & 1) * NS * 8, nR8 = nB + (z & 1) * NS * 8;         // xn(z-1) written, xn(z-2) read
+      const int pW8 = pB + (z & 1) * PS * 8, pR8 = pB + ((z - 1) & 1) * PS * 8;         // t'(z-2) written, t'(z-3) read
+      double tc[K1], nc[K1], pc[K1], r4[K1];
+      // ---- stage 1 on plane z: t = x + d.*(b - A x) ------------------------------------------------------------------------
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        tc[s] = 0.0;
+        if ((live1 >> s) & 1u) {
+          const int o8 = own8 + s * sstride8;
+          const double xp = *reinterpret_cast<const double*>(winb + (xq18 + o8));
+          if (s1) {
+            const int cq = (int)tabL[zb0 + rp[s]];
+            if (cq != rcls) M4_LOADRECS(cq);
+            double acc = 0.0;
+            M4_WALK(acc, xm[s], xp, xq8 + o8);
+            const double tv = xc[s] + dd[cq] * (b0[s] - acc);
+            *reinterpret_cast<double*>(winb + (tW8 + o8)) = tv;
+            tc[s] = tv;
+          }
+          xm[s] = xc[s];
+          xc[s] = xp;
+        }
+      }
+      // ---- stage 2 on plane z-1: r = b - A t, xn = t + d.*r, ||r||^2 on the core ------------------------------------------
+      const bool cnt2 = z - 1 >= zs && z - 1 < ze;      // (uniform) the plane belongs to this segment
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        nc[s] = 0.0;
+        if (s2 && ((live2 >> s) & 1u)) {
+          const int cq = (int)tabL[zb1 + rp[s]];
+          if (cq != rcls) M4_LOADRECS(cq);
+          const int o8 = own8 + s * sstride8;
+          double acc = 0.0;
+          M4_WALK(acc, t2[s], tc[s], tR8 + o8);
+          const double rr = b1[s] - acc;
+          const double xv = t1[s] + dd[cq] * rr;
+          *reinterpret_cast<double*>(winb + (nW8 + o8)) = xv;
+          nc[s] = xv;
+          if (cnt2 && ((core >> s) & 1u)) sq += rr * rr;
+        }
+      }
+      // ---- stage 3 on plane z-2: t' = xn + d.*(b - A xn) ---------------------------------------------------------------------
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        pc[s] = 0.0;
+        if (s3 && ((live3 >> s) & 1u)) {
+          const int cq = (int)tabL[zb2 + rp[s]];
+          if (cq != rcls) M4_LOADRECS(cq);
+          const int o8 = own8 + s * sstride8;
+          double acc = 0.0;
+          M4_WALK(acc, n2[s], nc[s], nR8 + o8);
+          const double tv = n1[s] + dd[cq] * (b2[s] - acc);
+          *reinterpret_cast<double*>(winb + (pW8 + o8)) = tv;
+          pc[s] = tv;
+        }
+      }
+      // ---- stage 4 on plane z-3: r' = b - A t' -----------------------------------------------------------------------------
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        r4[s] = 0.0;
+        if (s4 && ((core >> s) & 1u)) {
+          const int cq = (int)tabL[zb3 + rp[s]];
+          if (cq != rcls) M4_LOADRECS(cq);
+          const int o8 = own8 + s * sstride8;
+          double acc = 0.0;
+          M4_WALK(acc, p2[s], pc[s], pR8 + o8);
+          r4[s] = b3[s] - acc;
+        }
+      }
+      // ---- the stores of this iteration (every lane issues every store instruction) ---------------------------------------
+      {
+        const bool w3 = s3 && z - 2 >= zs && z - 2 < ze;   // (uniform) t' of plane z-2 belongs to this segment
+#pragma unroll
+        for (int s = 0; s < K1; ++s) {
+          const int rowp = (z - 2) * T.P + ip0 + s * ipstride, rowr = rowp - T.P;
+          double* qt_ = (w3 && ((core >> s) & 1u)) ? a.t + rowp : sk;
+          *qt_ = pc[s];
+          double* qr_ = (s4 && ((core >> s) & 1u)) ? a.r + rowr : sk;
+          *qr_ = r4[s];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < K1; ++s) {
+        t2[s] = t1[s];
+        t1[s] = tc[s];
+        n2[s] = n1[s];
+        n1[s] = nc[s];
+        p2[s] = p1[s];
+        p1[s] = pc[s];
+        b3[s] = b2[s];
+        b2[s] = b1[s];
+        b1[s] = b0[s];
+      }
+      qz = q1;
+      __syncthreads();
+    }
+  }
+  if (a.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w2 = 0; w2 < NT / 64; ++w2) t += red[w2];
+      a.sumsq[w] = t;
+    }
+  }
+#undef M4_LOADRECS
+#undef M4_WALK
+#undef M4_PAR
+#undef M4_LOADPAIR
+#undef M4_STAGE
+#undef M4_OPERANDS
+}
+
 // Band form: the values of a CSR operator re-laid as planar slots (build_band).  slot[c*NS + e] = the planar array entry e
 // of a row of structure class c goes to; slots a class does not fill keep the 0 they were initialised with.
 __global__ __launch_bounds__(BLK) void band_fill(const int* __restrict__ rowptr, const double* __restrict__ val,

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>   // declarations only: librccl is dlopen'ed by mg_dist_* (single-GPU users do not depend on it)
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -71,6 +72,9 @@ struct Options {
   long long march3_nt = 0;         // threads per workgroup (0: by the fill estimate; 1024 or 768)
   long long march3_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
   bool no_march3_lockstep = false, march3_lockstep_force = false;   // schedule of the 2-D tile form
+  bool no_march4 = false;          // solve loop: never run the two fine-level passes across the stopping test as one four-stage pass
+  long long march4_nt = 0;         // threads per workgroup of the four-stage pass (0: default; 1024 / 768 / 512 = 2 / 3 / 4 rows per lane)
+  long long march4_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -101,6 +105,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_LANE_RPL3", "no_lane_rpl3", 0, no_lane_rpl3), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
+      MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
@@ -222,6 +227,13 @@ struct Csr {
   size_t rm3_lds = 0;
   int rm3_k1 = 3, rm3_nt = 1024;
   double rm3_fill = 0.0;    // estimated L1 fills + stores per row (bytes) of the chosen geometry
+  // four-stage pass of the solve loop (csr_rowclass_march4_spmv): same classes and product map, its own tile geometry
+  bool rc_march4 = false;
+  DevBuf<mgk::M3Class> rm4_cls;
+  mgk::March4Dev rm4{};
+  size_t rm4_lds = 0;
+  int rm4_k1 = 3, rm4_nt = 768;
+  double rm4_fill = 0.0;
   // the same pass for a grid operator WITHOUT row classes (coefficients differ from row to row): structure classes + the
   // values in 7 planar arrays (build_band)
   bool rm3_var = false;
@@ -394,6 +406,8 @@ struct Csr {
     vb_slot.release();
     rm3_cls.release();
     rm3_cmap.release();
+    rc_march4 = false;
+    rm4_cls.release();
     rc_exc2.release();
     rc_nexc2 = 0;
     rp_ok = false;
@@ -991,15 +1005,23 @@ bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* 
   return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
 // the 2-D tile form (csr_rowclass_march3_spmv): template arguments from what is wanted
+// (12 >= stores per lane and iteration: K1 <= 4 rows x 3 outputs; 32 slabs shared by all workgroups; 1024 lanes)
+constexpr size_t M3_SINK_DOUBLES = (size_t)12 * 32 * 1024;
+// > 64 KB of dynamic LDS needs the function attribute - per DEVICE: one bit per device id, set on the first launch there
+static int big_lds_attr(const void* fn, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const unsigned long long bit = 1ULL << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return MG_OK;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  done.fetch_or(bit, std::memory_order_release);
+  return MG_OK;
+}
 template <bool ZERO, int OUT, int NT, int K1, bool VAR = false>
 int launch_march3(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
   auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, NT, K1, RM3_NPM, VAR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  MG_TRY(big_lds_attr(reinterpret_cast<const void*>(fn), attr_done));
   mgk::RowClassDev C = A.rcdev();
   if (VAR) {
     C = mgk::RowClassDev{};
@@ -1032,10 +1054,7 @@ int launch_march3_any(hipStream_t stream, const Csr& A, mgk::March2Args a, bool 
 int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::March2Args& a_in, bool from_zero) {
   mgk::March2Args a = a_in;
   const int nb1 = A.rm3.nblocks;
-  {
-    const size_t need = (size_t)12 * 32 * (size_t)A.rm3_nt;   // (12 >= stores per lane and iteration: K1 <= 4 rows x 3 outputs; 32 slabs shared by all workgroups)
-    if (h->m3sink.n < need) MG_TRY(h->m3sink.alloc(need));
-  }
+  if (h->m3sink.n < M3_SINK_DOUBLES) return fail(MG_ERR_STATE, "the store sink of the tile-form pass is missing (mg_finalize allocates it)");
   a.sink = h->m3sink.p;
   a.d = h->lev[(size_t)level].d.p;
   if (a.sumsq && (size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
@@ -1104,6 +1123,53 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
     launch_sum_final(h, h->partial.p, nb1);
     HIP_TRY(hipGetLastError());
   }
+  return MG_OK;
+}
+// The solve loop's two fine-level passes across the stopping test as ONE four-stage pass (csr_rowclass_march4_spmv):
+//   t = x + d.*(b - A x) ; r = b - A t ; ||r||^2 ; xn = t + d.*r ; tp = xn + d.*(b - A xn) ; rp = b - A tp
+// x, tp, rp: three different buffers; the iterate t is not stored (the caller re-creates it from x if the loop stops).
+template <int NT, int K1, int NPM>
+int launch_march4(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
+  auto* fn = &mgk::csr_rowclass_march4_spmv<NT, K1, NPM>;
+  static std::atomic<unsigned long long> attr_done{0};
+  MG_TRY(big_lds_attr(reinterpret_cast<const void*>(fn), attr_done));
+  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm4.nblocks), dim3(NT), A.rm4_lds, stream, A.rcdev(), a, A.rm4);
+  HIP_TRY(hipGetLastError());
+  return MG_OK;
+}
+bool march4_ok(const mg_hierarchy* h, int level, const double* x, const double* tp, const double* rp) {
+  const Level& L = h->lev[(size_t)level];
+  if (h->nrhs != 1 || h->relax_type != 0 || h->opt.no_march4) return false;
+  if (!L.A.rc_march4 || !L.A.has_rc || !L.A.rc_has_d || L.A.rc_nexc != 0 || L.A.d_bound != L.d.p) return false;
+  if (std::max<long long>(1, L.npre) != 2) return false;   // (xn is the input of the LAST pre-smoothing sweep)
+  if (x == tp || x == rp || tp == rp) return false;
+  return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+int k_four_stage(mg_hierarchy* h, int level, const double* b, const double* x, double* tp, double* rp) {
+  const Csr& A = h->lev[(size_t)level].A;
+  mgk::March2Args a{};
+  a.x = x;
+  a.b = b;
+  a.t = tp;
+  a.r = rp;
+  a.sumsq = h->partial.p;
+  if (h->m3sink.n < M3_SINK_DOUBLES) return fail(MG_ERR_STATE, "the store sink of the tile-form pass is missing (mg_finalize allocates it)");
+  a.sink = h->m3sink.p;
+  a.d = h->lev[(size_t)level].d.p;
+  const int nb1 = A.rm4.nblocks;
+  if ((size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the four-stage pass");
+  const double n8 = 8.0 * (double)A.n_rows;
+  {
+    const double tables = (double)A.rc_ncls * 88.0 + 2.0 * (double)(A.rm4.n1 + A.rm4.n2 + A.rm4.nplanes + A.rm4.ntab);
+    // algorithmic: four products with A (two fused sweeps, two residuals); moved: x, b in, t' and r' out
+    ProfScope ps(h, level, MG_K_FOUR_STAGE, 2.0 * (spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false)), tables + 4.0 * n8);
+    if (A.rm4_nt == 1024) MG_TRY((launch_march4<1024, 2, 2>(h->stream, A, a)));
+    else if (A.rm4_nt == 768) MG_TRY((launch_march4<768, 3, 2>(h->stream, A, a)));
+    else MG_TRY((launch_march4<512, 4, 3>(h->stream, A, a)));
+  }
+  ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
+  launch_sum_final(h, h->partial.p, nb1);
+  HIP_TRY(hipGetLastError());
   return MG_OK;
 }
 // Can the coarse-grid correction of level `level` ride in the staging of the first post-smoothing sweep?
@@ -1387,9 +1453,11 @@ int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, b
 // x1_given (with x_zero): xa already holds d.*b, the first update from x = 0 (written by the restriction that produced b).
 // defer_post (solve loop, fine level): leave the LAST post-smoothing sweep to the caller, who fuses it with the residual
 // of the stopping test (k_smooth_residual); *defer_post says whether that happened (result = x before that sweep).
+// pre_done (solve loop, fine level): the caller's four-stage pass already ran this level's pre-smoothing and residual -
+// xa holds the smoothed x, L.r = b - A x: the cycle starts at the restriction.
 int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero,
                 char ctype, double** result, bool r_valid = false, bool x1_ready = false, bool* defer_post = nullptr,
-                bool x1_given = false) {
+                bool x1_given = false, bool pre_done = false) {
   const int nl = (int)h->nlevels;
   if (l == nl - 1) {  // solveCoarsest (MGcycle.jl:13-18,67-69,177): x = LU \ b
     MG_TRY(k_coarse(h, l, b, xa));
@@ -1408,7 +1476,9 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   const long long npost = std::max<long long>(1, L.npost);
   bool from_zero = false;
   // pre-smoothing (MGcycle.jl:26-31,54).  x == 0: r = b, so the first sweep is x = d.*b.
-  if (h->relax_type == 1) {  // Jac-GMRES (MGcycle.jl:48-50): FGMRES on the residual, preconditioned by D
+  if (pre_done) {
+    npre = 0;
+  } else if (h->relax_type == 1) {  // Jac-GMRES (MGcycle.jl:48-50): FGMRES on the residual, preconditioned by D
     const double* r0 = b;
     if (x_zero) {
       MG_TRY(k_fill(h, cur, len, 0.0));
@@ -1435,7 +1505,9 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
     std::swap(cur, alt);
   }
   // r = b - A x ; bc = R r ; xc = 0 (MGcycle.jl:58-66)
-  if (fuse_pre) {
+  if (pre_done) {
+    // (L.r is the four-stage pass's r')
+  } else if (fuse_pre) {
     MG_TRY(k_smooth_residual(h, l, b, cur, alt, L.r.p, nullptr, false, from_zero));
     std::swap(cur, alt);
   } else {
@@ -1608,14 +1680,27 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
     spare = L.x2.p;
     fuse_post = march2_ok(h, 0, cur, alt, nullptr, spare) && march2_ok(h, 0, alt, spare, nullptr, cur) && march2_ok(h, 0, spare, cur, nullptr, alt);
   }
+  // Four-stage pass (csr_rowclass_march4_spmv): while the loop goes on by count, the fused last sweep + stopping-test residual of
+  // step k and the second pre-smoothing sweep + residual of step k+1 - back to back across the stopping test - are ONE pass:
+  // cur (x before the last sweep) -> alt = t' (x after the next cycle's pre-smoothing), L.r = r' = b - A t', ||r|| of step k.
+  // The next cycle then starts at its restriction (pre_done).  Speculative across the test: if it ends the loop, the iterate
+  // is re-created from the pass's input (t_missing4) and t', r' are dropped.
+  bool pre_done = false, t_missing4 = false;
   for (long long count = 1; count <= maxIter; ++count) {
     double* out = nullptr;
     // from the second step on, L.r = b - A*x is the residual just computed for the stopping test
     bool deferred = fuse_post;
-    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero, x1_ready, &deferred));
+    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero, x1_ready, &deferred, false, pre_done));
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
-    if (deferred) {
+    pre_done = false;
+    if (deferred && count < maxIter && !h->opt.no_dead_t && march4_ok(h, 0, cur, alt, L.r.p)) {
+      MG_TRY(k_four_stage(h, 0, b, cur, alt, L.r.p));
+      std::swap(cur, alt);        // cur = t' (the next cycle's x after pre-smoothing); alt = the input of the pass
+      pre_done = true;
+      x1_ready = false;
+      t_missing4 = true;
+    } else if (deferred) {
       // cur = x before the last sweep; alt <- the iterate; spare <- x + d.*r (unused if this was the last step).
       // The iterate itself is DEAD while the loop goes on (the next cycle starts from x + d.*r and recomputes its own
       // residual): unless this is the last step by count it is not stored (8 of the pass's 34 bytes per row); should the
@@ -1643,8 +1728,10 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
     if (resvec) resvec[it] = res;
     if (res / res0 < tol) break;  // SolveFuncs.jl:34-36
     t_missing = false;            // (the loop goes on: the iterate of this step is never read)
+    t_missing4 = false;
   }
   if (t_missing) MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, spare, cur));   // spare: the input of the last pass; cur: the iterate
+  if (t_missing4) MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, alt, cur));    // alt: the input of the four-stage pass; cur (t', dropped): the iterate
   if (cur != x) {
     HIP_TRY(hipMemcpyAsync(x, cur, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(spin_sync(h->stream));
@@ -2629,6 +2716,7 @@ int build_march3(Csr& A, const long long grid[3]) {
       !A.opt.no_march3 && !A.opt.no_march2 && !A.opt.no_march)
     return band_refill(A);
   A.rc_march3 = false;
+  A.rc_march4 = false;
   A.rm3_var = false;
   A.vband.release();
   if (!A.has_rc) return build_band(A, grid);
@@ -2755,6 +2843,99 @@ int build_band(Csr& A, const long long grid[3]) {
   A.rm3.vstride = vstride;
   A.rm3_var = true;
   A.band_ncls = (long long)ncls;
+  return MG_OK;
+}
+
+// Four-stage pass of the solve loop (csr_rowclass_march4_spmv) on an operator the two-stage tile form serves: same class
+// records (offsets re-expressed in its own pitch) and the same product map; tile geometry of its own - the stage-1 region
+// is WX = TX + 6 columns wide (three rings around the core), an NT-thread workgroup holds SY = NT / WX lines of it per slot
+// pass and K1 passes: TY = K1*SY - 6; 3 x slabs of TY + 8 lines, 2 each of t (TY + 6), xn (TY + 4), t' (TY + 2) within the
+// 160 KB of LDS; always the lockstep schedule (tiles x segments of planes = at most one workgroup per CU).
+int build_march4(Csr& A, const std::vector<mgk::M3Class>& recs3, const std::vector<std::vector<M3Ent>>& ents, int ncx, int ncy, int ncz,
+                 size_t dict_bytes, int ncu) {
+  A.rc_march4 = false;
+  if (A.opt.no_march4) return MG_OK;
+  const long long n1 = A.rm3.n1, n2 = A.rm3.n2, n3 = A.rm3.nplanes, P = n1 * n2;
+  if (n3 < 8) return MG_OK;
+  if (A.n_rows + 8 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
+  const long long lds_cap = 160 * 1024 - 1024;
+  struct Geo { long long NT, tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, K1, NPM, nb, segs, seglen; size_t lds; double fill; };
+  Geo best{};
+  bool have = false;
+  const long long want_nt = A.opt.march4_nt != 0 ? A.opt.march4_nt : 768;
+  for (long long NT : {1024LL, 768LL, 512LL}) {
+    if (NT != want_nt) continue;
+    const long long K1 = NT == 1024 ? 2 : NT == 768 ? 3 : 4, NPM = NT == 512 ? 3 : 2;
+    for (long long tilesx = 1; tilesx <= std::max<long long>({1, n1 / 16, A.opt.march4_tiles_x}); ++tilesx) {
+      if (A.opt.march4_tiles_x > 0 && tilesx != A.opt.march4_tiles_x) continue;
+      Geo g{};
+      g.NT = NT; g.K1 = K1; g.NPM = NPM; g.tilesx = tilesx;
+      g.TX = (n1 + tilesx - 1) / tilesx;
+      g.WX = g.TX + 6;
+      if (g.WX > NT / 2) continue;
+      g.SY = NT / g.WX;
+      g.NPL = (g.TX + 2 * mgk::RM4_G + 2) / 2;
+      g.pitch = 2 * g.NPL;
+      // the tallest tile the lanes, the pair loads and the LDS allow
+      long long TY = std::min<long long>(K1 * g.SY - 6, n2);
+      while (TY >= 2 && ((TY + 8) * g.NPL > NPM * NT || (long long)((size_t)(9 * (TY + 8) - 24) * (size_t)g.pitch * 8 + dict_bytes) > lds_cap)) --TY;
+      if (TY < 2) continue;
+      g.tilesy = (n2 + TY - 1) / TY;
+      g.TY = (n2 + g.tilesy - 1) / g.tilesy;                        // equal tiles
+      g.LY = g.TY + 8;
+      g.lds = (size_t)(9 * g.LY - 24) * (size_t)g.pitch * 8 + dict_bytes;
+      const long long tiles = g.tilesx * g.tilesy, slots = ncu;
+      if (tiles > slots) continue;
+      const long long S = std::min<long long>(slots / tiles, std::max<long long>(1, n3 / 8));
+      const long long Lz = (n3 + S - 1) / S;
+      const double eff = ((double)n3 / (double)(S * Lz)) * ((double)(tiles * S) / (double)slots);
+      g.segs = S; g.seglen = Lz; g.nb = tiles * S;
+      const double core = (double)g.TX * (double)g.TY, R = (double)Lz;
+      const double waste = (double)(g.tilesx * g.TX) * (double)(g.tilesy * g.TY) / (double)P;
+      auto lines = [](double W) { return 1.0 + 15.0 / W; };
+      const double fx = 8.0 * (double)((g.TX + 8) * (g.TY + 8)) / core * (1.0 + 8.0 / R) * lines((double)(g.TX + 8));
+      const double fb = 8.0 * (double)((g.TX + 6) * (g.TY + 6)) / core * (1.0 + 6.0 / R) * lines((double)(g.TX + 6));
+      g.fill = (waste * (8.0 + 0.5 * (fx - 8.0) + 8.0 + 0.5 * (fb - 8.0)) + 16.0) / eff;
+      if (!have || g.fill < best.fill) {
+        best = g;
+        have = true;
+      }
+    }
+  }
+  if (!have) return MG_OK;
+  if (best.nb < std::min<long long>(A.opt.march_min_wg, (long long)ncu * 3 / 4)) return MG_OK;   // small levels: latency-bound
+  const size_t ncls = recs3.size();
+  std::vector<mgk::M3Class> recs(recs3);
+  for (size_t c = 0; c < ncls; ++c) {
+    int nip = 0, first_off = 0;
+    for (const M3Ent& t : ents[c]) {
+      if (t.dz != 0) continue;
+      const int off = (int)((t.dy * best.pitch + t.dx) * 8);
+      if (nip == 0) first_off = off;
+      recs[c].off[nip++] = off;
+    }
+    for (int u = nip; u < mgk::RM3_NIP; ++u) recs[c].off[u] = first_off;
+  }
+  MG_TRY(A.rm4_cls.alloc(ncls));
+  HIP_TRY(hipMemcpy(A.rm4_cls.p, recs.data(), ncls * sizeof(mgk::M3Class), hipMemcpyHostToDevice));
+  mgk::March4Dev T{};
+  T.cls = A.rm4_cls.p;
+  T.cmap = A.rm3_cmap.p;
+  T.ncx = ncx; T.ncy = ncy; T.ntab = ncx * ncy * ncz;
+  T.n1 = (int)n1; T.n2 = (int)n2; T.nplanes = (int)n3; T.P = (int)P;
+  T.TX = (int)best.TX; T.TY = (int)best.TY; T.tiles_x = (int)best.tilesx; T.tiles_y = (int)best.tilesy;
+  T.WX = (int)best.WX; T.SY = (int)best.SY; T.pitch = (int)best.pitch; T.LY = (int)best.LY; T.NPL = (int)best.NPL;
+  T.nblocks = (int)best.nb; T.segs = (int)best.segs; T.seglen = (int)best.seglen;
+  T.n_cols = (int)A.n_cols; T.ncls = (int)ncls;
+  A.rm4 = T;
+  A.rm4_lds = best.lds;
+  A.rm4_k1 = (int)best.K1;
+  A.rm4_nt = (int)best.NT;
+  A.rm4_fill = best.fill;
+  A.rc_march4 = true;
+  if (A.opt.debug_format)
+    std::fprintf(stderr, "[mg] march4: tiles %lldx%lld of %lldx%lld (%lld threads, K1 %lld, SY %lld), %lld segments of %lld planes, LDS %zu B, est. %.1f B/row\n",
+                 best.tilesx, best.tilesy, best.TX, best.TY, best.NT, best.K1, best.SY, best.segs, best.seglen, best.lds, best.fill);
   return MG_OK;
 }
 
@@ -2996,6 +3177,7 @@ int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl_
   A.rm3_nt = (int)best.NT;
   A.rm3_fill = best.fill;
   A.rc_march3 = true;
+  if (!var && !box) MG_TRY(build_march4(A, recs, ents, ncx, ncy, ncz, dict_bytes, ncu));
   if (A.opt.debug_format)
     std::fprintf(stderr, "[mg] march3: grid %lldx%lldx%lld tiles %lldx%lld of %lldx%lld (%lld threads, K1 %lld, SY %lld), %lld workgroups%s, class maps %dx%dx%d, LDS %zu B, est. %.1f B/row\n",
                  n1, n2, n3, best.tilesx, best.tilesy, best.TX, best.TY, best.NT, best.K1, best.SY, best.nb,
@@ -3195,6 +3377,9 @@ int alloc_scratch(mg_hierarchy* h) {
     const size_t need = (size_t)std::max(h->lev[0].A.nblocks, h->lev[0].A.ln_blocks);
     if (need > h->partial.n) MG_TRY(h->partial.alloc(need));
   }
+  // store sink of the tile-form passes, at its largest size (12 stores x 32 slabs x 1024 lanes = 3 MB): never (re)allocated
+  // on the launch path - a launch may sit inside a stream capture, and earlier graphs hold the pointer
+  if (h->m3sink.n < M3_SINK_DOUBLES) MG_TRY(h->m3sink.alloc(M3_SINK_DOUBLES));
   // host-pointer API staging (fine level) + transpose scratch (any level, for mg_spmv)
   MG_TRY(h->stage_b.alloc((size_t)nmax * k));
   MG_TRY(h->stage_x.alloc((size_t)nmax * k));
@@ -4334,6 +4519,36 @@ int mg_sweep_residual_dev_FP64(mg_hierarchy* h, long long level, const double* b
   if (norm_r) MG_TRY(scalar_sync(h, norm_r));
   HIP_TRY(spin_sync(h->stream));
   prof_collect(h);
+  return MG_OK;
+}
+
+int mg_four_stage_dev_FP64(mg_hierarchy* h, long long level, const double* b, const double* x, double* tp, double* rp,
+                           double* norm_r) {
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  if (level < 1 || level >= h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  if (!b || !x || !tp || !rp) return fail(MG_ERR_INVALID, "null vector");
+  (void)hipSetDevice(h->device);
+  if (!march4_ok(h, (int)level - 1, x, tp, rp))
+    return fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the four-stage pass (one right-hand side, pointwise smoother, two "
+                "pre-smoothing sweeps, z-star grid operator without exception rows, distinct 16-byte aligned buffers)", level);
+  MG_TRY(k_four_stage(h, (int)level - 1, b, x, tp, rp));
+  if (norm_r) MG_TRY(scalar_sync(h, norm_r));
+  HIP_TRY(spin_sync(h->stream));
+  prof_collect(h);
+  return MG_OK;
+}
+int mg_four_stage_form(mg_hierarchy* h, long long level, long long* yes, long long* geometry) {
+  if (!h || !yes || !geometry) return fail(MG_ERR_INVALID, "null argument");
+  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
+  const Csr& A = h->lev[(size_t)level - 1].A;
+  *yes = (A.rc_march4 && !h->opt.no_march4) ? 1 : 0;
+  for (int i = 0; i < 12; ++i) geometry[i] = 0;
+  if (A.rc_march4) {
+    const long long g[12] = {A.rm4.tiles_x, A.rm4.tiles_y, A.rm4.TX, A.rm4.TY, A.rm4_k1, A.rm4.nblocks, (long long)A.rm4_lds,
+                             (long long)(A.rm4_fill * 100.0), A.rm4_nt, A.rm4.segs, A.rm4.seglen, A.rm4.ntab};
+    for (int i = 0; i < 12; ++i) geometry[i] = g[i];
+  }
   return MG_OK;
 }
 

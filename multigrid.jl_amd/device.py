@@ -24,9 +24,9 @@ LIB_PATH = os.environ.get("MGVCYCLE_LIB") or os.path.join(_HERE, "csrc", "libmgv
 
 MG_OP_A, MG_OP_P, MG_OP_R = 0, 1, 2
 (MG_K_SPMV, MG_K_RESIDUAL, MG_K_SMOOTH, MG_K_RESTRICT, MG_K_PROLONG, MG_K_DSCALE, MG_K_COARSE,
- MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_SMOOTH_RESIDUAL_NORM, MG_K_COUNT) = range(12)
+ MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_SMOOTH_RESIDUAL_NORM, MG_K_FOUR_STAGE, MG_K_COUNT) = range(13)
 KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm", "smooth+prolong", "smooth+residual",
-                "smooth+residual+norm"]
+                "smooth+residual+norm", "four-stage"]
 
 _ll = C.c_longlong
 _dp = C.POINTER(C.c_double)
@@ -76,6 +76,8 @@ SIGNATURES = {
     "mg_spmv_dev_FP64": (C.c_int, [_vp, _ll, _ll, C.c_double, _vp, C.c_double, _vp, _ll]),
     "mg_fused_dev_FP64": (C.c_int, [_vp, _ll, _ll, _vp, _vp, _vp, _ll]),
     "mg_sweep_residual_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
+    "mg_four_stage_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
+    "mg_four_stage_form": (C.c_int, [_vp, _ll, _lp, _lp]),
     "mg_time_op_dev_FP64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _dp, _dp]),
     "mg_profile_enable": (C.c_int, [_vp, _ll]),
     "mg_profile_get": (C.c_int, [_vp, _ll, _ll, _dp, _lp, _dp]),
@@ -511,6 +513,21 @@ class DeviceHierarchy:
             self.handle, level, _ptr(b), _ptr(x), _ptr(t), _ptr(r) if r is not None else None,
             _ptr(xn) if xn is not None else None, C.byref(ss) if want_norm else None), "mg_sweep_residual_dev")
         return float(ss.value)
+
+    def four_stage_dev(self, level, b, x, tp, rp, want_norm=True):
+        """The solve loop's two fine-level passes across the stopping test as one pass: t = x + d.*(b - A x), r = b - A t (||r||
+        returned), xn = t + d.*r, tp = xn + d.*(b - A xn), rp = b - A tp (csr_rowclass_march4_spmv)."""
+        ss = C.c_double(0.0)
+        _check(self.lib, self.lib.mg_four_stage_dev_FP64(self.handle, level, _ptr(b), _ptr(x), _ptr(tp), _ptr(rp),
+                                                         C.byref(ss) if want_norm else None), "mg_four_stage_dev")
+        return float(ss.value)
+
+    def four_stage_form(self, level: int):
+        """(available, geometry as sweep_residual_form's)."""
+        f = C.c_longlong(0)
+        g = (C.c_longlong * 12)()
+        _check(self.lib, self.lib.mg_four_stage_form(self.handle, level, C.byref(f), g), "mg_four_stage_form")
+        return bool(f.value), [int(v) for v in g]
 
     def set_stream(self, stream: int):
         """Enqueue on the caller's HIP stream (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
