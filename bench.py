@@ -123,8 +123,40 @@ def run_ranks(argv, n, extra_env=None, tag=""):
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    # Watch ALL ranks: rank 0's pipe is drained by a thread; the first rank that exits non-zero (or a global deadline,
+    # MG_BENCH_LAUNCH_TIMEOUT seconds, default 3600) ends the others - a rank left alone in an RCCL / gloo collective would
+    # otherwise wait forever (the raw communicator of the native sequencer has no watchdog).
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("MG_BENCH_LAUNCH_TIMEOUT", "3600"))
+    failed = None
+    while True:
+        rcs = [q.poll() for q in procs]
+        if all(c is not None for c in rcs):
+            break
+        bad = next((i for i, c in enumerate(rcs) if c not in (None, 0)), None)
+        if bad is not None or time.time() > deadline:
+            failed = f"rank {bad} exited with {rcs[bad]}" if bad is not None else "deadline reached"
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+            t_kill = time.time() + 10.0
+            while time.time() < t_kill and any(q.poll() is None for q in procs):
+                time.sleep(0.1)
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            break
+        time.sleep(0.2)
+    rcs = [q.wait() for q in procs]
+    reader.join(timeout=10.0)
+    out0 = b"".join(c for c in chunks if c)
+    if failed:
+        log(f"[launcher{tag}] {failed}: the remaining ranks were stopped")
+        if all(c == 0 for c in rcs):
+            rcs[0] = 1
     line = None
     for ln in (out0 or b"").decode(errors="replace").splitlines():
         ln = ln.strip()
@@ -187,11 +219,13 @@ def launch(args):
 
 
 def levels_for(cells):
-    """Coarsest grid 9^3 nodes: 32 -> 3, 256 -> 6, 512 -> 7."""
-    lv = 1
-    c = cells
-    while c > 8 and c % 2 == 0:
-        c //= 2
+    """Levels down to a coarsest grid of at most 9^3 nodes: 32 -> 3, 256 -> 6, 512 -> 7.  Node counts that become
+    even on the way (400 cells: 401 -> 201 -> 101 -> 51 -> 26 -> 14 -> 8) keep coarsening - full weighting handles them by
+    keeping the last node (GeometricTransferOperators.jl:35-36); stopping at the first even count left a 26^3 coarsest level
+    on the sparse-factor path (0.55 ms of a 2.4 ms step at 400^3, round 3)."""
+    lv, n = 1, cells + 1
+    while n > 9:
+        n = (n + 1) // 2 if n % 2 == 1 else n // 2 + 1
         lv += 1
     return lv
 
@@ -320,9 +354,19 @@ def main():
     kname, fmt_name = kernel_symbol(h, mg, p, 1, nrhs)
     # the dominant fine-level kernel: the single-stage fused sweep, or - where the two-stage marching kernel serves the
     # level - the sweep + residual pass (csr_rowclass_march2_spmv), whichever takes more of the step
-    dom = max((k for k in ((1, "smooth"), (1, "smooth+residual")) if k in prof), key=lambda k: prof[k][0])
+    dom = max((k for k in ((1, "smooth"), (1, "smooth+residual"), (1, "four-stage")) if k in prof), key=lambda k: prof[k][0])
     kdesc = "fine-level fused damped-Jacobi sweep x' = x + d.*(b - A x), level 1"
     tile_geo = None
+    if dom[1] == "four-stage":
+        ok4, geo = h.four_stage_form(1)
+        kname = f"mgk::csr_rowclass_march4_spmv<{geo[8]}, {geo[4]}, NPM, PITCH>"
+        tile_geo = {"tiles_per_line": geo[0], "tiles_per_column": geo[1], "TX": geo[2], "TY": geo[3], "rows_per_lane": geo[4],
+                    "threads_per_workgroup": geo[8], "workgroups": geo[5], "lds_bytes": geo[6],
+                    "schedule": f"lockstep: {geo[9]} segments of {geo[10]} planes per tile",
+                    "class_table_entries": geo[11], "estimated_fill_bytes_per_row": geo[7] / 100.0}
+        kdesc = ("the solve loop's two fine-level passes across the stopping test as ONE four-stage pass, level 1: last post-smoothing "
+                 "sweep t = x + d.*(b - A x), stopping-test residual r = b - A t with ||r||^2, first pre-smoothing update xn = t + d.*r, "
+                 "second pre-smoothing sweep t' = xn + d.*(b - A xn) and the restriction's residual r' = b - A t' (x, b in; t', r' out)")
     if dom[1] == "smooth+residual":
         form, geo = h.sweep_residual_form(1)
         kname = "mgk::csr_rowclass_march2_spmv<false>"
@@ -385,6 +429,33 @@ def main():
         roofline["solve_loop_variant"] = {"avg_launch_ms": round(ms2 / cnt2, 5), "launches": cnt2, "bytes_per_launch": mv2,
                                           "achieved": round(mv2 / (ms2 / cnt2) / 1e6, 1),
                                           "frac": round(mv2 / (ms2 / cnt2) / 1e6 / HBM_PEAK_GBS, 4)}
+    if dom[1] == "four-stage":
+        # Four products with A per 32 B/row: the pass is bound by vector-ALU issue (fp64 FMAs + LDS traffic of four stencil
+        # stages on tile + rings), not by HBM - its fraction of the HBM peak is LOWER than the two-stage pass's although it
+        # replaces two of them in less time than 1.5.  Reported next to it: the same time priced at the bytes of the two
+        # two-stage passes it replaces (x, b in, t + d.*r out; then x, b in, t, r out = 56 B/row) and of the four single-stage
+        # launches those replaced (4 x 24 B/row).
+        n8 = 8.0 * n
+        roofline["temporal_blocking"] = {
+            "stages_per_pass": 4, "moved_bytes_per_launch": mv_s,
+            "two_two_stage_passes_would_move": 7.0 * n8, "equivalent_vs_two_stage_passes": round(7.0 * n8 / avg_s / 1e6, 1),
+            "equivalent_vs_two_stage_passes_ratio_to_peak": round(7.0 * n8 / avg_s / 1e6 / HBM_PEAK_GBS, 4),
+            "four_single_stage_launches_would_move": 12.0 * n8, "equivalent_vs_single_stage": round(12.0 * n8 / avg_s / 1e6, 1),
+            "equivalent_vs_single_stage_ratio_to_peak": round(12.0 * n8 / avg_s / 1e6 / HBM_PEAK_GBS, 4),
+            "fp64_flops_per_launch": 2.0 * 36.0 * n, "fp64_tflops": round(2.0 * 36.0 * n / avg_s / 1e9, 2),
+            "note": "frac above = bytes THIS kernel has to move / its time / HBM peak; `equivalent_*` price the same time at the bytes "
+                    "of the launches it replaces - traffic avoided, not bandwidth.  fp64_flops: 4 stages x 9 fused multiply-adds per row "
+                    "(useful rows only; the rings add 17 %)"}
+        for key in ((1, "smooth+residual"), (1, "smooth+residual+norm")):
+            if key in prof:   # the two-stage passes still in the step (first cycle of a solve: from x = 0; last step by count)
+                ms2, cnt2, _ = prof[key]
+                roofline.setdefault("two_stage_passes_in_this_run", {})[key[1]] = {
+                    "avg_launch_ms": round(ms2 / cnt2, 5), "launches": cnt2, "bytes_per_launch": moved[key],
+                    "frac": round(moved[key] / (ms2 / cnt2) / 1e6 / HBM_PEAK_GBS, 4)}
+        # time-weighted fraction of the HBM peak over every fine-level sweep / residual launch of the run
+        tw_b = sum(moved[k] * prof[k][1] for k in prof if k[0] == 1 and k[1] in ("four-stage", "smooth+residual", "smooth+residual+norm", "smooth", "residual"))
+        tw_t = sum(prof[k][0] for k in prof if k[0] == 1 and k[1] in ("four-stage", "smooth+residual", "smooth+residual+norm", "smooth", "residual"))
+        roofline["fine_level_sweeps_time_weighted_frac"] = round(tw_b / tw_t / 1e6 / HBM_PEAK_GBS, 4) if tw_t > 0 else None
     if dom[1] == "smooth+residual":
         # Temporal blocking lowers the COMPULSORY bytes (34 B/row instead of 2 x 26 for the two launches it replaces), so
         # its fraction of the peak is not comparable with a single-stage kernel's: report, next to it, (a) the same time

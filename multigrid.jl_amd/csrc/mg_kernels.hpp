@@ -1414,6 +1414,23 @@ __device__ __forceinline__ d2_t march_load_pair(const double* __restrict__ x, lo
 }
 
 // class ids and first columns of the prolongation's rows e0, e0 + 1 (prefetched one plane ahead of their use)
+// The same pair with ONE 16-byte load in every lane, no branch and NO fix-up behind the load (a select on the loaded value
+// would be a wait right after the issue): the number of vector-memory instructions a lane issues is static (the loop-top
+// wait of the marching kernels counts them) and no load waits for an earlier one's destination registers - the two-path
+// form above makes the compiler put `s_waitcnt vmcnt(1)` in front of the second path's load, i.e. every iteration waits for
+// the stores of the previous one.  e0 even.  Returns the RAW pair at a clamped address: entries outside [0, n_cols) and
+// inactive pairs come back as some finite entries of x (their consumers multiply them by 0 or drop them); when only entry
+// e0 exists (n_cols odd, e0 = n_cols - 1) the pair one entry earlier is read and march_pair_fix, applied where the pair is
+// CONSUMED, moves it into place.
+__device__ __forceinline__ bool march_pair_tail(long long e0, bool act, int n_cols) { return act && e0 == (long long)n_cols - 1; }
+__device__ __forceinline__ d2_t march_load_pair_raw(const double* __restrict__ x, long long e0, bool act, int n_cols) {
+  const bool in = act && e0 >= 0 && e0 <= (long long)n_cols - 2;
+  const long long ec = in ? e0 : (march_pair_tail(e0, act, n_cols) ? e0 - 1 : 0);
+  return *reinterpret_cast<const d2_t*>(x + ec);           // (tail: a 16-byte load at an 8-byte aligned address)
+}
+__device__ __forceinline__ void march_pair_fix(d2_t& v, long long e0, bool act, int n_cols) {
+  if (march_pair_tail(e0, act, n_cols)) v.x = v.y;
+}
 struct ProRows {
   int cls0, cls1, first0, first1;
 };
@@ -2092,6 +2109,11 @@ struct March3Dev {
                       // bit 1 = b READ non-temporally as well (lockstep neighbours then fetch their common ring rows of b from HBM twice:
                       // +33 us per step at 400^3).  Off.
 #endif
+#ifndef MG_M3_RAW
+#define MG_M3_RAW 1   // slab pairs by ONE 16-byte load in every lane at a clamped address, no branch (march_load_pair_raw): round 4 found
+                      // `s_waitcnt vmcnt(1)` in front of the second path's load of the two-path form - every iteration waited for the
+                      // stores of the previous one.  0 restores the two-path loads (A/B).
+#endif
 #ifndef MG_M3_EXP
 #define MG_M3_EXP 0   // attribution builds (make variant): 1 no class walks, 2 no slab/operand loads, 3 no stores
 #endif
@@ -2256,7 +2278,17 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   do {                                                                                                                 \
     const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u && (p) >= 0 && (p) < T.nplanes;                                \
     const long long e0_ = ((long long)(p) * T.P + pg[m]) & ~1LL;                                                       \
-    (dst) = march_load_pair(src, e0_, act_ && MG_M3_EXP != 2, T.n_cols);                                               \
+    if (MG_M3_RAW) (dst) = MG_M3_EXP == 2 ? d2_t{1.0, 1.0} : march_load_pair_raw(src, e0_, act_, T.n_cols);            \
+    else (dst) = march_load_pair(src, e0_, act_ && MG_M3_EXP != 2, T.n_cols);                                          \
+  } while (0)
+  // (raw loads: the one pair whose second entry does not exist was read one entry earlier - moved into place where consumed)
+#define M3_FIXPAIR(v, p, m)                                                                                            \
+  do {                                                                                                                 \
+    if (MG_M3_RAW && (p) == T.nplanes - 1) {                                                         /* (uniform) */   \
+      const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u;                                                             \
+      const long long e0_ = ((long long)(p) * T.P + pg[m]) & ~1LL;                                                     \
+      march_pair_fix((v), e0_, act_, T.n_cols);                                                                        \
+    }                                                                                                                  \
   } while (0)
   // entry k of a slab line = in-plane index (line start) + k: a leading entry of an odd line start is dropped
 #define M3_STAGE(slot, p, m, v)                                                                                        \
@@ -2303,6 +2335,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       for (int m = 0; m < NPM; ++m) M3_LOADPAIR(q[m], z0 - 1 + pp, m);
 #pragma unroll
       for (int m = 0; m < NPM; ++m) {
+        M3_FIXPAIR(q[m], z0 - 1 + pp, m);
         M3_X1(q[m], z0 - 1 + pp, m);
         M3_STAGE(pp, z0 - 1 + pp, m, q[m]);
       }
@@ -2407,6 +2440,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       if (z + 2 <= z1 + 1) {
 #pragma unroll
         for (int m = 0; m < NPM; ++m) {
+          M3_FIXPAIR(cur[m], z + 2, m);
           M3_X1(cur[m], z + 2, m);
           M3_STAGE(q2, z + 2, m, cur[m]);
         }
@@ -2533,6 +2567,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
 #undef M3_PAIRCLS
 #undef M3_DROW
 #undef M3_LOADPAIR
+#undef M3_FIXPAIR
 #undef M3_STAGE
 #undef M3_OPERANDS
 }
@@ -2549,70 +2584,97 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
 // x and b go in ONCE, t' and r' come out once: 32 B/row where the two passes moved 24 + 32 and ran the tile twice.  The
 // two stages across the stopping test are speculative: if the test ends the loop, the caller re-creates the iterate t with
 // one single-stage sweep of x (still in its buffer) and drops t', r'.
-// Same layout as the two-stage tile kernel above - z-star classes from a verified product map, the z+-1 entries from the
-// lane's own registers, in-plane entries from LDS slabs - with three more rings: the tile core TX x TY carries a halo of
-// 3 rows for stage 1 (x staged with 4), 2 for stage 2, 1 for stage 3; 3 slabs of x and 2 each of t, xn, t' (same pitch and
-// origin, so one set of record offsets serves all; later stages' slabs drop the lines they never touch), stage k runs k-1
-// planes behind stage 1:
-//     iteration z:  x plane z+2 -> ring | t(z) | r, xn (z-1) | t' (z-2) | r' (z-3) | barrier
-// Same products in the same order and the same epilogue expressions as march3: t', r' and ||r|| are bit-identical to the
-// two passes'.  Stores: t'(z-2) and r'(z-3) by every lane (sink for lanes / planes with nothing to store).
+// Layout: the two-stage tile kernel's (z-star classes from a verified product map, z+-1 entries from the lane's own
+// registers, one barrier per plane) with three more rings and the in-plane star in CANONICAL form:
+//   * the tile core TX x TY carries a halo of 3 rows for stage 1 (x staged with 4), 2 for stage 2, 1 for stage 3; 3 slabs
+//     of x and 2 each of t, xn, t', all with the same pitch, origin and line count; stage k runs k-1 planes behind stage 1:
+//         iteration z:  x plane z+2 -> ring | t(z) | r, xn (z-1) | t' (z-2) | r' (z-3) | barrier
+//   * the in-plane entries of every class are a subset of {-y, -x, 0, +x, +y} (checked on the host): a class record is
+//     {value of the z-1 entry, of the z+1 entry, 5 in-plane values in that - the stored, ascending-column - order, 0 where
+//     the class has none, relaxPrec} with NO offsets; a missing entry multiplies a finite number by 0: the LDS is cleared
+//     once and only finite values are ever written - rows (outside the grid, beyond a stage's rings) and planes a stage does
+//     not serve are computed like any other from staged x / finite slab entries and a valid b: bounded garbage that no
+//     served row reads with a non-zero weight (a served row of stage k reads rows within one ring of itself = rows stage
+//     k-1 serves; only ||r||^2 and the global stores select);
+//   * a lane owns K1 VERTICALLY ADJACENT rows of one column: a row's own entry and its neighbours inside the lane's strip
+//     come from registers, so a row-stage reads 2 (left, right) + 2/K1 (above the strip, below it) values from LDS
+//     instead of 5, with immediate offsets;
+//   * a lane holds ONE class record for its strip, re-read per stage only where the plane's z-class changes: the K1
+//     accumulation chains of a stage carry no branch and interleave.  The strips of a tile row are shifted (ysh) so that
+//     none holds rows of different classes - the first line of the grid ends a strip, the last one starts one (host check;
+//     an operator whose lines differ in class beyond that keeps the two passes).
+// Same products in the same order and the same epilogue expressions as march3 (a product with a 0 value adds +-0): t', r'
+// are bit-identical to the two passes' (a zero may change its sign).  Stores: t'(z-2) and r'(z-3) by every lane (sink for
+// lanes / planes with nothing to store).
 // ------------------------------------------------------------------------------------------------
+struct M4Class {                // 64 bytes per class; built on the host (build_march4), copied to LDS by every workgroup
+  double v_lo, v_hi;            // value of the entry in plane z-1 / z+1 (0: the class has none)
+  double v[5];                  // in-plane values: (dy,dx) = (-1,0), (0,-1), (0,0), (0,+1), (+1,0); 0 where the class has none
+  double d;                     // relaxPrec of the class
+};
+static_assert(sizeof(M4Class) == 64, "M4Class is read with 16-byte LDS loads");
 struct March4Dev {
-  const M3Class* cls;           // [ncls] records with byte offsets in THIS kernel's pitch
+  const M4Class* cls;           // [ncls]
   const unsigned short* cmap;   // cx[n1] | cy[n2] | cz[nplanes] | tab  (shared with march3)
-  int ncx, ncy, ntab;
+  int ncx, ncy, ncz, ntab;
   int n1, n2, nplanes, P;
   int TX, TY;                   // core tile
   int tiles_x, tiles_y;
-  int WX, SY;                   // width of the stage-1 region (TX + 6); lines of it per slot pass (NT / WX)
+  int WX, SY;                   // width of the stage-1 region (TX + 6); lanes per column = strips of K1 lines (K1*SY >= TY + 6 + K1 - 1)
   int pitch;                    // doubles per slab line (2*NPL)
-  int LY, NPL;                  // lines of an x slab (TY + 8); 16-byte pairs per line
+  int LY, NPL;                  // staged lines of an x slab (TY + 8 + K1 - 1); 16-byte pairs per line
+  int LYA;                      // allocated lines of every slab (K1*SY + 2 >= LY)
   int nblocks;
   int segs, seglen;             // workgroup w = segment (w / tiles) of tile (w % tiles)
   int n_cols, ncls;
+  const int* ysh;               // [tiles_y] lines the strips of a tile row are shifted down by (0..K1-1) so that no strip holds
+                                // rows of different classes (the first / last line of the grid ends / starts a strip)
 };
 constexpr int RM4_G = 4;        // halo of the staged x (stage 1 runs on core + 3 rings)
+#ifndef MG_M4_EXP
+#define MG_M4_EXP 0   // attribution builds (make variant; scripts/march4_ab.py): 1 no accumulation chains, 2 no slab/operand loads, 3 no stores, 4 stages 3 and 4 skipped
+#endif
 
-template <int NT, int K1, int NPM>
+template <int NT, int K1, int NPM, int PITCH>
 __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, March2Args a, March4Dev T) {
   extern __shared__ double win[];
   __shared__ double red[NT / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int w = xcd_band(blockIdx.x, T.nblocks);
-  const int pitch = T.pitch;
-  const int XS = T.LY * pitch;                                    // doubles per x slab
-  const int TS = (T.LY - 2) * pitch, NS = (T.LY - 4) * pitch, PS = (T.LY - 6) * pitch;   // t, xn, t' slabs
-  // byte offsets (from win) of each ring's VIRTUAL line 0: slab line ly of every ring = in-plane line y0 - 4 + ly
-  const int tB = (3 * XS - pitch) * 8;
-  const int nB = (3 * XS + 2 * TS - 2 * pitch) * 8;
-  const int pB = (3 * XS + 2 * TS + 2 * NS - 3 * pitch) * 8;
+  constexpr int pitch = PITCH;   // (compile-time: the line offsets of every LDS access fold into the instruction's immediate offset)
+  constexpr int P8 = pitch * 8;
+  const int XS = T.LYA * pitch;                                   // doubles per slab (every ring)
+  const int XS8 = XS * 8;
+  // rings (byte offsets from win): x 3 slabs, t 2, xn 2, t' 2; slab line ly of every ring = in-plane line y0 - 4 + ly
+  const int tB = 3 * XS8, nB = 5 * XS8, pB = 7 * XS8;
   double* xw = win;
   char* winb = reinterpret_cast<char*>(win);
-  M3Class* dcl = reinterpret_cast<M3Class*>(win + (3 * XS + 2 * TS + 2 * NS + 2 * PS));   // [ncls]
-  double* dd = reinterpret_cast<double*>(dcl + T.ncls);                                    // [ncls] class relaxPrec
-  unsigned short* cxL = reinterpret_cast<unsigned short*>(dd + T.ncls);                    // cx | cy | cz | tab
+  M4Class* dcl = reinterpret_cast<M4Class*>(win + 9 * XS);                                 // [ncls]
+  unsigned short* cxL = reinterpret_cast<unsigned short*>(dcl + T.ncls);                   // cx | cy | cz | tab
   unsigned short* cyL = cxL + T.n1;
   unsigned short* czL = cyL + T.n2;
   unsigned short* tabL = czL + T.nplanes;
   {
-    const int nw = T.ncls * (int)(sizeof(M3Class) / 8);
+    const int nw = T.ncls * (int)(sizeof(M4Class) / 8);
     const double* srcd = reinterpret_cast<const double*>(T.cls);
     double* dstd = reinterpret_cast<double*>(dcl);
     for (int i = tid; i < nw; i += NT) dstd[i] = srcd[i];
-    for (int i = tid; i < T.ncls; i += NT) dd[i] = C.cls_d[i];
     const int nm = T.n1 + T.n2 + T.nplanes + T.ntab;
     for (int i = tid; i < nm; i += NT) cxL[i] = T.cmap[i];
+    for (int i = tid; i < 9 * XS; i += NT) win[i] = 0.0;          // every slab entry finite from the start
   }
   const int zstride = T.ncy * T.ncx;
-  // ---- the lane's place: column xx of the stage-1 region, lines j + s*SY ---------------------------------------------
-  const int xx = tid % T.WX, j = tid / T.WX;
-  const bool lane_ok = j < T.SY;
-  const int own8 = ((j + 1) * pitch + xx + 1) * 8;      // byte offset of slot 0's own entry inside a slab (every ring)
-  const int sstride8 = T.SY * pitch * 8;                // from slot s to slot s + 1
+  // ---- the lane's place: column xx of the stage-1 region, lines K1*j .. K1*j + K1-1 ------------------------------------
+  // Lanes beyond the WX*SY the region needs are TWINS of the lanes of the last strip line: same reads, same values, nothing
+  // written to the slabs (a twin's write could overtake the original's read of the entry it replaces), nothing stored to
+  // global memory, nothing added to ||r||^2 - so that no branch guards the arithmetic.
+  const int xx = tid % T.WX, jt = tid / T.WX;
+  const bool twin = jt >= T.SY;
+  const int j = twin ? T.SY - 1 : jt;
+  const int own8 = ((K1 * j + 1) * pitch + xx + 1) * 8;   // byte offset of row 0's own entry inside a slab (every ring); row s: + s*P8
   // ---- the lane's 16-byte pairs of an x slab ---------------------------------------------------------------------------
   int pofs[NPM], pline[NPM];
-  unsigned pflag = 0u;  // per m: bit 4m = the pair exists, bit 4m+1 = first pair of its line, bit 4m+2 = its line is inside the grid
+  unsigned pflag = 0u;  // per m: bit 4m = the pair exists, bit 4m+1 = first pair of its line, bit 4m+2 = its line is inside the grid, bit 4m+3 = pg[m] is odd
 #pragma unroll
   for (int m = 0; m < NPM; ++m) {
     const int pid = tid + m * NT;
@@ -2627,38 +2689,24 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
   const int zs = seg * T.seglen, ze = zs + T.seglen < T.nplanes ? zs + T.seglen : T.nplanes;
   double* sk = a.sink + ((size_t)(w & 31) * NT + tid);
   double sq = 0.0;
-  double rlo = 0.0, rhi = 0.0, rv[RM3_NIP];
-  int ro[RM3_NIP], rcls = -1;
-#pragma unroll
-  for (int u = 0; u < RM3_NIP; ++u) {
-    rv[u] = 0.0;
-    ro[u] = 0;
-  }
+  // class record of the lane (registers) - of the first of the four stages that needed another one
+  double rlo = 0.0, rhi = 0.0, rd = 0.0, rv0 = 0.0, rv1 = 0.0, rv2 = 0.0, rv3 = 0.0, rv4 = 0.0;
+  int rcls = -1;
 #define M4_LOADRECS(cq)                                                                                                \
   do {                                                                                                                 \
-    const M3Class* q_ = dcl + (cq);                                                                                    \
-    rlo = q_->v_lo;                                                                                                    \
-    rhi = q_->v_hi;                                                                                                    \
-    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) {                                                           \
-      rv[u_] = q_->v[u_];                                                                                              \
-      ro[u_] = q_->off[u_];                                                                                            \
-    }                                                                                                                  \
+    const M4Class* q_ = dcl + (cq);                                                                                    \
+    rlo = q_->v_lo; rhi = q_->v_hi;                                                                                    \
+    rv0 = q_->v[0]; rv1 = q_->v[1]; rv2 = q_->v[2]; rv3 = q_->v[3]; rv4 = q_->v[4];                                    \
+    rd = q_->d;                                                                                                        \
     rcls = (cq);                                                                                                       \
   } while (0)
-  // acc = (z-1 entry) + in-plane entries in stored order + (z+1 entry); base8: byte offset (from win) of the row's own entry
-#define M4_WALK(acc, lo_, hi_, base8)                                                                                  \
-  do {                                                                                                                 \
-    double xv_[RM3_NIP];                                                                                               \
-    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_)                                                             \
-      xv_[u_] = *reinterpret_cast<const double*>(winb + ((base8) + ro[u_]));                                           \
-    (acc) = (acc) + rlo * (lo_);                                                                                       \
-    _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_) (acc) = (acc) + rv[u_] * xv_[u_];                           \
-    (acc) = (acc) + rhi * (hi_);                                                                                       \
-  } while (0)
-  __syncthreads();   // dictionaries in place
+#define M4_LDS(off8) (*reinterpret_cast<const double*>(winb + (off8)))
+#define M4_LDSW(off8) (*reinterpret_cast<double*>(winb + (off8)))
+  __syncthreads();   // dictionaries in place, slabs cleared
   if (ze > zs) {
     const int ty = c / T.tiles_x, tx = c - ty * T.tiles_x;
-    const int x0 = tx * T.TX, y0 = ty * T.TY;
+    const int ysh = T.ysh[ty];
+    const int x0 = tx * T.TX, y0 = ty * T.TY - ysh;     // slab line ly = in-plane line y0 - 4 + ly; the core starts at line y0 + ysh
     int pg[NPM];
 #pragma unroll
     for (int m = 0; m < NPM; ++m) {
@@ -2666,33 +2714,61 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
       const int i2 = pofs[m] - pline[m] * pitch;        // 2*i
       if (yl >= 0 && yl < T.n2) pflag |= 4u << (4 * m);
       pg[m] = yl * T.n1 + x0 - RM4_G + i2;
+      if (pg[m] & 1) pflag |= 8u << (4 * m);
     }
     const int gx = x0 - 3 + xx;
-    const bool xin = lane_ok && gx >= 0 && gx < T.n1;
+    const bool xin = gx >= 0 && gx < T.n1;
     const int dxo = xx < 3 ? 3 - xx : (xx > T.TX + 2 ? xx - (T.TX + 2) : 0);    // rings between the column and the core
-    const int ip0 = (y0 - 3 + j) * T.n1 + gx;           // in-plane index of slot 0's row; slot s: + s*SY*n1
-    const int ipstride = T.SY * T.n1;
-    unsigned live1 = 0u, live2 = 0u, live3 = 0u, core = 0u;     // per slot: stage k is computed on the row
-    int rp[K1];
+    const int ip0 = (y0 - 3 + K1 * j) * T.n1 + gx;      // in-plane index of row 0; row s: + s*n1
+    unsigned lv = 0u;                                   // per row s: bit s = stage 1 is computed on it, bit 8+s stage 2, 16+s stage 3, 24+s stage 4 (core)
+    unsigned pk[K1];                                    // class of the row per z-class: byte zc = tab[zc][cy][cx]
     const int cxo = xin ? (int)cxL[gx] : 0;
+    unsigned pk0 = 0u;                                  // class word of the lane's first live row
+    bool have0 = false;
 #pragma unroll
     for (int s = 0; s < K1; ++s) {
-      const int yy = j + s * T.SY, gy = y0 - 3 + yy;
-      const bool l1 = xin && yy < T.TY + 6 && gy >= 0 && gy < T.n2;
-      const int dyo = yy < 3 ? 3 - yy : (yy > T.TY + 2 ? yy - (T.TY + 2) : 0);
+      const int yy = K1 * j + s, gy = y0 - 3 + yy;
+      const int yc = yy - ysh;                          // line of the stage-1 region (0 .. TY + 5)
+      const bool l1 = xin && yc >= 0 && yc < T.TY + 6 && gy >= 0 && gy < T.n2;
+      const int dyo = yc < 3 ? 3 - yc : (yc > T.TY + 2 ? yc - (T.TY + 2) : 0);
       const int dist = dxo > dyo ? dxo : dyo;
-      live1 |= (l1 ? 1u : 0u) << s;
-      live2 |= ((l1 && dist <= 2) ? 1u : 0u) << s;
-      live3 |= ((l1 && dist <= 1) ? 1u : 0u) << s;
-      core |= ((l1 && dist == 0) ? 1u : 0u) << s;
-      rp[s] = l1 ? (int)cyL[gy] * T.ncx + cxo : 0;
+      lv |= (l1 ? 1u : 0u) << s;
+      lv |= ((l1 && dist <= 2) ? 1u : 0u) << (8 + s);
+      lv |= ((l1 && dist <= 1) ? 1u : 0u) << (16 + s);
+      lv |= ((l1 && dist == 0 && !twin) ? 1u : 0u) << (24 + s);
+      unsigned v = 0u;
+      if (l1) {
+        const int rp = (int)cyL[gy] * T.ncx + cxo;
+        for (int zc = 0; zc < T.ncz; ++zc) v |= ((unsigned)tabL[zc * zstride + rp] & 255u) << (8 * zc);
+        if (!have0) { pk0 = v; have0 = true; }
+      }
+      pk[s] = v;
     }
-#define M4_PAR(p, m) ((int)(((long long)(p) * T.P + pg[m]) & 1LL))
+    // Pair m of plane p: global entries e0, e0 + 1 with e0 = (p*P + pg[m]) rounded down to even.  The load is ONE 16-byte
+    // access in every lane through a scalar base (x + pc*P - 4, pc = p clamped into the grid) and a 32-bit lane offset, no
+    // branch, no fix-up behind it: pairs of lines / planes outside the grid and offsets that would leave [0, n_cols - 2] are
+    // clamped to some valid pair of x (finite entries nobody reads with a non-zero weight).
+#define M4_PAR(p, m) ((int)((((unsigned)(p) & (unsigned)T.P) ^ (pflag >> (4 * (m) + 3))) & 1u))
 #define M4_LOADPAIR(dst, p, m)                                                                                         \
   do {                                                                                                                 \
-    const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u && (p) >= 0 && (p) < T.nplanes;                                \
-    const long long e0_ = ((long long)(p) * T.P + pg[m]) & ~1LL;                                                       \
-    (dst) = march_load_pair(a.x, e0_, act_, T.n_cols);                                                                 \
+    const int pc_ = (p) < 0 ? 0 : ((p) >= T.nplanes ? T.nplanes - 1 : (p));                          /* (uniform) */   \
+    const double* base_ = a.x + ((long long)pc_ * T.P - 4);                                          /* (uniform) */   \
+    const int lim_ = (int)((long long)T.n_cols - 2 - (long long)pc_ * T.P) + 4;                      /* (uniform) */   \
+    int off_ = pg[m] - M4_PAR(pc_, m) + 4;                                                                             \
+    off_ = (((pflag >> (4 * (m))) & 5u) == 5u) ? off_ : 4;                                                             \
+    const int lo_ = pc_ == 0 ? 4 : 0;                                     /* (uniform: nothing in front of x) */       \
+    off_ = off_ < lo_ ? lo_ : (off_ > lim_ ? lim_ : off_);                                                             \
+    if (MG_M4_EXP == 2) (dst) = d2_t{1.0, 1.0};                                                                        \
+    else (dst) = *reinterpret_cast<const d2_t*>(base_ + (unsigned)off_);                                               \
+  } while (0)
+    // (n_cols odd: the last entry of x is the first of a pair whose second does not exist - the clamp above read the pair
+    // one entry earlier; move it into place.  Only in the last plane.)
+#define M4_FIXPAIR(v, p, m)                                                                                            \
+  do {                                                                                                                 \
+    if ((p) == T.nplanes - 1 && (T.n_cols & 1)) {                                                    /* (uniform) */   \
+      const int lim_ = T.n_cols - 2 - (p) * T.P + 4;                                                                   \
+      if ((((pflag >> (4 * (m))) & 5u) == 5u) && pg[m] - M4_PAR(p, m) + 4 == lim_ + 1) (v).x = (v).y;                  \
+    }                                                                                                                  \
   } while (0)
 #define M4_STAGE(slot, p, m, v)                                                                                        \
   do {                                                                                                                 \
@@ -2712,7 +2788,10 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
 #pragma unroll
       for (int m = 0; m < NPM; ++m) M4_LOADPAIR(q[m], zA + pp, m);
 #pragma unroll
-      for (int m = 0; m < NPM; ++m) M4_STAGE(pp, zA + pp, m, q[m]);
+      for (int m = 0; m < NPM; ++m) {
+        M4_FIXPAIR(q[m], zA + pp, m);
+        M4_STAGE(pp, zA + pp, m, q[m]);
+      }
     }
     d2_t preb[NPM];
 #pragma unroll
@@ -2720,10 +2799,11 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     double nbb[K1];
 #define M4_OPERANDS(zz)                                                                                                \
   do {                                                                                                                 \
-    const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
+    const int pc_ = (zz) < 0 ? 0 : ((zz) >= T.nplanes ? T.nplanes - 1 : (zz));                       /* (uniform) */   \
+    const double* base_ = a.b + (long long)pc_ * T.P;                                                /* (uniform) */   \
     _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
-      const int r_ = (pv_ && ((live1 >> s_) & 1u)) ? (zz) * T.P + ip0 + s_ * ipstride : C.n_rows - 1;                  \
-      nbb[s_] = a.b[r_];                                                                                               \
+      const int r_ = ((lv >> s_) & 1u) ? ip0 + s_ * T.n1 : 0;                                                          \
+      nbb[s_] = MG_M4_EXP == 2 ? 1.0 : base_[(unsigned)r_];                                                            \
     }                                                                                                                  \
   } while (0)
     M4_OPERANDS(zA);
@@ -2731,18 +2811,53 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
 #pragma unroll
     for (int s = 0; s < K1; ++s) {
       xm[s] = 0.0;
-      if (zA - 1 >= 0 && ((live1 >> s) & 1u)) xm[s] = a.x[(zA - 1) * T.P + ip0 + s * ipstride];
+      if (zA - 1 >= 0 && ((lv >> s) & 1u)) xm[s] = a.x[(zA - 1) * T.P + ip0 + s * T.n1];
     }
 #pragma unroll
-    for (int i = 0; i < 2 * K1; ++i) sk[(size_t)i * 32 * NT] = 0.0;   // as many stores as an iteration issues, behind the loads (see march3)
+    for (int i = 0; i < (MG_M4_EXP == 3 ? 0 : 2 * K1); ++i) sk[(size_t)i * 32 * NT] = 0.0;   // as many stores as an iteration issues, behind the loads (see march3)
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < K1; ++s)   // own x of plane zA from its slab (slot 0)
-      xc[s] = ((live1 >> s) & 1u) ? *reinterpret_cast<const double*>(winb + (own8 + s * sstride8)) : 0.0;
-    double t1[K1], t2[K1], n1[K1], n2[K1], p1[K1], p2[K1], b1[K1], b2[K1], b3[K1];
+    for (int s = 0; s < K1; ++s)   // own x of plane zA from its slab (slot 0) - every row of the strip: a row beyond the region is its neighbour's neighbour
+      xc[s] = M4_LDS(own8 + s * P8);
+    double t1[K1], n1[K1], p1[K1], b1[K1], b2[K1], b3[K1];
 #pragma unroll
-    for (int s = 0; s < K1; ++s) t1[s] = t2[s] = n1[s] = n2[s] = p1[s] = p2[s] = b1[s] = b2[s] = b3[s] = 0.0;
+    for (int s = 0; s < K1; ++s) t1[s] = n1[s] = p1[s] = b1[s] = b2[s] = b3[s] = 0.0;
     int qz = 0;                    // ring slot of x plane z
+    int zc1 = 0, zc2 = 0, zc3 = 0; // z-classes of planes z-1, z-2, z-3
+    // acc = (z-1 entry) + in-plane entries in canonical (= stored) order + (z+1 entry)
+#define M4_ACC(acc, lo_, up_, le_, ow_, ri_, dn_, hi_)                                                                 \
+  do {                                                                                                                 \
+    (acc) = 0.0;                                                                                                       \
+    if (MG_M4_EXP != 1) {                                                                                              \
+      (acc) = (acc) + rlo * (lo_);                                                                                     \
+      (acc) = (acc) + rv0 * (up_);                                                                                     \
+      (acc) = (acc) + rv1 * (le_);                                                                                     \
+      (acc) = (acc) + rv2 * (ow_);                                                                                     \
+      (acc) = (acc) + rv3 * (ri_);                                                                                     \
+      (acc) = (acc) + rv4 * (dn_);                                                                                     \
+      (acc) = (acc) + rhi * (hi_);                                                                                     \
+    }                                                                                                                  \
+  } while (0)
+    // the record of this pass's class in the z-class of the stage's plane (re-read only when it differs from the one held:
+    // at the first / last planes, and in wavefronts that run more than one pass)
+#define M4_REC(zc_)                                                                                                    \
+  do {                                                                                                                 \
+    const int cq_ = (int)((pwp >> (8 * (zc_))) & 255u);                                                                \
+    if (cq_ != rcls) M4_LOADRECS(cq_);                                                                                 \
+  } while (0)
+    // one row-stage: left / right from the slab, above / below from the strip's registers or (first / last row) the slab
+#define M4_ROWSTAGE(rB, val, lo_, hi_, acc)                                                                            \
+  do {                                                                                                                 \
+    const int o8_ = (rB) + own8 + s * P8;                                                                              \
+    const double le_ = M4_LDS(o8_ - 8), ri_ = M4_LDS(o8_ + 8);                                                         \
+    const double up_ = s == 0 ? M4_LDS(o8_ - P8) : (val)[s > 0 ? s - 1 : 0];                                           \
+    const double dn_ = s == K1 - 1 ? M4_LDS(o8_ + P8) : (val)[s < K1 - 1 ? s + 1 : s];                                 \
+    M4_ACC(acc, (lo_)[s], up_, le_, (val)[s], ri_, dn_, (hi_)[s]);                                                     \
+  } while (0)
+#ifndef MG_M4_SCHED
+#define MG_M4_SCHED 1   // 1: the stages of an iteration are not interleaved by the scheduler (live ranges: 128 / 168 registers)
+#endif
+#define M4_SCHED do { if (MG_M4_SCHED) __builtin_amdgcn_sched_barrier(0); } while (0)
     for (int z = zA; z <= zE; ++z) {
       d2_t cur[NPM];
       double b0[K1];
@@ -2759,7 +2874,10 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
       const int q1 = qz == 2 ? 0 : qz + 1, q2 = q1 == 2 ? 0 : q1 + 1;   // slots of planes z+1, z+2
       if (z + 2 <= zE + 1) {
 #pragma unroll
-        for (int m = 0; m < NPM; ++m) M4_STAGE(q2, z + 2, m, cur[m]);
+        for (int m = 0; m < NPM; ++m) {
+          M4_FIXPAIR(cur[m], z + 2, m);
+          M4_STAGE(q2, z + 2, m, cur[m]);
+        }
       }
       if (z + 3 <= zE + 1) {
 #pragma unroll
@@ -2768,107 +2886,110 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
       if (z + 1 <= zE) M4_OPERANDS(z + 1);
       const bool s1 = z < T.nplanes;                                            // (uniform; z >= zA >= 0)
       const bool s2 = z - 1 >= 0 && z - 1 < T.nplanes && z >= zs - 1;           // plane z-1 in [zs-2, ze+1]
-      const bool s3 = z - 2 >= 0 && z - 2 < T.nplanes && z >= zs + 1;           // plane z-2 in [zs-1, ze]
-      const bool s4 = z >= zs + 3;                                              // plane z-3 in [zs, ze)
-      const int zb0 = s1 ? (int)czL[z] * zstride : 0;
-      const int zb1 = s2 ? (int)czL[z - 1] * zstride : 0;
-      const int zb2 = s3 ? (int)czL[z - 2] * zstride : 0;
-      const int zb3 = s4 ? (int)czL[z - 3] * zstride : 0;
-      const int xq8 = qz * XS * 8, xq18 = q1 * XS * 8;
-      const int tW8 = tB + (z & 1) * TS * 8, tR8 = tB + ((z - 1) & 1) * TS * 8;
-      const int nW8 = nB + ((z - 1) & 1) * NS * 8, nR8 = nB + (z & 1) * NS * 8;         // xn(z-1) written, xn(z-2) read
-      const int pW8 = pB + (z & 1) * PS * 8, pR8 = pB + ((z - 1) & 1) * PS * 8;         // t'(z-2) written, t'(z-3) read
+      const bool s3 = MG_M4_EXP != 4 && z - 2 >= 0 && z - 2 < T.nplanes && z >= zs + 1;   // plane z-2 in [zs-1, ze]
+      const bool s4 = MG_M4_EXP != 4 && z >= zs + 3;                                      // plane z-3 in [zs, ze)
+      const int zc0 = s1 ? __builtin_amdgcn_readfirstlane((int)czL[z]) : zc1;   // (uniform)
+      const bool cnt2 = z - 1 >= zs && z - 1 < ze;      // (uniform) plane z-1 belongs to this segment: its ||r||^2 counts
+      const int xq8 = qz * XS8, xq18 = q1 * XS8;
+      const int tW8 = tB + (z & 1) * XS8, tR8 = tB + ((z - 1) & 1) * XS8;
+      const int nW8 = nB + ((z - 1) & 1) * XS8, nR8 = nB + (z & 1) * XS8;       // xn(z-1) written, xn(z-2) read
+      const int pW8 = pB + (z & 1) * XS8, pR8 = pB + ((z - 1) & 1) * XS8;       // t'(z-2) written, t'(z-3) read
       double tc[K1], nc[K1], pc[K1], r4[K1];
-      // ---- stage 1 on plane z: t = x + d.*(b - A x) ------------------------------------------------------------------------
+      {
+        double xp[K1], t2[K1], n2[K1], p2[K1];
 #pragma unroll
-      for (int s = 0; s < K1; ++s) {
-        tc[s] = 0.0;
-        if ((live1 >> s) & 1u) {
-          const int o8 = own8 + s * sstride8;
-          const double xp = *reinterpret_cast<const double*>(winb + (xq18 + o8));
-          if (s1) {
-            const int cq = (int)tabL[zb0 + rp[s]];
-            if (cq != rcls) M4_LOADRECS(cq);
-            double acc = 0.0;
-            M4_WALK(acc, xm[s], xp, xq8 + o8);
-            const double tv = xc[s] + dd[cq] * (b0[s] - acc);
-            *reinterpret_cast<double*>(winb + (tW8 + o8)) = tv;
-            tc[s] = tv;
+        for (int s = 0; s < K1; ++s) xp[s] = M4_LDS(xq18 + own8 + s * P8);      // own x of plane z+1
+        // the z-1 entries of stages 2-4: the row's own entry of the slab this iteration overwrites (t(z-2), xn(z-3), t'(z-4))
+#pragma unroll
+        for (int s = 0; s < K1; ++s) {
+          t2[s] = M4_LDS(tW8 + own8 + s * P8);
+          n2[s] = M4_LDS(nW8 + own8 + s * P8);
+          p2[s] = M4_LDS(pW8 + own8 + s * P8);
+        }
+        {
+          const unsigned pwp = pk0;                             // (the strip's rows share their class: host check)
+          // ---- stage 1 on plane z: t = x + d.*(b - A x) --------------------------------------------------------------------
+          M4_REC(zc0);
+#pragma unroll
+          for (int s = 0; s < K1; ++s) {
+            double acc;
+            M4_ROWSTAGE(xq8, xc, xm, xp, acc);
+            const double tv = xc[s] + rd * (b0[s] - acc);
+            tc[s] = tv;   // (rows / planes the stage does not serve hold bounded garbage: read with weight 0 or never - header)
           }
+#pragma unroll
+          for (int s = 0; s < K1; ++s)
+            if (!twin) M4_LDSW(tW8 + own8 + s * P8) = tc[s];
+          M4_SCHED;
+          // ---- stage 2 on plane z-1: r = b - A t, xn = t + d.*r, ||r||^2 on the core ---------------------------------------
+          M4_REC(zc1);
+#pragma unroll
+          for (int s = 0; s < K1; ++s) {
+            double acc;
+            M4_ROWSTAGE(tR8, t1, t2, tc, acc);
+            const double rr = b1[s] - acc;
+            const double xv = t1[s] + rd * rr;
+            nc[s] = xv;
+            sq += (cnt2 && s2 && ((lv >> (24 + s)) & 1u)) ? rr * rr : 0.0;
+          }
+#pragma unroll
+          for (int s = 0; s < K1; ++s)
+            if (!twin) M4_LDSW(nW8 + own8 + s * P8) = nc[s];
+          M4_SCHED;
+          // ---- stage 3 on plane z-2: t' = xn + d.*(b - A xn) ------------------------------------------------------------------
+          M4_REC(zc2);
+#pragma unroll
+          for (int s = 0; s < K1; ++s) {
+            double acc;
+            M4_ROWSTAGE(nR8, n1, n2, nc, acc);
+            const double tv = n1[s] + rd * (b2[s] - acc);
+            pc[s] = tv;
+          }
+#pragma unroll
+          for (int s = 0; s < K1; ++s)
+            if (!twin) M4_LDSW(pW8 + own8 + s * P8) = pc[s];
+          M4_SCHED;
+          // ---- stage 4 on plane z-3: r' = b - A t' --------------------------------------------------------------------------
+          M4_REC(zc3);
+#pragma unroll
+          for (int s = 0; s < K1; ++s) {
+            double acc;
+            M4_ROWSTAGE(pR8, p1, p2, pc, acc);
+            r4[s] = b3[s] - acc;
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < K1; ++s) {
           xm[s] = xc[s];
-          xc[s] = xp;
-        }
-      }
-      // ---- stage 2 on plane z-1: r = b - A t, xn = t + d.*r, ||r||^2 on the core ------------------------------------------
-      const bool cnt2 = z - 1 >= zs && z - 1 < ze;      // (uniform) the plane belongs to this segment
-#pragma unroll
-      for (int s = 0; s < K1; ++s) {
-        nc[s] = 0.0;
-        if (s2 && ((live2 >> s) & 1u)) {
-          const int cq = (int)tabL[zb1 + rp[s]];
-          if (cq != rcls) M4_LOADRECS(cq);
-          const int o8 = own8 + s * sstride8;
-          double acc = 0.0;
-          M4_WALK(acc, t2[s], tc[s], tR8 + o8);
-          const double rr = b1[s] - acc;
-          const double xv = t1[s] + dd[cq] * rr;
-          *reinterpret_cast<double*>(winb + (nW8 + o8)) = xv;
-          nc[s] = xv;
-          if (cnt2 && ((core >> s) & 1u)) sq += rr * rr;
-        }
-      }
-      // ---- stage 3 on plane z-2: t' = xn + d.*(b - A xn) ---------------------------------------------------------------------
-#pragma unroll
-      for (int s = 0; s < K1; ++s) {
-        pc[s] = 0.0;
-        if (s3 && ((live3 >> s) & 1u)) {
-          const int cq = (int)tabL[zb2 + rp[s]];
-          if (cq != rcls) M4_LOADRECS(cq);
-          const int o8 = own8 + s * sstride8;
-          double acc = 0.0;
-          M4_WALK(acc, n2[s], nc[s], nR8 + o8);
-          const double tv = n1[s] + dd[cq] * (b2[s] - acc);
-          *reinterpret_cast<double*>(winb + (pW8 + o8)) = tv;
-          pc[s] = tv;
-        }
-      }
-      // ---- stage 4 on plane z-3: r' = b - A t' -----------------------------------------------------------------------------
-#pragma unroll
-      for (int s = 0; s < K1; ++s) {
-        r4[s] = 0.0;
-        if (s4 && ((core >> s) & 1u)) {
-          const int cq = (int)tabL[zb3 + rp[s]];
-          if (cq != rcls) M4_LOADRECS(cq);
-          const int o8 = own8 + s * sstride8;
-          double acc = 0.0;
-          M4_WALK(acc, p2[s], pc[s], pR8 + o8);
-          r4[s] = b3[s] - acc;
+          xc[s] = xp[s];
         }
       }
       // ---- the stores of this iteration (every lane issues every store instruction) ---------------------------------------
-      {
+      if (MG_M4_EXP != 3) {
         const bool w3 = s3 && z - 2 >= zs && z - 2 < ze;   // (uniform) t' of plane z-2 belongs to this segment
+        double* bt_ = a.t + (long long)(z - 2) * T.P;      // (uniform bases; dereferenced for planes of the segment only)
+        double* br_ = a.r + (long long)(z - 3) * T.P;
 #pragma unroll
         for (int s = 0; s < K1; ++s) {
-          const int rowp = (z - 2) * T.P + ip0 + s * ipstride, rowr = rowp - T.P;
-          double* qt_ = (w3 && ((core >> s) & 1u)) ? a.t + rowp : sk;
+          const unsigned row_ = (unsigned)(ip0 + s * T.n1);     // (a core row's in-plane index; anything for the others: sink)
+          double* qt_ = (w3 && ((lv >> (24 + s)) & 1u)) ? bt_ + row_ : sk;
           *qt_ = pc[s];
-          double* qr_ = (s4 && ((core >> s) & 1u)) ? a.r + rowr : sk;
+          double* qr_ = (s4 && ((lv >> (24 + s)) & 1u)) ? br_ + row_ : sk;
           *qr_ = r4[s];
         }
       }
 #pragma unroll
       for (int s = 0; s < K1; ++s) {
-        t2[s] = t1[s];
         t1[s] = tc[s];
-        n2[s] = n1[s];
         n1[s] = nc[s];
-        p2[s] = p1[s];
         p1[s] = pc[s];
         b3[s] = b2[s];
         b2[s] = b1[s];
         b1[s] = b0[s];
       }
+      zc3 = zc2;
+      zc2 = zc1;
+      zc1 = zc0;
       qz = q1;
       __syncthreads();
     }
@@ -2884,11 +3005,17 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     }
   }
 #undef M4_LOADRECS
-#undef M4_WALK
+#undef M4_LDS
+#undef M4_LDSW
 #undef M4_PAR
 #undef M4_LOADPAIR
+#undef M4_FIXPAIR
 #undef M4_STAGE
 #undef M4_OPERANDS
+#undef M4_ACC
+#undef M4_REC
+#undef M4_ROWSTAGE
+#undef M4_SCHED
 }
 
 // Band form: the values of a CSR operator re-laid as planar slots (build_band).  slot[c*NS + e] = the planar array entry e

@@ -75,6 +75,8 @@ struct Options {
   bool no_march4 = false;          // solve loop: never run the two fine-level passes across the stopping test as one four-stage pass
   long long march4_nt = 0;         // threads per workgroup of the four-stage pass (0: default; 1024 / 768 / 512 = 2 / 3 / 4 rows per lane)
   long long march4_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
+  long long march4_ty_max = 0;     // tests: tallest tile (several tile rows on small grids)
+  long long march4_k1 = 0;         // rows per lane (0: 2 / 3 / 4 at 1024 / 768 / 512 threads; 768 threads also take 4)
   bool debug_format = false, debug_timing = false;
   int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
   long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
@@ -105,7 +107,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_LANE_RPL3", "no_lane_rpl3", 0, no_lane_rpl3), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
-      MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x),
+      MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x), MG_OPT("MG_MARCH4_K1", "march4_k1", 1, march4_k1), MG_OPT("MG_MARCH4_TY_MAX", "march4_ty_max", 1, march4_ty_max),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
@@ -229,7 +231,8 @@ struct Csr {
   double rm3_fill = 0.0;    // estimated L1 fills + stores per row (bytes) of the chosen geometry
   // four-stage pass of the solve loop (csr_rowclass_march4_spmv): same classes and product map, its own tile geometry
   bool rc_march4 = false;
-  DevBuf<mgk::M3Class> rm4_cls;
+  DevBuf<mgk::M4Class> rm4_cls;
+  DevBuf<int> rm4_ysh;
   mgk::March4Dev rm4{};
   size_t rm4_lds = 0;
   int rm4_k1 = 3, rm4_nt = 768;
@@ -408,6 +411,7 @@ struct Csr {
     rm3_cmap.release();
     rc_march4 = false;
     rm4_cls.release();
+    rm4_ysh.release();
     rc_exc2.release();
     rc_nexc2 = 0;
     rp_ok = false;
@@ -1128,14 +1132,24 @@ int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double*
 // The solve loop's two fine-level passes across the stopping test as ONE four-stage pass (csr_rowclass_march4_spmv):
 //   t = x + d.*(b - A x) ; r = b - A t ; ||r||^2 ; xn = t + d.*r ; tp = xn + d.*(b - A xn) ; rp = b - A tp
 // x, tp, rp: three different buffers; the iterate t is not stored (the caller re-creates it from x if the loop stops).
-template <int NT, int K1, int NPM>
-int launch_march4(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
-  auto* fn = &mgk::csr_rowclass_march4_spmv<NT, K1, NPM>;
+template <int NT, int K1, int NPM, int PITCH>
+int launch_march4_p(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
+  auto* fn = &mgk::csr_rowclass_march4_spmv<NT, K1, NPM, PITCH>;
   static std::atomic<unsigned long long> attr_done{0};
   MG_TRY(big_lds_attr(reinterpret_cast<const void*>(fn), attr_done));
   hipLaunchKernelGGL(fn, dim3((unsigned)A.rm4.nblocks), dim3(NT), A.rm4_lds, stream, A.rcdev(), a, A.rm4);
   HIP_TRY(hipGetLastError());
   return MG_OK;
+}
+// (the slab pitch is a template argument: LDS line offsets as immediates; build_march4 pads a tile's lines to one of these)
+template <int NT, int K1, int NPM>
+int launch_march4(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
+  switch (A.rm4.pitch) {
+    case 48: return launch_march4_p<NT, K1, NPM, 48>(stream, A, a);
+    case 64: return launch_march4_p<NT, K1, NPM, 64>(stream, A, a);
+    case 80: return launch_march4_p<NT, K1, NPM, 80>(stream, A, a);
+    default: return fail(MG_ERR_STATE, "four-stage pass: no kernel for a slab pitch of %d", A.rm4.pitch);
+  }
 }
 bool march4_ok(const mg_hierarchy* h, int level, const double* x, const double* tp, const double* rp) {
   const Level& L = h->lev[(size_t)level];
@@ -1164,7 +1178,8 @@ int k_four_stage(mg_hierarchy* h, int level, const double* b, const double* x, d
     // algorithmic: four products with A (two fused sweeps, two residuals); moved: x, b in, t' and r' out
     ProfScope ps(h, level, MG_K_FOUR_STAGE, 2.0 * (spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false)), tables + 4.0 * n8);
     if (A.rm4_nt == 1024) MG_TRY((launch_march4<1024, 2, 2>(h->stream, A, a)));
-    else if (A.rm4_nt == 768) MG_TRY((launch_march4<768, 3, 2>(h->stream, A, a)));
+    else if (A.rm4_nt == 768 && A.rm4_k1 == 3) MG_TRY((launch_march4<768, 3, 2>(h->stream, A, a)));
+    else if (A.rm4_nt == 768) MG_TRY((launch_march4<768, 4, 3>(h->stream, A, a)));
     else MG_TRY((launch_march4<512, 4, 3>(h->stream, A, a)));
   }
   ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
@@ -2846,26 +2861,56 @@ int build_band(Csr& A, const long long grid[3]) {
   return MG_OK;
 }
 
-// Four-stage pass of the solve loop (csr_rowclass_march4_spmv) on an operator the two-stage tile form serves: same class
-// records (offsets re-expressed in its own pitch) and the same product map; tile geometry of its own - the stage-1 region
-// is WX = TX + 6 columns wide (three rings around the core), an NT-thread workgroup holds SY = NT / WX lines of it per slot
-// pass and K1 passes: TY = K1*SY - 6; 3 x slabs of TY + 8 lines, 2 each of t (TY + 6), xn (TY + 4), t' (TY + 2) within the
-// 160 KB of LDS; always the lockstep schedule (tiles x segments of planes = at most one workgroup per CU).
+// Four-stage pass of the solve loop (csr_rowclass_march4_spmv) on an operator the two-stage tile form serves: the same
+// classes and product map; the in-plane entries of every class must lie in {-y, -x, 0, +x, +y} (the records carry values
+// in that canonical order, no offsets), at most 4 z-classes and 255 classes (a lane packs its rows' class ids per
+// z-class into one register), relaxPrec constant per class.  Tile geometry of its own - the stage-1 region is WX = TX + 6
+// columns wide (three rings around the core), a lane owns K1 vertically adjacent rows, SY lanes per column:
+// TY <= K1*SY - 6; 3 slabs of x and 2 each of t, xn, t', all K1*SY + 2 lines, within the 160 KB of LDS; lockstep schedule
+// (tiles x segments of planes = at most one workgroup per CU).
 int build_march4(Csr& A, const std::vector<mgk::M3Class>& recs3, const std::vector<std::vector<M3Ent>>& ents, int ncx, int ncy, int ncz,
-                 size_t dict_bytes, int ncu) {
+                 size_t map_bytes, int ncu, const unsigned short* cy) {
   A.rc_march4 = false;
-  if (A.opt.no_march4) return MG_OK;
+  if (A.opt.no_march4 || !A.rc_has_d) return MG_OK;
   const long long n1 = A.rm3.n1, n2 = A.rm3.n2, n3 = A.rm3.nplanes, P = n1 * n2;
-  if (n3 < 8) return MG_OK;
+  const size_t ncls = recs3.size();
+  if (n3 < 8 || ncz > 4 || ncls > 255 || (size_t)A.rc_ncls != ncls) return MG_OK;
   if (A.n_rows + 8 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
+  // ---- records in canonical form ---------------------------------------------------------------------------------------------
+  std::vector<double> dcls(ncls);
+  HIP_TRY(hipMemcpy(dcls.data(), A.rc_d.p, ncls * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<mgk::M4Class> recs(ncls);
+  for (size_t c = 0; c < ncls; ++c) {
+    mgk::M4Class q{};
+    q.v_lo = recs3[c].v_lo;
+    q.v_hi = recs3[c].v_hi;
+    q.d = dcls[c];
+    int nip = 0, last = -1;
+    for (const M3Ent& t : ents[c]) {
+      if (t.dz != 0) continue;
+      int slot = -1;
+      if (t.dy == -1 && t.dx == 0) slot = 0;
+      else if (t.dy == 0 && t.dx == -1) slot = 1;
+      else if (t.dy == 0 && t.dx == 0) slot = 2;
+      else if (t.dy == 0 && t.dx == 1) slot = 3;
+      else if (t.dy == 1 && t.dx == 0) slot = 4;
+      if (slot < 0 || slot <= last) return MG_OK;       // a diagonal in-plane entry, or not in ascending order: two passes
+      last = slot;
+      q.v[slot] = recs3[c].v[nip++];
+    }
+    recs[c] = q;
+  }
   const long long lds_cap = 160 * 1024 - 1024;
-  struct Geo { long long NT, tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, K1, NPM, nb, segs, seglen; size_t lds; double fill; };
+  const size_t dict_bytes = ncls * sizeof(mgk::M4Class) + map_bytes;
+  struct Geo { long long NT, tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, LYA, K1, NPM, nb, segs, seglen; size_t lds; double fill, cost; };
   Geo best{};
   bool have = false;
-  const long long want_nt = A.opt.march4_nt != 0 ? A.opt.march4_nt : 768;
+  const long long want_nt = A.opt.march4_nt != 0 ? A.opt.march4_nt : 1024;
+  const long long want_k1 = A.opt.march4_k1 != 0 ? A.opt.march4_k1 : (want_nt == 1024 ? 2 : want_nt == 768 ? 3 : 4);
   for (long long NT : {1024LL, 768LL, 512LL}) {
     if (NT != want_nt) continue;
-    const long long K1 = NT == 1024 ? 2 : NT == 768 ? 3 : 4, NPM = NT == 512 ? 3 : 2;
+    const long long K1 = want_k1, NPM = (NT == 512 || (NT == 768 && K1 == 4)) ? 3 : 2;
+    if (!((NT == 1024 && K1 == 2) || (NT == 768 && (K1 == 3 || K1 == 4)) || (NT == 512 && K1 == 4))) continue;   // (instantiated shapes)
     for (long long tilesx = 1; tilesx <= std::max<long long>({1, n1 / 16, A.opt.march4_tiles_x}); ++tilesx) {
       if (A.opt.march4_tiles_x > 0 && tilesx != A.opt.march4_tiles_x) continue;
       Geo g{};
@@ -2873,30 +2918,45 @@ int build_march4(Csr& A, const std::vector<mgk::M3Class>& recs3, const std::vect
       g.TX = (n1 + tilesx - 1) / tilesx;
       g.WX = g.TX + 6;
       if (g.WX > NT / 2) continue;
-      g.SY = NT / g.WX;
       g.NPL = (g.TX + 2 * mgk::RM4_G + 2) / 2;
-      g.pitch = 2 * g.NPL;
+      g.pitch = 0;
+      for (long long pt : {48LL, 64LL, 80LL})      // (the instantiated pitches)
+        if (g.pitch == 0 && pt >= 2 * g.NPL) g.pitch = pt;
+      if (g.pitch == 0) continue;
       // the tallest tile the lanes, the pair loads and the LDS allow
-      long long TY = std::min<long long>(K1 * g.SY - 6, n2);
-      while (TY >= 2 && ((TY + 8) * g.NPL > NPM * NT || (long long)((size_t)(9 * (TY + 8) - 24) * (size_t)g.pitch * 8 + dict_bytes) > lds_cap)) --TY;
-      if (TY < 2) continue;
+      long long SY = NT / g.WX;
+      // (a tile row's strips may be shifted by up to K1 - 1 lines: that many more lines per column)
+      auto fits = [&](long long sy) {
+        const long long ty = std::min<long long>(K1 * sy - 6 - (K1 - 1), n2);
+        return ty >= 2 && (ty + 8 + K1 - 1) * g.NPL <= NPM * NT && (long long)((size_t)9 * (size_t)(K1 * sy + 2) * (size_t)g.pitch * 8 + dict_bytes) <= lds_cap;
+      };
+      while (SY >= 1 && !fits(SY)) --SY;
+      if (SY < 1) continue;
+      long long TY = std::min<long long>(K1 * SY - 6 - (K1 - 1), n2);
+      if (A.opt.march4_ty_max > 0) TY = std::min<long long>(TY, A.opt.march4_ty_max);
       g.tilesy = (n2 + TY - 1) / TY;
       g.TY = (n2 + g.tilesy - 1) / g.tilesy;                        // equal tiles
-      g.LY = g.TY + 8;
-      g.lds = (size_t)(9 * g.LY - 24) * (size_t)g.pitch * 8 + dict_bytes;
+      g.SY = (g.TY + 6 + (K1 - 1) + K1 - 1) / K1;                   // strips a column needs
+      g.LY = g.TY + 8 + (K1 - 1);
+      g.LYA = K1 * g.SY + 2;
+      g.lds = (size_t)9 * (size_t)g.LYA * (size_t)g.pitch * 8 + dict_bytes;
       const long long tiles = g.tilesx * g.tilesy, slots = ncu;
       if (tiles > slots) continue;
       const long long S = std::min<long long>(slots / tiles, std::max<long long>(1, n3 / 8));
       const long long Lz = (n3 + S - 1) / S;
       const double eff = ((double)n3 / (double)(S * Lz)) * ((double)(tiles * S) / (double)slots);
       g.segs = S; g.seglen = Lz; g.nb = tiles * S;
+      // Cost of a geometry = what ONE workgroup takes (they all run side by side, one per CU): iterations x time per iteration.
+      // Measured on 257^3 (profiles/r04_march4_ab.md: nine geometries at 1024 threads): an iteration costs 1.2 us + 1.05 ns per
+      // row of the stage-1 region, whatever the tile's shape - so the run length (planes of a segment + 6) decides: the most
+      // segments the tiles leave room for, tiles as large as the lanes allow.  (`fill`, kept for the reports: bytes per row.)
       const double core = (double)g.TX * (double)g.TY, R = (double)Lz;
       const double waste = (double)(g.tilesx * g.TX) * (double)(g.tilesy * g.TY) / (double)P;
-      auto lines = [](double W) { return 1.0 + 15.0 / W; };
-      const double fx = 8.0 * (double)((g.TX + 8) * (g.TY + 8)) / core * (1.0 + 8.0 / R) * lines((double)(g.TX + 8));
-      const double fb = 8.0 * (double)((g.TX + 6) * (g.TY + 6)) / core * (1.0 + 6.0 / R) * lines((double)(g.TX + 6));
-      g.fill = (waste * (8.0 + 0.5 * (fx - 8.0) + 8.0 + 0.5 * (fb - 8.0)) + 16.0) / eff;
-      if (!have || g.fill < best.fill) {
+      const double fx = 8.0 * (double)((g.TX + 8) * (g.TY + 8)) / core * (1.0 + 8.0 / R);
+      const double fb = 8.0 * (double)((g.TX + 6) * (g.TY + 6)) / core * (1.0 + 6.0 / R);
+      g.fill = (waste * (fx + fb) + 16.0) / eff;
+      g.cost = ((double)Lz + 6.0) * (1.2 + 1.05e-3 * (double)((g.TX + 6) * (g.TY + 6)));
+      if (!have || g.cost < best.cost) {
         best = g;
         have = true;
       }
@@ -2904,27 +2964,36 @@ int build_march4(Csr& A, const std::vector<mgk::M3Class>& recs3, const std::vect
   }
   if (!have) return MG_OK;
   if (best.nb < std::min<long long>(A.opt.march_min_wg, (long long)ncu * 3 / 4)) return MG_OK;   // small levels: latency-bound
-  const size_t ncls = recs3.size();
-  std::vector<mgk::M3Class> recs(recs3);
-  for (size_t c = 0; c < ncls; ++c) {
-    int nip = 0, first_off = 0;
-    for (const M3Ent& t : ents[c]) {
-      if (t.dz != 0) continue;
-      const int off = (int)((t.dy * best.pitch + t.dx) * 8);
-      if (nip == 0) first_off = off;
-      recs[c].off[nip++] = off;
+  // ---- strip shift per tile row: no strip of K1 lines may hold (live) rows of different y-classes ---------------------------------
+  std::vector<int> ysh((size_t)best.tilesy, -1);
+  for (long long ty = 0; ty < best.tilesy; ++ty) {
+    for (long long sh = 0; sh < best.K1 && ysh[(size_t)ty] < 0; ++sh) {
+      bool ok = true;
+      for (long long j = 0; j < best.SY && ok; ++j) {
+        int seen = -1;
+        for (long long r = 0; r < best.K1 && ok; ++r) {
+          const long long yc = best.K1 * j + r - sh, gy = ty * best.TY - 3 + yc;
+          if (yc < 0 || yc >= best.TY + 6 || gy < 0 || gy >= n2) continue;
+          if (seen < 0) seen = cy[gy];
+          else if (seen != cy[gy]) ok = false;
+        }
+      }
+      if (ok) ysh[(size_t)ty] = (int)sh;
     }
-    for (int u = nip; u < mgk::RM3_NIP; ++u) recs[c].off[u] = first_off;
+    if (ysh[(size_t)ty] < 0) return MG_OK;      // lines of different classes inside every strip layout: two passes
   }
+  MG_TRY(A.rm4_ysh.alloc(ysh.size()));
+  HIP_TRY(hipMemcpy(A.rm4_ysh.p, ysh.data(), ysh.size() * sizeof(int), hipMemcpyHostToDevice));
   MG_TRY(A.rm4_cls.alloc(ncls));
-  HIP_TRY(hipMemcpy(A.rm4_cls.p, recs.data(), ncls * sizeof(mgk::M3Class), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(A.rm4_cls.p, recs.data(), ncls * sizeof(mgk::M4Class), hipMemcpyHostToDevice));
   mgk::March4Dev T{};
   T.cls = A.rm4_cls.p;
+  T.ysh = A.rm4_ysh.p;
   T.cmap = A.rm3_cmap.p;
-  T.ncx = ncx; T.ncy = ncy; T.ntab = ncx * ncy * ncz;
+  T.ncx = ncx; T.ncy = ncy; T.ncz = ncz; T.ntab = ncx * ncy * ncz;
   T.n1 = (int)n1; T.n2 = (int)n2; T.nplanes = (int)n3; T.P = (int)P;
   T.TX = (int)best.TX; T.TY = (int)best.TY; T.tiles_x = (int)best.tilesx; T.tiles_y = (int)best.tilesy;
-  T.WX = (int)best.WX; T.SY = (int)best.SY; T.pitch = (int)best.pitch; T.LY = (int)best.LY; T.NPL = (int)best.NPL;
+  T.WX = (int)best.WX; T.SY = (int)best.SY; T.pitch = (int)best.pitch; T.LY = (int)best.LY; T.NPL = (int)best.NPL; T.LYA = (int)best.LYA;
   T.nblocks = (int)best.nb; T.segs = (int)best.segs; T.seglen = (int)best.seglen;
   T.n_cols = (int)A.n_cols; T.ncls = (int)ncls;
   A.rm4 = T;
@@ -3004,6 +3073,34 @@ int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl_
     }
     if (!okmap) return MG_OK;     // the classes are not a product of coordinate classes: the 1-D chunk form serves the level
     for (unsigned short v : tab) if (v >= ncls && !(box && v == 0xFFFF)) return MG_OK;
+    // Every entry of every class must point INSIDE the grid wherever the class occurs: the tile kernels read the in-plane
+    // neighbours of stage 2 (and later) from slabs that hold computed rows only - a wrap-around coupling (periodic in x: the
+    // shift n1 - 1 decomposes as dy = +1, dx = -1 and passes every check above) would read a line outside the grid as zeros.
+    // Such operators keep the 1-D chunk form / two launches, whose linear indexing computes them correctly.
+    {
+      auto span = [](const std::vector<unsigned short>& idx, int nidx, std::vector<long long>& lo, std::vector<long long>& hi) {
+        lo.assign((size_t)nidx, (long long)idx.size());
+        hi.assign((size_t)nidx, -1);
+        for (size_t i = 0; i < idx.size(); ++i) {
+          lo[idx[i]] = std::min<long long>(lo[idx[i]], (long long)i);
+          hi[idx[i]] = std::max<long long>(hi[idx[i]], (long long)i);
+        }
+      };
+      std::vector<long long> xlo, xhi, ylo, yhi, zlo, zhi;
+      span(cx, ncx, xlo, xhi);
+      span(cy, ncy, ylo, yhi);
+      span(cz, ncz, zlo, zhi);
+      for (int iz = 0; iz < ncz; ++iz)
+        for (int iy = 0; iy < ncy; ++iy)
+          for (int ix = 0; ix < ncx; ++ix) {
+            const unsigned short c = tab[((size_t)iz * ncy + iy) * ncx + ix];
+            if (c == 0xFFFF) continue;
+            for (const Ent& t : ents[c])
+              if (xlo[(size_t)ix] + t.dx < 0 || xhi[(size_t)ix] + t.dx >= n1 || ylo[(size_t)iy] + t.dy < 0 || yhi[(size_t)iy] + t.dy >= n2 ||
+                  zlo[(size_t)iz] + t.dz < 0 || zhi[(size_t)iz] + t.dz >= n3)
+                return MG_OK;
+          }
+    }
     cmap.insert(cmap.end(), cx.begin(), cx.end());
     cmap.insert(cmap.end(), cy.begin(), cy.end());
     cmap.insert(cmap.end(), cz.begin(), cz.end());
@@ -3177,7 +3274,7 @@ int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl_
   A.rm3_nt = (int)best.NT;
   A.rm3_fill = best.fill;
   A.rc_march3 = true;
-  if (!var && !box) MG_TRY(build_march4(A, recs, ents, ncx, ncy, ncz, dict_bytes, ncu));
+  if (!var && !box) MG_TRY(build_march4(A, recs, ents, ncx, ncy, ncz, (cmap.size() * 2 + 15) & ~(size_t)15, ncu, cmap.data() + n1));
   if (A.opt.debug_format)
     std::fprintf(stderr, "[mg] march3: grid %lldx%lldx%lld tiles %lldx%lld of %lldx%lld (%lld threads, K1 %lld, SY %lld), %lld workgroups%s, class maps %dx%dx%d, LDS %zu B, est. %.1f B/row\n",
                  n1, n2, n3, best.tilesx, best.tilesy, best.TX, best.TY, best.NT, best.K1, best.SY, best.nb,
@@ -4984,6 +5081,11 @@ int mg_time_op_dev_FP64(mg_hierarchy* h, long long level, long long kernel, long
         if (!march2_ok(h, l, xa, xb, L.r.p, nullptr)) rc = fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the two-stage marching kernel", level);
         else rc = k_smooth_residual(h, l, bvec, xa, xb, L.r.p, nullptr, false);
         bts = spmv_bytes(L.A, nrhs, true, true) + spmv_bytes(L.A, nrhs, true, false);
+        break;
+      case MG_K_FOUR_STAGE:
+        if (!march4_ok(h, l, xa, xb, L.r.p)) rc = fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the four-stage pass", level);
+        else rc = k_four_stage(h, l, bvec, xa, xb, L.r.p);
+        bts = 2.0 * (spmv_bytes(L.A, nrhs, true, true) + spmv_bytes(L.A, nrhs, true, false));
         break;
       case MG_K_PROLONG:
         rc = k_spmv(h, l, MG_K_PROLONG, L.P, 0.0, h->lev[(size_t)l + 1].x0.p, 1.0, xb);

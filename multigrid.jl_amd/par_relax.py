@@ -67,22 +67,37 @@ def setupHybridKaczmarz(param: hybridKaczmarz, AT, mesh):
     return param
 
 
+def _cheap_key(A):
+    """What a call can check for nothing: the object, its buffers and its shape.  A matrix converted on every call (CSC in,
+    CSR needed) never matches and pays the full key below - callers that sweep in a loop should hand over a CSR matrix."""
+    if not sp.isspmatrix_csr(A):
+        return None
+    return (id(A), A.data.ctypes.data, A.indices.ctypes.data, A.indptr.ctypes.data, A.nnz, A.shape)
+
+
 def _matrix_key(A):
-    """Identity of the VALUES as well as of the object: the reference passes AT.nzval on every call (parRelax.jl:61-64), so
-    a matrix modified in place, or a new one allocated at a recycled id, must not hit the uploaded copy."""
+    """Identity of the VALUES and of the PATTERN (row pointers included: equal data / indices with other row splits are
+    another matrix): the reference passes AT.nzval on every call (parRelax.jl:61-64), so a matrix modified in place, or a
+    new one allocated at a recycled id, must not hit the uploaded copy."""
     import zlib
-    A = A if sp.isspmatrix_csr(A) else sp.csr_matrix(A)
-    data = np.ascontiguousarray(A.data)
-    return (A.nnz, A.shape, zlib.crc32(data.view(np.uint8)), zlib.crc32(np.ascontiguousarray(A.indices).view(np.uint8)))
+    return (A.nnz, A.shape, zlib.crc32(np.ascontiguousarray(A.data).view(np.uint8)),
+            zlib.crc32(np.ascontiguousarray(A.indices).view(np.uint8)), zlib.crc32(np.ascontiguousarray(A.indptr).view(np.uint8)))
 
 
-def _device_handle(param: hybridKaczmarz, A):
-    key = _matrix_key(A)
+def _device_handle(param: hybridKaczmarz, A, values_changed: bool = True):
+    """The uploaded copy of A, re-used while A is the same matrix.  values_changed = False: the caller vouches that a CSR
+    matrix with the same buffers as last time still holds the same values (skips the O(nnz) hash of every call)."""
+    cheap = _cheap_key(A)
+    if param._handle is not None and cheap is not None and cheap == getattr(param, "_cheap", None) and not values_changed:
+        return param._handle
+    Ac = A if sp.isspmatrix_csr(A) else sp.csr_matrix(A)      # converted ONCE: key and upload use the same CSR
+    key = _matrix_key(Ac)
     if param._handle is not None and param._key == key:
+        param._cheap = cheap
         return param._handle
     param.close()
     lib = D.load_library()
-    A = sp.csr_matrix(A)
+    A = Ac.copy() if not Ac.has_sorted_indices else Ac
     A.sort_indices()
     cp = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1
     rv = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
@@ -93,13 +108,15 @@ def _device_handle(param: hybridKaczmarz, A):
     D._check(lib, lib.mg_kaczmarz_create_FP64_INT64(0, A.shape[0], D._i64(cp), D._f64(nz), D._i64(rv), arr.shape[1], arr.shape[0],
                                                     arr.ctypes.data_as(C.POINTER(C.c_uint)), D._f64(invd), C.byref(h)),
              "mg_kaczmarz_create")
-    param._handle, param._key = h, key
+    param._handle, param._key, param._cheap = h, key, cheap
     return h
 
 
-def applyHybridKaczmarz(param: hybridKaczmarz, AT, r: np.ndarray, x: np.ndarray, numDomains: Optional[int] = None):
-    """``numit`` sweeps of x towards AT' x = r, in place (parRelax.jl:59-65)."""
-    h = _device_handle(param, AT)
+def applyHybridKaczmarz(param: hybridKaczmarz, AT, r: np.ndarray, x: np.ndarray, numDomains: Optional[int] = None,
+                        values_changed: bool = True):
+    """``numit`` sweeps of x towards AT' x = r, in place (parRelax.jl:59-65).  values_changed = False (not in the reference's
+    signature): the CSR matrix handed over is unchanged since the last call - the uploaded copy is reused without hashing it."""
+    h = _device_handle(param, AT, values_changed)
     lib = D.load_library()
     if x.ndim == 2 and not x.flags.f_contiguous:
         raise ValueError("x must be column-major (Julia layout)")
@@ -115,9 +132,14 @@ def getHybridKaczmarzPrecond(param: hybridKaczmarz, AT, nrhs: int):
     n = AT.shape[1]
     x = np.zeros(n) if nrhs == 1 else np.zeros((n, nrhs), order="F")
 
+    Ac = AT if sp.isspmatrix_csr(AT) else sp.csr_matrix(AT)   # (converted once for every application of the closure)
+    _device_handle(param, Ac, True)
+
     def precond(r):
         x[...] = 0.0
-        applyHybridKaczmarz(param, AT, r, x)
+        # (the reference hands AT.nzval over on every call: values modified in place are honoured unless the caller set
+        # param.static_matrix = True, which skips the O(nnz) hash of every application)
+        applyHybridKaczmarz(param, Ac, r, x, values_changed=not getattr(param, "static_matrix", False))
         return x
 
     param.precond = precond

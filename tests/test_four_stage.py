@@ -27,20 +27,24 @@ def _setup(mg, ncells, levels, tol=1e-10, maxIter=6, pre=2, post=1, cyc="V", rel
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,nt,tiles_x", [([33, 25, 15], 768, 0), ([40, 30, 17], 1024, 2), ([23, 23, 23], 512, 1),
-                                              ([48, 40, 12], 768, 3), ([130, 9, 9], 1024, 0), ([20, 61, 33], 512, 0)])
-def test_four_stage_pass_bit_identical_to_the_two_passes(mg, built, monkeypatch, cells, nt, tiles_x):
+@pytest.mark.parametrize("cells,nt,k1,tiles_x,ty_max", [([33, 25, 15], 768, 3, 0, 0), ([40, 31, 17], 1024, 2, 2, 0), ([23, 23, 23], 512, 4, 1, 9),
+                                                        ([48, 40, 12], 768, 3, 3, 9), ([130, 9, 9], 1024, 2, 0, 0), ([20, 61, 33], 512, 4, 0, 13),
+                                                        ([36, 44, 10], 1024, 2, 0, 7), ([30, 50, 11], 768, 4, 2, 10)])
+def test_four_stage_pass_bit_identical_to_the_two_passes(mg, built, monkeypatch, cells, nt, k1, tiles_x, ty_max):
     """t', r' of the four-stage pass = the outputs of the two two-stage passes chained through xn = t + d.*r, bit for bit
     (same products, same order, same epilogue expressions); ||r|| to rounding (another partition of the partial sums);
-    against numpy to kernel tolerance.  Geometries forced: 2 / 3 / 4 rows per lane, partial tiles, several tiles per line."""
+    against numpy to kernel tolerance.  Geometries forced: 2 / 3 / 4 rows per lane, partial tiles, several tiles per line,
+    several tile rows (strips shifted so that the first / last line of the grid ends / starts a strip)."""
     import torch
     _small_grid_env(monkeypatch)
     monkeypatch.setenv("MG_MARCH4_NT", str(nt))
+    monkeypatch.setenv("MG_MARCH4_K1", str(k1))
     monkeypatch.setenv("MG_MARCH4_TILES_X", str(tiles_x))
+    monkeypatch.setenv("MG_MARCH4_TY_MAX", str(ty_max))
     A, p, b = _setup(mg, cells, 2)
     h = mg.to_device(p)
     ok, geo = h.four_stage_form(1)
-    assert ok and geo[8] == nt and (tiles_x == 0 or geo[0] == tiles_x), geo
+    assert ok and geo[8] == nt and geo[4] == k1 and (tiles_x == 0 or geo[0] == tiles_x) and (ty_max == 0 or geo[3] <= ty_max), geo
     assert h.sweep_residual_form(1)[0] == 3
     Al, dl = p.As[0], p.relaxPrecs[0]
     rng = np.random.default_rng(sum(cells) + nt)
@@ -53,7 +57,7 @@ def test_four_stage_pass_bit_identical_to_the_two_passes(mg, built, monkeypatch,
     nrm2 = h.sweep_residual_dev(1, bb, x, t, None, xn, True)
     t2, r2 = torch.zeros_like(x), torch.zeros_like(x)
     h.sweep_residual_dev(1, bb, xn, t2, r2)
-    assert torch.equal(tp, t2) and torch.equal(rp, r2)
+    assert torch.equal(tp, t2) and torch.equal(rp, r2)     # (0.0 == -0.0: a zero may change its sign)
     assert abs(nrm - nrm2) <= 1e-14 * nrm2
     # numpy
     t_w = xh + dl * (bh - Al @ xh)
@@ -68,8 +72,8 @@ def test_four_stage_pass_bit_identical_to_the_two_passes(mg, built, monkeypatch,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels,cyc,tol", [([33, 25, 15], 2, "V", 1e-10), ([40, 30, 17], 3, "W", 1e-10), ([23, 23, 23], 2, "F", 1e-10),
-                                                  ([33, 25, 15], 2, "V", 3e-3), ([48, 40, 12], 2, "V", 1e-1), ([40, 30, 17], 3, "V", 1e-30)])
+@pytest.mark.parametrize("cells,levels,cyc,tol", [([33, 25, 15], 2, "V", 1e-10), ([40, 31, 17], 3, "W", 1e-10), ([23, 23, 23], 2, "F", 1e-10),
+                                                  ([33, 25, 15], 2, "V", 3e-3), ([48, 41, 12], 2, "V", 1e-1), ([40, 31, 17], 3, "V", 1e-30)])
 def test_solve_with_the_four_stage_pass(mg, built, monkeypatch, cells, levels, cyc, tol):
     """solveMG through the four-stage pass: residual history and iterate against the oracle (1e-10), and against the same
     solve with MG_NO_MARCH4=1 - iterates bit-identical, also when the stopping test ends the loop before the step count

@@ -1124,3 +1124,52 @@ def test_coarse_subcycle_graph_replay(mg, built, cycle, monkeypatch):
         mg.clear_(p)
     assert np.array_equal(res["0"][0], res["1"][0])
     assert res["0"][1] == res["1"][1]
+
+
+def test_periodic_in_x_operator_stays_off_the_tile_forms(mg, built, monkeypatch):
+    """A coupling that wraps around a grid line (periodic in x: row (0, y, z) <-> row (n1-1, y, z)) decomposes as
+    (dy, dx) = (+1, -1) / (-1, +1), keeps the in-plane entries within +-1 and factors as a product map - every check of the
+    2-D tile forms passes, but at y = 0 / y = n2-1 the entry points at a line outside the grid, which the tile kernels hold as
+    zeros.  Such classes must keep the tile forms (march3, band, four-stage) off the operator; the forms that index linearly
+    compute it: fused sweep, residual and the sweep + residual pair against numpy, the solve against the oracle."""
+    import scipy.sparse as sp
+    import torch
+    from multigrid_jl_amd import device as D
+    monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
+    monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    monkeypatch.setenv("MG_MARCH_MAX_LEN", "64")
+    cells = [24, 20, 12]
+    A, mesh = mg.poisson_shifted(cells)
+    n1, n2, n3 = [c + 1 for c in cells]
+    w = abs(A[1, 0])
+    first = (np.arange(n2 * n3) * n1).astype(np.int64)
+    last = first + n1 - 1
+    Wm = sp.coo_matrix((np.full(first.size, -w), (first, last)), shape=A.shape)
+    Dg = sp.coo_matrix((np.full(2 * first.size, w), (np.concatenate([first, last]), np.concatenate([first, last]))), shape=A.shape)
+    A = (A + Wm + Wm.T + Dg).tocsr()
+    A.sort_indices()
+    p = mg.getMGparam(np.float64, np.int64, 2, 8, 6, 1e-10, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p, 1)
+    b = mg.seeded_rhs(A, 1)
+    h = mg.to_device(p)
+    form, _ = h.sweep_residual_form(1)
+    assert form != 3 and not h.four_stage_form(1)[0], form
+    Al, dl = p.As[0], p.relaxPrecs[0]
+    rng = np.random.default_rng(3)
+    xh, bh = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+    x, bb = torch.from_numpy(xh).cuda(), torch.from_numpy(bh).cuda()
+    t1, r1 = torch.zeros_like(x), torch.zeros_like(x)
+    h.fused_dev(1, D.MG_K_SMOOTH, bb, x, t1)
+    h.fused_dev(1, D.MG_K_RESIDUAL, bb, t1, r1)
+    t_want = xh + dl * (bh - Al @ xh)
+    r_want = bh - Al @ t_want
+    assert np.abs(t1.cpu().numpy() - t_want).max() / np.abs(t_want).max() < KERNEL_TOL
+    assert np.abs(r1.cpu().numpy() - r_want).max() / np.abs(r_want).max() < 10 * KERNEL_TOL
+    if form == 2:
+        t, r = torch.zeros_like(x), torch.zeros_like(x)
+        h.sweep_residual_dev(1, bb, x, t, r)
+        assert torch.equal(t, t1) and torch.equal(r, r1)
+    _compare_solve(mg, p, b)
+    mg.clear_(p)
