@@ -260,9 +260,6 @@ int mg_sweep_residual_dev_FP64(mg_hierarchy* h, long long level, const double* b
  * iterate with one sweep of the pass's input.  Exposed for kernel tests. */
 int mg_four_stage_dev_FP64(mg_hierarchy* h, long long level, const double* b_dev, const double* x_dev, double* tp_dev,
                            double* rp_dev, double* norm_r);
-/* *kind = 1 / 2 when operator `which` of `level` is applied as three 1-D operators (kron_restrict: `bc = R r`, MGcycle.jl:66 /
- * kron_prolong: `x += P xc`, l.90 - full weighting is a Kronecker product, GeometricTransferOperators.jl:5-20), else 0. */
-int mg_operator_separable(mg_hierarchy* h, long long level, long long which, long long* kind);
 /* *yes = 1 when level `level` has the four-stage form; geometry[12] as mg_sweep_residual_form's tile geometry. */
 int mg_four_stage_form(mg_hierarchy* h, long long level, long long* yes, long long* geometry);
 

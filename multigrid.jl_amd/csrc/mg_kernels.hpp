@@ -4189,243 +4189,4 @@ __global__ __launch_bounds__(64) void hybrid_kaczmarz(const int* __restrict__ ro
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Separable transfer operators (round 4).  Full weighting is a Kronecker product of three 1-D operators - P = P3 (x) P2 (x) P1
-// (GeometricTransferOperators.jl:5-20) and RT = P * 0.5^dim (MGsetup.jl:56-60) - and so is every operator M whose rows and
-// columns are grids and whose entries factor as M[(X,Y,Z),(x,y,z)] = Fz[Z,z] * Fy[Y,y] * Fx[X,x] with 1-D factors of at most
-// three CONSECUTIVE entries per row.  The host derives the factors from the stored CSR operator and verifies every entry
-// (build_kron: exact equality of (wx*wy)*wz with the stored value - full weighting's weights are powers of two); the
-// kernels then apply the three 1-D operators one after the other on a brick staged in LDS: 3 + 3 + 3 multiply-adds per
-// coarse row instead of 27 dictionary gathers (restriction `bc = R r`, MGcycle.jl:66), 2 + 2 + 2 instead of 8 per fine row
-// (prolongation `x += P xc`, l.90), coalesced loads, no index or class stream at all.
-// The sums are associated differently from the CSR row loop (x, then y, then z instead of 27 / 8 products in column order):
-// the results agree with the reference order to rounding (1e-16 relative; the parity bar is 1e-10), not bit for bit.
-// ------------------------------------------------------------------------------------------------
-struct KronDev {
-  const int* f0;      // first column of every 1-D row: x-factor rows [0, r[0]) | y-factor rows | z-factor rows
-  const double* w;    // 3 weights per 1-D row (0 beyond the row's entries), same order
-  int r[3];           // rows grid (x fastest)
-  int q[3];           // columns grid
-};
-constexpr int KR_T = 256;                       // threads per workgroup
-#ifndef MG_KR_BY
-#define MG_KR_BY 4
-#endif
-#ifndef MG_KR_BZ
-#define MG_KR_BZ 4
-#endif
-#ifndef MG_KP_BZ
-#define MG_KP_BZ 4
-#endif
-constexpr int KR_BX = 32, KR_BY = MG_KR_BY, KR_BZ = MG_KR_BZ; // coarse brick of the restriction
-constexpr int KR_FX = 2 * KR_BX + 1, KR_FY = 2 * KR_BY + 1, KR_FZ = 2 * KR_BZ + 1;   // largest fine box of a brick (host check)
-constexpr int KR_LXP = KR_FX + 1;
-constexpr size_t KR_LDS = (size_t)(KR_FZ * KR_FY * KR_LXP + KR_FZ * KR_FY * KR_BX) * 8;
-
-// bc = M r (rows = the coarse grid) [; y2 = d .* bc]
-__global__ __launch_bounds__(KR_T) void kron_restrict(KronDev K, const double* __restrict__ r, double* __restrict__ bc,
-                                                      const double* __restrict__ d, double* __restrict__ y2) {
-  extern __shared__ double kwin[];
-  double* b0 = kwin;                                   // [lz][ly][KR_LXP] fine box; later [lz][BY][BX]
-  double* b1 = kwin + KR_FZ * KR_FY * KR_LXP;          // [lz][ly][BX]
-  __shared__ int sf[KR_BX + KR_BY + KR_BZ];
-  __shared__ double sw[3 * (KR_BX + KR_BY + KR_BZ)];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nbx = (K.r[0] + KR_BX - 1) / KR_BX, nby = (K.r[1] + KR_BY - 1) / KR_BY;
-  const int bid = blockIdx.x;
-  const int bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
-  const int X0 = bx * KR_BX, Y0 = by * KR_BY, Z0 = bz * KR_BZ;
-  const int nX = min(KR_BX, K.r[0] - X0), nY = min(KR_BY, K.r[1] - Y0), nZ = min(KR_BZ, K.r[2] - Z0);
-  const int oy = K.r[0], oz = K.r[0] + K.r[1];
-  if (tid < KR_BX + KR_BY + KR_BZ) {
-    int g = -1;
-    if (tid < KR_BX) { if (tid < nX) g = X0 + tid; }
-    else if (tid < KR_BX + KR_BY) { if (tid - KR_BX < nY) g = oy + Y0 + tid - KR_BX; }
-    else if (tid - KR_BX - KR_BY < nZ) g = oz + Z0 + tid - KR_BX - KR_BY;
-    sf[tid] = g >= 0 ? K.f0[g] : 0;
-    for (int k = 0; k < 3; ++k) sw[3 * tid + k] = g >= 0 ? K.w[3 * (size_t)g + k] : 0.0;
-  }
-  // fine box of the brick: [fx0, fx0 + lx) x [fy0, fy0 + ly) x [fz0, fz0 + lz)
-  const int fx0 = K.f0[X0], fy0 = K.f0[oy + Y0], fz0 = K.f0[oz + Z0];
-  const int lx = min(K.f0[X0 + nX - 1] + 3, K.q[0]) - fx0, ly = min(K.f0[oy + Y0 + nY - 1] + 3, K.q[1]) - fy0,
-            lz = min(K.f0[oz + Z0 + nZ - 1] + 3, K.q[2]) - fz0;
-  // ---- stage the fine box: one line of lx entries per wavefront and trip, coalesced -------------------------------------
-  const long long qP = (long long)K.q[0] * K.q[1];
-  // (every load of a lane goes out before its first LDS write: a load-store loop waits for each load in turn)
-  {
-    constexpr int NL = (KR_FZ * KR_FY + KR_T / 64 - 1) / (KR_T / 64);     // lines per wavefront
-    const int nl = ly * lz;
-    double v[NL], vt = 0.0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int line = wave + i * (KR_T / 64);
-      const int lc = line < nl ? line : 0;
-      const int z = lc / ly, y = lc - z * ly;
-      const double* src = r + ((long long)(fz0 + z) * qP + (long long)(fy0 + y) * K.q[0] + fx0);
-      v[i] = src[lane < lx ? lane : 0];
-    }
-    if (lx > 64) {                                                          // entry 64 of line tid
-      const int lc = tid < nl ? tid : 0;
-      const int z = lc / ly, y = lc - z * ly;
-      vt = r[(long long)(fz0 + z) * qP + (long long)(fy0 + y) * K.q[0] + fx0 + 64];
-    }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int line = wave + i * (KR_T / 64);
-      if (line < nl && lane < lx) b0[line * KR_LXP + lane] = v[i];
-    }
-    if (lx > 64 && tid < nl) b0[tid * KR_LXP + 64] = vt;
-  }
-  __syncthreads();
-  // ---- x: b1[line][X] = sum_k wx[X][k] * b0[line][fx[X] - fx0 + k] ---------------------------------------------------------
-  {
-    const int X = lane & (KR_BX - 1), sub = lane / KR_BX;
-    const int o = sf[X] - fx0;
-    const double w0 = sw[3 * X], w1 = sw[3 * X + 1], w2 = sw[3 * X + 2];
-    const int i0 = min(max(o, 0), lx - 1), i1 = min(max(o + 1, 0), lx - 1), i2 = min(max(o + 2, 0), lx - 1);
-    for (int line = wave * (64 / KR_BX) + sub; line < ly * lz; line += (KR_T / 64) * (64 / KR_BX)) {
-      const double* q = b0 + line * KR_LXP;
-      double v = w0 * q[i0];
-      v = v + w1 * q[i1];
-      v = v + w2 * q[i2];
-      b1[line * KR_BX + X] = v;
-    }
-  }
-  __syncthreads();
-  // ---- y: b2[z][Y][X] = sum_k wy[Y][k] * b1[z][fy[Y] - fy0 + k][X]   (b2 over b0) -----------------------------------------------
-  double* b2 = b0;
-  for (int i = tid; i < lz * KR_BY * KR_BX; i += KR_T) {
-    const int X = i & (KR_BX - 1), Y = (i / KR_BX) % KR_BY, z = i / (KR_BX * KR_BY);
-    const int o = sf[KR_BX + Y] - fy0;
-    const int j0 = min(max(o, 0), ly - 1), j1 = min(max(o + 1, 0), ly - 1), j2 = min(max(o + 2, 0), ly - 1);
-    const double* q = b1 + (size_t)z * ly * KR_BX + X;
-    double v = sw[3 * (KR_BX + Y)] * q[j0 * KR_BX];
-    v = v + sw[3 * (KR_BX + Y) + 1] * q[j1 * KR_BX];
-    v = v + sw[3 * (KR_BX + Y) + 2] * q[j2 * KR_BX];
-    b2[i] = v;
-  }
-  __syncthreads();
-  // ---- z: out[Z][Y][X] = sum_k wz[Z][k] * b2[fz[Z] - fz0 + k][Y][X] ---------------------------------------------------------------
-  for (int i = tid; i < KR_BZ * KR_BY * KR_BX; i += KR_T) {
-    const int X = i & (KR_BX - 1), Y = (i / KR_BX) % KR_BY, Z = i / (KR_BX * KR_BY);
-    if (X < nX && Y < nY && Z < nZ) {
-      const int o = sf[KR_BX + KR_BY + Z] - fz0;
-      const int k0 = min(max(o, 0), lz - 1), k1 = min(max(o + 1, 0), lz - 1), k2 = min(max(o + 2, 0), lz - 1);
-      const double* q = b2 + Y * KR_BX + X;
-      double v = sw[3 * (KR_BX + KR_BY + Z)] * q[k0 * KR_BY * KR_BX];
-      v = v + sw[3 * (KR_BX + KR_BY + Z) + 1] * q[k1 * KR_BY * KR_BX];
-      v = v + sw[3 * (KR_BX + KR_BY + Z) + 2] * q[k2 * KR_BY * KR_BX];
-      const long long row = ((long long)(Z0 + Z) * K.r[1] + (Y0 + Y)) * K.r[0] + X0 + X;
-      bc[row] = v;
-      if (y2) y2[row] = d[row] * v;
-    }
-  }
-}
-
-// y = alpha * M xc + beta * y (rows = the fine grid): a fine brick of KP_BX x KP_BY x KP_BZ rows per workgroup
-constexpr int KP_BX = 64, KP_BY = 8, KP_BZ = MG_KP_BZ;
-constexpr int KP_CX = KP_BX / 2 + 2, KP_CY = KP_BY / 2 + 2, KP_CZ = KP_BZ / 2 + 2;   // largest coarse box of a brick (host check)
-__global__ __launch_bounds__(KR_T) void kron_prolong(KronDev K, const double* __restrict__ xc, double* __restrict__ y,
-                                                     double alpha, double beta) {
-  __shared__ double c0[KP_CZ * KP_CY * KP_CX];         // coarse box
-  __shared__ double c1[KP_BZ * KP_CY * KP_CX];         // z applied
-  __shared__ double c2[KP_BZ * KP_BY * KP_CX];         // z, y applied
-  __shared__ int sf[KP_BX + KP_BY + KP_BZ];
-  __shared__ double sw[3 * (KP_BX + KP_BY + KP_BZ)];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nbx = (K.r[0] + KP_BX - 1) / KP_BX, nby = (K.r[1] + KP_BY - 1) / KP_BY;
-  const int bid = blockIdx.x;
-  const int bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
-  const int x0 = bx * KP_BX, y0 = by * KP_BY, z0 = bz * KP_BZ;
-  const int nx = min(KP_BX, K.r[0] - x0), ny = min(KP_BY, K.r[1] - y0), nz = min(KP_BZ, K.r[2] - z0);
-  const int oy = K.r[0], oz = K.r[0] + K.r[1];
-  if (tid < KP_BX + KP_BY + KP_BZ) {
-    int g = -1;
-    if (tid < KP_BX) { if (tid < nx) g = x0 + tid; }
-    else if (tid < KP_BX + KP_BY) { if (tid - KP_BX < ny) g = oy + y0 + tid - KP_BX; }
-    else if (tid - KP_BX - KP_BY < nz) g = oz + z0 + tid - KP_BX - KP_BY;
-    sf[tid] = g >= 0 ? K.f0[g] : 0;
-    for (int k = 0; k < 3; ++k) sw[3 * tid + k] = g >= 0 ? K.w[3 * (size_t)g + k] : 0.0;
-  }
-  const int cx0 = K.f0[x0], cy0 = K.f0[oy + y0], cz0 = K.f0[oz + z0];
-  const int lx = min(K.f0[x0 + nx - 1] + 3, K.q[0]) - cx0, ly = min(K.f0[oy + y0 + ny - 1] + 3, K.q[1]) - cy0,
-            lz = min(K.f0[oz + z0 + nz - 1] + 3, K.q[2]) - cz0;
-  const long long qP = (long long)K.q[0] * K.q[1];
-  // the fine rows of this thread (x = lane, z-y lines wave, wave + 4, ...): their y loads go out first, then the coarse box -
-  // every load before the first LDS write
-  constexpr int NR = KP_BZ * KP_BY / (KR_T / 64);
-  double yv[NR];
-#pragma unroll
-  for (int t = 0; t < NR; ++t) {
-    const int line = wave + t * (KR_T / 64);
-    const int z = line / KP_BY, yy = line - z * KP_BY;
-    const bool in = lane < nx && yy < ny && z < nz;
-    const long long row = in ? ((long long)(z0 + z) * K.r[1] + (y0 + yy)) * K.r[0] + x0 + lane : 0;
-    yv[t] = beta == 0.0 ? 0.0 : y[row];
-  }
-  {
-    constexpr int NC = (KP_CZ * KP_CY * KP_CX + KR_T - 1) / KR_T;
-    const int nbox = lx * ly * lz;
-    double v[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      const int i = tid + k * KR_T;
-      const int ic = i < nbox ? i : 0;
-      const int x = ic % lx, line = ic / lx;
-      const int z = line / ly, yy = line - z * ly;
-      v[k] = xc[(long long)(cz0 + z) * qP + (long long)(cy0 + yy) * K.q[0] + cx0 + x];
-    }
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      const int i = tid + k * KR_T;
-      if (i < nbox) c0[(i / lx) * KP_CX + i % lx] = v[k];
-    }
-  }
-  __syncthreads();
-  // ---- z: c1[z][yc][xc] = sum_k wz[z][k] * c0[cz[z] - cz0 + k][yc][xc] ------------------------------------------------------------------
-  for (int i = tid; i < KP_BZ * ly * lx; i += KR_T) {
-    const int x = i % lx, yy = (i / lx) % ly, z = i / (lx * ly);
-    const int o = sf[KP_BX + KP_BY + z] - cz0;
-    const int k0 = min(max(o, 0), lz - 1), k1 = min(max(o + 1, 0), lz - 1), k2 = min(max(o + 2, 0), lz - 1);
-    const double* q = c0 + yy * KP_CX + x;
-    double v = sw[3 * (KP_BX + KP_BY + z)] * q[k0 * ly * KP_CX];
-    v = v + sw[3 * (KP_BX + KP_BY + z) + 1] * q[k1 * ly * KP_CX];
-    v = v + sw[3 * (KP_BX + KP_BY + z) + 2] * q[k2 * ly * KP_CX];
-    c1[(z * ly + yy) * KP_CX + x] = v;
-  }
-  __syncthreads();
-  // ---- y: c2[z][y][xc] = sum_k wy[y][k] * c1[z][cy[y] - cy0 + k][xc] ----------------------------------------------------------------------
-  for (int i = tid; i < KP_BZ * KP_BY * lx; i += KR_T) {
-    const int x = i % lx, yy = (i / lx) % KP_BY, z = i / (lx * KP_BY);
-    const int o = sf[KP_BX + yy] - cy0;
-    const int j0 = min(max(o, 0), ly - 1), j1 = min(max(o + 1, 0), ly - 1), j2 = min(max(o + 2, 0), ly - 1);
-    const double* q = c1 + z * ly * KP_CX + x;
-    double v = sw[3 * (KP_BX + yy)] * q[j0 * KP_CX];
-    v = v + sw[3 * (KP_BX + yy) + 1] * q[j1 * KP_CX];
-    v = v + sw[3 * (KP_BX + yy) + 2] * q[j2 * KP_CX];
-    c2[(z * KP_BY + yy) * KP_CX + x] = v;
-  }
-  __syncthreads();
-  // ---- x and the update: y[row] = alpha * sum_k wx[x][k] * c2[z][y][cx[x] - cx0 + k] + beta * y[row] -------------------------------------
-  {
-    const int x = lane;   // (KP_BX = 64: one fine column per lane)
-    const int o = sf[x] - cx0;
-    const double w0 = sw[3 * x], w1 = sw[3 * x + 1], w2 = sw[3 * x + 2];
-    const int i0 = min(max(o, 0), lx - 1), i1 = min(max(o + 1, 0), lx - 1), i2 = min(max(o + 2, 0), lx - 1);
-#pragma unroll
-    for (int t = 0; t < NR; ++t) {
-      const int line = wave + t * (KR_T / 64);
-      const int z = line / KP_BY, yy = line - z * KP_BY;
-      if (x < nx && yy < ny && z < nz) {
-        const double* q = c2 + line * KP_CX;
-        double v = w0 * q[i0];
-        v = v + w1 * q[i1];
-        v = v + w2 * q[i2];
-        const long long row = ((long long)(z0 + z) * K.r[1] + (y0 + yy)) * K.r[0] + x0 + x;
-        y[row] = beta == 0.0 ? alpha * v : alpha * v + beta * yv[t];
-      }
-    }
-  }
-}
-
 }  // namespace mgk

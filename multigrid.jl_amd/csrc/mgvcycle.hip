@@ -72,8 +72,6 @@ struct Options {
   long long march3_nt = 0;         // threads per workgroup (0: by the fill estimate; 1024 or 768)
   long long march3_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
   bool no_march3_lockstep = false, march3_lockstep_force = false;   // schedule of the 2-D tile form
-  bool no_kron = false;            // never apply grid transfer operators as three 1-D operators (kron_restrict / kron_prolong)
-  long long kron_min_rows = 100000;   // smallest operator (rows) served by them (smaller ones are launch-latency bound either way)
   bool no_march4 = false;          // solve loop: never run the two fine-level passes across the stopping test as one four-stage pass
   long long march4_nt = 0;         // threads per workgroup of the four-stage pass (0: default; 1024 / 768 / 512 = 2 / 3 / 4 rows per lane)
   long long march4_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
@@ -109,7 +107,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_LANE_RPL3", "no_lane_rpl3", 0, no_lane_rpl3), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
-      MG_OPT("MG_NO_KRON", "no_kron", 0, no_kron), MG_OPT("MG_KRON_MIN_ROWS", "kron_min_rows", 1, kron_min_rows), MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x), MG_OPT("MG_MARCH4_K1", "march4_k1", 1, march4_k1), MG_OPT("MG_MARCH4_TY_MAX", "march4_ty_max", 1, march4_ty_max),
+      MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x), MG_OPT("MG_MARCH4_K1", "march4_k1", 1, march4_k1), MG_OPT("MG_MARCH4_TY_MAX", "march4_ty_max", 1, march4_ty_max),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
@@ -231,12 +229,6 @@ struct Csr {
   size_t rm3_lds = 0;
   int rm3_k1 = 3, rm3_nt = 1024;
   double rm3_fill = 0.0;    // estimated L1 fills + stores per row (bytes) of the chosen geometry
-  // separable form (kron_restrict / kron_prolong): M = Fz (x) Fy (x) Fx on a rows grid and a columns grid (build_kron)
-  bool kron_ok = false;
-  int kron_kind = 0;              // 1: restriction-shaped (rows = coarse grid), 2: prolongation-shaped (rows = fine grid)
-  DevBuf<int> kron_f0;
-  DevBuf<double> kron_w;
-  mgk::KronDev kron{};
   // four-stage pass of the solve loop (csr_rowclass_march4_spmv): same classes and product map, its own tile geometry
   bool rc_march4 = false;
   DevBuf<mgk::M4Class> rm4_cls;
@@ -420,9 +412,6 @@ struct Csr {
     rc_march4 = false;
     rm4_cls.release();
     rm4_ysh.release();
-    kron_ok = false;
-    kron_f0.release();
-    kron_w.release();
     rc_exc2.release();
     rc_nexc2 = 0;
     rp_ok = false;
@@ -877,7 +866,6 @@ int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* npa
 
 // y = alpha*M*x + beta*y
 // d2 / y2 (optional, both or none; only where restrict_can_scale(M)): also y2 = d2 .* y
-static int big_lds_attr(const void* fn, std::atomic<unsigned long long>& done, size_t bytes = 160 * 1024 - 256);
 int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, const double* x,
            double beta, double* y, const double* d2 = nullptr, double* y2 = nullptr) {
   mgk::VecArgs v{};
@@ -889,22 +877,6 @@ int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, con
   v.d_full = d2;
   v.y2 = y2;
   const double extra = y2 ? 16.0 * (double)M.n_rows : 0.0;
-  if (M.kron_ok && h->nrhs == 1 && ((M.kron_kind == 1 && alpha == 1.0 && beta == 0.0) || (M.kron_kind == 2 && !y2))) {
-    // separable form: no matrix side at all - the source once (+ the brick overlap), the target once (read too when beta != 0)
-    const double moved = 8.0 * ((double)M.n_cols + (double)M.n_rows * (beta != 0.0 ? 2.0 : 1.0)) + extra + 32.0 * (double)(M.kron.r[0] + M.kron.r[1] + M.kron.r[2]);
-    ProfScope ps(h, level, kind, spmv_bytes(M, 1, beta != 0.0, false) + extra, moved);
-    if (M.kron_kind == 1) {
-      const long long nb = (long long)((M.kron.r[0] + mgk::KR_BX - 1) / mgk::KR_BX) * ((M.kron.r[1] + mgk::KR_BY - 1) / mgk::KR_BY) * ((M.kron.r[2] + mgk::KR_BZ - 1) / mgk::KR_BZ);
-      static std::atomic<unsigned long long> attr_done{0};
-      MG_TRY(big_lds_attr(reinterpret_cast<const void*>(&mgk::kron_restrict), attr_done, mgk::KR_LDS));
-      hipLaunchKernelGGL(mgk::kron_restrict, dim3((unsigned)nb), dim3(mgk::KR_T), mgk::KR_LDS, h->stream, M.kron, x, y, d2, y2);
-    } else {
-      const long long nb = (long long)((M.kron.r[0] + mgk::KP_BX - 1) / mgk::KP_BX) * ((M.kron.r[1] + mgk::KP_BY - 1) / mgk::KP_BY) * ((M.kron.r[2] + mgk::KP_BZ - 1) / mgk::KP_BZ);
-      hipLaunchKernelGGL(mgk::kron_prolong, dim3((unsigned)nb), dim3(mgk::KR_T), 0, h->stream, M.kron, x, y, alpha, beta);
-    }
-    HIP_TRY(hipGetLastError());
-    return MG_OK;
-  }
   ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false) + extra, moved_bytes(M, h->nrhs, beta != 0.0, false) + extra);
   return launch_csr<mgk::AXPBY>(h->stream, M, v);
 }
@@ -912,7 +884,6 @@ int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, con
 // streaming kernels csr_pattern_spmv / csr_stream_spmv for operators without row classes)?
 bool restrict_can_scale(const mg_hierarchy* h, const Csr& M) {
   if (h->nrhs != 1 || h->opt.no_restrict_scale) return false;
-  if (M.kron_ok && M.kron_kind == 1) return true;
   if (!M.has_rc) return M.max_row_nnz <= mgk::CHUNK - 2;   // the streaming kernels (pattern-coded or plain CSR), short rows: epilogue output
   return M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && M.rc_lane();
 }
@@ -1041,7 +1012,7 @@ bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* 
 // (12 >= stores per lane and iteration: K1 <= 4 rows x 3 outputs; 32 slabs shared by all workgroups; 1024 lanes)
 constexpr size_t M3_SINK_DOUBLES = (size_t)12 * 32 * 1024;
 // > 64 KB of dynamic LDS needs the function attribute - per DEVICE: one bit per device id, set on the first launch there
-static int big_lds_attr(const void* fn, std::atomic<unsigned long long>& done, size_t bytes) {
+static int big_lds_attr(const void* fn, std::atomic<unsigned long long>& done, size_t bytes = 160 * 1024 - 256) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   const unsigned long long bit = 1ULL << (dev & 63);
@@ -3317,121 +3288,6 @@ int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl_
 // of WP_ROWS in-plane rows the window [wlo, wlo + W) of coarse in-plane indices its rows read in any plane, and per row
 // the 16-bit index of its first column inside that window.  Any row that does not fit drops the operator back to the
 // lane kernel.
-// Separable form of a transfer operator: rows = a grid gr, columns = a grid gq (x fastest), every entry
-// M[(X,Y,Z),(x,y,z)] = Fz[Z,z] * Fy[Y,y] * Fx[X,x] with 1-D factors of at most three CONSECUTIVE entries per row - full weighting
-// (GeometricTransferOperators.jl:5-46: P = P3 (x) P2 (x) P1; MGsetup.jl:56-60: RT = P * 0.5^dim) and anything else built as a
-// Kronecker product of such 1-D operators.  The factors are read off the rows along the three axes through row (0,0,0) (their
-// entries in the column plane of that row's first entry), normalised so that (wx * wy) * wz is the entry, and EVERY stored entry
-// is then compared with that product, bit for bit (weights that are powers of two pass; an operator that fails keeps the
-// row-class / CSR kernels).  Brick extents are checked against the kernels' LDS boxes.
-int build_kron(Csr& M, const long long gr[3], const long long gq[3], bool restr) {
-  M.kron_ok = false;
-  if (M.opt.no_kron || M.regular_cols >= 0 || M.n_rows < M.opt.kron_min_rows) return MG_OK;
-  if (gr[0] < 1 || gr[1] < 1 || gr[2] < 1 || gq[0] < 1 || gq[1] < 1 || gq[2] < 1) return MG_OK;
-  if (gr[0] * gr[1] * gr[2] != M.n_rows || gq[0] * gq[1] * gq[2] != M.n_cols) return MG_OK;
-  if (M.h_rp.size() != (size_t)M.n_rows + 1 || M.h_ci.size() < (size_t)M.nnz) return MG_OK;
-  if (gr[0] > 65535 || gr[1] > 65535 || gr[2] > 65535) return MG_OK;
-  const long long r1 = gr[0], r2 = gr[1], r3 = gr[2], q1 = gq[0], q2 = gq[1], q3 = gq[2];
-  std::vector<double> val((size_t)std::max<long long>(M.nnz, 1));
-  HIP_TRY(hipMemcpy(val.data(), M.val.p, (size_t)M.nnz * sizeof(double), hipMemcpyDeviceToHost));
-  const int* rp = M.h_rp.data();
-  const int* ci = M.h_ci.data();
-  // ---- the three factors from the axis rows ----------------------------------------------------------------------------------------
-  const long long nr[3] = {r1, r2, r3};
-  std::vector<int> f0((size_t)(r1 + r2 + r3), 0), cnt((size_t)(r1 + r2 + r3), 0);
-  std::vector<double> w((size_t)3 * (size_t)(r1 + r2 + r3), 0.0);
-  // reference entry: the first one of row (0,0,0), m0 = Fx[0,x0] * Fy[0,y0] * Fz[0,z0].  The entries of row (X,0,0) in column
-  // plane (y0, z0) are Fx[X,:] * Fy[0,y0] * Fz[0,z0], likewise along y and z: their product is the entry times m0^2 - x carries
-  // the normalisation 1 / m0^2 (m0 a power of two for full weighting: exact)
-  if (rp[1] == rp[0]) return MG_OK;
-  const long long c00 = ci[(size_t)rp[0]];
-  const long long x0 = c00 % q1, y0 = (c00 / q1) % q2, z0 = c00 / (q1 * q2);
-  const double m0 = val[(size_t)rp[0]];
-  if (!(m0 != 0.0) || !std::isfinite(m0)) return MG_OK;
-  size_t base = 0;
-  for (int ax = 0; ax < 3; ++ax) {
-    const long long stride = ax == 0 ? 1 : (ax == 1 ? r1 : r1 * r2);
-    for (long long i = 0; i < nr[ax]; ++i) {
-      const long long row = i * stride;
-      double acc[3] = {0.0, 0.0, 0.0};
-      long long first = -1;
-      for (int k = rp[row]; k < rp[row + 1]; ++k) {
-        const long long c = ci[(size_t)k];
-        const long long cz = c / (q1 * q2), cy = (c / q1) % q2, cx = c % q1;
-        if ((ax != 0 && cx != x0) || (ax != 1 && cy != y0) || (ax != 2 && cz != z0)) continue;
-        const long long a = ax == 0 ? cx : (ax == 1 ? cy : cz);
-        if (first < 0) first = a;
-        if (a < first || a - first > 2) return MG_OK;
-        acc[a - first] = val[(size_t)k];
-      }
-      if (first < 0) return MG_OK;                                   // no entry in the reference column plane
-      f0[base + (size_t)i] = (int)first;
-      int n = 0;
-      for (int t = 0; t < 3; ++t)
-        if (acc[t] != 0.0) n = t + 1;
-      cnt[base + (size_t)i] = n;
-      for (int t = 0; t < 3; ++t) w[3 * (base + (size_t)i) + (size_t)t] = ax == 0 ? acc[t] / m0 / m0 : acc[t];
-    }
-    base += (size_t)nr[ax];
-  }
-  // monotone first columns, brick extents inside the kernels' boxes
-  const int BX = restr ? mgk::KR_BX : mgk::KP_BX, BY = restr ? mgk::KR_BY : mgk::KP_BY, BZ = restr ? mgk::KR_BZ : mgk::KP_BZ;
-  const int LX = restr ? mgk::KR_FX : mgk::KP_CX, LY = restr ? mgk::KR_FY : mgk::KP_CY, LZ = restr ? mgk::KR_FZ : mgk::KP_CZ;
-  const int BB[3] = {BX, BY, BZ}, LL[3] = {LX, LY, LZ};
-  const long long nq[3] = {q1, q2, q3};
-  base = 0;
-  for (int ax = 0; ax < 3; ++ax) {
-    for (long long i = 0; i + 1 < nr[ax]; ++i)
-      if (f0[base + (size_t)i + 1] < f0[base + (size_t)i]) return MG_OK;
-    for (long long i0 = 0; i0 < nr[ax]; i0 += BB[ax]) {
-      const long long i1 = std::min<long long>(i0 + BB[ax], nr[ax]) - 1;
-      const long long ext = std::min<long long>(f0[base + (size_t)i1] + 3, nq[ax]) - f0[base + (size_t)i0];
-      if (ext < 1 || ext > LL[ax]) return MG_OK;
-    }
-    for (long long i = 0; i < nr[ax]; ++i)
-      if (f0[base + (size_t)i] + cnt[base + (size_t)i] > nq[ax]) return MG_OK;
-    base += (size_t)nr[ax];
-  }
-  // ---- every entry against the product ----------------------------------------------------------------------------------------------------
-  bool ok = true;
-#pragma omp parallel for schedule(static) reduction(&& : ok)
-  for (long long Z = 0; Z < r3; ++Z) {
-    for (long long Y = 0; Y < r2 && ok; ++Y)
-      for (long long X = 0; X < r1 && ok; ++X) {
-        const long long row = (Z * r2 + Y) * r1 + X;
-        const size_t ix = (size_t)X, iy = (size_t)(r1 + Y), iz = (size_t)(r1 + r2 + Z);
-        long long expect = 0;
-        for (int kz = 0; kz < 3; ++kz)
-          for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx)
-              if ((w[3 * ix + kx] * w[3 * iy + ky]) * w[3 * iz + kz] != 0.0) ++expect;
-        if (rp[row + 1] - rp[row] != expect) { ok = false; break; }
-        for (int k = rp[row]; k < rp[row + 1]; ++k) {
-          const long long c = ci[(size_t)k];
-          const long long cz = c / (q1 * q2) - f0[iz], cy = (c / q1) % q2 - f0[iy], cx = c % q1 - f0[ix];
-          if (cx < 0 || cx > 2 || cy < 0 || cy > 2 || cz < 0 || cz > 2) { ok = false; break; }
-          const double prod = (w[3 * ix + (size_t)cx] * w[3 * iy + (size_t)cy]) * w[3 * iz + (size_t)cz];
-          if (std::memcmp(&prod, &val[(size_t)k], 8) != 0) { ok = false; break; }
-        }
-      }
-  }
-  if (!ok) return MG_OK;
-  MG_TRY(M.kron_f0.alloc(f0.size()));
-  MG_TRY(M.kron_w.alloc(w.size()));
-  HIP_TRY(hipMemcpy(M.kron_f0.p, f0.data(), f0.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M.kron_w.p, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
-  mgk::KronDev K{};
-  K.f0 = M.kron_f0.p;
-  K.w = M.kron_w.p;
-  for (int t = 0; t < 3; ++t) { K.r[t] = (int)gr[t]; K.q[t] = (int)gq[t]; }
-  M.kron = K;
-  M.kron_kind = restr ? 1 : 2;
-  M.kron_ok = true;
-  if (M.opt.debug_format)
-    std::fprintf(stderr, "[mg] separable %s: rows %lldx%lldx%lld, columns %lldx%lldx%lld\n", restr ? "restriction" : "prolongation", r1, r2, r3, q1, q2, q3);
-  return MG_OK;
-}
-
 int build_winp(Csr& M, const long long gf[3], const long long gc[3]) {
   if (M.rp_ok && M.rp_PF == gf[0] * gf[1] && M.rp_nplanes == gf[2] && M.rp_PC == gc[0] * gc[1]) return MG_OK;   // (same pattern, same hints)
   M.rp_ok = false;
@@ -3582,10 +3438,6 @@ int alloc_scratch(mg_hierarchy* h) {
       MG_TRY(build_schedule(L.P, L.grid, k));
       if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
       if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_winp(L.P, L.grid, h->lev[(size_t)l + 1].grid));
-      if (l + 1 < (int)h->nlevels && k == 1) {
-        MG_TRY(build_kron(L.R, h->lev[(size_t)l + 1].grid, L.grid, true));
-        MG_TRY(build_kron(L.P, L.grid, h->lev[(size_t)l + 1].grid, false));
-      }
     }
   }
   long long nmax = 0;
@@ -4781,13 +4633,6 @@ int mg_four_stage_dev_FP64(mg_hierarchy* h, long long level, const double* b, co
   if (norm_r) MG_TRY(scalar_sync(h, norm_r));
   HIP_TRY(spin_sync(h->stream));
   prof_collect(h);
-  return MG_OK;
-}
-int mg_operator_separable(mg_hierarchy* h, long long level, long long which, long long* kind) {
-  if (!h || !kind) return fail(MG_ERR_INVALID, "null argument");
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  *kind = M->kron_ok ? M->kron_kind : 0;
   return MG_OK;
 }
 int mg_four_stage_form(mg_hierarchy* h, long long level, long long* yes, long long* geometry) {

@@ -78,7 +78,6 @@ SIGNATURES = {
     "mg_sweep_residual_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
     "mg_four_stage_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
     "mg_four_stage_form": (C.c_int, [_vp, _ll, _lp, _lp]),
-    "mg_operator_separable": (C.c_int, [_vp, _ll, _ll, _lp]),
     "mg_time_op_dev_FP64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _dp, _dp]),
     "mg_profile_enable": (C.c_int, [_vp, _ll]),
     "mg_profile_get": (C.c_int, [_vp, _ll, _ll, _dp, _lp, _dp]),
@@ -522,12 +521,6 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_four_stage_dev_FP64(self.handle, level, _ptr(b), _ptr(x), _ptr(tp), _ptr(rp),
                                                          C.byref(ss) if want_norm else None), "mg_four_stage_dev")
         return float(ss.value)
-
-    def operator_separable(self, level: int, which: int) -> int:
-        """1 / 2: the operator is applied as three 1-D operators (restriction / prolongation shaped); 0: not."""
-        k = C.c_longlong(0)
-        _check(self.lib, self.lib.mg_operator_separable(self.handle, level, which, C.byref(k)), "mg_operator_separable")
-        return int(k.value)
 
     def four_stage_form(self, level: int):
         """(available, geometry as sweep_residual_form's)."""

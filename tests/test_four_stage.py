@@ -108,50 +108,3 @@ def test_solve_with_the_four_stage_pass(mg, built, monkeypatch, cells, levels, c
     assert np.array_equal(runs["four"][2], runs["two"][2])
     assert np.abs(runs["four"][1] - runs["two"][1]).max() <= 1e-14 * runs["two"][1][0]
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels", [([32, 32, 32], 3), ([33, 25, 15], 2), ([70, 9, 21], 2), ([64, 16, 8], 3), ([31, 31, 31], 2)])
-def test_separable_transfer_operators(mg, built, monkeypatch, cells, levels):
-    """Full weighting is a Kronecker product of 1-D operators (GeometricTransferOperators.jl:5-20; RT = P * 0.5^dim,
-    MGsetup.jl:56-60): `bc = R r` (MGcycle.jl:66) and `x += P xc` (l.90) applied as three 1-D operators on LDS bricks
-    (kron_restrict / kron_prolong) against scipy - odd and even node counts (the even branch keeps the last node,
-    GeometricTransferOperators.jl:35-36), partial bricks, every (alpha, beta) the cycle uses; the restriction's second output
-    d.*bc through the solve; and the solve with them against the oracle and against the row-class kernels (MG_NO_KRON=1)."""
-    import torch
-    from multigrid_jl_amd import device as D
-    _small_grid_env(monkeypatch)
-    monkeypatch.setenv("MG_KRON_MIN_ROWS", "0")
-    runs = {}
-    for name, off in (("kron", "0"), ("rowclass", "1")):
-        monkeypatch.setenv("MG_NO_KRON", off)
-        A, p, b = _setup(mg, cells, levels, maxIter=5)
-        h = mg.to_device(p)
-        rng = np.random.default_rng(5)
-        for level in range(1, levels):
-            P, R = p.Ps[level - 1], p.Rs[level - 1]
-            assert h.operator_separable(level, D.MG_OP_R) == (1 if off == "0" else 0)
-            assert h.operator_separable(level, D.MG_OP_P) == (2 if off == "0" else 0)
-            r = rng.standard_normal(R.shape[1])
-            bc = torch.full((R.shape[0],), np.nan, dtype=torch.float64).cuda()
-            h.spmv_dev(level, D.MG_OP_R, 1.0, torch.from_numpy(r).cuda(), 0.0, bc)
-            want = R @ r
-            assert np.abs(bc.cpu().numpy() - want).max() <= 1e-13 * np.abs(want).max()
-            xc = rng.standard_normal(P.shape[1])
-            for alpha, beta in ((1.0, 1.0), (1.0, 0.0), (-0.5, 1.0)):
-                x0 = rng.standard_normal(P.shape[0])
-                x = torch.from_numpy(x0.copy()).cuda()
-                h.spmv_dev(level, D.MG_OP_P, alpha, torch.from_numpy(xc).cuda(), beta, x)
-                want = alpha * (P @ xc) + beta * x0
-                assert np.abs(x.cpu().numpy() - want).max() <= 1e-13 * np.abs(want).max()
-        x = np.zeros_like(b)
-        mg.solveMG(p, b, x)
-        hist = {}
-        xo = np.zeros_like(b)
-        orc.solveMG(p, b, xo, False, hist)
-        assert np.abs(p.resvec - hist["resvec"]).max() / hist["resvec"][0] < RES_TOL
-        assert np.abs(x - xo).max() <= RES_TOL * np.abs(xo).max()
-        runs[name] = (x.copy(), np.asarray(p.resvec).copy())
-        mg.clear_(p)
-    # another association of the same sums: rounding, not bits
-    assert np.abs(runs["kron"][0] - runs["rowclass"][0]).max() <= 1e-12 * np.abs(runs["rowclass"][0]).max()
-    assert np.abs(runs["kron"][1] - runs["rowclass"][1]).max() <= 1e-12 * runs["rowclass"][1][0]
