@@ -62,9 +62,7 @@ typedef struct mg_hierarchy mg_hierarchy;
 #define MG_K_SMOOTH_RESIDUAL 9 /* t = x + d.*(b - A*x) and r = b - A*t in one pass (MGcycle.jl:129-131 + 58-60 / SolveFuncs.jl:26-27) */
 #define MG_K_SMOOTH_RESIDUAL_NORM 10 /* the same pass in the solve loop: last post-smoothing sweep + the stopping test's residual: ||r||^2 and t + d.*r out (SolveFuncs.jl:26-30); profile slot only */
 #define MG_K_FOUR_STAGE 11 /* solve loop, fine level: the last post-smoothing sweep + stopping-test residual of step k AND the second pre-smoothing sweep + residual of step k+1 in one pass (SolveFuncs.jl:24-37 around MGcycle.jl:26-31,54-60): x, b in; t', r' and ||r||^2 out; profile slot only */
-#define MG_K_SMALL_DOWN 12 /* a small level's descent in ONE workgroup: x = d.*b, (nu1 - 1) sweeps, r = b - A x, bc = R r (MGcycle.jl:26-31,54-66); profile slot only */
-#define MG_K_SMALL_UP 13   /* ... and its ascent: x += P xc, nu2 sweeps (MGcycle.jl:90-102); profile slot only */
-#define MG_K_COUNT 14
+#define MG_K_COUNT 12
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 

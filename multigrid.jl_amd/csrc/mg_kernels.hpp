@@ -4189,142 +4189,4 @@ __global__ __launch_bounds__(64) void hybrid_kaczmarz(const int* __restrict__ ro
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// A whole level visit in ONE workgroup (round 4).  The levels below a few thousand rows are launch-latency bound: C2's level 5
-// (17^3 = 4913 rows) took six launches of 6.5-7.7 us each - sweep, residual, restriction, (coarsest solve), prolongation, sweep -
-// for microseconds of arithmetic.  Every vector of such a level fits one CU's LDS (3 x 39 KB), so one 1024-thread workgroup
-// runs the descent [x = d.*b ; (nu1 - 1) sweeps ; r = b - A x ; bc = R r (; the next level's first update d.*bc)] and another
-// the ascent [x += P xc ; nu2 sweeps] with s_barrier between the phases (MGcycle.jl:26-31,54-66 and 90-102), the operators in
-// a compact row-class form built for this purpose (build_small: first column + class id per row, dictionary of (offset, value)
-// rows in LDS; rows summed in stored order with the single-stage kernels' epilogue expressions).
-// ------------------------------------------------------------------------------------------------
-struct SmallOp {
-  const unsigned short* cls;   // [n_rows]
-  const int* first;            // [n_rows] first column; nullptr: first column = row + delta[class] (square operators)
-  const int* ptr;              // [ncls + 1]
-  const int* off;              // [nent] column offset from the row's first column
-  const double* val;           // [nent]
-  const int* delta;            // [ncls] (first == nullptr)
-  int n_rows, n_cols, ncls, nent;
-};
-constexpr int SM_T = 1024;
-struct SmallLds {              // offsets (in bytes, 16-byte aligned) into the dynamic LDS of the two kernels; host: small_lds_layout
-  int xa, xb, bb, xc, aval, aoff, aptr, adelta, acls, tval, toff, tptr, total;
-};
-
-__device__ __forceinline__ void sm_stage_dict(const SmallOp& M, double* val, int* off, int* ptr, int tid) {
-  for (int i = tid; i < M.nent; i += SM_T) {
-    val[i] = M.val[i];
-    off[i] = M.off[i];
-  }
-  for (int i = tid; i <= M.ncls; i += SM_T) ptr[i] = M.ptr[i];
-}
-// sum_k val[k] * x[first + off[k]] over the entries of class c, in stored order
-__device__ __forceinline__ double sm_row(const double* x, int first, int c, const double* val, const int* off, const int* ptr) {
-  double acc = 0.0;
-  const int k1 = ptr[c + 1];
-  for (int k = ptr[c]; k < k1; ++k) acc = acc + val[k] * x[first + off[k]];
-  return acc;
-}
-
-// descent: x = d.*b ; (npre - 1) sweeps x <- x + d.*(b - A x) ; r = b - A x ; bc = R r [; xnext = dnext.*bc]; x -> x_out
-__global__ __launch_bounds__(SM_T) void small_level_down(SmallOp A, SmallOp R, SmallLds L, const double* __restrict__ d,
-                                                         const double* __restrict__ dnext, const double* __restrict__ b,
-                                                         double* __restrict__ x_out, double* __restrict__ bc,
-                                                         double* __restrict__ xnext, int npre) {
-  extern __shared__ double smw[];
-  char* w = reinterpret_cast<char*>(smw);
-  double* xa = reinterpret_cast<double*>(w + L.xa);
-  double* xb = reinterpret_cast<double*>(w + L.xb);
-  double* bb = reinterpret_cast<double*>(w + L.bb);
-  double* aval = reinterpret_cast<double*>(w + L.aval);
-  int* aoff = reinterpret_cast<int*>(w + L.aoff);
-  int* aptr = reinterpret_cast<int*>(w + L.aptr);
-  int* adelta = reinterpret_cast<int*>(w + L.adelta);
-  unsigned short* acls = reinterpret_cast<unsigned short*>(w + L.acls);
-  double* tval = reinterpret_cast<double*>(w + L.tval);
-  int* toff = reinterpret_cast<int*>(w + L.toff);
-  int* tptr = reinterpret_cast<int*>(w + L.tptr);
-  const int tid = threadIdx.x, n = A.n_rows;
-  for (int i = tid; i < n; i += SM_T) {
-    const double bi = b[i];
-    bb[i] = bi;
-    xa[i] = d[i] * bi;                       // relax's first update from x = 0 (MGcycle.jl:134 with r = b)
-    acls[i] = A.cls[i];
-  }
-  sm_stage_dict(A, aval, aoff, aptr, tid);
-  for (int i = tid; i < A.ncls; i += SM_T) adelta[i] = A.delta[i];
-  sm_stage_dict(R, tval, toff, tptr, tid);
-  __syncthreads();
-  for (int s = 1; s < npre; ++s) {
-    for (int i = tid; i < n; i += SM_T) {
-      const int c = acls[i];
-      const double acc = sm_row(xa, i + adelta[c], c, aval, aoff, aptr);
-      xb[i] = xa[i] + d[i] * (bb[i] - acc);
-    }
-    __syncthreads();
-    double* t = xa; xa = xb; xb = t;
-  }
-  for (int i = tid; i < n; i += SM_T) {
-    const int c = acls[i];
-    const double acc = sm_row(xa, i + adelta[c], c, aval, aoff, aptr);
-    xb[i] = bb[i] - acc;                     // r
-    x_out[i] = xa[i];
-  }
-  __syncthreads();
-  for (int j = tid; j < R.n_rows; j += SM_T) {
-    const int c = R.cls[j];
-    const double acc = sm_row(xb, R.first[j], c, tval, toff, tptr);
-    bc[j] = acc;
-    if (xnext) xnext[j] = dnext[j] * acc;
-  }
-}
-
-// ascent: x += P xc ; npost sweeps; x in / out in global memory
-__global__ __launch_bounds__(SM_T) void small_level_up(SmallOp A, SmallOp P, SmallLds L, const double* __restrict__ d,
-                                                       const double* __restrict__ b, double* __restrict__ x,
-                                                       const double* __restrict__ xcg, int npost) {
-  extern __shared__ double smw[];
-  char* w = reinterpret_cast<char*>(smw);
-  double* xa = reinterpret_cast<double*>(w + L.xa);
-  double* xb = reinterpret_cast<double*>(w + L.xb);
-  double* bb = reinterpret_cast<double*>(w + L.bb);
-  double* xc = reinterpret_cast<double*>(w + L.xc);
-  double* aval = reinterpret_cast<double*>(w + L.aval);
-  int* aoff = reinterpret_cast<int*>(w + L.aoff);
-  int* aptr = reinterpret_cast<int*>(w + L.aptr);
-  int* adelta = reinterpret_cast<int*>(w + L.adelta);
-  unsigned short* acls = reinterpret_cast<unsigned short*>(w + L.acls);
-  double* tval = reinterpret_cast<double*>(w + L.tval);
-  int* toff = reinterpret_cast<int*>(w + L.toff);
-  int* tptr = reinterpret_cast<int*>(w + L.tptr);
-  const int tid = threadIdx.x, n = A.n_rows;
-  for (int i = tid; i < n; i += SM_T) {
-    xa[i] = x[i];
-    bb[i] = b[i];
-    acls[i] = A.cls[i];
-  }
-  for (int i = tid; i < P.n_cols; i += SM_T) xc[i] = xcg[i];
-  sm_stage_dict(A, aval, aoff, aptr, tid);
-  for (int i = tid; i < A.ncls; i += SM_T) adelta[i] = A.delta[i];
-  sm_stage_dict(P, tval, toff, tptr, tid);
-  __syncthreads();
-  for (int i = tid; i < n; i += SM_T) {      // x += P xc (each row by its own thread)
-    const int c = P.cls[i];
-    const double acc = sm_row(xc, P.first[i], c, tval, toff, tptr);
-    xa[i] = 1.0 * acc + xa[i];
-  }
-  __syncthreads();
-  for (int s = 0; s < npost; ++s) {
-    for (int i = tid; i < n; i += SM_T) {
-      const int c = acls[i];
-      const double acc = sm_row(xa, i + adelta[c], c, aval, aoff, aptr);
-      xb[i] = xa[i] + d[i] * (bb[i] - acc);
-    }
-    __syncthreads();
-    double* t = xa; xa = xb; xb = t;
-  }
-  for (int i = tid; i < n; i += SM_T) x[i] = xa[i];
-}
-
 }  // namespace mgk

@@ -72,8 +72,6 @@ struct Options {
   long long march3_nt = 0;         // threads per workgroup (0: by the fill estimate; 1024 or 768)
   long long march3_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
   bool no_march3_lockstep = false, march3_lockstep_force = false;   // schedule of the 2-D tile form
-  bool no_small = false;           // never run a small level's descent / ascent as one workgroup each (small_level_down / _up)
-  long long small_max_rows = 5200; // largest level served that way (three vectors of it + the dictionaries must fit 160 KB of LDS)
   bool no_march4 = false;          // solve loop: never run the two fine-level passes across the stopping test as one four-stage pass
   long long march4_nt = 0;         // threads per workgroup of the four-stage pass (0: default; 1024 / 768 / 512 = 2 / 3 / 4 rows per lane)
   long long march4_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
@@ -109,7 +107,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_LANE_RPL3", "no_lane_rpl3", 0, no_lane_rpl3), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
-      MG_OPT("MG_NO_SMALL", "no_small", 0, no_small), MG_OPT("MG_SMALL_MAX_ROWS", "small_max_rows", 1, small_max_rows), MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x), MG_OPT("MG_MARCH4_K1", "march4_k1", 1, march4_k1), MG_OPT("MG_MARCH4_TY_MAX", "march4_ty_max", 1, march4_ty_max),
+      MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x), MG_OPT("MG_MARCH4_K1", "march4_k1", 1, march4_k1), MG_OPT("MG_MARCH4_TY_MAX", "march4_ty_max", 1, march4_ty_max),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
@@ -231,20 +229,6 @@ struct Csr {
   size_t rm3_lds = 0;
   int rm3_k1 = 3, rm3_nt = 1024;
   double rm3_fill = 0.0;    // estimated L1 fills + stores per row (bytes) of the chosen geometry
-  // compact row-class form of a SMALL operator for the one-workgroup level kernels (small_level_down / small_level_up; build_small)
-  bool sm_ok = false;
-  bool sm_implicit = false;     // first column = row + delta[class] (the level's A), else a first column per row (P, R)
-  DevBuf<int> sm_first, sm_ptr, sm_off, sm_delta;
-  DevBuf<unsigned short> sm_cls;
-  DevBuf<double> sm_val;
-  int sm_ncls = 0, sm_nent = 0;
-  std::vector<int> sm_h_rp, sm_h_ci;   // host pattern (a few thousand rows): new values re-derive the classes
-  mgk::SmallOp smdev() const {
-    mgk::SmallOp o{};
-    o.cls = sm_cls.p; o.first = sm_implicit ? nullptr : sm_first.p; o.ptr = sm_ptr.p; o.off = sm_off.p; o.val = sm_val.p;
-    o.delta = sm_delta.p; o.n_rows = (int)n_rows; o.n_cols = (int)n_cols; o.ncls = sm_ncls; o.nent = sm_nent;
-    return o;
-  }
   // four-stage pass of the solve loop (csr_rowclass_march4_spmv): same classes and product map, its own tile geometry
   bool rc_march4 = false;
   DevBuf<mgk::M4Class> rm4_cls;
@@ -459,9 +443,6 @@ struct Csr {
   }
   void release() {
     drop_rc();
-    sm_ok = false;
-    sm_first.release(); sm_ptr.release(); sm_off.release(); sm_delta.release(); sm_cls.release(); sm_val.release();
-    sm_h_rp.clear(); sm_h_ci.clear();
     h_rp.clear();
     h_rp.shrink_to_fit();
     h_ci.clear();
@@ -1206,67 +1187,6 @@ int k_four_stage(mg_hierarchy* h, int level, const double* b, const double* x, d
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
-// ---- a small level's descent and ascent as one workgroup each (small_level_down / small_level_up) -------------------------------
-// LDS layout shared by both kernels: three vectors of the level, the coarse vector (ascent), A's dictionary and class ids, the
-// transfer operator's dictionary.  Returns false when it does not fit.
-bool small_lds_layout(const Csr& A, const Csr& T, long long n, long long nc, mgk::SmallLds* out) {
-  auto al = [](long long b) { return (b + 15) & ~15LL; };
-  long long o = 0;
-  mgk::SmallLds L{};
-  L.xa = (int)o; o = al(o + 8 * n);
-  L.xb = (int)o; o = al(o + 8 * n);
-  L.bb = (int)o; o = al(o + 8 * n);
-  L.xc = (int)o; o = al(o + 8 * nc);
-  L.aval = (int)o; o = al(o + 8LL * A.sm_nent);
-  L.tval = (int)o; o = al(o + 8LL * T.sm_nent);
-  L.aoff = (int)o; o = al(o + 4LL * A.sm_nent);
-  L.aptr = (int)o; o = al(o + 4LL * (A.sm_ncls + 1));
-  L.adelta = (int)o; o = al(o + 4LL * A.sm_ncls);
-  L.toff = (int)o; o = al(o + 4LL * T.sm_nent);
-  L.tptr = (int)o; o = al(o + 4LL * (T.sm_ncls + 1));
-  L.acls = (int)o; o = al(o + 2 * n);
-  L.total = (int)o;
-  *out = L;
-  return o <= 160 * 1024 - 512;
-}
-bool small_ok(const mg_hierarchy* h, int l) {
-  if (l + 1 >= (int)h->nlevels) return false;
-  const Level& L = h->lev[(size_t)l];
-  if (h->opt.no_small || h->nrhs != 1 || h->relax_type != 0 || !L.relax_set) return false;
-  if (!L.A.sm_ok || !L.A.sm_implicit || !L.P.sm_ok || L.P.sm_implicit || !L.R.sm_ok || L.R.sm_implicit) return false;
-  const long long nc = h->lev[(size_t)l + 1].n;
-  mgk::SmallLds a{}, b{};
-  return small_lds_layout(L.A, L.R, L.n, nc, &a) && small_lds_layout(L.A, L.P, L.n, nc, &b);
-}
-int k_small_down(mg_hierarchy* h, int l, const double* b, double* x_out, double* bc, double* xnext, long long npre) {
-  Level& L = h->lev[(size_t)l];
-  Level& C = h->lev[(size_t)l + 1];
-  mgk::SmallLds lay{};
-  if (!small_lds_layout(L.A, L.R, L.n, C.n, &lay)) return fail(MG_ERR_STATE, "small-level kernel: the level does not fit the LDS");
-  static std::atomic<unsigned long long> attr_done{0};
-  MG_TRY(big_lds_attr(reinterpret_cast<const void*>(&mgk::small_level_down), attr_done, 160 * 1024 - 512));
-  // algorithmic: (npre - 1) sweeps + the residual + the restriction; moved: b in, x and bc out (+ the operators' class forms)
-  const double alg = (double)(npre - 1) * spmv_bytes(L.A, 1, true, true) + spmv_bytes(L.A, 1, true, false) + spmv_bytes(L.R, 1, false, false);
-  ProfScope ps(h, l, MG_K_SMALL_DOWN, alg, 8.0 * (double)(2 * L.n + 2 * C.n) + 2.0 * (double)L.n + 16.0 * (double)(L.A.sm_nent + L.R.sm_nent) + 6.0 * (double)C.n);
-  hipLaunchKernelGGL(mgk::small_level_down, dim3(1), dim3(mgk::SM_T), (size_t)lay.total, h->stream, L.A.smdev(), L.R.smdev(), lay, L.d.p,
-                     xnext ? C.d.p : nullptr, b, x_out, bc, xnext, (int)npre);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-int k_small_up(mg_hierarchy* h, int l, const double* b, double* x, const double* xc, long long npost) {
-  Level& L = h->lev[(size_t)l];
-  Level& C = h->lev[(size_t)l + 1];
-  mgk::SmallLds lay{};
-  if (!small_lds_layout(L.A, L.P, L.n, C.n, &lay)) return fail(MG_ERR_STATE, "small-level kernel: the level does not fit the LDS");
-  static std::atomic<unsigned long long> attr_done{0};
-  MG_TRY(big_lds_attr(reinterpret_cast<const void*>(&mgk::small_level_up), attr_done, 160 * 1024 - 512));
-  const double alg = (double)npost * spmv_bytes(L.A, 1, true, true) + spmv_bytes(L.P, 1, true, false);
-  ProfScope ps(h, l, MG_K_SMALL_UP, alg, 8.0 * (double)(3 * L.n + C.n) + 8.0 * (double)L.n + 16.0 * (double)(L.A.sm_nent + L.P.sm_nent));
-  hipLaunchKernelGGL(mgk::small_level_up, dim3(1), dim3(mgk::SM_T), (size_t)lay.total, h->stream, L.A.smdev(), L.P.smdev(), lay, L.d.p, b, x, xc,
-                     (int)npost);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
 // Can the coarse-grid correction of level `level` ride in the staging of the first post-smoothing sweep?
 // (one right-hand side, pointwise smoother, A on the marching kernel, P in row-class form without exception rows)
 bool can_fuse_prolong(mg_hierarchy* h, int level, const double* x, const double* out) {
@@ -1562,21 +1482,6 @@ int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb,
   Level& L = h->lev[l];
   Level& C = h->lev[l + 1];
   const long long len = L.n * h->nrhs;
-  // A level whose vectors fit one CU's LDS, entered with x = 0: its descent and its ascent are ONE single-workgroup launch each
-  if (x_zero && !pre_done && !(defer_post && *defer_post) && ctype != 'K' && small_ok(h, l)) {
-    if (defer_post) *defer_post = false;
-    const bool give_x1 = l + 1 < nl - 1 && C.relax_set;
-    MG_TRY(k_small_down(h, l, b, xa, C.b.p, give_x1 ? C.x0.p : nullptr, std::max<long long>(1, L.npre)));
-    double* xc = nullptr;
-    MG_TRY(cycle_sub(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc, give_x1));
-    if (l + 1 < nl - 1 && (ctype == 'W' || ctype == 'F')) {  // MGcycle.jl:78-85
-      double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
-      MG_TRY(cycle_sub(h, l + 1, C.b.p, xc, other, false, ctype == 'W' ? 'W' : 'V', &xc));
-    }
-    MG_TRY(k_small_up(h, l, b, xa, xc, std::max<long long>(1, L.npost)));
-    *result = xa;
-    return MG_OK;
-  }
   double* cur = xa;
   double* alt = xb;
   const double gmresTol = 1e-5;  // MGcycle.jl:5
@@ -3929,7 +3834,6 @@ int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val
   return MG_OK;
 }
 // Square operators first try the form without a first-column stream (the class also fixes first column - row).
-int build_small(Csr* M, const int* rp, const int* ci, const double* val);
 int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
   if (M->n_rows == M->n_cols) {
     if (!M->opt.no_implicit_first) {
@@ -4057,86 +3961,12 @@ int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, c
   {  // pattern-code the column indices when the operator has few distinct row patterns (grid operators)
     if (!M->opt.no_pattern) MG_TRY(build_patterns(M, rp, ci));
   }
-  if (n_rows <= M->opt.small_max_rows && !M->opt.no_small) {   // the compact form of the one-workgroup level kernels
-    M->sm_h_rp = rp;
-    M->sm_h_ci.assign(ci.begin(), ci.begin() + nnz);
-    MG_TRY(build_small(M, rp.data(), ci.data(), nzval));
-  }
   if (M->opt.debug_format)
       std::fprintf(stderr, "[mgvcycle] operator %lld x %lld, nnz %lld: row classes %lld (dictionary %lld, exception rows %d, "
                    "implicit first %d, window %d, paired rows %d), patterns %lld\n", M->n_rows, M->n_cols, M->nnz, M->has_rc ? M->rc_ncls : 0,
                    M->has_rc ? M->rc_entries : 0, M->rc_nexc, (int)M->rc_implicit, (int)M->rc_window, (int)M->rc_pair,
                    M->has_pat ? M->npat : 0);
   return MG_OK;
-}
-
-// Compact row-class form of a small operator (at most small_max_rows rows) for the one-workgroup level kernels: rows grouped by
-// bit-exact equality of (offsets from the first column, values) - and, for a square operator, of first column - row, so that no
-// per-row first column is needed; at most 512 classes / 4096 dictionary entries (they live in LDS).  Rows keep their stored order.
-int build_small(Csr* M, const int* rp, const int* ci, const double* val) {
-  M->sm_ok = false;
-  const long long n = M->n_rows;
-  if (M->opt.no_small || n < 1 || n > M->opt.small_max_rows || M->n_cols > 8 * M->opt.small_max_rows || M->regular_cols >= 0) return MG_OK;
-  const bool implicit = M->n_rows == M->n_cols;
-  std::vector<unsigned short> cls((size_t)n);
-  std::vector<int> first((size_t)n), ptr{0}, off, delta;
-  std::vector<double> vals;
-  std::unordered_map<unsigned long long, std::vector<int>> byhash;
-  for (long long i = 0; i < n; ++i) {
-    const int k0 = rp[i], k1 = rp[i + 1], len = k1 - k0;
-    if (len < 1) return MG_OK;                                 // an empty row has no first column
-    const int f = ci[k0], dl = f - (int)i;
-    unsigned long long hsh = 0x9E3779B97F4A7C15ULL * (unsigned long long)(len + 1) + (implicit ? (unsigned long long)(long long)dl : 0ULL);
-    for (int k = k0; k < k1; ++k) {
-      unsigned long long vb;
-      std::memcpy(&vb, &val[k], 8);
-      hsh ^= (vb + (unsigned long long)(ci[k] - f) * 0xD6E8FEB86659FD93ULL) + 0x9E3779B97F4A7C15ULL + (hsh << 6) + (hsh >> 2);
-    }
-    std::vector<int>& cand = byhash[hsh];
-    int found = -1;
-    for (int c : cand) {
-      if (ptr[(size_t)c + 1] - ptr[(size_t)c] != len || (implicit && delta[(size_t)c] != dl)) continue;
-      bool same = true;
-      for (int k = 0; k < len && same; ++k)
-        same = off[(size_t)ptr[(size_t)c] + (size_t)k] == ci[k0 + k] - f && std::memcmp(&vals[(size_t)ptr[(size_t)c] + (size_t)k], &val[k0 + k], 8) == 0;
-      if (same) { found = c; break; }
-    }
-    if (found < 0) {
-      if (ptr.size() - 1 >= 512 || off.size() + (size_t)len > 4096) return MG_OK;
-      found = (int)ptr.size() - 1;
-      for (int k = k0; k < k1; ++k) {
-        off.push_back(ci[k] - f);
-        vals.push_back(val[k]);
-      }
-      ptr.push_back((int)off.size());
-      delta.push_back(dl);
-      cand.push_back(found);
-    }
-    cls[(size_t)i] = (unsigned short)found;
-    first[(size_t)i] = f;
-  }
-  MG_TRY(M->sm_cls.alloc(cls.size()));
-  MG_TRY(M->sm_first.alloc(first.size()));
-  MG_TRY(M->sm_ptr.alloc(ptr.size()));
-  MG_TRY(M->sm_off.alloc(off.size()));
-  MG_TRY(M->sm_val.alloc(vals.size()));
-  MG_TRY(M->sm_delta.alloc(delta.size()));
-  HIP_TRY(hipMemcpy(M->sm_cls.p, cls.data(), cls.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->sm_first.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->sm_ptr.p, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->sm_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->sm_val.p, vals.data(), vals.size() * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->sm_delta.p, delta.data(), delta.size() * sizeof(int), hipMemcpyHostToDevice));
-  M->sm_ncls = (int)ptr.size() - 1;
-  M->sm_nent = (int)off.size();
-  M->sm_implicit = implicit;
-  M->sm_ok = true;
-  return MG_OK;
-}
-// new values on the stored pattern (mg_replace_values_FP64, mg_rap_FP64)
-int refresh_small(Csr* M, const double* val) {
-  if (M->sm_h_rp.size() != (size_t)M->n_rows + 1) { M->sm_ok = false; return MG_OK; }
-  return build_small(M, M->sm_h_rp.data(), M->sm_h_ci.data(), val);
 }
 
 // column -> entries in ascending row order (stable counting sort of the stored pattern), for colsumsq_kernel
@@ -4246,14 +4076,12 @@ int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long l
   // row-class dictionaries follow the new values (coarse values come back from HBM; rap_numeric adds every entry in a
   // fixed order, so rows that were bit-identical before a constant-coefficient update still are afterwards)
   MG_TRY(refresh_rowclasses(&L0.A, fine_nzval));
-  MG_TRY(refresh_small(&L0.A, fine_nzval));
   for (int l = 1; l < nl; ++l) {
     Csr& Ac = h->lev[(size_t)l].A;
-    if (!Ac.has_rc && Ac.sm_h_rp.empty()) continue;
+    if (!Ac.has_rc) continue;
     std::vector<double> hv((size_t)Ac.nnz);
     HIP_TRY(hipMemcpy(hv.data(), Ac.val.p, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
     MG_TRY(refresh_rowclasses(&Ac, hv.data()));
-    MG_TRY(refresh_small(&Ac, hv.data()));
   }
   for (int l = 0; l + 1 < nl; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));   // relaxPrecs were recomputed above
   for (int l = 0; l < nl; ++l) {   // tile / march tables follow the new classes
@@ -4696,7 +4524,6 @@ int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, co
   HIP_TRY(spin_sync(h->stream));
   HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
   MG_TRY(refresh_rowclasses(M, nzval));
-  MG_TRY(refresh_small(M, nzval));
   if (which == MG_OP_A) {
     Level& L = h->lev[(size_t)level - 1];
     if (L.relax_set) MG_TRY(derive_class_d(L));

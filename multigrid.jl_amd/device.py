@@ -24,10 +24,9 @@ LIB_PATH = os.environ.get("MGVCYCLE_LIB") or os.path.join(_HERE, "csrc", "libmgv
 
 MG_OP_A, MG_OP_P, MG_OP_R = 0, 1, 2
 (MG_K_SPMV, MG_K_RESIDUAL, MG_K_SMOOTH, MG_K_RESTRICT, MG_K_PROLONG, MG_K_DSCALE, MG_K_COARSE,
- MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_SMOOTH_RESIDUAL_NORM, MG_K_FOUR_STAGE, MG_K_SMALL_DOWN, MG_K_SMALL_UP,
- MG_K_COUNT) = range(15)
+ MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_SMOOTH_RESIDUAL_NORM, MG_K_FOUR_STAGE, MG_K_COUNT) = range(13)
 KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm", "smooth+prolong", "smooth+residual",
-                "smooth+residual+norm", "four-stage", "small-down", "small-up"]
+                "smooth+residual+norm", "four-stage"]
 
 _ll = C.c_longlong
 _dp = C.POINTER(C.c_double)

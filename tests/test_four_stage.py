@@ -108,45 +108,3 @@ def test_solve_with_the_four_stage_pass(mg, built, monkeypatch, cells, levels, c
     assert np.array_equal(runs["four"][2], runs["two"][2])
     assert np.abs(runs["four"][1] - runs["two"][1]).max() <= 1e-14 * runs["two"][1][0]
 
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels,cyc,relax,omega,pre,post", [([16, 16, 16], 3, "V", "Jac", 0.8, 2, 1), ([16, 12, 10], 3, "W", "Jac", 0.8, 1, 1),
-                                                                  ([15, 12, 9], 3, "F", "SPAI", 1.0, 3, 2), ([32, 32, 16], 4, "V", "Jac", 0.8, 2, 1),
-                                                                  ([64, 64], 4, "V", "Jac", 0.75, 0, 0), ([16, 16, 16], 2, "V", "SPAI", 1.0, 2, 2)])
-def test_small_levels_in_one_workgroup(mg, built, monkeypatch, cells, levels, cyc, relax, omega, pre, post):
-    """Levels whose vectors fit one CU's LDS run their descent [x = d.*b, sweeps, r = b - A x, bc = R r] and their ascent
-    [x += P xc, sweeps] (MGcycle.jl:26-31,54-66 / 90-102) as ONE single-workgroup launch each (small_level_down / _up): the
-    solve against the oracle (1e-10) and against the launch-per-operation path (MG_NO_SMALL=1; fused multiply-adds instead of
-    rounded products in the row sums: rounding, not bits), V / W / F cycles, Jacobi and SPAI, 0-3 sweeps, 2-D and 3-D, with
-    the coarsest level right below or further down; the profile shows the two launches per level visit."""
-    import torch
-    runs = {}
-    for name, off in (("small", "0"), ("launches", "1")):
-        monkeypatch.setenv("MG_NO_SMALL", off)
-        A, p, b = _setup(mg, cells, levels, maxIter=6, pre=pre, post=post, cyc=cyc, relax=relax, omega=omega)
-        h = mg.to_device(p)
-        x = np.zeros_like(b)
-        mg.solveMG(p, b, x)
-        hist = {}
-        xo = np.zeros_like(b)
-        orc.solveMG(p, b, xo, False, hist)
-        assert np.abs(p.resvec - hist["resvec"]).max() / hist["resvec"][0] < RES_TOL
-        assert np.abs(x - xo).max() <= RES_TOL * np.abs(xo).max()
-        # one cycle from a given iterate (the fine level then starts from a residual; the levels below from x = 0)
-        x1 = np.random.default_rng(3).standard_normal(b.shape)
-        xo1 = orc.recursiveCycle(p, b, x1.copy(), 1)
-        mg.recursiveCycle(p, b, x1, 1)
-        assert np.abs(x1 - xo1).max() <= RES_TOL * np.abs(xo1).max()
-        h.profile_reset()
-        h.profile_enable(True)
-        bd = torch.from_numpy(b).cuda()
-        xd = torch.zeros_like(bd)
-        h.solve_dev(bd, xd, 0.0, 2)
-        h.profile_enable(False)
-        kinds = {k[1] for k in h.profile()}
-        assert ("small-down" in kinds and "small-up" in kinds) == (off == "0"), kinds
-        runs[name] = (x.copy(), np.asarray(p.resvec).copy())
-        mg.clear_(p)
-    assert np.abs(runs["small"][0] - runs["launches"][0]).max() <= 1e-12 * np.abs(runs["launches"][0]).max()
-    assert np.abs(runs["small"][1] - runs["launches"][1]).max() <= 1e-12 * runs["launches"][1][0]
