@@ -72,6 +72,7 @@ struct Options {
   long long march3_nt = 0;         // threads per workgroup (0: by the fill estimate; 1024 or 768)
   long long march3_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
   bool no_march3_lockstep = false, march3_lockstep_force = false;   // schedule of the 2-D tile form
+  bool no_pipeline = false;        // solve loop: read a four-stage step's norm before the next step is enqueued (A/B)
   bool no_march4 = false;          // solve loop: never run the two fine-level passes across the stopping test as one four-stage pass
   long long march4_nt = 0;         // threads per workgroup of the four-stage pass (0: default; 1024 / 768 / 512 = 2 / 3 / 4 rows per lane)
   long long march4_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
@@ -107,7 +108,7 @@ const Options::Entry* Options::table(size_t* n) {
       MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
       MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_LANE_RPL3", "no_lane_rpl3", 0, no_lane_rpl3), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
       MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
-      MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x), MG_OPT("MG_MARCH4_K1", "march4_k1", 1, march4_k1), MG_OPT("MG_MARCH4_TY_MAX", "march4_ty_max", 1, march4_ty_max),
+      MG_OPT("MG_NO_PIPELINE", "no_pipeline", 0, no_pipeline), MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x), MG_OPT("MG_MARCH4_K1", "march4_k1", 1, march4_k1), MG_OPT("MG_MARCH4_TY_MAX", "march4_ty_max", 1, march4_ty_max),
       MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
       MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
       MG_OPT("MG_NT", "nt", 3, nt),
@@ -542,7 +543,8 @@ struct mg_hierarchy {
   // reductions
   DevBuf<double> partial, partial2, scalar;
   DevBuf<double> m3sink;       // csr_rowclass_march3_spmv: one slot per lane for the stores of lanes with nothing to store
-  double* h_scalar = nullptr;  // pinned
+  double* h_scalar = nullptr;  // pinned: [0] the scalar of scalar_sync / dot_sync; [1], [2] the norms of the pipelined solve loop
+  hipEvent_t pipe_ev[2] = {nullptr, nullptr};   // ... and the events behind them
   bool scalar_mirrored = false;   // the kernel that produced h->scalar also stored it into h_scalar (sum_final_mirror)
   int nred_blocks = 1024;
   // staging for the host-pointer API
@@ -1159,7 +1161,7 @@ bool march4_ok(const mg_hierarchy* h, int level, const double* x, const double* 
   if (x == tp || x == rp || tp == rp) return false;
   return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
-int k_four_stage(mg_hierarchy* h, int level, const double* b, const double* x, double* tp, double* rp) {
+int k_four_stage(mg_hierarchy* h, int level, const double* b, const double* x, double* tp, double* rp, double* host_slot = nullptr) {
   const Csr& A = h->lev[(size_t)level].A;
   mgk::March2Args a{};
   a.x = x;
@@ -1183,7 +1185,11 @@ int k_four_stage(mg_hierarchy* h, int level, const double* b, const double* x, d
     else MG_TRY((launch_march4<512, 4, 3>(h->stream, A, a)));
   }
   ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-  launch_sum_final(h, h->partial.p, nb1);
+  if (host_slot && !h->capturing) {   // (the pipelined stopping test: a pinned slot per step in flight)
+    hipLaunchKernelGGL(mgk::sum_final_mirror, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->scalar.p, host_slot);
+  } else {
+    launch_sum_final(h, h->partial.p, nb1);
+  }
   HIP_TRY(hipGetLastError());
   return MG_OK;
 }
@@ -1699,8 +1705,44 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
   // step k and the second pre-smoothing sweep + residual of step k+1 - back to back across the stopping test - are ONE pass:
   // cur (x before the last sweep) -> alt = t' (x after the next cycle's pre-smoothing), L.r = r' = b - A t', ||r|| of step k.
   // The next cycle then starts at its restriction (pre_done).  Speculative across the test: if it ends the loop, the iterate
-  // is re-created from the pass's input (t_missing4) and t', r' are dropped.
-  bool pre_done = false, t_missing4 = false;
+  // is re-created from the pass's input and t', r' are dropped.
+  // PIPELINED stopping test (round 4): the norm of such a step lands in a pinned slot of its own behind an event, and the host
+  // reads it only after it has enqueued the NEXT step - the device never waits for the host's round trip (30 us between the
+  // norm and the restriction in round 3's kernel trace; launch-bound stretches behind the graph launch as well).  The input of
+  // the unverified step (`keep`) stays untouched meanwhile: the next step plays in the two other buffers.  If the test ends
+  // the loop at step k, step k+1 was speculative: the stream is drained and the iterate of step k re-created from `keep`.
+  struct Pend { bool on = false; int slot = 0; } pend;
+  double* keep = nullptr;       // input of the pending (unverified) four-stage step
+  bool pre_done = false, stopped = false;
+  if (!h->pipe_ev[0]) {
+    HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev[1], hipEventDisableTiming));
+  }
+  // read the pending step's norm (waits for its event): one more entry of the residual history; *stop: the loop ends at that step
+  auto check_pending = [&](bool* stop) -> int {
+    if (!pend.on) return MG_OK;
+    hipError_t e;
+    while ((e = hipEventQuery(h->pipe_ev[pend.slot])) == hipErrorNotReady) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    HIP_TRY(e);
+    res = std::sqrt(h->h_scalar[1 + pend.slot]);
+    pend.on = false;
+    ++it;
+    if (resvec) resvec[it] = res;
+    if (res / res0 < tol) *stop = true;   // SolveFuncs.jl:34-36
+    return MG_OK;
+  };
+  // the loop ended at the step whose input is `keep`: whatever was enqueued behind it is dropped, its iterate re-created
+  auto finish_from_keep = [&]() -> int {
+    HIP_TRY(spin_sync(h->stream));
+    MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, keep, cur == keep ? alt : cur));
+    if (cur == keep) cur = alt;
+    stopped = true;
+    return MG_OK;
+  };
   for (long long count = 1; count <= maxIter; ++count) {
     double* out = nullptr;
     // from the second step on, L.r = b - A*x is the residual just computed for the stopping test
@@ -1709,13 +1751,32 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
     if (out != cur) std::swap(cur, alt);
     x_zero = false;
     pre_done = false;
+    bool stop = false;
     if (deferred && count < maxIter && !h->opt.no_dead_t && march4_ok(h, 0, cur, alt, L.r.p)) {
-      MG_TRY(k_four_stage(h, 0, b, cur, alt, L.r.p));
-      std::swap(cur, alt);        // cur = t' (the next cycle's x after pre-smoothing); alt = the input of the pass
+      const int slot = (int)(count & 1);
+      MG_TRY(k_four_stage(h, 0, b, cur, alt, L.r.p, h->h_scalar + 1 + slot));   // alt: neither cur nor keep
+      HIP_TRY(hipEventRecord(h->pipe_ev[slot], h->stream));
+      MG_TRY(check_pending(&stop));                   // the PREVIOUS step's norm, with this step already in the queue
+      if (stop) { MG_TRY(finish_from_keep()); break; }
+      double* freed = keep;                           // (verified: the previous step's input is free again)
+      keep = cur;                                     // this step's input: untouched until its norm has been read
+      cur = alt;                                      // t': the next cycle's x after pre-smoothing
+      if (freed) alt = freed;
+      else { alt = spare; spare = nullptr; }
+      pend.on = true;
+      pend.slot = slot;
       pre_done = true;
       x1_ready = false;
-      t_missing4 = true;
-    } else if (deferred) {
+      if (h->opt.no_pipeline) {
+        MG_TRY(check_pending(&stop));
+        if (stop) { MG_TRY(finish_from_keep()); break; }
+      }
+      continue;
+    }
+    MG_TRY(check_pending(&stop));                     // (a step of another kind: first the pending norm)
+    if (stop) { MG_TRY(finish_from_keep()); break; }
+    if (keep) { spare = keep; keep = nullptr; }
+    if (deferred) {
       // cur = x before the last sweep; alt <- the iterate; spare <- x + d.*r (unused if this was the last step).
       // The iterate itself is DEAD while the loop goes on (the next cycle starts from x + d.*r and recomputes its own
       // residual): unless this is the last step by count it is not stored (8 of the pass's 34 bytes per row); should the
@@ -1743,10 +1804,13 @@ int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long
     if (resvec) resvec[it] = res;
     if (res / res0 < tol) break;  // SolveFuncs.jl:34-36
     t_missing = false;            // (the loop goes on: the iterate of this step is never read)
-    t_missing4 = false;
   }
-  if (t_missing) MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, spare, cur));   // spare: the input of the last pass; cur: the iterate
-  if (t_missing4) MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, alt, cur));    // alt: the input of the four-stage pass; cur (t', dropped): the iterate
+  if (!stopped && pend.on) {      // (cannot happen: the last step by count is never a four-stage step; kept for safety)
+    bool stop = false;
+    MG_TRY(check_pending(&stop));
+    MG_TRY(finish_from_keep());
+  }
+  if (t_missing && !stopped) MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, spare, cur));   // spare: the input of the last pass; cur: the iterate
   if (cur != x) {
     HIP_TRY(hipMemcpyAsync(x, cur, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(spin_sync(h->stream));
@@ -4031,7 +4095,7 @@ int mg_create(long long nlevels, long long nrhs, long long device_id, mg_hierarc
     return fail(MG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
   }
   if (h->partial.alloc((size_t)h->nred_blocks) != MG_OK || h->partial2.alloc(256) != MG_OK || h->scalar.alloc(1) != MG_OK ||
-      hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), sizeof(double)) != hipSuccess) {
+      hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), 4 * sizeof(double)) != hipSuccess) {
     mg_destroy(h);
     return fail(MG_ERR_HIP, "allocation of reduction scratch failed");
   }
@@ -4155,6 +4219,7 @@ int mg_destroy(mg_hierarchy* h) {
   h->kAp.release();
   h->kw.release();
   if (h->h_scalar) (void)hipHostFree(h->h_scalar);
+  for (hipEvent_t& e : h->pipe_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (h->h_blk) (void)hipHostFree(h->h_blk);
   if (h->h_kscal) (void)hipHostFree(h->h_kscal);
   if (h->h_blk_c) (void)hipHostFree(h->h_blk_c);
