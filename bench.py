@@ -69,6 +69,11 @@ def parse():
                     help="N>1: sequence the sharded cycle from Python (torch.distributed) instead of the native mg_dist_* path")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; the median is reported")
     ap.add_argument("--no-generic-pass", action="store_true", help="skip the second pass with the streaming formats forced")
+    ap.add_argument("--no-divsiggrad", action="store_true", help="skip the variable-coefficient (div sigma grad) leg")
+    ap.add_argument("--global-cells", default="", help="single-GPU path: a,b,c cells of a non-cubic grid with h = 1/--cells in every "
+                                                       "direction (the GLOBAL grid of an N-GPU weak-scaling run, on one GPU)")
+    ap.add_argument("--strong-reference", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: also run the GLOBAL grid on ONE GPU in the same job (when it fits) and print strong_speedup_vs_n1")
     ap.add_argument("--n1-reference", default="auto", choices=["auto", "on", "off"],
                     help="--gpus N > 1 started without a launcher: also run the per-GPU workload on one GPU first and report "
                          "parallel_efficiency_vs_n1 (auto: weak scaling only - a strong-scaling N = 1 run of 512^3 is its own job)")
@@ -171,6 +176,45 @@ def run_ranks(argv, n, extra_env=None, tag=""):
     return rc, line
 
 
+def strong_reference_run(args, n):
+    """The north_star's scaling claim is STRONG: the same global grid on 1 and on N GPUs.  A weak-scaling run (cells^3 per GPU)
+    has the global grid cells x boxes; when that fits one GPU (512^3 = 135 M rows: 40 GB of HBM, ~170 GB of host memory during
+    setup) it is also run through the single-GPU path in this job, in a fresh process of its own, BEFORE the N-GPU run.
+    Returns its JSON line or None."""
+    if n <= 1 or args.workload != "c2" or args.strong_reference == "off" or os.environ.get("MG_BENCH_SHARE_GPU") == "1":
+        return None
+    from multigrid_jl_amd.distributed import default_domains
+    cells = args.cells or 256
+    gcells = [cells] * 3 if args.scaling == "strong" else [cells * d for d in default_domains(n, 3)]
+    rows = 1
+    for c in gcells:
+        rows *= c + 1
+    if args.strong_reference != "on" and rows > 140_000_000:
+        return None
+    a1 = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-generic-pass",
+          "--workload", "c2", "--cells", str(cells), "--global-cells", ",".join(str(c) for c in gcells)]
+    rc1, sref = run_ranks(a1, 1, {"MG_BENCH_N1_REFERENCE": "1"}, " n1-global")
+    if rc1 != 0 or sref is None:
+        log("[launcher] the N = 1 run of the global grid failed (memory?); strong_speedup_vs_n1 stays null")
+        return None
+    return sref
+
+
+def attach_strong_reference(line, sref):
+    """strong_speedup_vs_n1 = time per step of the global grid on ONE GPU / time per step of the N-GPU run (same box, same job)."""
+    if sref is not None:
+        line["strong_n1_reference"] = {"value": float(sref["value"]), "ms_per_step": sref.get("ms_per_step"),
+                                       "workload": sref["config"]["workload"], "path": "single-GPU path, same box, same job"}
+        line["strong_speedup_vs_n1"] = round(float(sref["ms_per_step"]) / float(line["ms_per_step"]), 4)
+    else:
+        line["strong_speedup_vs_n1"] = None
+
+
+import datetime
+PG_TIMEOUT = datetime.timedelta(minutes=40)      # (rank 0 may run the N = 1 reference of the global grid before it joins)
+STRONG_REF = None      # (torchrun launch: rank 0 runs the global grid on one GPU before it touches its own)
+
+
 def launch(args):
     """`python bench.py --gpus N` with no launcher around it: be the launcher.  Parses, starts N ranks, relays rank 0's
     single JSON line (plus what only the launcher knows: the N = 1 reference of the same per-GPU workload and the
@@ -201,9 +245,11 @@ def launch(args):
         if rc1 != 0 or ref is None:
             log("[launcher] the N = 1 reference run failed; parallel_efficiency_vs_n1 stays null")
             ref = None
+    sref = strong_reference_run(args, n)
     rc, line = run_ranks(argv, n, extra)
     if rc != 0 or line is None:
         raise SystemExit(rc or 1)
+    attach_strong_reference(line, sref)
     line["launcher"] = {"ranks_started": n, "gpus_visible": have, "shared_gpu": bool(extra),
                         "how": "bench.py started the ranks itself (fresh processes, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set)"}
     if ref is not None:
@@ -238,6 +284,16 @@ def main():
         return launch(args)          # no torchrun around us: start the ranks ourselves (this process stays GPU-free)
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus and not args.force_sharded_path:
         raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={os.environ['WORLD_SIZE']}")
+    global STRONG_REF
+    if ("WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1 and int(os.environ.get("RANK", "0")) == 0
+            and os.environ.get("MG_BENCH_CHILD") != "1" and not args.force_sharded_path):
+        # started by torchrun (the driver's N > 1 launch): no launcher of ours ran the strong reference - rank 0 does, in a child
+        # process, before anything here touches a GPU; the other ranks wait in the rendezvous meanwhile
+        try:
+            STRONG_REF = strong_reference_run(args, int(os.environ["WORLD_SIZE"]))
+        except Exception as e:      # (never let the reference take the scaling run down)
+            log(f"[rank 0] strong reference run failed: {type(e).__name__}: {e}")
+            STRONG_REF = None
     import torch
     import multigrid_jl_amd as mg
 
@@ -257,14 +313,14 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=PG_TIMEOUT)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=PG_TIMEOUT)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=PG_TIMEOUT)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the multigrid cycle has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -272,7 +328,7 @@ def main():
 
     cells = args.cells or {"c1": 32, "c2": 256, "c3": 256, "c5": 256}[args.workload]
     nrhs = 16 if args.workload == "c5" else 1
-    levels = args.levels or levels_for(cells)
+    levels = args.levels or levels_for(min(int(c) for c in args.global_cells.split(",")) if args.global_cells else cells)
     K, W = args.steps, args.warmup
 
     if world > 1:
@@ -294,13 +350,15 @@ def main():
         desc = (f"SA-AMG (theta=0.4, V(1,1) SPAI w=1) on anisotropic diffusion {cells}^3 cells, edge weights 16:4:1 x "
                 f"log-normal sigma, general CSR")
     else:
-        A, mesh = mg.poisson_shifted([cells] * 3)
+        gc = [int(c) for c in args.global_cells.split(",")] if args.global_cells else [cells] * 3
+        A, mesh = mg.poisson_shifted(gc, [v for g in gc for v in (0.0, g / float(cells))] if args.global_cells else None)
         t_op = time.perf_counter() - t0
         p = mg.getMGparam(np.float64, np.int64, levels, os.cpu_count() or 8, K, 0.0, "Jac", 0.8, 2, 1, "V",
                           "NoMUMPS", 0.5, 0.0, "FullWeighting")
         t0 = time.perf_counter()
         mg.MGsetup(A, mesh, p, nrhs)
-        desc = f"3D 7-pt Poisson {cells}^3 cells, GMG V(2,1) damped-Jacobi w=0.8"
+        desc = (f"3D 7-pt Poisson {cells}^3 cells, GMG V(2,1) damped-Jacobi w=0.8" if not args.global_cells else
+                f"3D 7-pt Poisson {'x'.join(str(c) for c in gc)} cells (h = 1/{cells}), GMG V(2,1) damped-Jacobi w=0.8")
     t_setup = time.perf_counter() - t0
     b_host = mg.seeded_rhs(A, nrhs)
     if world > 1:
@@ -549,6 +607,53 @@ def main():
             gen.update(line)
             gen.update({"kernel": kg, "device_format": fg})
         roofline["generic_csr"] = gen
+
+    # ---- the workload jInv actually sends: nodal div sigma grad with a log-normal cell coefficient
+    # (testGMG.jl:57-75 / testSAforDivSigGrad.jl:96-100 idiom) on the same grid, same solver parameters, DEFAULT format
+    # selection - every row of A has its own values (band form on the fine level, CSR kernels on the Galerkin levels below),
+    # P and R keep their row classes.  Host setup as in the reference (MGsetup, Galerkin products). -------------------------
+    if args.workload == "c2" and nrhs == 1 and not args.no_divsiggrad and not args.no_generic_pass:
+        import scipy.sparse as sp
+        t0 = time.perf_counter()
+        mesh2 = mg.getRegularMesh([0.0, 1.0] * 3, [cells] * 3)
+        sigma = np.exp(np.random.default_rng(5).standard_normal(cells ** 3))
+        A2 = mg.getNodalDivSigGradMatrix(mesh2, sigma)
+        A2 = (A2 + 1e-3 * abs(A2).sum(axis=0).max() * sp.identity(A2.shape[0], format="csr")).tocsr()
+        A2.sort_indices()
+        p2 = mg.getMGparam(np.float64, np.int64, levels, os.cpu_count() or 8, K, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0,
+                           "FullWeighting")
+        mg.MGsetup(A2, mesh2, p2, 1)
+        t_set2 = time.perf_counter() - t0
+        h2 = mg.device.DeviceHierarchy(p2, device_id=local_rank, nrhs=1)
+        b2 = torch.from_numpy(np.ascontiguousarray(mg.seeded_rhs(A2, 1))).to(dev)
+        x2 = torch.zeros_like(b2)
+        h2.solve_dev(b2, x2, 0.0, max(1, W))
+        dts = []
+        for _ in range(3):
+            x2.zero_()
+            barrier()
+            t0 = time.perf_counter()
+            it2, res2 = h2.solve_dev(b2, x2, 0.0, K)
+            barrier()
+            dts.append(time.perf_counter() - t0)
+        dt2 = sorted(dts)[1]
+        prof2, moved2, tot2 = profiled_pass(h2, b2, x2, K, torch)
+        form2, _ = h2.sweep_residual_form(1)
+        kt2 = {}
+        for (l, k), v in sorted(prof2.items()):
+            if v[0] / tot2 > 0.02:
+                a_ = v[0] / v[1]
+                kt2[f"L{l}:{k}"] = {"avg_ms": round(a_, 5), "launches_per_step": round(v[1] / K, 2), "moved_MB": round(moved2[(l, k)] / 1e6, 2),
+                                    "frac": round(moved2[(l, k)] / a_ / 1e6 / HBM_PEAK_GBS, 4)}
+        roofline["divsiggrad"] = {
+            "workload": f"nodal div sigma grad, log-normal sigma (seed 5), {cells}^3 cells + 1e-3 * max column sum * I, GMG V(2,1) Jacobi w=0.8, {p2.levels} levels "
+                        "(Galerkin coarse operators), default format selection",
+            "ms_per_step": round(dt2 / K * 1e3, 4), "dof_updates_per_s": round(n * K / dt2, 1),
+            "relres_after_steps": float(res2[-1] / res2[0]), "fine_level_form": {4: "band form (two-stage pass, values streamed once)",
+                                                                                 0: "two launches (CSR kernels)"}.get(form2, str(form2)),
+            "host_setup_s": round(t_set2, 1), "kernels": kt2}
+        h2.close()
+        del x2, b2, A2, p2
 
     # ---- CPU baseline: the C/OpenMP oracle ("port") on a bounded sample of the same workload ----
     cpu = None
@@ -810,6 +915,8 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
                                  "traffic avoided, not a bandwidth"},
             "cpu_baseline": None,
         }
+        if os.environ.get("MG_BENCH_CHILD") != "1":
+            attach_strong_reference(out, STRONG_REF)
         emit(out)
     dist.barrier()
     dist.destroy_process_group()

@@ -260,6 +260,14 @@ int mg_sweep_residual_dev_FP64(mg_hierarchy* h, long long level, const double* b
  * iterate with one sweep of the pass's input.  Exposed for kernel tests. */
 int mg_four_stage_dev_FP64(mg_hierarchy* h, long long level, const double* b_dev, const double* x_dev, double* tp_dev,
                            double* rp_dev, double* norm_r);
+/* transposeHierarchy (MGsetup.jl:274-318) on the resident hierarchy: As[l] <- As[l]' (every level), Ps[l] <- Rs[l]' (Rs[l] keeps its
+ * values: the reference's second assignment reads the new Ps[l]), relaxPrecs unchanged, dense coarsest inverse transposed in place.
+ * The transposes are computed in HBM (counting sort + per-column order: the stored-order CSR of the transpose), the device formats
+ * rebuilt from them; mg_finalize is called.  MG_ERR_UNSUPPORTED, nothing changed, when the coarsest solve is held as sparse
+ * factors or a column has more than 4096 entries: hand the transposed operators over with mg_set_operator_* instead. */
+int mg_transpose_hierarchy(mg_hierarchy* h);
+/* shape[3] = rows, columns, stored entries of operator `which` of `level` as the device holds it (after a transpose: of the transposed one). */
+int mg_operator_shape(mg_hierarchy* h, long long level, long long which, long long* shape);
 /* *yes = 1 when level `level` has the four-stage form; geometry[12] as mg_sweep_residual_form's tile geometry. */
 int mg_four_stage_form(mg_hierarchy* h, long long level, long long* yes, long long* geometry);
 

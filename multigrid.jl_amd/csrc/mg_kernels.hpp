@@ -4189,4 +4189,54 @@ __global__ __launch_bounds__(64) void hybrid_kaczmarz(const int* __restrict__ ro
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// transposeHierarchy on the device (MGsetup.jl:274-318): CSR transpose of an operator in HBM - count the entries of every
+// column, scan (host: n + 1 integers), scatter every entry to its column's segment (atomic cursors: any order), then sort
+// each segment by row index (one lane per column, insertion sort: segments are as long as a row of the transposed operator) -
+// the result is the stored-order CSR of the transpose, bit for bit what a host transpose gives, whatever the scatter's order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void transpose_count(const int* __restrict__ col, long long nnz, int* __restrict__ cnt) {
+  const long long stride = (long long)gridDim.x * BLK;
+  for (long long k = (long long)blockIdx.x * BLK + threadIdx.x; k < nnz; k += stride) atomicAdd(cnt + col[k] + 1, 1);
+}
+__global__ __launch_bounds__(BLK) void transpose_fill(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                      const double* __restrict__ val, int n_rows, const int* __restrict__ tptr,
+                                                      int* __restrict__ cursor, int* __restrict__ tcol, double* __restrict__ tval) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n_rows) return;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    const int c = col[k];
+    const int pos = tptr[c] + atomicAdd(cursor + c, 1);
+    tcol[pos] = i;
+    tval[pos] = val[k];
+  }
+}
+__global__ __launch_bounds__(BLK) void transpose_sort(const int* __restrict__ tptr, int n_cols, int* __restrict__ tcol,
+                                                      double* __restrict__ tval) {
+  const int c = blockIdx.x * BLK + threadIdx.x;
+  if (c >= n_cols) return;
+  const int k0 = tptr[c], k1 = tptr[c + 1];
+  for (int k = k0 + 1; k < k1; ++k) {
+    const int r = tcol[k];
+    const double v = tval[k];
+    int j = k - 1;
+    while (j >= k0 && tcol[j] > r) {
+      tcol[j + 1] = tcol[j];
+      tval[j + 1] = tval[j];
+      --j;
+    }
+    tcol[j + 1] = r;
+    tval[j + 1] = v;
+  }
+}
+__global__ __launch_bounds__(BLK) void dense_transpose_inplace(double* __restrict__ a, int n) {
+  const long long idx = (long long)blockIdx.x * BLK + threadIdx.x;
+  const long long i = idx / n, j = idx - i * n;
+  if (i < n && j < i) {
+    const double t = a[i * n + j];
+    a[i * n + j] = a[j * n + i];
+    a[j * n + i] = t;
+  }
+}
+
 }  // namespace mgk

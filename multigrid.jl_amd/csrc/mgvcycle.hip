@@ -4700,6 +4700,92 @@ int mg_four_stage_dev_FP64(mg_hierarchy* h, long long level, const double* b, co
   prof_collect(h);
   return MG_OK;
 }
+// transposeHierarchy (MGsetup.jl:274-318) on the resident hierarchy: As[l] <- As[l]' on every level, Ps[l] <- Rs[l]' (the reference
+// assigns `Ps[l] = sparse(Rs[l]'); Rs[l] = sparse(Ps[l]')` - the second line reads the NEW Ps[l], so Rs[l] keeps its values),
+// relaxPrecs unchanged (conj of real numbers), the coarsest solve for the transposed operator.  The transposes are computed in
+// HBM (transpose_count / _fill / _sort: deterministic stored-order CSR); the device formats are then rebuilt by the upload path
+// from the transposed arrays (row classes, patterns, tile geometries are functions of the operator), mg_finalize included.
+// MG_ERR_UNSUPPORTED (nothing changed) for hierarchies whose coarsest solve is held as sparse factors - the caller re-uploads.
+namespace {
+int transpose_on_device(const Csr& M, std::vector<long long>* colptr1, std::vector<long long>* rowval1, std::vector<double>* nzval) {
+  const long long n = M.n_rows, m = M.n_cols, nnz = M.nnz;
+  DevBuf<int> cnt, cursor, tcol;
+  DevBuf<double> tval;
+  MG_TRY(cnt.alloc((size_t)m + 1));
+  MG_TRY(cursor.alloc((size_t)m));
+  MG_TRY(tcol.alloc((size_t)std::max<long long>(nnz, 1)));
+  MG_TRY(tval.alloc((size_t)std::max<long long>(nnz, 1)));
+  HIP_TRY(hipMemset(cnt.p, 0, cnt.bytes()));
+  HIP_TRY(hipMemset(cursor.p, 0, cursor.bytes()));
+  const unsigned gb = (unsigned)std::min<long long>(65535, std::max<long long>(1, (nnz + mgk::BLK - 1) / mgk::BLK));
+  hipLaunchKernelGGL(mgk::transpose_count, dim3(gb), dim3(mgk::BLK), 0, nullptr, M.colidx.p, nnz, cnt.p);
+  HIP_TRY(hipGetLastError());
+  std::vector<int> tp((size_t)m + 1);
+  HIP_TRY(hipMemcpy(tp.data(), cnt.p, tp.size() * sizeof(int), hipMemcpyDeviceToHost));
+  int longest = 0;
+  for (long long j = 0; j < m; ++j) {
+    longest = std::max(longest, tp[(size_t)j + 1]);
+    tp[(size_t)j + 1] += tp[(size_t)j];
+  }
+  if (longest > 4096) return fail(MG_ERR_UNSUPPORTED, "a column of %d entries: the per-column sort of the device transpose is quadratic", longest);
+  HIP_TRY(hipMemcpy(cnt.p, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(mgk::transpose_fill, dim3((unsigned)((n + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, nullptr, M.rowptr.p, M.colidx.p,
+                     M.val.p, (int)n, cnt.p, cursor.p, tcol.p, tval.p);
+  hipLaunchKernelGGL(mgk::transpose_sort, dim3((unsigned)((m + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, nullptr, cnt.p, (int)m, tcol.p, tval.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<int> tc((size_t)std::max<long long>(nnz, 1));
+  nzval->resize((size_t)std::max<long long>(nnz, 1));
+  HIP_TRY(hipMemcpy(tc.data(), tcol.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(nzval->data(), tval.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
+  colptr1->resize((size_t)m + 1);
+  rowval1->resize((size_t)std::max<long long>(nnz, 1));
+  for (long long j = 0; j <= m; ++j) (*colptr1)[(size_t)j] = (long long)tp[(size_t)j] + 1;
+  for (long long k = 0; k < nnz; ++k) (*rowval1)[(size_t)k] = (long long)tc[(size_t)k] + 1;
+  return MG_OK;
+}
+}  // namespace
+int mg_transpose_hierarchy(mg_hierarchy* h) {
+  UploadFence upload_fence;
+  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
+  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
+  if (h->coarse_lu) return fail(MG_ERR_UNSUPPORTED, "the coarsest solve is held as sparse factors: re-upload the transposed hierarchy");
+  (void)hipSetDevice(h->device);
+  graphs_clear(h);
+  HIP_TRY(spin_sync(h->stream));
+  const int nl = (int)h->nlevels;
+  std::vector<long long> cp, rv;
+  std::vector<double> nz;
+  for (int l = 0; l < nl; ++l) {
+    Level& L = h->lev[(size_t)l];
+    MG_TRY(transpose_on_device(L.A, &cp, &rv, &nz));
+    const long long nr = L.A.n_cols, nc = L.A.n_rows;
+    MG_TRY(upload_csr(&L.A, h->opt, nr, nc, cp.data(), rv.data(), nz.data()));
+    if (l + 1 < nl) {   // Ps[l] <- Rs[l]'
+      MG_TRY(transpose_on_device(L.R, &cp, &rv, &nz));
+      const long long pr = L.R.n_cols, pc = L.R.n_rows;
+      MG_TRY(upload_csr(&L.P, h->opt, pr, pc, cp.data(), rv.data(), nz.data()));
+    }
+  }
+  if (!h->coarse_gmres && h->Ainv.p) {   // (A')^-1 = (A^-1)'
+    const long long n = h->n_coarse;
+    hipLaunchKernelGGL(mgk::dense_transpose_inplace, dim3((unsigned)((n * n + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, nullptr, h->Ainv.p, (int)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  h->finalized = false;
+  return mg_finalize(h);
+}
+
+int mg_operator_shape(mg_hierarchy* h, long long level, long long which, long long* shape) {
+  if (!h || !shape) return fail(MG_ERR_INVALID, "null argument");
+  Csr* M = pick(h, level, which);
+  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
+  shape[0] = M->n_rows;
+  shape[1] = M->n_cols;
+  shape[2] = M->nnz;
+  return MG_OK;
+}
 int mg_four_stage_form(mg_hierarchy* h, long long level, long long* yes, long long* geometry) {
   if (!h || !yes || !geometry) return fail(MG_ERR_INVALID, "null argument");
   if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);

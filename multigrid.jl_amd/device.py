@@ -78,6 +78,8 @@ SIGNATURES = {
     "mg_sweep_residual_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
     "mg_four_stage_dev_FP64": (C.c_int, [_vp, _ll, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
     "mg_four_stage_form": (C.c_int, [_vp, _ll, _lp, _lp]),
+    "mg_transpose_hierarchy": (C.c_int, [_vp]),
+    "mg_operator_shape": (C.c_int, [_vp, _ll, _ll, _lp]),
     "mg_time_op_dev_FP64": (C.c_int, [_vp, _ll, _ll, _ll, _ll, _dp, _dp]),
     "mg_profile_enable": (C.c_int, [_vp, _ll]),
     "mg_profile_get": (C.c_int, [_vp, _ll, _ll, _dp, _lp, _dp]),
@@ -521,6 +523,20 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_four_stage_dev_FP64(self.handle, level, _ptr(b), _ptr(x), _ptr(tp), _ptr(rp),
                                                          C.byref(ss) if want_norm else None), "mg_four_stage_dev")
         return float(ss.value)
+
+    def get_values(self, level: int, which: int) -> np.ndarray:
+        """nzval of operator `which` of `level` as the device holds it (stored CSR order)."""
+        nnz = C.c_longlong(0)
+        info = (C.c_longlong * 3)()
+        _check(self.lib, self.lib.mg_operator_shape(self.handle, level, which, info), "mg_operator_shape")
+        vals = np.zeros(int(info[2]), dtype=np.float64)
+        _check(self.lib, self.lib.mg_get_values_FP64(self.handle, level, which, _f64(vals), vals.size), "mg_get_values")
+        return vals
+
+    def transpose_hierarchy(self):
+        """transposeHierarchy (MGsetup.jl:274-318) on the resident hierarchy; raises MGDeviceError (status MG_ERR_UNSUPPORTED)
+        when the library cannot (sparse coarsest factors): the caller then re-uploads."""
+        _check(self.lib, self.lib.mg_transpose_hierarchy(self.handle), "mg_transpose_hierarchy")
 
     def four_stage_form(self, level: int):
         """(available, geometry as sweep_residual_form's)."""

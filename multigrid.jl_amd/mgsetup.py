@@ -217,4 +217,12 @@ def transposeHierarchy(param: MGparam, verbose: bool = False) -> None:
         param.As[l] = _as_csr(param.As[l].T)
     destroyCoarsestLU(param)
     defineCoarsestAinv(param, param.As[-1])
-    _release_device(param)
+    # The resident hierarchy is transposed in HBM (mg_transpose_hierarchy: counting-sort CSR transposes, dense coarsest inverse
+    # transposed in place, device formats rebuilt) instead of being dropped and uploaded again; what the library cannot do there
+    # (sparse coarsest factors) falls back to the lazy re-upload.
+    if param.device is not None:
+        from .device import MGDeviceError
+        try:
+            param.device.transpose_hierarchy()
+        except MGDeviceError:
+            _release_device(param)

@@ -778,7 +778,7 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cells,k1,nt,tiles_x,lockstep", [([33, 25, 7], 2, 1024, 0, 0), ([33, 25, 7], 3, 768, 2, 1), ([40, 30, 9], 4, 768, 3, 0),
-                                                          ([23, 23, 23], 3, 1024, 1, 1), ([48, 40, 12], 4, 768, 0, 1), ([20, 20, 3], 2, 1024, 1, 1),
+                                                          ([23, 23, 23], 3, 1024, 1, 1), ([40, 32, 10], 4, 768, 0, 1), ([20, 20, 3], 2, 1024, 1, 1),
                                                           ([257, 9, 4], 3, 1024, 0, 1)])
 def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k1, nt, tiles_x, lockstep):
     """csr_rowclass_march3_spmv (sweep + residual in one pass on 2-D in-plane tiles; the z-1 / z+1 entries from registers):
@@ -867,7 +867,7 @@ def _setup_divsiggrad(mg, cells, levels, relaxType="Jac", omega=0.8, pre=2, post
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cells,k1,tiles_x,lockstep,relax", [([33, 25, 7], 2, 0, 0, "Jac"), ([40, 30, 9], 3, 2, 1, "Jac"), ([23, 23, 23], 2, 1, 1, "SPAI"),
-                                                             ([48, 40, 12], 3, 0, 1, "Jac"), ([130, 9, 5], 2, 0, 0, "Jac")])
+                                                             ([40, 32, 10], 3, 0, 1, "Jac"), ([130, 9, 5], 2, 0, 0, "Jac")])
 def test_band_form_variable_coefficients(mg, built, monkeypatch, cells, k1, tiles_x, lockstep, relax):
     """Grid operators whose coefficients differ from row to row (div sigma grad: what jInv feeds the package) have no row
     classes; round 2 ran them through the pattern-coded CSR kernels only.  Band form: structure classes as a verified product
@@ -1020,7 +1020,7 @@ def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels", [([64, 64, 20], 3), ([48, 40, 20], 2), ([33, 65, 12], 2)])
+@pytest.mark.parametrize("cells,levels", [([56, 56, 16], 3), ([48, 40, 20], 3), ([33, 65, 12], 3)])
 def test_plane_tiles_of_256_rows_for_small_levels(mg, built, monkeypatch, cells, levels):
     """csr_rowclass_tile_spmv<..., 256>: a level whose 1024-row tiles would be too few for the chip takes 256-row tiles
     (same kernel, a quarter of the threads per workgroup).  Forced here by the workgroup threshold; bit-identical to the
