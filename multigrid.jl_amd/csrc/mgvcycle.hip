@@ -29,6784 +29,12 @@
 #include "../../include/mgvcycle.h"
 #include "mg_kernels.hpp"
 
-namespace {
 
-thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...) {
-  char buf[1024];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  g_err = buf;
-  return code;
-}
-
-// Busy-poll instead of hipStreamSynchronize: one 8-byte readback per step sits on the critical path of the
-// solve loop, so the thread spins on hipStreamQuery rather than parking on an interrupt.
-static inline hipError_t spin_sync(hipStream_t s) {
-  hipError_t e;
-  while ((e = hipStreamQuery(s)) == hipErrorNotReady) {
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#endif
-  }
-  return e;
-}
-
-
-// Switches and thresholds of the format selection (A/B measurements, tests).  Read from the environment ONCE per
-// handle - at mg_create / mg_op_create - and kept in the handle; mg_set_option overrides single entries through the
-// API before the operators are uploaded.  Nothing on the launch path reads the environment.
-struct Options {
-  bool no_rowclass = false, no_implicit_first = false, no_class_d = false, no_tile = false, no_window = false;
-  bool no_pattern = false, no_runs = false, no_sched = false, no_pair = false, no_fused_next = false;
-  bool no_march = false, fuse_prolong = false, no_lane = false, no_lane_mm = false;
-  bool no_tile_small = false;
-  bool no_march2 = false, no_tile_lane = false, no_winp = false, no_band = false, no_lane_rpl3 = false, no_march2_zero = false, no_mgs_chain = false, no_restrict_scale = false;   // never fuse a sweep with the residual that follows it (csr_rowclass_march2_spmv)
-  long long rap_chunk = 2048;      // target columns of a coarse row the numeric Galerkin product accumulates at a time (<= 2048; tests)
-  bool no_dead_t = false;          // solve loop: store the iterate of every step (A/B, bit-identity tests)
-  bool no_march3 = false;          // never use the 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv)
-  long long march3_k1 = 0;         // rows of the stage-1 region per lane (0: by the fill estimate; 2..4): tile height = K1 * (NT / (TX + 2)) - 2
-  long long march3_nt = 0;         // threads per workgroup (0: by the fill estimate; 1024 or 768)
-  long long march3_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
-  bool no_march3_lockstep = false, march3_lockstep_force = false;   // schedule of the 2-D tile form
-  bool no_pipeline = false;        // solve loop: read a four-stage step's norm before the next step is enqueued (A/B)
-  bool no_march4 = false;          // solve loop: never run the two fine-level passes across the stopping test as one four-stage pass
-  long long march4_nt = 0;         // threads per workgroup of the four-stage pass (0: default; 1024 / 768 / 512 = 2 / 3 / 4 rows per lane)
-  long long march4_tiles_x = 0;    // 0: chosen by the fill estimate; > 0: this many tiles per grid line
-  long long march4_ty_max = 0;     // tests: tallest tile (several tile rows on small grids)
-  long long march4_k1 = 0;         // rows per lane (0: 2 / 3 / 4 at 1024 / 768 / 512 threads; 768 threads also take 4)
-  bool debug_format = false, debug_timing = false;
-  int nt = -1;   // -1: by operator size; 0 / 1: force the cache policy of the matrix stream
-  long long rowclass_min_rows = 100000, rowclass_max_passes = 4, rowclass_keep_singletons = 1024;
-  long long stage_min_len = 1, tile_min_wg = 256, window_min_wg = 2048, pair_min_rows = 1000000, march_min_wg = 256;
-  long long march_wg_per_cu = 2;   // resident workgroups per CU of the marching kernel (49 KB of LDS each)
-  long long winp_min_rows = 100000;   // smallest prolongation-shaped operator served by csr_rowclass_winp_spmv
-  long long band_min_rows = 100000;   // smallest variable-coefficient grid operator held in band form (build_band)
-  long long march_max_len = 8;   // longest class the marching kernel is used for (27-point levels: plane tiles, measured)
-  bool dist_tail_graph = false;   // replay the replicated tail of the sharded sequencer as a HIP graph (measured slower)
-  bool no_graph = false, no_lane_pairs = false;
-  long long graph_max_rows = 300000;    // sub-cycles from the first level of at most this many rows*nrhs replay as one HIP graph
-  long long lu_multi_min_rows = 4096;   // sparse coarse factors of this many rows: per-level launches + dense trailing inverse
-  long long lu_dense_tail_min = 64;
-  long long lu_dense_tail_max = 16384;  // largest trailing block kept as an explicit inverse (8*M^2 bytes each for L and U: 2 x 2.1 GB)
-  double rowclass_min_cover = 0.9, sched_budget = 2.0e6;
-  struct Entry { const char* env; const char* key; int kind; size_t off; };   // kind 0 bool, 1 long long, 2 double, 3 int
-  static const Entry* table(size_t* n);
-  bool set(const char* key, double v, bool by_env);
-  static Options from_env();
-};
-#define MG_OPT(env, key, kind, field) {env, key, kind, offsetof(Options, field)}
-const Options::Entry* Options::table(size_t* n) {
-  static const Entry t[] = {
-      MG_OPT("MG_NO_ROWCLASS", "no_rowclass", 0, no_rowclass), MG_OPT("MG_NO_IMPLICIT_FIRST", "no_implicit_first", 0, no_implicit_first),
-      MG_OPT("MG_NO_CLASS_D", "no_class_d", 0, no_class_d), MG_OPT("MG_NO_TILE", "no_tile", 0, no_tile),
-      MG_OPT("MG_NO_WINDOW", "no_window", 0, no_window), MG_OPT("MG_NO_PATTERN", "no_pattern", 0, no_pattern),
-      MG_OPT("MG_NO_RUNS", "no_runs", 0, no_runs), MG_OPT("MG_NO_SCHED", "no_sched", 0, no_sched),
-      MG_OPT("MG_NO_PAIR", "no_pair", 0, no_pair), MG_OPT("MG_NO_FUSED_NEXT", "no_fused_next", 0, no_fused_next),
-      MG_OPT("MG_NO_MARCH", "no_march", 0, no_march), MG_OPT("MG_NO_MARCH2", "no_march2", 0, no_march2), MG_OPT("MG_NO_TILE_LANE", "no_tile_lane", 0, no_tile_lane), MG_OPT("MG_NO_TILE_SMALL", "no_tile_small", 0, no_tile_small), MG_OPT("MG_NO_WINP", "no_winp", 0, no_winp), MG_OPT("MG_NO_BAND", "no_band", 0, no_band), MG_OPT("MG_NO_LANE_RPL3", "no_lane_rpl3", 0, no_lane_rpl3), MG_OPT("MG_NO_MARCH2_ZERO", "no_march2_zero", 0, no_march2_zero), MG_OPT("MG_NO_MGS_CHAIN", "no_mgs_chain", 0, no_mgs_chain), MG_OPT("MG_NO_RESTRICT_SCALE", "no_restrict_scale", 0, no_restrict_scale), MG_OPT("MG_FUSE_PROLONG", "fuse_prolong", 0, fuse_prolong), MG_OPT("MG_NO_LANE", "no_lane", 0, no_lane), MG_OPT("MG_NO_LANE_MM", "no_lane_mm", 0, no_lane_mm),
-      MG_OPT("MG_RAP_CHUNK", "rap_chunk", 1, rap_chunk), MG_OPT("MG_NO_DEAD_T", "no_dead_t", 0, no_dead_t), MG_OPT("MG_NO_MARCH3", "no_march3", 0, no_march3), MG_OPT("MG_MARCH3_K1", "march3_k1", 1, march3_k1), MG_OPT("MG_MARCH3_TILES_X", "march3_tiles_x", 1, march3_tiles_x), MG_OPT("MG_MARCH3_NT", "march3_nt", 1, march3_nt),
-      MG_OPT("MG_NO_PIPELINE", "no_pipeline", 0, no_pipeline), MG_OPT("MG_NO_MARCH4", "no_march4", 0, no_march4), MG_OPT("MG_MARCH4_NT", "march4_nt", 1, march4_nt), MG_OPT("MG_MARCH4_TILES_X", "march4_tiles_x", 1, march4_tiles_x), MG_OPT("MG_MARCH4_K1", "march4_k1", 1, march4_k1), MG_OPT("MG_MARCH4_TY_MAX", "march4_ty_max", 1, march4_ty_max),
-      MG_OPT("MG_NO_MARCH3_LOCKSTEP", "no_march3_lockstep", 0, no_march3_lockstep), MG_OPT("MG_MARCH3_LOCKSTEP_FORCE", "march3_lockstep_force", 0, march3_lockstep_force),
-      MG_OPT("MG_DEBUG_FORMAT", "debug_format", 0, debug_format), MG_OPT("MG_DEBUG_TIMING", "debug_timing", 0, debug_timing),
-      MG_OPT("MG_NT", "nt", 3, nt),
-      MG_OPT("MG_ROWCLASS_MIN_ROWS", "rowclass_min_rows", 1, rowclass_min_rows),
-      MG_OPT("MG_ROWCLASS_MAX_PASSES", "rowclass_max_passes", 1, rowclass_max_passes),
-      MG_OPT("MG_ROWCLASS_KEEP_SINGLETONS", "rowclass_keep_singletons", 1, rowclass_keep_singletons),
-      MG_OPT("MG_STAGE_MIN_LEN", "stage_min_len", 1, stage_min_len), MG_OPT("MG_TILE_MIN_WG", "tile_min_wg", 1, tile_min_wg),
-      MG_OPT("MG_WINDOW_MIN_WG", "window_min_wg", 1, window_min_wg), MG_OPT("MG_PAIR_MIN_ROWS", "pair_min_rows", 1, pair_min_rows),
-      MG_OPT("MG_MARCH_MIN_WG", "march_min_wg", 1, march_min_wg), MG_OPT("MG_MARCH_MAX_LEN", "march_max_len", 1, march_max_len),
-      MG_OPT("MG_MARCH_WG_PER_CU", "march_wg_per_cu", 1, march_wg_per_cu), MG_OPT("MG_WINP_MIN_ROWS", "winp_min_rows", 1, winp_min_rows), MG_OPT("MG_BAND_MIN_ROWS", "band_min_rows", 1, band_min_rows),
-      MG_OPT("MG_NO_GRAPH", "no_graph", 0, no_graph), MG_OPT("MG_DIST_TAIL_GRAPH", "dist_tail_graph", 0, dist_tail_graph), MG_OPT("MG_NO_LANE_PAIRS", "no_lane_pairs", 0, no_lane_pairs), MG_OPT("MG_GRAPH_MAX_ROWS", "graph_max_rows", 1, graph_max_rows),
-      MG_OPT("MG_LU_MULTI_MIN_ROWS", "lu_multi_min_rows", 1, lu_multi_min_rows),
-      MG_OPT("MG_LU_DENSE_TAIL_MAX", "lu_dense_tail_max", 1, lu_dense_tail_max),
-      MG_OPT("MG_LU_DENSE_TAIL_MIN", "lu_dense_tail_min", 1, lu_dense_tail_min),
-      MG_OPT("MG_ROWCLASS_MIN_COVER", "rowclass_min_cover", 2, rowclass_min_cover),
-      MG_OPT("MG_SCHED_BUDGET", "sched_budget", 2, sched_budget),
-  };
-  *n = sizeof t / sizeof t[0];
-  return t;
-}
-#undef MG_OPT
-bool Options::set(const char* key, double v, bool by_env) {
-  size_t n = 0;
-  const Entry* t = table(&n);
-  for (size_t i = 0; i < n; ++i) {
-    if (std::strcmp(by_env ? t[i].env : t[i].key, key) != 0) continue;
-    char* base = reinterpret_cast<char*>(this) + t[i].off;
-    switch (t[i].kind) {
-      case 0: *reinterpret_cast<bool*>(base) = (v != 0.0); break;
-      case 1: *reinterpret_cast<long long*>(base) = (long long)v; break;
-      case 2: *reinterpret_cast<double*>(base) = v; break;
-      default: *reinterpret_cast<int*>(base) = (int)v; break;
-    }
-    return true;
-  }
-  return false;
-}
-Options Options::from_env() {
-  Options o;
-  size_t n = 0;
-  const Entry* t = table(&n);
-  for (size_t i = 0; i < n; ++i)
-    if (const char* e = std::getenv(t[i].env)) {
-      // historical semantics of the boolean switches: "1" switches on, anything else off (MG_DEBUG_TIMING: any value)
-      if (t[i].kind == 0) o.set(t[i].env, (e[0] == '1' || std::strcmp(t[i].env, "MG_DEBUG_TIMING") == 0) ? 1.0 : 0.0, true);
-      else o.set(t[i].env, std::atof(e), true);
-    }
-  if (o.sched_budget < 1.0) o.sched_budget = 1.0;
-  return o;
-}
-
-#define HIP_TRY(expr)                                                                        \
-  do {                                                                                       \
-    hipError_t e_ = (expr);                                                                  \
-    if (e_ != hipSuccess)                                                                    \
-      return fail(MG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
-                  __LINE__);                                                                 \
-  } while (0)
-
-#define MG_TRY(expr)            \
-  do {                          \
-    int rc_ = (expr);           \
-    if (rc_ != MG_OK) return rc_; \
-  } while (0)
-
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  int alloc(size_t count) {
-    release();
-    if (count == 0) count = 1;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
-    n = count;
-    return MG_OK;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-  size_t bytes() const { return n * sizeof(T); }
-};
-
-struct Csr {
-  Options opt;   // copied from the owning handle at upload
-  bool set = false;
-  long long n_rows = 0, n_cols = 0, nnz = 0;
-  DevBuf<int> rowptr, colidx, blk_row, sched;
-  DevBuf<int> blk_row_mm, sched_mm;  // second, smaller row-block partition for the block-RHS kernels
-  std::vector<int> h_blk_row_mm;
-  bool has_sched_mm = false;
-  int nblocks_mm = 0;
-  DevBuf<double> val;
-  // pattern-coded column indices (csr_pattern_spmv): first column + pattern id per row, offset dictionary
-  DevBuf<int> firstcol, pat_ptr, pat_off, run_ptr, runs;
-  DevBuf<unsigned short> pat;
-  bool has_runs = false;
-  long long nruns_total = 0;
-  bool has_pat = false;
-  long long npat = 0, dict_entries = 0;
-  // row classes (csr_rowclass_spmv): first column + class id per row, dictionary of (offset, value) rows
-  DevBuf<int> rc_first, rc_ptr, rc_off, rc_delta, rw_meta, rw_lb, rt_lb, rc_exc;
-  int rc_nexc = 0;          // exception rows (class id 0xFFFF), computed by csr_rows_spmv from the CSR arrays
-  std::vector<int> h_rc_ptr, h_rc_off, h_rc_delta;   // host copy of the dictionary (tile index tables)
-  int rc_major = 0;         // most frequent class
-  bool rc_tile = false;     // csr_rowclass_tile_spmv (plane tiles from the grid hint)
-  bool rc_march = false;    // csr_rowclass_march_spmv (z-marching ring of slabs; preferred over the tiles when set)
-  DevBuf<int> rm_lb;
-  int rm_P = 0, rm_nplanes = 0, rm_halo = 0, rm_chunks = 0, rm_nblocks = 0;
-  bool rc_march2 = false;   // csr_rowclass_march2_spmv can serve a sweep + residual pair on this operator
-  int rm2_nblocks = 0;
-  bool rc_march3 = false;   // ... and so can csr_rowclass_march3_spmv (2-D in-plane tiles, z-star classes): preferred
-  DevBuf<int> rc_exc2;      // box operators on the 2-D tile form: rows whose stage 2 is left to csr_rows_spmv (the layer behind the faces)
-  int rc_nexc2 = 0;
-  DevBuf<mgk::M3Class> rm3_cls;
-  DevBuf<unsigned short> rm3_cmap;   // cx | cy | cz | tab: class id = tab[cz[z]][cy[y]][cx[x]]
-  mgk::March3Dev rm3{};     // tile geometry
-  size_t rm3_lds = 0;
-  int rm3_k1 = 3, rm3_nt = 1024;
-  double rm3_fill = 0.0;    // estimated L1 fills + stores per row (bytes) of the chosen geometry
-  // four-stage pass of the solve loop (csr_rowclass_march4_spmv): same classes and product map, its own tile geometry
-  bool rc_march4 = false;
-  DevBuf<mgk::M4Class> rm4_cls;
-  DevBuf<int> rm4_ysh;
-  mgk::March4Dev rm4{};
-  size_t rm4_lds = 0;
-  int rm4_k1 = 3, rm4_nt = 768;
-  double rm4_fill = 0.0;
-  // the same pass for a grid operator WITHOUT row classes (coefficients differ from row to row): structure classes + the
-  // values in 7 planar arrays (build_band)
-  bool rm3_var = false;
-  DevBuf<double> vband;
-  DevBuf<unsigned short> vb_cls;   // structure class of every row
-  DevBuf<int> vb_slot;             // [class][entry] -> planar slot
-  long long vstride = 0;
-  long long band_ncls = 0;
-  int rt_P = 0, rt_nplanes = 0, rt_halo = 0, rt_chunks = 0, rt_nblocks = 0;
-  bool rt_lane = false;     // plane tiles with the per-lane walk of a padded LDS dictionary
-  int rt_cr = mgk::RT_CR;   // rows of a plane per workgroup: 1024, or 256 on levels too small to fill the chip with 1024-row tiles
-  // csr_rowclass_winp_spmv (prolongation-shaped operators: the source windows of a workgroup's rows staged in LDS)
-  bool rp_ok = false;
-  DevBuf<unsigned short> rp_wf;
-  DevBuf<int> rp_cz0, rp_wlo, rp_code;
-  int rp_PF = 0, rp_nplanes = 0, rp_PC = 0, rp_W = 0, rp_chunks = 0;
-  mgk::WinPDev winpdev() const {
-    mgk::WinPDev t;
-    t.wf = rp_wf.p;
-    t.cz0 = rp_cz0.p;
-    t.wlo = rp_wlo.p;
-    t.code = rp_code.p;
-    t.PF = rp_PF;
-    t.nplanes = rp_nplanes;
-    t.PC = rp_PC;
-    t.W = rp_W;
-    t.chunks = rp_chunks;
-    t.nblocks = rp_chunks * rp_nplanes;
-    t.n_cols = (int)n_cols;
-    t.ncls = (int)rc_ncls;
-    t.nent = (int)rc_entries;
-    t.maxlen = rc_maxlen;
-    return t;
-  }
-  size_t winp_lds_bytes() const { return (size_t)2 * rp_W * 8 + (size_t)rc_ncls * (size_t)rc_maxlen * 16; }
-  int rw_doubles = 0;   // x entries a workgroup of csr_rowclass_window_spmv stages in LDS
-  DevBuf<unsigned short> rc_cls;
-  DevBuf<double> rc_val, rc_d;
-  bool has_rc = false;
-  bool rc_implicit = false;   // first column = row + rc_delta[class]: no per-row first-column stream
-  bool rc_has_d = false;      // the level's relaxPrec is constant per class: SMOOTH reads it from rc_d
-  bool rc_window = false;     // csr_rowclass_window_spmv: the most frequent class's windows fit in LDS
-  std::vector<unsigned short> h_cls;  // host class ids (to test vectors for class-constancy)
-  long long rc_ncls = 0, rc_entries = 0;
-  std::vector<int> h_rp, h_ci;  // host pattern, kept only while has_rc (to re-derive the classes for new values)
-  std::vector<int> h_blk_row;  // host copy of the row-block boundaries (for building schedules)
-  int max_row_nnz = 0;
-  bool has_sched = false;
-  int nblocks = 0;
-  bool nt = false;  // non-temporal loads of the matrix stream (mg_kernels.hpp load_stream)
-  mgk::CsrDev dev() const {
-    mgk::CsrDev d;
-    d.rowptr = rowptr.p;
-    d.colidx = colidx.p;
-    d.val = val.p;
-    d.blk_row = blk_row.p;
-    d.sched = has_sched ? sched.p : nullptr;
-    d.nblocks = nblocks;
-    d.n_rows = (int)n_rows;
-    d.n_cols = (int)n_cols;
-    return d;
-  }
-  mgk::CsrDev dev_mm() const {
-    mgk::CsrDev d = dev();
-    d.blk_row = blk_row_mm.p;
-    d.sched = has_sched_mm ? sched_mm.p : nullptr;
-    d.nblocks = nblocks_mm;
-    return d;
-  }
-  const double* d_bound = nullptr;   // the relaxPrec vector rc_d was derived from (mg_op_bind_relax_dev_FP64 / mg_finalize)
-  bool rc_pair = false;     // plain row-class kernel with two consecutive rows per lane (alternating classes)
-  // csr_rowclass_lane_spmv (every lane walks its own class, dictionary in LDS) replaces the waterfall kernel when the
-  // dictionary fits
-  bool rc_lane() const { return has_rc && !opt.no_lane && rc_ncls <= mgk::RL_NCLS && rc_entries <= mgk::RL_DCAP; }
-  // block right-hand sides: csr_rowclass_lane_spmm when every row is in a dictionary class
-  bool rc_lane_mm() const { return rc_lane() && !opt.no_lane_mm && rc_nexc == 0; }
-  DevBuf<int> t_ptr, t_perm;   // transposed pattern (column -> entries in ascending row order): SPAI relaxPrec on the device
-  bool has_t = false;
-  DevBuf<int> sched_ln;     // L2-tiled order of the lane SpMM's row blocks (built for the current nrhs)
-  bool has_sched_ln = false;
-  int ln_rows = 0, ln_blocks = 0;
-  int rc_blocks() const {
-    const long long rows = rc_lane() ? mgk::RL_ROWS : (rc_pair ? 2 * mgk::BLK : mgk::RC_ROWS);
-    return (int)((n_rows + rows - 1) / rows);
-  }
-  // workgroups of the nrhs == 1 product (one fused ||r||^2 partial each)
-  int rw_blocks() const { return (int)((n_rows + mgk::RW_ROWS - 1) / mgk::RW_ROWS); }
-  int exc_blocks() const { return rc_nexc > mgk::BLK ? (rc_nexc + mgk::BLK - 1) / mgk::BLK : 0; }   // short lists: in-kernel
-  int blocks1() const { return has_rc ? (rc_march ? rm_nblocks : rc_tile ? rt_nblocks : rc_window ? rw_blocks() : rc_blocks()) + exc_blocks() : nblocks; }
-  mgk::MarchDev marchdev() const {
-    mgk::MarchDev t;
-    t.lb = rm_lb.p;
-    t.P = rm_P;
-    t.nplanes = rm_nplanes;
-    t.halo = rm_halo;
-    t.chunks = rm_chunks;
-    t.nblocks = rm_nblocks;
-    t.n_cols = (int)n_cols;
-    t.ncls = (int)rc_ncls;
-    t.nent = (int)rc_entries;
-    t.maxlen = rc_maxlen;
-    return t;
-  }
-  int rc_maxlen = 0;        // longest class of the dictionary
-  // Local operator of a sharded level: columns >= regular_cols are halo columns (appended after the owned ones); rows
-  // that reference one are forced to be exception rows, the first regular_cols rows are the owned box in natural order
-  long long regular_cols = -1;
-  // rows >= regular_rows are empty halo rows (-1: the square box form, regular_rows == regular_cols; a prolongation over
-  // [owned coarse | halo] columns has all its rows regular)
-  long long regular_rows = -1;
-  long long reg_rows() const { return regular_cols < 0 ? n_rows : (regular_rows >= 0 ? regular_rows : std::min(regular_cols, n_rows)); }
-  mgk::TileDev tiledev() const {
-    mgk::TileDev t;
-    t.tile_lb = rt_lb.p;
-    t.P = rt_P;
-    t.nplanes = rt_nplanes;
-    t.halo = rt_halo;
-    t.chunks = rt_chunks;
-    t.nblocks = rt_nblocks;
-    t.n_cols = (int)n_cols;
-    t.lane = rt_lane ? 1 : 0;
-    t.ncls = (int)rc_ncls;
-    t.maxlen = rc_maxlen;
-    return t;
-  }
-  size_t tile_lds_bytes() const {
-    return (size_t)(mgk::RT_NP + 2) * (size_t)(rt_cr + 2 * rt_halo) * sizeof(double) +
-           (rt_lane ? (size_t)rc_ncls * (size_t)rc_maxlen * 16 + (size_t)rc_ncls * 8 : 0);
-  }
-  mgk::RowClassDev rcdev() const {
-    mgk::RowClassDev c;
-    c.firstcol = rc_implicit ? nullptr : rc_first.p;
-    c.cls_delta = rc_delta.p;
-    c.cls_d = rc_d.p;
-    c.exc_rows = rc_exc.p;
-    c.nexc_inline = (rc_nexc > 0 && rc_nexc <= mgk::BLK) ? rc_nexc : 0;
-    c.rowptr = rowptr.p;
-    c.colidx = colidx.p;
-    c.val = val.p;
-    c.cls = rc_cls.p;
-    c.cls_ptr = rc_ptr.p;
-    c.cls_off = rc_off.p;
-    c.cls_val = rc_val.p;
-    c.nblocks = rc_blocks();
-    // a box operator's rows beyond the owned box are empty halo rows: no kernel may touch them - the row operands (b, d, y)
-    // are only n_own long, and "a safe row" for idle lanes must be one of the owned rows
-    c.n_rows = (int)reg_rows();
-    return c;
-  }
-  void drop_rc() {
-    rc_first.release();
-    rc_ptr.release();
-    rc_off.release();
-    rc_cls.release();
-    rc_val.release();
-    rc_delta.release();
-    rw_meta.release();
-    rw_lb.release();
-    rt_lb.release();
-    rm_lb.release();
-    rc_exc.release();
-    rc_nexc = 0;
-    rc_tile = false;
-    rc_march = false;
-    rc_march2 = false;
-    rc_march3 = false;
-    rm3_var = false;
-    vband.release();
-    vb_cls.release();
-    vb_slot.release();
-    rm3_cls.release();
-    rm3_cmap.release();
-    rc_march4 = false;
-    rm4_cls.release();
-    rm4_ysh.release();
-    rc_exc2.release();
-    rc_nexc2 = 0;
-    rp_ok = false;
-    rp_wf.release();
-    h_rc_ptr.clear();
-    h_rc_off.clear();
-    h_rc_delta.clear();
-    rc_d.release();
-    h_cls.clear();
-    h_cls.shrink_to_fit();
-    has_rc = false;
-    rc_implicit = false;
-    rc_has_d = false;
-    rc_window = false;
-    rc_pair = false;
-    rc_ncls = rc_entries = 0;
-  }
-  mgk::PatDev patdev() const {
-    mgk::PatDev p;
-    p.firstcol = firstcol.p;
-    p.pat = pat.p;
-    p.pat_ptr = pat_ptr.p;
-    p.pat_off = pat_off.p;
-    p.dict_entries = (int)dict_entries;
-    p.npat = (int)npat;
-    p.run_ptr = has_runs ? run_ptr.p : nullptr;
-    p.runs = has_runs ? runs.p : nullptr;
-    return p;
-  }
-  void release() {
-    drop_rc();
-    h_rp.clear();
-    h_rp.shrink_to_fit();
-    h_ci.clear();
-    h_ci.shrink_to_fit();
-    run_ptr.release();
-    runs.release();
-    has_runs = false;
-    firstcol.release();
-    pat_ptr.release();
-    pat_off.release();
-    pat.release();
-    has_pat = false;
-    t_ptr.release();
-    t_perm.release();
-    has_t = false;
-    rowptr.release();
-    colidx.release();
-    blk_row.release();
-    sched.release();
-    has_sched = false;
-    blk_row_mm.release();
-    sched_mm.release();
-    has_sched_mm = false;
-    val.release();
-    set = false;
-  }
-  size_t bytes() const {
-    return blk_row_mm.bytes() + sched_mm.bytes() + rowptr.bytes() + colidx.bytes() + blk_row.bytes() + val.bytes() + sched.bytes() + firstcol.bytes() +
-           pat_ptr.bytes() + pat_off.bytes() + pat.bytes() + run_ptr.bytes() + runs.bytes();
-  }
-};
-
-struct Level {
-  long long grid[3] = {0, 0, 0};  // optional hint: the rows are an x-fastest n1 x n2 x n3 nodal grid
-  Csr A, P, R;  // P, R: transfer to/from the next coarser level (unset on the coarsest)
-  DevBuf<double> d;
-  bool relax_set = false;
-  long long npre = 1, npost = 1;
-  long long n = 0;
-  // CYCLEmem (MGdef.jl:56-60) plus the Jacobi ping-pong partner of x
-  DevBuf<double> b, r, x0, x1;
-  DevBuf<double> x2;   // fine level, solve loop: third rotating buffer of the fused last sweep + residual (allocated on first use)
-  DevBuf<double> x3;   // scratch for outputs of the fused sweep + residual nobody asked for (test entry point only)
-  // FGMRESmem (FGMRES.jl:3-8): Z and A*Z bases, `inner` contiguous vectors of n*nrhs each.
-  // relaxZ/relaxAZ: memRelax[level] (Jac-GMRES smoother); kZ/kAZ: memKcycle (K-cycle recursion INTO this level)
-  DevBuf<double> relaxZ, relaxAZ, kZ, kAZ;
-  long long relax_inner = 0;
-};
-
-struct ProfSlot {
-  double ms = 0.0;
-  long long launches = 0;
-  double bytes = 0.0;   // algorithmic (CSR-priced) bytes, SURVEY 8d: SUM over the launches (reported per launch = / launches)
-  double moved = 0.0;   // bytes the kernel IN USE has to move (device format + each vector once): SUM over the launches
-};
-
-}  // namespace
-
-struct mg_hierarchy {
-  Options opt;
-  int device = 0;
-  long long nlevels = 0;
-  long long nrhs = 1;
-  char cycle = 'V';
-  int relax_type = 0;  // 0: pointwise d (Jac / SPAI, MGcycle.jl:122-136); 1: Jac-GMRES (FGMRES.jl:48-126)
-  bool finalized = false;
-  std::vector<Level> lev;
-  DevBuf<double> Ainv;  // row-major n_c x n_c
-  long long n_coarse = 0;
-  bool coarse_set = false;
-  // sparse-factor form of the coarsest solve (parLU layout), used instead of Ainv when coarse_lu is true
-  bool coarse_lu = false;
-  DevBuf<int> luLptr, luLcol, luUptr, luUcol, luP, luQ, luLorder, luLlvl, luUorder, luUlvl;
-  DevBuf<double> luLval, luUval, luWork;
-  int nLlvl = 0, nUlvl = 0;
-  // chip-wide form (factors of >= lu_multi_min_rows rows): host copies of the level pointers for the per-level
-  // launches, and the explicit inverses of the dense trailing blocks (rows n-luML.. of L, n-luMU.. of U)
-  std::vector<int> luLlvl_h, luUlvl_h;
-  DevBuf<double> luInvL, luInvU, luTail;
-  DevBuf<int> luLslot, luUslot;   // per level slot {row, first, end of the off-diagonal entries, diagonal entry}
-  int luML = 0, luMU = 0;
-  bool lu_multi = false;
-  bool lu_only = false;     // a stand-alone factor applier (mg_lu_*): one "level" that consists of the coarsest solve only
-  // launch-bound coarse sub-cycles replay as HIP graphs (captured on first use; keyed by level, buffers and cycle)
-  struct GraphKey {
-    int level; bool x_zero; char ctype; const void* b; const void* xa; const void* xb; bool x1_given;
-    bool operator<(const GraphKey& o) const {
-      return std::tie(level, x_zero, ctype, b, xa, xb, x1_given) < std::tie(o.level, o.x_zero, o.ctype, o.b, o.xa, o.xb, o.x1_given);
-    }
-  };
-  struct GraphEntry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; double* result = nullptr; };
-  std::map<GraphKey, GraphEntry> graphs;
-  bool capturing = false;
-  long long graph_launches = 0;
-  hipStream_t stream = nullptr;
-  bool owns_stream = true;
-  // reductions
-  DevBuf<double> partial, partial2, scalar;
-  DevBuf<double> m3sink;       // csr_rowclass_march3_spmv: one slot per lane for the stores of lanes with nothing to store
-  double* h_scalar = nullptr;  // pinned: [0] the scalar of scalar_sync / dot_sync; [1], [2] the norms of the pipelined solve loop
-  hipEvent_t pipe_ev[2] = {nullptr, nullptr};   // ... and the events behind them
-  bool scalar_mirrored = false;   // the kernel that produced h->scalar also stored it into h_scalar (sum_final_mirror)
-  int nred_blocks = 1024;
-  // staging for the host-pointer API
-  DevBuf<double> stage_b, stage_x, stage_t;
-  // Krylov work vectors (allocated on the first mg_pcg call)
-  DevBuf<double> kr, kz, kp, kAp, kw;
-  DevBuf<double> blk_partial, blk_c;   // block Krylov: Gram partials, coefficient slots
-  double* h_blk = nullptr;             // pinned k x k readback
-  double* h_blk_c = nullptr;           // pinned ring of coefficient matrices
-  unsigned blk_c_next = 0;
-  DevBuf<double> kwc_blk;   // the same for a block of right-hand sides (blockFGMRES branch, MGcycle.jl:166)
-  DevBuf<double> kscal;     // FGMRES: the Hessenberg column of an inner step, on the device
-  double* h_kscal = nullptr;   // ... and its pinned readback (66 doubles)
-  DevBuf<double> kstepZ, kstepAZ, kstepX;   // mg_kcycle_step_async_dev_FP64: the K-step INTO this hierarchy's first level
-  DevBuf<double> kwc, coarse_d;   // coarseSolveType "GMRES": FGMRES work space and the Jacobi preconditioner of the coarsest level
-  bool coarse_gmres = false;
-  // fine-level operands of the last cycle/solve (used as inputs by mg_time_op_dev_FP64)
-  const double* last_b = nullptr;
-  double* last_x = nullptr;
-  // profiling
-  bool prof = false;
-  std::vector<ProfSlot> slots;  // [level][kernel]
-  struct Pending {
-    hipEvent_t a, b;
-    int level, kernel;
-    double bytes, moved;
-  };
-  std::vector<Pending> pending;
-  std::vector<hipEvent_t> ev_pool;
-};
-
-namespace {
-
-// ---------------------------------------------------------------------------------------------
-// algorithmic bytes: int32 indices + fp64 values, each vector element once
-// ---------------------------------------------------------------------------------------------
-double spmv_bytes(const Csr& M, long long nrhs, bool reads_y_or_b, bool smooth) {
-  double bts = 12.0 * (double)M.nnz + 4.0 * (double)(M.n_rows + 1);
-  bts += 8.0 * (double)nrhs * (double)(M.n_cols + M.n_rows);  // x read, y written
-  if (reads_y_or_b) bts += 8.0 * (double)nrhs * (double)M.n_rows;
-  if (smooth) bts += 8.0 * (double)M.n_rows;  // d; the x[row] term is the already-counted x read
-  return bts;
-}
-
-// Matrix-side bytes one launch of the kernel IN USE streams for M (the device format chosen at upload).
-double format_bytes(const Csr& M, long long nrhs) {
-  if (M.has_rc && nrhs == 1 && M.rp_ok)   // LDS-staged prolongation: class id + 16-bit window index per row
-    return 4.0 * (double)M.n_rows + 12.0 * (double)M.rc_entries;
-  if (M.has_rc && (nrhs == 1 || (M.rc_lane_mm() && M.ln_blocks > 0)))   // (block right-hand sides: the lane SpMM)
-    return (M.rc_implicit ? 2.0 : 6.0) * (double)M.n_rows + 12.0 * (double)M.rc_entries;
-  if (nrhs == 1 && M.has_pat)
-    return 8.0 * (double)M.nnz + 4.0 * (double)M.dict_entries +
-           (M.has_runs ? 20.0 * (double)M.nruns_total + 8.0 * (double)M.nblocks : 10.0 * (double)M.n_rows);
-  return 12.0 * (double)M.nnz + 4.0 * (double)(M.n_rows + 1);
-}
-// Compulsory bytes of one launch in that format: the matrix side above + every vector element once
-// (class_d: the relaxPrec comes from the class dictionary instead of an 8 B/row stream).
-double moved_bytes(const Csr& M, long long nrhs, bool reads_y_or_b, bool smooth, bool class_d = false) {
-  double bts = format_bytes(M, nrhs) + 8.0 * (double)nrhs * (double)(M.n_cols + M.n_rows);
-  if (reads_y_or_b) bts += 8.0 * (double)nrhs * (double)M.n_rows;
-  if (smooth && !class_d) bts += 8.0 * (double)M.n_rows;
-  return bts;
-}
-
-int grid_for(long long total) {
-  long long g = (total + mgk::BLK - 1) / mgk::BLK;
-  return (int)std::max<long long>(1, std::min<long long>(g, 2048));
-}
-
-// ---- profiling helpers --------------------------------------------------------------------------
-hipEvent_t get_event(mg_hierarchy* h) {
-  if (!h->ev_pool.empty()) {
-    hipEvent_t e = h->ev_pool.back();
-    h->ev_pool.pop_back();
-    return e;
-  }
-  hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
-  return e;
-}
-
-// h->scalar = sum of np partials, also stored straight into the pinned h_scalar (scalar_sync then needs no copy)
-void launch_sum_final(mg_hierarchy* h, const double* partial, int np) {
-  hipLaunchKernelGGL(mgk::sum_final_mirror, dim3(1), dim3(mgk::BLK), 0, h->stream, partial, np, h->scalar.p, h->h_scalar);
-  h->scalar_mirrored = !h->capturing;
-}
-struct ProfScope {
-  mg_hierarchy* h;
-  bool on;
-  mg_hierarchy::Pending p;
-  ProfScope(mg_hierarchy* h_, int level, int kernel, double bytes, double moved = -1.0) : h(h_), on(h_->prof) {
-    if (!on) return;
-    p.a = get_event(h);
-    p.b = get_event(h);
-    p.level = level;
-    p.kernel = kernel;
-    p.bytes = bytes;
-    p.moved = moved < 0.0 ? bytes : moved;
-    (void)hipEventRecord(p.a, h->stream);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(p.b, h->stream);
-    h->pending.push_back(p);
-  }
-};
-
-void prof_collect(mg_hierarchy* h) {
-  for (auto& p : h->pending) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-      ProfSlot& s = h->slots[(size_t)p.level * MG_K_COUNT + p.kernel];
-      s.ms += ms;
-      s.launches += 1;
-      s.bytes += p.bytes;   // (launches of one slot may differ: the fused sweep + residual writes r, x + d.*r or neither)
-      s.moved += p.moved;
-    }
-    h->ev_pool.push_back(p.a);
-    h->ev_pool.push_back(p.b);
-  }
-  h->pending.clear();
-}
-
-// ---- kernel launchers ---------------------------------------------------------------------------
-int pow2_ge(long long v) {
-  int g = 1;
-  while (g < v && g < 64) g <<= 1;
-  return g;
-}
-
-// csr_rowclass_march3_spmv: 16-byte pairs of a slab per lane
-constexpr int RM3_NPM = 2;
-// dynamic LDS of csr_rowclass_march2_spmv: 4 x slabs + 4 t slabs + dictionary
-size_t march2_lds_bytes(int halo) {
-  const size_t slx = (size_t)(mgk::RM_C + 4 * halo + 2), slt = (size_t)(mgk::RM_C + 2 * halo);
-  return (4 * slx + 4 * slt) * sizeof(double) + 16 * (size_t)mgk::RM_DCAP + 8 * (size_t)mgk::RM_NCLS + 4 * (size_t)(mgk::RM_NCLS + 4);
-}
-
-// can the z-marching kernel serve this launch?  (staged variants read x workgroup-wide: never in place; its staging
-// loads are 16 bytes wide: x must be 16-byte aligned, which every allocation base is)
-bool march_ok(const Csr& M, const mgk::VecArgs& v) {
-  return v.nrhs == 1 && M.has_rc && M.rc_march && v.y != v.x && v.y2 != v.x && (v.xs == nullptr || v.xs == v.x) &&
-         (reinterpret_cast<uintptr_t>(v.x) & 15) == 0;
-}
-
-// nparts (optional): number of per-workgroup ||out||^2 partials the launch writes to v.sumsq.
-// pro (optional, SMOOTH on a marching operator only): stage x + Pm*xc instead of x (the fused coarse-grid correction).
-// phase: 0 = the whole product; 1 = every row that is in a dictionary class; 2 = the exception rows only (the sharded
-// cycle computes the rows that read the halo - forced exception rows - after the exchange has landed).  Operators that
-// are not stored as row classes compute everything in phase 2.
-// Lane SpMM: lanes per row.  Even nrhs: two columns (16 bytes) per lane, G = pow2 >= nrhs/2 lanes per row.
-static inline bool lane_mm_pairs(const Csr& M, long long nrhs) { return nrhs % 2 == 0 && !M.opt.no_lane_pairs; }
-static inline int lane_mm_group(const Csr& M, long long nrhs) { return lane_mm_pairs(M, nrhs) ? pow2_ge(nrhs / 2) : pow2_ge(nrhs); }
-// rows per lane of the row-class SpMM: 3 for a square operator in the paired-column form (A: sweeps, residuals), else 2
-static inline int lane_mm_rpl(const Csr& M, long long nrhs) { return (lane_mm_pairs(M, nrhs) && M.n_rows == M.n_cols && !M.opt.no_lane_rpl3) ? 3 : 2; }
-static inline bool aligned16(const mgk::VecArgs& v) {
-  auto ok = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-  return ok(v.x) && ok(v.y) && ok(v.b) && ok(v.xs);
-}
-template <int MODE>
-int launch_csr(hipStream_t stream, const Csr& M, const mgk::VecArgs& v, int* nparts = nullptr,
-               const mgk::ProDev* pro = nullptr, int phase = 0) {
-  if (nparts) *nparts = M.nblocks;
-  if (M.nblocks <= 0) return MG_OK;
-  const dim3 grid(M.nblocks), blk(mgk::BLK);
-  if (pro && !march_ok(M, v)) return fail(MG_ERR_STATE, "fused prolongation needs the marching kernel");
-  if (phase != 0 && !(v.nrhs == 1 && M.has_rc)) {
-    if (phase == 1) {   // nothing is launched: no partial is written either (phase 2 computes the whole product)
-      if (nparts) *nparts = 0;
-      return MG_OK;
-    }
-    phase = 0;
-  }
-  if (phase == 2) {   // (v.sumsq, if set, points at the first free partial: the caller advanced it past phase 1's)
-    if (nparts) *nparts = 0;
-    if (M.rc_nexc > 0) {
-      mgk::VecArgs ve = v;
-      ve.d = v.d_full;
-      const int nbx = (M.rc_nexc + mgk::BLK - 1) / mgk::BLK;
-      hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3(nbx), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, 0);
-      HIP_TRY(hipGetLastError());
-      if (nparts) *nparts = nbx;
-    }
-    return MG_OK;
-  }
-  if (v.nrhs == 1 && M.has_rc) {
-    int nb_main;
-    mgk::RowClassDev C = M.rcdev();
-    if (phase == 1) C.nexc_inline = 0;    // the exception rows get their own launch (phase 2)
-    const bool exc = C.nexc_inline > 0;   // a short list of exception rows rides in the last workgroup
-    if (march_ok(M, v)) {
-      const mgk::MarchDev T = M.marchdev();
-      const int SL = mgk::RM_C + 2 * M.rm_halo;
-      const size_t lds = (size_t)mgk::RM_RING * (size_t)((SL + 3) & ~1) * sizeof(double) + mgk::RM_DICT_BYTES;
-      nb_main = M.rm_nblocks;
-      static bool lds_attr_set[3] = {false, false, false};
-      if (!lds_attr_set[MODE]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march_spmv<MODE, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march_spmv<MODE, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (MODE == mgk::SMOOTH) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march_spmv<mgk::SMOOTH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march_spmv<mgk::SMOOTH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        }
-        (void)hipGetLastError();
-        lds_attr_set[MODE] = true;
-      }
-      mgk::ProDev Q{};
-      if (pro) Q = *pro;
-      if (MODE == mgk::SMOOTH && pro) {
-        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<mgk::SMOOTH, true, true>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
-        else hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<mgk::SMOOTH, false, true>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
-      } else {
-        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<MODE, true, false>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
-        else hipLaunchKernelGGL((mgk::csr_rowclass_march_spmv<MODE, false, false>), dim3(nb_main), dim3(mgk::RM_C), lds, stream, C, v, T, Q);
-      }
-    } else if (M.rc_tile && v.y != v.x) {   // (the staged variants read x workgroup-wide: never in place)
-      const size_t lds = M.tile_lds_bytes();
-      nb_main = M.rt_nblocks;
-      static bool lds_attr_set[3] = {false, false, false};   // up to 80 KiB of dynamic LDS: lift the 64 KiB default once
-      if (!lds_attr_set[MODE]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE, false, mgk::RT_CR>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_tile_spmv<MODE, true, mgk::RT_CR>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipGetLastError();
-        lds_attr_set[MODE] = true;
-      }
-      if (M.rt_cr == 256) {
-        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, true, 256>), dim3(nb_main), dim3(256), lds, stream, C, v, M.tiledev());
-        else hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, false, 256>), dim3(nb_main), dim3(256), lds, stream, C, v, M.tiledev());
-      } else {
-        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, true, mgk::RT_CR>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, C, v, M.tiledev());
-        else hipLaunchKernelGGL((mgk::csr_rowclass_tile_spmv<MODE, false, mgk::RT_CR>), dim3(nb_main), dim3(mgk::RT_CR), lds, stream, C, v, M.tiledev());
-      }
-    } else if (M.rc_window && v.y != v.x) {
-      nb_main = M.rw_blocks();
-      const size_t lds = (size_t)M.rw_doubles * sizeof(double);
-      if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, true>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
-      else hipLaunchKernelGGL((mgk::csr_rowclass_window_spmv<MODE, false>), dim3(nb_main), blk, lds, stream, C, v, M.rw_meta.p, M.rw_lb.p, nb_main, (int)M.n_cols);
-    } else if (MODE == mgk::AXPBY && M.rp_ok && v.y != v.x) {
-      // a prolongation-shaped operator: the coarse windows of a workgroup's rows staged in LDS; exception rows (a sharded
-      // level's rows that read halo columns) from the CSR arrays - behind it here, or as phase 2 behind the exchange
-      const mgk::WinPDev T = M.winpdev();
-      nb_main = T.nblocks;
-      hipLaunchKernelGGL((mgk::csr_rowclass_winp_spmv<0>), dim3(nb_main), dim3(mgk::WP_T), M.winp_lds_bytes(), stream, C, v, T);
-      if (M.rc_nexc > 0 && phase == 0) {
-        mgk::VecArgs ve = v;
-        ve.d = v.d_full;
-        hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3((M.rc_nexc + mgk::BLK - 1) / mgk::BLK), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, 0);
-      }
-      if (nparts) *nparts = 0;
-      HIP_TRY(hipGetLastError());
-      return MG_OK;
-    } else if (M.rc_lane()) {
-      nb_main = M.rc_blocks();
-      mgk::LaneDev T;
-      T.ncls = (int)M.rc_ncls;
-      T.nent = (int)M.rc_entries;
-      T.maxlen = M.rc_maxlen;
-      T.nblocks = nb_main;
-      // adjacent rows per lane (16-byte operand accesses) for operators whose classes alternate row by row (a
-      // prolongation; measured on C2: P 115 -> 105 us, but R 59 -> 82 us), where the vectors are 16-byte aligned
-      const bool pair = M.rc_pair && ((reinterpret_cast<uintptr_t>(v.y) | reinterpret_cast<uintptr_t>(v.b) |
-                                       reinterpret_cast<uintptr_t>(v.d) | reinterpret_cast<uintptr_t>(v.xs)) & 15) == 0;
-      if (pair) {
-        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmv<MODE, true, true>), dim3(nb_main), blk, 0, stream, C, v, T);
-        else hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmv<MODE, false, true>), dim3(nb_main), blk, 0, stream, C, v, T);
-      } else {
-        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmv<MODE, true, false>), dim3(nb_main), blk, 0, stream, C, v, T);
-        else hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmv<MODE, false, false>), dim3(nb_main), blk, 0, stream, C, v, T);
-      }
-    } else {
-      nb_main = M.rc_blocks();
-      if (M.rc_pair) {
-        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, true, true>), dim3(nb_main), blk, 0, stream, C, v);
-        else hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, false, true>), dim3(nb_main), blk, 0, stream, C, v);
-      } else {
-        if (exc) hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, true, false>), dim3(nb_main), blk, 0, stream, C, v);
-        else hipLaunchKernelGGL((mgk::csr_rowclass_spmv<MODE, false, false>), dim3(nb_main), blk, 0, stream, C, v);
-      }
-    }
-    if (M.rc_nexc > mgk::BLK && phase == 0) {   // rows of rare classes, from the CSR arrays; their ||r||^2 partials follow the others
-      mgk::VecArgs ve = v;
-      ve.d = v.d_full;
-      hipLaunchKernelGGL((mgk::csr_rows_spmv<MODE>), dim3(M.exc_blocks()), blk, 0, stream, M.dev(), M.rc_exc.p, M.rc_nexc, ve, nb_main);
-    }
-    if (nparts) *nparts = nb_main + (phase == 0 ? M.exc_blocks() : 0);
-  } else if (v.nrhs == 1 && M.has_pat) {
-    const bool dl = M.dict_entries <= mgk::DICT_LDS && M.npat < mgk::DICT_LDS;
-    if (M.nt && dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
-    else if (M.nt) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, true, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
-    else if (dl) hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, false, true>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
-    else hipLaunchKernelGGL((mgk::csr_pattern_spmv<MODE, false, false>), grid, blk, 0, stream, M.dev(), M.patdev(), v);
-  } else if (v.nrhs == 1) {
-    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, true>), grid, blk, 0, stream, M.dev(), v);
-    else hipLaunchKernelGGL((mgk::csr_stream_spmv<MODE, false>), grid, blk, 0, stream, M.dev(), v);
-  } else if (M.rc_lane_mm() && M.ln_blocks > 0 && M.ln_rows == lane_mm_rpl(M, v.nrhs) * (mgk::BLK / lane_mm_group(M, v.nrhs)) &&
-             (!lane_mm_pairs(M, v.nrhs) || aligned16(v))) {
-    mgk::LaneDev T;
-    T.ncls = (int)M.rc_ncls;
-    T.nent = (int)M.rc_entries;
-    T.maxlen = M.rc_maxlen;
-    T.nblocks = M.ln_blocks;
-    const int G = lane_mm_group(M, v.nrhs);
-    const int* sched = M.has_sched_ln ? M.sched_ln.p : nullptr;
-    if (nparts) *nparts = lane_mm_pairs(M, v.nrhs) ? M.ln_blocks : 0;   // (only the paired form writes ||out||^2 partials)
-    if (lane_mm_pairs(M, v.nrhs))   // two columns (16 bytes) per lane
-      if (lane_mm_rpl(M, v.nrhs) == 3) hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm2<MODE, 3>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
-      else hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm2<MODE, 2>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
-    else
-      hipLaunchKernelGGL((mgk::csr_rowclass_lane_spmm<MODE>), dim3(M.ln_blocks), blk, 0, stream, M.rcdev(), v, T, G, sched);
-  } else {
-    const int G = pow2_ge(v.nrhs);
-    const dim3 grid_mm(M.nblocks_mm);
-    if (M.nt) hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, true>), grid_mm, blk, 0, stream, M.dev_mm(), v, G);
-    else hipLaunchKernelGGL((mgk::csr_stream_spmm<MODE, false>), grid_mm, blk, 0, stream, M.dev_mm(), v, G);
-  }
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-
-// y = alpha*M*x + beta*y
-// d2 / y2 (optional, both or none; only where restrict_can_scale(M)): also y2 = d2 .* y
-int k_spmv(mg_hierarchy* h, int level, int kind, const Csr& M, double alpha, const double* x,
-           double beta, double* y, const double* d2 = nullptr, double* y2 = nullptr) {
-  mgk::VecArgs v{};
-  v.x = x;
-  v.y = y;
-  v.alpha = alpha;
-  v.beta = beta;
-  v.nrhs = (int)h->nrhs;
-  v.d_full = d2;
-  v.y2 = y2;
-  const double extra = y2 ? 16.0 * (double)M.n_rows : 0.0;
-  ProfScope ps(h, level, kind, spmv_bytes(M, h->nrhs, beta != 0.0, false) + extra, moved_bytes(M, h->nrhs, beta != 0.0, false) + extra);
-  return launch_csr<mgk::AXPBY>(h->stream, M, v);
-}
-// Is the product with M served, for one right-hand side, by a kernel that can write d.*out too (csr_rowclass_lane_spmv, or the
-// streaming kernels csr_pattern_spmv / csr_stream_spmv for operators without row classes)?
-bool restrict_can_scale(const mg_hierarchy* h, const Csr& M) {
-  if (h->nrhs != 1 || h->opt.no_restrict_scale) return false;
-  if (!M.has_rc) return M.max_row_nnz <= mgk::CHUNK - 2;   // the streaming kernels (pattern-coded or plain CSR), short rows: epilogue output
-  return M.rc_nexc == 0 && !M.rc_march && !M.rc_tile && !M.rc_window && !M.rp_ok && M.rc_lane();
-}
-// out = b - A*x
-int k_residual(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x,
-               double* out) {
-  mgk::VecArgs v{};
-  v.x = x;
-  v.y = out;
-  v.b = b;
-  v.nrhs = (int)h->nrhs;
-  ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, h->nrhs, true, false), moved_bytes(A, h->nrhs, true, false));
-  return launch_csr<mgk::RESID>(h->stream, A, v);
-}
-int k_sumsq(mg_hierarchy* h, const double* x, long long len);
-// out = b - A*x and h->scalar = ||out||^2 in the same pass (nrhs == 1); falls back to two kernels for blocks
-// xnext (optional): also write x + d.*(b - A x), the first damped-Jacobi update of the next cycle, when the kernel
-// that serves A can do it (plane-tile row-class kernel, level's own relaxPrec); *xnext_done reports whether it was.
-// r_dead: the caller will not read `out` when xnext was written (the solve loop: the next cycle starts from xnext and
-// recomputes its own residual), so the store of r is skipped as well.
-int k_residual_sumsq(mg_hierarchy* h, int level, const Csr& A, const double* b, const double* x, double* out,
-                     double* xnext = nullptr, bool* xnext_done = nullptr, bool r_dead = false) {
-  if (xnext_done) *xnext_done = false;
-  mgk::VecArgs v{};
-  v.x = x;
-  v.y = out;
-  v.b = b;
-  v.nrhs = (int)h->nrhs;
-  if (h->nrhs != 1) {
-    // block right-hand sides: the paired-column lane SpMM writes ||r||^2 partials and, optionally, x + d.*r
-    const bool fused = A.rc_lane_mm() && A.ln_blocks > 0 && lane_mm_pairs(A, h->nrhs) &&
-                       A.ln_rows == lane_mm_rpl(A, h->nrhs) * (mgk::BLK / lane_mm_group(A, h->nrhs)) && (size_t)A.ln_blocks <= h->partial.n;
-    mgk::VecArgs t = v;
-    t.xs = x;
-    if (xnext) t.y2 = xnext;
-    if (!fused || !aligned16(t) || (xnext && (reinterpret_cast<uintptr_t>(xnext) & 15u))) {
-      MG_TRY(k_residual(h, level, A, b, x, out));
-      return k_sumsq(h, out, A.n_rows * h->nrhs);
-    }
-    v.sumsq = h->partial.p;
-    if (xnext && out != x && xnext != x && h->relax_type == 0 && &A == &h->lev[(size_t)level].A && !h->opt.no_fused_next) {
-      v.y2 = xnext;
-      if (r_dead) v.y = nullptr;
-      v.xs = x;
-      v.d = v.d_full = h->lev[(size_t)level].d.p;
-      if (xnext_done) *xnext_done = true;
-    }
-    int nb1 = 0;
-    {
-      const double vec = 8.0 * (double)A.n_rows * (double)h->nrhs;
-      ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, h->nrhs, true, false) + ((v.y2 && v.y) ? vec : 0.0),
-                   moved_bytes(A, h->nrhs, true, false) - (v.y ? 0.0 : vec) + (v.y2 ? vec : 0.0));
-      MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v, &nb1));
-    }
-    ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-    const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
-    hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
-    launch_sum_final(h, h->partial2.p, nb2);
-    HIP_TRY(hipGetLastError());
-    return MG_OK;
-  }
-  if ((size_t)std::max(A.blocks1(), A.nblocks) > h->partial.n) {
-    MG_TRY(k_residual(h, level, A, b, x, out));
-    return k_sumsq(h, out, A.n_rows * h->nrhs);
-  }
-  v.sumsq = h->partial.p;
-  // the LDS-staged row-class kernels (march, tile) have x, r and the class's relaxPrec at hand: second output
-  if (xnext && A.has_rc && (A.rc_tile || march_ok(A, v)) && A.rc_nexc == 0 && out != x && xnext != x && h->relax_type == 0 &&
-      &A == &h->lev[(size_t)level].A && !h->opt.no_fused_next) {
-    v.y2 = xnext;
-    if (r_dead) v.y = nullptr;
-    v.xs = x;
-    v.d = A.rc_has_d ? nullptr : h->lev[(size_t)level].d.p;
-    v.d_full = h->lev[(size_t)level].d.p;
-    if (xnext_done) *xnext_done = true;
-  }
-  int nb1 = 0;
-  {
-    ProfScope ps(h, level, MG_K_RESIDUAL, spmv_bytes(A, 1, true, false) + ((v.y2 && v.y) ? 8.0 * (double)A.n_rows : 0.0),
-                 moved_bytes(A, 1, true, false) - (v.y ? 0.0 : 8.0 * (double)A.n_rows) + (v.y2 ? 8.0 * (double)A.n_rows : 0.0));
-    MG_TRY(launch_csr<mgk::RESID>(h->stream, A, v, &nb1));
-  }
-  ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-  const int nb2 = std::min(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
-  hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, (long long)nb1, h->partial2.p);
-  launch_sum_final(h, h->partial2.p, nb2);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-int scalar_sync(mg_hierarchy* h, double* out);
-int scalar_wait(mg_hierarchy* h);
-
-// out = x + d.*(b - A*x)
-int k_smooth(mg_hierarchy* h, int level, const Csr& A, const double* d, const double* b,
-             const double* x, double* out) {
-  mgk::VecArgs v{};
-  v.x = x;
-  v.xs = x;
-  v.y = out;
-  v.b = b;
-  v.d = d;
-  v.d_full = d;
-  // the level's own relaxPrec, constant per row class: read from the dictionary instead of streamed (rc_d)
-  if (h->nrhs == 1 && A.has_rc && A.rc_has_d && d == h->lev[(size_t)level].d.p && &A == &h->lev[(size_t)level].A) v.d = nullptr;
-  v.nrhs = (int)h->nrhs;
-  ProfScope ps(h, level, MG_K_SMOOTH, spmv_bytes(A, h->nrhs, true, true), moved_bytes(A, h->nrhs, true, true, v.d == nullptr));
-  return launch_csr<mgk::SMOOTH>(h->stream, A, v);
-}
-// One sweep and the residual of its result in one pass (csr_rowclass_march2_spmv):
-//   t = x + d.*(b - A x) ;  r = b - A t  [; xn = t + d.*r ; ||r||^2 partials]
-// for the level's own A with its own relaxPrec read from the class dictionary.  x, t, r, xn: four different buffers.
-bool march2_ok(const mg_hierarchy* h, int level, const double* x, const double* t, const double* r, const double* xn) {
-  const Level& L = h->lev[(size_t)level];
-  if (h->nrhs != 1 || h->relax_type != 0) return false;
-  if (L.A.rm3_var && L.A.rc_march3) {        // band form: values and relaxPrec are streamed per row
-    if (!L.relax_set) return false;
-  } else {
-    if (!L.A.has_rc || !L.A.rc_has_d || L.A.rc_nexc != 0) return false;
-    if (!(L.A.rc_march && L.A.rc_march2) && !L.A.rc_march3) return false;
-    if (L.A.d_bound != L.d.p) return false;   // the dictionary's relaxPrec is this level's
-  }
-  if ((t && (x == t || t == r || t == xn)) || x == r || x == xn || (r && r == xn)) return false;   // (t, r, xn: each optional)
-  return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-}
-// the 2-D tile form (csr_rowclass_march3_spmv): template arguments from what is wanted
-// (12 >= stores per lane and iteration: K1 <= 4 rows x 3 outputs; 32 slabs shared by all workgroups; 1024 lanes)
-constexpr size_t M3_SINK_DOUBLES = (size_t)12 * 32 * 1024;
-// > 64 KB of dynamic LDS needs the function attribute - per DEVICE: one bit per device id, set on the first launch there
-static int big_lds_attr(const void* fn, std::atomic<unsigned long long>& done, size_t bytes = 160 * 1024 - 256) {
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  const unsigned long long bit = 1ULL << (dev & 63);
-  if (done.load(std::memory_order_acquire) & bit) return MG_OK;
-  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  done.fetch_or(bit, std::memory_order_release);
-  return MG_OK;
-}
-template <bool ZERO, int OUT, int NT, int K1, bool VAR = false>
-int launch_march3(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
-  auto* fn = &mgk::csr_rowclass_march3_spmv<ZERO, OUT, NT, K1, RM3_NPM, VAR>;
-  static std::atomic<unsigned long long> attr_done{0};
-  MG_TRY(big_lds_attr(reinterpret_cast<const void*>(fn), attr_done));
-  mgk::RowClassDev C = A.rcdev();
-  if (VAR) {
-    C = mgk::RowClassDev{};
-    C.n_rows = (int)A.n_rows;
-  }
-  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm3.nblocks), dim3(NT), A.rm3_lds, stream, C, a, A.rm3);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-template <bool ZERO, int OUT>
-int launch_march3_k(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
-  if (A.rm3_var) return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 512, 2, true>(stream, A, a) : launch_march3<ZERO, OUT, 512, 3, true>(stream, A, a);
-  if (A.rm3_nt == 768) return A.rm3_k1 == 3 ? launch_march3<ZERO, OUT, 768, 3>(stream, A, a) : launch_march3<ZERO, OUT, 768, 4>(stream, A, a);
-  return A.rm3_k1 == 2 ? launch_march3<ZERO, OUT, 1024, 2>(stream, A, a) : launch_march3<ZERO, OUT, 1024, 3>(stream, A, a);
-}
-// dispatch on (from_zero, outputs); `scratch` (n_rows doubles, may be null when t and one of r / xn are given in one of the
-// instantiated combinations) takes the outputs nobody asked for
-int launch_march3_any(hipStream_t stream, const Csr& A, mgk::March2Args a, bool from_zero, double* scratch) {
-  int o = (a.r ? 1 : 0) | (a.xn ? 2 : 0) | (a.t ? 4 : 0);
-  if (!(o == 5 || o == 2 || o == 6 || o == 7)) {   // (t, r) cycle; (xn) solve loop, iterate dead; (t, xn) its last step; all
-    if (!scratch) return fail(MG_ERR_STATE, "this combination of outputs needs a scratch vector");
-    if (!a.t) a.t = scratch;      // (one scratch vector takes every output nobody asked for: written, never read)
-    if (!a.r) a.r = scratch;
-    if (!a.xn) a.xn = scratch;
-    o = 7;
-  }
-  if (from_zero) return o == 5 ? launch_march3_k<true, 5>(stream, A, a) : o == 2 ? launch_march3_k<true, 2>(stream, A, a) : o == 6 ? launch_march3_k<true, 6>(stream, A, a) : launch_march3_k<true, 7>(stream, A, a);
-  return o == 5 ? launch_march3_k<false, 5>(stream, A, a) : o == 2 ? launch_march3_k<false, 2>(stream, A, a) : o == 6 ? launch_march3_k<false, 6>(stream, A, a) : launch_march3_k<false, 7>(stream, A, a);
-}
-int k_smooth_residual3(mg_hierarchy* h, int level, const Csr& A, const mgk::March2Args& a_in, bool from_zero) {
-  mgk::March2Args a = a_in;
-  const int nb1 = A.rm3.nblocks;
-  if (h->m3sink.n < M3_SINK_DOUBLES) return fail(MG_ERR_STATE, "the store sink of the tile-form pass is missing (mg_finalize allocates it)");
-  a.sink = h->m3sink.p;
-  a.d = h->lev[(size_t)level].d.p;
-  if (a.sumsq && (size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
-  const double n8 = 8.0 * (double)A.n_rows;
-  {
-    // moved: no class-id stream in this form (the ids come from the product map) - the class records, the index maps, x and b
-    // in, the outputs asked for out
-    // (band form: + the 7 planar value arrays and relaxPrec, once for both stages)
-    const double tables = (double)(A.rm3_var ? A.band_ncls : A.rc_ncls) * 88.0 + 2.0 * (double)(A.rm3.n1 + A.rm3.n2 + A.rm3.nplanes + A.rm3.ntab) +
-                          (A.rm3_var ? 8.0 * (double)(mgk::RM3_NIP + 3) * (double)A.n_rows : 0.0);
-    ProfScope ps(h, level, a.sumsq ? MG_K_SMOOTH_RESIDUAL_NORM : MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (a.xn && a.r ? n8 : 0.0),
-                 tables + n8 * (2.0 + (a.t ? 1.0 : 0.0) + (a.r ? 1.0 : 0.0) + (a.xn ? 1.0 : 0.0)));
-    // the combinations the cycle and the solve loop use are instantiated exactly; anything else (the test entry point) runs
-    // the all-outputs kernel with the missing vectors pointed at a scratch vector of the level
-    const int o = (a.r ? 1 : 0) | (a.xn ? 2 : 0) | (a.t ? 4 : 0);
-    double* scratch = nullptr;
-    if (!(o == 5 || o == 2 || o == 6 || o == 7)) {
-      Level& L = h->lev[(size_t)level];
-      if (L.x3.n != (size_t)A.n_rows) MG_TRY(L.x3.alloc((size_t)A.n_rows));
-      scratch = L.x3.p;
-    }
-    MG_TRY(launch_march3_any(h->stream, A, a, from_zero, scratch));
-  }
-  if (a.sumsq) {
-    ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-    launch_sum_final(h, h->partial.p, nb1);
-    HIP_TRY(hipGetLastError());
-  }
-  return MG_OK;
-}
-// from_zero: the sweep's input is x1 = d.*b (the level is entered with x = 0): x is not read, no dscale launch is needed
-int k_smooth_residual(mg_hierarchy* h, int level, const double* b, const double* x, double* t, double* r, double* xn,
-                      bool want_sumsq, bool from_zero = false) {
-  const Csr& A = h->lev[(size_t)level].A;
-  mgk::March2Args a{};
-  a.x = x;
-  a.b = b;
-  a.t = t;
-  a.r = r;
-  a.xn = xn;
-  a.sumsq = want_sumsq ? h->partial.p : nullptr;
-  if (A.rc_march3) return k_smooth_residual3(h, level, A, a, from_zero);
-  mgk::MarchDev T = A.marchdev();
-  T.nblocks = A.rm2_nblocks;
-  if (want_sumsq && (size_t)T.nblocks > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the fused sweep + residual");
-  const size_t lds = march2_lds_bytes(A.rm_halo);
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march2_spmv<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mgk::csr_rowclass_march2_spmv<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipGetLastError();
-    lds_attr_set = true;
-  }
-  const double n8 = 8.0 * (double)A.n_rows;
-  {
-    // algorithmic: the two products; moved: class ids + x + b in, t and r (and/or xn) out
-    ProfScope ps(h, level, want_sumsq ? MG_K_SMOOTH_RESIDUAL_NORM : MG_K_SMOOTH_RESIDUAL, spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false) + (xn && r ? n8 : 0.0),
-                 format_bytes(A, 1) + n8 * (2.0 + (t ? 1.0 : 0.0) + (r ? 1.0 : 0.0) + (xn ? 1.0 : 0.0)));
-    if (from_zero) hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<true>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
-    else hipLaunchKernelGGL((mgk::csr_rowclass_march2_spmv<false>), dim3(T.nblocks), dim3(mgk::RM_C), lds, h->stream, A.rcdev(), a, T);
-    HIP_TRY(hipGetLastError());
-  }
-  if (want_sumsq) {   // one partial per workgroup (<= one per CU): a single-workgroup final sum
-    const int nb1 = T.nblocks;
-    ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-    launch_sum_final(h, h->partial.p, nb1);
-    HIP_TRY(hipGetLastError());
-  }
-  return MG_OK;
-}
-// The solve loop's two fine-level passes across the stopping test as ONE four-stage pass (csr_rowclass_march4_spmv):
-//   t = x + d.*(b - A x) ; r = b - A t ; ||r||^2 ; xn = t + d.*r ; tp = xn + d.*(b - A xn) ; rp = b - A tp
-// x, tp, rp: three different buffers; the iterate t is not stored (the caller re-creates it from x if the loop stops).
-template <int NT, int K1, int NPM, int PITCH>
-int launch_march4_p(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
-  auto* fn = &mgk::csr_rowclass_march4_spmv<NT, K1, NPM, PITCH>;
-  static std::atomic<unsigned long long> attr_done{0};
-  MG_TRY(big_lds_attr(reinterpret_cast<const void*>(fn), attr_done));
-  hipLaunchKernelGGL(fn, dim3((unsigned)A.rm4.nblocks), dim3(NT), A.rm4_lds, stream, A.rcdev(), a, A.rm4);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-// (the slab pitch is a template argument: LDS line offsets as immediates; build_march4 pads a tile's lines to one of these)
-template <int NT, int K1, int NPM>
-int launch_march4(hipStream_t stream, const Csr& A, const mgk::March2Args& a) {
-  switch (A.rm4.pitch) {
-    case 48: return launch_march4_p<NT, K1, NPM, 48>(stream, A, a);
-    case 64: return launch_march4_p<NT, K1, NPM, 64>(stream, A, a);
-    case 80: return launch_march4_p<NT, K1, NPM, 80>(stream, A, a);
-    default: return fail(MG_ERR_STATE, "four-stage pass: no kernel for a slab pitch of %d", A.rm4.pitch);
-  }
-}
-bool march4_ok(const mg_hierarchy* h, int level, const double* x, const double* tp, const double* rp) {
-  const Level& L = h->lev[(size_t)level];
-  if (h->nrhs != 1 || h->relax_type != 0 || h->opt.no_march4) return false;
-  if (!L.A.rc_march4 || !L.A.has_rc || !L.A.rc_has_d || L.A.rc_nexc != 0 || L.A.d_bound != L.d.p) return false;
-  if (std::max<long long>(1, L.npre) != 2) return false;   // (xn is the input of the LAST pre-smoothing sweep)
-  if (x == tp || x == rp || tp == rp) return false;
-  return (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-}
-int k_four_stage(mg_hierarchy* h, int level, const double* b, const double* x, double* tp, double* rp, double* host_slot = nullptr) {
-  const Csr& A = h->lev[(size_t)level].A;
-  mgk::March2Args a{};
-  a.x = x;
-  a.b = b;
-  a.t = tp;
-  a.r = rp;
-  a.sumsq = h->partial.p;
-  if (h->m3sink.n < M3_SINK_DOUBLES) return fail(MG_ERR_STATE, "the store sink of the tile-form pass is missing (mg_finalize allocates it)");
-  a.sink = h->m3sink.p;
-  a.d = h->lev[(size_t)level].d.p;
-  const int nb1 = A.rm4.nblocks;
-  if ((size_t)nb1 > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small for the four-stage pass");
-  const double n8 = 8.0 * (double)A.n_rows;
-  {
-    const double tables = (double)A.rc_ncls * 88.0 + 2.0 * (double)(A.rm4.n1 + A.rm4.n2 + A.rm4.nplanes + A.rm4.ntab);
-    // algorithmic: four products with A (two fused sweeps, two residuals); moved: x, b in, t' and r' out
-    ProfScope ps(h, level, MG_K_FOUR_STAGE, 2.0 * (spmv_bytes(A, 1, true, true) + spmv_bytes(A, 1, true, false)), tables + 4.0 * n8);
-    if (A.rm4_nt == 1024) MG_TRY((launch_march4<1024, 2, 2>(h->stream, A, a)));
-    else if (A.rm4_nt == 768 && A.rm4_k1 == 3) MG_TRY((launch_march4<768, 3, 2>(h->stream, A, a)));
-    else if (A.rm4_nt == 768) MG_TRY((launch_march4<768, 4, 3>(h->stream, A, a)));
-    else MG_TRY((launch_march4<512, 4, 3>(h->stream, A, a)));
-  }
-  ProfScope ps2(h, level, MG_K_NORM, 8.0 * (double)nb1, 8.0 * (double)nb1);
-  if (host_slot && !h->capturing) {   // (the pipelined stopping test: a pinned slot per step in flight)
-    hipLaunchKernelGGL(mgk::sum_final_mirror, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->scalar.p, host_slot);
-  } else {
-    launch_sum_final(h, h->partial.p, nb1);
-  }
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-// Can the coarse-grid correction of level `level` ride in the staging of the first post-smoothing sweep?
-// (one right-hand side, pointwise smoother, A on the marching kernel, P in row-class form without exception rows)
-bool can_fuse_prolong(mg_hierarchy* h, int level, const double* x, const double* out) {
-  const Level& L = h->lev[(size_t)level];
-  if (!h->opt.fuse_prolong || h->nrhs != 1 || h->relax_type != 0) return false;   // off by default: measured slower (DESIGN)
-  if (!L.A.has_rc || !L.A.rc_march || !L.P.has_rc || L.P.rc_nexc != 0) return false;
-  if (L.P.rc_ncls > mgk::RM_PNCLS || L.P.rc_entries > mgk::RM_PDCAP) return false;
-  return out != x && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-}
-// out = xp + d.*(b - A*xp) with xp = x + P*xc: the prolongation (MGcycle.jl:90) and the first post-smoothing sweep
-// (l.92-102) in ONE pass over the level - x + P*xc exists only in LDS (x itself is left as it was).
-int k_smooth_prolong(mg_hierarchy* h, int level, const double* b, const double* x, const double* xc, double* out) {
-  Level& L = h->lev[(size_t)level];
-  mgk::VecArgs v{};
-  v.x = x;
-  v.xs = x;
-  v.y = out;
-  v.b = b;
-  v.d = L.A.rc_has_d ? nullptr : L.d.p;
-  v.d_full = L.d.p;
-  v.nrhs = 1;
-  mgk::ProDev Q{};
-  Q.Pm = L.P.rcdev();
-  Q.xc = xc;
-  Q.ncls = (int)L.P.rc_ncls;
-  Q.nent = (int)L.P.rc_entries;
-  Q.maxlen = L.P.rc_maxlen;
-  ProfScope ps(h, level, MG_K_SMOOTH_PROLONG, spmv_bytes(L.A, 1, true, true) + spmv_bytes(L.P, 1, true, false),
-               moved_bytes(L.A, 1, true, true, v.d == nullptr) + format_bytes(L.P, 1) + 8.0 * (double)L.P.n_cols);
-  return launch_csr<mgk::SMOOTH>(h->stream, L.A, v, nullptr, &Q);
-}
-int k_dscale(mg_hierarchy* h, int level, const double* d, const double* b, double* x, long long n) {
-  ProfScope ps(h, level, MG_K_DSCALE, 8.0 * (double)n * (1.0 + 2.0 * (double)h->nrhs));
-  hipLaunchKernelGGL(mgk::dscale_kernel, dim3(grid_for(n * h->nrhs / 2 + 1)), dim3(mgk::BLK), 0,
-                     h->stream, d, b, x, n, (int)h->nrhs);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-// xout = x + d.*r (first sweep when r = b - A x is already known)
-int k_xpdr(mg_hierarchy* h, int level, const double* x, const double* d, const double* r, double* xout,
-           long long n) {
-  ProfScope ps(h, level, MG_K_DSCALE, 8.0 * (double)n * (1.0 + 3.0 * (double)h->nrhs));
-  const Csr& A = h->lev[(size_t)level].A;
-  if (h->nrhs == 1 && A.has_rc && A.rc_has_d && d == h->lev[(size_t)level].d.p && n == A.n_rows) {
-    // the level's relaxPrec is constant per row class: stream the 2-byte class ids instead of d
-    hipLaunchKernelGGL(mgk::xpdr_cls_kernel, dim3(grid_for(n / 2 + 1)), dim3(mgk::BLK), 0, h->stream, x, A.rc_cls.p,
-                       A.rc_d.p, d, r, xout, n);
-    HIP_TRY(hipGetLastError());
-    return MG_OK;
-  }
-  hipLaunchKernelGGL(mgk::xpdr_kernel, dim3(grid_for(n * h->nrhs / 2 + 1)), dim3(mgk::BLK), 0,
-                     h->stream, x, d, r, xout, n, (int)h->nrhs);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-int k_fill(mg_hierarchy* h, double* x, long long n, double val) {
-  hipLaunchKernelGGL(mgk::fill_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, x, n, val);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-int fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>& work, const double* b,
-                double* x, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
-                double* resvec, long long* nres);
-int block_fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>* work, const double* B,
-                      double* X, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
-                      double* resvec, long long* nres);
-int k_coarse(mg_hierarchy* h, int level, const double* b, double* x) {
-  const long long n = h->n_coarse;
-  if (h->coarse_gmres) {
-    // coarseSolveType "GMRES" (MGcycle.jl:152-168): x = 0; one restart of FGMRES(10), tol 0.01, M = d .* v with
-    // d = relaxParam ./ diag(A_c) (defineCoarsestAinv, MGsetup.jl:334)
-    ProfScope ps(h, level, MG_K_COARSE, 0.0);
-    MG_TRY(k_fill(h, x, n * h->nrhs, 0.0));
-    if (h->nrhs != 1)   // MGcycle.jl:166: KrylovMethods.blockFGMRES(Afun, b, 10, tol = 0.01, maxIter = 1, M = M2, X = x)
-      return block_fgmres_core(h, level, 1, h->coarse_d.p, &h->kwc_blk, b, x, 10, 0.01, 1, nullptr, nullptr, nullptr, nullptr);
-    return fgmres_core(h, level, 1, h->coarse_d.p, h->kwc, b, x, 10, 0.01, 1, nullptr, nullptr, nullptr, nullptr);
-  }
-  if (h->coarse_lu) {
-    ProfScope ps(h, level, MG_K_COARSE, 12.0 * (double)(h->luLval.n + h->luUval.n) + 16.0 * (double)n * (double)h->nrhs);
-    mgk::LuDev F;
-    F.n = (int)n;
-    F.Lptr = h->luLptr.p; F.Lcol = h->luLcol.p; F.Lval = h->luLval.p;
-    F.Uptr = h->luUptr.p; F.Ucol = h->luUcol.p; F.Uval = h->luUval.p;
-    F.p = h->luP.p; F.q = h->luQ.p;
-    F.Lorder = h->luLorder.p; F.Llvl = h->luLlvl.p; F.nLlvl = h->nLlvl;
-    F.Uorder = h->luUorder.p; F.Ulvl = h->luUlvl.p; F.nUlvl = h->nUlvl;
-    if (!h->lu_multi) {
-      hipLaunchKernelGGL(mgk::sptrsv_lu, dim3(1), dim3(1024), 0, h->stream, F, b, x, h->luWork.p, (int)h->nrhs);
-      HIP_TRY(hipGetLastError());
-      return MG_OK;
-    }
-    const int nr = (int)h->nrhs;
-    double* y = h->luWork.p;
-    auto wave_blocks = [](long long waves) { return dim3((unsigned)((waves * 64 + mgk::BLK - 1) / mgk::BLK)); };
-    // y = L \ b[p]: the levels ahead of the trailing block one launch each, the block through its inverse
-    const int nLl = (int)h->luLlvl_h.size() - 1, nUl = (int)h->luUlvl_h.size() - 1;
-    for (int l = 0; l < nLl; ++l) {
-      const int t0 = h->luLlvl_h[(size_t)l], t1 = h->luLlvl_h[(size_t)l + 1];
-      hipLaunchKernelGGL(mgk::sptrsv_level<true>, wave_blocks(t1 - t0), dim3(mgk::BLK), 0, h->stream, F,
-                         reinterpret_cast<const int4*>(h->luLslot.p), t0, t1, b, y, nr);
-    }
-    if (h->luML > 0) {
-      const int n0 = (int)n - h->luML;
-      hipLaunchKernelGGL(mgk::sptrsv_tail_rhs, wave_blocks(h->luML), dim3(mgk::BLK), 0, h->stream, F, n0, b, y, h->luTail.p, nr);
-      hipLaunchKernelGGL(mgk::tri_apply<true>, wave_blocks((long long)h->luML * nr), dim3(mgk::BLK), 0, h->stream,
-                         h->luInvL.p, (h->luML + 63) / 64 * 64, h->luTail.p, y + (size_t)n0 * (size_t)nr, h->luML, nr);
-    }
-    // y = U \ y: the trailing block first, then the levels behind it
-    if (h->luMU > 0) {
-      const int n0 = (int)n - h->luMU;
-      HIP_TRY(hipMemcpyAsync(h->luTail.p, y + (size_t)n0 * (size_t)nr, (size_t)h->luMU * (size_t)nr * sizeof(double),
-                             hipMemcpyDeviceToDevice, h->stream));
-      hipLaunchKernelGGL(mgk::tri_apply<false>, wave_blocks((long long)h->luMU * nr), dim3(mgk::BLK), 0, h->stream,
-                         h->luInvU.p, (h->luMU + 63) / 64 * 64, h->luTail.p, y + (size_t)n0 * (size_t)nr, h->luMU, nr);
-    }
-    for (int l = 0; l < nUl; ++l) {
-      const int t0 = h->luUlvl_h[(size_t)l], t1 = h->luUlvl_h[(size_t)l + 1];
-      hipLaunchKernelGGL(mgk::sptrsv_level<false>, wave_blocks(t1 - t0), dim3(mgk::BLK), 0, h->stream, F,
-                         reinterpret_cast<const int4*>(h->luUslot.p), t0, t1, b, y, nr);
-    }
-    hipLaunchKernelGGL(mgk::sptrsv_scatter, dim3((unsigned)((n * nr + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0,
-                       h->stream, h->luQ.p, y, x, (int)n, nr);
-    HIP_TRY(hipGetLastError());
-    return MG_OK;
-  }
-  ProfScope ps(h, level, MG_K_COARSE,
-               8.0 * ((double)n * (double)n + 2.0 * (double)n * (double)h->nrhs));
-  const long long waves = n * h->nrhs;
-  const long long blocks = (waves * 64 + mgk::BLK - 1) / mgk::BLK;
-  hipLaunchKernelGGL(mgk::dense_apply, dim3((unsigned)blocks), dim3(mgk::BLK), 0, h->stream,
-                     h->Ainv.p, b, x, (int)n, (int)h->nrhs);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-// sum of squares of x[0..len) -> h->scalar (device); no sync
-int k_sumsq(mg_hierarchy* h, const double* x, long long len) {
-  ProfScope ps(h, 0, MG_K_NORM, 8.0 * (double)len);
-  const int nb = std::min<long long>(h->nred_blocks, std::max<long long>(1, (len / 2 + mgk::BLK - 1) / mgk::BLK));
-  hipLaunchKernelGGL(mgk::sumsq_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, x, len,
-                     h->partial.p);
-  launch_sum_final(h, h->partial.p, nb);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-// host value of sqrt(h->scalar); synchronises the stream
-// h->scalar on the host (*h->h_scalar) once the stream has drained
-int scalar_wait(mg_hierarchy* h) {
-  if (!h->scalar_mirrored) HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  h->scalar_mirrored = false;
-  HIP_TRY(spin_sync(h->stream));
-  return MG_OK;
-}
-int scalar_sync(mg_hierarchy* h, double* out) {
-  MG_TRY(scalar_wait(h));
-  *out = std::sqrt(*h->h_scalar);
-  return MG_OK;
-}
-// host value of sqrt(sum of squares); synchronises the stream
-int norm_sync(mg_hierarchy* h, const double* x, long long len, double* out) {
-  MG_TRY(k_sumsq(h, x, len));
-  return scalar_sync(h, out);
-}
-
-// ---- FGMRES_relaxation (FGMRES.jl:48-126) --------------------------------------------------------------
-// Moore-Penrose inverse of a small symmetric matrix (H = (AZ)'(AZ), k <= 16) by cyclic Jacobi rotations;
-// cut-off as Julia's pinv: rtol = eps * k relative to the largest singular value.
-void pinv_sym(const std::vector<double>& H, int k, std::vector<double>& Pinv) {
-  std::vector<double> A(H), V((size_t)k * k, 0.0);
-  for (int i = 0; i < k; ++i) V[(size_t)i * k + i] = 1.0;
-  for (int sweep = 0; sweep < 100; ++sweep) {
-    double off = 0.0;
-    for (int p = 0; p < k; ++p)
-      for (int q = p + 1; q < k; ++q) off += A[(size_t)p * k + q] * A[(size_t)p * k + q];
-    if (off < 1e-300) break;
-    for (int p = 0; p < k; ++p)
-      for (int q = p + 1; q < k; ++q) {
-        const double apq = A[(size_t)p * k + q];
-        if (apq == 0.0) continue;
-        const double theta = (A[(size_t)q * k + q] - A[(size_t)p * k + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-        for (int i = 0; i < k; ++i) {
-          const double aip = A[(size_t)i * k + p], aiq = A[(size_t)i * k + q];
-          A[(size_t)i * k + p] = c * aip - sn * aiq;
-          A[(size_t)i * k + q] = sn * aip + c * aiq;
-        }
-        for (int i = 0; i < k; ++i) {
-          const double api = A[(size_t)p * k + i], aqi = A[(size_t)q * k + i];
-          A[(size_t)p * k + i] = c * api - sn * aqi;
-          A[(size_t)q * k + i] = sn * api + c * aqi;
-        }
-        for (int i = 0; i < k; ++i) {
-          const double vip = V[(size_t)i * k + p], viq = V[(size_t)i * k + q];
-          V[(size_t)i * k + p] = c * vip - sn * viq;
-          V[(size_t)i * k + q] = sn * vip + c * viq;
-        }
-      }
-  }
-  double smax = 0.0;
-  for (int i = 0; i < k; ++i) smax = std::max(smax, std::fabs(A[(size_t)i * k + i]));
-  const double tol = 2.220446049250313e-16 * k * smax;
-  Pinv.assign((size_t)k * k, 0.0);
-  for (int e = 0; e < k; ++e) {
-    const double lam = A[(size_t)e * k + e];
-    if (std::fabs(lam) <= tol) continue;
-    for (int i = 0; i < k; ++i)
-      for (int j = 0; j < k; ++j) Pinv[(size_t)i * k + j] += V[(size_t)i * k + e] * V[(size_t)j * k + e] / lam;
-  }
-}
-
-int k_axpby(mg_hierarchy* h, double a, const double* x, double b, double* y, long long n) {
-  hipLaunchKernelGGL(mgk::axpby_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, a, x, b, y, n);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-
-int dot_sync(mg_hierarchy* h, const double* x, const double* y, long long len, double* out);
-
-// x0 += Z*t where t minimises ||r0 - A Z t|| over the `inner` directions z_1 = M r0, z_j = M (A z_{j-1}).
-// prec(v, z) must write z = M v (length n*nrhs).  x0_is_zero: x0 is overwritten with the correction
-// (K-cycle: xc = 0 on entry, MGcycle.jl:63-64, and x0 doubles as scratch of the inner cycles).
-template <class Prec>
-int fgmres_relax(mg_hierarchy* h, int lv, const double* r0, double* x0, long long inner, Prec prec,
-                 double TOL, double* Zb, double* AZb, bool x0_is_zero) {
-  Level& L = h->lev[(size_t)lv];
-  const long long len = L.n * h->nrhs;
-  if (inner <= 0) {
-    if (x0_is_zero) MG_TRY(k_fill(h, x0, len, 0.0));
-    return MG_OK;  // w = Z*t with no columns: x0 unchanged (FGMRES.jl:119-121)
-  }
-  const int k = (int)inner;
-  double rnorm0 = 0.0;
-  MG_TRY(norm_sync(h, r0, len, &rnorm0));
-  std::vector<double> H((size_t)k * k, 0.0), xi((size_t)k, 0.0), t((size_t)k, 0.0), Pinv;
-  int used = 0;
-  for (int j = 0; j < k; ++j) {
-    double* z = Zb + (size_t)j * len;
-    double* w = AZb + (size_t)j * len;
-    MG_TRY(prec(j == 0 ? r0 : AZb + (size_t)(j - 1) * len, z));          // z = prec(r0) / prec(w)   (l.83-87)
-    MG_TRY(k_spmv(h, lv, MG_K_SPMV, L.A, 1.0, z, 0.0, w));                // w = A z                  (l.91)
-    used = j + 1;
-    for (int i = 0; i <= j; ++i) {                                       // t = AZ' * w              (l.95)
-      double d = 0.0;
-      MG_TRY(dot_sync(h, AZb + (size_t)i * len, w, len, &d));
-      H[(size_t)i * k + j] = d;
-      H[(size_t)j * k + i] = d;                                          // H[:,j] = t; H[j,:] = t'  (l.99-101)
-    }
-    MG_TRY(dot_sync(h, w, r0, len, &xi[(size_t)j]));                     // xi[j] = dot(w, r0)       (l.97)
-    pinv_sym(H, k, Pinv);                                                // t = pinv(H)*xi           (l.102)
-    double tHt = 0.0, txi = 0.0;
-    for (int a = 0; a < k; ++a) {
-      double s = 0.0;
-      for (int b = 0; b < k; ++b) s += Pinv[(size_t)a * k + b] * xi[(size_t)b];
-      t[(size_t)a] = s;
-    }
-    for (int a = 0; a < k; ++a) {
-      double s = 0.0;
-      for (int b = 0; b < k; ++b) s += H[(size_t)a * k + b] * t[(size_t)b];
-      tHt += t[(size_t)a] * s;
-      txi += t[(size_t)a] * xi[(size_t)a];
-    }
-    const double rn = std::sqrt(std::fabs(tHt - 2.0 * txi + rnorm0 * rnorm0));   // l.104
-    if (rn < TOL) break;                                                          // l.114-117
-  }
-  for (int j = 0; j < used; ++j)                                         // x0 += Z*t                (l.121-123)
-    MG_TRY(k_axpby(h, t[(size_t)j], Zb + (size_t)j * len, (j == 0 && x0_is_zero) ? 0.0 : 1.0, x0, len));
-  return MG_OK;
-}
-
-// ---- the cycle ------------------------------------------------------------------------------------
-// Returns in *result the buffer (xa or xb) that holds the level's x after the cycle.
-// l is 0-based.  xa holds the incoming x when !x_zero; xb is the Jacobi ping-pong partner.
-// r_valid: L.r already holds b - A*x for the incoming x (solveMG computed it for its stopping test,
-// SolveFuncs.jl:26-30, and recursiveCycle would recompute the same values, MGcycle.jl:26-31).
-// x1_ready (with r_valid): xb already holds xa + d.*r, the first pre-smoothing update (written by the residual kernel
-// of the previous solve step, k_residual_sumsq's xnext).
-int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
-              bool x1_given = false);
-// x1_given (with x_zero): xa already holds d.*b, the first update from x = 0 (written by the restriction that produced b).
-// defer_post (solve loop, fine level): leave the LAST post-smoothing sweep to the caller, who fuses it with the residual
-// of the stopping test (k_smooth_residual); *defer_post says whether that happened (result = x before that sweep).
-// pre_done (solve loop, fine level): the caller's four-stage pass already ran this level's pre-smoothing and residual -
-// xa holds the smoothed x, L.r = b - A x: the cycle starts at the restriction.
-int cycle_level(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero,
-                char ctype, double** result, bool r_valid = false, bool x1_ready = false, bool* defer_post = nullptr,
-                bool x1_given = false, bool pre_done = false) {
-  const int nl = (int)h->nlevels;
-  if (l == nl - 1) {  // solveCoarsest (MGcycle.jl:13-18,67-69,177): x = LU \ b
-    MG_TRY(k_coarse(h, l, b, xa));
-    *result = xa;
-    return MG_OK;
-  }
-  Level& L = h->lev[l];
-  Level& C = h->lev[l + 1];
-  const long long len = L.n * h->nrhs;
-  double* cur = xa;
-  double* alt = xb;
-  const double gmresTol = 1e-5;  // MGcycle.jl:5
-  auto diag_prec = [&](const double* v, double* z) { return k_dscale(h, l, L.d.p, v, z, L.n); };  // MM (l.36-38)
-  // relax() always performs at least one update: `for i=1:numit-1 ... end; x .+= d.*r` (MGcycle.jl:127-134)
-  long long npre = std::max<long long>(1, L.npre);
-  const long long npost = std::max<long long>(1, L.npost);
-  bool from_zero = false;
-  // pre-smoothing (MGcycle.jl:26-31,54).  x == 0: r = b, so the first sweep is x = d.*b.
-  if (pre_done) {
-    npre = 0;
-  } else if (h->relax_type == 1) {  // Jac-GMRES (MGcycle.jl:48-50): FGMRES on the residual, preconditioned by D
-    const double* r0 = b;
-    if (x_zero) {
-      MG_TRY(k_fill(h, cur, len, 0.0));
-    } else {
-      if (!r_valid) MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
-      r0 = L.r.p;
-    }
-    MG_TRY(fgmres_relax(h, l, r0, cur, L.npre, diag_prec, gmresTol, L.relaxZ.p, L.relaxAZ.p, false));
-    npre = 0;
-  } else if (x_zero) {
-    // two sweeps from x = 0 on a level the two-stage pass serves: x1 = d.*b is formed inside that pass
-    from_zero = !x1_given && npre == 2 && !h->opt.no_march2_zero && march2_ok(h, l, cur, alt, L.r.p, nullptr);
-    if (!from_zero && !x1_given) MG_TRY(k_dscale(h, l, L.d.p, b, cur, L.n));
-    --npre;
-  } else if (r_valid) {
-    if (!x1_ready) MG_TRY(k_xpdr(h, l, cur, L.d.p, L.r.p, alt, L.n));
-    std::swap(cur, alt);
-    --npre;
-  }
-  // the last pre-smoothing sweep and r = b - A x (MGcycle.jl:58-60) in one pass where the marching kernel allows
-  const bool fuse_pre = npre >= 1 && march2_ok(h, l, cur, alt, L.r.p, nullptr);
-  for (long long s = 0; s < npre - (fuse_pre ? 1 : 0); ++s) {
-    MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
-    std::swap(cur, alt);
-  }
-  // r = b - A x ; bc = R r ; xc = 0 (MGcycle.jl:58-66)
-  if (pre_done) {
-    // (L.r is the four-stage pass's r')
-  } else if (fuse_pre) {
-    MG_TRY(k_smooth_residual(h, l, b, cur, alt, L.r.p, nullptr, false, from_zero));
-    std::swap(cur, alt);
-  } else {
-    MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
-  }
-  // the restriction also writes the coarse level's first update x = d.*bc where its kernel can (no dscale launch there)
-  const bool give_x1 = h->relax_type == 0 && !(ctype == 'K') && l + 1 < nl - 1 && C.relax_set && restrict_can_scale(h, L.R);
-  MG_TRY(k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, C.b.p, give_x1 ? C.d.p : nullptr, give_x1 ? C.x0.p : nullptr));
-  double* xc = nullptr;
-  if (ctype == 'K' && l + 1 < nl - 1) {
-    // K-cycle (MGcycle.jl:72-76): 2 steps of FGMRES on A_{l+1} xc = bc, preconditioned by the K-cycle of level l+1
-    auto kprec = [&](const double* v, double* z) {
-      double* res = nullptr;
-      MG_TRY(cycle_level(h, l + 1, v, C.x0.p, C.x1.p, true, 'K', &res));
-      HIP_TRY(hipMemcpyAsync(z, res, sizeof(double) * C.n * h->nrhs, hipMemcpyDeviceToDevice, h->stream));
-      return (int)MG_OK;
-    };
-    MG_TRY(fgmres_relax(h, l + 1, C.b.p, C.x0.p, 2, kprec, gmresTol, C.kZ.p, C.kAZ.p, true));
-    xc = C.x0.p;
-  } else {
-    MG_TRY(cycle_sub(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc, give_x1));
-  }
-  if (l + 1 < nl - 1) {  // MGcycle.jl:78-85
-    if (ctype == 'W') {
-      double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
-      MG_TRY(cycle_sub(h, l + 1, C.b.p, xc, other, false, 'W', &xc));
-    } else if (ctype == 'F') {
-      double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
-      MG_TRY(cycle_sub(h, l + 1, C.b.p, xc, other, false, 'V', &xc));
-    }
-  }
-  // x += P xc (MGcycle.jl:90) and post-smoothing (l.92-102)
-  long long post_done = 0;
-  if (can_fuse_prolong(h, l, cur, alt)) {   // prolongation fused into the staging of the first sweep
-    MG_TRY(k_smooth_prolong(h, l, b, cur, xc, alt));
-    std::swap(cur, alt);
-    post_done = 1;
-  } else {
-    MG_TRY(k_spmv(h, l, MG_K_PROLONG, L.P, 1.0, xc, 1.0, cur));
-  }
-  if (h->relax_type == 1) {
-    MG_TRY(k_residual(h, l, L.A, b, cur, L.r.p));
-    MG_TRY(fgmres_relax(h, l, L.r.p, cur, L.npost, diag_prec, gmresTol, L.relaxZ.p, L.relaxAZ.p, false));
-  } else {
-    long long nlast = npost;
-    if (defer_post && *defer_post && post_done < npost) --nlast;   // the caller runs the last sweep (fused with its residual)
-    else if (defer_post) *defer_post = false;
-    for (long long s = post_done; s < nlast; ++s) {
-      MG_TRY(k_smooth(h, l, L.A, L.d.p, b, cur, alt));
-      std::swap(cur, alt);
-    }
-  }
-  if (defer_post && h->relax_type == 1) *defer_post = false;
-  *result = cur;
-  return MG_OK;
-}
-
-// Setup entry points copy with blocking hipMemcpy on the NULL stream while every kernel runs on the handle's
-// non-blocking stream, which does not order against it.  A blocking copy from pageable memory may return once the
-// data sits in the runtime's staging buffer, the DMA still in flight (seen on MI355X: a solve launched right after
-// an upload read zeros).  Every uploading entry point therefore ends with a device-wide fence.
-struct UploadFence {
-  ~UploadFence() { (void)hipDeviceSynchronize(); }
-};
-
-int check_ready(mg_hierarchy* h, long long n, long long nrhs) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized: call mg_finalize first");
-  if (n != h->lev[0].n) return fail(MG_ERR_INVALID, "n=%lld does not match the fine level (%lld rows)", n, h->lev[0].n);
-  if (nrhs != h->nrhs)
-    return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld: call mg_set_nrhs (adjustMemoryForNumRHS)", nrhs, h->nrhs);
-  return MG_OK;
-}
-
-void graphs_clear(mg_hierarchy* h) {
-  if (h->graphs.empty()) return;
-  if (h->stream) (void)spin_sync(h->stream);   // a replay may still be running
-  for (auto& kv : h->graphs) {
-    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-  }
-  h->graphs.clear();
-}
-
-// The levels below a few hundred thousand rows are launch-bound (8-14 us per kernel for microseconds of work): the
-// whole sub-cycle from the first such level down - smoothers, transfers, coarsest solve, every launch with fixed
-// arguments on hierarchy-owned buffers - is captured once into a HIP graph and replayed.  Not for cycles with host
-// decisions inside (Jac-GMRES smoothing, K-cycles, GMRES coarsest solve) and not while profiling (events per launch).
-bool graph_ok(const mg_hierarchy* h, int l, char ctype) {
-  if (h->opt.no_graph || h->prof || h->capturing || h->relax_type == 1 || ctype == 'K' || h->coarse_gmres) return false;
-  // a caller's stream (mg_set_stream) may be the legacy null stream, which cannot capture, or be part of a capture of
-  // the caller's own: only the hierarchy's own stream is captured, unless the caller vouches for its stream (dist tail)
-  if (!h->stream || (!h->owns_stream && !h->opt.dist_tail_graph)) return false;
-  if (h->lev[(size_t)l].n * h->nrhs > h->opt.graph_max_rows) return false;
-  return (int)h->nlevels - l >= 2 || (h->coarse_lu && h->lu_multi);
-}
-int cycle_sub(mg_hierarchy* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
-              bool x1_given) {
-  if (!graph_ok(h, l, ctype)) return cycle_level(h, l, b, xa, xb, x_zero, ctype, result, false, false, nullptr, x1_given);
-  const mg_hierarchy::GraphKey key{l, x_zero, ctype, b, xa, xb, x1_given};
-  auto it = h->graphs.find(key);
-  if (it == h->graphs.end()) {
-    if (h->graphs.size() >= 64) graphs_clear(h);   // callers cycling through many buffers: start over
-    mg_hierarchy::GraphEntry e;
-    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    h->capturing = true;
-    const int rc = cycle_level(h, l, b, xa, xb, x_zero, ctype, &e.result, false, false, nullptr, x1_given);
-    h->capturing = false;
-    const hipError_t ce = hipStreamEndCapture(h->stream, &e.graph);
-    if (rc != MG_OK || ce != hipSuccess) {
-      if (e.graph) (void)hipGraphDestroy(e.graph);
-      if (rc != MG_OK) return rc;
-      HIP_TRY(ce);
-    }
-    HIP_TRY(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
-    it = h->graphs.emplace(key, e).first;
-  }
-  HIP_TRY(hipGraphLaunch(it->second.exec, h->stream));
-  ++h->graph_launches;
-  *result = it->second.result;
-  return MG_OK;
-}
-
-// one cycle on device buffers; result guaranteed to be in x on return (no sync)
-int cycle_dev(mg_hierarchy* h, const double* b, double* x, bool x_zero) {
-  double* res = nullptr;
-  h->last_b = b;
-  h->last_x = x;
-  MG_TRY(cycle_sub(h, 0, b, x, h->lev[0].x1.p, x_zero, h->cycle, &res));
-  if (res != x)
-    HIP_TRY(hipMemcpyAsync(x, res, sizeof(double) * h->lev[0].n * h->nrhs, hipMemcpyDeviceToDevice, h->stream));
-  return MG_OK;
-}
-
-int solve_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long maxIter,
-              long long* iters, double* resvec) {
-  Level& L = h->lev[0];
-  const long long len = L.n * h->nrhs;
-  double res = 0.0, res0 = 0.0, xn = 0.0;
-  h->last_b = b;
-  h->last_x = x;
-  // SolveFuncs.jl:14-22
-  MG_TRY(norm_sync(h, x, len, &xn));
-  bool x_zero = (xn == 0.0);
-  if (x_zero) {
-    MG_TRY(norm_sync(h, b, len, &res0));
-  } else {
-    MG_TRY(k_residual_sumsq(h, 0, L.A, b, x, L.r.p));
-    MG_TRY(scalar_sync(h, &res0));
-  }
-  res = res0;
-  if (resvec) resvec[0] = res0;
-  long long it = 0;
-  double* cur = x;
-  double* alt = L.x1.p;
-  const bool dbg = h->opt.debug_timing;
-  auto tprev = std::chrono::steady_clock::now();
-  bool x1_ready = false;
-  bool t_missing = false;
-  // Where the marching kernel allows, the last post-smoothing sweep of the cycle is left out of cycle_level and runs
-  // fused with the residual of the stopping test: x_in -> t = x (the iterate) and xn = x + d.*r (the next cycle's first
-  // update) in one pass, rotating three buffers (cur, alt, spare).
-  double* spare = nullptr;
-  bool fuse_post = false;
-  if (h->nrhs == 1 && !h->opt.no_march2 && !h->opt.no_fused_next && (L.A.rc_march2 || L.A.rc_march3) && std::max<long long>(1, L.npost) >= 1) {
-    if (L.x2.n != (size_t)len) {
-      MG_TRY(L.x2.alloc((size_t)len));
-      HIP_TRY(hipMemsetAsync(L.x2.p, 0, L.x2.bytes(), h->stream));
-    }
-    spare = L.x2.p;
-    fuse_post = march2_ok(h, 0, cur, alt, nullptr, spare) && march2_ok(h, 0, alt, spare, nullptr, cur) && march2_ok(h, 0, spare, cur, nullptr, alt);
-  }
-  // Four-stage pass (csr_rowclass_march4_spmv): while the loop goes on by count, the fused last sweep + stopping-test residual of
-  // step k and the second pre-smoothing sweep + residual of step k+1 - back to back across the stopping test - are ONE pass:
-  // cur (x before the last sweep) -> alt = t' (x after the next cycle's pre-smoothing), L.r = r' = b - A t', ||r|| of step k.
-  // The next cycle then starts at its restriction (pre_done).  Speculative across the test: if it ends the loop, the iterate
-  // is re-created from the pass's input and t', r' are dropped.
-  // PIPELINED stopping test (round 4): the norm of such a step lands in a pinned slot of its own behind an event, and the host
-  // reads it only after it has enqueued the NEXT step - the device never waits for the host's round trip (30 us between the
-  // norm and the restriction in round 3's kernel trace; launch-bound stretches behind the graph launch as well).  The input of
-  // the unverified step (`keep`) stays untouched meanwhile: the next step plays in the two other buffers.  If the test ends
-  // the loop at step k, step k+1 was speculative: the stream is drained and the iterate of step k re-created from `keep`.
-  struct Pend { bool on = false; int slot = 0; } pend;
-  double* keep = nullptr;       // input of the pending (unverified) four-stage step
-  bool pre_done = false, stopped = false;
-  if (!h->pipe_ev[0]) {
-    HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->pipe_ev[1], hipEventDisableTiming));
-  }
-  // read the pending step's norm (waits for its event): one more entry of the residual history; *stop: the loop ends at that step
-  auto check_pending = [&](bool* stop) -> int {
-    if (!pend.on) return MG_OK;
-    hipError_t e;
-    while ((e = hipEventQuery(h->pipe_ev[pend.slot])) == hipErrorNotReady) {
-#if defined(__x86_64__)
-      __builtin_ia32_pause();
-#endif
-    }
-    HIP_TRY(e);
-    res = std::sqrt(h->h_scalar[1 + pend.slot]);
-    pend.on = false;
-    ++it;
-    if (resvec) resvec[it] = res;
-    if (res / res0 < tol) *stop = true;   // SolveFuncs.jl:34-36
-    return MG_OK;
-  };
-  // the loop ended at the step whose input is `keep`: whatever was enqueued behind it is dropped, its iterate re-created
-  auto finish_from_keep = [&]() -> int {
-    HIP_TRY(spin_sync(h->stream));
-    MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, keep, cur == keep ? alt : cur));
-    if (cur == keep) cur = alt;
-    stopped = true;
-    return MG_OK;
-  };
-  for (long long count = 1; count <= maxIter; ++count) {
-    double* out = nullptr;
-    // from the second step on, L.r = b - A*x is the residual just computed for the stopping test
-    bool deferred = fuse_post;
-    MG_TRY(cycle_level(h, 0, b, cur, alt, x_zero, h->cycle, &out, /*r_valid=*/count > 1 || !x_zero, x1_ready, &deferred, false, pre_done));
-    if (out != cur) std::swap(cur, alt);
-    x_zero = false;
-    pre_done = false;
-    bool stop = false;
-    if (deferred && count < maxIter && !h->opt.no_dead_t && march4_ok(h, 0, cur, alt, L.r.p)) {
-      const int slot = (int)(count & 1);
-      MG_TRY(k_four_stage(h, 0, b, cur, alt, L.r.p, h->h_scalar + 1 + slot));   // alt: neither cur nor keep
-      HIP_TRY(hipEventRecord(h->pipe_ev[slot], h->stream));
-      MG_TRY(check_pending(&stop));                   // the PREVIOUS step's norm, with this step already in the queue
-      if (stop) { MG_TRY(finish_from_keep()); break; }
-      double* freed = keep;                           // (verified: the previous step's input is free again)
-      keep = cur;                                     // this step's input: untouched until its norm has been read
-      cur = alt;                                      // t': the next cycle's x after pre-smoothing
-      if (freed) alt = freed;
-      else { alt = spare; spare = nullptr; }
-      pend.on = true;
-      pend.slot = slot;
-      pre_done = true;
-      x1_ready = false;
-      if (h->opt.no_pipeline) {
-        MG_TRY(check_pending(&stop));
-        if (stop) { MG_TRY(finish_from_keep()); break; }
-      }
-      continue;
-    }
-    MG_TRY(check_pending(&stop));                     // (a step of another kind: first the pending norm)
-    if (stop) { MG_TRY(finish_from_keep()); break; }
-    if (keep) { spare = keep; keep = nullptr; }
-    if (deferred) {
-      // cur = x before the last sweep; alt <- the iterate; spare <- x + d.*r (unused if this was the last step).
-      // The iterate itself is DEAD while the loop goes on (the next cycle starts from x + d.*r and recomputes its own
-      // residual): unless this is the last step by count it is not stored (8 of the pass's 34 bytes per row); should the
-      // stopping test end the loop here after all, one single-stage sweep of the same input reproduces it bit for bit.
-      const bool last = count == maxIter || h->opt.no_dead_t;
-      MG_TRY(k_smooth_residual(h, 0, b, cur, last ? alt : nullptr, nullptr, count < maxIter ? spare : nullptr, true));
-      x1_ready = count < maxIter;
-      double* freed = cur;
-      cur = alt;
-      alt = spare;
-      spare = freed;
-      t_missing = !last;
-    } else {
-      // SolveFuncs.jl:26-30: r = b - A x and ||r|| in one pass; where the kernel allows, the same pass also writes
-      // alt = x + d.*r, the first pre-smoothing update of the next cycle (unused if this was the last step)
-      MG_TRY(k_residual_sumsq(h, 0, L.A, b, cur, L.r.p, count < maxIter ? alt : nullptr, &x1_ready, /*r_dead=*/true));
-    }
-    MG_TRY(scalar_sync(h, &res));
-    ++it;
-    if (dbg) {
-      auto tnow = std::chrono::steady_clock::now();
-      fprintf(stderr, "[mg] step %lld: %.3f ms\n", count, std::chrono::duration<double, std::milli>(tnow - tprev).count());
-      tprev = tnow;
-    }
-    if (resvec) resvec[it] = res;
-    if (res / res0 < tol) break;  // SolveFuncs.jl:34-36
-    t_missing = false;            // (the loop goes on: the iterate of this step is never read)
-  }
-  if (!stopped && pend.on) {      // (cannot happen: the last step by count is never a four-stage step; kept for safety)
-    bool stop = false;
-    MG_TRY(check_pending(&stop));
-    MG_TRY(finish_from_keep());
-  }
-  if (t_missing && !stopped) MG_TRY(k_smooth(h, 0, L.A, L.d.p, b, spare, cur));   // spare: the input of the last pass; cur: the iterate
-  if (cur != x) {
-    HIP_TRY(hipMemcpyAsync(x, cur, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(spin_sync(h->stream));
-  }
-  if (iters) *iters = it;
-  return MG_OK;
-}
-
-// dot(x,y) on the host; synchronises the stream
-int dot_sync(mg_hierarchy* h, const double* x, const double* y, long long len, double* out) {
-  const int nb = (int)std::min<long long>(h->nred_blocks, std::max<long long>(1, (len / 2 + mgk::BLK - 1) / mgk::BLK));
-  hipLaunchKernelGGL(mgk::dot_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, x, y, len, h->partial.p);
-  launch_sum_final(h, h->partial.p, nb);
-  HIP_TRY(hipGetLastError());
-  MG_TRY(scalar_wait(h));
-  *out = *h->h_scalar;
-  return MG_OK;
-}
-
-// y = A x on level `level` and *out = x'y: where the marching kernel serves the product its per-workgroup partials are of
-// x[row]*y[row] (VecArgs::dotx), else the product and a dot pass.  Synchronises the stream.
-int k_spmv_dot(mg_hierarchy* h, int level, const Csr& A, const double* x, double* y, double* out) {
-  mgk::VecArgs v{};
-  v.x = x;
-  v.y = y;
-  v.alpha = 1.0;
-  v.beta = 0.0;
-  v.nrhs = (int)h->nrhs;
-  if (h->nrhs == 1 && march_ok(A, v) && A.rc_nexc == 0 && (size_t)A.rm_nblocks <= h->partial.n) {
-    v.sumsq = h->partial.p;
-    v.dotx = 1;
-    int nb1 = 0;
-    {
-      ProfScope ps(h, level, MG_K_SPMV, spmv_bytes(A, 1, false, false), moved_bytes(A, 1, false, false));
-      MG_TRY(launch_csr<mgk::AXPBY>(h->stream, A, v, &nb1));
-    }
-    launch_sum_final(h, h->partial.p, nb1);
-    HIP_TRY(hipGetLastError());
-    MG_TRY(scalar_wait(h));
-    *out = *h->h_scalar;
-    return MG_OK;
-  }
-  MG_TRY(k_spmv(h, level, MG_K_SPMV, A, 1.0, x, 0.0, y));
-  return dot_sync(h, x, y, (long long)A.n_rows * h->nrhs, out);
-}
-
-// Preconditioned CG with one multigrid cycle (x = 0 on entry) as M: solveCG_MG (SolveFuncs.jl:104-116) ->
-// KrylovMethods.cg (v0.6.0, un-vendored: Manifest.toml:35-41), restated from its published algorithm:
-//   r = b - A x0 ; z = M r ; p = z ; nr0 = ||b||
-//   loop: Ap = A p ; gamma = r.z ; alpha = gamma / p.Ap ; (alpha == Inf || alpha < 0 -> flag -2)
-//         x += alpha p ; r -= alpha Ap ; resvec = ||r||/nr0 ; (<= tol -> flag 0)
-//         z = M r ; beta = z.r / gamma ; p = z + beta p
-int pcg_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long maxIter, long long* iters,
-            long long* flag_out, double* resvec) {
-  Level& L = h->lev[0];
-  const long long n = L.n;
-  if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "mg_pcg: block right-hand sides (KrylovMethods.blockCG) are not on the device path yet");
-  if (h->kr.n != (size_t)n) {
-    MG_TRY(h->kr.alloc((size_t)n));
-    MG_TRY(h->kz.alloc((size_t)n));
-    MG_TRY(h->kp.alloc((size_t)n));
-    MG_TRY(h->kAp.alloc((size_t)n));
-  }
-  double* r = h->kr.p;
-  double* z = h->kz.p;
-  double* p = h->kp.p;
-  double* Ap = h->kAp.p;
-  double nr0 = 0.0;
-  MG_TRY(norm_sync(h, b, n, &nr0));
-  long long it = 0, flag = -1;
-  if (nr0 == 0.0) {  // cg returns zeros, flag -9
-    MG_TRY(k_fill(h, x, n, 0.0));
-    HIP_TRY(spin_sync(h->stream));
-    if (iters) *iters = 0;
-    if (flag_out) *flag_out = -9;
-    return MG_OK;
-  }
-  MG_TRY(k_residual(h, 0, L.A, b, x, r));                              // r = b - A(x)
-  MG_TRY(cycle_dev(h, r, z, true));                                    // z = M(r), x = 0 on entry
-  HIP_TRY(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
-  // Three passes of the textbook loop are folded into their neighbours (same values, fewer sweeps over the vectors and one
-  // host synchronisation less per iteration): gamma = r'z of iteration k+1 IS z'r of iteration k (computed once); p'Ap comes
-  // out of the product kernel where the marching kernel serves A (partials of p[row]*Ap[row]); ||r||^2 out of the update.
-  double gamma = 0.0;
-  MG_TRY(dot_sync(h, r, z, n, &gamma));
-  const int nb_upd = (int)std::min<long long>(grid_for(n), (long long)h->partial.n);
-  for (long long k = 1; k <= maxIter; ++k) {
-    it = k;
-    double pAp = 0.0, rn = 0.0;
-    MG_TRY(k_spmv_dot(h, 0, L.A, p, Ap, &pAp));                        // Ap = A(p), p'Ap
-    const double alpha = gamma / pAp;
-    if (std::isinf(alpha) || alpha < 0.0) { flag = -2; break; }
-    hipLaunchKernelGGL(mgk::cg_update_xr_norm, dim3(nb_upd), dim3(mgk::BLK), 0, h->stream, alpha, p, Ap, x, r, n, h->partial.p);
-    launch_sum_final(h, h->partial.p, nb_upd);
-    HIP_TRY(hipGetLastError());
-    MG_TRY(scalar_sync(h, &rn));
-    if (resvec) resvec[k - 1] = rn / nr0;
-    if (rn / nr0 <= tol) { flag = 0; break; }
-    MG_TRY(cycle_dev(h, r, z, true));
-    double zr = 0.0;
-    MG_TRY(dot_sync(h, z, r, n, &zr));
-    const double beta = zr / gamma;
-    gamma = zr;                                                        // = r'z at the top of the next iteration
-    hipLaunchKernelGGL(mgk::cg_update_p, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, beta, z, p, n);
-    HIP_TRY(hipGetLastError());
-  }
-  HIP_TRY(spin_sync(h->stream));
-  if (iters) *iters = it;
-  if (flag_out) *flag_out = flag;
-  return MG_OK;
-}
-
-// Preconditioned BiCGSTAB with the multigrid cycle as M1 (M2 = identity): solveBiCGSTAB_MG (SolveFuncs.jl:87-101)
-// -> KrylovMethods.bicgstb (v0.6.0, un-vendored).  Restated from the published algorithm (van der Vorst 1992 as in
-// Barrett et al., "Templates", which KrylovMethods follows): resvec[0] = ||r0||/||b||, then two entries per
-// iteration (||s||/||b|| after the first half step, ||r||/||b|| after the second); flags: 0 converged,
-// -1 maxIter, -2 breakdown (rho == 0 or omega == 0), -3 converged on the half step, -9 b == 0.
-int bicgstab_dev(mg_hierarchy* h, const double* b, double* x, double tol, long long maxIter, long long* iters,
-                 long long* flag_out, double* resvec, long long* nres) {
-  Level& L = h->lev[0];
-  const long long n = L.n;
-  if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "mg_bicgstab: block right-hand sides (blockBiCGSTB) are not on the device path yet");
-  if (h->kr.n != (size_t)n) {
-    MG_TRY(h->kr.alloc((size_t)n));
-    MG_TRY(h->kz.alloc((size_t)n));
-    MG_TRY(h->kp.alloc((size_t)n));
-    MG_TRY(h->kAp.alloc((size_t)n));
-  }
-  if (h->kw.n != (size_t)n * 4) MG_TRY(h->kw.alloc((size_t)n * 4));
-  double* r = h->kr.p;       // residual, then s
-  double* phat = h->kz.p;    // M p / M s
-  double* p = h->kp.p;
-  double* v = h->kAp.p;
-  double* rtld = h->kw.p;
-  double* t = h->kw.p + n;
-  double* shat = h->kw.p + 2 * n;
-  double bn = 0.0, err = 0.0;
-  MG_TRY(norm_sync(h, b, n, &bn));
-  long long it = 0, flag = -1, nr = 0;
-  if (bn == 0.0) {
-    MG_TRY(k_fill(h, x, n, 0.0));
-    HIP_TRY(spin_sync(h->stream));
-    if (iters) *iters = 0;
-    if (flag_out) *flag_out = -9;
-    if (nres) *nres = 0;
-    return MG_OK;
-  }
-  MG_TRY(k_residual(h, 0, L.A, b, x, r));
-  MG_TRY(norm_sync(h, r, n, &err));
-  err /= bn;
-  if (resvec) resvec[nr] = err;
-  ++nr;
-  if (err < tol) {
-    if (iters) *iters = 0;
-    if (flag_out) *flag_out = 0;
-    if (nres) *nres = nr;
-    return MG_OK;
-  }
-  HIP_TRY(hipMemcpyAsync(rtld, r, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
-  double omega = 1.0, alpha = 0.0, rho1 = 0.0;
-  for (long long k = 1; k <= maxIter; ++k) {
-    it = k;
-    double rho = 0.0;
-    MG_TRY(dot_sync(h, rtld, r, n, &rho));
-    if (rho == 0.0) { flag = -2; break; }
-    if (k > 1) {
-      const double beta = (rho / rho1) * (alpha / omega);
-      MG_TRY(k_axpby(h, -omega, v, 1.0, p, n));      // p = p - omega v
-      MG_TRY(k_axpby(h, 1.0, r, beta, p, n));        // p = r + beta p
-    } else {
-      HIP_TRY(hipMemcpyAsync(p, r, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
-    }
-    MG_TRY(cycle_dev(h, p, phat, true));              // p_hat = M1(p)
-    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, phat, 0.0, v));
-    double rv = 0.0;
-    MG_TRY(dot_sync(h, rtld, v, n, &rv));
-    alpha = rho / rv;
-    MG_TRY(k_axpby(h, -alpha, v, 1.0, r, n));         // s = r - alpha v (in r)
-    double sn = 0.0;
-    MG_TRY(norm_sync(h, r, n, &sn));
-    if (resvec) resvec[nr] = sn / bn;
-    ++nr;
-    if (sn / bn < tol) {                              // converged on the half step
-      MG_TRY(k_axpby(h, alpha, phat, 1.0, x, n));
-      flag = -3;
-      break;
-    }
-    MG_TRY(cycle_dev(h, r, shat, true));              // s_hat = M1(s)
-    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, shat, 0.0, t));
-    double ts = 0.0, tt = 0.0;
-    MG_TRY(dot_sync(h, t, r, n, &ts));
-    MG_TRY(dot_sync(h, t, t, n, &tt));
-    omega = ts / tt;
-    MG_TRY(k_axpby(h, alpha, phat, 1.0, x, n));
-    MG_TRY(k_axpby(h, omega, shat, 1.0, x, n));       // x += alpha p_hat + omega s_hat
-    MG_TRY(k_axpby(h, -omega, t, 1.0, r, n));         // r = s - omega t
-    MG_TRY(norm_sync(h, r, n, &err));
-    err /= bn;
-    if (resvec) resvec[nr] = err;
-    ++nr;
-    if (err <= tol) { flag = 0; break; }
-    if (omega == 0.0) { flag = -2; break; }
-    rho1 = rho;
-  }
-  HIP_TRY(spin_sync(h->stream));
-  if (iters) *iters = it;
-  if (flag_out) *flag_out = flag;
-  if (nres) *nres = nr;
-  return MG_OK;
-}
-
-// Flexible restarted GMRES with the multigrid cycle as (right) preconditioner: solveGMRES_MG (SolveFuncs.jl:119-133)
-// -> KrylovMethods.fgmres (v0.6.0, un-vendored), restated from the published algorithm (Saad's FGMRES(m): modified
-// Gram-Schmidt Arnoldi, Givens rotations, residual estimate |s_{i+1}|/||b|| after every inner step).  maxIter counts
-// restarts, `inner` is the Krylov dimension; resvec gets one entry per inner step; flag 0 converged, -1 not, -9 b = 0.
-// Flexible restarted GMRES on level `lv` (0-based).  precond 0: one multigrid cycle from level 0 (solveGMRES_MG,
-// lv must be 0); precond 1: z = dprec .* v (the Jacobi-preconditioned coarsest solve, MGcycle.jl:152-168).
-int fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>& work, const double* b,
-                double* x, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
-                double* resvec, long long* nres) {
-  Level& L = h->lev[(size_t)lv];
-  const long long n = L.n;
-  if (h->nrhs != 1) return fail(MG_ERR_UNSUPPORTED, "fgmres: block right-hand sides (blockFGMRES) are not on the device path yet");
-  if (inner < 1 || inner > 64) return fail(MG_ERR_INVALID, "inner must be in [1,64]");
-  const int m = (int)inner;
-  if (work.n != (size_t)n * (size_t)(2 * m + 2)) MG_TRY(work.alloc((size_t)n * (size_t)(2 * m + 2)));
-  double* V = work.p;                         // m+1 basis vectors
-  double* Z = work.p + (size_t)(m + 1) * n;   // m preconditioned vectors
-  double* r = Z + (size_t)m * n;               // residual / w
-  double bn = 0.0, rn = 0.0;
-  MG_TRY(norm_sync(h, b, n, &bn));
-  long long nr = 0, flag = -1, total = 0;
-  if (bn == 0.0) {
-    MG_TRY(k_fill(h, x, n, 0.0));
-    HIP_TRY(spin_sync(h->stream));
-    if (iters) *iters = 0;
-    if (flag_out) *flag_out = -9;
-    if (nres) *nres = 0;
-    return MG_OK;
-  }
-  MG_TRY(k_residual(h, lv, L.A, b, x, r));
-  MG_TRY(norm_sync(h, r, n, &rn));
-  double err = rn / bn;
-  if (err < tol) {
-    if (iters) *iters = 0;
-    if (flag_out) *flag_out = 0;
-    if (nres) *nres = 0;
-    return MG_OK;
-  }
-  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs((size_t)m, 0.0), sn((size_t)m, 0.0), s((size_t)m + 1, 0.0), y((size_t)m, 0.0);
-  auto Hat = [&](int i, int j) -> double& { return H[(size_t)i * m + j]; };
-  for (long long it = 1; it <= maxIter && flag != 0; ++it) {
-    MG_TRY(k_axpby(h, 1.0 / rn, r, 0.0, V, n));                          // V[:,1] = r/||r||
-    std::fill(s.begin(), s.end(), 0.0);
-    s[0] = rn;
-    int used = 0;
-    for (int i = 0; i < m; ++i) {
-      double* vi = V + (size_t)i * n;
-      double* zi = Z + (size_t)i * n;
-      double* w = V + (size_t)(i + 1) * n;
-      if (precond == 0) MG_TRY(cycle_dev(h, vi, zi, true));               // z = M(V[:,i])
-      else MG_TRY(k_dscale(h, lv, dprec, vi, zi, n));
-      MG_TRY(k_spmv(h, lv, MG_K_SPMV, L.A, 1.0, zi, 0.0, w));             // w = A z
-      // modified Gram-Schmidt with the chain dot -> update -> dot on the device: h_k = w.V_k stays in HBM, the update
-      // w -= h_k V_k reads it there and produces the partials of the next dot (or of ||w||^2) in the same pass; the i+2
-      // scalars come back in ONE readback per inner step (round 2: one host synchronisation instead of i+2)
-      if (h->opt.no_mgs_chain) {   // (A/B: one dot, one host synchronisation and one update per basis vector)
-        for (int k = 0; k <= i; ++k) {
-          double hk = 0.0;
-          MG_TRY(dot_sync(h, w, V + (size_t)k * n, n, &hk));
-          Hat(k, i) = hk;
-          MG_TRY(k_axpby(h, -hk, V + (size_t)k * n, 1.0, w, n));
-        }
-        double wn = 0.0;
-        MG_TRY(norm_sync(h, w, n, &wn));
-        Hat(i + 1, i) = wn;
-        if (wn != 0.0) MG_TRY(k_axpby(h, 1.0 / wn, w, 0.0, w, n));
-      } else {
-        if (h->kscal.n < (size_t)m + 2) MG_TRY(h->kscal.alloc((size_t)m + 2));
-        if (!h->h_kscal) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_kscal), sizeof(double) * 66));
-        const int nb = (int)std::min<long long>(h->nred_blocks, std::max<long long>(1, (n / 2 + mgk::BLK - 1) / mgk::BLK));
-        double* hd = h->kscal.p;
-        hipLaunchKernelGGL(mgk::dot_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, w, V, n, h->partial.p);
-        hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb, hd);
-        for (int k = 0; k <= i; ++k) {
-          hipLaunchKernelGGL(mgk::mgs_step, dim3(nb), dim3(mgk::BLK), 0, h->stream, hd + k, V + (size_t)k * n, w,
-                             k < i ? V + (size_t)(k + 1) * n : (const double*)nullptr, n, h->partial.p);
-          hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb, hd + k + 1);
-        }
-        hipLaunchKernelGGL(mgk::scale_rsqrt, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, hd + i + 1, w, n);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->h_kscal, hd, sizeof(double) * (size_t)(i + 2), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(spin_sync(h->stream));
-        for (int k = 0; k <= i; ++k) Hat(k, i) = h->h_kscal[k];
-        Hat(i + 1, i) = std::sqrt(h->h_kscal[i + 1]);
-      }
-      for (int k = 0; k < i; ++k) {                                       // previous rotations
-        const double t = cs[(size_t)k] * Hat(k, i) + sn[(size_t)k] * Hat(k + 1, i);
-        Hat(k + 1, i) = -sn[(size_t)k] * Hat(k, i) + cs[(size_t)k] * Hat(k + 1, i);
-        Hat(k, i) = t;
-      }
-      const double a = Hat(i, i), bq = Hat(i + 1, i);
-      const double rr = std::hypot(a, bq);
-      cs[(size_t)i] = (rr == 0.0) ? 1.0 : a / rr;
-      sn[(size_t)i] = (rr == 0.0) ? 0.0 : bq / rr;
-      Hat(i, i) = rr;
-      Hat(i + 1, i) = 0.0;
-      s[(size_t)i + 1] = -sn[(size_t)i] * s[(size_t)i];
-      s[(size_t)i] = cs[(size_t)i] * s[(size_t)i];
-      err = std::fabs(s[(size_t)i + 1]) / bn;
-      if (resvec) resvec[nr] = err;
-      ++nr;
-      ++total;
-      used = i + 1;
-      if (err <= tol) { flag = 0; break; }
-    }
-    for (int i = used - 1; i >= 0; --i) {                                 // y = H \ s (upper triangular)
-      double acc = s[(size_t)i];
-      for (int k = i + 1; k < used; ++k) acc -= Hat(i, k) * y[(size_t)k];
-      y[(size_t)i] = acc / Hat(i, i);
-    }
-    for (int i = 0; i < used; ++i) MG_TRY(k_axpby(h, y[(size_t)i], Z + (size_t)i * n, 1.0, x, n));   // x += Z y
-    if (flag == 0) break;
-    MG_TRY(k_residual(h, lv, L.A, b, x, r));
-    MG_TRY(norm_sync(h, r, n, &rn));
-    err = rn / bn;
-    if (err <= tol) { flag = 0; break; }
-  }
-  HIP_TRY(spin_sync(h->stream));
-  if (iters) *iters = total;
-  if (flag_out) *flag_out = flag;
-  if (nres) *nres = nr;
-  return MG_OK;
-}
-
-int fgmres_dev(mg_hierarchy* h, const double* b, double* x, long long inner, double tol, long long maxIter,
-               long long* iters, long long* flag_out, double* resvec, long long* nres) {
-  return fgmres_core(h, 0, 0, nullptr, h->kw, b, x, inner, tol, maxIter, iters, flag_out, resvec, nres);
-}
-
-// ---- block Krylov drivers (SolveFuncs.jl:95,113,130 -> KrylovMethods.blockBiCGSTB / blockCG / blockFGMRES) -----------
-// The package is not vendored; the published algorithms (O'Leary's block CG, El Guennouni-Jbilou-
-// Sadok block BiCGSTAB, block flexible GMRES) are implemented here with every n x k block resident in HBM (row-major [n][k], k <= 16): products with A
-// are SpMM launches, the preconditioner is one cycle on the whole block, k x k Gram matrices come back through one
-// 8*k*k-byte readback each, and the small dense algebra (pseudo-inverse, LU solve, triangular factor, block least
-// squares) runs on the host.
-struct SmallMat {   // row-major dense helper, host
-  int r = 0, c = 0;
-  std::vector<double> a;
-  SmallMat() {}
-  SmallMat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
-  double& operator()(int i, int j) { return a[(size_t)i * c + j]; }
-  double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
-};
-SmallMat sm_mul(const SmallMat& A, const SmallMat& B) {
-  SmallMat C(A.r, B.c);
-  for (int i = 0; i < A.r; ++i)
-    for (int k = 0; k < A.c; ++k) {
-      const double v = A(i, k);
-      for (int j = 0; j < B.c; ++j) C(i, j) += v * B(k, j);
-    }
-  return C;
-}
-SmallMat sm_T(const SmallMat& A) {
-  SmallMat C(A.c, A.r);
-  for (int i = 0; i < A.r; ++i)
-    for (int j = 0; j < A.c; ++j) C(j, i) = A(i, j);
-  return C;
-}
-// X = A \ B by Gaussian elimination with partial pivoting (A k x k); false if singular
-bool sm_solve(SmallMat A, SmallMat B, SmallMat& X) {
-  const int k = A.r;
-  for (int p = 0; p < k; ++p) {
-    int piv = p;
-    for (int i = p + 1; i < k; ++i)
-      if (std::fabs(A(i, p)) > std::fabs(A(piv, p))) piv = i;
-    if (A(piv, p) == 0.0) return false;
-    if (piv != p) {
-      for (int j = 0; j < k; ++j) std::swap(A(p, j), A(piv, j));
-      for (int j = 0; j < B.c; ++j) std::swap(B(p, j), B(piv, j));
-    }
-    for (int i = p + 1; i < k; ++i) {
-      const double f = A(i, p) / A(p, p);
-      if (f == 0.0) continue;
-      for (int j = p; j < k; ++j) A(i, j) -= f * A(p, j);
-      for (int j = 0; j < B.c; ++j) B(i, j) -= f * B(p, j);
-    }
-  }
-  X = SmallMat(k, B.c);
-  for (int j = 0; j < B.c; ++j)
-    for (int i = k - 1; i >= 0; --i) {
-      double acc = B(i, j);
-      for (int t = i + 1; t < k; ++t) acc -= A(i, t) * X(t, j);
-      X(i, j) = acc / A(i, i);
-    }
-  return true;
-}
-// upper triangular Rf with G = Rf'Rf for a positive SEMI-definite Gram matrix
-SmallMat sm_chol_semidefinite(const SmallMat& G, double rtol = 1e-14) {
-  const int k = G.r;
-  SmallMat R(k, k);
-  for (int c = 0; c < k; ++c) {
-    double d = G(c, c);
-    for (int a = 0; a < c; ++a) d -= R(a, c) * R(a, c);
-    if (G(c, c) <= 0.0 || d <= rtol * G(c, c)) continue;
-    R(c, c) = std::sqrt(d);
-    for (int j = c + 1; j < k; ++j) {
-      double t = G(c, j);
-      for (int a = 0; a < c; ++a) t -= R(a, c) * R(a, j);
-      R(c, j) = t / R(c, c);
-    }
-  }
-  return R;
-}
-// T with W*T = W*Rf^+: T[:,c] = (e_c - T[:,:c] Rf[:c,c]) / Rf[c,c], zero for zero pivots
-SmallMat sm_tri_pinv(const SmallMat& R) {
-  const int k = R.r;
-  SmallMat T(k, k);
-  for (int c = 0; c < k; ++c) {
-    if (R(c, c) == 0.0) continue;
-    for (int i = 0; i < k; ++i) {
-      double t = (i == c) ? 1.0 : 0.0;
-      for (int a = 0; a < c; ++a) t -= T(i, a) * R(a, c);
-      T(i, c) = t / R(c, c);
-    }
-  }
-  return T;
-}
-// min || xi - H Y ||_F over Y by Householder QR of H (rows x cols, rows >= cols); returns the residual norm
-double sm_lstsq(SmallMat H, SmallMat xi, SmallMat& Y) {
-  const int m = H.r, n = H.c, k = xi.c;
-  for (int j = 0; j < n; ++j) {
-    double nrm = 0.0;
-    for (int i = j; i < m; ++i) nrm += H(i, j) * H(i, j);
-    nrm = std::sqrt(nrm);
-    if (nrm == 0.0) continue;
-    const double alpha = H(j, j) > 0 ? -nrm : nrm;
-    std::vector<double> v((size_t)m, 0.0);
-    for (int i = j; i < m; ++i) v[(size_t)i] = H(i, j);
-    v[(size_t)j] -= alpha;
-    double vn = 0.0;
-    for (int i = j; i < m; ++i) vn += v[(size_t)i] * v[(size_t)i];
-    if (vn == 0.0) continue;
-    for (int c = j; c < n; ++c) {
-      double d = 0.0;
-      for (int i = j; i < m; ++i) d += v[(size_t)i] * H(i, c);
-      d *= 2.0 / vn;
-      for (int i = j; i < m; ++i) H(i, c) -= d * v[(size_t)i];
-    }
-    for (int c = 0; c < k; ++c) {
-      double d = 0.0;
-      for (int i = j; i < m; ++i) d += v[(size_t)i] * xi(i, c);
-      d *= 2.0 / vn;
-      for (int i = j; i < m; ++i) xi(i, c) -= d * v[(size_t)i];
-    }
-  }
-  Y = SmallMat(n, k);
-  for (int c = 0; c < k; ++c)
-    for (int i = n - 1; i >= 0; --i) {
-      double acc = xi(i, c);
-      for (int t = i + 1; t < n; ++t) acc -= H(i, t) * Y(t, c);
-      Y(i, c) = (H(i, i) != 0.0) ? acc / H(i, i) : 0.0;
-    }
-  double res = 0.0;
-  for (int i = n; i < m; ++i)
-    for (int c = 0; c < k; ++c) res += xi(i, c) * xi(i, c);
-  return std::sqrt(res);
-}
-
-// G = X'Y (k x k) to the host; synchronises the stream
-int blk_gram(mg_hierarchy* h, const double* X, const double* Y, long long n, int k, SmallMat& G) {
-  const int nb = (int)std::min<long long>(256, std::max<long long>(1, (n + mgk::BLK - 1) / mgk::BLK));
-  if (h->blk_partial.n < (size_t)nb * k * k + (size_t)k * k) MG_TRY(h->blk_partial.alloc((size_t)nb * k * k + (size_t)k * k));
-  if (!h->h_blk) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_blk), sizeof(double) * mgk::BLK_KMAX * mgk::BLK_KMAX));
-  double* out = h->blk_partial.p + (size_t)nb * k * k;
-  hipLaunchKernelGGL(mgk::blk_gram_partial, dim3(nb, k), dim3(mgk::BLK), 0, h->stream, X, Y, n, k, h->blk_partial.p);
-  hipLaunchKernelGGL(mgk::blk_gram_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->blk_partial.p, nb, k, out);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h->h_blk, out, sizeof(double) * k * k, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(spin_sync(h->stream));
-  G = SmallMat(k, k);
-  std::memcpy(G.a.data(), h->h_blk, sizeof(double) * k * k);
-  return MG_OK;
-}
-// out = s*add + in*C   (add may be null; out may alias in or add)
-int blk_comb(mg_hierarchy* h, double* out, const double* add, double s, const double* in, const SmallMat& Cm, long long n, int k) {
-  if (h->blk_c.n < (size_t)mgk::BLK_KMAX * mgk::BLK_KMAX * 8) MG_TRY(h->blk_c.alloc((size_t)mgk::BLK_KMAX * mgk::BLK_KMAX * 8));
-  // a ring of 8 coefficient slots (pinned host + device): copies are asynchronous and earlier launches may still read
-  // theirs; the stream is drained once per lap of the ring
-  constexpr size_t SLOT = (size_t)mgk::BLK_KMAX * mgk::BLK_KMAX;
-  if (!h->h_blk_c) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_blk_c), sizeof(double) * SLOT * 8));
-  const unsigned si = h->blk_c_next++ % 8;
-  if (si == 0 && h->blk_c_next > 1) HIP_TRY(spin_sync(h->stream));
-  double* slot = h->blk_c.p + si * SLOT;
-  std::memcpy(h->h_blk_c + si * SLOT, Cm.a.data(), sizeof(double) * k * k);
-  HIP_TRY(hipMemcpyAsync(slot, h->h_blk_c + si * SLOT, sizeof(double) * k * k, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(mgk::blk_comb, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, out, add, s, in, slot, n, k);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-SmallMat sm_scaled_identity(int k, double v) {
-  SmallMat I(k, k);
-  for (int i = 0; i < k; ++i) I(i, i) = v;
-  return I;
-}
-int blk_colnorms(mg_hierarchy* h, const double* X, long long n, int k, std::vector<double>& out) {
-  SmallMat G;
-  MG_TRY(blk_gram(h, X, X, n, k, G));
-  out.assign((size_t)k, 0.0);
-  for (int j = 0; j < k; ++j) out[(size_t)j] = std::sqrt(std::max(0.0, G(j, j)));
-  return MG_OK;
-}
-int blk_work(mg_hierarchy* h, size_t nblocks, long long n, int k, double** base) {
-  const size_t need = nblocks * (size_t)n * (size_t)k;
-  if (h->kw.n < need) MG_TRY(h->kw.alloc(need));
-  *base = h->kw.p;
-  return MG_OK;
-}
-
-// blockCG (O'Leary 1980): Alpha = pinv(P'Q) P'R ; X += P Alpha ; R -= Q Alpha ; Beta = -pinv(P'Q) Q'Z ; P = Z + P Beta
-int block_pcg_dev(mg_hierarchy* h, const double* B, double* X, double tol, long long maxIter, long long* iters,
-                  long long* flag_out, double* resmat) {
-  Level& L = h->lev[0];
-  const long long n = L.n;
-  const int k = (int)h->nrhs;
-  if (k > mgk::BLK_KMAX) return fail(MG_ERR_UNSUPPORTED, "block Krylov drivers hold at most %d right-hand sides", mgk::BLK_KMAX);
-  const size_t len = (size_t)n * k;
-  double* w = nullptr;
-  MG_TRY(blk_work(h, 4, n, k, &w));
-  double *R = w, *Z = w + len, *P = w + 2 * len, *Q = w + 3 * len;
-  std::vector<double> nb, rn;
-  MG_TRY(blk_colnorms(h, B, n, k, nb));
-  long long it = 0, flag = -1;
-  bool any = false;
-  for (double v : nb) any = any || v > 0.0;
-  if (!any) {
-    MG_TRY(k_fill(h, X, (long long)len, 0.0));
-    HIP_TRY(spin_sync(h->stream));
-    if (iters) *iters = 0;
-    if (flag_out) *flag_out = -9;
-    return MG_OK;
-  }
-  for (double& v : nb) if (!(v > 0.0)) v = 1.0;
-  MG_TRY(k_residual(h, 0, L.A, B, X, R));                         // R = B - A X
-  MG_TRY(cycle_dev(h, R, Z, true));                               // Z = M(R)
-  HIP_TRY(hipMemcpyAsync(P, Z, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
-  for (long long iter = 1; iter <= maxIter; ++iter) {
-    it = iter;
-    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, P, 0.0, Q));         // Q = A P
-    SmallMat PTQ, PTR, QTZ;
-    MG_TRY(blk_gram(h, P, Q, n, k, PTQ));
-    MG_TRY(blk_gram(h, P, R, n, k, PTR));
-    std::vector<double> Hs((size_t)k * k), Pinv;
-    for (int i = 0; i < k; ++i)
-      for (int j = 0; j < k; ++j) Hs[(size_t)i * k + j] = 0.5 * (PTQ(i, j) + PTQ(j, i));
-    pinv_sym(Hs, k, Pinv);
-    SmallMat Pi(k, k);
-    Pi.a = Pinv;
-    const SmallMat Alpha = sm_mul(Pi, PTR);
-    MG_TRY(blk_comb(h, X, X, 1.0, P, Alpha, n, k));               // X += P Alpha
-    SmallMat negAlpha = Alpha;
-    for (double& v : negAlpha.a) v = -v;
-    MG_TRY(blk_comb(h, R, R, 1.0, Q, negAlpha, n, k));            // R -= Q Alpha
-    MG_TRY(blk_colnorms(h, R, n, k, rn));
-    double worst = 0.0;
-    for (int j = 0; j < k; ++j) {
-      const double rel = rn[(size_t)j] / nb[(size_t)j];
-      if (resmat) resmat[(size_t)(iter - 1) * k + j] = rel;
-      worst = std::max(worst, rel);
-    }
-    if (worst <= tol) { flag = 0; break; }
-    MG_TRY(cycle_dev(h, R, Z, true));
-    MG_TRY(blk_gram(h, Q, Z, n, k, QTZ));
-    SmallMat Beta = sm_mul(Pi, QTZ);
-    for (double& v : Beta.a) v = -v;
-    MG_TRY(blk_comb(h, P, Z, 1.0, P, Beta, n, k));                // P = Z + P Beta
-  }
-  HIP_TRY(spin_sync(h->stream));
-  if (iters) *iters = it;
-  if (flag_out) *flag_out = flag;
-  return MG_OK;
-}
-
-// blockBiCGSTB (El Guennouni, Jbilou, Sadok 2003), right-preconditioned by the cycle
-int block_bicgstab_dev(mg_hierarchy* h, const double* B, double* X, double tol, long long maxIter, long long* iters,
-                       long long* flag_out, double* resvec, long long* nres) {
-  Level& L = h->lev[0];
-  const long long n = L.n;
-  const int k = (int)h->nrhs;
-  if (k > mgk::BLK_KMAX) return fail(MG_ERR_UNSUPPORTED, "block Krylov drivers hold at most %d right-hand sides", mgk::BLK_KMAX);
-  const size_t len = (size_t)n * k;
-  double* w = nullptr;
-  MG_TRY(blk_work(h, 7, n, k, &w));
-  double *R = w, *R0 = w + len, *P = w + 2 * len, *Ph = w + 3 * len, *V = w + 4 * len, *Sh = w + 5 * len, *T = w + 6 * len;
-  std::vector<double> nb, rn;
-  MG_TRY(blk_colnorms(h, B, n, k, nb));
-  long long it = 0, flag = -1, nr = 0;
-  bool any = false;
-  for (double v : nb) any = any || v > 0.0;
-  auto finish = [&](long long f) {
-    if (iters) *iters = it;
-    if (flag_out) *flag_out = f;
-    if (nres) *nres = nr;
-    return (int)MG_OK;
-  };
-  if (!any) {
-    MG_TRY(k_fill(h, X, (long long)len, 0.0));
-    HIP_TRY(spin_sync(h->stream));
-    return finish(-9);
-  }
-  for (double& v : nb) if (!(v > 0.0)) v = 1.0;
-  auto worst_rel = [&](const double* blk, double* out) -> int {
-    MG_TRY(blk_colnorms(h, blk, n, k, rn));
-    double wv = 0.0;
-    for (int j = 0; j < k; ++j) wv = std::max(wv, rn[(size_t)j] / nb[(size_t)j]);
-    *out = wv;
-    return MG_OK;
-  };
-  MG_TRY(k_residual(h, 0, L.A, B, X, R));
-  double err = 0.0;
-  MG_TRY(worst_rel(R, &err));
-  if (resvec) resvec[nr] = err;
-  ++nr;
-  if (err < tol) return finish(0);
-  HIP_TRY(hipMemcpyAsync(R0, R, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(P, R, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
-  const SmallMat I1 = sm_scaled_identity(k, 1.0);
-  for (long long iter = 1; iter <= maxIter; ++iter) {
-    it = iter;
-    MG_TRY(cycle_dev(h, P, Ph, true));                            // Phat = M(P)
-    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, Ph, 0.0, V));        // V = A Phat
-    SmallMat RtV, RtR, alpha;
-    MG_TRY(blk_gram(h, R0, V, n, k, RtV));
-    MG_TRY(blk_gram(h, R0, R, n, k, RtR));
-    if (!sm_solve(RtV, RtR, alpha)) { flag = -2; break; }
-    SmallMat nalpha = alpha;
-    for (double& v : nalpha.a) v = -v;
-    MG_TRY(blk_comb(h, R, R, 1.0, V, nalpha, n, k));              // S = R - V alpha   (in R)
-    double sn = 0.0;
-    MG_TRY(worst_rel(R, &sn));
-    if (resvec) resvec[nr] = sn;
-    ++nr;
-    if (sn < tol) {
-      MG_TRY(blk_comb(h, X, X, 1.0, Ph, alpha, n, k));
-      flag = -3;
-      break;
-    }
-    MG_TRY(cycle_dev(h, R, Sh, true));                            // Shat = M(S)
-    MG_TRY(k_spmv(h, 0, MG_K_SPMV, L.A, 1.0, Sh, 0.0, T));        // T = A Shat
-    SmallMat TS, TT;
-    MG_TRY(blk_gram(h, T, R, n, k, TS));
-    MG_TRY(blk_gram(h, T, T, n, k, TT));
-    double ts = 0.0, tt = 0.0;
-    for (int j = 0; j < k; ++j) { ts += TS(j, j); tt += TT(j, j); }
-    if (tt == 0.0) { flag = -2; break; }
-    const double omega = ts / tt;
-    MG_TRY(blk_comb(h, X, X, 1.0, Ph, alpha, n, k));              // X += Phat alpha + omega Shat
-    MG_TRY(blk_comb(h, X, X, 1.0, Sh, sm_scaled_identity(k, omega), n, k));
-    MG_TRY(blk_comb(h, R, R, 1.0, T, sm_scaled_identity(k, -omega), n, k));   // R = S - omega T
-    MG_TRY(worst_rel(R, &err));
-    if (resvec) resvec[nr] = err;
-    ++nr;
-    if (err <= tol) { flag = 0; break; }
-    if (omega == 0.0) { flag = -2; break; }
-    SmallMat RtT, beta;
-    MG_TRY(blk_gram(h, R0, T, n, k, RtT));
-    if (!sm_solve(RtV, RtT, beta)) { flag = -2; break; }
-    for (double& v : beta.a) v = -v;
-    MG_TRY(blk_comb(h, P, P, 1.0, V, sm_scaled_identity(k, -omega), n, k));   // P - omega V
-    MG_TRY(blk_comb(h, P, R, 1.0, P, beta, n, k));                // P = R + (P - omega V) beta
-  }
-  HIP_TRY(spin_sync(h->stream));
-  return finish(flag);
-}
-
-// W -> orthonormal block (in place) by Cholesky QR applied twice; Rf with W_in = Q Rf
-int blk_cholqr(mg_hierarchy* h, double* W, long long n, int k, SmallMat& Rf) {
-  SmallMat G;
-  MG_TRY(blk_gram(h, W, W, n, k, G));
-  const SmallMat R1 = sm_chol_semidefinite(G);
-  MG_TRY(blk_comb(h, W, nullptr, 0.0, W, sm_tri_pinv(R1), n, k));
-  MG_TRY(blk_gram(h, W, W, n, k, G));
-  const SmallMat R2 = sm_chol_semidefinite(G);
-  MG_TRY(blk_comb(h, W, nullptr, 0.0, W, sm_tri_pinv(R2), n, k));
-  Rf = sm_mul(R2, R1);
-  return MG_OK;
-}
-
-// blockFGMRES: block flexible GMRES(inner), block modified Gram-Schmidt, exact block least squares per inner step
-// lv: the level whose A is solved; precond 0: Z = one cycle from x = 0 (level 0 only), 1: Z = dprec .* V (the Jacobi
-// preconditioner of the coarsest-level GMRES branch, MGcycle.jl:157-159); work: own work space (nullptr: the block drivers')
-int block_fgmres_core(mg_hierarchy* h, int lv, int precond, const double* dprec, DevBuf<double>* work, const double* B,
-                      double* X, long long inner, double tol, long long maxIter, long long* iters, long long* flag_out,
-                      double* resvec, long long* nres) {
-  Level& L = h->lev[(size_t)lv];
-  const long long n = L.n;
-  const int k = (int)h->nrhs;
-  if (k > mgk::BLK_KMAX) return fail(MG_ERR_UNSUPPORTED, "block Krylov drivers hold at most %d right-hand sides", mgk::BLK_KMAX);
-  if (inner < 1 || inner > 64) return fail(MG_ERR_INVALID, "inner must be in [1,64]");
-  if (precond == 0 && lv != 0) return fail(MG_ERR_INVALID, "the cycle preconditions the fine level only");
-  const int m = (int)inner;
-  const size_t len = (size_t)n * k;
-  double* w = nullptr;
-  if (work) {
-    const size_t need = (size_t)(2 * m + 2) * len;
-    if (work->n < need) MG_TRY(work->alloc(need));
-    w = work->p;
-  } else {
-    MG_TRY(blk_work(h, (size_t)(2 * m + 2), n, k, &w));
-  }
-  double* Vb = w;                              // m+1 blocks
-  double* Zb = w + (size_t)(m + 1) * len;      // m blocks
-  double* R = Zb + (size_t)m * len;            // residual / W
-  long long nr = 0, flag = -1, total = 0;
-  auto finish = [&](long long f) {
-    if (iters) *iters = total;
-    if (flag_out) *flag_out = f;
-    if (nres) *nres = nr;
-    return (int)MG_OK;
-  };
-  auto fro = [&](const double* blk, double* out) -> int {
-    std::vector<double> cn;
-    MG_TRY(blk_colnorms(h, blk, n, k, cn));
-    double s2 = 0.0;
-    for (double v : cn) s2 += v * v;
-    *out = std::sqrt(s2);
-    return MG_OK;
-  };
-  double bn = 0.0, rn = 0.0;
-  MG_TRY(fro(B, &bn));
-  if (bn == 0.0) {
-    MG_TRY(k_fill(h, X, (long long)len, 0.0));
-    HIP_TRY(spin_sync(h->stream));
-    return finish(-9);
-  }
-  MG_TRY(k_residual(h, lv, L.A, B, X, R));
-  MG_TRY(fro(R, &rn));
-  if (rn / bn < tol) return finish(0);
-  for (long long it = 1; it <= maxIter && flag != 0; ++it) {
-    SmallMat H((m + 1) * k, m * k), xi((m + 1) * k, k), Rf, Y;
-    HIP_TRY(hipMemcpyAsync(Vb, R, sizeof(double) * len, hipMemcpyDeviceToDevice, h->stream));
-    MG_TRY(blk_cholqr(h, Vb, n, k, Rf));
-    for (int i = 0; i < k; ++i)
-      for (int j = 0; j < k; ++j) xi(i, j) = Rf(i, j);
-    int used = 0;
-    for (int j = 0; j < m; ++j) {
-      double* Vj = Vb + (size_t)j * len;
-      double* Zj = Zb + (size_t)j * len;
-      double* W = Vb + (size_t)(j + 1) * len;
-      if (precond == 0) MG_TRY(cycle_dev(h, Vj, Zj, true));        // Z_j = M(V_j)
-      else MG_TRY(k_dscale(h, lv, dprec, Vj, Zj, n));
-      MG_TRY(k_spmv(h, lv, MG_K_SPMV, L.A, 1.0, Zj, 0.0, W));      // W = A Z_j
-      for (int i = 0; i <= j; ++i) {                               // block modified Gram-Schmidt
-        SmallMat Hij;
-        MG_TRY(blk_gram(h, Vb + (size_t)i * len, W, n, k, Hij));
-        for (int a = 0; a < k; ++a)
-          for (int b = 0; b < k; ++b) H(i * k + a, j * k + b) = Hij(a, b);
-        for (double& v : Hij.a) v = -v;
-        MG_TRY(blk_comb(h, W, W, 1.0, Vb + (size_t)i * len, Hij, n, k));
-      }
-      SmallMat Hn;
-      MG_TRY(blk_cholqr(h, W, n, k, Hn));
-      for (int a = 0; a < k; ++a)
-        for (int b = 0; b < k; ++b) H((j + 1) * k + a, j * k + b) = Hn(a, b);
-      SmallMat Hb((j + 2) * k, (j + 1) * k), xb((j + 2) * k, k);
-      for (int a = 0; a < Hb.r; ++a) {
-        for (int b = 0; b < Hb.c; ++b) Hb(a, b) = H(a, b);
-        for (int b = 0; b < k; ++b) xb(a, b) = xi(a, b);
-      }
-      const double err = sm_lstsq(Hb, xb, Y) / bn;
-      if (resvec) resvec[nr] = err;
-      ++nr;
-      ++total;
-      used = j + 1;
-      if (err <= tol) { flag = 0; break; }
-    }
-    for (int j = 0; j < used; ++j) {                               // X += Z_j Y_j
-      SmallMat Yj(k, k);
-      for (int a = 0; a < k; ++a)
-        for (int b = 0; b < k; ++b) Yj(a, b) = Y(j * k + a, b);
-      MG_TRY(blk_comb(h, X, X, 1.0, Zb + (size_t)j * len, Yj, n, k));
-    }
-    if (flag == 0) break;
-    MG_TRY(k_residual(h, lv, L.A, B, X, R));
-    MG_TRY(fro(R, &rn));
-    if (rn / bn <= tol) { flag = 0; break; }
-  }
-  HIP_TRY(spin_sync(h->stream));
-  return finish(flag);
-}
-int block_fgmres_dev(mg_hierarchy* h, const double* B, double* X, long long inner, double tol, long long maxIter,
-                     long long* iters, long long* flag_out, double* resvec, long long* nres) {
-  return block_fgmres_core(h, 0, 0, nullptr, nullptr, B, X, inner, tol, maxIter, iters, flag_out, resvec, nres);
-}
-
-// ---- host <-> device block transfer (column-major host <-> row-major device) --------------------
-int upload_block(mg_hierarchy* h, const double* host, double* dev, long long n, long long nrhs) {
-  const size_t bytes = sizeof(double) * (size_t)n * (size_t)nrhs;
-  if (nrhs == 1) {
-    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream));
-  } else {
-    HIP_TRY(hipMemcpyAsync(h->stage_t.p, host, bytes, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(mgk::colmajor_to_rowmajor, dim3(grid_for(n * nrhs)), dim3(mgk::BLK), 0, h->stream,
-                       h->stage_t.p, dev, n, (int)nrhs);
-    HIP_TRY(hipGetLastError());
-  }
-  return MG_OK;
-}
-int download_block(mg_hierarchy* h, const double* dev, double* host, long long n, long long nrhs) {
-  const size_t bytes = sizeof(double) * (size_t)n * (size_t)nrhs;
-  if (nrhs == 1) {
-    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
-  } else {
-    hipLaunchKernelGGL(mgk::rowmajor_to_colmajor, dim3(grid_for(n * nrhs)), dim3(mgk::BLK), 0, h->stream,
-                       dev, h->stage_t.p, n, (int)nrhs);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host, h->stage_t.p, bytes, hipMemcpyDeviceToHost, h->stream));
-  }
-  HIP_TRY(spin_sync(h->stream));
-  return MG_OK;
-}
-
-// L2-tiled processing order of the row blocks of M, whose rows form an x-fastest n1 x n2 x n3 grid.
-// In natural order two blocks that gather from the same z-neighbour planes are a whole plane apart; when
-// three planes of the gathered vector (x nrhs) exceed an XCD's 4 MiB L2 those gathers miss.  Walking the
-// grid in y-tiles (all z for T consecutive y-lines, then the next tile) brings the reuse distance down to
-// ~2T lines.  Pure scheduling: every block computes exactly what it computed before.
-int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const std::vector<int>& h_blk, int nb,
-                       DevBuf<int>& sched, bool& has);
-// Plane tiles for csr_rowclass_tile_spmv: needs the row-class form without a first-column stream and a grid hint
-// whose plane size divides the row count; the halo is what the most frequent class reaches inside a plane.
-int build_tile(Csr& A, const long long grid[3]) {
-  A.rc_tile = false;
-  if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty()) return MG_OK;
-  if (A.opt.no_tile) return MG_OK;
-  if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != (A.regular_cols >= 0 ? A.regular_cols : A.n_rows)) return MG_OK;
-  const long long P = grid[0] * grid[1];
-  if (P < mgk::RT_CR / 2 || A.n_rows + (mgk::RT_NP + 2) * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
-  // 1024 rows of a plane per workgroup; levels whose 1024-row tiles number fewer than tile_min_wg take 256-row tiles (4 x
-  // the workgroups, a quarter of the threads each) if THOSE fill the chip - else the lane kernel serves the level
-  long long CRt = mgk::RT_CR;
-  {
-    const long long groups = (grid[2] + mgk::RT_NP - 1) / mgk::RT_NP;
-    if (((P + CRt - 1) / CRt) * groups < A.opt.tile_min_wg && !A.opt.no_tile_small && ((P + 255) / 256) * groups >= A.opt.tile_min_wg) CRt = 256;
-  }
-  auto split = [&](long long sh, long long& dz, long long& rest) {
-    dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
-    rest = sh - dz * P;
-  };
-  const int cm = A.rc_major;
-  {
-    const long long min_len = A.opt.stage_min_len;    // as for the window kernel
-    if (A.h_rc_ptr[(size_t)cm + 1] - A.h_rc_ptr[(size_t)cm] < min_len) return MG_OK;
-  }
-  long long halo = 1;
-  for (int k = A.h_rc_ptr[(size_t)cm]; k < A.h_rc_ptr[(size_t)cm + 1]; ++k) {
-    long long dz, rest;
-    split((long long)A.h_rc_delta[(size_t)cm] + A.h_rc_off[(size_t)k], dz, rest);
-    if (dz < -1 || dz > 1) return MG_OK;
-    halo = std::max(halo, rest < 0 ? -rest : rest);
-  }
-  const long long SL = CRt + 2 * halo;
-  if ((mgk::RT_NP + 2) * SL * 8 > 80 * 1024) return MG_OK;   // two workgroups per CU
-  std::vector<int> lbs(A.h_rc_off.size(), -1);
-  for (size_t c = 0; c + 1 < A.h_rc_ptr.size(); ++c)
-    for (int k = A.h_rc_ptr[c]; k < A.h_rc_ptr[c + 1]; ++k) {
-      long long dz, rest;
-      split((long long)A.h_rc_delta[c] + A.h_rc_off[(size_t)k], dz, rest);
-      if (dz >= -1 && dz <= 1 && rest >= -halo && rest <= halo) lbs[(size_t)k] = (int)((dz + 1) * SL + rest + halo);
-    }
-  MG_TRY(A.rt_lb.alloc(lbs.size()));
-  HIP_TRY(hipMemcpy(A.rt_lb.p, lbs.data(), lbs.size() * sizeof(int), hipMemcpyHostToDevice));
-  A.rt_P = (int)P;
-  A.rt_nplanes = (int)grid[2];
-  A.rt_halo = (int)halo;
-  A.rt_lane = !A.opt.no_tile_lane && std::all_of(lbs.begin(), lbs.end(), [](int v) { return v >= 0; }) &&
-              A.rc_ncls * (long long)A.rc_maxlen <= mgk::RT_LCAP &&
-              (mgk::RT_NP + 2) * SL * 8 + A.rc_ncls * (long long)A.rc_maxlen * 16 + A.rc_ncls * 8 <= 80 * 1024;
-  A.rt_cr = (int)CRt;
-  A.rt_chunks = (int)((P + CRt - 1) / CRt);
-  A.rt_nblocks = (int)(((grid[2] + mgk::RT_NP - 1) / mgk::RT_NP) * A.rt_chunks);
-  {
-    // 4096 rows per workgroup: a level that yields fewer workgroups than the chip has CUs is latency-bound and runs
-    // faster on the 256/512-row kernels (C2 level 3, 65^3 rows: 85 workgroups, 26 us against 17 us)
-    if (A.rt_nblocks < A.opt.tile_min_wg) return MG_OK;
-  }
-  A.rc_tile = true;
-  return MG_OK;
-}
-
-// z-marching form (csr_rowclass_march_spmv): same preconditions as the plane tiles; the workgroups are one balanced
-// round of the resident slots (2 per CU), each with at least 8 planes to walk.
-int build_march(Csr& A, const long long grid[3]) {
-  A.rc_march = false;
-  if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march) return MG_OK;
-  // (a padded local operator of a sharded level: the grid is the owned box = its first regular_cols rows)
-  if (grid[0] < 1 || grid[1] < 1 || grid[2] < 2 || grid[0] * grid[1] * grid[2] != (A.regular_cols >= 0 ? A.regular_cols : A.n_rows)) return MG_OK;
-  const long long P = grid[0] * grid[1];
-  if (P < 64 || A.n_rows + 4 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
-  auto split = [&](long long sh, long long& dz, long long& rest) {
-    dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
-    rest = sh - dz * P;
-  };
-  const int cm = A.rc_major;
-  if (A.h_rc_ptr[(size_t)cm + 1] - A.h_rc_ptr[(size_t)cm] < A.opt.stage_min_len) return MG_OK;
-  long long halo = 1;
-  for (int k = A.h_rc_ptr[(size_t)cm]; k < A.h_rc_ptr[(size_t)cm + 1]; ++k) {
-    long long dz, rest;
-    split((long long)A.h_rc_delta[(size_t)cm] + A.h_rc_off[(size_t)k], dz, rest);
-    if (dz < -1 || dz > 1) return MG_OK;
-    halo = std::max(halo, rest < 0 ? -rest : rest);
-  }
-  if (halo > 510) return MG_OK;   // one 16-byte pair per thread covers the slab
-  if (A.rc_ncls > mgk::RM_NCLS || A.rc_entries > mgk::RM_DCAP) return MG_OK;   // the dictionary lives in LDS
-  if (A.rc_maxlen > A.opt.march_max_len) return MG_OK;
-  std::vector<int> lbs(A.h_rc_off.size(), -1);
-  for (size_t c = 0; c + 1 < A.h_rc_ptr.size(); ++c)
-    for (int k = A.h_rc_ptr[c]; k < A.h_rc_ptr[c + 1]; ++k) {
-      long long dz, rest;
-      split((long long)A.h_rc_delta[c] + A.h_rc_off[(size_t)k], dz, rest);
-      if (dz >= -1 && dz <= 1 && rest >= -halo && rest <= halo) lbs[(size_t)k] = (int)(((rest + halo) << 2) | (dz + 1));
-      else return MG_OK;   // an entry outside the staged shifts (not a grid operator / wrong hint): plane tiles + gathers
-    }
-  const long long chunks = (P + mgk::RM_C - 1) / mgk::RM_C;
-  const long long items = chunks * grid[2];
-  int dev = 0, ncu = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const long long nb = std::max<long long>(1, std::min<long long>(A.opt.march_wg_per_cu * ncu, items / 8));
-  if (nb < A.opt.march_min_wg) return MG_OK;   // small levels: latency-bound, the other kernels serve them
-  MG_TRY(A.rm_lb.alloc(lbs.size()));
-  HIP_TRY(hipMemcpy(A.rm_lb.p, lbs.data(), lbs.size() * sizeof(int), hipMemcpyHostToDevice));
-  A.rm_P = (int)P;
-  A.rm_nplanes = (int)grid[2];
-  A.rm_halo = (int)halo;
-  A.rm_chunks = (int)chunks;
-  A.rm_nblocks = (int)nb;
-  A.rc_march = true;
-  // two stages per pass (sweep + residual): no exception rows, x slab of RM_C + 4*halo entries in two 16-byte pairs per
-  // thread, ring of 4 x slabs + 4 t slabs + dictionary within the 160 KB of LDS; one workgroup per CU
-  A.rc_march2 = false;
-  A.rm2_nblocks = (int)std::max<long long>(1, std::min<long long>(ncu, items / 8));
-  if (!A.opt.no_march2 && A.rc_nexc == 0 && A.regular_cols < 0 && 2 * halo <= mgk::RM_C && march2_lds_bytes((int)halo) <= 160 * 1024 - 256 &&
-      A.rm2_nblocks >= std::min<long long>(A.opt.march_min_wg, ncu))
-    A.rc_march2 = true;
-  return MG_OK;
-}
-int build_march3(Csr& A, const long long grid[3]);
-// every staged form of a level's A that depends on the grid hint and on the classes
-int build_staged(Csr& A, const long long grid[3]) {
-  MG_TRY(build_tile(A, grid));
-  MG_TRY(build_march(A, grid));
-  return build_march3(A, grid);
-}
-
-// 2-D tile form of the two-stage pass (csr_rowclass_march3_spmv): the operator must be a grid operator of z-star classes -
-// per class at most one entry in plane z-1 (the first) and one in plane z+1 (the last), both at the row's own in-plane
-// position, and at most RM3_NIP in-plane entries (dy, dx), |dy|, |dx| <= 1 - whose class ids factor as
-// cls(x, y, z) = tab[cz[z]][cy[y]][cx[x]] (found by hashing the three families of grid slices, then VERIFIED row by row).
-// Tile geometry: the stage-1 region is WX = TX + 2 columns wide, an NT-thread workgroup holds SY = NT / WX lines of it per
-// slot pass and K1 passes, so TY = K1*SY - 2; threads per workgroup (1024 with K1 <= 3: 128 registers per lane; 768 with
-// K1 <= 4: 168), tiles per line and K1 are chosen by an estimate of the bytes filled per row (halo, run ends, the partial
-// cache lines at both ends of a tile's line segments), within the LDS (3 x slabs + 2 t slabs + tables <= 160 KB) and the
-// 16-byte pairs a lane can load per slab.  Schedule: lockstep (tiles x segments of planes = about one workgroup per CU, all
-// tiles of a segment on one XCD) when that keeps >= 85 % of the balanced schedule's parallel efficiency.
-struct M3Ent { int dz, dy, dx; };
-int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl, size_t ncls,
-                      const std::vector<std::vector<M3Ent>>& ents, bool var);
-int build_band(Csr& A, const long long grid[3]);
-int band_refill(Csr& A) {
-  const int NS = mgk::RM3_NIP + 2;
-  hipLaunchKernelGGL(mgk::band_fill, dim3((unsigned)((A.n_rows + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, nullptr, A.rowptr.p, A.val.p,
-                     A.vb_cls.p, A.vb_slot.p, NS, A.vband.p, A.vstride, (int)A.n_rows);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  return MG_OK;
-}
-int build_march3(Csr& A, const long long grid[3]) {
-  // band form, same pattern (the pattern of a set operator never changes: mg_replace_values / mg_rap keep it), same grid: only
-  // the values moved - one kernel refills the planar arrays from the CSR values
-  if (!A.has_rc && A.rm3_var && A.rc_march3 && A.rm3.n1 == grid[0] && A.rm3.n2 == grid[1] && A.rm3.nplanes == grid[2] && !A.opt.no_band &&
-      !A.opt.no_march3 && !A.opt.no_march2 && !A.opt.no_march)
-    return band_refill(A);
-  A.rc_march3 = false;
-  A.rc_march4 = false;
-  A.rm3_var = false;
-  A.vband.release();
-  if (!A.has_rc) return build_band(A, grid);
-  if (!A.has_rc || !A.rc_implicit || A.h_rc_ptr.empty() || A.opt.no_march3 || A.opt.no_march2 || A.opt.no_march) return MG_OK;
-  // a box operator of a sharded level (regular_cols >= 0): the grid is the owned box = its first regular_cols rows; the rows
-  // that read the halo are exception rows (class 0xFFFF) and stay so here
-  const bool box = A.regular_cols >= 0;
-  const long long nreg = box ? A.regular_cols : A.n_rows;
-  if (A.rc_nexc != 0 && !box) return MG_OK;
-  A.rc_exc2.release();
-  A.rc_nexc2 = 0;
-  const long long n1 = grid[0], n2 = grid[1], n3 = grid[2];
-  if (n1 < 4 || n2 < 4 || n3 < 3 || n1 * n2 * n3 != nreg) return MG_OK;
-  if (n1 > 65535 || n2 > 65535 || n3 > 65535 || A.h_cls.size() != (size_t)A.n_rows) return MG_OK;
-  const long long P = n1 * n2;
-  if (A.n_rows + 4 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
-  const size_t ncls = A.h_rc_ptr.size() - 1;
-  if (ncls > (size_t)mgk::RM3_NCLS) return MG_OK;
-  // ---- classes: decompose every column shift into (dz, dy, dx) ------------------------------------------------------------
-  using Ent = M3Ent;
-  std::vector<std::vector<Ent>> ents(ncls);
-  for (size_t c = 0; c < ncls; ++c) {
-    int nip = 0;
-    const int k0 = A.h_rc_ptr[c], k1 = A.h_rc_ptr[c + 1];
-    for (int k = k0; k < k1; ++k) {
-      const long long sh = (long long)A.h_rc_delta[c] + A.h_rc_off[(size_t)k];
-      const long long dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
-      const long long rest = sh - dz * P;
-      const long long dy = (rest >= 0) ? (rest + n1 / 2) / n1 : -((-rest + n1 / 2) / n1);
-      const long long dx = rest - dy * n1;
-      if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) return MG_OK;
-      if (dz != 0 && (dy != 0 || dx != 0)) return MG_OK;           // not a z-star
-      if (dz == -1 && k != k0) return MG_OK;                       // the z-1 entry comes first ...
-      if (dz == 1 && k != k1 - 1) return MG_OK;                    // ... the z+1 entry last (ascending columns)
-      if (dz == 0 && ++nip > mgk::RM3_NIP) return MG_OK;
-      ents[c].push_back({(int)dz, (int)dy, (int)dx});
-    }
-  }
-  return build_march3_impl(A, grid, A.h_cls.data(), ncls, ents, false);
-}
-
-// Band form (csr_rowclass_march3_spmv<..., VAR = true>) of a grid operator that has NO row classes because its coefficients
-// differ from row to row: classes of the STRUCTURE (the sorted list of column shifts of a row), which must be z-stars and
-// factor as a product map exactly like the value classes of build_march3, and the values re-laid as 7 planar arrays
-// (slot 0 the z-1 entry, 1..5 the in-plane entries in stored order, 6 the z+1 entry; 0 where a row has none).  Built from the
-// device's CSR arrays (copied back once), re-built whenever build_staged runs again (new values: replaceMatrixInHierarchy).
-int build_band(Csr& A, const long long grid[3]) {
-  if (A.opt.no_band || A.opt.no_march3 || A.opt.no_march2 || A.opt.no_march || A.regular_cols >= 0) return MG_OK;
-  const long long n1 = grid[0], n2 = grid[1], n3 = grid[2];
-  if (n1 < 4 || n2 < 4 || n3 < 3 || n1 * n2 * n3 != A.n_rows || A.n_cols != A.n_rows) return MG_OK;
-  if (A.n_rows < A.opt.band_min_rows || A.max_row_nnz > mgk::RM3_NIP + 2) return MG_OK;
-  const long long P = n1 * n2, n = A.n_rows;
-  std::vector<int> rp((size_t)n + 1), ci((size_t)std::max<long long>(A.nnz, 1));
-  HIP_TRY(hipMemcpy(rp.data(), A.rowptr.p, rp.size() * sizeof(int), hipMemcpyDeviceToHost));
-  if (A.nnz > 0) HIP_TRY(hipMemcpy(ci.data(), A.colidx.p, (size_t)A.nnz * sizeof(int), hipMemcpyDeviceToHost));
-  // ---- structure classes: rows with the same list of shifts --------------------------------------------------------------
-  std::vector<unsigned short> cl((size_t)n);
-  std::vector<std::vector<long long>> shifts;          // per class
-  std::unordered_map<unsigned long long, std::vector<int>> byhash;
-  for (long long i = 0; i < n; ++i) {
-    const int k0 = rp[(size_t)i], k1 = rp[(size_t)i + 1];
-    unsigned long long hsh = 0x9E3779B97F4A7C15ULL * (unsigned long long)(k1 - k0 + 1);
-    for (int k = k0; k < k1; ++k) {
-      hsh ^= (unsigned long long)((long long)ci[(size_t)k] - i) + 0x9E3779B97F4A7C15ULL + (hsh << 6) + (hsh >> 2);
-    }
-    std::vector<int>& cand = byhash[hsh];
-    int found = -1;
-    for (int c : cand) {
-      const std::vector<long long>& sh = shifts[(size_t)c];
-      if ((int)sh.size() != k1 - k0) continue;
-      bool same = true;
-      for (int k = k0; k < k1 && same; ++k) same = sh[(size_t)(k - k0)] == (long long)ci[(size_t)k] - i;
-      if (same) { found = c; break; }
-    }
-    if (found < 0) {
-      if (shifts.size() >= (size_t)mgk::RM3_NCLS) return MG_OK;
-      std::vector<long long> sh((size_t)(k1 - k0));
-      for (int k = k0; k < k1; ++k) sh[(size_t)(k - k0)] = (long long)ci[(size_t)k] - i;
-      found = (int)shifts.size();
-      shifts.push_back(sh);
-      cand.push_back(found);
-    }
-    cl[(size_t)i] = (unsigned short)found;
-  }
-  const size_t ncls = shifts.size();
-  std::vector<std::vector<M3Ent>> ents(ncls);
-  for (size_t c = 0; c < ncls; ++c) {
-    int nip = 0;
-    const size_t len = shifts[c].size();
-    for (size_t k = 0; k < len; ++k) {
-      const long long sh = shifts[c][k];
-      if (k > 0 && sh <= shifts[c][k - 1]) return MG_OK;             // (ascending columns)
-      const long long dz = (sh >= 0) ? (sh + P / 2) / P : -((-sh + P / 2) / P);
-      const long long rest = sh - dz * P;
-      const long long dy = (rest >= 0) ? (rest + n1 / 2) / n1 : -((-rest + n1 / 2) / n1);
-      const long long dx = rest - dy * n1;
-      if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) return MG_OK;
-      if (dz != 0 && (dy != 0 || dx != 0)) return MG_OK;             // not a z-star
-      if (dz == -1 && k != 0) return MG_OK;
-      if (dz == 1 && k != len - 1) return MG_OK;
-      if (dz == 0 && ++nip > mgk::RM3_NIP) return MG_OK;
-      ents[c].push_back({(int)dz, (int)dy, (int)dx});
-    }
-  }
-  MG_TRY(build_march3_impl(A, grid, cl.data(), ncls, ents, true));
-  if (!A.rc_march3) return MG_OK;
-  // ---- the values as planar slots: class ids + slot table to the device, one kernel fills (and later refills) the arrays ------
-  const long long vstride = (n + 15) & ~15LL;
-  const int NS = mgk::RM3_NIP + 2;
-  std::vector<int> slot(ncls * (size_t)NS, 0);
-  for (size_t c = 0; c < ncls; ++c) {
-    int nip = 0, e = 0;
-    for (const M3Ent& t : ents[c]) slot[c * (size_t)NS + (size_t)e++] = t.dz == -1 ? 0 : t.dz == 1 ? NS - 1 : 1 + nip++;
-  }
-  MG_TRY(A.vband.alloc((size_t)NS * (size_t)vstride));
-  MG_TRY(A.vb_cls.alloc(cl.size()));
-  MG_TRY(A.vb_slot.alloc(slot.size()));
-  HIP_TRY(hipMemset(A.vband.p, 0, A.vband.bytes()));
-  HIP_TRY(hipMemcpy(A.vb_cls.p, cl.data(), cl.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(A.vb_slot.p, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
-  A.vstride = vstride;
-  MG_TRY(band_refill(A));
-  A.rm3.vband = A.vband.p;
-  A.rm3.vstride = vstride;
-  A.rm3_var = true;
-  A.band_ncls = (long long)ncls;
-  return MG_OK;
-}
-
-// Four-stage pass of the solve loop (csr_rowclass_march4_spmv) on an operator the two-stage tile form serves: the same
-// classes and product map; the in-plane entries of every class must lie in {-y, -x, 0, +x, +y} (the records carry values
-// in that canonical order, no offsets), at most 4 z-classes and 255 classes (a lane packs its rows' class ids per
-// z-class into one register), relaxPrec constant per class.  Tile geometry of its own - the stage-1 region is WX = TX + 6
-// columns wide (three rings around the core), a lane owns K1 vertically adjacent rows, SY lanes per column:
-// TY <= K1*SY - 6; 3 slabs of x and 2 each of t, xn, t', all K1*SY + 2 lines, within the 160 KB of LDS; lockstep schedule
-// (tiles x segments of planes = at most one workgroup per CU).
-int build_march4(Csr& A, const std::vector<mgk::M3Class>& recs3, const std::vector<std::vector<M3Ent>>& ents, int ncx, int ncy, int ncz,
-                 size_t map_bytes, int ncu, const unsigned short* cy) {
-  A.rc_march4 = false;
-  if (A.opt.no_march4 || !A.rc_has_d) return MG_OK;
-  const long long n1 = A.rm3.n1, n2 = A.rm3.n2, n3 = A.rm3.nplanes, P = n1 * n2;
-  const size_t ncls = recs3.size();
-  if (n3 < 8 || ncz > 4 || ncls > 255 || (size_t)A.rc_ncls != ncls) return MG_OK;
-  if (A.n_rows + 8 * P >= (1LL << 31) - 1) return MG_OK;   // int32 row arithmetic in the kernel
-  // ---- records in canonical form ---------------------------------------------------------------------------------------------
-  std::vector<double> dcls(ncls);
-  HIP_TRY(hipMemcpy(dcls.data(), A.rc_d.p, ncls * sizeof(double), hipMemcpyDeviceToHost));
-  std::vector<mgk::M4Class> recs(ncls);
-  for (size_t c = 0; c < ncls; ++c) {
-    mgk::M4Class q{};
-    q.v_lo = recs3[c].v_lo;
-    q.v_hi = recs3[c].v_hi;
-    q.d = dcls[c];
-    int nip = 0, last = -1;
-    for (const M3Ent& t : ents[c]) {
-      if (t.dz != 0) continue;
-      int slot = -1;
-      if (t.dy == -1 && t.dx == 0) slot = 0;
-      else if (t.dy == 0 && t.dx == -1) slot = 1;
-      else if (t.dy == 0 && t.dx == 0) slot = 2;
-      else if (t.dy == 0 && t.dx == 1) slot = 3;
-      else if (t.dy == 1 && t.dx == 0) slot = 4;
-      if (slot < 0 || slot <= last) return MG_OK;       // a diagonal in-plane entry, or not in ascending order: two passes
-      last = slot;
-      q.v[slot] = recs3[c].v[nip++];
-    }
-    recs[c] = q;
-  }
-  const long long lds_cap = 160 * 1024 - 1024;
-  const size_t dict_bytes = ncls * sizeof(mgk::M4Class) + map_bytes;
-  struct Geo { long long NT, tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, LYA, K1, NPM, nb, segs, seglen; size_t lds; double fill, cost; };
-  Geo best{};
-  bool have = false;
-  const long long want_nt = A.opt.march4_nt != 0 ? A.opt.march4_nt : 1024;
-  const long long want_k1 = A.opt.march4_k1 != 0 ? A.opt.march4_k1 : (want_nt == 1024 ? 2 : want_nt == 768 ? 3 : 4);
-  for (long long NT : {1024LL, 768LL, 512LL}) {
-    if (NT != want_nt) continue;
-    const long long K1 = want_k1, NPM = (NT == 512 || (NT == 768 && K1 == 4)) ? 3 : 2;
-    if (!((NT == 1024 && K1 == 2) || (NT == 768 && (K1 == 3 || K1 == 4)) || (NT == 512 && K1 == 4))) continue;   // (instantiated shapes)
-    for (long long tilesx = 1; tilesx <= std::max<long long>({1, n1 / 16, A.opt.march4_tiles_x}); ++tilesx) {
-      if (A.opt.march4_tiles_x > 0 && tilesx != A.opt.march4_tiles_x) continue;
-      Geo g{};
-      g.NT = NT; g.K1 = K1; g.NPM = NPM; g.tilesx = tilesx;
-      g.TX = (n1 + tilesx - 1) / tilesx;
-      g.WX = g.TX + 6;
-      if (g.WX > NT / 2) continue;
-      g.NPL = (g.TX + 2 * mgk::RM4_G + 2) / 2;
-      g.pitch = 0;
-      for (long long pt : {48LL, 64LL, 80LL})      // (the instantiated pitches)
-        if (g.pitch == 0 && pt >= 2 * g.NPL) g.pitch = pt;
-      if (g.pitch == 0) continue;
-      // the tallest tile the lanes, the pair loads and the LDS allow
-      long long SY = NT / g.WX;
-      // (a tile row's strips may be shifted by up to K1 - 1 lines: that many more lines per column)
-      auto fits = [&](long long sy) {
-        const long long ty = std::min<long long>(K1 * sy - 6 - (K1 - 1), n2);
-        return ty >= 2 && (ty + 8 + K1 - 1) * g.NPL <= NPM * NT && (long long)((size_t)9 * (size_t)(K1 * sy + 2) * (size_t)g.pitch * 8 + dict_bytes) <= lds_cap;
-      };
-      while (SY >= 1 && !fits(SY)) --SY;
-      if (SY < 1) continue;
-      long long TY = std::min<long long>(K1 * SY - 6 - (K1 - 1), n2);
-      if (A.opt.march4_ty_max > 0) TY = std::min<long long>(TY, A.opt.march4_ty_max);
-      g.tilesy = (n2 + TY - 1) / TY;
-      g.TY = (n2 + g.tilesy - 1) / g.tilesy;                        // equal tiles
-      g.SY = (g.TY + 6 + (K1 - 1) + K1 - 1) / K1;                   // strips a column needs
-      g.LY = g.TY + 8 + (K1 - 1);
-      g.LYA = K1 * g.SY + 2;
-      g.lds = (size_t)9 * (size_t)g.LYA * (size_t)g.pitch * 8 + dict_bytes;
-      const long long tiles = g.tilesx * g.tilesy, slots = ncu;
-      if (tiles > slots) continue;
-      const long long S = std::min<long long>(slots / tiles, std::max<long long>(1, n3 / 8));
-      const long long Lz = (n3 + S - 1) / S;
-      const double eff = ((double)n3 / (double)(S * Lz)) * ((double)(tiles * S) / (double)slots);
-      g.segs = S; g.seglen = Lz; g.nb = tiles * S;
-      // Cost of a geometry = what ONE workgroup takes (they all run side by side, one per CU): iterations x time per iteration.
-      // Measured on 257^3 (profiles/r04_march4_ab.md: nine geometries at 1024 threads): an iteration costs 1.2 us + 1.05 ns per
-      // row of the stage-1 region, whatever the tile's shape - so the run length (planes of a segment + 6) decides: the most
-      // segments the tiles leave room for, tiles as large as the lanes allow.  (`fill`, kept for the reports: bytes per row.)
-      const double core = (double)g.TX * (double)g.TY, R = (double)Lz;
-      const double waste = (double)(g.tilesx * g.TX) * (double)(g.tilesy * g.TY) / (double)P;
-      const double fx = 8.0 * (double)((g.TX + 8) * (g.TY + 8)) / core * (1.0 + 8.0 / R);
-      const double fb = 8.0 * (double)((g.TX + 6) * (g.TY + 6)) / core * (1.0 + 6.0 / R);
-      g.fill = (waste * (fx + fb) + 16.0) / eff;
-      g.cost = ((double)Lz + 6.0) * (1.2 + 1.05e-3 * (double)((g.TX + 6) * (g.TY + 6)));
-      if (!have || g.cost < best.cost) {
-        best = g;
-        have = true;
-      }
-    }
-  }
-  if (!have) return MG_OK;
-  if (best.nb < std::min<long long>(A.opt.march_min_wg, (long long)ncu * 3 / 4)) return MG_OK;   // small levels: latency-bound
-  // ---- strip shift per tile row: no strip of K1 lines may hold (live) rows of different y-classes ---------------------------------
-  std::vector<int> ysh((size_t)best.tilesy, -1);
-  for (long long ty = 0; ty < best.tilesy; ++ty) {
-    for (long long sh = 0; sh < best.K1 && ysh[(size_t)ty] < 0; ++sh) {
-      bool ok = true;
-      for (long long j = 0; j < best.SY && ok; ++j) {
-        int seen = -1;
-        for (long long r = 0; r < best.K1 && ok; ++r) {
-          const long long yc = best.K1 * j + r - sh, gy = ty * best.TY - 3 + yc;
-          if (yc < 0 || yc >= best.TY + 6 || gy < 0 || gy >= n2) continue;
-          if (seen < 0) seen = cy[gy];
-          else if (seen != cy[gy]) ok = false;
-        }
-      }
-      if (ok) ysh[(size_t)ty] = (int)sh;
-    }
-    if (ysh[(size_t)ty] < 0) return MG_OK;      // lines of different classes inside every strip layout: two passes
-  }
-  MG_TRY(A.rm4_ysh.alloc(ysh.size()));
-  HIP_TRY(hipMemcpy(A.rm4_ysh.p, ysh.data(), ysh.size() * sizeof(int), hipMemcpyHostToDevice));
-  MG_TRY(A.rm4_cls.alloc(ncls));
-  HIP_TRY(hipMemcpy(A.rm4_cls.p, recs.data(), ncls * sizeof(mgk::M4Class), hipMemcpyHostToDevice));
-  mgk::March4Dev T{};
-  T.cls = A.rm4_cls.p;
-  T.ysh = A.rm4_ysh.p;
-  T.cmap = A.rm3_cmap.p;
-  T.ncx = ncx; T.ncy = ncy; T.ncz = ncz; T.ntab = ncx * ncy * ncz;
-  T.n1 = (int)n1; T.n2 = (int)n2; T.nplanes = (int)n3; T.P = (int)P;
-  T.TX = (int)best.TX; T.TY = (int)best.TY; T.tiles_x = (int)best.tilesx; T.tiles_y = (int)best.tilesy;
-  T.WX = (int)best.WX; T.SY = (int)best.SY; T.pitch = (int)best.pitch; T.LY = (int)best.LY; T.NPL = (int)best.NPL; T.LYA = (int)best.LYA;
-  T.nblocks = (int)best.nb; T.segs = (int)best.segs; T.seglen = (int)best.seglen;
-  T.n_cols = (int)A.n_cols; T.ncls = (int)ncls;
-  A.rm4 = T;
-  A.rm4_lds = best.lds;
-  A.rm4_k1 = (int)best.K1;
-  A.rm4_nt = (int)best.NT;
-  A.rm4_fill = best.fill;
-  A.rc_march4 = true;
-  if (A.opt.debug_format)
-    std::fprintf(stderr, "[mg] march4: tiles %lldx%lld of %lldx%lld (%lld threads, K1 %lld, SY %lld), %lld segments of %lld planes, LDS %zu B, est. %.1f B/row\n",
-                 best.tilesx, best.tilesy, best.TX, best.TY, best.NT, best.K1, best.SY, best.segs, best.seglen, best.lds, best.fill);
-  return MG_OK;
-}
-
-int build_march3_impl(Csr& A, const long long grid[3], const unsigned short* cl_in, size_t ncls,
-                      const std::vector<std::vector<M3Ent>>& ents, bool var) {
-  using Ent = M3Ent;
-  const bool box = A.regular_cols >= 0;
-  const long long nreg = box ? A.regular_cols : A.n_rows;
-  const long long n1 = grid[0], n2 = grid[1], n3 = grid[2];
-  const long long P = n1 * n2;
-  // ---- class ids as a product of three index maps --------------------------------------------------------------------------
-  // hash of every x-slice / y-slice / z-slice of the class array; equal hashes = same index; then the exact check
-  std::vector<unsigned short> cmap;
-  int ncx = 0, ncy = 0, ncz = 0;
-  {
-    const unsigned short* cl = cl_in;
-    std::vector<unsigned long long> hx((size_t)n1, 0), hy((size_t)n2, 0), hz((size_t)n3, 0);
-    auto mix = [](unsigned long long v) {
-      v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
-      return v;
-    };
-    for (long long z = 0; z < n3; ++z)
-      for (long long y = 0; y < n2; ++y) {
-        const unsigned short* line = cl + (z * n2 + y) * n1;
-        unsigned long long hl = 0;
-        for (long long x = 0; x < n1; ++x) {
-          const unsigned long long v = (unsigned long long)line[x] + 1;
-          hx[(size_t)x] += mix(v * 0x9E3779B97F4A7C15ULL + (unsigned long long)(z * n2 + y));
-          hl += mix(v * 0xD6E8FEB86659FD93ULL + (unsigned long long)x);
-        }
-        hy[(size_t)y] += mix(hl + (unsigned long long)z * 0x9E3779B97F4A7C15ULL);
-        hz[(size_t)z] += mix(hl + (unsigned long long)y * 0xC2B2AE3D27D4EB4FULL);
-      }
-    auto index_of = [](const std::vector<unsigned long long>& hv, std::vector<unsigned short>& idx, std::vector<long long>& rep) {
-      std::unordered_map<unsigned long long, int> seen;
-      idx.resize(hv.size());
-      for (size_t i = 0; i < hv.size(); ++i) {
-        auto itf = seen.find(hv[i]);
-        if (itf == seen.end()) {
-          itf = seen.emplace(hv[i], (int)rep.size()).first;
-          rep.push_back((long long)i);
-        }
-        idx[i] = (unsigned short)itf->second;
-      }
-    };
-    std::vector<unsigned short> cx, cy, cz;
-    std::vector<long long> rx, ry, rz;
-    index_of(hx, cx, rx);
-    index_of(hy, cy, ry);
-    index_of(hz, cz, rz);
-    ncx = (int)rx.size(); ncy = (int)ry.size(); ncz = (int)rz.size();
-    if ((long long)ncx * ncy * ncz > mgk::RM3_TAB) return MG_OK;
-    std::vector<unsigned short> tab((size_t)ncx * ncy * ncz);
-    for (int iz = 0; iz < ncz; ++iz)
-      for (int iy = 0; iy < ncy; ++iy)
-        for (int ix = 0; ix < ncx; ++ix) tab[((size_t)iz * ncy + iy) * ncx + ix] = cl[(rz[(size_t)iz] * n2 + ry[(size_t)iy]) * n1 + rx[(size_t)ix]];
-    bool okmap = true;
-#pragma omp parallel for schedule(static) reduction(&& : okmap)
-    for (long long z = 0; z < n3; ++z) {
-      for (long long y = 0; y < n2 && okmap; ++y) {
-        const unsigned short* line = cl + (z * n2 + y) * n1;
-        const unsigned short* trow = tab.data() + ((size_t)cz[(size_t)z] * ncy + cy[(size_t)y]) * ncx;
-        for (long long x = 0; x < n1; ++x)
-          if (line[x] != trow[cx[(size_t)x]]) { okmap = false; break; }
-      }
-    }
-    if (!okmap) return MG_OK;     // the classes are not a product of coordinate classes: the 1-D chunk form serves the level
-    for (unsigned short v : tab) if (v >= ncls && !(box && v == 0xFFFF)) return MG_OK;
-    // Every entry of every class must point INSIDE the grid wherever the class occurs: the tile kernels read the in-plane
-    // neighbours of stage 2 (and later) from slabs that hold computed rows only - a wrap-around coupling (periodic in x: the
-    // shift n1 - 1 decomposes as dy = +1, dx = -1 and passes every check above) would read a line outside the grid as zeros.
-    // Such operators keep the 1-D chunk form / two launches, whose linear indexing computes them correctly.
-    {
-      auto span = [](const std::vector<unsigned short>& idx, int nidx, std::vector<long long>& lo, std::vector<long long>& hi) {
-        lo.assign((size_t)nidx, (long long)idx.size());
-        hi.assign((size_t)nidx, -1);
-        for (size_t i = 0; i < idx.size(); ++i) {
-          lo[idx[i]] = std::min<long long>(lo[idx[i]], (long long)i);
-          hi[idx[i]] = std::max<long long>(hi[idx[i]], (long long)i);
-        }
-      };
-      std::vector<long long> xlo, xhi, ylo, yhi, zlo, zhi;
-      span(cx, ncx, xlo, xhi);
-      span(cy, ncy, ylo, yhi);
-      span(cz, ncz, zlo, zhi);
-      for (int iz = 0; iz < ncz; ++iz)
-        for (int iy = 0; iy < ncy; ++iy)
-          for (int ix = 0; ix < ncx; ++ix) {
-            const unsigned short c = tab[((size_t)iz * ncy + iy) * ncx + ix];
-            if (c == 0xFFFF) continue;
-            for (const Ent& t : ents[c])
-              if (xlo[(size_t)ix] + t.dx < 0 || xhi[(size_t)ix] + t.dx >= n1 || ylo[(size_t)iy] + t.dy < 0 || yhi[(size_t)iy] + t.dy >= n2 ||
-                  zlo[(size_t)iz] + t.dz < 0 || zhi[(size_t)iz] + t.dz >= n3)
-                return MG_OK;
-          }
-    }
-    cmap.insert(cmap.end(), cx.begin(), cx.end());
-    cmap.insert(cmap.end(), cy.begin(), cy.end());
-    cmap.insert(cmap.end(), cz.begin(), cz.end());
-    cmap.insert(cmap.end(), tab.begin(), tab.end());
-    if (box && A.rc_nexc > 0) {
-      // Stage 2 (r = b - A t) of a row next to an exception row needs that row's t, which exists only after the exchange:
-      // such rows (the layer behind the faces) are left to csr_rows_spmv as well.  Their set must be sx[x] | sy[y] | sz[z].
-      std::vector<unsigned char> near((size_t)nreg, 0);
-#pragma omp parallel for schedule(static)
-      for (long long i = 0; i < nreg; ++i) {
-        const unsigned short c = cl[i];
-        if (c == 0xFFFF) continue;
-        for (int k = A.h_rc_ptr[c]; k < A.h_rc_ptr[(size_t)c + 1]; ++k) {
-          const long long col = i + A.h_rc_delta[c] + A.h_rc_off[(size_t)k];
-          if (col >= 0 && col < nreg && cl[col] == 0xFFFF) { near[(size_t)i] = 1; break; }
-        }
-      }
-      std::vector<unsigned short> sx((size_t)n1, 1), sy((size_t)n2, 1), sz((size_t)n3, 1);
-      for (long long z = 0; z < n3; ++z)
-        for (long long y = 0; y < n2; ++y)
-          for (long long x = 0; x < n1; ++x) {
-            const long long i = (z * n2 + y) * n1 + x;
-            if (cl[i] == 0xFFFF || near[(size_t)i]) continue;
-            sx[(size_t)x] = 0; sy[(size_t)y] = 0; sz[(size_t)z] = 0;     // a row computed in full: none of its coordinates is flagged
-          }
-      std::vector<int> list2;
-      for (long long z = 0; z < n3; ++z)
-        for (long long y = 0; y < n2; ++y)
-          for (long long x = 0; x < n1; ++x) {
-            const long long i = (z * n2 + y) * n1 + x;
-            if (cl[i] == 0xFFFF) continue;
-            const bool flag = sx[(size_t)x] | sy[(size_t)y] | sz[(size_t)z];
-            if (near[(size_t)i] && !flag) return MG_OK;                 // not a union of coordinate layers: two launches per pair
-            if (flag) list2.push_back((int)i);                          // (a superset of `near` is harmless: computed by the list kernel)
-          }
-      cmap.insert(cmap.end(), sx.begin(), sx.end());
-      cmap.insert(cmap.end(), sy.begin(), sy.end());
-      cmap.insert(cmap.end(), sz.begin(), sz.end());
-      A.rc_nexc2 = (int)list2.size();
-      if (!list2.empty()) {
-        MG_TRY(A.rc_exc2.alloc(list2.size()));
-        HIP_TRY(hipMemcpy(A.rc_exc2.p, list2.data(), list2.size() * sizeof(int), hipMemcpyHostToDevice));
-      }
-    }
-  }
-  // ---- tile geometry ------------------------------------------------------------------------------------------------------
-  int dev = 0, ncu = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const long long lds_cap = 160 * 1024 - 1024;
-  const size_t dict_bytes = ncls * (sizeof(mgk::M3Class) + 8) + ((cmap.size() * 2 + 15) & ~(size_t)15);
-  struct Geo { long long NT, tilesx, TX, TY, tilesy, WX, SY, NPL, pitch, LY, K1, nb, segs, seglen; size_t lds; double fill; };
-  Geo best{};
-  bool have = false;
-  // (VAR: 3 x 8 more doubles per row and lane in registers - 512 threads, 256 registers per lane, two or three rows per lane)
-  for (long long NT : {1024LL, 768LL, 512LL}) {
-    if (var != (NT == 512)) continue;
-    if (!var && A.opt.march3_nt != 0 && A.opt.march3_nt != NT) continue;
-    for (long long K1 = 2; K1 <= (NT == 768 ? 4 : 3); ++K1) {
-      if (A.opt.march3_k1 != 0 && K1 != A.opt.march3_k1 && !(var && A.opt.march3_k1 > 3)) continue;
-      if (NT == 768 && K1 < 3) continue;
-      for (long long tilesx = 1; tilesx <= std::max<long long>({1, n1 / 16, A.opt.march3_tiles_x}); ++tilesx) {
-        if (A.opt.march3_tiles_x > 0 && tilesx != A.opt.march3_tiles_x) continue;
-        Geo g{};
-        g.NT = NT;
-        g.K1 = K1;
-        g.tilesx = tilesx;
-        g.TX = (n1 + tilesx - 1) / tilesx;
-        g.WX = g.TX + 2;
-        if (g.WX > NT / 2) continue;
-        g.SY = NT / g.WX;
-        g.TY = std::min<long long>(K1 * g.SY - 2, n2);
-        if (g.TY < 2) continue;
-        g.tilesy = (n2 + g.TY - 1) / g.TY;
-        g.TY = (n2 + g.tilesy - 1) / g.tilesy;                        // equal tiles
-        g.NPL = (g.TX + 6) / 2;
-        g.pitch = 2 * g.NPL;
-        g.LY = g.TY + 4;
-        if (g.LY * g.NPL > (long long)RM3_NPM * NT) continue;
-        g.lds = (size_t)(3 * g.LY + 2 * (g.TY + 2)) * (size_t)g.pitch * 8 + dict_bytes;
-        if ((long long)g.lds > lds_cap) continue;
-        const long long wg_per_cu = 1;   // (> 100 registers per lane: one workgroup of 12-16 waves per CU whatever the LDS)
-        const long long tiles = g.tilesx * g.tilesy, items = tiles * n3, slots = wg_per_cu * ncu;
-        // balanced: equal contiguous ranges of the (tile, plane) list; lockstep: tiles x segments
-        g.nb = std::max<long long>(1, std::min<long long>(slots, items / 4));
-        double R = (double)items / (double)g.nb, eff = 1.0;
-        g.segs = 0;
-        g.seglen = 0;
-        if (!A.opt.no_march3_lockstep && tiles <= slots) {
-          const long long S = std::min<long long>(slots / tiles, n3 / 4);
-          if (S >= 1) {
-            const long long Lz = (n3 + S - 1) / S;
-            const double e = ((double)n3 / (double)(S * Lz)) * ((double)(tiles * S) / (double)slots);
-            if (e >= 0.85 || A.opt.march3_lockstep_force) {
-              g.segs = S;
-              g.seglen = Lz;
-              g.nb = tiles * S;
-              R = (double)Lz;
-              eff = e;
-            }
-          }
-        }
-        const double core = (double)g.TX * (double)g.TY;
-        // fills per row of the grid: tiles are equal, so partial tiles at the far edges are charged through tiles*core / P;
-        // a line segment of W doubles at an arbitrary alignment touches W/16 + 15/16 cache lines of 128 bytes
-        const double waste = (double)(g.tilesx * g.TX) * (double)(g.tilesy * g.TY) / (double)P;
-        auto lines = [](double W) { return 1.0 + 15.0 / W; };
-        // (lockstep: neighbouring tiles stage their common halo lines at the same time on one XCD - measured on 257^3: the
-        // fabric traffic falls to 1.02 x compulsory, the pass gains 5 %: the halo excess is charged at half)
-        const double share = g.segs > 0 ? 0.5 : 1.0;
-        const double fx = 8.0 * (double)((g.TX + 4) * (g.TY + 4)) / core * (1.0 + 3.0 / R) * lines((double)(g.TX + 4));
-        const double fb = 8.0 * (double)((g.TX + 2) * (g.TY + 2)) / core * (1.0 + 2.0 / R) * lines((double)(g.TX + 2));
-        g.fill = (waste * (8.0 + share * (fx - 8.0) + 8.0 + share * (fb - 8.0)) + 16.0) / eff;
-        if (!have || g.fill < best.fill) {
-          best = g;
-          have = true;
-        }
-      }
-    }
-  }
-  if (!have) return MG_OK;
-  if (best.nb < std::min<long long>(A.opt.march_min_wg, (long long)ncu * 3 / 4)) return MG_OK;   // small levels: latency-bound, other kernels
-  // ---- class records with byte offsets in the chosen pitch ------------------------------------------------------------------
-  std::vector<mgk::M3Class> recs(ncls);
-  for (size_t c = 0; c < ncls; ++c) {
-    mgk::M3Class q{};
-    int nip = 0, first_off = 0;
-    std::vector<double> vals(ents[c].size(), 1.0);   // (VAR: the records carry the structure only)
-    if (!var) {
-      const int k0 = A.h_rc_ptr[c];
-      vals.resize((size_t)(A.h_rc_ptr[c + 1] - k0));
-      if (!vals.empty()) HIP_TRY(hipMemcpy(vals.data(), A.rc_val.p + k0, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
-    }
-    for (size_t e = 0; e < ents[c].size(); ++e) {
-      const Ent& t = ents[c][e];
-      if (t.dz == -1) q.v_lo = vals[e];
-      else if (t.dz == 1) q.v_hi = vals[e];
-      else {
-        const int off = (int)((t.dy * best.pitch + t.dx) * 8);
-        if (nip == 0) first_off = off;
-        q.v[nip] = vals[e];
-        q.off[nip] = off;
-        ++nip;
-      }
-    }
-    for (int u = nip; u < mgk::RM3_NIP; ++u) {
-      q.v[u] = 0.0;
-      q.off[u] = first_off;
-    }
-    q.flags = 0;
-    recs[c] = q;
-  }
-  MG_TRY(A.rm3_cls.alloc(ncls));
-  HIP_TRY(hipMemcpy(A.rm3_cls.p, recs.data(), ncls * sizeof(mgk::M3Class), hipMemcpyHostToDevice));
-  MG_TRY(A.rm3_cmap.alloc(cmap.size()));
-  HIP_TRY(hipMemcpy(A.rm3_cmap.p, cmap.data(), cmap.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  mgk::March3Dev T{};
-  T.cls = A.rm3_cls.p;
-  T.cmap = A.rm3_cmap.p;
-  T.ncx = ncx; T.ncy = ncy; T.ntab = ncx * ncy * ncz;
-  T.n1 = (int)n1; T.n2 = (int)n2; T.nplanes = (int)n3; T.P = (int)P;
-  T.TX = (int)best.TX; T.TY = (int)best.TY; T.tiles_x = (int)best.tilesx; T.tiles_y = (int)best.tilesy;
-  T.WX = (int)best.WX; T.SY = (int)best.SY; T.pitch = (int)best.pitch; T.LY = (int)best.LY; T.NPL = (int)best.NPL;
-  T.nblocks = (int)best.nb;
-  T.segs = (int)best.segs; T.seglen = (int)best.seglen;
-  T.n_cols = (int)A.n_cols; T.ncls = (int)ncls;
-  T.has_exc = (box && A.rc_nexc > 0) ? 1 : 0;
-  A.rm3 = T;
-  A.rm3_lds = best.lds;
-  A.rm3_k1 = (int)best.K1;
-  A.rm3_nt = (int)best.NT;
-  A.rm3_fill = best.fill;
-  A.rc_march3 = true;
-  if (!var && !box) MG_TRY(build_march4(A, recs, ents, ncx, ncy, ncz, (cmap.size() * 2 + 15) & ~(size_t)15, ncu, cmap.data() + n1));
-  if (A.opt.debug_format)
-    std::fprintf(stderr, "[mg] march3: grid %lldx%lldx%lld tiles %lldx%lld of %lldx%lld (%lld threads, K1 %lld, SY %lld), %lld workgroups%s, class maps %dx%dx%d, LDS %zu B, est. %.1f B/row\n",
-                 n1, n2, n3, best.tilesx, best.tilesy, best.TX, best.TY, best.NT, best.K1, best.SY, best.nb,
-                 best.segs ? " (lockstep)" : "", ncx, ncy, ncz, best.lds, best.fill);
-  return MG_OK;
-}
-
-// Prolongation-shaped operators (csr_rowclass_winp_spmv): rows = a fine grid gf, columns = a coarse grid gc, explicit
-// first columns.  Everything is derived from the stored pattern and checked against it: the coarse plane of each fine
-// plane's first columns (cz0), the split of every dictionary offset into plane shift (0 or 1) + in-plane rest, per chunk
-// of WP_ROWS in-plane rows the window [wlo, wlo + W) of coarse in-plane indices its rows read in any plane, and per row
-// the 16-bit index of its first column inside that window.  Any row that does not fit drops the operator back to the
-// lane kernel.
-int build_winp(Csr& M, const long long gf[3], const long long gc[3]) {
-  if (M.rp_ok && M.rp_PF == gf[0] * gf[1] && M.rp_nplanes == gf[2] && M.rp_PC == gc[0] * gc[1]) return MG_OK;   // (same pattern, same hints)
-  M.rp_ok = false;
-  // (a prolongation of a sharded level: columns [owned coarse box | halo]; the rows that read the halo are exception rows,
-  // computed by csr_rows_spmv behind the exchange - they take no part in the windows)
-  const bool boxp = M.regular_cols >= 0;
-  if (!M.has_rc || M.rc_implicit || (M.rc_nexc != 0 && !boxp) || M.opt.no_winp || (boxp && M.reg_rows() != M.n_rows)) return MG_OK;
-  if (gf[0] < 1 || gf[1] < 1 || gf[2] < 1 || gc[0] < 1 || gc[1] < 1 || gc[2] < 1) return MG_OK;
-  if (gf[0] * gf[1] * gf[2] != M.n_rows || gc[0] * gc[1] * gc[2] != (boxp ? M.regular_cols : M.n_cols)) return MG_OK;
-  if (M.h_rp.size() != (size_t)M.n_rows + 1 || M.h_cls.size() != (size_t)M.n_rows || M.h_rc_ptr.empty()) return MG_OK;
-  if (M.rc_ncls * (long long)M.rc_maxlen > 1024 || M.n_rows < M.opt.winp_min_rows) return MG_OK;   // the padded dictionary lives in LDS (16 KB)
-  const long long PF = gf[0] * gf[1], PC = gc[0] * gc[1], nz = gf[2];
-  if (PF >= (1LL << 30) || PC < 4) return MG_OK;
-  const size_t ncls = M.h_rc_ptr.size() - 1;
-  std::vector<long long> rest(M.h_rc_off.size());
-  std::vector<int> dzc(M.h_rc_off.size());
-  std::vector<long long> cmin(ncls, 0), cmax(ncls, 0);   // per class: smallest / largest in-plane rest, second plane shifted by 0
-  std::vector<char> csecond(ncls, 0);
-  for (size_t c = 0; c < ncls; ++c)
-    for (int k = M.h_rc_ptr[c]; k < M.h_rc_ptr[c + 1]; ++k) {
-      const long long off = M.h_rc_off[(size_t)k];
-      if (off < 0) return MG_OK;
-      const long long d = (off + PC / 2) / PC;
-      if (d > 1) return MG_OK;
-      dzc[(size_t)k] = (int)d;
-      rest[(size_t)k] = off - d * PC;
-      cmin[c] = std::min(cmin[c], rest[(size_t)k]);
-      cmax[c] = std::max(cmax[c], rest[(size_t)k]);
-      if (d) csecond[c] = 1;
-    }
-  std::vector<int> cz0((size_t)nz, INT_MAX);
-  for (long long z = 0; z < nz; ++z)
-    for (long long p = 0; p < PF; ++p) {
-      const long long i = z * PF + p;
-      if (M.h_cls[(size_t)i] == 0xFFFF) continue;                      // (exception row: not served by the windows)
-      if (M.h_rp[(size_t)i + 1] == M.h_rp[(size_t)i]) return MG_OK;   // an empty row has no first column
-      cz0[(size_t)z] = std::min<long long>(cz0[(size_t)z], M.h_ci[(size_t)M.h_rp[(size_t)i]] / PC);
-    }
-  for (long long z = 0; z < nz; ++z)
-    if (cz0[(size_t)z] == INT_MAX) cz0[(size_t)z] = 0;                 // (a plane of exception rows only)
-  const long long chunks = (PF + mgk::WP_ROWS - 1) / mgk::WP_ROWS;
-  std::vector<long long> lo((size_t)chunks, LLONG_MAX), hi((size_t)chunks, LLONG_MIN);
-  std::vector<char> two((size_t)nz, 0);   // does any row of the plane read the second coarse plane?
-  for (long long z = 0; z < nz; ++z)
-    for (long long p = 0; p < PF; ++p) {
-      const long long i = z * PF + p;
-      const unsigned short c = M.h_cls[(size_t)i];
-      if (c == 0xFFFF) continue;
-      const long long fi = (long long)M.h_ci[(size_t)M.h_rp[(size_t)i]] - (long long)cz0[(size_t)z] * PC;   // in-plane index of the first column
-      if (fi < 0 || fi >= PC) return MG_OK;
-      if (c >= ncls) return MG_OK;
-      if (csecond[c] && (long long)cz0[(size_t)z] + 1 >= gc[2]) return MG_OK;   // would read past the last coarse plane
-      if (csecond[c]) two[(size_t)z] = 1;
-      const size_t ch = (size_t)(p / mgk::WP_ROWS);
-      lo[ch] = std::min(lo[ch], fi + cmin[c]);
-      hi[ch] = std::max(hi[ch], fi + cmax[c]);
-    }
-  long long W = 1;
-  for (size_t ch = 0; ch < (size_t)chunks; ++ch) {
-    if (lo[ch] == LLONG_MAX) { lo[ch] = 0; hi[ch] = 0; }              // (a chunk of exception rows only)
-    W = std::max(W, hi[ch] - lo[ch] + 1);
-  }
-  W = (W + 1) & ~1LL;   // (the dictionary behind the windows stays 16-byte aligned)
-  if (W > 2048) return MG_OK;   // 32 KB of windows per workgroup at most (+ <= 16 KB of dictionary: below the 64 KB default)
-  std::vector<unsigned short> wf((size_t)M.n_rows);
-  for (long long z = 0; z < nz; ++z)
-    for (long long p = 0; p < PF; ++p) {
-      const long long i = z * PF + p;
-      if (M.h_cls[(size_t)i] == 0xFFFF) { wf[(size_t)i] = 0; continue; }
-      const long long fi = (long long)M.h_ci[(size_t)M.h_rp[(size_t)i]] - (long long)cz0[(size_t)z] * PC;
-      const long long w = fi - lo[(size_t)(p / mgk::WP_ROWS)];
-      if (w < 0 || w >= W) return MG_OK;
-      wf[(size_t)i] = (unsigned short)w;
-    }
-  std::vector<int> code(M.h_rc_off.size()), wlo((size_t)chunks);
-  for (size_t k = 0; k < code.size(); ++k) code[k] = (int)(dzc[k] * W + rest[k]);
-  for (size_t ch = 0; ch < (size_t)chunks; ++ch) wlo[ch] = (int)lo[ch];
-  for (long long z = 0; z < nz; ++z)
-    if (!two[(size_t)z]) cz0[(size_t)z] |= 0x40000000;   // one window suffices for this plane
-  MG_TRY(M.rp_wf.alloc(wf.size()));
-  MG_TRY(M.rp_cz0.alloc(cz0.size()));
-  MG_TRY(M.rp_wlo.alloc(wlo.size()));
-  MG_TRY(M.rp_code.alloc(code.size()));
-  HIP_TRY(hipMemcpy(M.rp_wf.p, wf.data(), wf.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M.rp_cz0.p, cz0.data(), cz0.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M.rp_wlo.p, wlo.data(), wlo.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M.rp_code.p, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
-  M.rp_PF = (int)PF;
-  M.rp_nplanes = (int)nz;
-  M.rp_PC = (int)PC;
-  M.rp_W = (int)W;
-  M.rp_chunks = (int)chunks;
-  M.rp_ok = true;
-  if (M.opt.debug_format) std::fprintf(stderr, "[mgvcycle] prolongation-shaped operator %lld x %lld: windows of %lld coarse entries per %d rows\n", M.n_rows, M.n_cols, W, mgk::WP_ROWS);
-  return MG_OK;
-}
-
-int build_schedule(Csr& M, const long long grid[3], long long nrhs) {
-  MG_TRY(build_schedule_for(M, grid, nrhs, M.h_blk_row, M.nblocks, M.sched, M.has_sched));
-  M.ln_rows = M.ln_blocks = 0;
-  M.has_sched_ln = false;
-  if (nrhs > 1 && M.set && M.rc_lane_mm()) {   // uniform row blocks of the lane SpMM for this nrhs
-    M.ln_rows = lane_mm_rpl(M, nrhs) * (mgk::BLK / lane_mm_group(M, nrhs));
-    M.ln_blocks = (int)((M.n_rows + M.ln_rows - 1) / M.ln_rows);
-    std::vector<int> blk((size_t)M.ln_blocks + 1);
-    for (int b = 0; b <= M.ln_blocks; ++b) blk[(size_t)b] = (int)std::min<long long>((long long)b * M.ln_rows, M.n_rows);
-    MG_TRY(build_schedule_for(M, grid, nrhs, blk, M.ln_blocks, M.sched_ln, M.has_sched_ln));
-  }
-  return build_schedule_for(M, grid, nrhs, M.h_blk_row_mm, M.nblocks_mm, M.sched_mm, M.has_sched_mm);
-}
-int build_schedule_for(Csr& M, const long long grid[3], long long nrhs, const std::vector<int>& h_blk, int nb,
-                       DevBuf<int>& sched, bool& has) {
-  has = false;
-  if (!M.set || grid[0] <= 0) return MG_OK;
-  const long long n1 = grid[0], n2 = grid[1], n3 = std::max<long long>(1, grid[2]);
-  if (n1 * n2 * n3 != M.n_rows || n3 < 2 || n2 < 8) return MG_OK;
-  // gathered-vector bytes per (y,z) line of the row grid, three z-planes in the window
-  const double line_bytes = 3.0 * ((double)M.n_cols / (double)(n2 * n3)) * 8.0 * (double)nrhs;
-  const double plane_window = line_bytes * (double)n2;
-  const double budget = M.opt.sched_budget;  // default 2 MB of the 4 MiB per-XCD L2 (the rest: matrix stream, b/d/out lines); tests force tiling
-  if (plane_window <= budget) return MG_OK;  // natural order already keeps the window in L2
-  long long T = (long long)(budget / line_bytes);
-  T = std::max<long long>(4, std::min<long long>(T, n2));
-  std::vector<long long> key((size_t)nb);
-  for (int b = 0; b < nb; ++b) {
-    const long long r0 = h_blk[(size_t)b];
-    const long long y = (r0 / n1) % n2, z = r0 / (n1 * n2);
-    key[(size_t)b] = ((y / T) * n3 + z) * n2 + y;
-  }
-  std::vector<int> order((size_t)nb);
-  for (int b = 0; b < nb; ++b) order[(size_t)b] = b;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] < key[(size_t)b]; });
-  MG_TRY(sched.alloc((size_t)nb));
-  HIP_TRY(hipMemcpy(sched.p, order.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice));
-  has = true;
-  return MG_OK;
-}
-
-int alloc_scratch(mg_hierarchy* h) {
-  const long long k = h->nrhs;
-  if (h->coarse_lu) MG_TRY(h->luWork.alloc((size_t)h->n_coarse * (size_t)k));
-  if (h->coarse_lu && std::max(h->luML, h->luMU) > 0) MG_TRY(h->luTail.alloc((size_t)std::max(h->luML, h->luMU) * (size_t)k));
-  if (!h->opt.no_sched) {
-    for (int l = 0; l < (int)h->nlevels; ++l) {
-      Level& L = h->lev[(size_t)l];
-      MG_TRY(build_schedule(L.A, L.grid, k));
-      MG_TRY(build_staged(L.A, L.grid));
-      MG_TRY(build_schedule(L.P, L.grid, k));
-      if (l + 1 < (int)h->nlevels) MG_TRY(build_schedule(L.R, h->lev[(size_t)l + 1].grid, k));
-      if (l + 1 < (int)h->nlevels && k == 1) MG_TRY(build_winp(L.P, L.grid, h->lev[(size_t)l + 1].grid));
-    }
-  }
-  long long nmax = 0;
-  for (int l = 0; l < (int)h->nlevels; ++l) {
-    Level& L = h->lev[l];
-    const size_t len = (size_t)L.n * (size_t)k;
-    nmax = std::max(nmax, L.n);
-    MG_TRY(L.r.alloc(len));
-    MG_TRY(L.x1.alloc(len));
-    HIP_TRY(hipMemset(L.r.p, 0, L.r.bytes()));
-    HIP_TRY(hipMemset(L.x1.p, 0, L.x1.bytes()));
-    if (l > 0) {
-      MG_TRY(L.b.alloc(len));
-      MG_TRY(L.x0.alloc(len));
-      HIP_TRY(hipMemset(L.b.p, 0, L.b.bytes()));
-      HIP_TRY(hipMemset(L.x0.p, 0, L.x0.bytes()));
-    }
-    // FGMRESmem (MGsetup.jl:190-215): memRelax[l] for Jac-GMRES, memKcycle for levels 2..nl-1 of a K-cycle
-    L.relaxZ.release();
-    L.relaxAZ.release();
-    L.kZ.release();
-    L.kAZ.release();
-    if (h->relax_type == 1 && l < (int)h->nlevels - 1) {
-      L.relax_inner = std::max<long long>(1, std::max(L.npre, L.npost));
-      MG_TRY(L.relaxZ.alloc(len * (size_t)L.relax_inner));
-      MG_TRY(L.relaxAZ.alloc(len * (size_t)L.relax_inner));
-    }
-    if (h->cycle == 'K' && l > 0 && l < (int)h->nlevels - 1) {
-      MG_TRY(L.kZ.alloc(len * 2));
-      MG_TRY(L.kAZ.alloc(len * 2));
-    }
-  }
-  {  // the fused residual+norm writes one partial per row block
-    const size_t need = (size_t)std::max(h->lev[0].A.nblocks, h->lev[0].A.ln_blocks);
-    if (need > h->partial.n) MG_TRY(h->partial.alloc(need));
-  }
-  // store sink of the tile-form passes, at its largest size (12 stores x 32 slabs x 1024 lanes = 3 MB): never (re)allocated
-  // on the launch path - a launch may sit inside a stream capture, and earlier graphs hold the pointer
-  if (h->m3sink.n < M3_SINK_DOUBLES) MG_TRY(h->m3sink.alloc(M3_SINK_DOUBLES));
-  // host-pointer API staging (fine level) + transpose scratch (any level, for mg_spmv)
-  MG_TRY(h->stage_b.alloc((size_t)nmax * k));
-  MG_TRY(h->stage_x.alloc((size_t)nmax * k));
-  MG_TRY(h->stage_t.alloc((size_t)nmax * k));
-  HIP_TRY(hipMemset(h->stage_b.p, 0, h->stage_b.bytes()));
-  HIP_TRY(hipMemset(h->stage_x.p, 0, h->stage_x.bytes()));
-  HIP_TRY(hipMemset(h->stage_t.p, 0, h->stage_t.bytes()));
-  h->last_b = nullptr;
-  h->last_x = nullptr;
-  return MG_OK;
-}
-
-// Dictionary-code the column indices: per row (first column, pattern id), pattern = cols - cols[0].
-// Adopted only if it is a clear win: <= 65535 patterns and a dictionary below 1/16 of the index array.
-int build_patterns(Csr* M, const std::vector<int>& rp, const std::vector<int>& ci) {
-  M->has_pat = false;
-  const long long n = M->n_rows;
-  // short rows (full-weighting P: 1..8 entries) gain little index traffic and pay the extra dependent
-  // descriptor loads: measured +18 % time on C2's prolongation -> keep plain CSR below 5 entries per row
-  if (M->nnz < 5 * n) return MG_OK;
-  std::vector<int> first((size_t)n, 0);
-  std::vector<unsigned short> pid((size_t)n, 0);
-  std::vector<int> pptr(1, 0), poff;
-  std::unordered_map<unsigned long long, std::vector<int>> table;  // hash -> pattern ids
-  const size_t dict_cap = (size_t)std::max<long long>(4096, M->nnz / 16);
-  for (long long i = 0; i < n; ++i) {
-    const int s = rp[(size_t)i], e = rp[(size_t)i + 1];
-    const int f = (e > s) ? ci[(size_t)s] : 0;
-    first[(size_t)i] = f;
-    unsigned long long hsh = 1469598103934665603ull ^ (unsigned long long)(e - s);
-    for (int k = s; k < e; ++k) {
-      hsh ^= (unsigned long long)(unsigned int)(ci[(size_t)k] - f);
-      hsh *= 1099511628211ull;
-    }
-    std::vector<int>& cand = table[hsh];
-    int found = -1;
-    for (int id : cand) {
-      const int ps = pptr[(size_t)id], len = pptr[(size_t)id + 1] - ps;
-      if (len != e - s) continue;
-      bool same = true;
-      for (int k = 0; k < len; ++k)
-        if (poff[(size_t)ps + k] != ci[(size_t)s + k] - f) { same = false; break; }
-      if (same) { found = id; break; }
-    }
-    if (found < 0) {
-      found = (int)pptr.size() - 1;
-      if (found >= 65535 || poff.size() + (size_t)(e - s) > dict_cap) return MG_OK;  // not a grid-like operator
-      for (int k = s; k < e; ++k) poff.push_back(ci[(size_t)k] - f);
-      pptr.push_back((int)poff.size());
-      cand.push_back(found);
-    }
-    pid[(size_t)i] = (unsigned short)found;
-  }
-  if (poff.empty()) poff.push_back(0);
-  MG_TRY(M->firstcol.alloc(first.size()));
-  MG_TRY(M->pat.alloc(pid.size()));
-  MG_TRY(M->pat_ptr.alloc(pptr.size()));
-  MG_TRY(M->pat_off.alloc(poff.size()));
-  HIP_TRY(hipMemcpy(M->firstcol.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->pat.p, pid.data(), pid.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->pat_ptr.p, pptr.data(), pptr.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->pat_off.p, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
-  M->npat = (long long)pptr.size() - 1;
-  M->dict_entries = (long long)poff.size();
-  M->has_pat = true;
-  // run-length form of the row descriptors, per row block
-  {
-    if (M->opt.no_runs) return MG_OK;
-    // the descriptors are 10 B/row: worth compressing next to 56 B/row of values (7-point), not next to
-    // 216 B/row (27-point), where the run lookup costs more than it saves (measured -5 % / +4 %)
-    if (M->nnz >= 16 * n) return MG_OK;
-  }
-  const int nb = M->nblocks;
-  std::vector<int> rptr((size_t)nb + 1, 0), runs;
-  for (int b = 0; b < nb; ++b) {
-    const int r0 = M->h_blk_row[(size_t)b], r1 = M->h_blk_row[(size_t)b + 1];
-    const size_t mark = runs.size();
-    int count = 0;
-    bool ok = true;
-    int i = r0;
-    while (i < r1) {
-      const int pidv = pid[(size_t)i], f0 = first[(size_t)i];
-      int stride = 0, j = i + 1;
-      if (j < r1 && pid[(size_t)j] == pidv) {
-        stride = first[(size_t)j] - f0;
-        while (j < r1 && pid[(size_t)j] == pidv && first[(size_t)j] == f0 + (j - i) * stride) ++j;
-      }
-      if (++count > mgk::MAXRUNS) { ok = false; break; }
-      runs.push_back(i - r0);
-      runs.push_back(pidv);
-      runs.push_back(f0);
-      runs.push_back(stride);
-      runs.push_back(rp[(size_t)i]);
-      i = j;
-    }
-    const bool longrow = (r1 - r0 == 1) && (rp[(size_t)r1] - rp[(size_t)r0] > mgk::CHUNK - 2);
-    if (!ok || longrow) runs.resize(mark);  // this block keeps the per-row descriptors
-    rptr[(size_t)b + 1] = (int)(runs.size() / 5);
-  }
-  if (runs.empty()) return MG_OK;
-  MG_TRY(M->run_ptr.alloc(rptr.size()));
-  MG_TRY(M->runs.alloc(runs.size()));
-  HIP_TRY(hipMemcpy(M->run_ptr.p, rptr.data(), rptr.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->runs.p, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice));
-  M->nruns_total = (long long)(runs.size() / 5);
-  M->has_runs = true;
-  return MG_OK;
-}
-
-// Row classes: rows with identical column offsets (relative to the row's first column) AND bit-identical values.
-// Accepted when the operator really is that redundant: at most 65535 classes and a dictionary of at most
-// min(nnz/16, 2^18) entries (3 MiB: L2-resident).  Anything else keeps the streaming formats.  Lossless.
-int build_rowclasses_try(Csr* M, const int* rp, const int* ci, const double* val, bool implicit) {
-  M->drop_rc();
-  const long long n = M->n_rows;
-  if (n < 1 || M->nnz < 1) return MG_OK;
-  bool pair_choice = false;
-  const size_t cap = (size_t)std::min<long long>(1LL << 18, std::max<long long>(64, M->nnz / 16));
-  // Phase 1: classify every row (raw classes, unbounded ids).  Mostly regular operators - a grid operator whose
-  // rows were renumbered near sub-domain faces, irregular boundaries - have a few popular classes and a tail of
-  // singletons; give up only when the operator is irregular throughout.
-  const size_t raw_cls_cap = (size_t)std::max<long long>(65535, n / 8);
-  const size_t raw_ent_cap = (size_t)std::max<long long>((long long)cap, M->nnz / 4);
-  std::vector<int> first((size_t)n, 0), rptr(1, 0), roff, rdelta, rid((size_t)n, 0);
-  std::vector<double> rval;
-  std::unordered_map<unsigned long long, std::vector<int>> table;
-  for (long long i = 0; i < n; ++i) {
-    const int s = rp[(size_t)i], e = rp[(size_t)i + 1];
-    const int f = (e > s) ? ci[(size_t)s] : 0;
-    first[(size_t)i] = f;
-    if (M->regular_cols >= 0 && (i >= M->reg_rows() || (e > s && ci[(size_t)e - 1] >= M->regular_cols))) {
-      rid[(size_t)i] = -1;   // halo row, or a row that reads the halo (columns are sorted): forced exception row
-      continue;
-    }
-    unsigned long long hsh = 1469598103934665603ull ^ (unsigned long long)(e - s);
-    const int dlt = (int)(f - i);
-    if (implicit) {
-      hsh ^= (unsigned long long)(unsigned int)dlt;
-      hsh *= 1099511628211ull;
-    }
-    for (int k = s; k < e; ++k) {
-      unsigned long long bits;
-      std::memcpy(&bits, &val[(size_t)k], 8);
-      hsh ^= (unsigned long long)(unsigned int)(ci[(size_t)k] - f);
-      hsh *= 1099511628211ull;
-      hsh ^= bits;
-      hsh *= 1099511628211ull;
-    }
-    std::vector<int>& cand = table[hsh];
-    int found = -1;
-    for (int id : cand) {
-      const int ps = rptr[(size_t)id], len = rptr[(size_t)id + 1] - ps;
-      if (len != e - s) continue;
-      if (implicit && rdelta[(size_t)id] != dlt) continue;
-      bool same = true;
-      for (int k = 0; k < len && same; ++k)
-        same = roff[(size_t)ps + k] == ci[(size_t)s + k] - f &&
-               std::memcmp(&rval[(size_t)ps + k], &val[(size_t)s + k], 8) == 0;
-      if (same) { found = id; break; }
-    }
-    if (found < 0) {
-      found = (int)rptr.size() - 1;
-      if ((size_t)found >= raw_cls_cap || roff.size() + (size_t)(e - s) > raw_ent_cap) return MG_OK;  // irregular
-      for (int k = s; k < e; ++k) {
-        roff.push_back(ci[(size_t)k] - f);
-        rval.push_back(val[(size_t)k]);
-      }
-      rptr.push_back((int)roff.size());
-      rdelta.push_back(dlt);
-      cand.push_back(found);
-    }
-    rid[(size_t)i] = found;
-    // early exit for operators that are irregular from the start (SA-AMG levels: 2.5 G non-zeros in C3's hierarchy
-    // would otherwise be hashed up to the caps above): more than half of the first 8192 rows distinct
-    if (i == 8191 && rptr.size() - 1 > 4096) return MG_OK;
-  }
-  table.clear();
-  // Phase 2: keep the most frequent classes that fit the id width and the dictionary cap; rows of any other class
-  // are EXCEPTION rows (class id 0xFFFF): the row-class kernels skip them and csr_rows_spmv computes them from the
-  // CSR arrays.  Accepted when the kept classes cover enough rows (MG_ROWCLASS_MIN_COVER, default 0.9).
-  const size_t nraw = rptr.size() - 1;
-  std::vector<long long> freq(nraw, 0);
-  for (long long i = 0; i < n; ++i)
-    if (rid[(size_t)i] >= 0) freq[(size_t)rid[(size_t)i]]++;
-  std::vector<int> order(nraw);
-  for (size_t c = 0; c < nraw; ++c) order[c] = (int)c;
-  std::sort(order.begin(), order.end(), [&](int x, int y) { return freq[(size_t)x] != freq[(size_t)y] ? freq[(size_t)x] > freq[(size_t)y] : x < y; });
-  std::vector<int> remap(nraw, 0xFFFF), cptr(1, 0), coff, cdelta;
-  std::vector<double> cval;
-  long long covered = 0, nsingle = 0;
-  const long long keep_single = M->opt.rowclass_keep_singletons;   // default 1024; tests
-  for (size_t c = 0; c < nraw; ++c) nsingle += freq[c] == 1;
-  for (size_t t = 0; t < nraw && cptr.size() - 1 < 65535; ++t) {
-    const int c = order[t];
-    const int ps = rptr[(size_t)c], len = rptr[(size_t)c + 1] - ps;
-    // a few singletons (the corners of a box) may as well live in the dictionary; a long tail of them (rows next
-    // to sub-domain faces) becomes exception rows
-    if (freq[(size_t)c] < 2 && nsingle > keep_single) break;
-    if (coff.size() + (size_t)len > cap) break;
-    remap[(size_t)c] = (int)cptr.size() - 1;
-    coff.insert(coff.end(), roff.begin() + ps, roff.begin() + ps + len);
-    cval.insert(cval.end(), rval.begin() + ps, rval.begin() + ps + len);
-    cptr.push_back((int)coff.size());
-    cdelta.push_back(rdelta[(size_t)c]);
-    covered += freq[(size_t)c];
-  }
-  {
-    const double min_cover = M->opt.rowclass_min_cover;
-    const double nreg = (double)M->reg_rows();
-    if (cptr.size() < 2 || (double)covered < min_cover * nreg) return MG_OK;
-  }
-  std::vector<unsigned short> cid((size_t)n, 0);
-  std::vector<int> exc;
-  for (long long i = 0; i < n; ++i) {
-    const int c = rid[(size_t)i] >= 0 ? remap[(size_t)rid[(size_t)i]] : 0xFFFF;
-    cid[(size_t)i] = (unsigned short)c;
-    // (the empty halo rows of a padded local operator are never computed: not even exception rows)
-    if (c == 0xFFFF && i < M->reg_rows()) exc.push_back((int)i);
-  }
-  { std::vector<int>().swap(rid); std::vector<int>().swap(roff); std::vector<double>().swap(rval); }
-  if (coff.empty()) { coff.push_back(0); cval.push_back(0.0); }
-  {
-    // The kernel serves one class per waterfall pass: it only pays when a wavefront's 64 consecutive rows hold few
-    // classes.  Measured on C2: levels of 35 937 rows and fewer (every wave sees a dozen classes, and the whole level
-    // is L2-resident anyway) ran 3x slower than with the streaming kernels -> require <= 4 classes per wave on
-    // average, and enough rows for the matrix stream to matter.
-    const long long min_rows = M->opt.rowclass_min_rows, max_passes = M->opt.rowclass_max_passes;   // 100000 / 4; tests, A/B
-    if (n < min_rows) return MG_OK;
-    long long passes = 0, waves = 0;
-    for (long long w0 = 0; w0 < n; w0 += 64) {
-      unsigned short seen[64];
-      int ns = 0;
-      const long long w1 = std::min(n, w0 + 64);
-      for (long long i = w0; i < w1; ++i) {
-        if (cid[(size_t)i] == 0xFFFF) continue;   // exception rows cost no pass
-        bool dup = false;
-        for (int t = 0; t < ns; ++t)
-          if (seen[t] == cid[(size_t)i]) { dup = true; break; }
-        if (!dup) seen[ns++] = cid[(size_t)i];
-      }
-      passes += ns;
-      ++waves;
-    }
-    if (passes > max_passes * waves) return MG_OK;
-    // two consecutive rows per lane when that roughly halves the passes (classes alternating row by row)
-    long long passes2 = 0;
-    for (long long w0 = 0; w0 < n; w0 += 128) {
-      unsigned short seen[128];
-      int ns = 0;
-      const long long w1 = std::min(n, w0 + 128);
-      for (long long i = w0; i < w1; ++i) {
-        if (cid[(size_t)i] == 0xFFFF) continue;
-        bool dup = false;
-        for (int t = 0; t < ns; ++t)
-          if (seen[t] == cid[(size_t)i]) { dup = true; break; }
-        if (!dup) seen[ns++] = cid[(size_t)i];
-      }
-      passes2 += ns;
-    }
-    // (only where a wave really holds alternating classes: uniform operators measured slower this way, R1 70 -> 84 us)
-    // and only on large operators - C2's level 3 (65^3 rows, 4 classes per wave) ran 30 % slower paired
-    const long long pair_min = M->opt.pair_min_rows;
-    pair_choice = !M->opt.no_pair && n >= pair_min && 2 * passes >= 3 * waves && 10 * passes2 <= 7 * passes;
-  }
-  if (cdelta.empty()) cdelta.push_back(0);
-  if (!implicit) MG_TRY(M->rc_first.alloc(first.size()));
-  MG_TRY(M->rc_delta.alloc(cdelta.size()));
-  HIP_TRY(hipMemcpy(M->rc_delta.p, cdelta.data(), cdelta.size() * sizeof(int), hipMemcpyHostToDevice));
-  MG_TRY(M->rc_cls.alloc(cid.size()));
-  MG_TRY(M->rc_ptr.alloc(cptr.size()));
-  MG_TRY(M->rc_off.alloc(coff.size()));
-  MG_TRY(M->rc_val.alloc(cval.size()));
-  if (!implicit) HIP_TRY(hipMemcpy(M->rc_first.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->rc_cls.p, cid.data(), cid.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->rc_ptr.p, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->rc_off.p, coff.data(), coff.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->rc_val.p, cval.data(), cval.size() * sizeof(double), hipMemcpyHostToDevice));
-  M->rc_ncls = (long long)cptr.size() - 1;
-  M->rc_entries = (long long)coff.size();
-  M->rc_nexc = (int)exc.size();
-  if (!exc.empty()) {
-    MG_TRY(M->rc_exc.alloc(exc.size()));
-    HIP_TRY(hipMemcpy(M->rc_exc.p, exc.data(), exc.size() * sizeof(int), hipMemcpyHostToDevice));
-  }
-  M->has_rc = true;
-  M->rc_implicit = implicit;
-  M->rc_pair = pair_choice;
-  M->h_rc_ptr = cptr;
-  M->h_rc_off = coff;
-  M->h_rc_delta = cdelta;
-  M->rc_maxlen = 0;
-  for (size_t c = 0; c + 1 < cptr.size(); ++c) M->rc_maxlen = std::max(M->rc_maxlen, cptr[c + 1] - cptr[c]);
-  if (implicit) {   // LDS-window kernel: do the windows of the most frequent class fit for a full workgroup of rows?
-    std::vector<long long> cnt(cptr.size() - 1, 0);
-    for (long long i = 0; i < n; ++i)
-      if (cid[(size_t)i] != 0xFFFF) cnt[cid[(size_t)i]]++;
-    const size_t cm = (size_t)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
-    M->rc_major = (int)cm;
-    const int ps = cptr[cm], len = cptr[cm + 1] - ps;
-    // MG_STAGE_MIN_LEN: shortest class worth staging (A/B switch; measured on C2, profiles/r01_nt_ab.md:
-    // -25 % on the 27-point levels, -5 % on the 7-point one with the spill-free tile kernel)
-    const long long min_len = M->opt.stage_min_len;
-    // small levels are latency-bound and faster on the plain kernel (C2 level 3, 65^3 rows: 15 us against 23 us)
-    const long long min_wg = M->opt.window_min_wg;
-    bool ok = !M->opt.no_window && len >= min_len && len <= mgk::RW_MAXLEN && 2 * cnt[cm] >= n &&
-              (n + mgk::RW_ROWS - 1) / mgk::RW_ROWS >= min_wg;
-    if (ok) {
-      const long long W = mgk::RW_ROWS;
-      std::vector<int> meta(mgk::RW_META_HDR, 0), ivs;
-      std::unordered_map<long long, int> lb_of_shift;   // staged shift (delta + off) -> LDS index
-      const long long dcm = cdelta[cm];
-      long long base = 0, o_start = coff[(size_t)ps], o_end = o_start;
-      for (int k = 0; k < len; ++k) {
-        const long long off = coff[(size_t)ps + k];
-        if (k > 0 && off > o_end + W) {   // a new window (offsets ascend: CSR rows are sorted)
-          ivs.push_back((int)o_start);
-          ivs.push_back((int)(o_end - o_start + W));
-          ivs.push_back((int)base);
-          base += o_end - o_start + W;
-          o_start = off;
-        }
-        o_end = off;
-        lb_of_shift[dcm + off] = (int)(base + (off - o_start));
-      }
-      ivs.push_back((int)o_start);
-      ivs.push_back((int)(o_end - o_start + W));
-      ivs.push_back((int)base);
-      base += o_end - o_start + W;
-      const int nint = (int)(ivs.size() / 3);
-      ok = base <= mgk::RW_CAP && nint <= mgk::RW_MAXINT;
-      if (ok) {
-        meta[0] = (int)cm;
-        meta[1] = nint;
-        auto it0 = lb_of_shift.find(0);
-        meta[2] = it0 == lb_of_shift.end() ? -1 : it0->second;
-        meta[3] = (int)base;
-        meta.insert(meta.end(), ivs.begin(), ivs.end());
-        // every dictionary entry of every class: the LDS index of its shift, or -1 (gathers from global memory)
-        std::vector<int> lbs(coff.size(), -1);
-        for (size_t c = 0; c + 1 < cptr.size(); ++c)
-          for (int k = cptr[c]; k < cptr[c + 1]; ++k) {
-            auto it = lb_of_shift.find((long long)cdelta[c] + coff[(size_t)k]);
-            if (it != lb_of_shift.end()) lbs[(size_t)k] = it->second;
-          }
-        MG_TRY(M->rw_meta.alloc(meta.size()));
-        HIP_TRY(hipMemcpy(M->rw_meta.p, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
-        MG_TRY(M->rw_lb.alloc(lbs.size()));
-        HIP_TRY(hipMemcpy(M->rw_lb.p, lbs.data(), lbs.size() * sizeof(int), hipMemcpyHostToDevice));
-        M->rw_doubles = (int)base;
-      }
-    }
-    M->rc_window = ok;
-  }
-  M->h_cls.swap(cid);
-  return MG_OK;
-}
-// Square operators first try the form without a first-column stream (the class also fixes first column - row).
-int build_rowclasses(Csr* M, const int* rp, const int* ci, const double* val) {
-  if (M->n_rows == M->n_cols) {
-    if (!M->opt.no_implicit_first) {
-      MG_TRY(build_rowclasses_try(M, rp, ci, val, true));
-      if (M->has_rc) return MG_OK;
-    }
-  }
-  return build_rowclasses_try(M, rp, ci, val, false);
-}
-// relaxPrec constant per class (d = omega/a_ii and a_ii is part of the class): keep it in the dictionary
-// relaxPrec constant over every dictionary class (omega / a_ii is, by construction): the fused sweep can read it from the
-// dictionary instead of streaming 8 B/row.  d_dev: device vector over the operator's regular rows.
-int derive_class_d_csr(Csr& A, const double* d_dev, size_t n_d) {
-  A.rc_has_d = false;
-  A.d_bound = nullptr;
-  const size_t nreg = (size_t)(A.regular_cols >= 0 ? A.regular_cols : A.n_rows);
-  if (!A.has_rc || A.h_cls.size() != (size_t)A.n_rows || n_d != nreg || !d_dev) return MG_OK;
-  if (A.opt.no_class_d) return MG_OK;
-  std::vector<double> hd(nreg), dc((size_t)A.rc_ncls, 0.0);
-  std::vector<char> seen((size_t)A.rc_ncls, 0);
-  HIP_TRY(hipMemcpy(hd.data(), d_dev, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < hd.size(); ++i) {
-    const unsigned short c = A.h_cls[i];
-    if (c == 0xFFFF) continue;   // exception rows read d from memory (csr_rows_spmv, xpdr_cls_kernel)
-    if (!seen[c]) { seen[c] = 1; dc[c] = hd[i]; }
-    else if (std::memcmp(&dc[c], &hd[i], 8) != 0) return MG_OK;   // not class-constant: keep streaming d
-  }
-  MG_TRY(A.rc_d.alloc(dc.size()));
-  HIP_TRY(hipMemcpy(A.rc_d.p, dc.data(), dc.size() * sizeof(double), hipMemcpyHostToDevice));
-  A.rc_has_d = true;
-  A.d_bound = d_dev;
-  return MG_OK;
-}
-int derive_class_d(Level& L) { return derive_class_d_csr(L.A, L.d.p, L.d.n); }
-// New values on the stored pattern (mg_replace_values_FP64, mg_rap_FP64): the classes are re-derived from the host
-// pattern kept for that purpose; an operator that is no longer redundant falls back to the streaming kernels.
-int refresh_rowclasses(Csr* M, const double* val) {
-  if (!M->has_rc) return MG_OK;
-  if (M->h_rp.size() != (size_t)M->n_rows + 1) { M->drop_rc(); return MG_OK; }
-  return build_rowclasses(M, M->h_rp.data(), M->h_ci.data(), val);
-}
-
-// Validate Julia's (colptr,rowval,nzval) of the transposed CSC (1-based Int64), convert to 0-based int32
-// CSR (the reference's C side does the -1 per access, parRelax.h:24-27), cut the rows into row blocks
-// and upload.
-int upload_csr(Csr* M, const Options& opt, long long n_rows, long long n_cols, const long long* colptr,
-               const long long* rowval, const double* nzval, long long regular_cols = -1, long long regular_rows = -1) {
-  if (n_rows < 1 || n_cols < 1 || !colptr || !rowval || !nzval)
-    return fail(MG_ERR_INVALID, "empty operator or null array");
-  if (n_rows >= (1LL << 31) - 1 || n_cols >= (1LL << 31) - 1)
-    return fail(MG_ERR_UNSUPPORTED, "dimension exceeds int32 device indices");
-  if (colptr[0] != 1) return fail(MG_ERR_INVALID, "colptr[1] must be 1 (1-based Julia arrays expected)");
-  const long long nnz = colptr[n_rows] - 1;
-  if (nnz < 0 || nnz >= (1LL << 31) - 4096)
-    return fail(MG_ERR_UNSUPPORTED, "nnz=%lld does not fit int32 row pointers on device", nnz);
-  std::vector<int> rp((size_t)n_rows + 1);
-  for (long long i = 0; i <= n_rows; ++i) {
-    const long long v = colptr[i] - 1;
-    if (v < 0 || v > nnz || (i > 0 && v < (long long)rp[(size_t)i - 1]))
-      return fail(MG_ERR_INVALID, "colptr is not a monotone 1-based pointer array at %lld", i);
-    rp[(size_t)i] = (int)v;
-  }
-  const size_t pad = 2 * mgk::BLK;  // loads of a trailing (idx, idx+1) pair stay in bounds
-  std::vector<int> ci((size_t)nnz + pad, 0);
-  for (long long k = 0; k < nnz; ++k) {
-    const long long c = rowval[k] - 1;
-    if (c < 0 || c >= n_cols) return fail(MG_ERR_INVALID, "rowval[%lld]=%lld outside 1..%lld", k + 1, rowval[k], n_cols);
-    ci[(size_t)k] = (int)c;
-  }
-  // row blocks: consecutive rows, <= maxrows rows and an (even-aligned) nnz span <= chunk
-  // (a box-form local operator computes its owned rows only: the empty halo rows behind them get no row block)
-  const long long n_rows_blk = regular_cols >= 0 ? (regular_rows >= 0 ? regular_rows : std::min(regular_cols, n_rows)) : n_rows;
-  auto make_blocks = [&](int maxrows, int chunk) {
-    std::vector<int> bl;
-    bl.push_back(0);
-    long long r = 0;
-    while (r < n_rows_blk) {
-      const long long base = rp[(size_t)r] & ~1LL;
-      long long e = r + 1;  // a block always holds at least one row (a longer row takes the long-row path)
-      while (e < n_rows_blk && (e - r) < maxrows && (rp[(size_t)e + 1] - base) <= chunk) ++e;
-      bl.push_back((int)e);
-      r = e;
-    }
-    return bl;
-  };
-  std::vector<int> blk = make_blocks(mgk::MAXROWS, mgk::CHUNK);
-  std::vector<int> blk_mm = make_blocks(mgk::MM_MAXROWS, mgk::MM_CHUNK);
-  M->release();
-  M->opt = opt;
-  M->regular_cols = regular_cols;
-  M->regular_rows = regular_rows;
-  M->n_rows = n_rows;
-  M->n_cols = n_cols;
-  M->nnz = nnz;
-  M->nblocks = (int)blk.size() - 1;
-  MG_TRY(M->rowptr.alloc(rp.size()));
-  MG_TRY(M->colidx.alloc(ci.size()));
-  MG_TRY(M->val.alloc((size_t)nnz + pad));
-  MG_TRY(M->blk_row.alloc(blk.size()));
-  HIP_TRY(hipMemcpy(M->rowptr.p, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->colidx.p, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(M->val.p, 0, ((size_t)nnz + pad) * sizeof(double)));
-  HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(M->blk_row.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
-  M->h_blk_row = blk;
-  M->max_row_nnz = 0;
-  for (long long i = 0; i < n_rows; ++i) M->max_row_nnz = std::max(M->max_row_nnz, rp[(size_t)i + 1] - rp[(size_t)i]);
-  M->nblocks_mm = (int)blk_mm.size() - 1;
-  MG_TRY(M->blk_row_mm.alloc(blk_mm.size()));
-  HIP_TRY(hipMemcpy(M->blk_row_mm.p, blk_mm.data(), blk_mm.size() * sizeof(int), hipMemcpyHostToDevice));
-  M->h_blk_row_mm = blk_mm;
-  M->set = true;
-  // cache policy of the matrix stream: non-temporal once the operator is too large to stay in the
-  // 256 MiB Infinity Cache between two uses anyway (measured, profiles/r01_nt_ab.md: +2..17 % on the
-  // 685 MB..1.4 GB operators of C2, -5..25 % on the 89 MB ones); MG_NT=0/1 forces one policy
-  M->nt = (12.0 * (double)nnz > 128.0e6);
-  if (M->opt.nt >= 0) M->nt = (M->opt.nt == 1);
-  if (!M->opt.no_rowclass) {  // few distinct rows (offsets AND values): no matrix stream at all at nrhs == 1
-    MG_TRY(build_rowclasses(M, rp.data(), ci.data(), nzval));
-    if (M->has_rc) {
-      M->h_rp = rp;
-      M->h_ci = ci;
-    }
-  }
-  {  // pattern-code the column indices when the operator has few distinct row patterns (grid operators)
-    if (!M->opt.no_pattern) MG_TRY(build_patterns(M, rp, ci));
-  }
-  if (M->opt.debug_format)
-      std::fprintf(stderr, "[mgvcycle] operator %lld x %lld, nnz %lld: row classes %lld (dictionary %lld, exception rows %d, "
-                   "implicit first %d, window %d, paired rows %d), patterns %lld\n", M->n_rows, M->n_cols, M->nnz, M->has_rc ? M->rc_ncls : 0,
-                   M->has_rc ? M->rc_entries : 0, M->rc_nexc, (int)M->rc_implicit, (int)M->rc_window, (int)M->rc_pair,
-                   M->has_pat ? M->npat : 0);
-  return MG_OK;
-}
-
-// column -> entries in ascending row order (stable counting sort of the stored pattern), for colsumsq_kernel
-int build_transposed_pattern(Csr& A) {
-  if (A.has_t) return MG_OK;
-  std::vector<int> rp((size_t)A.n_rows + 1), ci((size_t)A.nnz);
-  HIP_TRY(hipMemcpy(rp.data(), A.rowptr.p, rp.size() * sizeof(int), hipMemcpyDeviceToHost));
-  if (A.nnz > 0) HIP_TRY(hipMemcpy(ci.data(), A.colidx.p, ci.size() * sizeof(int), hipMemcpyDeviceToHost));
-  std::vector<int> tp((size_t)A.n_cols + 1, 0), perm((size_t)std::max<long long>(A.nnz, 1));
-  for (long long k = 0; k < A.nnz; ++k) ++tp[(size_t)ci[(size_t)k] + 1];
-  for (long long j = 0; j < A.n_cols; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
-  std::vector<int> next(tp.begin(), tp.end() - 1);
-  for (long long i = 0; i < A.n_rows; ++i)
-    for (int k = rp[(size_t)i]; k < rp[(size_t)i + 1]; ++k) perm[(size_t)next[(size_t)ci[(size_t)k]]++] = k;
-  MG_TRY(A.t_ptr.alloc(tp.size()));
-  MG_TRY(A.t_perm.alloc(perm.size()));
-  HIP_TRY(hipMemcpy(A.t_ptr.p, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(A.t_perm.p, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice));
-  A.has_t = true;
-  return MG_OK;
-}
-
-Csr* pick(mg_hierarchy* h, long long level, long long which) {
-  if (level < 1 || level > h->nlevels) return nullptr;
-  Level& L = h->lev[level - 1];
-  if (which == MG_OP_A) return &L.A;
-  if (which == MG_OP_P) return &L.P;
-  if (which == MG_OP_R) return &L.R;
-  return nullptr;
-}
-
-}  // namespace
-
-// =================================================================================================
-// C ABI
-// =================================================================================================
-extern "C" {
-
-const char* mg_last_error(void) { return g_err.c_str(); }
-const char* mg_version(void) { return "mgvcycle 0.1 (gfx950, fp64, csr-stream)"; }
-
-int mg_create(long long nlevels, long long nrhs, long long device_id, mg_hierarchy** out) {
-  if (!out) return fail(MG_ERR_INVALID, "out is null");
-  *out = nullptr;
-  if (nlevels < 1 || nlevels > 64) return fail(MG_ERR_INVALID, "nlevels=%lld out of range [1,64]", nlevels);
-  if (nrhs < 1) return fail(MG_ERR_INVALID, "nrhs=%lld must be >= 1", nrhs);
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
-  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
-  HIP_TRY(hipSetDevice((int)device_id));
-  mg_hierarchy* h = new mg_hierarchy();
-  h->opt = Options::from_env();   // the only place the environment is read for this handle
-  h->device = (int)device_id;
-  h->nlevels = nlevels;
-  h->nrhs = nrhs;
-  h->lev.resize((size_t)nlevels);
-  h->slots.resize((size_t)nlevels * MG_K_COUNT);
-  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    delete h;
-    return fail(MG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
-  }
-  if (h->partial.alloc((size_t)h->nred_blocks) != MG_OK || h->partial2.alloc(256) != MG_OK || h->scalar.alloc(1) != MG_OK ||
-      hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), 4 * sizeof(double)) != hipSuccess) {
-    mg_destroy(h);
-    return fail(MG_ERR_HIP, "allocation of reduction scratch failed");
-  }
-  *out = h;
-  return MG_OK;
-}
-
-// replaceMatrixInHierarchy on the device (MGsetup.jl:226-270): new fine values (same sparsity), then per level
-// relaxPrecs[l] = getRelaxPrec(As[l]) and As[l+1] = Ps[l]*As[l]*Rs[l] on the fixed patterns.  The coarsest
-// factorisation stays with the host: fetch the coarsest values with mg_get_values_FP64, factor, hand the
-// inverse back with mg_set_coarse_dense_inverse_FP64 and call mg_finalize.
-int mg_rap_FP64(mg_hierarchy* h, const double* fine_nzval, long long nnz, long long relaxKind,
-                const double* omega, long long* levels_done) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  if (!fine_nzval || !omega) return fail(MG_ERR_INVALID, "null argument");
-  if (relaxKind != 0 && relaxKind != 1) return fail(MG_ERR_INVALID, "relaxKind must be 0 (Jac) or 1 (SPAI)");
-  Level& L0 = h->lev[0];
-  if (nnz != L0.A.nnz) return fail(MG_ERR_INVALID, "nnz=%lld differs from the stored fine pattern (%lld)", nnz, L0.A.nnz);
-  (void)hipSetDevice(h->device);
-  const int nl = (int)h->nlevels;
-  HIP_TRY(spin_sync(h->stream));
-  HIP_TRY(hipMemcpyAsync(L0.A.val.p, fine_nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  for (int l = 0; l + 1 < nl; ++l) {
-    Level& L = h->lev[(size_t)l];
-    Level& C = h->lev[(size_t)l + 1];
-    const int nb = (int)((L.n + mgk::BLK - 1) / mgk::BLK);
-    if (relaxKind == 0) {
-      hipLaunchKernelGGL(mgk::relax_jacobi, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), omega[l], L.d.p);
-    } else {
-      MG_TRY(build_transposed_pattern(L.A));   // (first SPAI re-setup of this level only)
-      hipLaunchKernelGGL(mgk::colsumsq_kernel, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.val.p, L.A.t_ptr.p, L.A.t_perm.p,
-                         (int)L.A.n_cols, L.r.p);   // L.r as scratch for the column sums
-      hipLaunchKernelGGL(mgk::relax_spai, dim3(nb), dim3(mgk::BLK), 0, h->stream, L.A.dev(), omega[l], L.r.p, L.d.p);
-    }
-    hipLaunchKernelGGL(mgk::rap_numeric, dim3((unsigned)C.n), dim3(64), 0, h->stream, L.R.dev(), L.A.dev(), L.P.dev(),
-                       C.A.rowptr.p, C.A.colidx.p, C.A.val.p, (int)std::max<long long>(1, std::min<long long>(h->opt.rap_chunk, mgk::RAP_CAP)));
-    HIP_TRY(hipGetLastError());
-  }
-  HIP_TRY(spin_sync(h->stream));
-  // row-class dictionaries follow the new values (coarse values come back from HBM; rap_numeric adds every entry in a
-  // fixed order, so rows that were bit-identical before a constant-coefficient update still are afterwards)
-  MG_TRY(refresh_rowclasses(&L0.A, fine_nzval));
-  for (int l = 1; l < nl; ++l) {
-    Csr& Ac = h->lev[(size_t)l].A;
-    if (!Ac.has_rc) continue;
-    std::vector<double> hv((size_t)Ac.nnz);
-    HIP_TRY(hipMemcpy(hv.data(), Ac.val.p, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
-    MG_TRY(refresh_rowclasses(&Ac, hv.data()));
-  }
-  for (int l = 0; l + 1 < nl; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));   // relaxPrecs were recomputed above
-  for (int l = 0; l < nl; ++l) {   // tile / march tables follow the new classes
-    MG_TRY(build_staged(h->lev[(size_t)l].A, h->lev[(size_t)l].grid));
-  }
-  if (levels_done) *levels_done = nl - 1;
-  return MG_OK;
-}
-
-int mg_get_values_FP64(mg_hierarchy* h, long long level, long long which, double* out, long long nnz) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  if (!out || nnz != M->nnz) return fail(MG_ERR_INVALID, "nnz=%lld differs from the stored pattern (%lld)", nnz, M->nnz);
-  (void)hipSetDevice(h->device);
-  HIP_TRY(spin_sync(h->stream));
-  HIP_TRY(hipMemcpy(out, M->val.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
-  return MG_OK;
-}
-
-int mg_get_relax_FP64(mg_hierarchy* h, long long level, double* out, long long n) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  Level& L = h->lev[(size_t)level - 1];
-  if (!out || !L.relax_set || n != (long long)L.d.n) return fail(MG_ERR_INVALID, "relaxPrecs[%lld] not set or wrong length", level);
-  (void)hipSetDevice(h->device);
-  HIP_TRY(spin_sync(h->stream));
-  HIP_TRY(hipMemcpy(out, L.d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-  return MG_OK;
-}
-
-int mg_destroy(mg_hierarchy* h) {
-  if (!h) return MG_OK;
-  graphs_clear(h);
-  (void)hipSetDevice(h->device);
-  if (h->stream) (void)spin_sync(h->stream);
-  prof_collect(h);
-  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-  for (auto& L : h->lev) {
-    L.A.release();
-    L.P.release();
-    L.R.release();
-    L.d.release();
-    L.b.release();
-    L.r.release();
-    L.x0.release();
-    L.x1.release();
-    L.x2.release();
-    L.x3.release();
-  }
-  h->m3sink.release();
-  h->Ainv.release();
-  for (DevBuf<int>* d : {&h->luLptr, &h->luLcol, &h->luUptr, &h->luUcol, &h->luP, &h->luQ, &h->luLorder, &h->luLlvl,
-                         &h->luUorder, &h->luUlvl})
-    d->release();
-  h->luLval.release();
-  h->luUval.release();
-  h->luWork.release();
-  h->luInvL.release(); h->luInvU.release(); h->luTail.release(); h->luLslot.release(); h->luUslot.release();
-  h->kwc.release();
-  h->coarse_d.release();
-  h->partial.release();
-  h->partial2.release();
-  h->scalar.release();
-  h->stage_b.release();
-  h->stage_x.release();
-  h->stage_t.release();
-  h->kr.release();
-  h->kz.release();
-  h->kp.release();
-  h->kAp.release();
-  h->kw.release();
-  if (h->h_scalar) (void)hipHostFree(h->h_scalar);
-  for (hipEvent_t& e : h->pipe_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-  if (h->h_blk) (void)hipHostFree(h->h_blk);
-  if (h->h_kscal) (void)hipHostFree(h->h_kscal);
-  if (h->h_blk_c) (void)hipHostFree(h->h_blk_c);
-  h->blk_partial.release();
-  h->blk_c.release();
-  if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
-  delete h;
-  return MG_OK;
-}
-
-int mg_set_operator_FP64_INT64(mg_hierarchy* h, long long level, long long which, long long n_rows,
-                               long long n_cols, const long long* colptr, const long long* rowval,
-                               const double* nzval) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  Csr* M = pick(h, level, which);
-  if (!M) return fail(MG_ERR_INVALID, "bad (level=%lld, which=%lld)", level, which);
-  if ((which == MG_OP_P || which == MG_OP_R) && level == h->nlevels)
-    return fail(MG_ERR_INVALID, "the coarsest level %lld has no transfer operators", level);
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_csr(M, h->opt, n_rows, n_cols, colptr, rowval, nzval));
-  h->finalized = false;
-  return MG_OK;
-}
-
-int mg_set_relax_FP64(mg_hierarchy* h, long long level, const double* d, long long n,
-                      long long relaxPre, long long relaxPost) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  if (!d || n < 1) return fail(MG_ERR_INVALID, "empty relaxPrec");
-  if (relaxPre < 0 || relaxPost < 0) return fail(MG_ERR_INVALID, "negative sweep count");
-  (void)hipSetDevice(h->device);
-  Level& L = h->lev[(size_t)level - 1];
-  MG_TRY(L.d.alloc((size_t)n));
-  HIP_TRY(hipMemcpy(L.d.p, d, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-  L.relax_set = true;
-  L.A.rc_has_d = false;   // re-derived by mg_finalize
-  L.npre = relaxPre;
-  L.npost = relaxPost;
-  h->finalized = false;
-  return MG_OK;
-}
-
-// Override one format-selection switch of this handle (the names of DESIGN.md's table without the MG_ prefix, lower
-// case: "no_rowclass", "no_tile", "tile_min_wg", ...).  Takes effect for operators uploaded afterwards and for the next
-// mg_finalize; call it right after mg_create.
-int mg_set_option(mg_hierarchy* h, const char* key, double value) {
-  if (!h || !key) return fail(MG_ERR_INVALID, "null argument");
-  graphs_clear(h);
-  if (!h->opt.set(key, value, false)) return fail(MG_ERR_INVALID, "unknown option '%s'", key);
-  for (auto& L : h->lev) {
-    L.A.opt = h->opt;
-    L.P.opt = h->opt;
-    L.R.opt = h->opt;
-  }
-  h->finalized = false;
-  return MG_OK;
-}
-
-int mg_graph_launches(mg_hierarchy* h, long long* launches, long long* graphs) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (launches) *launches = h->graph_launches;
-  if (graphs) *graphs = (long long)h->graphs.size();
-  return MG_OK;
-}
-
-int mg_set_grid_hint(mg_hierarchy* h, long long level, long long n1, long long n2, long long n3) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  if (n1 < 1 || n2 < 1 || n3 < 1) return fail(MG_ERR_INVALID, "grid dimensions must be >= 1");
-  Level& L = h->lev[(size_t)level - 1];
-  L.grid[0] = n1;
-  L.grid[1] = n2;
-  L.grid[2] = n3;
-  h->finalized = false;
-  return MG_OK;
-}
-
-int mg_set_relax_type(mg_hierarchy* h, long long relaxType) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  if (relaxType != 0 && relaxType != 1) return fail(MG_ERR_INVALID, "relaxType must be 0 (Jac/SPAI) or 1 (Jac-GMRES)");
-  h->relax_type = (int)relaxType;
-  h->finalized = false;
-  return MG_OK;
-}
-
-int mg_set_cycle_type(mg_hierarchy* h, long long cycleType) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F' && cycleType != 'K')
-    return fail(MG_ERR_INVALID, "cycleType must be 'V', 'W', 'F' or 'K'");
-  if (h->cycle == (char)cycleType) return MG_OK;   // (the cycle type is part of the graph key: nothing to drop)
-  graphs_clear(h);
-  if ((cycleType == 'K') != (h->cycle == 'K')) h->finalized = false;  // memKcycle must be (de)allocated
-  h->cycle = (char)cycleType;
-  return MG_OK;
-}
-
-int mg_set_coarse_dense_inverse_FP64(mg_hierarchy* h, long long n, const double* Ainv) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  if (n < 1 || !Ainv) return fail(MG_ERR_INVALID, "empty coarse inverse");
-  if (n > 46000) return fail(MG_ERR_UNSUPPORTED, "dense coarse inverse of order %lld is too large", n);
-  (void)hipSetDevice(h->device);
-  // column-major -> row-major on the host (one-off, setup time)
-  std::vector<double> rm((size_t)n * (size_t)n);
-  for (long long j = 0; j < n; ++j)
-    for (long long i = 0; i < n; ++i) rm[(size_t)i * n + j] = Ainv[(size_t)j * n + i];
-  MG_TRY(h->Ainv.alloc(rm.size()));
-  HIP_TRY(hipMemcpy(h->Ainv.p, rm.data(), rm.size() * sizeof(double), hipMemcpyHostToDevice));
-  h->n_coarse = n;
-  h->coarse_set = true;
-  h->coarse_lu = false;
-  h->coarse_gmres = false;
-  h->finalized = false;
-  return MG_OK;
-}
-
-// Coarsest solve from sparse LU factors in the layout of the reference's native applier (deps/src/parLU.cpp:120-190;
-// produced by setupLUFactor, parallelJuliaSolver.jl:113-148): CSR L (diagonal last in each row) and U (diagonal first),
-// 1-based Int64 row pointers / column indices, permutations p, q with A[p,q] = L*U, i.e. x[q] = U \ (L \ b[p]).
-int mg_set_coarse_lu_FP64_INT64(mg_hierarchy* h, long long n, const long long* Lptr, const long long* Lcol,
-                                const double* Lval, const long long* Uptr, const long long* Ucol,
-                                const double* Uval, const long long* p, const long long* q) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  if (n < 1 || !Lptr || !Lcol || !Lval || !Uptr || !Ucol || !Uval || !p || !q) return fail(MG_ERR_INVALID, "null or empty factor");
-  if (n >= (1LL << 31) - 1 || Lptr[n] - 1 >= (1LL << 31) || Uptr[n] - 1 >= (1LL << 31))
-    return fail(MG_ERR_UNSUPPORTED, "factors exceed int32 device indices");
-  (void)hipSetDevice(h->device);
-  const size_t N = (size_t)n;
-  // dependency levels of the rows [0, n-M) of a triangular factor; the trailing M rows are handled apart (for U they
-  // are solved BEFORE every level, for L after all of them), so they impose no ordering here
-  auto levels = [&](const std::vector<int>& P, const std::vector<int>& Cc, bool lower, int M, std::vector<int>& order,
-                    std::vector<int>& lvlptr) {
-    const int na = (int)n - M;
-    std::vector<int> lvl((size_t)na, 0);
-    int nl = 0;
-    if (lower) {
-      for (int i = 0; i < na; ++i) {
-        int m = 0;
-        for (int k = P[(size_t)i]; k < P[(size_t)i + 1] - 1; ++k) m = std::max(m, lvl[(size_t)Cc[(size_t)k]] + 1);
-        lvl[(size_t)i] = m;
-        nl = std::max(nl, m + 1);
-      }
-    } else {
-      for (int i = na - 1; i >= 0; --i) {
-        int m = 0;
-        for (int k = P[(size_t)i] + 1; k < P[(size_t)i + 1]; ++k)
-          if (Cc[(size_t)k] < na) m = std::max(m, lvl[(size_t)Cc[(size_t)k]] + 1);
-        lvl[(size_t)i] = m;
-        nl = std::max(nl, m + 1);
-      }
-    }
-    lvlptr.assign((size_t)nl + 1, 0);
-    for (int i = 0; i < na; ++i) lvlptr[(size_t)lvl[(size_t)i] + 1]++;
-    for (int l = 0; l < nl; ++l) lvlptr[(size_t)l + 1] += lvlptr[(size_t)l];
-    order.resize((size_t)na);
-    std::vector<int> pos(lvlptr.begin(), lvlptr.end() - 1);
-    for (int i = 0; i < na; ++i) order[(size_t)pos[(size_t)lvl[(size_t)i]]++] = i;
-  };
-  auto conv = [&](const long long* ptr, const long long* col, bool lower, std::vector<int>& P, std::vector<int>& Cc,
-                  std::vector<int>& order, std::vector<int>& lvlptr) -> int {
-    const long long nnz = ptr[n] - 1;
-    P.resize(N + 1);
-    Cc.resize((size_t)nnz);
-    for (size_t i = 0; i <= N; ++i) P[i] = (int)(ptr[i] - 1);
-    for (long long k = 0; k < nnz; ++k) {
-      const long long c = col[k] - 1;
-      if (c < 0 || c >= n) return fail(MG_ERR_INVALID, "factor column index out of range");
-      Cc[(size_t)k] = (int)c;
-    }
-    if (lower) {
-      for (size_t i = 0; i < N; ++i) {
-        if (P[i + 1] - P[i] < 1 || Cc[(size_t)P[i + 1] - 1] != (int)i) return fail(MG_ERR_INVALID, "L: the diagonal must be the last entry of row %zu", i + 1);
-        for (int k = P[i]; k < P[i + 1] - 1; ++k)
-          if (Cc[(size_t)k] >= (int)i) return fail(MG_ERR_INVALID, "L is not lower triangular");
-      }
-    } else {
-      for (size_t ii = 0; ii < N; ++ii) {
-        if (P[ii + 1] - P[ii] < 1 || Cc[(size_t)P[ii]] != (int)ii) return fail(MG_ERR_INVALID, "U: the diagonal must be the first entry of row %zu", ii + 1);
-        for (int k = P[ii] + 1; k < P[ii + 1]; ++k)
-          if (Cc[(size_t)k] <= (int)ii) return fail(MG_ERR_INVALID, "U is not upper triangular");
-      }
-    }
-    levels(P, Cc, lower, 0, order, lvlptr);
-    return MG_OK;
-  };
-  std::vector<int> LP, LC, LO, LL, UP, UC, UO, UL, pp(N), qq(N);
-  MG_TRY(conv(Lptr, Lcol, true, LP, LC, LO, LL));
-  MG_TRY(conv(Uptr, Ucol, false, UP, UC, UO, UL));
-  for (size_t i = 0; i < N; ++i) {
-    if (p[i] < 1 || p[i] > n || q[i] < 1 || q[i] > n) return fail(MG_ERR_INVALID, "permutation entry out of range");
-    pp[i] = (int)(p[i] - 1);
-    qq[i] = (int)(q[i] - 1);
-  }
-  auto up_i = [&](DevBuf<int>& d, const std::vector<int>& v) -> int {
-    MG_TRY(d.alloc(v.size()));
-    HIP_TRY(hipMemcpy(d.p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
-    return MG_OK;
-  };
-  MG_TRY(up_i(h->luLptr, LP)); MG_TRY(up_i(h->luLcol, LC)); MG_TRY(up_i(h->luLorder, LO)); MG_TRY(up_i(h->luLlvl, LL));
-  MG_TRY(up_i(h->luUptr, UP)); MG_TRY(up_i(h->luUcol, UC)); MG_TRY(up_i(h->luUorder, UO)); MG_TRY(up_i(h->luUlvl, UL));
-  MG_TRY(up_i(h->luP, pp)); MG_TRY(up_i(h->luQ, qq));
-  MG_TRY(h->luLval.alloc(LC.size()));
-  MG_TRY(h->luUval.alloc(UC.size()));
-  HIP_TRY(hipMemcpy(h->luLval.p, Lval, LC.size() * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->luUval.p, Uval, UC.size() * sizeof(double), hipMemcpyHostToDevice));
-  h->nLlvl = (int)LL.size() - 1;
-  h->nUlvl = (int)UL.size() - 1;
-  // chip-wide form: the trailing chains of single-row levels (rows n-1, n-2, ... one per level: the dense last
-  // supernode) are solved through the explicit inverse of their dense block
-  h->lu_multi = n >= h->opt.lu_multi_min_rows;
-  h->luML = h->luMU = 0;
-  h->luInvL.release(); h->luInvU.release(); h->luTail.release();
-  if (h->lu_multi) {
-    // Size M of the trailing block: a level costs ~8 us of dependent latency whatever its width, the dense product
-    // 8*M^2/2 bytes of traffic per factor - take the candidate with the smallest estimate.  (33^3 Poisson level under
-    // a minimum-degree ordering: 3284 levels per factor at M = 0, 639 at M = 4096, 132 at M = 8192.)
-    const int cap = (int)std::min<long long>(h->opt.lu_dense_tail_max, n);
-    int M = 0;
-    double best = 0.0;
-    std::vector<int> o, lp;
-    for (int cand = 0; cand <= cap; cand = cand == 0 ? (int)std::max<long long>(h->opt.lu_dense_tail_min, 1) : cand * 2) {
-      levels(LP, LC, true, cand, o, lp);
-      double est = 8e-6 * (double)(lp.size() - 1);
-      levels(UP, UC, false, cand, o, lp);
-      est += 8e-6 * (double)(lp.size() - 1) + 2.0 * 4.0 * (double)cand * (double)cand / 4e12;
-      if (cand == 0 || est < best) { best = est; M = cand; }
-    }
-    auto slots = [&](const std::vector<int>& P, bool lower, const std::vector<int>& order, DevBuf<int>& d) -> int {
-      std::vector<int> sl(order.size() * 4);
-      for (size_t t = 0; t < order.size(); ++t) {
-        const int r = order[t];
-        sl[4 * t] = r;
-        sl[4 * t + 1] = lower ? P[(size_t)r] : P[(size_t)r] + 1;          // off-diagonal entries [s, e)
-        sl[4 * t + 2] = lower ? P[(size_t)r + 1] - 1 : P[(size_t)r + 1];
-        sl[4 * t + 3] = lower ? P[(size_t)r + 1] - 1 : P[(size_t)r];      // the diagonal entry
-      }
-      return up_i(d, sl);
-    };
-    levels(LP, LC, true, M, o, h->luLlvl_h);
-    MG_TRY(slots(LP, true, o, h->luLslot));
-    levels(UP, UC, false, M, o, h->luUlvl_h);
-    MG_TRY(slots(UP, false, o, h->luUslot));
-    const int ML = M, MU = M;
-    auto invert = [&](bool lower, int M, const DevBuf<int>& ptr, const DevBuf<int>& col, const DevBuf<double>& val,
-                      DevBuf<double>& inv) -> int {
-      const int ld = (M + 63) / 64 * 64;
-      DevBuf<double> D;
-      MG_TRY(D.alloc((size_t)ld * (size_t)ld));
-      MG_TRY(inv.alloc((size_t)ld * (size_t)ld));
-      HIP_TRY(hipMemsetAsync(D.p, 0, (size_t)ld * (size_t)ld * sizeof(double), h->stream));
-      hipLaunchKernelGGL(mgk::tri_gather_block, dim3((unsigned)(((long long)ld * 64 + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK),
-                         0, h->stream, ptr.p, col.p, val.p, (int)n - M, M, ld, D.p);
-      if (lower) hipLaunchKernelGGL(mgk::tri_inverse<true>, dim3((unsigned)(ld / 64)), dim3(256), 0, h->stream, D.p, inv.p, ld);
-      else hipLaunchKernelGGL(mgk::tri_inverse<false>, dim3((unsigned)(ld / 64)), dim3(256), 0, h->stream, D.p, inv.p, ld);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      return MG_OK;
-    };
-    if (ML > 0) MG_TRY(invert(true, ML, h->luLptr, h->luLcol, h->luLval, h->luInvL));
-    if (MU > 0) MG_TRY(invert(false, MU, h->luUptr, h->luUcol, h->luUval, h->luInvU));
-    h->luML = ML;
-    h->luMU = MU;
-    if (h->opt.debug_format)
-      std::fprintf(stderr, "[mgvcycle] coarse LU n=%lld: dense trailing block %d, L %zu levels ahead of it (%d in all), U %zu behind it (%d)\n",
-                   n, M, h->luLlvl_h.size() - 1, h->nLlvl, h->luUlvl_h.size() - 1, h->nUlvl);
-  }
-  h->n_coarse = n;
-  h->coarse_set = true;
-  h->coarse_lu = true;
-  h->coarse_gmres = false;
-  h->Ainv.release();
-  h->finalized = false;
-  return MG_OK;
-}
-
-// Coarsest solve by Jacobi-preconditioned FGMRES (coarseSolveType "GMRES", MGcycle.jl:152-168): d = relaxParam ./ diag(A_c)
-// as defineCoarsestAinv stores it in param.LU (MGsetup.jl:334).
-int mg_set_coarse_gmres_FP64(mg_hierarchy* h, long long n, const double* d) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  if (n < 1 || !d) return fail(MG_ERR_INVALID, "empty preconditioner");
-  (void)hipSetDevice(h->device);
-  MG_TRY(h->coarse_d.alloc((size_t)n));
-  HIP_TRY(hipMemcpy(h->coarse_d.p, d, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-  h->n_coarse = n;
-  h->coarse_set = true;
-  h->coarse_gmres = true;
-  h->coarse_lu = false;
-  h->Ainv.release();
-  h->finalized = false;
-  return MG_OK;
-}
-
-int mg_finalize(mg_hierarchy* h) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  (void)hipSetDevice(h->device);
-  const int nl = (int)h->nlevels;
-  for (int l = 0; l < nl; ++l) {
-    Level& L = h->lev[l];
-    if (h->lu_only && nl == 1 && !L.A.set) {   // mg_lu_*: no operator, only the factors
-      L.n = h->n_coarse;
-      continue;
-    }
-    if (!L.A.set) return fail(MG_ERR_STATE, "As[%d] was not set", l + 1);
-    if (L.A.n_rows != L.A.n_cols) return fail(MG_ERR_INVALID, "As[%d] is not square", l + 1);
-    L.n = L.A.n_rows;
-    if (l < nl - 1) {
-      if (!L.P.set || !L.R.set) return fail(MG_ERR_STATE, "Ps[%d]/Rs[%d] were not set", l + 1, l + 1);
-      if (!L.relax_set) return fail(MG_ERR_STATE, "relaxPrecs[%d] was not set", l + 1);
-      if ((long long)L.d.n != L.n) return fail(MG_ERR_INVALID, "relaxPrecs[%d] has length %zu, expected %lld", l + 1, L.d.n, L.n);
-    }
-  }
-  for (int l = 0; l < nl - 1; ++l) {
-    Level& L = h->lev[l];
-    const long long nc = h->lev[l + 1].A.n_rows;
-    if (L.P.n_rows != L.n || L.P.n_cols != nc)
-      return fail(MG_ERR_INVALID, "Ps[%d] is %lldx%lld, expected %lldx%lld", l + 1, L.P.n_rows, L.P.n_cols, L.n, nc);
-    if (L.R.n_rows != nc || L.R.n_cols != L.n)
-      return fail(MG_ERR_INVALID, "Rs[%d] is %lldx%lld, expected %lldx%lld", l + 1, L.R.n_rows, L.R.n_cols, nc, L.n);
-  }
-  if (!h->coarse_set) return fail(MG_ERR_STATE, "the coarsest solve was not set");
-  if (h->n_coarse != h->lev[nl - 1].n)
-    return fail(MG_ERR_INVALID, "coarse inverse order %lld != coarsest level size %lld", h->n_coarse, h->lev[nl - 1].n);
-  for (int l = 0; l < nl - 1; ++l) MG_TRY(derive_class_d(h->lev[(size_t)l]));
-  MG_TRY(alloc_scratch(h));
-
-  h->finalized = true;
-  return MG_OK;
-}
-
-int mg_set_nrhs(mg_hierarchy* h, long long nrhs) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  if (nrhs < 1) return fail(MG_ERR_INVALID, "nrhs must be >= 1");
-  if (nrhs == h->nrhs) return MG_OK;
-  (void)hipSetDevice(h->device);
-  h->nrhs = nrhs;
-  if (h->finalized) {
-    HIP_TRY(spin_sync(h->stream));
-    MG_TRY(alloc_scratch(h));
-  }
-  return MG_OK;
-}
-
-int mg_replace_values_FP64(mg_hierarchy* h, long long level, long long which, const double* nzval,
-                           long long nnz) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  if (nnz != M->nnz) return fail(MG_ERR_INVALID, "nnz=%lld differs from the stored pattern (%lld)", nnz, M->nnz);
-  (void)hipSetDevice(h->device);
-  HIP_TRY(spin_sync(h->stream));
-  HIP_TRY(hipMemcpy(M->val.p, nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-  MG_TRY(refresh_rowclasses(M, nzval));
-  if (which == MG_OP_A) {
-    Level& L = h->lev[(size_t)level - 1];
-    if (L.relax_set) MG_TRY(derive_class_d(L));
-    MG_TRY(build_staged(L.A, L.grid));
-  }
-  return MG_OK;
-}
-
-// ---- device-resident hot path ---------------------------------------------------------------------
-int mg_cycle_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
-                      long long x_is_zero) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
-  (void)hipSetDevice(h->device);
-  bool xz = (x_is_zero == 1);
-  if (x_is_zero < 0) {  // norm(x)>0.0 decides (MGcycle.jl:29)
-    double xn = 0.0;
-    MG_TRY(norm_sync(h, x, n * nrhs, &xn));
-    xz = (xn == 0.0);
-  }
-  MG_TRY(cycle_dev(h, b, x, xz));
-  HIP_TRY(spin_sync(h->stream));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_solve_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
-                      double tol, long long maxIter, long long* iters, double* resvec) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
-  if (maxIter < 0) return fail(MG_ERR_INVALID, "maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(solve_dev(h, b, x, tol, maxIter, iters, resvec));
-  HIP_TRY(spin_sync(h->stream));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_spmv_dev_FP64(mg_hierarchy* h, long long level, long long which, double alpha,
-                     const double* x, double beta, double* y, long long nrhs) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  if (nrhs != h->nrhs) return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld", nrhs, h->nrhs);
-  if (!x || !y) return fail(MG_ERR_INVALID, "null vector");
-  if (x == y) return fail(MG_ERR_INVALID, "x and y must not alias");
-  (void)hipSetDevice(h->device);
-  MG_TRY(k_spmv(h, (int)level - 1, MG_K_SPMV, *M, alpha, x, beta, y));
-  HIP_TRY(spin_sync(h->stream));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_fused_dev_FP64(mg_hierarchy* h, long long level, long long kernel, const double* b,
-                      const double* x, double* out, long long nrhs) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  if (nrhs != h->nrhs) return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld", nrhs, h->nrhs);
-  if (!b || !x || !out || out == x) return fail(MG_ERR_INVALID, "null vector or out aliases x");
-  Level& L = h->lev[(size_t)level - 1];
-  (void)hipSetDevice(h->device);
-  if (kernel == MG_K_RESIDUAL) {
-    MG_TRY(k_residual(h, (int)level - 1, L.A, b, x, out));
-  } else if (kernel == MG_K_SMOOTH) {
-    if (!L.relax_set) return fail(MG_ERR_STATE, "relaxPrecs[%lld] was not set", level);
-    MG_TRY(k_smooth(h, (int)level - 1, L.A, L.d.p, b, x, out));
-  } else {
-    return fail(MG_ERR_INVALID, "kernel must be MG_K_RESIDUAL or MG_K_SMOOTH");
-  }
-  HIP_TRY(spin_sync(h->stream));
-  prof_collect(h);
-  return MG_OK;
-}
-
-// t = x + d.*(b - A x) and r = b - A t (optionally xn = t + d.*r and ||r||^2) in one pass over the level: the fused
-// form of relax's last sweep + the residual that follows it (MGcycle.jl:129-131 + 58-60; SolveFuncs.jl:26-30).
-int mg_sweep_residual_dev_FP64(mg_hierarchy* h, long long level, const double* b, const double* x, double* t, double* r,
-                               double* xn, double* norm_r) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  if (level < 1 || level >= h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  if (!b || !x || !t) return fail(MG_ERR_INVALID, "null vector");
-  (void)hipSetDevice(h->device);
-  if (!march2_ok(h, (int)level - 1, x, t, r, xn))
-    return fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the two-stage marching kernel (one right-hand side, pointwise "
-                "smoother, grid operator without exception rows, distinct 16-byte aligned buffers)", level);
-  MG_TRY(k_smooth_residual(h, (int)level - 1, b, x, t, r, xn, norm_r != nullptr));
-  if (norm_r) MG_TRY(scalar_sync(h, norm_r));
-  HIP_TRY(spin_sync(h->stream));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_four_stage_dev_FP64(mg_hierarchy* h, long long level, const double* b, const double* x, double* tp, double* rp,
-                           double* norm_r) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  if (level < 1 || level >= h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  if (!b || !x || !tp || !rp) return fail(MG_ERR_INVALID, "null vector");
-  (void)hipSetDevice(h->device);
-  if (!march4_ok(h, (int)level - 1, x, tp, rp))
-    return fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the four-stage pass (one right-hand side, pointwise smoother, two "
-                "pre-smoothing sweeps, z-star grid operator without exception rows, distinct 16-byte aligned buffers)", level);
-  MG_TRY(k_four_stage(h, (int)level - 1, b, x, tp, rp));
-  if (norm_r) MG_TRY(scalar_sync(h, norm_r));
-  HIP_TRY(spin_sync(h->stream));
-  prof_collect(h);
-  return MG_OK;
-}
-// transposeHierarchy (MGsetup.jl:274-318) on the resident hierarchy: As[l] <- As[l]' on every level, Ps[l] <- Rs[l]' (the reference
-// assigns `Ps[l] = sparse(Rs[l]'); Rs[l] = sparse(Ps[l]')` - the second line reads the NEW Ps[l], so Rs[l] keeps its values),
-// relaxPrecs unchanged (conj of real numbers), the coarsest solve for the transposed operator.  The transposes are computed in
-// HBM (transpose_count / _fill / _sort: deterministic stored-order CSR); the device formats are then rebuilt by the upload path
-// from the transposed arrays (row classes, patterns, tile geometries are functions of the operator), mg_finalize included.
-// MG_ERR_UNSUPPORTED (nothing changed) for hierarchies whose coarsest solve is held as sparse factors - the caller re-uploads.
-namespace {
-int transpose_on_device(const Csr& M, std::vector<long long>* colptr1, std::vector<long long>* rowval1, std::vector<double>* nzval) {
-  const long long n = M.n_rows, m = M.n_cols, nnz = M.nnz;
-  DevBuf<int> cnt, cursor, tcol;
-  DevBuf<double> tval;
-  MG_TRY(cnt.alloc((size_t)m + 1));
-  MG_TRY(cursor.alloc((size_t)m));
-  MG_TRY(tcol.alloc((size_t)std::max<long long>(nnz, 1)));
-  MG_TRY(tval.alloc((size_t)std::max<long long>(nnz, 1)));
-  HIP_TRY(hipMemset(cnt.p, 0, cnt.bytes()));
-  HIP_TRY(hipMemset(cursor.p, 0, cursor.bytes()));
-  const unsigned gb = (unsigned)std::min<long long>(65535, std::max<long long>(1, (nnz + mgk::BLK - 1) / mgk::BLK));
-  hipLaunchKernelGGL(mgk::transpose_count, dim3(gb), dim3(mgk::BLK), 0, nullptr, M.colidx.p, nnz, cnt.p);
-  HIP_TRY(hipGetLastError());
-  std::vector<int> tp((size_t)m + 1);
-  HIP_TRY(hipMemcpy(tp.data(), cnt.p, tp.size() * sizeof(int), hipMemcpyDeviceToHost));
-  int longest = 0;
-  for (long long j = 0; j < m; ++j) {
-    longest = std::max(longest, tp[(size_t)j + 1]);
-    tp[(size_t)j + 1] += tp[(size_t)j];
-  }
-  if (longest > 4096) return fail(MG_ERR_UNSUPPORTED, "a column of %d entries: the per-column sort of the device transpose is quadratic", longest);
-  HIP_TRY(hipMemcpy(cnt.p, tp.data(), tp.size() * sizeof(int), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(mgk::transpose_fill, dim3((unsigned)((n + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, nullptr, M.rowptr.p, M.colidx.p,
-                     M.val.p, (int)n, cnt.p, cursor.p, tcol.p, tval.p);
-  hipLaunchKernelGGL(mgk::transpose_sort, dim3((unsigned)((m + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, nullptr, cnt.p, (int)m, tcol.p, tval.p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  std::vector<int> tc((size_t)std::max<long long>(nnz, 1));
-  nzval->resize((size_t)std::max<long long>(nnz, 1));
-  HIP_TRY(hipMemcpy(tc.data(), tcol.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(nzval->data(), tval.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
-  colptr1->resize((size_t)m + 1);
-  rowval1->resize((size_t)std::max<long long>(nnz, 1));
-  for (long long j = 0; j <= m; ++j) (*colptr1)[(size_t)j] = (long long)tp[(size_t)j] + 1;
-  for (long long k = 0; k < nnz; ++k) (*rowval1)[(size_t)k] = (long long)tc[(size_t)k] + 1;
-  return MG_OK;
-}
-}  // namespace
-int mg_transpose_hierarchy(mg_hierarchy* h) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  if (h->coarse_lu) return fail(MG_ERR_UNSUPPORTED, "the coarsest solve is held as sparse factors: re-upload the transposed hierarchy");
-  (void)hipSetDevice(h->device);
-  graphs_clear(h);
-  HIP_TRY(spin_sync(h->stream));
-  const int nl = (int)h->nlevels;
-  std::vector<long long> cp, rv;
-  std::vector<double> nz;
-  for (int l = 0; l < nl; ++l) {
-    Level& L = h->lev[(size_t)l];
-    MG_TRY(transpose_on_device(L.A, &cp, &rv, &nz));
-    const long long nr = L.A.n_cols, nc = L.A.n_rows;
-    MG_TRY(upload_csr(&L.A, h->opt, nr, nc, cp.data(), rv.data(), nz.data()));
-    if (l + 1 < nl) {   // Ps[l] <- Rs[l]'
-      MG_TRY(transpose_on_device(L.R, &cp, &rv, &nz));
-      const long long pr = L.R.n_cols, pc = L.R.n_rows;
-      MG_TRY(upload_csr(&L.P, h->opt, pr, pc, cp.data(), rv.data(), nz.data()));
-    }
-  }
-  if (!h->coarse_gmres && h->Ainv.p) {   // (A')^-1 = (A^-1)'
-    const long long n = h->n_coarse;
-    hipLaunchKernelGGL(mgk::dense_transpose_inplace, dim3((unsigned)((n * n + mgk::BLK - 1) / mgk::BLK)), dim3(mgk::BLK), 0, nullptr, h->Ainv.p, (int)n);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-  }
-  h->finalized = false;
-  return mg_finalize(h);
-}
-
-int mg_operator_shape(mg_hierarchy* h, long long level, long long which, long long* shape) {
-  if (!h || !shape) return fail(MG_ERR_INVALID, "null argument");
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  shape[0] = M->n_rows;
-  shape[1] = M->n_cols;
-  shape[2] = M->nnz;
-  return MG_OK;
-}
-int mg_four_stage_form(mg_hierarchy* h, long long level, long long* yes, long long* geometry) {
-  if (!h || !yes || !geometry) return fail(MG_ERR_INVALID, "null argument");
-  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  const Csr& A = h->lev[(size_t)level - 1].A;
-  *yes = (A.rc_march4 && !h->opt.no_march4) ? 1 : 0;
-  for (int i = 0; i < 12; ++i) geometry[i] = 0;
-  if (A.rc_march4) {
-    const long long g[12] = {A.rm4.tiles_x, A.rm4.tiles_y, A.rm4.TX, A.rm4.TY, A.rm4_k1, A.rm4.nblocks, (long long)A.rm4_lds,
-                             (long long)(A.rm4_fill * 100.0), A.rm4_nt, A.rm4.segs, A.rm4.seglen, A.rm4.ntab};
-    for (int i = 0; i < 12; ++i) geometry[i] = g[i];
-  }
-  return MG_OK;
-}
-
-// ---- host-buffer hot path (what the Julia glue ccalls) ------------------------------------------
-// x == 0 everywhere?  Blocks of 4096 entries are OR-reduced bitwise (vectorises; the element-wise loop with its early
-// exit does not: 13 ms for 136 MB on the box's core) and only a block with a set bit - a non-zero or a -0.0 - is
-// looked at entry by entry.
-static bool host_all_zero(const double* x, long long len) {
-  const long long B = 4096;
-  for (long long i0 = 0; i0 < len; i0 += B) {
-    const long long i1 = std::min(len, i0 + B);
-    unsigned long long acc = 0;
-    for (long long i = i0; i < i1; ++i) {
-      unsigned long long bits;
-      std::memcpy(&bits, x + i, 8);
-      acc |= bits;
-    }
-    if (acc != 0)
-      for (long long i = i0; i < i1; ++i)
-        if (x[i] != 0.0) return false;
-  }
-  return true;
-}
-
-// the caller's initial guess into the staging buffer: x == 0 (the usual call) is a device memset instead of n*nrhs*8
-// bytes over PCIe (the scan of a zero vector runs at memory speed: host_all_zero)
-static int upload_x_or_zero(mg_hierarchy* h, const double* x, long long n, long long nrhs) {
-  const long long len = n * nrhs;
-  if (host_all_zero(x, len)) {
-    HIP_TRY(hipMemsetAsync(h->stage_x.p, 0, sizeof(double) * (size_t)len, h->stream));
-    return MG_OK;
-  }
-  return upload_block(h, x, h->stage_x.p, n, nrhs);
-}
-
-int mg_cycle_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
-                  long long x_is_zero) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
-  (void)hipSetDevice(h->device);
-  bool xz = (x_is_zero == 1);
-  if (x_is_zero < 0) xz = host_all_zero(x, n * nrhs);   // norm(x) > 0.0 decides (MGcycle.jl:29)
-  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  if (!xz) MG_TRY(upload_block(h, x, h->stage_x.p, n, nrhs));
-  MG_TRY(cycle_dev(h, h->stage_b.p, h->stage_x.p, xz));
-  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_solve_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
-                  double tol, long long maxIter, long long* iters, double* resvec) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
-  if (maxIter < 0) return fail(MG_ERR_INVALID, "maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  MG_TRY(upload_x_or_zero(h, x, n, nrhs));
-  MG_TRY(solve_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, resvec));
-  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_pcg_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol,
-                    long long maxIter, long long* iters, long long* flag, double* resvec) {
-  MG_TRY(check_ready(h, n, 1));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(pcg_dev(h, b, x, tol, maxIter, iters, flag, resvec));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol, long long maxIter,
-                long long* iters, long long* flag, double* resvec) {
-  MG_TRY(check_ready(h, n, 1));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
-  MG_TRY(upload_x_or_zero(h, x, n, 1));
-  MG_TRY(pcg_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec));
-  MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long inner, double tol,
-                   long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
-  MG_TRY(check_ready(h, n, 1));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
-  MG_TRY(upload_x_or_zero(h, x, n, 1));
-  MG_TRY(fgmres_dev(h, h->stage_b.p, h->stage_x.p, inner, tol, maxIter, iters, flag, resvec, nres));
-  MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_fgmres_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long inner, double tol,
-                       long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
-  MG_TRY(check_ready(h, n, 1));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(fgmres_dev(h, b, x, inner, tol, maxIter, iters, flag, resvec, nres));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_bicgstab_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol,
-                         long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
-  MG_TRY(check_ready(h, n, 1));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(bicgstab_dev(h, b, x, tol, maxIter, iters, flag, resvec, nres));
-  prof_collect(h);
-  return MG_OK;
-}
-
-int mg_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long long n, double tol, long long maxIter,
-                     long long* iters, long long* flag, double* resvec, long long* nres) {
-  MG_TRY(check_ready(h, n, 1));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_block(h, b, h->stage_b.p, n, 1));
-  MG_TRY(upload_x_or_zero(h, x, n, 1));
-  MG_TRY(bicgstab_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec, nres));
-  MG_TRY(download_block(h, h->stage_x.p, x, n, 1));
-  prof_collect(h);
-  return MG_OK;
-}
-
-// ---- block Krylov drivers: host (column-major n x nrhs) and device-resident (row-major [n][nrhs]) forms ---------------
-int mg_block_pcg_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
-                          long long maxIter, long long* iters, long long* flag, double* resmat) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(block_pcg_dev(h, b, x, tol, maxIter, iters, flag, resmat));
-  prof_collect(h);
-  return MG_OK;
-}
-int mg_block_pcg_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
-                      long long maxIter, long long* iters, long long* flag, double* resmat) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  MG_TRY(upload_x_or_zero(h, x, n, nrhs));
-  MG_TRY(block_pcg_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resmat));
-  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
-  prof_collect(h);
-  return MG_OK;
-}
-int mg_block_bicgstab_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
-                               long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(block_bicgstab_dev(h, b, x, tol, maxIter, iters, flag, resvec, nres));
-  prof_collect(h);
-  return MG_OK;
-}
-int mg_block_bicgstab_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, double tol,
-                           long long maxIter, long long* iters, long long* flag, double* resvec, long long* nres) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  MG_TRY(upload_x_or_zero(h, x, n, nrhs));
-  MG_TRY(block_bicgstab_dev(h, h->stage_b.p, h->stage_x.p, tol, maxIter, iters, flag, resvec, nres));
-  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
-  prof_collect(h);
-  return MG_OK;
-}
-int mg_block_fgmres_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, long long inner,
-                             double tol, long long maxIter, long long* iters, long long* flag, double* resvec,
-                             long long* nres) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(block_fgmres_dev(h, b, x, inner, tol, maxIter, iters, flag, resvec, nres));
-  prof_collect(h);
-  return MG_OK;
-}
-int mg_block_fgmres_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs, long long inner,
-                         double tol, long long maxIter, long long* iters, long long* flag, double* resvec,
-                         long long* nres) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x || maxIter < 0) return fail(MG_ERR_INVALID, "null vector or maxIter < 0");
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_block(h, b, h->stage_b.p, n, nrhs));
-  MG_TRY(upload_x_or_zero(h, x, n, nrhs));
-  MG_TRY(block_fgmres_dev(h, h->stage_b.p, h->stage_x.p, inner, tol, maxIter, iters, flag, resvec, nres));
-  MG_TRY(download_block(h, h->stage_x.p, x, n, nrhs));
-  prof_collect(h);
-  return MG_OK;
-}
-
-// Mixed-precision preconditioner hook (getMultigridPreconditioner, SolveFuncs.jl:52-58): the caller's block is Float32,
-// the hierarchy Float64: bl .= b ; z .= 0 ; recursiveCycle(param, bl, z, 1) ; z2 .= z.  b32 / z32: n x nrhs column-major.
-int mg_cycle_mixed_FP32(mg_hierarchy* h, const float* b32, float* z32, long long n, long long nrhs) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b32 || !z32) return fail(MG_ERR_INVALID, "null vector");
-  (void)hipSetDevice(h->device);
-  const long long len = n * nrhs;
-  float* f32 = reinterpret_cast<float*>(h->stage_t.p);              // n*nrhs doubles of scratch hold n*nrhs floats twice over
-  HIP_TRY(hipMemcpyAsync(f32, b32, sizeof(float) * (size_t)len, hipMemcpyHostToDevice, h->stream));
-  if (nrhs == 1) {
-    hipLaunchKernelGGL(mgk::f32_to_f64, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, f32, h->stage_b.p, len);
-  } else {   // column-major float -> row-major double through stage_x
-    hipLaunchKernelGGL(mgk::f32_to_f64, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, f32, h->stage_x.p, len);
-    hipLaunchKernelGGL(mgk::colmajor_to_rowmajor, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, h->stage_x.p, h->stage_b.p, n, (int)nrhs);
-  }
-  HIP_TRY(hipGetLastError());
-  MG_TRY(cycle_dev(h, h->stage_b.p, h->stage_x.p, true));
-  if (nrhs == 1) {
-    hipLaunchKernelGGL(mgk::f64_to_f32, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, h->stage_x.p, f32, len);
-  } else {
-    hipLaunchKernelGGL(mgk::rowmajor_to_colmajor, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, h->stage_x.p, h->stage_b.p, n, (int)nrhs);
-    hipLaunchKernelGGL(mgk::f64_to_f32, dim3(grid_for(len)), dim3(mgk::BLK), 0, h->stream, h->stage_b.p, f32, len);
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(z32, f32, sizeof(float) * (size_t)len, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(spin_sync(h->stream));
-  prof_collect(h);
-  return MG_OK;
-}
-
-// Page-lock a long-lived host array (param.memCycle[1].x, the caller's b) so that the host-pointer entry points move it
-// at full PCIe rate: the CALLER owns the lifetime - unregister before the array is freed or resized.
-// ---- stand-alone sparse-factor applier: the device counterpart of the reference's parallelJuliaSolver backend 3 --------
-// applyLUsolve_FP64_INT64 (deps/src/parLU.cpp:52-63): x[q] = U \ (L \ b[p]) (l.120-190) and, with doTranspose, the
-// solve with the transposed matrix x[p] = L' \ (U' \ b[q]) (l.194-260), one right-hand side per OpenMP task there.
-// Here: the factors live in HBM in the form of the coarsest solve (level-scheduled, chip-wide for large factors); the
-// transposed solve uses the transposed factors (U' is lower triangular with its diagonal last, L' upper with its
-// diagonal first, the permutations swap roles), built on first use.
-struct mg_lu {
-  int device = 0;
-  long long n = 0;
-  std::vector<long long> Lptr, Lcol, Uptr, Ucol, p, q;
-  std::vector<double> Lval, Uval;
-  mg_hierarchy* fwd = nullptr;
-  mg_hierarchy* trans = nullptr;
-};
-namespace {
-// CSR (1-based) of the transpose of an n x n CSR (1-based) matrix; columns of every row come out ascending
-void transpose_csr1(long long n, const std::vector<long long>& ptr, const std::vector<long long>& col, const std::vector<double>& val,
-                    std::vector<long long>& tp, std::vector<long long>& tc, std::vector<double>& tv) {
-  const size_t nnz = col.size();
-  tp.assign((size_t)n + 1, 0);
-  tc.resize(nnz);
-  tv.resize(nnz);
-  for (size_t k = 0; k < nnz; ++k) tp[(size_t)col[k]]++;            // count of column c at index c (1-based) -> shifted prefix
-  long long run = 1;
-  for (long long c = 0; c < n; ++c) {
-    const long long cnt = tp[(size_t)c + 1];
-    tp[(size_t)c] = run;
-    run += cnt;
-  }
-  tp[(size_t)n] = run;
-  std::vector<long long> pos(tp.begin(), tp.end() - 1);
-  for (long long r = 0; r < n; ++r)
-    for (long long k = ptr[(size_t)r] - 1; k < ptr[(size_t)r + 1] - 1; ++k) {
-      const long long c = col[(size_t)k] - 1;
-      const long long w = pos[(size_t)c]++ - 1;
-      tc[(size_t)w] = r + 1;
-      tv[(size_t)w] = val[(size_t)k];
-    }
-}
-int lu_hierarchy(mg_lu* f, bool transposed, mg_hierarchy** out) {
-  mg_hierarchy*& h = transposed ? f->trans : f->fwd;
-  if (!h) {
-    MG_TRY(mg_create(1, 1, f->device, &h));
-    h->lu_only = true;
-    int rc;
-    if (!transposed) {
-      rc = mg_set_coarse_lu_FP64_INT64(h, f->n, f->Lptr.data(), f->Lcol.data(), f->Lval.data(), f->Uptr.data(), f->Ucol.data(),
-                                       f->Uval.data(), f->p.data(), f->q.data());
-    } else {
-      std::vector<long long> lp, lc, up, uc;
-      std::vector<double> lv, uv;
-      transpose_csr1(f->n, f->Uptr, f->Ucol, f->Uval, lp, lc, lv);   // U' : lower triangular, diagonal last
-      transpose_csr1(f->n, f->Lptr, f->Lcol, f->Lval, up, uc, uv);   // L' : upper triangular, diagonal first
-      rc = mg_set_coarse_lu_FP64_INT64(h, f->n, lp.data(), lc.data(), lv.data(), up.data(), uc.data(), uv.data(), f->q.data(),
-                                       f->p.data());
-    }
-    if (rc == MG_OK) rc = mg_finalize(h);
-    if (rc != MG_OK) {
-      mg_destroy(h);
-      h = nullptr;
-      return rc;
-    }
-  }
-  *out = h;
-  return MG_OK;
-}
-}  // namespace
-
-int mg_lu_create_FP64_INT64(long long device_id, long long n, const long long* Lptr, const long long* Lcol, const double* Lval,
-                            const long long* Uptr, const long long* Ucol, const double* Uval, const long long* p,
-                            const long long* q, mg_lu** out) {
-  if (!out) return fail(MG_ERR_INVALID, "out is null");
-  *out = nullptr;
-  if (n < 1 || !Lptr || !Lcol || !Lval || !Uptr || !Ucol || !Uval || !p || !q) return fail(MG_ERR_INVALID, "null or empty factor");
-  if (Lptr[0] != 1 || Uptr[0] != 1 || Lptr[n] < 1 || Uptr[n] < 1) return fail(MG_ERR_INVALID, "row pointers must be 1-based");
-  mg_lu* f = new mg_lu();
-  f->device = (int)device_id;
-  f->n = n;
-  f->Lptr.assign(Lptr, Lptr + n + 1);
-  f->Uptr.assign(Uptr, Uptr + n + 1);
-  f->Lcol.assign(Lcol, Lcol + (Lptr[n] - 1));
-  f->Lval.assign(Lval, Lval + (Lptr[n] - 1));
-  f->Ucol.assign(Ucol, Ucol + (Uptr[n] - 1));
-  f->Uval.assign(Uval, Uval + (Uptr[n] - 1));
-  f->p.assign(p, p + n);
-  f->q.assign(q, q + n);
-  mg_hierarchy* h = nullptr;
-  const int rc = lu_hierarchy(f, false, &h);   // validates and uploads the factors
-  if (rc != MG_OK) {
-    delete f;
-    return rc;
-  }
-  *out = f;
-  return MG_OK;
-}
-
-// b, x: host, n x nrhs column-major (a Julia Array{Float64,2} or Vector); b is NOT used as work space (the reference
-// overwrites it, parLU.cpp:176)
-int mg_lu_solve_FP64(mg_lu* f, const double* b, double* x, long long n, long long nrhs, long long doTranspose) {
-  if (!f) return fail(MG_ERR_INVALID, "null factor handle");
-  if (n != f->n) return fail(MG_ERR_INVALID, "n=%lld but the factors have order %lld", n, f->n);
-  if (nrhs < 1 || !b || !x) return fail(MG_ERR_INVALID, "bad argument");
-  mg_hierarchy* h = nullptr;
-  MG_TRY(lu_hierarchy(f, doTranspose != 0, &h));
-  MG_TRY(mg_set_nrhs(h, nrhs));
-  return mg_cycle_FP64(h, b, x, n, nrhs, 1);
-}
-
-// device-resident form: b_dev, x_dev row-major [n][nrhs] in HBM
-int mg_lu_solve_dev_FP64(mg_lu* f, const double* b_dev, double* x_dev, long long n, long long nrhs, long long doTranspose) {
-  if (!f) return fail(MG_ERR_INVALID, "null factor handle");
-  if (n != f->n) return fail(MG_ERR_INVALID, "n=%lld but the factors have order %lld", n, f->n);
-  if (nrhs < 1 || !b_dev || !x_dev) return fail(MG_ERR_INVALID, "bad argument");
-  mg_hierarchy* h = nullptr;
-  MG_TRY(lu_hierarchy(f, doTranspose != 0, &h));
-  MG_TRY(mg_set_nrhs(h, nrhs));
-  return mg_cycle_dev_FP64(h, b_dev, x_dev, n, nrhs, 1);
-}
-
-int mg_lu_destroy(mg_lu* f) {
-  if (!f) return MG_OK;
-  if (f->fwd) mg_destroy(f->fwd);
-  if (f->trans) mg_destroy(f->trans);
-  delete f;
-  return MG_OK;
-}
-
-int mg_host_register(void* ptr, long long bytes) {
-  if (!ptr || bytes < 1) return fail(MG_ERR_INVALID, "null pointer or empty range");
-  HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
-  return MG_OK;
-}
-int mg_host_unregister(void* ptr) {
-  if (!ptr) return fail(MG_ERR_INVALID, "null pointer");
-  HIP_TRY(hipHostUnregister(ptr));
-  return MG_OK;
-}
-
-int mg_spmv_FP64(mg_hierarchy* h, long long level, long long which, double alpha, const double* x,
-                 double beta, double* y, long long nrhs) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  if (nrhs != h->nrhs) return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld", nrhs, h->nrhs);
-  if (!x || !y) return fail(MG_ERR_INVALID, "null vector");
-  (void)hipSetDevice(h->device);
-  MG_TRY(upload_block(h, x, h->stage_x.p, M->n_cols, nrhs));
-  if (beta != 0.0) MG_TRY(upload_block(h, y, h->stage_b.p, M->n_rows, nrhs));
-  MG_TRY(k_spmv(h, (int)level - 1, MG_K_SPMV, *M, alpha, h->stage_x.p, beta, h->stage_b.p));
-  MG_TRY(download_block(h, h->stage_b.p, y, M->n_rows, nrhs));
-  prof_collect(h);
-  return MG_OK;
-}
-
-// ---- measurement --------------------------------------------------------------------------------------
-int mg_time_op_dev_FP64(mg_hierarchy* h, long long level, long long kernel, long long nrhs,
-                        long long reps, double* ms_avg, double* bytes) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  if (nrhs != h->nrhs) return fail(MG_ERR_INVALID, "nrhs=%lld but the scratch is sized for %lld", nrhs, h->nrhs);
-  if (reps < 1 || !ms_avg) return fail(MG_ERR_INVALID, "reps < 1 or null output");
-  (void)hipSetDevice(h->device);
-  const int l = (int)level - 1;
-  Level& L = h->lev[(size_t)l];
-  const bool coarsest = (l == (int)h->nlevels - 1);
-  if (coarsest && kernel != MG_K_COARSE && kernel != MG_K_SPMV && kernel != MG_K_RESIDUAL)
-    return fail(MG_ERR_INVALID, "kernel %lld does not run on the coarsest level", kernel);
-  // operands: the level's own scratch (contents are whatever the last cycle left: finite values)
-  const double* bvec = (l == 0) ? (h->last_b ? h->last_b : h->stage_b.p) : L.b.p;
-  double* xa = (l == 0) ? (h->last_x ? h->last_x : h->stage_x.p) : L.x0.p;
-  double* xb = L.x1.p;
-  const bool was_prof = h->prof;
-  h->prof = false;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  double bts = 0.0;
-  int rc = MG_OK;
-  for (long long it = -2; it < reps && rc == MG_OK; ++it) {  // two untimed warm-up launches
-    if (it == 0) (void)hipEventRecord(e0, h->stream);
-    switch (kernel) {
-      case MG_K_SPMV:
-        rc = k_spmv(h, l, MG_K_SPMV, L.A, 1.0, xa, 0.0, L.r.p);
-        bts = spmv_bytes(L.A, nrhs, false, false);
-        break;
-      case MG_K_RESIDUAL:
-        rc = k_residual(h, l, L.A, bvec, xa, L.r.p);
-        bts = spmv_bytes(L.A, nrhs, true, false);
-        break;
-      case MG_K_SMOOTH:
-        rc = k_smooth(h, l, L.A, L.d.p, bvec, xa, xb);
-        bts = spmv_bytes(L.A, nrhs, true, true);
-        break;
-      case MG_K_RESTRICT:
-        rc = k_spmv(h, l, MG_K_RESTRICT, L.R, 1.0, L.r.p, 0.0, h->lev[(size_t)l + 1].b.p);
-        bts = spmv_bytes(L.R, nrhs, false, false);
-        break;
-      case MG_K_SMOOTH_RESIDUAL:
-        if (!march2_ok(h, l, xa, xb, L.r.p, nullptr)) rc = fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the two-stage marching kernel", level);
-        else rc = k_smooth_residual(h, l, bvec, xa, xb, L.r.p, nullptr, false);
-        bts = spmv_bytes(L.A, nrhs, true, true) + spmv_bytes(L.A, nrhs, true, false);
-        break;
-      case MG_K_FOUR_STAGE:
-        if (!march4_ok(h, l, xa, xb, L.r.p)) rc = fail(MG_ERR_UNSUPPORTED, "level %lld is not served by the four-stage pass", level);
-        else rc = k_four_stage(h, l, bvec, xa, xb, L.r.p);
-        bts = 2.0 * (spmv_bytes(L.A, nrhs, true, true) + spmv_bytes(L.A, nrhs, true, false));
-        break;
-      case MG_K_PROLONG:
-        rc = k_spmv(h, l, MG_K_PROLONG, L.P, 0.0, h->lev[(size_t)l + 1].x0.p, 1.0, xb);
-        bts = spmv_bytes(L.P, nrhs, true, false);
-        break;
-      case MG_K_DSCALE:
-        rc = k_dscale(h, l, L.d.p, bvec, xb, L.n);
-        bts = 8.0 * (double)L.n * (1.0 + 2.0 * (double)nrhs);
-        break;
-      case MG_K_COARSE:
-        if (!coarsest) rc = fail(MG_ERR_INVALID, "MG_K_COARSE runs on the coarsest level only");
-        else rc = k_coarse(h, l, L.b.p, L.x0.p);
-        bts = h->coarse_lu ? 12.0 * (double)(h->luLval.n + h->luUval.n) + 16.0 * (double)L.n * (double)nrhs
-                           : 8.0 * ((double)L.n * (double)L.n + 2.0 * (double)L.n * (double)nrhs);
-        break;
-      case MG_K_NORM:
-        rc = k_sumsq(h, L.r.p, L.n * nrhs);
-        bts = 8.0 * (double)L.n * (double)nrhs;
-        break;
-      default:
-        rc = fail(MG_ERR_INVALID, "unknown kernel %lld", kernel);
-    }
-  }
-  if (rc == MG_OK) {
-    (void)hipEventRecord(e1, h->stream);
-    hipError_t e = spin_sync(h->stream);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e != hipSuccess) rc = fail(MG_ERR_HIP, "event timing failed: %s", hipGetErrorString(e));
-    *ms_avg = (double)ms / (double)reps;
-    if (bytes) *bytes = bts;
-  }
-  (void)spin_sync(h->stream);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  h->prof = was_prof;
-  return rc;
-}
-
-int mg_profile_enable(mg_hierarchy* h, long long on) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  h->prof = (on != 0);
-  return MG_OK;
-}
-int mg_profile_reset(mg_hierarchy* h) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  for (auto& s : h->slots) s = ProfSlot();
-  return MG_OK;
-}
-int mg_profile_get(mg_hierarchy* h, long long level, long long kernel, double* total_ms,
-                   long long* launches, double* bytes_per_launch) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (level < 1 || level > h->nlevels || kernel < 0 || kernel >= MG_K_COUNT)
-    return fail(MG_ERR_INVALID, "bad (level=%lld, kernel=%lld)", level, kernel);
-  const ProfSlot& s = h->slots[(size_t)(level - 1) * MG_K_COUNT + (size_t)kernel];
-  if (total_ms) *total_ms = s.ms;
-  if (launches) *launches = s.launches;
-  if (bytes_per_launch) *bytes_per_launch = s.launches > 0 ? s.bytes / (double)s.launches : 0.0;
-  return MG_OK;
-}
-
-int mg_profile_get_moved(mg_hierarchy* h, long long level, long long kernel, double* moved_bytes_per_launch) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  if (level < 1 || level > h->nlevels || kernel < 0 || kernel >= MG_K_COUNT || !moved_bytes_per_launch)
-    return fail(MG_ERR_INVALID, "bad (level=%lld, kernel=%lld)", level, kernel);
-  const ProfSlot& sl = h->slots[(size_t)(level - 1) * MG_K_COUNT + (size_t)kernel];
-  *moved_bytes_per_launch = sl.launches > 0 ? sl.moved / (double)sl.launches : 0.0;
-  return MG_OK;
-}
-
-int mg_operator_format(mg_hierarchy* h, long long level, long long which, long long* npatterns,
-                       long long* dict_entries, double* index_bytes_per_launch) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  if (npatterns) *npatterns = M->has_pat ? M->npat : 0;
-  if (dict_entries) *dict_entries = M->has_pat ? M->dict_entries : 0;
-  // bytes of row pointers + column information one nrhs=1 launch streams
-  if (index_bytes_per_launch)
-    *index_bytes_per_launch = M->has_pat
-        ? (M->has_runs ? 20.0 * (double)M->nruns_total + 8.0 * (double)M->nblocks : 10.0 * (double)M->n_rows) +
-              4.0 * (double)M->dict_entries
-        : 4.0 * (double)M->nnz + 4.0 * (double)(M->n_rows + 1);
-  return MG_OK;
-}
-
-int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, long long* nclasses,
-                           long long* dict_entries, double* matrix_bytes_per_launch) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  if (nclasses) *nclasses = M->has_rc ? M->rc_ncls : 0;
-  if (dict_entries) *dict_entries = M->has_rc ? M->rc_entries : 0;
-  if (matrix_bytes_per_launch) {
-    if (M->has_rc) {
-      *matrix_bytes_per_launch = (M->rc_implicit ? 2.0 : 6.0) * (double)M->n_rows + 12.0 * (double)M->rc_entries;
-    } else if (M->has_pat) {
-      *matrix_bytes_per_launch = 8.0 * (double)M->nnz + 4.0 * (double)M->dict_entries +
-          (M->has_runs ? 20.0 * (double)M->nruns_total + 8.0 * (double)M->nblocks : 10.0 * (double)M->n_rows);
-    } else {
-      *matrix_bytes_per_launch = 12.0 * (double)M->nnz + 4.0 * (double)(M->n_rows + 1);
-    }
-  }
-  return MG_OK;
-}
-
-int mg_operator_rowclass_flags(mg_hierarchy* h, long long level, long long which, long long* implicit_first,
-                               long long* class_relax, long long* kernel_variant, long long* exception_rows) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  Csr* M = pick(h, level, which);
-  if (!M || !M->set) return fail(MG_ERR_INVALID, "operator (level=%lld, which=%lld) not set", level, which);
-  if (implicit_first) *implicit_first = (M->has_rc && M->rc_implicit) ? 1 : 0;
-  if (class_relax) *class_relax = (M->has_rc && M->rc_has_d) ? 1 : 0;
-  if (kernel_variant) {
-    if (h->nrhs > 1)   // block right-hand sides: 5 csr_rowclass_lane_spmm, 6 csr_rowclass_lane_spmm2, else the CSR stream
-      *kernel_variant = (M->has_rc && M->rc_lane_mm() && M->ln_blocks > 0) ? (lane_mm_pairs(*M, h->nrhs) ? 6 : 5) : -1;
-    else
-      *kernel_variant = !M->has_rc ? -1 : M->rc_march ? 3 : M->rc_tile ? 2 : M->rc_window ? 1 : M->rc_lane() ? 4 : 0;
-  }
-  if (exception_rows) *exception_rows = M->has_rc ? M->rc_nexc : 0;
-  return MG_OK;
-}
-
-// Which kernel fuses a sweep with the residual that follows it on this level's A (one right-hand side): *form = 0 none
-// (two launches), 2 csr_rowclass_march2_spmv (1-D chunks), 3 csr_rowclass_march3_spmv (2-D in-plane tiles).  geometry
-// (optional, 12 entries, form 3): tiles per line, tiles per column, TX, TY, rows of the stage-1 region per lane (K1),
-// workgroups, dynamic LDS bytes, estimated bytes filled + stored per row x 100, threads per workgroup, segments of the
-// lockstep schedule (0: balanced ranges), planes per segment, entries of the class table.
-int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, long long* geometry) {
-  if (!h || !form) return fail(MG_ERR_INVALID, "null argument");
-  if (level < 1 || level > h->nlevels) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  const Csr& A = h->lev[(size_t)level - 1].A;
-  *form = 0;
-  if (!A.set || h->nrhs != 1) return MG_OK;
-  const bool band = A.rm3_var && A.rc_march3;
-  if (!band && (!A.has_rc || !A.rc_has_d || A.rc_nexc != 0)) return MG_OK;
-  if (A.rc_march3) {
-    *form = band ? 4 : 3;
-    if (geometry) {
-      const long long g[12] = {A.rm3.tiles_x, A.rm3.tiles_y, A.rm3.TX, A.rm3.TY, A.rm3_k1, A.rm3.nblocks, (long long)A.rm3_lds,
-                               (long long)(A.rm3_fill * 100.0), A.rm3_nt, A.rm3.segs, A.rm3.seglen, A.rm3.ntab};
-      std::copy(g, g + 12, geometry);
-    }
-  } else if (A.rc_march && A.rc_march2) {
-    *form = 2;
-  }
-  return MG_OK;
-}
-
-int mg_cycle_bytes(mg_hierarchy* h, double* bytes) {
-  if (!h || !bytes) return fail(MG_ERR_INVALID, "null argument");
-  if (!h->finalized) return fail(MG_ERR_STATE, "hierarchy not finalized");
-  // one V-cycle from x = 0 (SURVEY.md 8d "minimal-traffic fused model"); W/F revisit coarse levels
-  // and are accounted by the profile counters instead.
-  const long long k = h->nrhs;
-  double t = 0.0;
-  const int nl = (int)h->nlevels;
-  for (int l = 0; l < nl - 1; ++l) {
-    const Level& L = h->lev[(size_t)l];
-    const long long npre = std::max<long long>(1, L.npre), npost = std::max<long long>(1, L.npost);
-    t += 8.0 * (double)L.n * (1.0 + 2.0 * (double)k);                          // x = d.*b
-    t += (double)(npre - 1 + npost) * spmv_bytes(L.A, k, true, true);          // fused sweeps
-    t += spmv_bytes(L.A, k, true, false);                                      // residual
-    t += spmv_bytes(L.R, k, false, false);                                     // restriction
-    t += spmv_bytes(L.P, k, true, false);                                      // prolongation-add
-  }
-  const double nc = (double)h->n_coarse;
-  t += 8.0 * (nc * nc + 2.0 * nc * (double)k);
-  *bytes = t;
-  return MG_OK;
-}
-
-int mg_device_bytes(mg_hierarchy* h, double* bytes) {
-  if (!h || !bytes) return fail(MG_ERR_INVALID, "null argument");
-  double t = 0.0;
-  for (auto& L : h->lev)
-    t += (double)(L.A.bytes() + L.P.bytes() + L.R.bytes() + L.d.bytes() + L.b.bytes() + L.r.bytes() +
-                  L.x0.bytes() + L.x1.bytes());
-  t += (double)(h->Ainv.bytes() + h->stage_b.bytes() + h->stage_x.bytes() + h->stage_t.bytes());
-  *bytes = t;
-  return MG_OK;
-}
-
-// ---- stand-alone operators and vector kernels (building blocks of the multi-GPU cycle) ------------
-struct mg_operator {
-  int device = 0;
-  Csr M;
-  DevBuf<double> m3sink, m3scratch;   // csr_rowclass_march3_spmv: store sink; outputs nobody asked for
-};
-
-int mg_op_create_FP64_INT64(long long device_id, long long n_rows, long long n_cols,
-                            const long long* colptr, const long long* rowval, const double* nzval,
-                            mg_operator** out) {
-  UploadFence upload_fence;
-  if (!out) return fail(MG_ERR_INVALID, "out is null");
-  *out = nullptr;
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
-  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
-  HIP_TRY(hipSetDevice((int)device_id));
-  mg_operator* op = new mg_operator();
-  op->device = (int)device_id;
-  const int rc = upload_csr(&op->M, Options::from_env(), n_rows, n_cols, colptr, rowval, nzval);
-  if (rc != MG_OK) {
-    op->M.release();
-    delete op;
-    return rc;
-  }
-  *out = op;
-  return MG_OK;
-}
-
-// A rank's local operator of a sharded level in BOX form: square, rows/columns [owned box in natural x-fastest order |
-// halo], the halo rows empty; n1 x n2 x n3 = the owned box (= regular_cols rows).  Rows that read a halo column become
-// exception rows (phase 2 of mg_op_apply_phase_dev_FP64), all others keep the row-class form of the global grid operator
-// and run the staged kernels (z-marching / plane tiles) of the single-GPU path.
-int mg_op_create_box_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
-                                const long long* rowval, const double* nzval, long long n1, long long n2, long long n3,
-                                long long regular_cols, mg_operator** out) {
-  UploadFence upload_fence;
-  if (!out) return fail(MG_ERR_INVALID, "out is null");
-  *out = nullptr;
-  if (n_rows != n_cols || regular_cols < 1 || regular_cols > n_rows || n1 * n2 * n3 != regular_cols)
-    return fail(MG_ERR_INVALID, "box operator must be square with n1*n2*n3 == regular_cols <= n_rows");
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
-  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
-  HIP_TRY(hipSetDevice((int)device_id));
-  mg_operator* op = new mg_operator();
-  op->device = (int)device_id;
-  int rc = upload_csr(&op->M, Options::from_env(), n_rows, n_cols, colptr, rowval, nzval, regular_cols);
-  const long long grid[3] = {n1, n2, n3};
-  if (rc == MG_OK) rc = build_staged(op->M, grid);
-  if (rc != MG_OK) {
-    op->M.release();
-    delete op;
-    return rc;
-  }
-  *out = op;
-  return MG_OK;
-}
-
-// A transfer operator of a sharded level with grid hints: rows = a fine box f1 x f2 x f3 (n_rows, natural order), columns =
-// [owned coarse box c1 x c2 x c3 (regular_cols) | halo].  The rows that read a halo column become exception rows; the others
-// take the LDS-staged prolongation kernel (csr_rowclass_winp_spmv) when the pattern fits it, with the same phase split as box
-// operators: phase 1 overlaps the exchange of the coarse vector, phase 2 follows it.
-int mg_op_create_grid_FP64_INT64(long long device_id, long long n_rows, long long n_cols, const long long* colptr,
-                                 const long long* rowval, const double* nzval, long long regular_cols, long long f1, long long f2,
-                                 long long f3, long long c1, long long c2, long long c3, mg_operator** out) {
-  UploadFence upload_fence;
-  if (!out) return fail(MG_ERR_INVALID, "out is null");
-  *out = nullptr;
-  const bool hints = f1 != 0 || f2 != 0 || f3 != 0 || c1 != 0 || c2 != 0 || c3 != 0;   // (all zero: only the owned | halo split)
-  if (regular_cols < 1 || regular_cols > n_cols || (hints && (f1 * f2 * f3 != n_rows || c1 * c2 * c3 != regular_cols)))
-    return fail(MG_ERR_INVALID, "grid operator: f1*f2*f3 must equal n_rows and c1*c2*c3 regular_cols <= n_cols");
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
-  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
-  HIP_TRY(hipSetDevice((int)device_id));
-  mg_operator* op = new mg_operator();
-  op->device = (int)device_id;
-  int rc = upload_csr(&op->M, Options::from_env(), n_rows, n_cols, colptr, rowval, nzval, regular_cols, n_rows);
-  const long long gf[3] = {f1, f2, f3}, gc[3] = {c1, c2, c3};
-  if (rc == MG_OK && hints) rc = build_winp(op->M, gf, gc);
-  if (rc != MG_OK) {
-    op->M.release();
-    delete op;
-    return rc;
-  }
-  *out = op;
-  return MG_OK;
-}
-
-int mg_op_kernel_variant(mg_operator* op, long long* variant, long long* exception_rows) {
-  if (!op) return fail(MG_ERR_INVALID, "null operator");
-  const Csr& M = op->M;
-  if (variant) *variant = !M.has_rc ? -1 : M.rc_march ? 3 : M.rc_tile ? 2 : M.rc_window ? 1 : M.rp_ok ? 5 : M.rc_lane() ? 4 : 0;
-  if (exception_rows) *exception_rows = M.has_rc ? M.rc_nexc : 0;
-  return MG_OK;
-}
-
-int mg_op_destroy(mg_operator* op) {
-  if (!op) return MG_OK;
-  (void)hipSetDevice(op->device);
-  op->M.release();
-  op->m3sink.release();
-  op->m3scratch.release();
-  delete op;
-  return MG_OK;
-}
-
-// Announce the relaxPrec vector (device, one entry per regular row) this operator will be swept with: when it is
-// bit-identical over every dictionary class the fused sweeps called with THIS pointer read it from the dictionary
-// instead of streaming it.  Call again after the vector's contents change.
-int mg_op_bind_relax_dev_FP64(mg_operator* op, const double* d_dev, long long n) {
-  UploadFence upload_fence;
-  if (!op || !op->M.set || !d_dev || n < 1) return fail(MG_ERR_INVALID, "bad argument");
-  (void)hipSetDevice(op->device);
-  (void)hipDeviceSynchronize();   // d may have been written on another stream
-  return derive_class_d_csr(op->M, d_dev, (size_t)n);
-}
-
-int mg_op_apply_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
-                         double* y, const double* b, const double* d, long long nrhs, void* stream) {
-  return mg_op_apply_rows_dev_FP64(op, kernel, alpha, x, beta, y, b, d, nrhs, 0, stream);
-}
-
-int mg_op_apply_rows_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
-                              double* y, const double* b, const double* d, long long nrhs,
-                              long long row_offset, void* stream) {
-  return mg_op_apply_phase_dev_FP64(op, kernel, alpha, x, beta, y, b, d, nrhs, row_offset, 0, stream);
-}
-
-int mg_op_apply_phase_dev_FP64(mg_operator* op, long long kernel, double alpha, const double* x, double beta,
-                               double* y, const double* b, const double* d, long long nrhs,
-                               long long row_offset, long long phase, void* stream) {
-  if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
-  if (phase < 0 || phase > 2) return fail(MG_ERR_INVALID, "phase must be 0, 1 or 2");
-  if (!x || !y || nrhs < 1 || row_offset < 0) return fail(MG_ERR_INVALID, "null vector, nrhs < 1 or negative row offset");
-  if (kernel == MG_K_SMOOTH && y == x) return fail(MG_ERR_INVALID, "the Jacobi update must not alias x");
-  mgk::VecArgs v{};
-  v.x = x;
-  v.xs = x + row_offset * nrhs;
-  v.y = y + row_offset * nrhs;
-  v.b = b ? b + row_offset * nrhs : nullptr;
-  v.d = d ? d + row_offset : nullptr;
-  v.d_full = v.d;
-  // relaxPrec bound to this operator and constant per class: read from the dictionary (2 B/row instead of 10)
-  if (d && nrhs == 1 && row_offset == 0 && op->M.has_rc && op->M.rc_has_d && d == op->M.d_bound) v.d = nullptr;
-  v.alpha = alpha;
-  v.beta = beta;
-  v.nrhs = (int)nrhs;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  switch (kernel) {
-    case MG_K_SPMV:
-    case MG_K_RESTRICT:
-    case MG_K_PROLONG:
-      return launch_csr<mgk::AXPBY>(s, op->M, v, nullptr, nullptr, (int)phase);
-    case MG_K_RESIDUAL:
-      if (!b) return fail(MG_ERR_INVALID, "residual needs b");
-      return launch_csr<mgk::RESID>(s, op->M, v, nullptr, nullptr, (int)phase);
-    case MG_K_SMOOTH:
-      if (!b || !d) return fail(MG_ERR_INVALID, "smoother needs b and d");
-      return launch_csr<mgk::SMOOTH>(s, op->M, v, nullptr, nullptr, (int)phase);
-    default:
-      return fail(MG_ERR_INVALID, "kernel %lld is not an operator kernel", kernel);
-  }
-}
-
-// r = b - M x on an operator with the squared norm of r fused (per-workgroup partials written from partials_dev on,
-// *nparts of them) and, optionally, xnext = x + d.*r as a second output (the next cycle's first damped-Jacobi update);
-// r_dev may be NULL when only the norm and xnext are wanted.  phase as mg_op_apply_phase_dev_FP64.  One right-hand side.
-int mg_op_residual_fused_dev_FP64(mg_operator* op, const double* x, const double* b, const double* d, double* r_dev,
-                                  double* xnext_dev, double* partials_dev, long long phase, long long* nparts, void* stream) {
-  if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
-  if (!x || !b || !partials_dev || !nparts || phase < 0 || phase > 2 || (xnext_dev && !d)) return fail(MG_ERR_INVALID, "bad argument");
-  const Csr& M = op->M;
-  mgk::VecArgs v{};
-  v.x = x;
-  v.xs = x;
-  v.y = r_dev;
-  v.b = b;
-  v.nrhs = 1;
-  v.sumsq = partials_dev;
-  // the staged row-class kernels (march, tile) and the exception-row kernel can write the second output
-  const bool can_y2 = M.has_rc && (M.rc_tile || march_ok(M, v)) && xnext_dev && xnext_dev != x && !(phase == 0 && M.rc_nexc > 0);
-  if (can_y2) {
-    v.y2 = xnext_dev;
-    v.d = (M.rc_has_d && d == M.d_bound) ? nullptr : d;
-    v.d_full = d;
-  } else if (!r_dev) {
-    return fail(MG_ERR_INVALID, "this operator's kernel cannot produce xnext: pass r_dev");
-  }
-  int np = 0;
-  MG_TRY(launch_csr<mgk::RESID>(reinterpret_cast<hipStream_t>(stream), M, v, &np, nullptr, (int)phase));
-  *nparts = np;
-  return MG_OK;
-}
-// 1 if mg_op_residual_fused_dev_FP64 can write xnext for this operator and these vectors (x 16-byte aligned etc.)
-int mg_op_can_fuse_next(mg_operator* op, const double* x, long long* yes) {
-  if (!op || !yes) return fail(MG_ERR_INVALID, "null argument");
-  mgk::VecArgs v{};
-  v.x = x;
-  v.xs = x;
-  v.nrhs = 1;
-  *yes = (op->M.has_rc && (op->M.rc_tile || march_ok(op->M, v))) ? 1 : 0;
-  return MG_OK;
-}
-
-// Can mg_op_sweep_residual_dev_FP64 serve this operator with these vectors?  (2-D tile form of the two-stage pass: grid
-// operator of z-star classes, relaxPrec bound to the operator and constant per class, x 16-byte aligned.)  *lists: rows the
-// pass leaves to mg_op_apply_list_dev_FP64 - list 1 (rows that read the halo: neither t nor r), list 2 (rows next to them: r).
-int mg_op_can_sweep_residual(mg_operator* op, const double* x, const double* d, long long* yes, long long* list1, long long* list2) {
-  if (!op || !yes) return fail(MG_ERR_INVALID, "null argument");
-  const Csr& M = op->M;
-  *yes = (M.set && M.has_rc && M.rc_march3 && M.rc_has_d && d && d == M.d_bound && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
-  if (list1) *list1 = M.rc_nexc;
-  if (list2) *list2 = M.rc_nexc2;
-  return MG_OK;
-}
-
-// One damped-Jacobi sweep and the residual of its result in ONE pass (csr_rowclass_march3_spmv) over an operator:
-//   t = x + d.*(b - M x) on every row that has a class;  r = b - M t [xn = t + d.*r, ||r||^2 partials] on every such row
-//   that is not in list 2.  t, r, xn: each optional; d: the relaxPrec bound with mg_op_bind_relax_dev_FP64.
-int mg_op_sweep_residual_dev_FP64(mg_operator* op, const double* x, const double* b, const double* d, double* t, double* r,
-                                  double* xn, double* partials_dev, long long* nparts, void* stream) {
-  if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
-  if (!x || !b || !d || (partials_dev && !nparts)) return fail(MG_ERR_INVALID, "bad argument");
-  long long yes = 0;
-  MG_TRY(mg_op_can_sweep_residual(op, x, d, &yes, nullptr, nullptr));
-  if (!yes) return fail(MG_ERR_UNSUPPORTED, "this operator is not served by the two-stage pass");
-  if ((t && (x == t || t == r || t == xn)) || x == r || x == xn || (r && r == xn)) return fail(MG_ERR_INVALID, "x, t, r, xn must be distinct buffers");
-  (void)hipSetDevice(op->device);
-  const Csr& M = op->M;
-  const size_t need = (size_t)12 * 32 * (size_t)M.rm3_nt;
-  if (op->m3sink.n < need) MG_TRY(op->m3sink.alloc(need));
-  const int o = (r ? 1 : 0) | (xn ? 2 : 0) | (t ? 4 : 0);
-  if (!(o == 5 || o == 2 || o == 6 || o == 7) && op->m3scratch.n < (size_t)M.n_rows) MG_TRY(op->m3scratch.alloc((size_t)M.n_rows));
-  mgk::March2Args a{};
-  a.x = x;
-  a.b = b;
-  a.t = t;
-  a.r = r;
-  a.xn = xn;
-  a.sumsq = partials_dev;
-  a.sink = op->m3sink.p;
-  a.d = d;
-  MG_TRY(launch_march3_any(reinterpret_cast<hipStream_t>(stream), M, a, false, op->m3scratch.p));
-  if (nparts) *nparts = partials_dev ? M.rm3.nblocks : 0;
-  return MG_OK;
-}
-
-// The rows mg_op_sweep_residual_dev_FP64 leaves out, from the CSR arrays (csr_rows_spmv): list 1 = the rows that read the
-// halo, list 2 = the rows next to them.  kernel: MG_K_SMOOTH (y = x + d.*(b - M x)) or MG_K_RESIDUAL (y = b - M x; y2, if
-// given, = xs + d.*y with xs = x; partials_dev, if given, receives ||y||^2 partials, *nparts of them).
-int mg_op_apply_list_dev_FP64(mg_operator* op, long long list, long long kernel, const double* x, double* y, const double* b,
-                              const double* d, double* y2, double* partials_dev, long long* nparts, void* stream) {
-  if (!op || !op->M.set) return fail(MG_ERR_INVALID, "null or empty operator");
-  if ((list != 1 && list != 2) || !x || !b || (!y && !y2 && !partials_dev) || (partials_dev && !nparts)) return fail(MG_ERR_INVALID, "bad argument");
-  if ((kernel == MG_K_SMOOTH || y2) && !d) return fail(MG_ERR_INVALID, "this kernel needs d");
-  const Csr& M = op->M;
-  const int n = list == 1 ? M.rc_nexc : M.rc_nexc2;
-  const int* rows = list == 1 ? M.rc_exc.p : M.rc_exc2.p;
-  if (nparts) *nparts = 0;
-  if (n <= 0) return MG_OK;
-  (void)hipSetDevice(op->device);
-  mgk::VecArgs v{};
-  v.x = x;
-  v.xs = x;
-  v.y = y;
-  v.b = b;
-  v.d = d;
-  v.d_full = d;
-  v.y2 = y2;
-  v.nrhs = 1;
-  v.sumsq = partials_dev;
-  const int nb = (n + mgk::BLK - 1) / mgk::BLK;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (kernel == MG_K_SMOOTH) hipLaunchKernelGGL((mgk::csr_rows_spmv<mgk::SMOOTH>), dim3(nb), dim3(mgk::BLK), 0, s, M.dev(), rows, n, v, 0);
-  else if (kernel == MG_K_RESIDUAL) hipLaunchKernelGGL((mgk::csr_rows_spmv<mgk::RESID>), dim3(nb), dim3(mgk::BLK), 0, s, M.dev(), rows, n, v, 0);
-  else return fail(MG_ERR_INVALID, "kernel %lld is not a list kernel", kernel);
-  HIP_TRY(hipGetLastError());
-  if (nparts && partials_dev) *nparts = nb;
-  return MG_OK;
-}
-
-int mg_op_info(mg_operator* op, long long* n_rows, long long* n_cols, long long* nnz, double* device_bytes) {
-  if (!op) return fail(MG_ERR_INVALID, "null operator");
-  if (n_rows) *n_rows = op->M.n_rows;
-  if (n_cols) *n_cols = op->M.n_cols;
-  if (nnz) *nnz = op->M.nnz;
-  if (device_bytes) *device_bytes = (double)op->M.bytes();
-  return MG_OK;
-}
-
-int mg_vec_dscale_dev_FP64(const double* d, const double* b, double* x, long long n, long long nrhs, void* stream) {
-  if (!d || !b || !x || n < 1 || nrhs < 1) return fail(MG_ERR_INVALID, "bad vector arguments");
-  hipLaunchKernelGGL(mgk::dscale_kernel, dim3(grid_for(n * nrhs / 2 + 1)), dim3(mgk::BLK), 0,
-                     reinterpret_cast<hipStream_t>(stream), d, b, x, n, (int)nrhs);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-
-int mg_vec_xpdr_dev_FP64(const double* x, const double* d, const double* r, double* xout, long long n,
-                         long long nrhs, void* stream) {
-  if (!x || !d || !r || !xout || n < 1 || nrhs < 1) return fail(MG_ERR_INVALID, "bad vector arguments");
-  hipLaunchKernelGGL(mgk::xpdr_kernel, dim3(grid_for(n * nrhs / 2 + 1)), dim3(mgk::BLK), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, d, r, xout, n, (int)nrhs);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-
-// out[0] = sum_i x[i]^2 ; workspace: >= 1024 doubles
-int mg_vec_sumsq_dev_FP64(const double* x, long long len, double* workspace, double* out, void* stream) {
-  if (!x || !workspace || !out || len < 1) return fail(MG_ERR_INVALID, "bad vector arguments");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nb = (int)std::min<long long>(1024, std::max<long long>(1, (len / 2 + mgk::BLK - 1) / mgk::BLK));
-  hipLaunchKernelGGL(mgk::sumsq_partial, dim3(nb), dim3(mgk::BLK), 0, s, x, len, workspace);
-  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, s, workspace, nb, out);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-
-// ---- hybrid Kaczmarz relaxation (deps/src/parRelax.h:7-43) -------------------------------------------------------------
-struct mg_kaczmarz {
-  int device = 0;
-  long long n = 0, nnz = 0, num_domains = 0, domain_length = 0;
-  DevBuf<int> rowptr, col;
-  DevBuf<double> val, invD, x, b;
-  DevBuf<unsigned int> arr;
-  hipStream_t stream = nullptr;
-};
-
-int mg_kaczmarz_create_FP64_INT64(long long device_id, long long n, const long long* rowptr, const double* valA,
-                                  const long long* colA, long long numDomains, long long domainLength,
-                                  const unsigned int* ArrIdxs, const double* invD, mg_kaczmarz** out) {
-  UploadFence upload_fence;
-  if (!out) return fail(MG_ERR_INVALID, "out is null");
-  *out = nullptr;
-  if (n < 1 || !rowptr || !valA || !colA || !ArrIdxs || !invD || numDomains < 1 || domainLength < 1)
-    return fail(MG_ERR_INVALID, "null or empty argument");
-  if (n >= (1LL << 31) - 1 || numDomains * domainLength >= (1LL << 31)) return fail(MG_ERR_UNSUPPORTED, "dimension exceeds int32 device indices");
-  if (rowptr[0] != 1) return fail(MG_ERR_INVALID, "rowptr[1] must be 1 (1-based Julia arrays expected)");
-  const long long nnz = rowptr[n] - 1;
-  if (nnz < 0 || nnz >= (1LL << 31) - 1) return fail(MG_ERR_UNSUPPORTED, "nnz does not fit int32");
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the relaxation has no CPU fallback");
-  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
-  std::vector<int> rp((size_t)n + 1), ci((size_t)std::max<long long>(nnz, 1));
-  for (long long i = 0; i <= n; ++i) {
-    const long long v = rowptr[i] - 1;
-    if (v < 0 || v > nnz || (i > 0 && v < rp[(size_t)i - 1])) return fail(MG_ERR_INVALID, "rowptr is not a monotone 1-based pointer array");
-    rp[(size_t)i] = (int)v;
-  }
-  for (long long k = 0; k < nnz; ++k) {
-    const long long c = colA[k] - 1;
-    if (c < 0 || c >= n) return fail(MG_ERR_INVALID, "column index out of range");
-    ci[(size_t)k] = (int)c;
-  }
-  for (long long t = 0; t < numDomains * domainLength; ++t)
-    if ((long long)ArrIdxs[t] > n) return fail(MG_ERR_INVALID, "ArrIdxs entry %u exceeds n=%lld", ArrIdxs[t], n);
-  HIP_TRY(hipSetDevice((int)device_id));
-  mg_kaczmarz* k = new mg_kaczmarz();
-  k->device = (int)device_id;
-  k->n = n;
-  k->nnz = nnz;
-  k->num_domains = numDomains;
-  k->domain_length = domainLength;
-  int rc = MG_OK;
-  auto up = [&]() -> int {
-    MG_TRY(k->rowptr.alloc(rp.size()));
-    MG_TRY(k->col.alloc(ci.size()));
-    MG_TRY(k->val.alloc((size_t)std::max<long long>(nnz, 1)));
-    MG_TRY(k->invD.alloc((size_t)n));
-    MG_TRY(k->arr.alloc((size_t)(numDomains * domainLength)));
-    HIP_TRY(hipMemcpy(k->rowptr.p, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(k->col.p, ci.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(k->val.p, valA, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(k->invD.p, invD, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(k->arr.p, ArrIdxs, (size_t)(numDomains * domainLength) * sizeof(unsigned int), hipMemcpyHostToDevice));
-    HIP_TRY(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
-    return MG_OK;
-  };
-  rc = up();
-  if (rc != MG_OK) {
-    mg_kaczmarz_destroy(k);
-    return rc;
-  }
-  *out = k;
-  return MG_OK;
-}
-
-int mg_kaczmarz_destroy(mg_kaczmarz* k) {
-  if (!k) return MG_OK;
-  (void)hipSetDevice(k->device);
-  if (k->stream) {
-    (void)spin_sync(k->stream);
-    (void)hipStreamDestroy(k->stream);
-  }
-  k->rowptr.release();
-  k->col.release();
-  k->val.release();
-  k->invD.release();
-  k->arr.release();
-  k->x.release();
-  k->b.release();
-  delete k;
-  return MG_OK;
-}
-
-// numit sweeps on device-resident x (in/out) and b, column-major n x nrhs; one launch per sweep (the barrier the
-// reference's `omp for` has between sweeps).  sequential != 0: one wavefront walks all sub-domains in order (the
-// reference with one thread); otherwise one wavefront per sub-domain.
-int mg_kaczmarz_apply_dev_FP64(mg_kaczmarz* k, double* x_dev, const double* b_dev, long long nrhs, long long numit,
-                               long long sequential) {
-  if (!k || !x_dev || !b_dev || nrhs < 1 || numit < 0) return fail(MG_ERR_INVALID, "bad argument");
-  (void)hipSetDevice(k->device);
-  for (long long it = 0; it < numit; ++it)
-    hipLaunchKernelGGL(mgk::hybrid_kaczmarz, dim3(sequential ? 1u : (unsigned)k->num_domains), dim3(64), 0, k->stream,
-                       k->rowptr.p, k->col.p, k->val.p, k->arr.p, (int)k->num_domains, (int)k->domain_length, x_dev, b_dev,
-                       (int)nrhs, k->n, k->invD.p, sequential ? 1 : 0);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(spin_sync(k->stream));
-  return MG_OK;
-}
-
-// Host buffers, exactly the reference's call (parRelax.jl:61-64): x (in/out) and b are n x nrhs column-major.
-int mg_kaczmarz_apply_FP64(mg_kaczmarz* k, double* x, const double* b, long long nrhs, long long numit, long long sequential) {
-  if (!k || !x || !b || nrhs < 1 || numit < 0) return fail(MG_ERR_INVALID, "bad argument");
-  (void)hipSetDevice(k->device);
-  const size_t len = (size_t)k->n * (size_t)nrhs;
-  if (k->x.n != len) {
-    MG_TRY(k->x.alloc(len));
-    MG_TRY(k->b.alloc(len));
-  }
-  HIP_TRY(hipMemcpyAsync(k->x.p, x, len * sizeof(double), hipMemcpyHostToDevice, k->stream));
-  HIP_TRY(hipMemcpyAsync(k->b.p, b, len * sizeof(double), hipMemcpyHostToDevice, k->stream));
-  MG_TRY(mg_kaczmarz_apply_dev_FP64(k, k->x.p, k->b.p, nrhs, numit, sequential));
-  HIP_TRY(hipMemcpyAsync(x, k->x.p, len * sizeof(double), hipMemcpyDeviceToHost, k->stream));
-  HIP_TRY(spin_sync(k->stream));
-  return MG_OK;
-}
-
-// =================================================================================================================
-// Native multi-GPU sequencer (one process per GPU): the level schedule of the sharded cycle in C++, halo exchange by
-// RCCL send/recv on a side stream overlapped with the interior rows, scalar all-reduce for the norm, replicated tail.
-// Partition: the reference's DomainDecomposition box rule (DDIndices.jl:41-47, DDService.jl:27-48); worker map analogue:
-// DDParallel.jl:105,133-139.  The host (multigrid.jl_amd/distributed.py, or the Julia glue) cuts the hierarchy into
-// local operators [owned | halo] and send lists; this code owns the vectors and the hot loop.
-// =================================================================================================================
-namespace {
-// RCCL is loaded lazily (dlopen) so that single-GPU users of the library do not depend on it.
-// Prototypes, handle types and enumerators come from the RCCL header this library is built against (rccl/rccl.h):
-// decltype(&ncclSend) etc. - if the ABI moves, the build follows it or fails, it cannot go silently wrong.
-struct Rccl {
-  typedef ncclUniqueId UniqueId;
-  void* lib = nullptr;
-  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-  decltype(&ncclCommInitRank) CommInitRank = nullptr;
-  decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclCommCount) CommCount = nullptr;
-  decltype(&ncclGroupStart) GroupStart = nullptr;
-  decltype(&ncclGroupEnd) GroupEnd = nullptr;
-  decltype(&ncclSend) Send = nullptr;
-  decltype(&ncclRecv) Recv = nullptr;
-  decltype(&ncclAllReduce) AllReduce = nullptr;
-  decltype(&ncclAllGather) AllGather = nullptr;
-  decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  bool load() {
-    if (lib) return true;
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);          // the copy torch already mapped, if any
-      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (lib) break;
-    }
-    if (!lib) return false;
-    auto sym = [&](const char* n) { return dlsym(lib, n); };
-    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
-    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
-    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
-    CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
-    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
-    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
-    Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
-    Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
-    AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
-    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
-    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-    return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && AllGather;
-  }
-};
-Rccl g_rccl;
-constexpr ncclDataType_t NCCL_DOUBLE = ncclFloat64;
-constexpr ncclRedOp_t NCCL_SUM = ncclSum;
-static_assert(sizeof(ncclUniqueId) == 128, "mg_dist_unique_id / mg_dist_create exchange the RCCL id as 128 bytes");
-static_assert(ncclFloat64 == 8 && ncclSum == 0, "RCCL enumerators moved: check the glue in INTEGRATION.md");
-
-struct DistPlan {
-  bool set = false, active = false;
-  long long n_own_src = 0, n_halo = 0, n_send = 0;
-  DevBuf<int> send_idx;
-  DevBuf<double> send_buf;
-  std::vector<long long> send_splits, recv_splits;   // per peer
-  double *h_send = nullptr, *h_recv = nullptr;       // pinned staging (plug-in transport)
-};
-struct DistLevel {
-  long long n_own = 0, n_int = 0;
-  mg_operator *A_int = nullptr, *A_bnd = nullptr, *P = nullptr, *R = nullptr;   // borrowed handles
-  const double* d = nullptr;                                                    // borrowed device vector (n_own)
-  long long npre = 1, npost = 1;
-  long long npre_raw = 1, npost_raw = 1;   // relaxPre/relaxPost(level) as given: the inner dimension of a Jac-GMRES relaxation
-  DevBuf<double> relZ, relAZ;              // FGMRESmem (FGMRES.jl:3-8) of the Jac-GMRES smoother: Z (with halo tail each), A*Z
-  DevBuf<double> kZ, kAZ;                  // memKcycle: the 2-step FGMRES of a K-cycle INTO this level
-  bool box = false;   // A_int is a box operator (mg_op_create_box_FP64_INT64): phase 1 overlaps the exchange, phase 2 follows it
-  DistPlan planA, planR, planP;
-  long long cap_x = 0, cap_r = 0;
-  DevBuf<double> x0, x1, r, b;
-  DevBuf<double> x2;   // fine level, solve loop: third rotating buffer of the fused last sweep + residual (allocated on first use)
-};
-}  // namespace
-
-// rows of a row-major block [n][k]: dst row i = src row idx[i]
-__global__ __launch_bounds__(256) void dist_pack(const double* __restrict__ src, const int* __restrict__ idx,
-                                                 double* __restrict__ dst, long long n, int k) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e < n * k) {
-    const long long i = e / k;
-    dst[e] = src[(long long)idx[i] * k + (e - i * k)];
-  }
-}
-__global__ __launch_bounds__(256) void dist_gather64(const double* __restrict__ src, const long long* __restrict__ idx,
-                                                     double* __restrict__ dst, long long n, int k) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e < n * k) {
-    const long long i = e / k;
-    dst[e] = src[idx[i] * k + (e - i * k)];
-  }
-}
-
-struct mg_dist {
-  int device = 0, rank = 0, world = 1;
-  ncclComm_t comm = nullptr;            // RCCL transport
-  mg_exchange_fn plug = nullptr;        // host-staged transport (tests / one shared GPU)
-  void* plug_user = nullptr;
-  hipStream_t stream = nullptr, side = nullptr;
-  hipEvent_t ev_packed = nullptr, ev_landed = nullptr;
-  std::vector<DistLevel> lev;
-  char cycle = 'V';
-  int relax_type = 0;                   // 0: pointwise (Jac / SPAI), 1: Jac-GMRES (MGcycle.jl:48-50,96-98)
-  bool finalized = false;
-  long long nrhs = 1;                   // right-hand sides per call (blocks are row-major [n][nrhs], as in mg_hierarchy)
-  bool no_pair = false;                 // MG_DIST_NO_PAIR=1: never fuse a sweep with the residual that follows it (A/B, tests)
-  // replicated tail
-  mg_hierarchy* tail = nullptr;
-  // what the tail's handle looked like before this sequencer borrowed it (restored by mg_dist_release_tail / destroy)
-  hipStream_t tail_prev_stream = nullptr;
-  bool tail_prev_owns = false, tail_prev_no_graph = false, tail_borrowed = false;
-  long long n_tail = 0, own_tail = 0, max_tail = 0, nl_total = 0;
-  DevBuf<double> bc_pad, bc_all, b_tail, x_tail;
-  DevBuf<long long> gather_index;
-  // reductions
-  DevBuf<double> partial, partial2, scalar;
-  double* h_scalar = nullptr;
-  double* h_stage = nullptr;            // pinned staging for the plug-in collectives
-  size_t h_stage_n = 0;
-};
-
-namespace {
-int dist_nccl(ncclResult_t rc, const char* what) {
-  if (rc == ncclSuccess) return MG_OK;
-  return fail(MG_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
-}
-#define NCCL_TRY(expr) MG_TRY(dist_nccl((expr), #expr))
-
-int dist_stage(mg_dist* h, size_t n) {
-  if (h->h_stage_n >= n) return MG_OK;
-  if (h->h_stage) (void)hipHostFree(h->h_stage);
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), sizeof(double) * n));
-  h->h_stage_n = n;
-  return MG_OK;
-}
-
-// Start filling the halo tail buf[n_own_src : n_own_src + n_halo] (values the peers need are packed first).
-// RCCL: pack on the compute stream, send/recv on the side stream; the compute stream goes on.  Plug-in: done on return.
-int dist_exchange_start(mg_dist* h, DistPlan& p, double* buf) {
-  if (!p.set || !p.active) return MG_OK;
-  const long long k = h->nrhs;
-  if (p.n_send > 0)
-    hipLaunchKernelGGL(dist_pack, dim3((unsigned)((p.n_send * k + 255) / 256)), dim3(256), 0, h->stream, buf, p.send_idx.p, p.send_buf.p, p.n_send, (int)k);
-  HIP_TRY(hipGetLastError());
-  double* recv = buf + p.n_own_src * k;
-  if (h->comm) {
-    HIP_TRY(hipEventRecord(h->ev_packed, h->stream));
-    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_packed, 0));
-    NCCL_TRY(g_rccl.GroupStart());
-    long long so = 0, ro = 0;
-    for (int peer = 0; peer < h->world; ++peer) {
-      const long long ns = p.send_splits[(size_t)peer] * k, nr = p.recv_splits[(size_t)peer] * k;
-      if (ns > 0) NCCL_TRY(g_rccl.Send(p.send_buf.p + so, (size_t)ns, NCCL_DOUBLE, peer, h->comm, h->side));
-      if (nr > 0) NCCL_TRY(g_rccl.Recv(recv + ro, (size_t)nr, NCCL_DOUBLE, peer, h->comm, h->side));
-      so += ns;
-      ro += nr;
-    }
-    NCCL_TRY(g_rccl.GroupEnd());
-    HIP_TRY(hipEventRecord(h->ev_landed, h->side));
-    return MG_OK;
-  }
-  // host-staged transport
-  if (p.n_send > 0) HIP_TRY(hipMemcpyAsync(p.h_send, p.send_buf.p, sizeof(double) * (size_t)(p.n_send * k), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(spin_sync(h->stream));
-  std::vector<long long> ssk(p.send_splits), rsk(p.recv_splits);     // (counts in doubles: rows x right-hand sides)
-  for (auto& c : ssk) c *= k;
-  for (auto& c : rsk) c *= k;
-  if (h->plug(h->plug_user, 0, p.h_send, ssk.data(), p.h_recv, rsk.data(), 0) != 0)
-    return fail(MG_ERR_HIP, "exchange plug-in failed (all_to_all)");
-  if (p.n_halo > 0) HIP_TRY(hipMemcpyAsync(recv, p.h_recv, sizeof(double) * (size_t)(p.n_halo * k), hipMemcpyHostToDevice, h->stream));
-  return MG_OK;
-}
-// Make the compute stream wait for the halo started by dist_exchange_start.
-int dist_exchange_finish(mg_dist* h, DistPlan& p) {
-  if (!p.set || !p.active) return MG_OK;
-  if (h->comm) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_landed, 0));
-  return MG_OK;
-}
-
-int dist_apply(mg_dist* h, mg_operator* op, long long kernel, double alpha, const double* x, double beta, double* y,
-               const double* b, const double* d, long long row_offset) {
-  if (!op) return MG_OK;
-  return mg_op_apply_rows_dev_FP64(op, kernel, alpha, x, beta, y, b, d, h->nrhs, row_offset, h->stream);
-}
-// out = b - A x / out = x + d.*(b - A x) on this rank's rows, the halo exchange overlapped with the interior rows
-int dist_apply_A(mg_dist* h, DistLevel& L, long long kernel, double* x, double* out, const double* b) {
-  MG_TRY(dist_exchange_start(h, L.planA, x));
-  if (L.box) {   // rows of the owned box that do not read the halo (staged kernels), then - halo landed - the rest
-    MG_TRY(mg_op_apply_phase_dev_FP64(L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, h->nrhs, 0, 1, h->stream));
-    MG_TRY(dist_exchange_finish(h, L.planA));
-    MG_TRY(mg_op_apply_phase_dev_FP64(L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, h->nrhs, 0, 2, h->stream));
-    return MG_OK;
-  }
-  MG_TRY(dist_apply(h, L.A_int, kernel, 1.0, x, 0.0, out, b, L.d, 0));
-  MG_TRY(dist_exchange_finish(h, L.planA));
-  MG_TRY(dist_apply(h, L.A_bnd, kernel, 1.0, x, 0.0, out, b, L.d, L.n_int));
-  return MG_OK;
-}
-// global Frobenius norm of a sharded vector: local sum of squares + one scalar all-reduce (SolveFuncs.jl:15,20,30)
-int dist_reduce_scalar(mg_dist* h, double* out);
-int dist_norm(mg_dist* h, const double* v, long long n, double* out) {
-  MG_TRY(mg_vec_sumsq_dev_FP64(v, n, h->partial.p, h->scalar.p, h->stream));
-  return dist_reduce_scalar(h, out);
-}
-
-// all-reduce h->scalar (a local sum of squares) and return its square root on the host
-int dist_reduce_scalar(mg_dist* h, double* out) {
-  if (h->comm) {
-    NCCL_TRY(g_rccl.AllReduce(h->scalar.p, h->scalar.p, 1, NCCL_DOUBLE, NCCL_SUM, h->comm, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(spin_sync(h->stream));
-  } else {
-    HIP_TRY(hipMemcpyAsync(h->h_scalar, h->scalar.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(spin_sync(h->stream));
-    if (h->world > 1) {
-      double in = *h->h_scalar, outv = 0.0;
-      if (h->plug(h->plug_user, 1, &in, nullptr, &outv, nullptr, 1) != 0) return fail(MG_ERR_HIP, "exchange plug-in failed (all_reduce)");
-      *h->h_scalar = outv;
-    }
-  }
-  *out = std::sqrt(*h->h_scalar);
-  return MG_OK;
-}
-
-// Can the sweep + residual pair of this level run as one two-stage pass (box-form level whose A is on the 2-D tile form)?
-bool dist_pair_ok(mg_dist* h, DistLevel& L, const double* x) {
-  if (!L.box || h->relax_type != 0 || h->no_pair || !L.A_int || h->nrhs != 1) return false;
-  long long yes = 0;
-  if (mg_op_can_sweep_residual(L.A_int, x, L.d, &yes, nullptr, nullptr) != MG_OK) return false;
-  return yes != 0;
-}
-// One sweep and the residual of its result on a sharded box-form level (MGcycle.jl:54-60; SolveFuncs.jl:26-30 with the last
-// post-smoothing sweep): t = x + d.*(b - A x), r = b - A t [, xn = t + d.*r, ||r|| over all ranks].  Two exchanges as for
-// the two launches it replaces, one pass over the level instead of two:
-//   exchange(x) || two-stage pass: t everywhere but on the rows that read the halo, r two layers in
-//   -> t on those rows -> exchange(t) || r of the layer behind them -> r on them.
-// t: a buffer with a halo tail (cap_x).  r / xn: each optional.
-int dist_sweep_residual(mg_dist* h, DistLevel& L, double* x, double* t, double* r, double* xn, const double* b, double* norm) {
-  long long n0 = 0, n1 = 0, n2 = 0;
-  double* part = norm ? h->partial.p : nullptr;
-  if (norm) {
-    const Csr& M = L.A_int->M;
-    const size_t need = (size_t)M.rm3.nblocks + (size_t)(M.rc_nexc + M.rc_nexc2) / mgk::BLK + 4;
-    if (need > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small (%zu > %zu)", need, h->partial.n);
-  }
-  MG_TRY(dist_exchange_start(h, L.planA, x));
-  MG_TRY(mg_op_sweep_residual_dev_FP64(L.A_int, x, b, L.d, t, r, xn, part, &n0, h->stream));
-  MG_TRY(dist_exchange_finish(h, L.planA));
-  MG_TRY(mg_op_apply_list_dev_FP64(L.A_int, 1, MG_K_SMOOTH, x, t, b, L.d, nullptr, nullptr, nullptr, h->stream));
-  MG_TRY(dist_exchange_start(h, L.planA, t));
-  MG_TRY(mg_op_apply_list_dev_FP64(L.A_int, 2, MG_K_RESIDUAL, t, r, b, L.d, xn, part ? part + n0 : nullptr, &n1, h->stream));
-  MG_TRY(dist_exchange_finish(h, L.planA));
-  MG_TRY(mg_op_apply_list_dev_FP64(L.A_int, 1, MG_K_RESIDUAL, t, r, b, L.d, xn, part ? part + n0 + n1 : nullptr, &n2, h->stream));
-  if (norm) {
-    const long long nb1 = n0 + n1 + n2;
-    const int nb2 = (int)std::min<long long>(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
-    hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->partial2.p);
-    hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
-    HIP_TRY(hipGetLastError());
-    MG_TRY(dist_reduce_scalar(h, norm));
-  }
-  return MG_OK;
-}
-
-// SolveFuncs.jl:26-30 on the sharded fine level: r = b - A x and ||r|| in ONE pass over the level (per-workgroup partial
-// sums, one scalar all-reduce).  Box-form levels also get alt = x + d.*r, the next cycle's first damped-Jacobi update,
-// from the same pass (*x1_ready), and then do not store r at all - as solve_dev does on one GPU.
-int dist_residual_norm(mg_dist* h, DistLevel& L, double* x, const double* b, double* alt, double* norm, bool* x1_ready) {
-  *x1_ready = false;
-  long long can = 0;
-  if (L.box && alt && h->nrhs == 1) MG_TRY(mg_op_can_fuse_next(L.A_int, x, &can));
-  if (!L.box || h->nrhs != 1) {     // (blocks: the Frobenius norm over the whole n x nrhs block, SolveFuncs.jl:30)
-    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, x, L.r.p, b));
-    return dist_norm(h, L.r.p, L.n_own * h->nrhs, norm);
-  }
-  long long n1 = 0, n2 = 0;
-  {   // capacity before anything is written: every launch form of this operator writes at most this many partials
-    const Csr& M = L.A_int->M;
-    const size_t need = (size_t)std::max(M.blocks1(), M.nblocks) + (size_t)(M.rc_nexc + mgk::BLK - 1) / mgk::BLK + 1;
-    if (need > h->partial.n) return fail(MG_ERR_STATE, "partial-sum buffer too small (%zu > %zu)", need, h->partial.n);
-  }
-  MG_TRY(dist_exchange_start(h, L.planA, x));
-  MG_TRY(mg_op_residual_fused_dev_FP64(L.A_int, x, b, L.d, can ? nullptr : L.r.p, can ? alt : nullptr, h->partial.p, 1, &n1, h->stream));
-  MG_TRY(dist_exchange_finish(h, L.planA));
-  MG_TRY(mg_op_residual_fused_dev_FP64(L.A_int, x, b, L.d, can ? nullptr : L.r.p, can ? alt : nullptr, h->partial.p + n1, 2, &n2, h->stream));
-  const long long nb1 = n1 + n2;
-  if (nb1 <= 0) return fail(MG_ERR_STATE, "the fused residual wrote no partial sums");
-  const int nb2 = (int)std::min<long long>(256, (nb1 + mgk::BLK - 1) / mgk::BLK);
-  hipLaunchKernelGGL(mgk::sum_partial, dim3(nb2), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb1, h->partial2.p);
-  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial2.p, nb2, h->scalar.p);
-  HIP_TRY(hipGetLastError());
-  MG_TRY(dist_reduce_scalar(h, norm));
-  *x1_ready = can != 0;
-  return MG_OK;
-}
-
-// dot(x, y) over all ranks (local partial sums + one scalar all-reduce); the same bits on every rank
-int dist_dot(mg_dist* h, const double* x, const double* y, long long n, double* out) {
-  const int nb = (int)std::max<long long>(1, std::min<long long>((long long)h->partial.n, (n / 2 + mgk::BLK - 1) / mgk::BLK));
-  hipLaunchKernelGGL(mgk::dot_partial, dim3(nb), dim3(mgk::BLK), 0, h->stream, x, y, n, h->partial.p);
-  hipLaunchKernelGGL(mgk::sum_final, dim3(1), dim3(mgk::BLK), 0, h->stream, h->partial.p, nb, h->scalar.p);
-  HIP_TRY(hipGetLastError());
-  double nrm = 0.0;
-  MG_TRY(dist_reduce_scalar(h, &nrm));   // sqrt of the all-reduced sum ...
-  *out = *h->h_scalar;                   // ... whose raw value stays in the pinned scalar
-  return MG_OK;
-}
-int dist_axpby(mg_dist* h, double a, const double* x, double b, double* y, long long n) {
-  hipLaunchKernelGGL(mgk::axpby_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, a, x, b, y, n);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-int dist_fill(mg_dist* h, double* x, long long n, double val) {
-  hipLaunchKernelGGL(mgk::fill_kernel, dim3(grid_for(n)), dim3(mgk::BLK), 0, h->stream, x, n, val);
-  HIP_TRY(hipGetLastError());
-  return MG_OK;
-}
-// FGMRES_relaxation (FGMRES.jl:48-126) on a sharded level - the mirror of fgmres_relax: x0 += Z*t where t minimises
-// ||r0 - A Z t|| over the `inner` directions z_1 = M r0, z_j = M (A z_{j-1}).  Products with A exchange the halo of z (the
-// vectors of Z are cap_x long: owned rows + halo tail), dots are all-reduced, so the small pseudo-inverse and the
-// data-dependent exit (l.114-117) come out identical on every rank.
-extern "C++" {
-template <class Prec>
-int dist_fgmres_relax(mg_dist* h, DistLevel& L, const double* r0, double* x0, long long inner, Prec prec, double TOL,
-                      DevBuf<double>& Zbuf, DevBuf<double>& AZbuf, bool x0_is_zero) {
-  const long long n = L.n_own;
-  if (inner <= 0) {
-    if (x0_is_zero) MG_TRY(dist_fill(h, x0, n, 0.0));
-    return MG_OK;  // w = Z*t with no columns: x0 unchanged (FGMRES.jl:119-121)
-  }
-  const int k = (int)inner;
-  if (Zbuf.n < (size_t)k * (size_t)L.cap_x) {
-    MG_TRY(Zbuf.alloc((size_t)k * (size_t)L.cap_x));
-    HIP_TRY(hipMemsetAsync(Zbuf.p, 0, Zbuf.bytes(), h->stream));
-  }
-  if (AZbuf.n < (size_t)k * (size_t)n) MG_TRY(AZbuf.alloc((size_t)k * (size_t)n));
-  double rnorm0 = 0.0;
-  MG_TRY(dist_norm(h, r0, n, &rnorm0));
-  std::vector<double> H((size_t)k * k, 0.0), xi((size_t)k, 0.0), t((size_t)k, 0.0), Pinv;
-  int used = 0;
-  for (int j = 0; j < k; ++j) {
-    double* z = Zbuf.p + (size_t)j * (size_t)L.cap_x;
-    double* w = AZbuf.p + (size_t)j * (size_t)n;
-    MG_TRY(prec(j == 0 ? r0 : AZbuf.p + (size_t)(j - 1) * (size_t)n, z));   // z = prec(r0) / prec(w)   (l.83-87)
-    MG_TRY(dist_apply_A(h, L, MG_K_SPMV, z, w, nullptr));                    // w = A z                  (l.91)
-    used = j + 1;
-    for (int i = 0; i <= j; ++i) {                                           // t = AZ' * w              (l.95)
-      double d = 0.0;
-      MG_TRY(dist_dot(h, AZbuf.p + (size_t)i * (size_t)n, w, n, &d));
-      H[(size_t)i * k + j] = d;
-      H[(size_t)j * k + i] = d;
-    }
-    MG_TRY(dist_dot(h, w, r0, n, &xi[(size_t)j]));                           // xi[j] = dot(w, r0)       (l.97)
-    pinv_sym(H, k, Pinv);                                                    // t = pinv(H)*xi           (l.102)
-    double tHt = 0.0, txi = 0.0;
-    for (int a = 0; a < k; ++a) {
-      double sacc = 0.0;
-      for (int b = 0; b < k; ++b) sacc += Pinv[(size_t)a * k + b] * xi[(size_t)b];
-      t[(size_t)a] = sacc;
-    }
-    for (int a = 0; a < k; ++a) {
-      double sacc = 0.0;
-      for (int b = 0; b < k; ++b) sacc += H[(size_t)a * k + b] * t[(size_t)b];
-      tHt += t[(size_t)a] * sacc;
-      txi += t[(size_t)a] * xi[(size_t)a];
-    }
-    const double rn = std::sqrt(std::fabs(tHt - 2.0 * txi + rnorm0 * rnorm0));   // l.104
-    if (rn < TOL) break;                                                          // l.114-117
-  }
-  for (int j = 0; j < used; ++j)                                             // x0 += Z*t                (l.121-123)
-    MG_TRY(dist_axpby(h, t[(size_t)j], Zbuf.p + (size_t)j * (size_t)L.cap_x, (j == 0 && x0_is_zero) ? 0.0 : 1.0, x0, n));
-  return MG_OK;
-}
-}  // extern "C++"
-
-// the sharded cycle: mirror of cycle_level (MGcycle.jl:1-118); returns the buffer holding x
-// defer_post (optional, in/out): asked with true, the LAST post-smoothing sweep is left out where it can run fused with the
-// residual that follows the cycle (dist_sweep_residual) - *defer_post tells whether it was.
-int dist_cycle(mg_dist* h, int l, const double* b, double* xa, double* xb, bool x_zero, char ctype, double** result,
-               bool r_valid = false, bool x1_ready = false, bool* defer_post = nullptr) {
-  DistLevel& L = h->lev[(size_t)l];
-  double *cur = xa, *alt = xb;
-  long long npre = L.npre;
-  const long long npost = L.npost;
-  const double gmresTol = 1e-5;  // MGcycle.jl:5
-  auto diag_prec = [&](const double* v, double* z) { return mg_vec_dscale_dev_FP64(L.d, v, z, L.n_own, h->nrhs, h->stream); };   // MM (l.36-38)
-  if (h->relax_type == 1) {      // Jac-GMRES (MGcycle.jl:48-50): FGMRES on the residual, preconditioned by D
-    const double* r0 = b;
-    if (x_zero) {
-      MG_TRY(dist_fill(h, cur, L.n_own, 0.0));
-    } else {
-      if (!r_valid) MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
-      r0 = L.r.p;
-    }
-    MG_TRY(dist_fgmres_relax(h, L, r0, cur, L.npre_raw, diag_prec, gmresTol, L.relZ, L.relAZ, false));
-    npre = 0;
-  } else if (x_zero) {
-    MG_TRY(mg_vec_dscale_dev_FP64(L.d, b, cur, L.n_own, h->nrhs, h->stream));
-    --npre;
-  } else if (r_valid) {
-    if (!x1_ready) MG_TRY(mg_vec_xpdr_dev_FP64(cur, L.d, L.r.p, alt, L.n_own, h->nrhs, h->stream));   // (else: written by the residual pass)
-    std::swap(cur, alt);
-    --npre;
-  }
-  // the last pre-smoothing sweep and the residual for the restriction as ONE pass where the level allows (MGcycle.jl:54-60)
-  const bool pair_pre = npre >= 1 && dist_pair_ok(h, L, cur);
-  for (long long s = 0; s < npre - (pair_pre ? 1 : 0); ++s) {
-    MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
-    std::swap(cur, alt);
-  }
-  if (pair_pre && dist_pair_ok(h, L, cur)) {
-    MG_TRY(dist_sweep_residual(h, L, cur, alt, L.r.p, nullptr, b, nullptr));
-    std::swap(cur, alt);
-  } else {
-    if (pair_pre) {   // (the buffer the remaining sweep starts from is not aligned for the pass: two launches)
-      MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
-      std::swap(cur, alt);
-    }
-    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
-  }
-  MG_TRY(dist_exchange_start(h, L.planR, L.r.p));
-  // R held with the owned | halo column split: the coarse rows that read owned residuals only run beside the exchange
-  auto restrict_to = [&](double* bc) {
-    if (L.R && L.R->M.regular_cols >= 0) {
-      MG_TRY(mg_op_apply_phase_dev_FP64(L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, bc, nullptr, nullptr, h->nrhs, 0, 1, h->stream));
-      MG_TRY(dist_exchange_finish(h, L.planR));
-      MG_TRY(mg_op_apply_phase_dev_FP64(L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, bc, nullptr, nullptr, h->nrhs, 0, 2, h->stream));
-    } else {
-      MG_TRY(dist_exchange_finish(h, L.planR));
-      MG_TRY(dist_apply(h, L.R, MG_K_RESTRICT, 1.0, L.r.p, 0.0, bc, nullptr, nullptr, 0));
-    }
-    return (int)MG_OK;
-  };
-  if (l + 1 < (int)h->lev.size()) {
-    DistLevel& C = h->lev[(size_t)l + 1];
-    MG_TRY(restrict_to(C.b.p));
-    double* xc = nullptr;
-    if (ctype == 'K') {
-      // K-cycle (MGcycle.jl:72-76): 2 steps of FGMRES on A_{l+1} xc = bc, preconditioned by the K-cycle of level l+1
-      // (level l+1 is sharded, hence never the coarsest).  C.x0 doubles as scratch of the inner cycles (xc = 0 on entry).
-      auto kprec = [&](const double* v, double* z) {
-        double* res = nullptr;
-        MG_TRY(dist_cycle(h, l + 1, v, C.x0.p, C.x1.p, true, 'K', &res));
-        HIP_TRY(hipMemcpyAsync(z, res, sizeof(double) * (size_t)C.n_own, hipMemcpyDeviceToDevice, h->stream));
-        return (int)MG_OK;
-      };
-      MG_TRY(dist_fgmres_relax(h, C, C.b.p, C.x0.p, 2, kprec, gmresTol, C.kZ, C.kAZ, true));
-      xc = C.x0.p;
-    } else {
-      MG_TRY(dist_cycle(h, l + 1, C.b.p, C.x0.p, C.x1.p, true, ctype, &xc));
-    }
-    if (ctype == 'W' || ctype == 'F') {
-      double* other = (xc == C.x0.p) ? C.x1.p : C.x0.p;
-      MG_TRY(dist_cycle(h, l + 1, C.b.p, xc, other, false, ctype == 'W' ? 'W' : 'V', &xc));
-    }
-    MG_TRY(dist_exchange_start(h, L.planP, xc));
-    if (L.P && L.P->M.regular_cols >= 0) {   // grid form: the rows that read owned coarse entries only run beside the exchange
-      MG_TRY(mg_op_apply_phase_dev_FP64(L.P, MG_K_PROLONG, 1.0, xc, 1.0, cur, nullptr, nullptr, h->nrhs, 0, 1, h->stream));
-      MG_TRY(dist_exchange_finish(h, L.planP));
-      MG_TRY(mg_op_apply_phase_dev_FP64(L.P, MG_K_PROLONG, 1.0, xc, 1.0, cur, nullptr, nullptr, h->nrhs, 0, 2, h->stream));
-    } else {
-      MG_TRY(dist_exchange_finish(h, L.planP));
-      MG_TRY(dist_apply(h, L.P, MG_K_PROLONG, 1.0, xc, 1.0, cur, nullptr, nullptr, 0));
-    }
-  } else {
-    // restrict into this rank's rows of the first replicated level, all-gather, run the tail replicated
-    MG_TRY(restrict_to(h->bc_pad.p));
-    if (h->comm) {
-      NCCL_TRY(g_rccl.AllGather(h->bc_pad.p, h->bc_all.p, (size_t)(h->max_tail * h->nrhs), NCCL_DOUBLE, h->comm, h->stream));
-    } else if (h->world > 1) {
-      const long long mt = h->max_tail * h->nrhs;      // doubles per rank: padded share x right-hand sides
-      MG_TRY(dist_stage(h, (size_t)mt * (size_t)(h->world + 1)));
-      HIP_TRY(hipMemcpyAsync(h->h_stage, h->bc_pad.p, sizeof(double) * (size_t)mt, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(spin_sync(h->stream));
-      if (h->plug(h->plug_user, 2, h->h_stage, nullptr, h->h_stage + mt, nullptr, mt) != 0)
-        return fail(MG_ERR_HIP, "exchange plug-in failed (all_gather)");
-      HIP_TRY(hipMemcpyAsync(h->bc_all.p, h->h_stage + mt, sizeof(double) * (size_t)(mt * h->world), hipMemcpyHostToDevice, h->stream));
-    } else {
-      HIP_TRY(hipMemcpyAsync(h->bc_all.p, h->bc_pad.p, sizeof(double) * (size_t)(h->max_tail * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
-    }
-    hipLaunchKernelGGL(dist_gather64, dim3((unsigned)((h->n_tail * h->nrhs + 255) / 256)), dim3(256), 0, h->stream, h->bc_all.p, h->gather_index.p, h->b_tail.p, h->n_tail, (int)h->nrhs);
-    HIP_TRY(hipGetLastError());
-    MG_TRY(mg_set_cycle_type(h->tail, ctype));
-    if (ctype == 'K' && (long long)h->lev.size() < h->nl_total - 1) {
-      // the first replicated level is not the coarsest: its K-step runs replicated, identically on every rank
-      MG_TRY(mg_kcycle_step_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail));
-    } else
-    MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, h->nrhs, 1));
-    if ((long long)h->lev.size() < h->nl_total - 1 && (ctype == 'W' || ctype == 'F')) {       // second visit (MGcycle.jl:79-84)
-      MG_TRY(mg_set_cycle_type(h->tail, ctype == 'W' ? 'W' : 'V'));
-      MG_TRY(mg_cycle_async_dev_FP64(h->tail, h->b_tail.p, h->x_tail.p, h->n_tail, h->nrhs, 0));
-    }
-    MG_TRY(dist_apply(h, L.P, MG_K_PROLONG, 1.0, h->x_tail.p, 1.0, cur, nullptr, nullptr, 0));
-  }
-  if (h->relax_type == 1) {      // MGcycle.jl:96-98
-    MG_TRY(dist_apply_A(h, L, MG_K_RESIDUAL, cur, L.r.p, b));
-    MG_TRY(dist_fgmres_relax(h, L, L.r.p, cur, L.npost_raw, diag_prec, gmresTol, L.relZ, L.relAZ, false));
-  } else {
-    const bool defer = defer_post && *defer_post && npost >= 1;
-    for (long long s = 0; s < npost - (defer ? 1 : 0); ++s) {
-      MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
-      std::swap(cur, alt);
-    }
-    if (defer_post) *defer_post = defer && dist_pair_ok(h, L, cur);
-    if (defer && !*defer_post) {   // (not fusable from this buffer after all: the sweep runs here)
-      MG_TRY(dist_apply_A(h, L, MG_K_SMOOTH, cur, alt, b));
-      std::swap(cur, alt);
-    }
-  }
-  if (h->relax_type == 1 && defer_post) *defer_post = false;
-  *result = cur;
-  return MG_OK;
-}
-
-int dist_set_plan(mg_dist* h, DistPlan& p, long long n_own_src, long long n_halo, long long n_send, const long long* send_idx,
-                  const long long* send_splits, const long long* recv_splits, long long active) {
-  p.set = true;
-  p.active = active != 0;
-  p.n_own_src = n_own_src;
-  p.n_halo = n_halo;
-  p.n_send = n_send;
-  p.send_splits.assign(send_splits, send_splits + h->world);
-  p.recv_splits.assign(recv_splits, recv_splits + h->world);
-  long long ss = 0, rs = 0;
-  for (int q = 0; q < h->world; ++q) { ss += p.send_splits[(size_t)q]; rs += p.recv_splits[(size_t)q]; }
-  if (ss != n_send || rs != n_halo) return fail(MG_ERR_INVALID, "halo plan: splits do not add up (send %lld/%lld, recv %lld/%lld)", ss, n_send, rs, n_halo);
-  std::vector<int> idx((size_t)std::max<long long>(n_send, 1), 0);
-  for (long long i = 0; i < n_send; ++i) {
-    if (send_idx[i] < 0 || send_idx[i] >= n_own_src) return fail(MG_ERR_INVALID, "halo plan: send index out of range");
-    idx[(size_t)i] = (int)send_idx[i];
-  }
-  MG_TRY(p.send_idx.alloc(idx.size()));
-  MG_TRY(p.send_buf.alloc(idx.size() * (size_t)h->nrhs));
-  HIP_TRY(hipMemcpy(p.send_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
-  if (!h->comm) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_send), sizeof(double) * (size_t)(std::max<long long>(n_send, 1) * h->nrhs)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p.h_recv), sizeof(double) * (size_t)(std::max<long long>(n_halo, 1) * h->nrhs)));
-  }
-  return MG_OK;
-}
-void dist_free_plan(DistPlan& p) {
-  p.send_idx.release();
-  p.send_buf.release();
-  if (p.h_send) (void)hipHostFree(p.h_send);
-  if (p.h_recv) (void)hipHostFree(p.h_recv);
-  p.h_send = p.h_recv = nullptr;
-}
-}  // namespace
-
-int mg_dist_unique_id(char* id128) {
-  if (!id128) return fail(MG_ERR_INVALID, "null argument");
-  if (!g_rccl.load()) return fail(MG_ERR_HIP, "librccl.so could not be loaded");
-  Rccl::UniqueId u;
-  NCCL_TRY(g_rccl.GetUniqueId(&u));
-  std::memcpy(id128, u.internal, 128);
-  return MG_OK;
-}
-
-int mg_dist_create(long long device_id, long long rank, long long world, const char* unique_id128, long long nlevels,
-                   long long nl_total, long long cycleType, mg_dist** out) {
-  if (!out) return fail(MG_ERR_INVALID, "out is null");
-  *out = nullptr;
-  if (world < 1 || rank < 0 || rank >= world || nlevels < 1 || nl_total <= nlevels)
-    return fail(MG_ERR_INVALID, "bad rank/world/levels (%lld/%lld, %lld sharded of %lld)", rank, world, nlevels, nl_total);
-  if (cycleType != 'V' && cycleType != 'W' && cycleType != 'F' && cycleType != 'K') return fail(MG_ERR_UNSUPPORTED, "the sharded cycle implements V, W, F and K");
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) return fail(MG_ERR_HIP, "no HIP device visible: the multigrid cycle has no CPU fallback");
-  if (device_id < 0 || device_id >= ndev) return fail(MG_ERR_INVALID, "device_id=%lld but %d devices visible", device_id, ndev);
-  HIP_TRY(hipSetDevice((int)device_id));
-  mg_dist* h = new mg_dist();
-  h->device = (int)device_id;
-  h->rank = (int)rank;
-  h->world = (int)world;
-  h->cycle = (char)cycleType;
-  h->nl_total = nl_total;
-  h->lev.resize((size_t)nlevels);
-  if (const char* e = std::getenv("MG_DIST_NO_PAIR")) h->no_pair = e[0] == '1';   // (read once, here: nothing on the launch path reads the environment)
-  auto bail = [&](int rc) { mg_dist_destroy(h); return rc; };
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_landed, hipEventDisableTiming) != hipSuccess ||
-      h->partial.alloc(1024) != MG_OK || h->partial2.alloc(256) != MG_OK || h->scalar.alloc(1) != MG_OK || hipHostMalloc(reinterpret_cast<void**>(&h->h_scalar), sizeof(double)) != hipSuccess)
-    return bail(fail(MG_ERR_HIP, "stream / event / scratch creation failed"));
-  if (unique_id128) {
-    if (!g_rccl.load()) return bail(fail(MG_ERR_HIP, "librccl.so could not be loaded"));
-    Rccl::UniqueId u;
-    std::memcpy(u.internal, unique_id128, 128);
-    const ncclResult_t rc = g_rccl.CommInitRank(&h->comm, (int)world, u, (int)rank);
-    if (rc != ncclSuccess) return bail(dist_nccl(rc, "ncclCommInitRank"));
-  }
-  *out = h;
-  return MG_OK;
-}
-
-// Ranks of this handle's communicator AS RCCL REPORTS THEM (ncclCommCount); 0 when the handle uses the plug-in transport.
-int mg_dist_comm_count(mg_dist* h, long long* count) {
-  if (!h || !count) return fail(MG_ERR_INVALID, "null argument");
-  *count = 0;
-  if (!h->comm) return MG_OK;
-  if (!g_rccl.CommCount) return fail(MG_ERR_UNSUPPORTED, "this librccl has no ncclCommCount");
-  int c = 0;
-  NCCL_TRY(g_rccl.CommCount(h->comm, &c));
-  *count = c;
-  return MG_OK;
-}
-
-// Right-hand sides per call (default 1): blocks are row-major [n][nrhs] everywhere, as in mg_hierarchy (MGdef.jl:163-176: the
-// reference is block-capable everywhere; one Frobenius stopping criterion for the block, SolveFuncs.jl:30).  Call it right
-// after mg_dist_create - the plans, the tail and the level vectors are sized with it.  Blocks run the pointwise smoothers and
-// the V / W / F cycles (the K-cycle's and Jac-GMRES's small systems are per right-hand side in the reference: refused here).
-int mg_dist_set_nrhs(mg_dist* h, long long nrhs) {
-  if (!h || nrhs < 1) return fail(MG_ERR_INVALID, "null handle or nrhs < 1");
-  for (const DistLevel& L : h->lev)
-    if (L.planA.set || L.n_own > 0) return fail(MG_ERR_STATE, "mg_dist_set_nrhs must precede the levels and plans");
-  if (h->tail) return fail(MG_ERR_STATE, "mg_dist_set_nrhs must precede mg_dist_set_tail_INT64");
-  if (nrhs > 1 && (h->cycle == 'K' || h->relax_type == 1)) return fail(MG_ERR_UNSUPPORTED, "blocks of right-hand sides: V, W, F cycles with pointwise smoothers");
-  h->nrhs = nrhs;
-  h->finalized = false;
-  return MG_OK;
-}
-
-int mg_dist_set_exchange_plugin(mg_dist* h, mg_exchange_fn fn, void* user) {
-  if (!h || !fn) return fail(MG_ERR_INVALID, "null argument");
-  if (h->comm) return fail(MG_ERR_STATE, "this handle was created with an RCCL communicator");
-  h->plug = fn;
-  h->plug_user = user;
-  return MG_OK;
-}
-
-int mg_dist_set_level(mg_dist* h, long long level, long long n_own, long long n_int, mg_operator* A_int, mg_operator* A_bnd,
-                      mg_operator* P, mg_operator* R, const double* d_dev, long long relaxPre, long long relaxPost) {
-  if (!h) return fail(MG_ERR_INVALID, "null handle");
-  if (level < 1 || level > (long long)h->lev.size()) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  if (n_own < 1 || n_int < 0 || n_int > n_own || !P || !R || !d_dev || (n_int > 0 && !A_int) || (n_int < n_own && !A_bnd))
-    return fail(MG_ERR_INVALID, "inconsistent level description");
-  DistLevel& L = h->lev[(size_t)level - 1];
-  L.n_own = n_own;
-  L.n_int = n_int;
-  L.A_int = A_int;
-  L.A_bnd = A_bnd;
-  L.P = P;
-  L.R = R;
-  L.d = d_dev;
-  L.npre = std::max<long long>(1, relaxPre);      // relax() always updates once (MGcycle.jl:127-134)
-  L.npost = std::max<long long>(1, relaxPost);
-  L.npre_raw = relaxPre;
-  L.npost_raw = relaxPost;
-  L.box = false;
-  h->finalized = false;
-  return MG_OK;
-}
-
-// 0: pointwise smoothers (Jac / SPAI, the relaxPrec vectors), 1: Jac-GMRES (FGMRES_relaxation preconditioned by the
-// relaxPrec vector; relaxPre/relaxPost are its inner dimensions).  The replicated tail carries its own setting.
-int mg_dist_set_relax_type(mg_dist* h, long long relax_type) {
-  if (!h) return fail(MG_ERR_INVALID, "null handle");
-  if (relax_type != 0 && relax_type != 1) return fail(MG_ERR_INVALID, "relax_type must be 0 (pointwise) or 1 (Jac-GMRES)");
-  h->relax_type = (int)relax_type;
-  return MG_OK;
-}
-
-// Level `level` holds its A as ONE box operator (mg_op_create_box_FP64_INT64, passed as A_int with n_int = n_own).
-int mg_dist_set_level_box(mg_dist* h, long long level, long long on) {
-  if (!h) return fail(MG_ERR_INVALID, "null handle");
-  if (level < 1 || level > (long long)h->lev.size()) return fail(MG_ERR_INVALID, "bad level %lld", level);
-  h->lev[(size_t)level - 1].box = on != 0;
-  return MG_OK;
-}
-
-int mg_dist_set_plan_INT64(mg_dist* h, long long level, long long which, long long n_own_src, long long n_halo, long long n_send,
-                           const long long* send_idx, const long long* send_splits, const long long* recv_splits, long long active) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null handle");
-  if (level < 1 || level > (long long)h->lev.size() || which < 0 || which > 2) return fail(MG_ERR_INVALID, "bad (level, which)");
-  if (!send_splits || !recv_splits || (n_send > 0 && !send_idx) || n_halo < 0 || n_send < 0) return fail(MG_ERR_INVALID, "bad plan arrays");
-  (void)hipSetDevice(h->device);
-  DistLevel& L = h->lev[(size_t)level - 1];
-  DistPlan& p = which == MG_OP_A ? L.planA : (which == MG_OP_P ? L.planP : L.planR);
-  dist_free_plan(p);
-  h->finalized = false;
-  return dist_set_plan(h, p, n_own_src, n_halo, n_send, send_idx, send_splits, recv_splits, active);
-}
-
-int mg_dist_set_tail_INT64(mg_dist* h, mg_hierarchy* tail, long long n_tail, long long own_tail, long long max_tail,
-                           const long long* gather_index) {
-  UploadFence upload_fence;
-  if (!h || !tail || !gather_index || n_tail < 1 || max_tail < 1 || own_tail < 0 || own_tail > max_tail) return fail(MG_ERR_INVALID, "bad tail description");
-  (void)hipSetDevice(h->device);
-  h->tail = tail;
-  h->n_tail = n_tail;
-  h->own_tail = own_tail;
-  h->max_tail = max_tail;
-  const size_t kk = (size_t)h->nrhs;
-  MG_TRY(h->bc_pad.alloc((size_t)max_tail * kk));
-  MG_TRY(h->bc_all.alloc((size_t)max_tail * (size_t)h->world * kk));
-  MG_TRY(h->b_tail.alloc((size_t)n_tail * kk));
-  MG_TRY(h->x_tail.alloc((size_t)n_tail * kk));
-  if (tail->nrhs != h->nrhs) return fail(MG_ERR_INVALID, "the tail hierarchy is set up for %lld right-hand sides, the sequencer for %lld", tail->nrhs, h->nrhs);
-  MG_TRY(h->gather_index.alloc((size_t)n_tail));
-  for (long long i = 0; i < n_tail; ++i)
-    if (gather_index[i] < 0 || gather_index[i] >= max_tail * h->world) return fail(MG_ERR_INVALID, "gather index out of range");
-  HIP_TRY(hipMemset(h->bc_pad.p, 0, h->bc_pad.bytes()));
-  HIP_TRY(hipMemset(h->x_tail.p, 0, h->x_tail.bytes()));
-  HIP_TRY(hipMemcpy(h->gather_index.p, gather_index, (size_t)n_tail * sizeof(long long), hipMemcpyHostToDevice));
-  // The tail enqueues on this sequencer's stream from now on.  Its own stream (if it owns one) is parked, not destroyed,
-  // and comes back with mg_dist_release_tail / mg_dist_destroy - the handle stays usable by its owner afterwards.
-  graphs_clear(tail);
-  (void)spin_sync(tail->stream);
-  h->tail_prev_stream = tail->stream;
-  h->tail_prev_owns = tail->owns_stream;
-  h->tail_prev_no_graph = tail->opt.no_graph;
-  h->tail_borrowed = true;
-  tail->stream = h->stream;
-  tail->owns_stream = false;
-  // Measured at world size 1 on 256^3 (bench.py --force-sharded-path): replaying the tail as a HIP graph between the
-  // all-gather and the prolongation costs 40-80 us per step (0.98 -> 1.02-1.06 ms) where the single-GPU cycle gains 23:
-  // off unless the tail's handle asks for it (mg_set_option(tail, "dist_tail_graph", 1) / MG_DIST_TAIL_GRAPH=1).
-  if (!tail->opt.dist_tail_graph) tail->opt.no_graph = true;
-  h->finalized = false;
-  return MG_OK;
-}
-
-int mg_dist_finalize(mg_dist* h) {
-  UploadFence upload_fence;
-  if (!h) return fail(MG_ERR_INVALID, "null handle");
-  (void)hipSetDevice(h->device);
-  if (!h->tail) return fail(MG_ERR_STATE, "the replicated tail was not set");
-  for (DistLevel& L : h->lev)   // relaxPrec from the class dictionary where the level's A allows it
-    if (L.A_int && L.d && L.A_int->M.has_rc) {
-      const long long nreg = L.A_int->M.regular_cols >= 0 ? L.A_int->M.regular_cols : L.A_int->M.n_rows;
-      (void)hipDeviceSynchronize();
-      MG_TRY(derive_class_d_csr(L.A_int->M, L.d, (size_t)nreg));
-    }
-  if (h->world > 1 && !h->comm && !h->plug) return fail(MG_ERR_STATE, "no transport: pass an RCCL unique id to mg_dist_create or set an exchange plug-in");
-  const int a = (int)h->lev.size();
-  for (int l = 0; l < a; ++l) {
-    DistLevel& L = h->lev[(size_t)l];
-    if (L.n_own < 1) return fail(MG_ERR_STATE, "sharded level %d was not set", l + 1);
-    if (!L.planA.set || !L.planR.set || (l + 1 < a && !L.planP.set)) return fail(MG_ERR_STATE, "halo plans of level %d are incomplete", l + 1);
-    long long halo_x = L.planA.n_halo;
-    if (l > 0 && h->lev[(size_t)l - 1].planP.set) halo_x = std::max(halo_x, h->lev[(size_t)l - 1].planP.n_halo);
-    L.cap_x = L.n_own + halo_x;
-    L.cap_r = L.n_own + L.planR.n_halo;
-    MG_TRY(L.x0.alloc((size_t)(L.cap_x * h->nrhs)));
-    MG_TRY(L.x1.alloc((size_t)(L.cap_x * h->nrhs)));
-    MG_TRY(L.r.alloc((size_t)(L.cap_r * h->nrhs)));
-    HIP_TRY(hipMemset(L.x0.p, 0, L.x0.bytes()));
-    HIP_TRY(hipMemset(L.x1.p, 0, L.x1.bytes()));
-    HIP_TRY(hipMemset(L.r.p, 0, L.r.bytes()));
-    if (l > 0) {
-      MG_TRY(L.b.alloc((size_t)(L.n_own * h->nrhs)));
-      HIP_TRY(hipMemset(L.b.p, 0, L.b.bytes()));
-    }
-  }
-  // one ||r||^2 partial per workgroup of the fused residual pass: at most one per 256 rows, + the exception rows' blocks
-  {
-    size_t need = (size_t)(2 * (h->lev[0].n_own / 256 + 2) + 1024);
-    if (h->lev[0].A_int) {
-      const Csr& M = h->lev[0].A_int->M;
-      need = std::max(need, (size_t)std::max(M.blocks1(), M.nblocks) + (size_t)(M.rc_nexc + mgk::BLK - 1) / mgk::BLK + 2);
-    }
-    MG_TRY(h->partial.alloc(need));
-  }
-  h->finalized = true;
-  return MG_OK;
-}
-
-int mg_dist_cycle_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long long n_own, long long x_is_zero) {
-  if (!h || !b_loc || !x_loc) return fail(MG_ERR_INVALID, "null argument");
-  if (!h->finalized) return fail(MG_ERR_STATE, "mg_dist_finalize was not called");
-  DistLevel& L = h->lev[0];
-  if (n_own != L.n_own) return fail(MG_ERR_INVALID, "n_own=%lld but this rank owns %lld fine rows", n_own, L.n_own);
-  (void)hipSetDevice(h->device);
-  HIP_TRY(hipMemcpyAsync(L.x0.p, x_loc, sizeof(double) * (size_t)(n_own * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
-  double* res = nullptr;
-  MG_TRY(dist_cycle(h, 0, b_loc, L.x0.p, L.x1.p, x_is_zero != 0, h->cycle, &res));
-  HIP_TRY(hipMemcpyAsync(x_loc, res, sizeof(double) * (size_t)(n_own * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(spin_sync(h->stream));
-  return MG_OK;
-}
-
-// solveMG (SolveFuncs.jl:3-39) on sharded vectors
-int mg_dist_solve_dev_FP64(mg_dist* h, const double* b_loc, double* x_loc, long long n_own, double tol, long long maxIter,
-                           long long* iters, double* resvec) {
-  if (!h || !b_loc || !x_loc || maxIter < 0) return fail(MG_ERR_INVALID, "null argument or maxIter < 0");
-  if (!h->finalized) return fail(MG_ERR_STATE, "mg_dist_finalize was not called");
-  DistLevel& L = h->lev[0];
-  if (n_own != L.n_own) return fail(MG_ERR_INVALID, "n_own=%lld but this rank owns %lld fine rows", n_own, L.n_own);
-  (void)hipSetDevice(h->device);
-  double *cur = L.x0.p, *alt = L.x1.p;
-  HIP_TRY(hipMemcpyAsync(cur, x_loc, sizeof(double) * (size_t)(n_own * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
-  double xn = 0.0, res0 = 0.0, res = 0.0;
-  MG_TRY(dist_norm(h, cur, n_own * h->nrhs, &xn));
-  bool x_zero = (xn == 0.0);
-  bool x1_ready = false;
-  if (x_zero) {
-    MG_TRY(dist_norm(h, b_loc, n_own * h->nrhs, &res0));
-  } else {
-    MG_TRY(dist_residual_norm(h, L, cur, b_loc, nullptr, &res0, &x1_ready));
-  }
-  if (resvec) resvec[0] = res0;
-  long long it = 0;
-  // Where the fine level's A allows, the last post-smoothing sweep is left out of the cycle and runs fused with the residual of
-  // the stopping test (SolveFuncs.jl:26-30): x -> the iterate t, ||r||, and xn = t + d.*r, the next cycle's first update;
-  // three buffers rotate (as solve_dev does on one GPU)
-  double* spare = nullptr;
-  bool fuse_post = false;
-  if (h->relax_type == 0 && L.npost >= 1 && dist_pair_ok(h, L, cur)) {
-    if (L.x2.n != (size_t)L.cap_x) {
-      MG_TRY(L.x2.alloc((size_t)L.cap_x));
-      HIP_TRY(hipMemsetAsync(L.x2.p, 0, L.x2.bytes(), h->stream));
-    }
-    spare = L.x2.p;
-    fuse_post = dist_pair_ok(h, L, alt) && dist_pair_ok(h, L, spare);
-  }
-  for (long long count = 1; count <= maxIter; ++count) {
-    double* out = nullptr;
-    bool deferred = fuse_post;
-    MG_TRY(dist_cycle(h, 0, b_loc, cur, alt, x_zero, h->cycle, &out, count > 1 || !x_zero, x1_ready, fuse_post ? &deferred : nullptr));
-    if (out != cur) std::swap(cur, alt);
-    x_zero = false;
-    if (fuse_post && deferred) {
-      // cur = x before the last sweep; alt <- the iterate; spare <- t + d.*r (not written on the last step)
-      MG_TRY(dist_sweep_residual(h, L, cur, alt, nullptr, count < maxIter ? spare : nullptr, b_loc, &res));
-      x1_ready = count < maxIter;
-      double* freed = cur;
-      cur = alt;
-      alt = spare;
-      spare = freed;
-    } else {
-      MG_TRY(dist_residual_norm(h, L, cur, b_loc, (count < maxIter && h->relax_type == 0) ? alt : nullptr, &res, &x1_ready));
-    }
-    ++it;
-    if (resvec) resvec[it] = res;
-    if (res / res0 < tol) break;
-  }
-  HIP_TRY(hipMemcpyAsync(x_loc, cur, sizeof(double) * (size_t)(n_own * h->nrhs), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(spin_sync(h->stream));
-  if (iters) *iters = it;
-  return MG_OK;
-}
-
-// Hand the replicated tail's hierarchy back to its owner: its stream and graph option as they were before
-// mg_dist_set_tail_INT64.  Call it BEFORE destroying the tail's handle when that happens first; mg_dist_destroy calls it
-// otherwise.  The sequencer cannot cycle afterwards (mg_dist_set_tail_INT64 again to re-attach).
-int mg_dist_release_tail(mg_dist* h) {
-  if (!h) return fail(MG_ERR_INVALID, "null handle");
-  if (h->tail && h->tail_borrowed) {
-    (void)hipSetDevice(h->device);
-    if (h->stream) (void)spin_sync(h->stream);
-    graphs_clear(h->tail);
-    h->tail->stream = h->tail_prev_stream;
-    h->tail->owns_stream = h->tail_prev_owns;
-    h->tail->opt.no_graph = h->tail_prev_no_graph;
-  }
-  h->tail = nullptr;
-  h->tail_borrowed = false;
-  h->finalized = false;
-  return MG_OK;
-}
-
-int mg_dist_destroy(mg_dist* h) {
-  if (!h) return MG_OK;
-  (void)hipSetDevice(h->device);
-  if (h->stream) (void)spin_sync(h->stream);
-  if (h->side) (void)spin_sync(h->side);
-  if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
-  (void)mg_dist_release_tail(h);
-  for (auto& L : h->lev) {
-    dist_free_plan(L.planA);
-    dist_free_plan(L.planR);
-    dist_free_plan(L.planP);
-    L.x0.release();
-    L.x1.release();
-    L.x2.release();
-    L.r.release();
-    L.b.release();
-  }
-  h->bc_pad.release();
-  h->bc_all.release();
-  h->b_tail.release();
-  h->x_tail.release();
-  h->gather_index.release();
-  h->partial.release();
-  h->partial2.release();
-  h->scalar.release();
-  if (h->h_scalar) (void)hipHostFree(h->h_scalar);
-  if (h->h_stage) (void)hipHostFree(h->h_stage);
-  if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
-  if (h->ev_landed) (void)hipEventDestroy(h->ev_landed);
-  if (h->side) (void)hipStreamDestroy(h->side);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
-  delete h;
-  return MG_OK;
-}
-
-// Run the hierarchy's kernels on the caller's stream (e.g. torch's current stream) instead of its own.
-int mg_set_stream(mg_hierarchy* h, void* stream) {
-  if (!h) return fail(MG_ERR_INVALID, "null hierarchy handle");
-  graphs_clear(h);
-  (void)hipSetDevice(h->device);
-  (void)spin_sync(h->stream);
-  if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
-  h->stream = reinterpret_cast<hipStream_t>(stream);
-  h->owns_stream = false;
-  return MG_OK;
-}
-
-// Enqueue one cycle and return without waiting (x_is_zero must be 0 or 1).
-int mg_cycle_async_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n, long long nrhs,
-                            long long x_is_zero) {
-  MG_TRY(check_ready(h, n, nrhs));
-  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
-  if (x_is_zero != 0 && x_is_zero != 1) return fail(MG_ERR_INVALID, "x_is_zero must be 0 or 1 for the asynchronous cycle");
-  (void)hipSetDevice(h->device);
-  return cycle_dev(h, b, x, x_is_zero == 1);
-}
-
-// The K-cycle's step INTO this hierarchy's first level (MGcycle.jl:72-76): x = 2 steps of FGMRES on A_1 x = b from x = 0,
-// preconditioned by the K-cycle of level 1.  For a hierarchy that is the replicated tail of a sharded one (mg_dist_*): the
-// level above it is sharded and its K-branch lands here.  A one-level hierarchy just solves.  Asynchronous like
-// mg_cycle_async_dev_FP64 as far as the stream goes (the FGMRES dots are host-visible, as everywhere in a K-cycle).
-int mg_kcycle_step_async_dev_FP64(mg_hierarchy* h, const double* b, double* x, long long n) {
-  MG_TRY(check_ready(h, n, 1));
-  if (!b || !x) return fail(MG_ERR_INVALID, "null vector");
-  (void)hipSetDevice(h->device);
-  if (h->nlevels < 2) return cycle_dev(h, b, x, true);
-  Level& L = h->lev[0];
-  if (h->kstepZ.n != (size_t)(2 * n)) {
-    MG_TRY(h->kstepZ.alloc((size_t)(2 * n)));
-    MG_TRY(h->kstepAZ.alloc((size_t)(2 * n)));
-    MG_TRY(h->kstepX.alloc((size_t)n));
-  }
-  auto kprec = [&](const double* v, double* z) {
-    double* res = nullptr;
-    MG_TRY(cycle_level(h, 0, v, h->kstepX.p, L.x1.p, true, 'K', &res));
-    HIP_TRY(hipMemcpyAsync(z, res, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
-    return (int)MG_OK;
-  };
-  return fgmres_relax(h, 0, b, x, 2, kprec, 1e-5, h->kstepZ.p, h->kstepAZ.p, true);
-}
-
-}  // extern "C"
+// One translation unit, six parts (round 4: the 6 800-line file split by responsibility; the order is the dependency order):
+#include "mg_types.inc"      // Options, DevBuf, Csr, Level, mg_hierarchy
+#include "mg_launch.inc"     // byte accounting, profiling slots, kernel launchers
+#include "mg_schedule.inc"   // FGMRES relaxation, cycle_level, HIP graphs, solve loop
+#include "mg_krylov.inc"     // PCG / BiCGSTAB / FGMRES and block variants
+#include "mg_formats.inc"    // upload, format builders, scratch
+#include "mg_cabi.inc"       // extern "C": the single-GPU API
+#include "mg_dist.inc"       // extern "C": the native multi-GPU sequencer
