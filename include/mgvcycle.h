@@ -349,7 +349,9 @@ int mg_op_bind_relax_dev_FP64(mg_operator* op, const double* d_dev, long long n)
 
 /* Which kernel fuses a damped-Jacobi sweep with the residual that follows it (MGcycle.jl:129-131 + 58-60) on this level's
  * A: *form = 0 none (two launches), 2 the 1-D chunk form, 3 the 2-D in-plane tile form, 4 the same with the coefficients
- * streamed per row (band form of a grid operator without row classes); geometry (optional, 12 entries, forms 3 and 4): tiles per line, tiles per column, TX, TY, rows per lane, workgroups, LDS bytes, estimated fill bytes per row x
+ * streamed per row (band form of a grid operator without row classes), 5 the 27-point marching form (csr_rowclass_march27_spmv: t and r
+ * out only; it also serves single sweeps / residuals of the level; geometry: the pair's, [7] = workgroups of the single-product
+ * geometry); geometry (optional, 12 entries, forms 3 and 4): tiles per line, tiles per column, TX, TY, rows per lane, workgroups, LDS bytes, estimated fill bytes per row x
  * 100, threads per workgroup, segments of the lockstep schedule (0: balanced), planes per segment, class-table entries. */
 int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, long long* geometry);
 /* kernel variant serving the operator at nrhs == 1 (as mg_operator_rowclass_flags) and its exception rows */

@@ -2650,17 +2650,19 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
   double* xw = win;
   char* winb = reinterpret_cast<char*>(win);
   M4Class* dcl = reinterpret_cast<M4Class*>(win + 9 * XS);                                 // [ncls]
-  unsigned short* cxL = reinterpret_cast<unsigned short*>(dcl + T.ncls);                   // cx | cy | cz | tab
-  unsigned short* cyL = cxL + T.n1;
-  unsigned short* czL = cyL + T.n2;
+  // (cx | cy are read once per lane, from global memory; the LDS copy holds cz | tab: 2*(n1 + n2) bytes more for the slabs)
+  const unsigned short* cxG = T.cmap;
+  const unsigned short* cyG = cxG + T.n1;
+  unsigned short* czL = reinterpret_cast<unsigned short*>(dcl + T.ncls);                   // cz | tab
   unsigned short* tabL = czL + T.nplanes;
   {
     const int nw = T.ncls * (int)(sizeof(M4Class) / 8);
     const double* srcd = reinterpret_cast<const double*>(T.cls);
     double* dstd = reinterpret_cast<double*>(dcl);
     for (int i = tid; i < nw; i += NT) dstd[i] = srcd[i];
-    const int nm = T.n1 + T.n2 + T.nplanes + T.ntab;
-    for (int i = tid; i < nm; i += NT) cxL[i] = T.cmap[i];
+    const int nm = T.nplanes + T.ntab;
+    const unsigned short* czG = cyG + T.n2;
+    for (int i = tid; i < nm; i += NT) czL[i] = czG[i];
     for (int i = tid; i < 9 * XS; i += NT) win[i] = 0.0;          // every slab entry finite from the start
   }
   const int zstride = T.ncy * T.ncx;
@@ -2722,7 +2724,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     const int ip0 = (y0 - 3 + K1 * j) * T.n1 + gx;      // in-plane index of row 0; row s: + s*n1
     unsigned lv = 0u;                                   // per row s: bit s = stage 1 is computed on it, bit 8+s stage 2, 16+s stage 3, 24+s stage 4 (core)
     unsigned pk[K1];                                    // class of the row per z-class: byte zc = tab[zc][cy][cx]
-    const int cxo = xin ? (int)cxL[gx] : 0;
+    const int cxo = xin ? (int)cxG[gx] : 0;
     unsigned pk0 = 0u;                                  // class word of the lane's first live row
     bool have0 = false;
 #pragma unroll
@@ -2738,7 +2740,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
       lv |= ((l1 && dist == 0 && !twin) ? 1u : 0u) << (24 + s);
       unsigned v = 0u;
       if (l1) {
-        const int rp = (int)cyL[gy] * T.ncx + cxo;
+        const int rp = (int)cyG[gy] * T.ncx + cxo;
         for (int zc = 0; zc < T.ncz; ++zc) v |= ((unsigned)tabL[zc * zstride + rp] & 255u) << (8 * zc);
         if (!have0) { pk0 = v; have0 = true; }
       }

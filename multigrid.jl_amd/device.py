@@ -613,7 +613,8 @@ class DeviceHierarchy:
         return bool(a.value), bool(b.value)
 
     def sweep_residual_form(self, level: int):
-        """(form, geometry): 0 two launches, 2 csr_rowclass_march2_spmv, 3 csr_rowclass_march3_spmv with its tile geometry
+        """(form, geometry): 0 two launches, 2 csr_rowclass_march2_spmv, 5 csr_rowclass_march27_spmv (27-point levels; geometry of
+        the pair, [7] = workgroups of its single-product geometry), 3 (4: band form) csr_rowclass_march3_spmv with its tile geometry
         [tiles per line, tiles per column, TX, TY, rows per lane, workgroups, LDS bytes, est. fill bytes per row x 100,
         threads per workgroup, lockstep segments (0: balanced ranges), planes per segment, class-table entries]."""
         f = C.c_longlong(0)

@@ -72,6 +72,32 @@ def test_four_stage_pass_bit_identical_to_the_two_passes(mg, built, monkeypatch,
 
 
 @pytest.mark.gpu
+def test_four_stage_pass_with_more_workgroups_than_cus(mg, built, monkeypatch):
+    """A plane with more tiles than the chip has CUs (513-node lines) takes several rounds of shorter segments: 183 tiles x 4
+    segments = 732 workgroups here, same bits as the two passes."""
+    import torch
+    _small_grid_env(monkeypatch)
+    monkeypatch.setenv("MG_MARCH4_TILES_X", "3")
+    monkeypatch.setenv("MG_MARCH4_TY_MAX", "2")
+    monkeypatch.setenv("MG_MARCH4_SEGS", "4")
+    A, p, b = _setup(mg, [48, 120, 33], 2)
+    h = mg.to_device(p)
+    ok, geo = h.four_stage_form(1)
+    assert ok and geo[5] > 512 and geo[9] == 4, geo
+    rng = np.random.default_rng(11)
+    x, bb = torch.from_numpy(rng.standard_normal(A.shape[0])).cuda(), torch.from_numpy(rng.standard_normal(A.shape[0])).cuda()
+    tp, rp = torch.full_like(x, np.nan), torch.full_like(x, np.nan)
+    nrm = h.four_stage_dev(1, bb, x, tp, rp)
+    t, xn = torch.zeros_like(x), torch.zeros_like(x)
+    nrm2 = h.sweep_residual_dev(1, bb, x, t, None, xn, True)
+    t2, r2 = torch.zeros_like(x), torch.zeros_like(x)
+    h.sweep_residual_dev(1, bb, xn, t2, r2)
+    assert torch.equal(tp, t2) and torch.equal(rp, r2)
+    assert abs(nrm - nrm2) <= 1e-14 * nrm2
+    mg.clear_(p)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cells,levels,cyc,tol", [([33, 25, 15], 2, "V", 1e-10), ([40, 31, 17], 3, "W", 1e-10), ([23, 23, 23], 2, "F", 1e-10),
                                                   ([33, 25, 15], 2, "V", 3e-3), ([36, 33, 12], 2, "V", 1e-1), ([40, 31, 17], 3, "V", 1e-30)])
 def test_solve_with_the_four_stage_pass(mg, built, monkeypatch, cells, levels, cyc, tol):
