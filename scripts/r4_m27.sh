@@ -1,8 +1,10 @@
 #!/bin/bash
-# A/B of the 27-point marching form on C2 (level 2 = 129^3 nodes): bench.py kernel table per variant
+# A/B of the 27-point marching form on C2 (level 2 = 129^3 nodes): parity tests, then bench.py kernel table per variant
 set -u
 out=gpurun_out/r4m27
 mkdir -p $out
+timeout -k 10 500 python -m pytest tests/test_march27.py -x -q > $out/tests.log 2>&1 || { tail -30 $out/tests.log; exit 1; }
+tail -2 $out/tests.log
 run() {  # name, env...
   name=$1; shift
   env "$@" python bench.py --cells ${CELLS:-256} --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass --no-divsiggrad > $out/$name.json 2> $out/$name.err
