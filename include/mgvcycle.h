@@ -302,7 +302,8 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
  * serves the operator at nrhs == 1: -1 none (streaming formats), 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv
  * (x staged in LDS per workgroup of consecutive rows), 2 csr_rowclass_tile_spmv (plane tiles from the grid hint),
  * 3 csr_rowclass_march_spmv (z-marching ring of slabs from the grid hint), 4 csr_rowclass_lane_spmv (every lane
- * walks its own row's class, dictionary in LDS: the default for operators that are not staged); with a block of
+ * walks its own row's class, dictionary in LDS: the default for operators that are not staged), 7 csr_rowclass_marchr_spmv
+ * (a restriction of a vertex-centred grid pair walking the fine planes: mg_marchr.hpp); with a block of
  * right-hand sides (current nrhs > 1): 5 csr_rowclass_lane_spmm (one column per lane), 6 csr_rowclass_lane_spmm2 (even
  * nrhs: two columns = 16 bytes per lane; its residual form also writes the ||r||^2 partials and x + d.*r), -1 the
  * CSR-stream SpMM;

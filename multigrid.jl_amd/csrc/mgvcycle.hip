@@ -29,6 +29,7 @@
 #include "../../include/mgvcycle.h"
 #include "mg_kernels.hpp"
 #include "mg_march27.hpp"
+#include "mg_marchr.hpp"
 
 
 // One translation unit, six parts (round 4: the 6 800-line file split by responsibility; the order is the dependency order):

@@ -623,7 +623,8 @@ class DeviceHierarchy:
         return int(f.value), [int(v) for v in g]
 
     def operator_kernel_variant(self, level: int, which: int) -> int:
-        """-1 streaming formats, 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv, 2 csr_rowclass_tile_spmv."""
+        """-1 streaming formats, 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv, 2 csr_rowclass_tile_spmv, 3 csr_rowclass_march_spmv,
+        4 csr_rowclass_lane_spmv, 7 csr_rowclass_marchr_spmv (marching restriction)."""
         return self.operator_kernel_info(level, which)[0]
 
     def operator_kernel_info(self, level: int, which: int):
