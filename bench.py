@@ -8,7 +8,8 @@ hierarchy, b and x resident in HBM.
 
 Workloads (BASELINE.json configs):
   c2 (default)  3-D 7-pt Poisson 256^3 cells, GMG V(2,1) damped Jacobi w=0.8, 6 levels, fp64, nrhs=1
-  c5            same operator, 16 right-hand sides (block SpMM path)
+  c5            same operator, 16 right-hand sides (solved column by column on the single-vector kernels where the fine
+                level has the four-stage pass - MG_NO_COLUMNS=1: the block SpMM path)
   c3            SA-AMG on anisotropic diffusion (edge weights 16:4:1 x log-normal sigma), general CSR, V(1,1) SPAI
   c1            32^3 cells (CPU-plumbing size; parity case, not a bench line)
 Use --cells N to shrink the grid for quick checks (the JSON then names the reduced workload).

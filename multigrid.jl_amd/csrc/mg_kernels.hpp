@@ -3032,6 +3032,40 @@ __global__ __launch_bounds__(BLK) void band_fill(const int* __restrict__ rowptr,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Block of right-hand sides [n][k] (row-major: a row's k entries side by side) <-> k columns of stride ns (column c at
+// out + c*ns): the column-wise solve of a block (solve_dev_columns) runs the single-vector kernels on each column.
+// 256 rows per workgroup through LDS: both sides coalesced.
+// ------------------------------------------------------------------------------------------------
+template <bool TO_COLUMNS>
+__global__ __launch_bounds__(256) void block_columns_transpose(const double* __restrict__ in, double* __restrict__ out, long long n, int k, long long ns) {
+  extern __shared__ double tile[];          // [k][257]
+  const long long r0 = (long long)blockIdx.x * 256;
+  const int rows = (int)((n - r0) < 256 ? (n - r0) : 256);
+  const int tid = threadIdx.x;
+  if (TO_COLUMNS) {
+    for (int idx = tid; idx < rows * k; idx += 256) {
+      const int row = idx / k, col = idx - row * k;
+      tile[col * 257 + row] = in[r0 * k + idx];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 256 * k; idx += 256) {
+      const int col = idx >> 8, row = idx & 255;
+      if (row < rows) out[(long long)col * ns + r0 + row] = tile[col * 257 + row];
+    }
+  } else {
+    for (int idx = tid; idx < 256 * k; idx += 256) {
+      const int col = idx >> 8, row = idx & 255;
+      if (row < rows) tile[col * 257 + row] = in[(long long)col * ns + r0 + row];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rows * k; idx += 256) {
+      const int row = idx / k, col = idx - row * k;
+      out[r0 * k + idx] = tile[col * 257 + row];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exception rows of a row-class operator (rows whose class was too rare for the dictionary: a few per cent next to
 // sub-domain faces or irregular boundaries): one lane per listed row, straight from the CSR arrays, same epilogues.
 // ------------------------------------------------------------------------------------------------
