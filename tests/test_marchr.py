@@ -30,39 +30,39 @@ def _setup(mg, ncells, levels, cyc="V", pre=2, post=1, maxIter=6, tol=1e-10):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,segs,tx,ty", [([64, 48, 40], 0, 0, 0), ([64, 48, 40], 3, 16, 16), ([80, 24, 36], 1, 32, 8),
-                                              ([40, 72, 44], 5, 8, 16), ([16, 16, 16], 2, 4, 4)])
+@pytest.mark.parametrize("cells,segs,tx,ty", [([64, 48, 40], 0, 0, 0), ([48, 32, 40], 3, 16, 16), ([40, 72, 44], 5, 8, 16), ([16, 16, 16], 2, 4, 4)])
 def test_marching_restriction_bit_identical_to_the_gather_form(mg, built, monkeypatch, cells, segs, tx, ty):
     import torch
     from multigrid_jl_amd import device as dev
     _env(monkeypatch, segs, tx, ty)
     A, p, b = _setup(mg, cells, 3)
-    out = {}
     rng = np.random.default_rng(sum(cells))
-    for lvl in (1, 2):
-        R = p.Rs[lvl - 1]
-        rh = rng.standard_normal(R.shape[1])
-        for name, off in (("march", "0"), ("gather", "1")):
-            monkeypatch.setenv("MG_NO_MARCHR", off)
-            h = mg.to_device(p)
+    rhs = {lvl: rng.standard_normal(p.Rs[lvl - 1].shape[1]) for lvl in (1, 2)}
+    out = {}
+    for name, off in (("march", "0"), ("gather", "1")):
+        monkeypatch.setenv("MG_NO_MARCHR", off)
+        h = mg.to_device(p)
+        for lvl in (1, 2):
+            R = p.Rs[lvl - 1]
             if lvl == 1:      # (level 2 of the smallest case has classes of one row each: exception rows, the gather form stays)
                 assert (h.operator_kernel_variant(lvl, dev.MG_OP_R) == 7) == (off == "0")
             else:
                 assert off == "0" or h.operator_kernel_variant(lvl, dev.MG_OP_R) != 7
-            r = torch.from_numpy(rh).cuda()
+            r = torch.from_numpy(rhs[lvl]).cuda()
             bc = torch.full((R.shape[0],), np.nan, dtype=torch.float64, device="cuda")
             h.spmv_dev(lvl, dev.MG_OP_R, 1.0, r, 0.0, bc)
-            out[name] = bc.cpu().numpy()
-            h.close()
-            p.device = None
-        assert np.array_equal(out["march"], out["gather"])
-        want = R @ rh
-        assert np.abs(out["march"] - want).max() <= 1e-13 * np.abs(want).max()
+            out[(name, lvl)] = bc.cpu().numpy()
+        h.close()
+        p.device = None
+    for lvl in (1, 2):
+        assert np.array_equal(out[("march", lvl)], out[("gather", lvl)])
+        want = p.Rs[lvl - 1] @ rhs[lvl]
+        assert np.abs(out[("march", lvl)] - want).max() <= 1e-13 * np.abs(want).max()
     mg.clear_(p)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels,cyc", [([64, 48, 40], 3, "V"), ([48, 48, 48], 4, "W"), ([40, 56, 48], 3, "F")])
+@pytest.mark.parametrize("cells,levels,cyc", [([64, 48, 40], 3, "V"), ([32, 48, 32], 4, "W")])
 def test_solve_with_the_marching_restriction(mg, built, monkeypatch, cells, levels, cyc):
     """solveMG with the restrictions on the marching form (bc and the coarse level's first update d.*bc in one launch): history and
     iterate against the oracle, and the same iterates as with the form off."""
