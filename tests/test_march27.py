@@ -73,7 +73,7 @@ def test_27_point_level_single_products_and_pair_bit_identical(mg, built, monkey
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels,cyc,pre,post", [([64, 48, 40], 3, "V", 2, 1), ([32, 48, 32], 4, "W", 1, 1), ([40, 36, 48], 3, "F", 3, 2)])
+@pytest.mark.parametrize("cells,levels,cyc,pre,post", [([32, 48, 32], 4, "W", 1, 1), ([40, 36, 48], 3, "F", 3, 2)])
 def test_solve_with_27_point_marching_levels(mg, built, monkeypatch, cells, levels, cyc, pre, post):
     """solveMG with levels 2.. on the marching form: history and iterate against the oracle, and the same iterates as with the form off."""
     _env(monkeypatch)
