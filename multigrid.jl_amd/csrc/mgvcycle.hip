@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>   // declarations only: librccl is dlopen'ed by mg_dist_* (single-GPU users do not depend on it)
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
