@@ -28,7 +28,7 @@ def _setup(mg, ncells, levels, tol=1e-10, maxIter=6, pre=2, post=1, cyc="V", rel
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cells,nt,k1,tiles_x,ty_max", [([33, 25, 15], 768, 3, 0, 0), ([40, 31, 17], 1024, 2, 2, 0), ([23, 23, 23], 512, 4, 1, 9),
-                                                        ([130, 9, 9], 1024, 2, 0, 0), ([36, 44, 10], 1024, 2, 0, 7), ([30, 50, 11], 768, 4, 2, 10)])
+                                                        ([130, 9, 9], 1024, 2, 0, 0), ([30, 50, 11], 768, 4, 2, 10)])
 def test_four_stage_pass_bit_identical_to_the_two_passes(mg, built, monkeypatch, cells, nt, k1, tiles_x, ty_max):
     """t', r' of the four-stage pass = the outputs of the two two-stage passes chained through xn = t + d.*r, bit for bit
     (same products, same order, same epilogue expressions); ||r|| to rounding (another partition of the partial sums);
@@ -97,8 +97,8 @@ def test_four_stage_pass_with_more_workgroups_than_cus(mg, built, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells,levels,cyc,tol", [([33, 25, 15], 2, "V", 1e-10), ([40, 31, 17], 3, "W", 1e-10), ([23, 23, 23], 2, "F", 1e-10),
-                                                  ([33, 25, 15], 2, "V", 3e-3), ([36, 33, 12], 2, "V", 1e-1), ([40, 31, 17], 3, "V", 1e-30)])
+@pytest.mark.parametrize("cells,levels,cyc,tol", [([40, 31, 17], 3, "W", 1e-10), ([23, 23, 23], 2, "F", 1e-30),
+                                                  ([33, 25, 15], 2, "V", 3e-3), ([36, 33, 12], 2, "V", 1e-1)])
 def test_solve_with_the_four_stage_pass(mg, built, monkeypatch, cells, levels, cyc, tol):
     """solveMG through the four-stage pass: residual history and iterate against the oracle (1e-10), and against the same
     solve with MG_NO_MARCH4=1 - iterates bit-identical, also when the stopping test ends the loop before the step count

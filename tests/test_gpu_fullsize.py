@@ -106,8 +106,10 @@ def c5(mg, built):
 
 
 def test_c5_block_residual_history_matches_c_oracle(mg, c5):
-    """One solveMG step on the 16-column block (SpMM kernels, Frobenius criterion, SolveFuncs.jl:30) against the
-    C/OpenMP oracle, which streams A once per column as the reference's ParSpMatVec does."""
+    """One solveMG step on the 16-column block (Frobenius criterion, SolveFuncs.jl:30) against the C/OpenMP oracle, which
+    streams A once per column as the reference's ParSpMatVec does.  Since round 4 the default path solves such a block
+    column by column on the single-vector kernels (solve_dev_columns: this is its full-size check); the block SpMM kernels
+    are compared with it and with the oracle in tests/test_block_columns.py and at the operator level in test_gpu_parity.py."""
     A, p, b = c5
     x = np.zeros_like(b, order="F")
     mg.solveMG(p, b, x)
