@@ -665,7 +665,7 @@ def main():
         out = {
             "metric": "V-cycle DoF-updates/s", "value": round(dof_per_s, 1), "unit": "DoF-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
-            "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",   # (N = 1: the first point of that series)
             "data": "synthetic",
             "config": {"workload": f"{desc} ({n} nodal DoF), {p.levels} levels, nrhs={nrhs}, fp64, "
                                    f"solveMG step = cycle + residual + norm",
