@@ -264,7 +264,9 @@ int mg_four_stage_dev_FP64(mg_hierarchy* h, long long level, const double* b_dev
  * values: the reference's second assignment reads the new Ps[l]), relaxPrecs unchanged, dense coarsest inverse transposed in place.
  * The transposes are computed in HBM (counting sort + per-column order: the stored-order CSR of the transpose), the device formats
  * rebuilt from them; mg_finalize is called.  MG_ERR_UNSUPPORTED, nothing changed, when the coarsest solve is held as sparse
- * factors or a column has more than 4096 entries: hand the transposed operators over with mg_set_operator_* instead. */
+ * factors or a column has more than 4096 entries (both checked before the first operator is replaced): hand the transposed
+ * operators over with mg_set_operator_* instead.  Any OTHER error (MG_ERR_HIP: an allocation or a launch failed half way) leaves
+ * the handle unfinalized - every entry point refuses it - and the hierarchy must be uploaded again. */
 int mg_transpose_hierarchy(mg_hierarchy* h);
 /* shape[3] = rows, columns, stored entries of operator `which` of `level` as the device holds it (after a transpose: of the transposed one). */
 int mg_operator_shape(mg_hierarchy* h, long long level, long long which, long long* shape);
@@ -503,6 +505,36 @@ int mg_dist_comm_count(mg_dist* h, long long* count);
  * itself otherwise, so the tail must outlive the sequencer or be released first. */
 int mg_dist_release_tail(mg_dist* h);
 int mg_dist_destroy(mg_dist* h);
+
+/* ---- sharded cycle with deep ghost layers (one process per GPU; csrc/mg_ghost.inc) -------------------------------------
+ * The communication-avoiding form of the sharded cycle - the reference's `overlap` (getBoxWithOverlap,
+ * src/DomainDecomposition/DDIndices.jl:61-92; box rule l.41-47; fan-out DDParallel.jl:87-105,133-139).  The host builds this
+ * rank's part of the hierarchy on EXTENDED boxes - owned box + g ghost layers towards every neighbour, nested from level to
+ * level (fine = 2 * coarse - 1 nodes) - and uploads it as an ORDINARY mg_hierarchy (mg_create ... mg_finalize): levels
+ * 1..nlevels_sharded are extended-box grid operators, the levels below them are replicated on every rank; the restriction
+ * into the first replicated level has one row per node of that level, non-empty for the nodes this rank owns.  These calls
+ * attach geometry, exchange plans and transport; afterwards mg_cycle_dev_FP64 / mg_solve_dev_FP64 run the sharded cycle on
+ * vectors of the extended fine box (b: owned rows valid on entry; x: owned rows valid on return), with every single-GPU
+ * kernel form (four-stage pass, 27-point marching form, marching restriction, staged prolongation, pipelined stopping
+ * test) and ONE exchange per fused pass: the library tracks on how many ghost layers each level vector is still valid
+ * (a product with A costs one) and refreshes all layers at once where the next operation needs more - on the fine level
+ * right behind the four-stage pass, overlapped with the whole coarse cycle on a side stream.  Norms are sums over the
+ * owned rows of all ranks.  One right-hand side, pointwise smoothers, V / W / F cycles, direct coarsest solve (anything
+ * else: mg_dist_*).  Transport: RCCL (the 128-byte id of mg_dist_unique_id) or the host-staged plug-in (ops 0 and 1). */
+int mg_ghost_attach(mg_hierarchy* h, long long rank, long long world, long long nlevels_sharded, const char* unique_id128);
+int mg_ghost_set_exchange_plugin(mg_hierarchy* h, mg_exchange_fn fn, void* user);
+/* Sharded level `level` (1-based): extended box ext[3] (nodes per dimension, x fastest, 1 for unused dimensions); owned box
+ * [own_lo, own_hi) in extended-box coordinates; gmin = the smallest ghost width over the cut sides of ANY rank (every rank
+ * must take the same exchange decisions); send_idx: extended-box ids (0-based) of owned nodes grouped by destination rank,
+ * recv_idx: extended-box ids of ghost nodes grouped by owner - each peer's part in ascending global id on both sides. */
+int mg_ghost_set_level_INT64(mg_hierarchy* h, long long level, const long long* ext, const long long* own_lo,
+                             const long long* own_hi, long long gmin, long long n_send, const long long* send_idx,
+                             const long long* send_splits, long long n_recv, const long long* recv_idx,
+                             const long long* recv_splits);
+int mg_ghost_finalize(mg_hierarchy* h);
+/* exchanges started / doubles sent by this rank since mg_ghost_attach; ranks of the RCCL communicator (0: plug-in) */
+int mg_ghost_stats(mg_hierarchy* h, long long* exchanges, long long* doubles_sent);
+int mg_ghost_comm_count(mg_hierarchy* h, long long* count);
 
 const char* mg_last_error(void);
 const char* mg_version(void);

@@ -2629,6 +2629,9 @@ struct March4Dev {
   int n_cols, ncls;
   const int* ysh;               // [tiles_y] lines the strips of a tile row are shifted down by (0..K1-1) so that no strip holds
                                 // rows of different classes (the first / last line of the grid ends / starts a strip)
+  // rows whose r^2 counts towards ||r||^2: [oxl, oxh) x [oyl, oyh) x [ozl, ozh) - the whole grid, or the OWNED box of a rank
+  // whose grid is its box extended by ghost layers (mg_ghost_*: the ghost rows are some other rank's to count)
+  int oxl, oxh, oyl, oyh, ozl, ozh;
 };
 constexpr int RM4_G = 4;        // halo of the staged x (stage 1 runs on core + 3 rings)
 #ifndef MG_M4_EXP
@@ -2722,7 +2725,9 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     const bool xin = gx >= 0 && gx < T.n1;
     const int dxo = xx < 3 ? 3 - xx : (xx > T.TX + 2 ? xx - (T.TX + 2) : 0);    // rings between the column and the core
     const int ip0 = (y0 - 3 + K1 * j) * T.n1 + gx;      // in-plane index of row 0; row s: + s*n1
-    unsigned lv = 0u;                                   // per row s: bit s = stage 1 is computed on it, bit 8+s stage 2, 16+s stage 3, 24+s stage 4 (core)
+    unsigned lv = 0u;                                   // per row s: bit s = stage 1 is computed on it, bit 8+s stage 2, 16+s stage 3, 24+s stage 4 (core),
+                                                        // bit 4+s = a core row whose r^2 counts (inside the owned box)
+    const bool xown = gx >= T.oxl && gx < T.oxh;
     unsigned pk[K1];                                    // class of the row per z-class: byte zc = tab[zc][cy][cx]
     const int cxo = xin ? (int)cxG[gx] : 0;
     unsigned pk0 = 0u;                                  // class word of the lane's first live row
@@ -2738,6 +2743,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
       lv |= ((l1 && dist <= 2) ? 1u : 0u) << (8 + s);
       lv |= ((l1 && dist <= 1) ? 1u : 0u) << (16 + s);
       lv |= ((l1 && dist == 0 && !twin) ? 1u : 0u) << (24 + s);
+      lv |= ((l1 && dist == 0 && !twin && xown && gy >= T.oyl && gy < T.oyh) ? 1u : 0u) << (4 + s);
       unsigned v = 0u;
       if (l1) {
         const int rp = (int)cyG[gy] * T.ncx + cxo;
@@ -2891,7 +2897,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
       const bool s3 = MG_M4_EXP != 4 && z - 2 >= 0 && z - 2 < T.nplanes && z >= zs + 1;   // plane z-2 in [zs-1, ze]
       const bool s4 = MG_M4_EXP != 4 && z >= zs + 3;                                      // plane z-3 in [zs, ze)
       const int zc0 = s1 ? __builtin_amdgcn_readfirstlane((int)czL[z]) : zc1;   // (uniform)
-      const bool cnt2 = z - 1 >= zs && z - 1 < ze;      // (uniform) plane z-1 belongs to this segment: its ||r||^2 counts
+      const bool cnt2 = z - 1 >= zs && z - 1 < ze && z - 1 >= T.ozl && z - 1 < T.ozh;   // (uniform) plane z-1 belongs to this segment (and to the owned box): its ||r||^2 counts
       const int xq8 = qz * XS8, xq18 = q1 * XS8;
       const int tW8 = tB + (z & 1) * XS8, tR8 = tB + ((z - 1) & 1) * XS8;
       const int nW8 = nB + ((z - 1) & 1) * XS8, nR8 = nB + (z & 1) * XS8;       // xn(z-1) written, xn(z-2) read
@@ -2932,7 +2938,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
             const double rr = b1[s] - acc;
             const double xv = t1[s] + rd * rr;
             nc[s] = xv;
-            sq += (cnt2 && s2 && ((lv >> (24 + s)) & 1u)) ? rr * rr : 0.0;
+            sq += (cnt2 && s2 && ((lv >> (4 + s)) & 1u)) ? rr * rr : 0.0;
           }
 #pragma unroll
           for (int s = 0; s < K1; ++s)
@@ -3581,6 +3587,33 @@ __global__ __launch_bounds__(BLK) void sumsq_partial(const double* __restrict__ 
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * x[n - 1];
   const double s = block_sum(acc, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// sum of squares over a sub-box [lo, hi) of an x-fastest n1 x n2 x n3 grid vector (the owned box inside a rank's extended box:
+// the norms of the sharded solve count every global row once).  One (y, z) line of the sub-box per wavefront and trip.
+struct BoxDev { int n1, n2, n3, lo[3], hi[3]; };
+__global__ __launch_bounds__(BLK) void sumsq_box_partial(const double* __restrict__ x, BoxDev B, double* __restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * BLK) >> 6;
+  const int ly = B.hi[1] - B.lo[1], lz = B.hi[2] - B.lo[2];
+  double acc = 0.0;
+  for (long long q = wave; q < (long long)ly * lz; q += nwaves) {
+    const int z = (int)(q / ly) + B.lo[2], y = (int)(q % ly) + B.lo[1];
+    const double* line = x + ((long long)z * B.n2 + y) * B.n1;
+    for (int i = B.lo[0] + lane; i < B.hi[0]; i += 64) acc += line[i] * line[i];
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// ghost layers of a sharded level: dst[idx[i]] = src[i] (the received values into their places in the extended box)
+__global__ __launch_bounds__(BLK) void ghost_unpack(const double* __restrict__ src, const int* __restrict__ idx, double* __restrict__ dst, long long n) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) dst[idx[i]] = src[i];
+}
+__global__ __launch_bounds__(BLK) void ghost_pack(const double* __restrict__ src, const int* __restrict__ idx, double* __restrict__ dst, long long n) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
 }
 
 __global__ __launch_bounds__(BLK) void sum_partial(const double* __restrict__ x, long long n,

@@ -33,9 +33,10 @@
 #include "mg_marchr.hpp"
 
 
-// One translation unit, six parts (round 4: the 6 800-line file split by responsibility; the order is the dependency order):
+// One translation unit, eight parts (round 4: the 6 800-line file split by responsibility; the order is the dependency order):
 #include "mg_types.inc"      // Options, DevBuf, Csr, Level, mg_hierarchy
 #include "mg_launch.inc"     // byte accounting, profiling slots, kernel launchers
+#include "mg_ghost.inc"      // ghost-layer form of the sharded cycle: exchange, validity bookkeeping, global norms
 #include "mg_schedule.inc"   // FGMRES relaxation, cycle_level, HIP graphs, solve loop
 #include "mg_krylov.inc"     // PCG / BiCGSTAB / FGMRES and block variants
 #include "mg_formats.inc"    // upload, format builders, scratch

@@ -136,6 +136,12 @@ SIGNATURES = {
     "mg_dist_release_tail": (C.c_int, [_vp]),
     "mg_dist_comm_count": (C.c_int, [_vp, _lp]),
     "mg_dist_destroy": (C.c_int, [_vp]),
+    "mg_ghost_attach": (C.c_int, [_vp, _ll, _ll, _ll, C.c_char_p]),
+    "mg_ghost_set_exchange_plugin": (C.c_int, [_vp, _vp, _vp]),
+    "mg_ghost_set_level_INT64": (C.c_int, [_vp, _ll, _lp, _lp, _lp, _ll, _ll, _lp, _lp, _ll, _lp, _lp]),
+    "mg_ghost_finalize": (C.c_int, [_vp]),
+    "mg_ghost_stats": (C.c_int, [_vp, _lp, _lp]),
+    "mg_ghost_comm_count": (C.c_int, [_vp, _lp]),
     "mg_last_error": (C.c_char_p, []),
     "mg_version": (C.c_char_p, []),
 }

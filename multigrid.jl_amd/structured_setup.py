@@ -117,21 +117,16 @@ def _make_plan(requests_all, src: _LevelGeom, rank: int, nranks: int, recv_split
     return HaloPlan(int(src.own_loc.size), int(n_halo), send_idx.astype(np.int64), send_splits, list(recv_splits))
 
 
-def structured_gmg(global_cells, numDomains, comm, backend, param: MGparam, operator, domain=None, nrhs: int = 1,
-                   replicate_below: int = 300_000, gather_objects=None):
-    """Build this rank's ``DistributedHierarchy`` of a FullWeighting/Galerkin GMG hierarchy without any
-    global matrix.
-
-    ``operator(mesh_loc) -> csr`` generates the fine operator on a sub-mesh (rows next to an artificial
-    cut may be anything: they are discarded).  ``param`` carries levels / smoother / cycle settings as for
-    ``MGsetup``.  ``gather_objects(obj) -> list`` defaults to ``torch.distributed.all_gather_object``.
-    Returns (hierarchy, info) where info holds the level geometry (for building right-hand sides).
-    """
-    DistributedHierarchy.check_supported(param)
+def setup_on_margin_box(global_cells, numDomains, rank, size, param: MGparam, operator, domain=None,
+                        replicate_below: int = 300_000):
+    """The reference's setup steps (``getFWInterp``, ``RT = P*0.5^dim``, ``Ps*AT*Rs``, ``getRelaxPrec``;
+    MGsetup.jl:54-60,76,102) on this rank's box EXTENDED by a margin of 3*2^a nodes (a = number of sharded levels),
+    aligned to 2^a so that all a coarsenings stay nested.  Rows in the outermost layer next to an artificial cut are
+    wrong on every level; every other row equals the global hierarchy's row.  Shared by the two sharded layouts
+    (``structured_gmg``: owned rows + halo columns; ``ghost_dist.ghost_gmg``: extended boxes with ghost layers)."""
     cells = np.asarray(global_cells, dtype=np.int64)
     nd = np.asarray(numDomains, dtype=np.int64)
     dim = cells.size
-    rank, size = comm.rank, comm.size
     if int(np.prod(nd)) != size:
         raise ValueError("numDomains does not match the number of ranks")
     nl = int(param.levels)
@@ -179,6 +174,25 @@ def structured_gmg(global_cells, numDomains, comm, backend, param: MGparam, oper
     geoms = []
     for l in range(a + 1):
         geoms.append(_LevelGeom((cells >> l) + 1, [v >> l for v in lo_e], (cells_loc >> l) + 1, own1d[l], box, nd))
+    return dict(cells=cells, nd=nd, dim=dim, nl=nl, a=a, domain=domain, h=h, nglob=nglob, box=box, own1d=own1d, lo_e=lo_e,
+                hi_e=hi_e, cells_loc=cells_loc, As=As, Ps=Ps, Rs=Rs, ds=ds, geoms=geoms)
+
+
+def structured_gmg(global_cells, numDomains, comm, backend, param: MGparam, operator, domain=None, nrhs: int = 1,
+                   replicate_below: int = 300_000, gather_objects=None):
+    """Build this rank's ``DistributedHierarchy`` of a FullWeighting/Galerkin GMG hierarchy without any
+    global matrix.
+
+    ``operator(mesh_loc) -> csr`` generates the fine operator on a sub-mesh (rows next to an artificial
+    cut may be anything: they are discarded).  ``param`` carries levels / smoother / cycle settings as for
+    ``MGsetup``.  ``gather_objects(obj) -> list`` defaults to ``torch.distributed.all_gather_object``.
+    Returns (hierarchy, info) where info holds the level geometry (for building right-hand sides).
+    """
+    DistributedHierarchy.check_supported(param)
+    S = setup_on_margin_box(global_cells, numDomains, comm.rank, comm.size, param, operator, domain, replicate_below)
+    cells, nd, dim, rank, size, nl, a = S["cells"], S["nd"], S["dim"], comm.rank, comm.size, S["nl"], S["a"]
+    domain, h, nglob, box, own1d = S["domain"], S["h"], S["nglob"], S["box"], S["own1d"]
+    cells_loc, As, Ps, Rs, ds, geoms = S["cells_loc"], S["As"], S["Ps"], S["Rs"], S["ds"], S["geoms"]
     # ---- cut out the owned rows, renumber columns, collect halo requests ---------------------------------
     pieces, requests = [], {}
     for l in range(a):

@@ -1,0 +1,273 @@
+"""Ghost-layer form of the sharded cycle (multigrid.jl_amd/ghost_dist.py, csrc/mg_ghost.inc).
+
+CPU (-m "not gpu"): gloo worlds of 2, 4 and 8 ranks - geometry, local hierarchies on extended boxes, exchange plans and the
+validity rules (results poisoned with NaN beyond the depth the rules claim) through the test-only numpy sequencer
+(tests/ghost_cpu_checker.py) against the oracle's single-process solveMG on the global hierarchy.
+GPU (-m gpu): the library's own schedule (mg_ghost_*) with 1, 2 and 4 processes sharing the one GPU of the box through the
+host-staged transport, and RCCL at a world of one, against the oracle.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+CASES = {
+    # name: (cells, levels, replicate_below, smoother, omega, npre, npost)
+    "3d-a2": ([32, 32, 32], 4, 1000, "Jac", 0.8, 2, 1),
+    "3d-a3": ([32, 32, 64], 5, 1000, "Jac", 0.8, 2, 1),
+    "3d-v11": ([32, 32, 32], 4, 1000, "SPAI", 1.0, 1, 1),
+    "3d-v32": ([32, 32, 32], 4, 1000, "Jac", 0.8, 3, 2),
+    "2d": ([64, 96], 4, 300, "Jac", 0.8, 2, 1),
+}
+
+
+def _param(mg, case, cyc):
+    cells, levels, rb, rel, om, npre, npost = CASES[case]
+    return mg.getMGparam(np.float64, np.int64, levels, 8, 8, 1e-10, rel, om, npre, npost, cyc, "NoMUMPS", 0.5, 0.0), cells, rb
+
+
+def _domains(world, dim, case):
+    from multigrid_jl_amd import distributed as dd
+    if dim == 2:
+        return {1: [1, 1], 2: [1, 2], 4: [2, 2], 8: [2, 4]}[world]
+    return dd.default_domains(world, 3)
+
+
+def _global_reference(mg, case, cyc, tol, maxit):
+    """The oracle's solveMG on the GLOBAL hierarchy (single process)."""
+    from oracle import mg_oracle as orc
+    p, cells, _ = _param(mg, case, cyc)
+    A, mesh = mg.poisson_shifted(cells)
+    mg.MGsetup(A, mesh, p)
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    p.maxOuterIter, p.relativeTol = maxit, tol
+    hist = {}
+    orc.solveMG(p, b, x, False, hist)
+    return A, b, x, np.asarray(hist["resvec"])
+
+
+def _worker(rank, world, port, case, cyc, mode, q, tol, maxit):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import multigrid_jl_amd as mg
+        from multigrid_jl_amd import ghost_dist as gd
+        from multigrid_jl_amd.structured_setup import poisson_operator
+        p, cells, rb = _param(mg, case, cyc)
+        G = gd.ghost_gmg(cells, _domains(world, len(cells), case), rank, world, p, poisson_operator(cells), replicate_below=rb)
+        A, mesh = mg.poisson_shifted(cells)
+        b = mg.seeded_rhs(A)
+        b_ext = b[G.gid_fine]
+        own = G.levels[0].own_mask()
+        extra = {}
+        if mode == "cpu":
+            from ghost_cpu_checker import GhostCpuSequencer
+            S = GhostCpuSequencer(G)
+            it, resvec, x_ext = S.solve(b_ext, np.zeros_like(b_ext), tol, maxit)
+            S2 = GhostCpuSequencer(G)
+            it2, resvec2, x2 = S2.solve(b_ext, np.zeros_like(b_ext), tol, maxit, fused4=False)
+            assert it2 == it and np.allclose(resvec2, resvec, rtol=1e-12, atol=0) and np.allclose(x2[own], x_ext[own], rtol=0, atol=1e-12 * np.abs(x_ext[own]).max())
+            xc = S.cycle(b_ext, x_ext, False)
+            extra["exchanges"] = S.exchanges
+        else:
+            torch.cuda.set_device(0)
+            transport = "plugin" if world > 1 else mode
+            os.environ.update(MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3", MG_MARCH_MIN_WG="0",
+                              MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_WINP_MIN_ROWS="0", MG_MARCH27_MIN_ROWS="0", MG_MARCHR_MIN_ROWS="0")
+            H = gd.NativeGhostHierarchy(G, 0, transport=("rccl" if transport == "rccl" else "plugin"))
+            bt = torch.from_numpy(b_ext).cuda()
+            xt = torch.zeros_like(bt)
+            it, resvec = H.solve(bt, xt, tol, maxit)
+            x_ext = xt.cpu().numpy()
+            x2t = xt.clone()
+            H.cycle(bt, x2t, False)
+            xc = x2t.cpu().numpy()
+            extra["exchanges"], extra["sent"] = H.exchanges()
+            extra["four_stage"] = H.dev.four_stage_form(1)[0]
+            extra["comm_count"] = H.comm_count()
+            H.close()
+        out = [None] * world
+        dist.all_gather_object(out, (G.gid_fine[own], x_ext[own], xc[own], int(it), np.asarray(resvec), extra))
+        if rank == 0:
+            x = np.zeros_like(b)
+            x2 = np.zeros_like(b)
+            for gid, xl, x2l, *_ in out:
+                x[gid] = xl
+                x2[gid] = x2l
+            its = [o[3] for o in out]
+            q.put(("ok", its, [o[4] for o in out], x, x2, [o[5] for o in out]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+
+
+def _run(world, case, cyc, mode, tol=1e-8, maxit=6):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, cyc, mode, q, tol, maxit)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    try:
+        res = q.get(timeout=600)
+    finally:
+        for pr in procs:
+            pr.join(timeout=60)
+            if pr.is_alive():
+                pr.kill()
+    assert res[0] == "ok", res[1]
+    return res[1:]
+
+
+def _check(mg, world, case, cyc, mode, tol=1e-8, maxit=6):
+    from oracle import mg_oracle as orc
+    A, b, x_ref, res_ref = _global_reference(mg, case, cyc, tol, maxit)
+    its, resvecs, x, x2, extra = _run(world, case, cyc, mode, tol, maxit)
+    assert all(i == len(res_ref) - 1 for i in its), (its, len(res_ref) - 1)
+    for rv in resvecs:                      # every rank holds the same, global, residual history
+        assert len(rv) == len(res_ref)
+        assert np.abs(rv - res_ref).max() <= 1e-10 * res_ref[0], np.abs(rv - res_ref).max() / res_ref[0]
+    assert np.abs(x - x_ref).max() <= 1e-10 * np.abs(x_ref).max()
+    # one more cycle from the non-zero iterate through the public cycle entry
+    p, cells, _ = _param(mg, case, cyc)
+    Ag, mesh = mg.poisson_shifted(cells)
+    mg.MGsetup(Ag, mesh, p)
+    xc = orc.recursiveCycle(p, b, x_ref.copy(), 1, None, cyc)
+    assert np.abs(x2 - xc).max() <= 1e-10 * np.abs(xc).max()
+    return extra
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import multigrid_jl_amd as m
+    return m
+
+
+def test_ghost_boxes_are_nested_and_cover(mg):
+    from multigrid_jl_amd import ghost_dist as gd
+    cells, nd, a = [64, 64, 128], [2, 2, 2], 3
+    for rank in range(8):
+        lv = gd.ghost_boxes(cells, nd, gd.default_box_of(rank, nd), a)
+        for l in range(a):
+            n_l = [(c >> l) + 1 for c in cells]
+            for k in range(3):
+                (olo, ohi), (elo, ehi) = lv[l]["own"][k], lv[l]["ext"][k]
+                assert 0 <= elo <= olo <= ohi <= ehi <= n_l[k] - 1
+                if l + 1 < a:
+                    assert (elo, ehi) == (2 * lv[l + 1]["ext"][k][0], 2 * lv[l + 1]["ext"][k][1])     # nested: fine = 2*coarse - 1 nodes
+                    assert lv[l + 1]["own"][k] == (-(-olo // 2), ohi // 2)                               # owner of the coincident node
+        assert lv[a - 1]["gmin"] == gd.G_LAST and lv[0]["gmin"] >= 4 * gd.G_LAST - 3
+    # the owned boxes of a level tile the grid
+    for l in range(a):
+        seen = np.zeros([(c >> l) + 1 for c in cells][::-1], dtype=int)
+        for rank in range(8):
+            o = gd.ghost_boxes(cells, nd, gd.default_box_of(rank, nd), a)[l]["own"]
+            seen[o[2][0]:o[2][1] + 1, o[1][0]:o[1][1] + 1, o[0][0]:o[0][1] + 1] += 1
+        assert (seen == 1).all()
+
+
+def test_local_hierarchy_rows_equal_global(mg):
+    """World of 4 computed in ONE process (no communication needed for the check): every extended-box operator row that is not
+    in the outermost cut layer equals the global hierarchy's row; R into the replicated level holds the owned nodes' rows."""
+    from multigrid_jl_amd import ghost_dist as gd
+    from multigrid_jl_amd.structured_setup import poisson_operator
+    case = "3d-a2"
+    p, cells, rb = _param(mg, case, "V")
+    pg, _, _ = _param(mg, case, "V")
+    A, mesh = mg.poisson_shifted(cells)
+    mg.MGsetup(A, mesh, pg)
+    world, nd = 4, [1, 2, 2]
+    pieces = {}
+
+    class _Captured(Exception):
+        pass
+
+    for rank in range(world):          # two passes: the tail pieces first (what all_gather_object would deliver)
+        def capture(obj, _r=rank):
+            pieces[_r] = obj
+            raise _Captured()
+        try:
+            gd.ghost_gmg(cells, nd, rank, world, p, poisson_operator(cells), replicate_below=rb, gather_objects=capture)
+        except _Captured:
+            pass
+    full = [pieces[r] for r in range(world)]
+    cover = None
+    for rank in range(world):
+        G = gd.ghost_gmg(cells, nd, rank, world, p, poisson_operator(cells), replicate_below=rb, gather_objects=lambda obj: full)
+        a = G.a
+        assert a == 2 and len(G.param.As) == len(pg.As)
+        for l in range(a):
+            L = G.levels[l]
+            nodes = [(c >> l) + 1 for c in cells]
+            ax = [np.arange(L.ext_n[k]) + L.ext_lo[k] for k in range(3)]
+            gid = (ax[0][None, None, :] + nodes[0] * (ax[1][None, :, None] + nodes[1] * ax[2][:, None, None])).reshape(-1)
+            inner = L.depth_mask(L.gmin - 1)
+            Aloc = G.param.As[l]
+            Ag = pg.As[l][gid, :][:, gid]
+            diff = abs(Aloc - Ag).tocsr()
+            rows_bad = np.unique(diff.nonzero()[0][np.abs(diff.data if diff.nnz else np.zeros(0)) > 1e-12 * abs(Ag).max()]) if diff.nnz else np.zeros(0, dtype=int)
+            assert not inner[rows_bad].any(), f"level {l}: a row inside the valid region differs from the global operator"
+            assert np.allclose(G.param.relaxPrecs[l][inner], pg.relaxPrecs[l][gid][inner], rtol=1e-13)
+        # into the replicated level: rows of the owned nodes only, together one copy of the global restriction
+        Rt = G.param.Rs[a - 1]
+        owned_rows = np.diff(Rt.indptr) > 0
+        cover = owned_rows.astype(int) if cover is None else cover + owned_rows.astype(int)
+        for j in range(a, len(pg.As)):
+            assert abs(G.param.As[j] - pg.As[j]).max() <= 1e-12 * abs(pg.As[j]).max()
+    assert (cover == 1).all()
+
+
+@pytest.mark.parametrize("world,case,cyc", [(2, "3d-a2", "V"), (4, "3d-a2", "W"), (8, "3d-a2", "V"), (2, "3d-a3", "V"), (4, "3d-a3", "F"),
+                                            (2, "3d-v11", "V"), (4, "3d-v32", "V"), (2, "2d", "V"), (4, "2d", "W")])
+def test_ghost_form_cpu_vs_oracle(mg, world, case, cyc):
+    extra = _check(mg, world, case, cyc, "cpu")
+    assert all(e["exchanges"] > 0 for e in extra)
+
+
+def test_ghost_form_early_stop_cpu(mg):
+    """The stopping test ends the loop in the middle: same step count and iterate as the oracle."""
+    _check(mg, 2, "3d-a2", "V", "cpu", tol=1e-3, maxit=8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case,cyc", [(1, "3d-a2", "V"), (2, "3d-a2", "V"), (4, "3d-a2", "W"), (2, "3d-a3", "F"), (4, "3d-v32", "V"),
+                                            (2, "3d-v11", "V"), (2, "2d", "V")])
+def test_ghost_form_hip_plugin_vs_oracle(mg, world, case, cyc):
+    """The library's schedule (mg_ghost_*) with `world` processes sharing the GPU through the host-staged transport."""
+    extra = _check(mg, world, case, cyc, "plugin")
+    if world > 1:
+        assert all(e["exchanges"] > 0 for e in extra)
+
+
+@pytest.mark.gpu
+def test_ghost_form_hip_rccl_world1(mg):
+    """RCCL transport at a world of one: ncclCommInitRank from the library's own id, all-reduces on the compute stream."""
+    extra = _check(mg, 1, "3d-a2", "V", "rccl")
+    assert extra[0]["comm_count"] == 1
+
+
+@pytest.mark.gpu
+def test_ghost_form_hip_early_stop(mg):
+    _check(mg, 2, "3d-a2", "V", "plugin", tol=1e-3, maxit=8)
