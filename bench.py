@@ -68,8 +68,14 @@ def parse():
     ap.add_argument("--cpu-cycles", type=int, default=0, help="cycles of the CPU baseline sample (0 = auto)")
     ap.add_argument("--python-sequencer", action="store_true",
                     help="N>1: sequence the sharded cycle from Python (torch.distributed) instead of the native mg_dist_* path")
+    ap.add_argument("--sharded-form", default="ghost", choices=["ghost", "halo"],
+                    help="N>1 / --force-sharded-path: ghost = every rank runs the single-GPU kernels on its box extended by ghost layers "
+                         "(mg_ghost_*, one exchange per fused pass); halo = round 2-4's form (mg_dist_*: owned rows + halo columns, one exchange per product)")
+    ap.add_argument("--ghost-dry", default="", help="R/N: timing aid - this ONE process is rank R of a world of N in the ghost-layer form, alone on "
+                                                    "its GPU (exchanges pack and unpack, nothing travels): one GPU's compute share of the N-GPU step")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; the median is reported")
     ap.add_argument("--no-generic-pass", action="store_true", help="skip the second pass with the streaming formats forced")
+    ap.add_argument("--no-c5-leg", action="store_true", help="skip the 16-right-hand-side leg (BASELINE configs[4]) on the same handle")
     ap.add_argument("--no-divsiggrad", action="store_true", help="skip the variable-coefficient (div sigma grad) leg")
     ap.add_argument("--global-cells", default="", help="single-GPU path: a,b,c cells of a non-cubic grid with h = 1/--cells in every "
                                                        "direction (the GLOBAL grid of an N-GPU weak-scaling run, on one GPU)")
@@ -334,9 +340,11 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MG_HOST_THREADS", str(max(1, (os.cpu_count() or 8) // world)))
-    if world > 1 or args.force_sharded_path:
+    if world > 1 or args.force_sharded_path or args.ghost_dry:
         if args.workload != "c2":
             raise SystemExit("the multi-GPU bench is defined for the c2/c4 Poisson workload")
+        if args.sharded_form == "ghost" and not args.python_sequencer:
+            return bench_ghost(args, mg, torch, dist, cells, K, W, rank, world, local_rank)
         return bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank)
 
     # ---- host setup (CPU, as in the reference) ---------------------------------------------------
@@ -550,6 +558,40 @@ def main():
             roofline["row_classes_L1"] = {"classes": rc[0], "dictionary_entries": rc[1], "implicit_first_column": fl[0],
                                           "relaxPrec_from_dictionary": fl[1]}
 
+    # ---- BASELINE configs[4] (C5) on the SAME handle: 16 right-hand sides (adjustMemoryForNumRHS = mg_set_nrhs), a few steps ----
+    c5_leg = None
+    if args.workload == "c2" and nrhs == 1 and not args.no_c5_leg and cells >= 64:
+        try:
+            k5, K5 = 16, max(2, min(K, 5))
+            b16 = torch.from_numpy(np.ascontiguousarray(mg.seeded_rhs(A, k5))).to(dev)      # row-major [n][16]: the library's block layout
+            x16 = torch.zeros_like(b16)
+            h.set_nrhs(k5)
+            h.solve_dev(b16, x16, 0.0, 2)
+            d5 = []
+            for _ in range(3):
+                x16.zero_()
+                barrier()
+                t0 = time.perf_counter()
+                it5, res5 = h.solve_dev(b16, x16, 0.0, K5)
+                barrier()
+                d5.append(time.perf_counter() - t0)
+            dt5 = sorted(d5)[1]
+            c5_leg = {"workload": f"the same hierarchy, 16 right-hand sides (BASELINE configs[4]): solveMG on the n x 16 block, Frobenius criterion",
+                      "ms_per_step": round(dt5 / K5 * 1e3, 4), "dof_updates_per_s": round(n * k5 * K5 / dt5, 1), "steps": K5,
+                      "timed_regions_ms_per_step": [round(v / K5 * 1e3, 4) for v in d5], "relres_after_steps": float(res5[-1] / res5[0]),
+                      "path": "column by column on the single-vector kernels, columns alternating between two streams (solve_dev_columns)"
+                              if not os.environ.get("MG_NO_COLUMNS") else "block SpMM kernels (MG_NO_COLUMNS=1)"}
+            del b16, x16
+            h.set_nrhs(1)
+            torch.cuda.empty_cache()
+        except Exception as e:
+            c5_leg = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                h.set_nrhs(1)
+            except Exception:
+                pass
+    if c5_leg is not None:
+        roofline["c5_leg"] = c5_leg
     # ---- the same K steps with the STREAMING formats forced for this handle (mg_set_option no_rowclass = 1): what
     # an operator without repeated rows gets (variable coefficients, SA-AMG); its SURVEY 8d fraction ------------------
     if nrhs == 1 and roofline.get("row_classes_L1") and not args.no_generic_pass:
@@ -665,10 +707,10 @@ def main():
         out = {
             "metric": "V-cycle DoF-updates/s", "value": round(dof_per_s, 1), "unit": "DoF-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",   # (N = 1: the first point of that series)
+            "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",   # (one GPU: neither weak nor strong)
             "data": "synthetic",
             "config": {"workload": f"{desc} ({n} nodal DoF), {p.levels} levels, nrhs={nrhs}, fp64, "
-                                   f"solveMG step = cycle + residual + norm",
+                                   f"one step = one cycle + residual + norm of solveMG",
                        "cells": cells, "levels": p.levels, "nrhs": nrhs, "N": n, "nnz": int(A.nnz),
                        "level_rows": [int(a.shape[0]) for a in p.As], "level_nnz": [int(a.nnz) for a in p.As],
                        "parallelism": "1 process per GPU"},
@@ -884,7 +926,13 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
     dt = float(tt.item())
     lb = torch.tensor([Hpy.local_algorithmic_bytes()], device=red_dev, dtype=torch.float64)
     dist.all_reduce(lb, op=dist.ReduceOp.MAX)
-    rccl_ranks = H.comm_count() if hasattr(H, "comm_count") else None
+    rccl_ranks = H.comm_count()
+    kern_table = None
+    if world == 1:      # (one process: a world of one, or a dry rank) where the step goes, launch by launch (instrumented pass: graphs off, events on)
+        prof, moved, tot_ms = profiled_pass(H.dev, b, x, K, torch)
+        kern_table = {f"L{l}:{k}": {"avg_us": round(v[0] / v[1] * 1e3, 2), "launches_per_step": round(v[1] / K, 2), "us_per_step": round(v[0] / K * 1e3, 1)}
+                      for (l, k), v in sorted(prof.items())}
+        kern_table["kernel_ms_per_step"] = round(tot_ms / K, 4) if hasattr(H, "comm_count") else None
     if rank == 0:
         ach = float(lb.item()) / (dt / K) / 1e9
         out = {
@@ -921,6 +969,165 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
         emit(out)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def bench_ghost(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
+    """N > 1 in the GHOST-LAYER form (multigrid.jl_amd/ghost_dist.py, csrc/mg_ghost.inc): every rank runs the single-GPU kernels - the
+    four-stage pass, the 27-point marching form, the marching restriction, the pipelined stopping test - on its box extended by ghost
+    layers, one exchange per fused pass.  Weak (cells^3 per GPU: 512^3 on 8 GPUs = BASELINE configs[3]) or strong (--scaling strong:
+    the same cells^3 grid in N boxes).  --force-sharded-path: a world of one through the same code (and RCCL); --ghost-dry R/N: rank R
+    of N alone on this GPU, nothing travels (one GPU's compute share, redundant ghost rows included)."""
+    from multigrid_jl_amd import distributed as dd, ghost_dist as gd, structured_setup as ss
+    share = os.environ.get("MG_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", local_rank)
+    dry = None
+    if args.ghost_dry:
+        dry = tuple(int(v) for v in args.ghost_dry.split("/"))
+        if world != 1 or len(dry) != 2 or not (0 <= dry[0] < dry[1]):
+            raise SystemExit("--ghost-dry R/N needs ONE process and 0 <= R < N")
+    grank, gworld = (dry if dry else (rank, world))
+    domains = dd.default_domains(gworld, 3)
+    strong = args.scaling == "strong"
+    if strong:
+        gcells = [cells] * 3
+        domain = np.ravel([[0.0, 1.0]] * 3)
+    else:
+        gcells = [cells * d for d in domains]
+        domain = np.ravel([[0.0, float(d)] for d in domains])      # h = 1/cells in every direction, as on one GPU
+    levels = args.levels or levels_for(min(gcells))
+    p = mg.getMGparam(np.float64, np.int64, levels, os.cpu_count() or 8, K, 0.0, "Jac", 0.8, 2, 1, "V",
+                      "NoMUMPS", 0.5, 0.0, "FullWeighting")
+    t0 = time.perf_counter()
+    G = gd.ghost_gmg(gcells, domains, grank, gworld, p, ss.poisson_operator(gcells, domain), domain=domain, nrhs=1, dry_tail=bool(dry))
+    t_host = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    transport = "dry" if dry else ("plugin" if share else "rccl")
+    H = gd.NativeGhostHierarchy(G, local_rank, transport=transport)
+    t_up = time.perf_counter() - t0
+    n = int(np.prod(np.asarray(gcells) + 1))
+    b_ext, ssq = gd.local_rhs(G)
+    red_dev = torch.device("cpu") if share else dev
+    tot = torch.tensor([ssq], device=red_dev, dtype=torch.float64)
+    if dist is not None and not dry:
+        dist.all_reduce(tot)
+    b = torch.from_numpy(np.ascontiguousarray(b_ext / float(tot.item()) ** 0.5)).to(dev)
+    x = torch.zeros_like(b)
+    L0 = G.levels[0]
+    n_own = int(np.prod([L0.own_hi[k] - L0.own_lo[k] for k in range(3)]))
+    ok4, geo4 = H.dev.four_stage_form(1)
+    log(f"[rank {grank}/{gworld}] global {gcells} cells over boxes {domains}: extended box {L0.ext_n} = {L0.n} rows for {n_own} owned "
+        f"({L0.n / n_own:.3f} x), {G.a} sharded levels (ghost layers {[L.gmin for L in G.levels]}) + replicated levels from {G.n_tail} rows; "
+        f"four-stage pass {'on' if ok4 else 'OFF'}; host setup {t_host:.1f}s, upload {t_up:.1f}s, HBM {H.dev.device_bytes() / 1e9:.2f} GB")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None and not dry:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < args.prewarm and (dist is None or dry or world == 1):
+        H.dev.time_op(1, mg.device.MG_K_RESIDUAL, 50)
+    for _ in range(10 if (args.prewarm > 0 and world > 1) else 0):      # fixed count: every rank enters the same exchanges
+        H.cycle(b, x, False)
+    if W > 0:
+        x.zero_()
+        H.solve(b, x, 0.0, W)
+    region = []
+    e0 = H.exchanges()
+    for _ in range(max(1, args.repeats)):
+        x.zero_()
+        barrier()
+        t0 = time.perf_counter()
+        iters, resvec = H.solve(b, x, 0.0, K)
+        barrier()
+        region.append(time.perf_counter() - t0)
+        assert iters == K
+    e1 = H.exchanges()
+    reg = torch.tensor(region, device=red_dev, dtype=torch.float64)
+    if dist is not None and not dry:
+        dist.all_reduce(reg, op=dist.ReduceOp.MAX)      # every region: the slowest rank
+    region = [float(v) for v in reg.cpu().numpy()]
+    dt = float(np.median(region))
+    nreg = max(1, args.repeats)
+    per_step_exch = (e1[0] - e0[0]) / (nreg * K)
+    per_step_sent = (e1[1] - e0[1]) * 8.0 / (nreg * K)
+    rccl_ranks = H.comm_count()
+    kern_table = None
+    if world == 1:      # (one process: a world of one, or a dry rank) where the step goes, launch by launch (instrumented pass: graphs off, events on)
+        prof, moved, tot_ms = profiled_pass(H.dev, b, x, K, torch)
+        kern_table = {f"L{l}:{k}": {"avg_us": round(v[0] / v[1] * 1e3, 2), "launches_per_step": round(v[1] / K, 2), "us_per_step": round(v[0] / K * 1e3, 1)}
+                      for (l, k), v in sorted(prof.items())}
+        kern_table["kernel_ms_per_step"] = round(tot_ms / K, 4)
+    rows_ext = torch.tensor([float(sum(L.n for L in G.levels)), float(L0.n) / n_own], device=red_dev, dtype=torch.float64)
+    if dist is not None and not dry:
+        dist.all_reduce(rows_ext, op=dist.ReduceOp.MAX)
+    # the same box through the plain single-GPU path, same process, same GPU (a world of one only: the extended box IS the grid)
+    same_job = None
+    if world == 1 and not dry and not os.environ.get("MG_BENCH_NO_SAME_JOB"):
+        try:
+            H.close()
+            A1, mesh1 = mg.poisson_shifted(gcells, [v for g in gcells for v in (0.0, g / float(cells))])
+            p1 = mg.getMGparam(np.float64, np.int64, levels, os.cpu_count() or 8, K, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0, "FullWeighting")
+            mg.MGsetup(A1, mesh1, p1, 1)
+            h1 = mg.to_device(p1, device_id=local_rank)
+            b1 = torch.from_numpy(np.ascontiguousarray(mg.seeded_rhs(A1, 1))).to(dev)
+            x1 = torch.zeros_like(b1)
+            if W > 0:
+                h1.solve_dev(b1, x1, 0.0, W)
+            r1 = []
+            for _ in range(nreg):
+                x1.zero_()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                it1, rv1 = h1.solve_dev(b1, x1, 0.0, K)
+                torch.cuda.synchronize()
+                r1.append(time.perf_counter() - t0)
+            d1 = float(np.median(r1))
+            same_job = {"single_gpu_ms_per_step": round(d1 / K * 1e3, 4), "sharded_over_single": round(dt / d1, 4),
+                        "resvec_rel_diff": float(np.abs(np.asarray(rv1) - np.asarray(resvec)).max() / rv1[0]),
+                        "note": "the same grid through the plain single-GPU path (mg_create ... mg_solve_dev_FP64), same process, same GPU, right after the sharded run"}
+        except Exception as e:
+            same_job = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        out = {
+            "metric": "V-cycle DoF-updates/s", "value": round((n_own if dry else n) * K / dt, 1), "unit": "DoF-updates/s",
+            "n_gpus": 1 if dry else world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
+            "timed_regions_ms_per_step": [round(v / K * 1e3, 4) for v in region],
+            "higher_is_better": True, "scaling": (None if (world == 1) else args.scaling), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3D 7-pt Poisson, " + (f"{cells}^3 cells" if strong else f"{cells}^3 cells per GPU") + f" = {gcells} cells global ({n} nodal DoF), "
+                                   f"GMG V(2,1) damped-Jacobi w=0.8, {levels} levels, nrhs=1, fp64; one step = one cycle + residual + norm of solveMG",
+                       "cells_per_gpu": cells, "global_cells": gcells, "levels": levels, "nrhs": 1, "N": n,
+                       "parallelism": f"DomainDecomposition boxes {domains} with ghost layers (the reference's overlap, DDIndices.jl:61-92): {G.a} sharded levels on "
+                                      f"extended boxes, ghost widths {[L.gmin for L in G.levels]}, replicated levels from {G.n_tail} rows; every rank runs the "
+                                      f"single-GPU kernels (four-stage pass {'on' if ok4 else 'off'}), one exchange per fused pass on a side stream, one "
+                                      f"all-reduce into the first replicated level, norms over owned rows; sharded host setup"},
+            "relres_after_steps": float(resvec[-1] / resvec[0]),
+            "sharded_form": "ghost layers (mg_ghost_*)",
+            "transport": {"dry": "none (dry run: ONE rank of the world alone on its GPU - timing of its compute share only, numbers meaningless)",
+                          "plugin": "plug-in (host-staged, ranks share one GPU)", "rccl": "RCCL"}[transport],
+            "rccl_comm_ranks": rccl_ranks,
+            "ghost": {"extended_over_owned_rows_fine": round(float(rows_ext[1].item()), 4), "exchanges_per_step": round(per_step_exch, 3),
+                      "bytes_sent_per_step_per_rank": round(per_step_sent, 1), "fine_extended_box": [int(v) for v in L0.ext_n],
+                      "four_stage_geometry": geo4},
+            "setup_s": {"host": round(t_host, 2), "upload": round(t_up, 2)},
+            "roofline": {"bound": "hbm", "kernel": "per-kernel fractions are reported by the N = 1 line (the same kernels run here)", "achieved": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+            "cpu_baseline": None,
+        }
+        if dry:
+            out["dry_run"] = {"rank": grank, "world": gworld, "owned_rows": n_own,
+                              "note": "value = owned rows x steps / time of THIS rank alone; x world = the N-GPU rate with free communication"}
+        if kern_table is not None:
+            out["kernels"] = kern_table
+        if same_job is not None:
+            out["same_job_single_gpu"] = same_job
+        if os.environ.get("MG_BENCH_CHILD") != "1" and not dry:
+            attach_strong_reference(out, STRONG_REF)
+        emit(out)
+    if dist is not None and not dry:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def bench_distributed(args, mg, torch, dist, A, mesh, p, b_host, cells, nrhs, K, W, rank, world, local_rank,

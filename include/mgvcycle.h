@@ -62,7 +62,8 @@ typedef struct mg_hierarchy mg_hierarchy;
 #define MG_K_SMOOTH_RESIDUAL 9 /* t = x + d.*(b - A*x) and r = b - A*t in one pass (MGcycle.jl:129-131 + 58-60 / SolveFuncs.jl:26-27) */
 #define MG_K_SMOOTH_RESIDUAL_NORM 10 /* the same pass in the solve loop: last post-smoothing sweep + the stopping test's residual: ||r||^2 and t + d.*r out (SolveFuncs.jl:26-30); profile slot only */
 #define MG_K_FOUR_STAGE 11 /* solve loop, fine level: the last post-smoothing sweep + stopping-test residual of step k AND the second pre-smoothing sweep + residual of step k+1 in one pass (SolveFuncs.jl:24-37 around MGcycle.jl:26-31,54-60): x, b in; t', r' and ||r||^2 out; profile slot only */
-#define MG_K_COUNT 12
+#define MG_K_GHOST 12 /* ghost-layer form of the sharded cycle: pack + (host-staged / dry transport) unpack kernels of one exchange on the compute stream; profile slot only */
+#define MG_K_COUNT 13
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 
@@ -532,6 +533,9 @@ int mg_ghost_set_level_INT64(mg_hierarchy* h, long long level, const long long* 
                              const long long* send_splits, long long n_recv, const long long* recv_idx,
                              const long long* recv_splits);
 int mg_ghost_finalize(mg_hierarchy* h);
+/* Timing aid: rank R of a world of N alone on its GPU - exchanges run their pack / unpack kernels, nothing travels, sums stay
+ * local (before mg_ghost_finalize; not with RCCL).  Results are meaningless, the step time is one GPU's compute share. */
+int mg_ghost_set_dry(mg_hierarchy* h, long long on);
 /* exchanges started / doubles sent by this rank since mg_ghost_attach; ranks of the RCCL communicator (0: plug-in) */
 int mg_ghost_stats(mg_hierarchy* h, long long* exchanges, long long* doubles_sent);
 int mg_ghost_comm_count(mg_hierarchy* h, long long* count);

@@ -24,9 +24,9 @@ LIB_PATH = os.environ.get("MGVCYCLE_LIB") or os.path.join(_HERE, "csrc", "libmgv
 
 MG_OP_A, MG_OP_P, MG_OP_R = 0, 1, 2
 (MG_K_SPMV, MG_K_RESIDUAL, MG_K_SMOOTH, MG_K_RESTRICT, MG_K_PROLONG, MG_K_DSCALE, MG_K_COARSE,
- MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_SMOOTH_RESIDUAL_NORM, MG_K_FOUR_STAGE, MG_K_COUNT) = range(13)
+ MG_K_NORM, MG_K_SMOOTH_PROLONG, MG_K_SMOOTH_RESIDUAL, MG_K_SMOOTH_RESIDUAL_NORM, MG_K_FOUR_STAGE, MG_K_GHOST, MG_K_COUNT) = range(14)
 KERNEL_NAMES = ["spmv", "residual", "smooth", "restrict", "prolong", "dscale", "coarse", "norm", "smooth+prolong", "smooth+residual",
-                "smooth+residual+norm", "four-stage"]
+                "smooth+residual+norm", "four-stage", "ghost-exchange"]
 
 _ll = C.c_longlong
 _dp = C.POINTER(C.c_double)
@@ -140,6 +140,7 @@ SIGNATURES = {
     "mg_ghost_set_exchange_plugin": (C.c_int, [_vp, _vp, _vp]),
     "mg_ghost_set_level_INT64": (C.c_int, [_vp, _ll, _lp, _lp, _lp, _ll, _ll, _lp, _lp, _ll, _lp, _lp]),
     "mg_ghost_finalize": (C.c_int, [_vp]),
+    "mg_ghost_set_dry": (C.c_int, [_vp, _ll]),
     "mg_ghost_stats": (C.c_int, [_vp, _lp, _lp]),
     "mg_ghost_comm_count": (C.c_int, [_vp, _lp]),
     "mg_last_error": (C.c_char_p, []),

@@ -179,7 +179,7 @@ class GhostSetup:
 
 
 def ghost_gmg(global_cells, numDomains, rank: int, size: int, param: MGparam, operator, domain=None, nrhs: int = 1,
-              replicate_below: int = 300_000, gather_objects=None, g_last: int = G_LAST) -> GhostSetup:
+              replicate_below: int = 300_000, gather_objects=None, g_last: int = G_LAST, dry_tail: bool = False) -> GhostSetup:
     """Build this rank's part of a FullWeighting / Galerkin GMG hierarchy in the ghost-layer form (no global matrix).
 
     ``operator(mesh_loc) -> csr`` generates the fine operator on a sub-mesh (rows next to an artificial cut may be
@@ -237,7 +237,9 @@ def ghost_gmg(global_cells, numDomains, rank: int, size: int, param: MGparam, op
     # ---- the replicated levels: assemble the first one from everybody's rows, plain MGsetup below ---------------------
     T_rows = sp.csr_matrix(As[a][gt.own_loc, :])
     tail_piece = (gt.own_gid, T_rows.indptr, gt.gid[T_rows.indices], T_rows.data)
-    if size > 1:
+    if dry_tail:
+        gathered = None
+    elif size > 1:
         if gather_objects is None:
             import torch.distributed as dist
 
@@ -248,18 +250,31 @@ def ghost_gmg(global_cells, numDomains, rank: int, size: int, param: MGparam, op
         gathered = gather_objects(tail_piece)
     else:
         gathered = [tail_piece]
-    rows_i, cols_i, vals_i = [], [], []
-    for gids, indptr, gcols, data in gathered:
-        rows_i.append(np.repeat(gids, np.diff(indptr)))
-        cols_i.append(gcols)
-        vals_i.append(data)
-    A_tail = sp.csr_matrix((np.concatenate(vals_i), (np.concatenate(rows_i), np.concatenate(cols_i))), shape=(nt, nt))
-    A_tail.sort_indices()
-    p_tail = getMGparam(np.float64, np.int64, nl - a, param.numCores, param.maxOuterIter, param.relativeTol,
-                        param.relaxType, param.relaxParam, lambda level, _s=a: param.relaxPre(level + _s),
-                        lambda level, _s=a: param.relaxPost(level + _s), param.cycleType, param.coarseSolveType,
-                        param.strongConnParam, param.FilteringParam, param.transferOperatorType)
-    MGsetup(A_tail, getRegularMesh(S["domain"], cells >> a), p_tail, nrhs)
+    if dry_tail:
+        # TIMING AID (one rank of a larger world alone on its GPU, NativeGhostHierarchy(transport="dry")): the other ranks' rows of
+        # the first replicated level do not exist here; a hierarchy of the same sizes and stencils stands in - the operator
+        # re-discretised one level above and coarsened once (27-point Galerkin levels, as the real tail has)
+        from .distributed import _sub_hierarchy
+        mesh_up = getRegularMesh(S["domain"], cells >> (a - 1))
+        p_up = getMGparam(np.float64, np.int64, nl - a + 1, param.numCores, param.maxOuterIter, param.relativeTol,
+                          param.relaxType, param.relaxParam, lambda level, _s=a - 1: param.relaxPre(level + _s),
+                          lambda level, _s=a - 1: param.relaxPost(level + _s), param.cycleType, param.coarseSolveType,
+                          param.strongConnParam, param.FilteringParam, param.transferOperatorType)
+        MGsetup(sp.csr_matrix(operator(mesh_up)), mesh_up, p_up, nrhs)
+        p_tail = _sub_hierarchy(p_up, 1)
+    else:
+        rows_i, cols_i, vals_i = [], [], []
+        for gids, indptr, gcols, data in gathered:
+            rows_i.append(np.repeat(gids, np.diff(indptr)))
+            cols_i.append(gcols)
+            vals_i.append(data)
+        A_tail = sp.csr_matrix((np.concatenate(vals_i), (np.concatenate(rows_i), np.concatenate(cols_i))), shape=(nt, nt))
+        A_tail.sort_indices()
+        p_tail = getMGparam(np.float64, np.int64, nl - a, param.numCores, param.maxOuterIter, param.relativeTol,
+                            param.relaxType, param.relaxParam, lambda level, _s=a: param.relaxPre(level + _s),
+                            lambda level, _s=a: param.relaxPost(level + _s), param.cycleType, param.coarseSolveType,
+                            param.strongConnParam, param.FilteringParam, param.transferOperatorType)
+        MGsetup(A_tail, getRegularMesh(S["domain"], cells >> a), p_tail, nrhs)
     # ---- the local hierarchy as one MGparam (levels 0..a-1 on extended boxes, a.. replicated) ---------------------------
     p = getMGparam(np.float64, np.int64, a + len(p_tail.As), param.numCores, param.maxOuterIter, param.relativeTol,
                    param.relaxType, param.relaxParam, param.relaxPre, param.relaxPost, param.cycleType,
@@ -336,7 +351,8 @@ class NativeGhostHierarchy:
 
     transport="rccl": the library's own RCCL communicator (unique id from rank 0, broadcast with ``torch.distributed``);
     transport="plugin": every exchange goes through ``torch.distributed`` on host buffers (tests, ranks sharing one GPU);
-    a world of one rank needs neither."""
+    transport="dry": timing aid - one rank of a larger world alone on its GPU, nothing travels (``ghost_gmg(dry_tail=True)``);
+    a world of one rank needs none of them."""
 
     def __init__(self, G: GhostSetup, device_id: int = 0, transport: str = "rccl", group=None, options=None):
         import ctypes as C
@@ -360,7 +376,9 @@ class NativeGhostHierarchy:
             uid = C.create_string_buffer(box[0], 128)
         D._check(lib, lib.mg_ghost_attach(h, rank, size, G.a, uid), "mg_ghost_attach")
         self._cb = None
-        if uid is None and size > 1:
+        if transport == "dry":
+            D._check(lib, lib.mg_ghost_set_dry(h, 1), "mg_ghost_set_dry")
+        elif uid is None and size > 1:
             self._install_plugin()
         i64 = lambda v: np.ascontiguousarray(v, dtype=np.int64)
         for l, L in enumerate(G.levels, start=1):

@@ -271,3 +271,77 @@ def test_ghost_form_hip_rccl_world1(mg):
 @pytest.mark.gpu
 def test_ghost_form_hip_early_stop(mg):
     _check(mg, 2, "3d-a2", "V", "plugin", tol=1e-3, maxit=8)
+
+
+def _worker_c4box(rank, world, port, cells, levels, q, steps):
+    """One rank of the C4-sized run in the ghost-layer form: its 257^3 box + ghost layers, plug-in transport."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["MG_HOST_THREADS"] = str(max(1, (os.cpu_count() or 2) // world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        import multigrid_jl_amd as mg
+        from multigrid_jl_amd import distributed as dd, ghost_dist as gd, structured_setup as ss
+        p = mg.getMGparam(np.float64, np.int64, levels, 8, steps, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+        G = gd.ghost_gmg(cells, dd.default_domains(world, 3), rank, world, p, ss.poisson_operator(cells))
+        b_ext, ss2 = gd.local_rhs(G)
+        tot = torch.tensor([ss2], dtype=torch.float64)
+        dist.all_reduce(tot)
+        H = gd.NativeGhostHierarchy(G, 0, transport="plugin")
+        bt = torch.from_numpy(b_ext / float(tot.item()) ** 0.5).cuda()
+        xt = torch.zeros_like(bt)
+        e0 = H.exchanges()
+        it, resvec = H.solve(bt, xt, 0.0, steps)
+        e1 = H.exchanges()
+        own = torch.from_numpy(G.levels[0].own_mask()).cuda()
+        xo = xt[own]
+        sums = torch.tensor([float(xo.sum().item()), float((xo * xo).sum().item())], dtype=torch.float64)
+        dist.all_reduce(sums)
+        info = dict(four_stage=H.dev.four_stage_form(1)[0], a=G.a, gmin=[L.gmin for L in G.levels], ext=[L.ext_n for L in G.levels],
+                    exchanges=e1[0] - e0[0], sent=e1[1] - e0[1], sweep_form=[H.dev.sweep_residual_form(l + 1)[0] for l in range(G.a)])
+        if rank == 0:
+            q.put(("ok", it, resvec, sums.numpy(), info))
+        dist.barrier()
+        H.close()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+@pytest.mark.gpu
+def test_c4_per_gpu_box_size_two_ranks_ghost_form_vs_c_oracle(mg):
+    """BASELINE.json configs[3] (512^3 cells over 8 GPUs) puts a 257^3-node box on every GPU.  Two such boxes - 256 x 256 x 512
+    cells, 33.9 M rows - on two ranks sharing this box's one GPU in the GHOST-LAYER form (host-staged transport): the fine level of
+    each rank runs the four-stage pass on 257 x 257 x 269 nodes, level 2 the 27-point marching form, the restriction the marching
+    form; four solveMG steps (from-zero step, two four-stage steps, last step) against the C/OpenMP oracle on the global hierarchy."""
+    from oracle import c_oracle
+    cells, levels, world, steps = [256, 256, 512], 6, 2, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c4box, args=(r, world, port, cells, levels, q, steps)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    A, mesh = mg.poisson_shifted(cells)                      # (the checker's hierarchy, while the ranks set up theirs)
+    p = mg.getMGparam(np.float64, np.int64, levels, 8, steps, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p, 1)
+    b = mg.seeded_rhs(A)
+    co = c_oracle.COracle(p, 1)
+    xo = np.zeros_like(b)
+    ito, rv = co.solveMG(b, xo, 0.0, steps, c_oracle.max_threads())
+    res = q.get(timeout=900)
+    for pr in procs:
+        pr.join(timeout=300)
+    assert res[0] == "ok", res[1]
+    _, it, resvec, sums, info = res
+    print("ghost form, C4 box size:", info)
+    assert info["four_stage"] == 1 and info["a"] == 3 and info["gmin"][0] >= 9, info
+    assert info["sweep_form"][0] == 3 and info["sweep_form"][1] == 5, info      # 2-D tile form on the fine level, 27-point marching form on level 2
+    assert it == ito == steps
+    assert np.abs(np.asarray(resvec) - rv).max() / rv[0] < 1e-10
+    assert abs(sums[0] - xo.sum()) <= 1e-9 * np.abs(xo).sum() and abs(sums[1] - xo @ xo) <= 1e-10 * (xo @ xo)
+    # communication the schedule issued: at most one fine-level exchange per step + two per coarser sharded level and step (+ b once)
+    assert info["exchanges"] <= steps * (1 + 2 * (info["a"] - 1)) + 1, info

@@ -33,6 +33,29 @@ def test_c2_residual_history_matches_c_oracle(mg, c2):
     assert abs(np.linalg.norm(b - A @ x) - p.resvec[-1]) <= 1e-10 * p.resvec[0]
 
 
+def test_c2_early_stop_at_full_size_matches_c_oracle(mg, c2):
+    """solveMG with tol = 1e-3, maxIter = 6 at 256^3: the default loop (four-stage pass, pipelined stopping test, three rotating
+    buffers) stops in the middle - the step behind the stopping test was speculative, the iterate is re-created from the input of
+    the last verified pass (finish_from_keep).  Step count, residual history and iterate against the C/OpenMP oracle."""
+    A, p, b = c2
+    keep = (p.maxOuterIter, p.relativeTol)
+    try:
+        p.maxOuterIter, p.relativeTol = 6, 1e-3
+        x = np.zeros_like(b)
+        mg.solveMG(p, b, x)
+        resvec = np.array(p.resvec)
+    finally:
+        p.maxOuterIter, p.relativeTol = keep
+    assert p.device.four_stage_form(1)[0] == 1
+    co = c_oracle.COracle(p, 1)
+    xo = np.zeros_like(b)
+    it, rv = co.solveMG(b, xo, 1e-3, 6, c_oracle.max_threads())
+    assert 2 <= it < 6 and len(resvec) == it + 1, (it, len(resvec))          # stopped early, and at the same step
+    assert np.abs(rv - resvec).max() / rv[0] < 1e-10
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    assert abs(np.linalg.norm(b - A @ x) - resvec[-1]) <= 1e-10 * resvec[0]
+
+
 def test_c2_checksums(mg, c2):
     A, p, b = c2
     ones = np.ones(A.shape[0])
@@ -96,13 +119,19 @@ def test_c2_size_variable_coefficients_band_form_matches_c_oracle(mg, built):
 
 # ---- C5: block multigrid, 16 right-hand sides, 256^3 cells (BASELINE.json configs[4]) -----------------------------
 @pytest.fixture(scope="module")
-def c5(mg, built):
-    A, mesh = mg.poisson_shifted([256, 256, 256])
-    p = mg.getMGparam(np.float64, np.int64, 6, 8, 1, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
-    mg.MGsetup(A, mesh, p, 16)
+def c5(mg, c2):
+    """C2's hierarchy (the same handle: adjustMemoryForNumRHS / mg_set_nrhs re-sizes the scratch) with 16 right-hand sides, and the
+    C/OpenMP oracle's one step on the block (computed once for both tests below)."""
+    A, p, _ = c2
     b = np.asfortranarray(mg.seeded_rhs(A, 16))
-    yield A, p, b
-    mg.clear_(p)
+    keep = p.maxOuterIter
+    p.maxOuterIter = 1
+    co = c_oracle.COracle(p, 16)
+    xo = np.zeros_like(b, order="F")
+    it, rv = co.solveMG(b, xo, 0.0, 1, c_oracle.max_threads())
+    assert it == 1
+    yield A, p, b, xo, rv
+    p.maxOuterIter = keep
 
 
 def test_c5_block_residual_history_matches_c_oracle(mg, c5):
@@ -110,13 +139,10 @@ def test_c5_block_residual_history_matches_c_oracle(mg, c5):
     streams A once per column as the reference's ParSpMatVec does.  Since round 4 the default path solves such a block
     column by column on the single-vector kernels (solve_dev_columns: this is its full-size check); the block SpMM kernels
     are compared with it and with the oracle in tests/test_block_columns.py and at the operator level in test_gpu_parity.py."""
-    A, p, b = c5
+    A, p, b, xo, rv = c5
     x = np.zeros_like(b, order="F")
     mg.solveMG(p, b, x)
-    co = c_oracle.COracle(p, 16)
-    xo = np.zeros_like(b, order="F")
-    it, rv = co.solveMG(b, xo, 0.0, 1, c_oracle.max_threads())
-    assert it == 1 and np.abs(rv - p.resvec).max() / rv[0] < 1e-10
+    assert np.abs(rv - p.resvec).max() / rv[0] < 1e-10
     assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
     # every column is the single-vector cycle of that column: the block path couples nothing (x0 = 0, V-cycle)
     p1 = mg.getMGparam(np.float64, np.int64, 6, 8, 1, 0.0, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
@@ -130,6 +156,27 @@ def test_c5_block_residual_history_matches_c_oracle(mg, c5):
         p1.device = None
     # the reported Frobenius residual is the true one
     assert abs(np.linalg.norm(b - A @ x) - p.resvec[-1]) <= 1e-10 * p.resvec[0]
+
+
+def test_c5_block_spmm_kernels_at_full_size_match_c_oracle(mg, c5):
+    """The same step with the column-wise path switched off (mg_set_option no_columns): the block kernels the north_star names -
+    csr_rowclass_lane_spmm2 with two columns per lane on every level, ||R||_F and x + d.*r fused into the residual pass - at
+    256^3 x 16 against the C/OpenMP oracle."""
+    from multigrid_jl_amd import device as D
+    A, p, b, xo, rv = c5
+    x = np.zeros_like(b, order="F")
+    mg.solveMG(p, b, x)                      # (makes sure the handle exists and is sized for 16 columns)
+    h = p.device
+    try:
+        D._check(h.lib, h.lib.mg_set_option(h.handle, b"no_columns", 1.0), "mg_set_option")
+        D._check(h.lib, h.lib.mg_finalize(h.handle), "mg_finalize")
+        x[...] = 0.0
+        mg.solveMG(p, b, x)
+        assert np.abs(rv - p.resvec).max() / rv[0] < 1e-10
+        assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    finally:
+        D._check(h.lib, h.lib.mg_set_option(h.handle, b"no_columns", 0.0), "mg_set_option")
+        D._check(h.lib, h.lib.mg_finalize(h.handle), "mg_finalize")
 
 
 # ---- C3: SA-AMG on anisotropic diffusion, general CSR (BASELINE.json configs[2]) at 128^3 cells ----------------------
