@@ -31,6 +31,7 @@
 #include "mg_kernels.hpp"
 #include "mg_march27.hpp"
 #include "mg_marchr.hpp"
+#include "mg_small.hpp"
 
 
 // One translation unit, eight parts (round 4: the 6 800-line file split by responsibility; the order is the dependency order):

@@ -631,7 +631,7 @@ class DeviceHierarchy:
 
     def operator_kernel_variant(self, level: int, which: int) -> int:
         """-1 streaming formats, 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv, 2 csr_rowclass_tile_spmv, 3 csr_rowclass_march_spmv,
-        4 csr_rowclass_lane_spmv, 7 csr_rowclass_marchr_spmv (marching restriction)."""
+        4 csr_rowclass_lane_spmv, 7 csr_rowclass_marchr_spmv (marching restriction), 8 the small-grid-level kernels (mg_small.hpp)."""
         return self.operator_kernel_info(level, which)[0]
 
     def operator_kernel_info(self, level: int, which: int):

@@ -13,6 +13,7 @@ RES_TOL = 1e-10
 
 def _env(monkeypatch):
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")

@@ -57,7 +57,7 @@ def _problem(kind, nrhs, cyc):
 
 def _worker(rank, world, port, kind, nrhs, cyc, use_hip, q, backend="gloo", native=None, box=False):
     if box and box != "plain" and use_hip:       # let the small local operators of the test take the row-class / staged kernels
-        os.environ.update(MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3",
+        os.environ.update(MG_NO_SMALL="1", MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3",
                           MG_MARCH_MIN_WG="0", MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_MARCH_MAX_LEN="64",
                           MG_WINP_MIN_ROWS="0")
     try:
@@ -223,6 +223,7 @@ def test_hip_distributed_rowclass_with_exception_rows(built, world, monkeypatch)
     [interior | boundary] order, halo columns appended): with the size thresholds lifted they are stored as row classes
     plus EXCEPTION rows (csr_rows_spmv) and the sharded solve must still match the oracle."""
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.2")
     monkeypatch.setenv("MG_ROWCLASS_KEEP_SINGLETONS", "0")

@@ -92,7 +92,7 @@ def _worker(rank, world, port, case, cyc, mode, q, tol, maxit):
         else:
             torch.cuda.set_device(0)
             transport = "plugin" if world > 1 else mode
-            os.environ.update(MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3", MG_MARCH_MIN_WG="0",
+            os.environ.update(MG_NO_SMALL="1", MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3", MG_MARCH_MIN_WG="0",
                               MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_WINP_MIN_ROWS="0", MG_MARCH27_MIN_ROWS="0", MG_MARCHR_MIN_ROWS="0")
             H = gd.NativeGhostHierarchy(G, 0, transport=("rccl" if transport == "rccl" else "plugin"))
             bt = torch.from_numpy(b_ext).cuda()

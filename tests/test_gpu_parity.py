@@ -402,6 +402,7 @@ def test_rowclass_kernel_paths(mg, built, monkeypatch):
     from multigrid_jl_amd import device as D
     # by default only operators of >= 100 000 rows with <= 4 classes per wavefront are stored this way
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_STAGE_MIN_LEN", "0")          # LDS-staged variants also on the 7-point level
     monkeypatch.setenv("MG_TILE_MIN_WG", "0")            # ... and on levels with few workgroups
@@ -514,6 +515,7 @@ def test_rowclass_exception_rows(mg, built, monkeypatch, n_odd):
     import scipy.sparse as sp
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_KEEP_SINGLETONS", "0")    # unique rows become exception rows, not dictionary classes
     monkeypatch.setenv("MG_WINDOW_MIN_WG", "0")
@@ -569,6 +571,7 @@ def test_rowclass_variants_on_odd_grids(mg, built, cells, levels, monkeypatch):
     import torch
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_TILE_MIN_WG", "0")
@@ -635,6 +638,7 @@ def test_wrong_grid_hint_changes_nothing(mg, built, monkeypatch):
     from global memory and the solve is still the oracle's."""
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_TILE_MIN_WG", "0")
     A, p, b = _setup(mg, [40, 30, 5], 2)                    # nodes 41 x 31 x 6
@@ -658,6 +662,7 @@ def test_march_kernel_and_fused_prolongation(mg, built, monkeypatch, cells, leve
     import torch
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_TILE_MIN_WG", "0")
@@ -716,6 +721,7 @@ def test_march2_sweep_and_residual_in_one_pass(mg, built, monkeypatch, cells, le
     import torch
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
@@ -790,6 +796,7 @@ def test_march3_two_stage_pass_on_inplane_tiles(mg, built, monkeypatch, cells, k
     import torch
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
@@ -985,6 +992,7 @@ def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, 
     import torch
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_WINP_MIN_ROWS", "0")
@@ -1027,6 +1035,7 @@ def test_plane_tiles_of_256_rows_for_small_levels(mg, built, monkeypatch, cells,
     lane kernel that serves the level otherwise, and to the oracle within the solve tolerance."""
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_NO_MARCH", "1")
@@ -1052,6 +1061,7 @@ def test_march_with_wrong_grid_hint_and_exception_rows(mg, built, monkeypatch):
     import scipy.sparse as sp
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_KEEP_SINGLETONS", "0")
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
@@ -1086,6 +1096,7 @@ def test_rowclass_lane_spmm_block_rhs(mg, built, monkeypatch, nrhs):
     against the oracle, and bit-identical to itself under the L2-tiled block order; csr_stream_spmm (MG_NO_LANE_MM=1)
     gives the same iterates to fp64 reassociation."""
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     runs = {}
@@ -1136,6 +1147,7 @@ def test_periodic_in_x_operator_stays_off_the_tile_forms(mg, built, monkeypatch)
     import torch
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_SMALL", "1")           # (this test is about the row-class forms: keep the small-level kernels out)
     monkeypatch.setenv("MG_ROWCLASS_MAX_PASSES", "64")
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")

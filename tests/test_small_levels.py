@@ -1,0 +1,93 @@
+"""-m gpu: the one-trip kernels of the small grid levels (csrc/mg_small.hpp: grid27_small_spmv / _restrict, grid_small_prolong).
+They replace the streaming kernels on grid levels below `rowclass_min_rows`; every product is compared with numpy on the host's
+operators and with the kernels they replace (a second handle with no_small = 1), whole solves with the oracle."""
+import numpy as np
+import pytest
+
+from oracle import mg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _hier(mg, cells, levels, relax="Jac", om=0.8, cyc="V"):
+    A, mesh = mg.poisson_shifted(cells)
+    p = mg.getMGparam(np.float64, np.int64, levels, 8, 6, 1e-10, relax, om, 2, 1, cyc, "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p)
+    return A, p
+
+
+@pytest.mark.parametrize("cells,levels,relax", [([24, 16, 32], 3, "Jac"), ([16, 16, 16], 3, "SPAI"), ([40, 24], 3, "Jac"), ([8, 64, 12], 2, "Jac")])
+def test_small_level_kernels_vs_numpy_and_streaming_kernels(mg, built, cells, levels, relax):
+    from multigrid_jl_amd import device as D
+    A, p = _hier(mg, cells, levels, relax, 1.0 if relax == "SPAI" else 0.8)
+    h = D.DeviceHierarchy(p, 0, 1)
+    h0 = D.DeviceHierarchy(p, 0, 1, options={"no_small": 1})
+    import torch
+    rng = np.random.default_rng(5)
+    try:
+        nl = len(p.As)
+        for l in range(1, nl):
+            assert h.operator_kernel_variant(l, D.MG_OP_A) == 8, (l, h.operator_kernel_variant(l, D.MG_OP_A))
+            assert h.operator_kernel_variant(l, D.MG_OP_R) == 8 and h.operator_kernel_variant(l, D.MG_OP_P) == 8
+            assert h0.operator_kernel_variant(l, D.MG_OP_A) != 8
+            Al, Pl, Rl, d = p.As[l - 1], p.Ps[l - 1], p.Rs[l - 1], np.asarray(p.relaxPrecs[l - 1])
+            n, nc = Al.shape[0], Pl.shape[1]
+            x, b, xc = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(nc)
+            xt, bt, xct = (torch.from_numpy(v).cuda() for v in (x, b, xc))
+            for kern, ref in ((D.MG_K_RESIDUAL, b - Al @ x), (D.MG_K_SMOOTH, x + d * (b - Al @ x))):
+                out, out0 = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
+                h.fused_dev(l, kern, bt, xt, out)
+                h0.fused_dev(l, kern, bt, xt, out0)
+                scale = np.abs(ref).max()
+                assert np.abs(out.cpu().numpy() - ref).max() <= 1e-13 * scale
+                assert np.abs(out.cpu().numpy() - out0.cpu().numpy()).max() <= 1e-13 * scale
+            # A x, R x, x += P xc
+            y = torch.zeros(n, dtype=torch.float64, device="cuda")
+            h.spmv_dev(l, D.MG_OP_A, 1.0, xt, 0.0, y)
+            assert np.abs(y.cpu().numpy() - Al @ x).max() <= 1e-13 * np.abs(Al @ x).max()
+            yc = torch.zeros(nc, dtype=torch.float64, device="cuda")
+            h.spmv_dev(l, D.MG_OP_R, 1.0, xt, 0.0, yc)
+            assert np.abs(yc.cpu().numpy() - Rl @ x).max() <= 1e-13 * np.abs(Rl @ x).max()
+            yf = bt.clone()
+            h.spmv_dev(l, D.MG_OP_P, 1.0, xct, 1.0, yf)
+            yf0 = bt.clone()
+            h0.spmv_dev(l, D.MG_OP_P, 1.0, xct, 1.0, yf0)
+            assert np.abs(yf.cpu().numpy() - (b + Pl @ xc)).max() <= 1e-13 * np.abs(b + Pl @ xc).max()
+            assert np.abs(yf.cpu().numpy() - yf0.cpu().numpy()).max() <= 1e-13 * np.abs(b + Pl @ xc).max()
+    finally:
+        h.close()
+        h0.close()
+
+
+@pytest.mark.parametrize("cells,levels,cyc", [([32, 32, 32], 4, "V"), ([32, 16, 24], 3, "W"), ([64, 48], 4, "F")])
+def test_solves_with_small_level_kernels_match_the_oracle(mg, built, cells, levels, cyc):
+    A, p = _hier(mg, cells, levels, cyc=cyc)
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    mg.solveMG(p, b, x)
+    from multigrid_jl_amd import device as D
+    assert p.device.operator_kernel_variant(2, D.MG_OP_A) == 8
+    hist = {}
+    xo = np.zeros_like(b)
+    orc.solveMG(p, b, xo, False, hist)
+    assert np.abs(p.resvec - hist["resvec"]).max() <= 1e-10 * hist["resvec"][0]
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    mg.clear_(p)
+
+
+def test_small_levels_follow_new_values(mg, built):
+    """replaceMatrixInHierarchy on the device (mg_rap_FP64): the position-code records are rebuilt from the new values."""
+    A, p = _hier(mg, [16, 16, 16], 3)
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    mg.solveMG(p, b, x)
+    A2 = (A * 1.75).tocsr()
+    mg.replaceMatrixInHierarchy(p, A2)
+    x = np.zeros_like(b)
+    mg.solveMG(p, b, x)
+    hist = {}
+    xo = np.zeros_like(b)
+    orc.solveMG(p, b, xo, False, hist)
+    assert np.abs(p.resvec - hist["resvec"]).max() <= 1e-10 * hist["resvec"][0]
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    mg.clear_(p)
