@@ -25,11 +25,13 @@ def test_launcher_refuses_more_ranks_than_gpus_unless_sharing_is_allowed():
 
 
 @pytest.mark.gpu
-def test_bench_gpus2_from_a_bare_python_call():
+@pytest.mark.parametrize("form", ["ghost", "halo"])
+def test_bench_gpus2_from_a_bare_python_call(form):
     """Two fresh rank processes sharing the box's one GPU (host-staged plug-in transport), started by bench.py itself;
-    rank 0's single JSON line comes back with n_gpus = 2 and the launcher's N = 1 reference."""
+    rank 0's single JSON line comes back with n_gpus = 2 and the launcher's N = 1 reference - in the ghost-layer form (default:
+    mg_ghost_*) and in the halo form of rounds 2-4 (mg_dist_*)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "32", "--steps", "3",
-                        "--warmup", "1"], capture_output=True, text=True, env=_clean_env(MG_BENCH_ALLOW_SHARE="1"),
+                        "--warmup", "1", "--sharded-form", form], capture_output=True, text=True, env=_clean_env(MG_BENCH_ALLOW_SHARE="1"),
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -38,5 +40,7 @@ def test_bench_gpus2_from_a_bare_python_call():
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["launcher"]["ranks_started"] == 2 and out["launcher"]["shared_gpu"] is True
     assert out["n1_reference"]["value"] > 0 and out["parallel_efficiency_vs_n1"] is not None
-    assert "native C++ sequencer" in out["config"]["parallelism"]
+    assert ("ghost layers" if form == "ghost" else "native C++ sequencer") in out["config"]["parallelism"]
+    if form == "ghost":
+        assert out["ghost"]["exchanges_per_step"] > 0 and out["transport"].startswith("plug-in")
     assert 0 < out["relres_after_steps"] < 1e-2
