@@ -523,6 +523,10 @@ int mg_dist_destroy(mg_dist* h);
  * owned rows of all ranks.  One right-hand side, pointwise smoothers, V / W / F cycles, direct coarsest solve (anything
  * else: mg_dist_*).  Transport: RCCL (the 128-byte id of mg_dist_unique_id) or the host-staged plug-in (ops 0 and 1). */
 int mg_ghost_attach(mg_hierarchy* h, long long rank, long long world, long long nlevels_sharded, const char* unique_id128);
+/* (RCCL transport, optional but recommended for world > 1) a SECOND communicator - another id of mg_dist_unique_id - for the
+ * ghost-layer send / recv on the side stream: RCCL serialises the operations of one communicator in issue order whatever
+ * their streams; with its own communicator the fine level's exchange overlaps the coarse cycle and its all-reduces. */
+int mg_ghost_set_side_comm(mg_hierarchy* h, const char* unique_id128);
 int mg_ghost_set_exchange_plugin(mg_hierarchy* h, mg_exchange_fn fn, void* user);
 /* Sharded level `level` (1-based): extended box ext[3] (nodes per dimension, x fastest, 1 for unused dimensions); owned box
  * [own_lo, own_hi) in extended-box coordinates; gmin = the smallest ghost width over the cut sides of ANY rank (every rank

@@ -123,4 +123,77 @@ __global__ __launch_bounds__(256) void grid_small_prolong(SmallPDev T, const dou
   x[row] = 1.0 * acc + 1.0 * px;      // (the AXPBY epilogue with alpha = beta = 1: alpha*acc + beta*y)
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Long rows: one WAVEFRONT per row.  The Galerkin levels of an SA-AMG hierarchy on anisotropic diffusion carry rows of a few hundred
+// to several thousand entries (SA-AMG.jl:44-50: the smoothed prolongation widens every coarse stencil; BASELINE config C3: levels 3-5
+// hold 80 % of the hierarchy's 2.5 G non-zeros).  The LDS-staged segmented reduction of csr_stream_spmv serves them at 0.36-0.58 of
+// the HBM peak: every product goes through LDS and two barriers although a row is far longer than a wavefront.  Here the 64 lanes
+// stride over the row - 512-byte value and 256-byte index loads per wavefront instruction, four of each in flight per lane, the
+// gathers of x behind them - accumulate in registers and meet in one shuffle tree per row: no LDS, no barrier.  A workgroup owns a
+// contiguous band of rows (xcd_band: neighbouring rows share their gather window in the XCD's L2).  Summation order: per lane its
+// strided entries in stored order, then a fixed tree - deterministic, fp64 reassociation against the CSR row loop (<= 1e-13).
+// ------------------------------------------------------------------------------------------------------------------------------
+// IDX16: the column indices are 16-bit offsets from the row's first column (ci16 / rowbase: 10 instead of 12 bytes per non-zero)
+template <int MODE, bool NT, bool IDX16>
+__global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int nwg, int rows_per_wg, const unsigned short* __restrict__ ci16,
+                                                        const int* __restrict__ rowbase) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int w = xcd_band((int)blockIdx.x, nwg);
+  const int r0 = w * rows_per_wg, r1 = r0 + rows_per_wg < A.n_rows ? r0 + rows_per_wg : A.n_rows;
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const int k0 = __builtin_amdgcn_readfirstlane(A.rowptr[row]), k1 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+    const double* __restrict__ xb = IDX16 ? v.x + __builtin_amdgcn_readfirstlane(rowbase[row]) : v.x;
+#define LR_COL(kk) (IDX16 ? (int)(NT ? __builtin_nontemporal_load(ci16 + (kk)) : ci16[(kk)]) : (NT ? __builtin_nontemporal_load(A.colidx + (kk)) : A.colidx[(kk)]))
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int k = k0 + lane;
+    // eight values + eight indices in flight per lane (6 KB per wavefront), the gathers behind them
+    for (; k + 448 < k1; k += 512) {
+      double vv[8];
+      int cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        vv[u] = NT ? __builtin_nontemporal_load(A.val + k + 64 * u) : A.val[k + 64 * u];
+        cc[u] = LR_COL(k + 64 * u);
+      }
+      double xx[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xx[u] = xb[cc[u]];
+      a0 = a0 + vv[0] * xx[0];
+      a1 = a1 + vv[1] * xx[1];
+      a2 = a2 + vv[2] * xx[2];
+      a3 = a3 + vv[3] * xx[3];
+      a0 = a0 + vv[4] * xx[4];
+      a1 = a1 + vv[5] * xx[5];
+      a2 = a2 + vv[6] * xx[6];
+      a3 = a3 + vv[7] * xx[7];
+    }
+    for (; k + 64 < k1; k += 128) {
+      const double v0 = NT ? __builtin_nontemporal_load(A.val + k) : A.val[k], v1 = NT ? __builtin_nontemporal_load(A.val + k + 64) : A.val[k + 64];
+      const int c0 = LR_COL(k), c1 = LR_COL(k + 64);
+      a0 = a0 + v0 * xb[c0];
+      a1 = a1 + v1 * xb[c1];
+    }
+    for (; k < k1; k += 64) {
+      const double vv = NT ? __builtin_nontemporal_load(A.val + k) : A.val[k];
+      const int cc = LR_COL(k);
+      a2 = a2 + vv * xb[cc];
+    }
+#undef LR_COL
+    double acc = (a0 + a1) + (a2 + a3);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+      double out;
+      if (MODE == AXPBY) {
+        out = v.alpha * acc + (v.beta != 0.0 ? v.beta * v.y[row] : 0.0);
+        if (v.y2) v.y2[row] = v.d_full[row] * out;
+      } else if (MODE == RESID) {
+        out = v.b[row] - acc;
+      } else {
+        out = v.xs[row] + v.d_full[row] * (v.b[row] - acc);
+      }
+      v.y[row] = out;
+    }
+  }
+}
+
 }  // namespace mgk

@@ -138,6 +138,7 @@ SIGNATURES = {
     "mg_dist_destroy": (C.c_int, [_vp]),
     "mg_ghost_attach": (C.c_int, [_vp, _ll, _ll, _ll, C.c_char_p]),
     "mg_ghost_set_exchange_plugin": (C.c_int, [_vp, _vp, _vp]),
+    "mg_ghost_set_side_comm": (C.c_int, [_vp, C.c_char_p]),
     "mg_ghost_set_level_INT64": (C.c_int, [_vp, _ll, _lp, _lp, _lp, _ll, _ll, _lp, _lp, _ll, _lp, _lp]),
     "mg_ghost_finalize": (C.c_int, [_vp]),
     "mg_ghost_set_dry": (C.c_int, [_vp, _ll]),

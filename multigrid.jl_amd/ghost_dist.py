@@ -364,17 +364,20 @@ class NativeGhostHierarchy:
         self.lib = lib = self.dev.lib
         h = self.dev.handle
         rank, size = G.rank, G.size
-        uid = None
-        if transport == "rccl":
-            buf = C.create_string_buffer(128)
+        uid = uid2 = None
+        if transport == "rccl":      # two communicators: collectives on the compute stream, ghost-layer send / recv on the side stream
+            buf, buf2 = C.create_string_buffer(128), C.create_string_buffer(128)
             if rank == 0:
                 D._check(lib, lib.mg_dist_unique_id(buf), "mg_dist_unique_id")
-            box = [buf.raw if rank == 0 else None]
+                D._check(lib, lib.mg_dist_unique_id(buf2), "mg_dist_unique_id")
+            box = [buf.raw if rank == 0 else None, buf2.raw if rank == 0 else None]
             if size > 1:
                 import torch.distributed as dist
                 dist.broadcast_object_list(box, src=0, group=group)
-            uid = C.create_string_buffer(box[0], 128)
+            uid, uid2 = C.create_string_buffer(box[0], 128), C.create_string_buffer(box[1], 128)
         D._check(lib, lib.mg_ghost_attach(h, rank, size, G.a, uid), "mg_ghost_attach")
+        if uid2 is not None:
+            D._check(lib, lib.mg_ghost_set_side_comm(h, uid2), "mg_ghost_set_side_comm")
         self._cb = None
         if transport == "dry":
             D._check(lib, lib.mg_ghost_set_dry(h, 1), "mg_ghost_set_dry")

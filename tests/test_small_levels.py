@@ -91,3 +91,44 @@ def test_small_levels_follow_new_values(mg, built):
     assert np.abs(p.resvec - hist["resvec"]).max() <= 1e-10 * hist["resvec"][0]
     assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
     mg.clear_(p)
+
+
+@pytest.mark.parametrize("n,m,avg", [(3000, 3000, 400), (517, 2100, 1500), (64, 64, 64), (2000, 900, 120), (300, 200000, 1200), (1500, 1500, 1100)])
+def test_long_row_kernel_vs_numpy(mg, built, n, m, avg):
+    """csr_longrow_spmv (one wavefront per row; operators without row classes whose rows average >= 1000 entries - the Galerkin
+    levels of an SA-AMG hierarchy; 16-bit column offsets where every row spans < 65536 columns, 32-bit ones in the 200 000-column
+    case; the shorter-row cases stay on csr_stream_spmv): y = alpha A x + beta y [+ d.*y], b - A x, x + d.*(b - A x) against numpy, ragged rows included
+    (empty rows, one row far longer than the rest)."""
+    import scipy.sparse as sp
+    import torch
+    from multigrid_jl_amd import device as D
+    rng = np.random.default_rng(n + m)
+    lens = np.clip(rng.poisson(avg, n), 0, m)
+    lens[0] = 0
+    lens[n // 2] = min(m, 4 * avg)
+    rows = np.repeat(np.arange(n), lens)
+    cols = np.concatenate([np.sort(rng.choice(m, size=int(k), replace=False)) for k in lens]) if lens.sum() else np.zeros(0, dtype=int)
+    M = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n, m))
+    M.sort_indices()
+    op = D.DeviceOperator(M, 0)
+    op0 = None
+    try:
+        x = rng.standard_normal(m)
+        y0 = rng.standard_normal(n)
+        xt = torch.from_numpy(x).cuda()
+        y = torch.from_numpy(y0.copy()).cuda()
+        op.apply(D.MG_K_SPMV, xt, y, alpha=-1.5, beta=0.25)
+        ref = -1.5 * (M @ x) + 0.25 * y0
+        assert np.abs(y.cpu().numpy() - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+        if n == m:
+            b, d = rng.standard_normal(n), rng.standard_normal(n)
+            bt, dt = torch.from_numpy(b).cuda(), torch.from_numpy(d).cuda()
+            out = torch.zeros(n, dtype=torch.float64, device="cuda")
+            op.apply(D.MG_K_RESIDUAL, xt, out, b=bt)
+            ref = b - M @ x
+            assert np.abs(out.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+            op.apply(D.MG_K_SMOOTH, xt, out, b=bt, d=dt)
+            ref = x + d * (b - M @ x)
+            assert np.abs(out.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+    finally:
+        op.close()
