@@ -695,6 +695,33 @@ def main():
             "relres_after_steps": float(res2[-1] / res2[0]), "fine_level_form": {4: "band form (two-stage pass, values streamed once)",
                                                                                  0: "two launches (CSR kernels)"}.get(form2, str(form2)),
             "host_setup_s": round(t_set2, 1), "kernels": kt2}
+        # 16 right-hand sides on this hierarchy: the matrix streams are real here (no row classes), so the block SpMM kernels - one pass
+        # over A for all columns - are what runs (the column-wise path needs the four-stage pass of a constant-coefficient fine level)
+        if not args.no_c5_leg:
+            try:
+                k5, K5 = 16, max(2, min(K, 4))
+                b16 = torch.from_numpy(np.ascontiguousarray(mg.seeded_rhs(A2, k5))).to(dev)
+                x16 = torch.zeros_like(b16)
+                h2.set_nrhs(k5)
+                h2.solve_dev(b16, x16, 0.0, 1)
+                d5 = []
+                for _ in range(3):
+                    x16.zero_()
+                    barrier()
+                    t0 = time.perf_counter()
+                    it5, res5 = h2.solve_dev(b16, x16, 0.0, K5)
+                    barrier()
+                    d5.append(time.perf_counter() - t0)
+                dt5 = sorted(d5)[1]
+                roofline["divsiggrad"]["block16"] = {
+                    "workload": "the same hierarchy, 16 right-hand sides: block SpMM kernels (csr_stream_spmm: A streamed once for all columns)",
+                    "ms_per_step": round(dt5 / K5 * 1e3, 4), "dof_updates_per_s": round(n * k5 * K5 / dt5, 1), "steps": K5,
+                    "sixteen_single_vector_steps_ms": round(16 * dt2 / K * 1e3, 4),
+                    "speedup_over_column_by_column": round(16 * (dt2 / K) / (dt5 / K5), 3),
+                    "relres_after_steps": float(res5[-1] / res5[0])}
+                del b16, x16
+            except Exception as e:
+                roofline["divsiggrad"]["block16"] = {"error": f"{type(e).__name__}: {e}"}
         h2.close()
         del x2, b2, A2, p2
 
