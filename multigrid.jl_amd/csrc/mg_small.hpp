@@ -109,9 +109,10 @@ __global__ __launch_bounds__(256) void grid_small_prolong(SmallPDev T, const dou
   const double w = wz * wy * wx;      // (every entry of the row carries the same weight: 1/2 per odd coordinate)
   double xv[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int dz = (s >> 2) & oz, dy = (s >> 1) & oy, dx = s & ox;   // (an absent neighbour repeats a present one: weight 0 below)
-    xv[s] = xc[c0 + dz * T.Pc + dy * T.nc1 + dx];
+  for (int s = 0; s < 8; ++s) {      // (only the neighbours the row has are loaded: 1, 2, 4 or 8 of them)
+    const bool on = (((s >> 2) & 1) <= oz) && (((s >> 1) & 1) <= oy) && ((s & 1) <= ox);
+    xv[s] = 0.0;
+    if (on) xv[s] = xc[c0 + ((s >> 2) & 1) * T.Pc + ((s >> 1) & 1) * T.nc1 + (s & 1)];
   }
   const double px = x[row];
   double acc = 0.0;
