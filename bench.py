@@ -953,13 +953,7 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
     dt = float(tt.item())
     lb = torch.tensor([Hpy.local_algorithmic_bytes()], device=red_dev, dtype=torch.float64)
     dist.all_reduce(lb, op=dist.ReduceOp.MAX)
-    rccl_ranks = H.comm_count()
-    kern_table = None
-    if world == 1:      # (one process: a world of one, or a dry rank) where the step goes, launch by launch (instrumented pass: graphs off, events on)
-        prof, moved, tot_ms = profiled_pass(H.dev, b, x, K, torch)
-        kern_table = {f"L{l}:{k}": {"avg_us": round(v[0] / v[1] * 1e3, 2), "launches_per_step": round(v[1] / K, 2), "us_per_step": round(v[0] / K * 1e3, 1)}
-                      for (l, k), v in sorted(prof.items())}
-        kern_table["kernel_ms_per_step"] = round(tot_ms / K, 4) if hasattr(H, "comm_count") else None
+    rccl_ranks = H.comm_count() if hasattr(H, "comm_count") else None
     if rank == 0:
         ach = float(lb.item()) / (dt / K) / 1e9
         out = {

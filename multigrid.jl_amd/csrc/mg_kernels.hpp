@@ -2100,23 +2100,9 @@ struct March3Dev {
                                 // row (x, y, z) is left out where sx[x] | sy[y] | sz[z] (a neighbour is such a row)
 };
 
-#ifndef MG_M3_PD
-#define MG_M3_PD 1    // x planes in flight in registers (1 or 2)
-#endif
-#ifndef MG_M3_NT
-#define MG_M3_NT 0    // experiment (profiles/r03_march3_ab.md section 8): bit 0 = t WRITTEN non-temporally (so that r rather than t stays cached
-                      // for the restriction: restriction 66 -> 62 us, but the pass itself 4 us slower - neutral over four alternations);
-                      // bit 1 = b READ non-temporally as well (lockstep neighbours then fetch their common ring rows of b from HBM twice:
-                      // +33 us per step at 400^3).  Off.
-#endif
-#ifndef MG_M3_RAW
-#define MG_M3_RAW 1   // slab pairs by ONE 16-byte load in every lane at a clamped address, no branch (march_load_pair_raw): round 4 found
-                      // `s_waitcnt vmcnt(1)` in front of the second path's load of the two-path form - every iteration waited for the
-                      // stores of the previous one.  0 restores the two-path loads (A/B).
-#endif
-#ifndef MG_M3_EXP
-#define MG_M3_EXP 0   // attribution builds (make variant): 1 no class walks, 2 no slab/operand loads, 3 no stores
-#endif
+constexpr int RM3_PD = 1;   // x planes in flight in registers (2 was measured slower: profiles/r03_march3_ab.md section 7)
+// (slab pairs: ONE 16-byte load in every lane at a clamped address, no branch - march_load_pair_raw; the two-path form put
+// `s_waitcnt vmcnt(1)` in front of its second path: every iteration waited for the stores of the previous one)
 // VAR (round 3): the same pass for grid operators whose COEFFICIENTS differ from row to row (div sigma grad - what jInv feeds
 // this package; MGsetup.jl:226-270 exists because sigma changes every outer iteration).  The classes then describe the
 // STRUCTURE only (which neighbours a row has: offsets, no values), still as a verified product map; the values are streamed
@@ -2215,7 +2201,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   } while (0)
   // acc = (z-1 entry) + in-plane entries in stored order + (z+1 entry); base8: byte address of the row's own entry in the slab
 #define M3_WALK(acc, lo_, hi_, slab, base8)                                                                            \
-  if (MG_M3_EXP != 1) do {                                                                                             \
+  do {                                                                                                                 \
     double xv_[RM3_NIP];                                                                                               \
     _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_)                                                             \
       xv_[u_] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(slab) + ((base8) + ro[u_]));            \
@@ -2225,7 +2211,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   } while (0)
   // VAR: the same walk with the row's own values vv_[0..6] (z-1, in-plane x RM3_NIP, z+1); the record gives the offsets
 #define M3_WALKV(acc, lo_, hi_, slab, base8, vv_)                                                                      \
-  if (MG_M3_EXP != 1) do {                                                                                             \
+  do {                                                                                                                 \
     double xv_[RM3_NIP];                                                                                               \
     _Pragma("unroll") for (int u_ = 0; u_ < RM3_NIP; ++u_)                                                             \
       xv_[u_] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(slab) + ((base8) + ro[u_]));            \
@@ -2278,13 +2264,12 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
   do {                                                                                                                 \
     const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u && (p) >= 0 && (p) < T.nplanes;                                \
     const long long e0_ = ((long long)(p) * T.P + pg[m]) & ~1LL;                                                       \
-    if (MG_M3_RAW) (dst) = MG_M3_EXP == 2 ? d2_t{1.0, 1.0} : march_load_pair_raw(src, e0_, act_, T.n_cols);            \
-    else (dst) = march_load_pair(src, e0_, act_ && MG_M3_EXP != 2, T.n_cols);                                          \
+    (dst) = march_load_pair_raw(src, e0_, act_, T.n_cols);                                                             \
   } while (0)
   // (raw loads: the one pair whose second entry does not exist was read one entry earlier - moved into place where consumed)
 #define M3_FIXPAIR(v, p, m)                                                                                            \
   do {                                                                                                                 \
-    if (MG_M3_RAW && (p) == T.nplanes - 1) {                                                         /* (uniform) */   \
+    if ((p) == T.nplanes - 1) {                                                                           /* (uniform) */   \
       const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u;                                                             \
       const long long e0_ = ((long long)(p) * T.P + pg[m]) & ~1LL;                                                     \
       march_pair_fix((v), e0_, act_, T.n_cols);                                                                        \
@@ -2340,10 +2325,10 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
         M3_STAGE(pp, z0 - 1 + pp, m, q[m]);
       }
     }
-    // Loads in flight.  MG_M3_PD planes ahead: with 2, iteration z consumes what iteration z-2 asked for and refills the SAME
+    // Loads in flight.  RM3_PD planes ahead: with 2, iteration z consumes what iteration z-2 asked for and refills the SAME
     // register buffer, so nothing is copied between buffers (a copy of a register whose load is in flight is a wait): the
     // loop below is unrolled by two and each half uses its own buffer (PB = half).
-    constexpr int NBUF = MG_M3_PD == 2 ? 2 : 1;
+    constexpr int NBUF = RM3_PD == 2 ? 2 : 1;
     d2_t preb[NBUF][NPM];         // x planes z+2 [, z+3]
 #pragma unroll
     for (int q = 0; q < NBUF; ++q)
@@ -2357,11 +2342,11 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     const bool pv_ = (zz) >= 0 && (zz) < T.nplanes;                                                                    \
     _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
       const int r_ = (pv_ && ((live1 >> s_) & 1u)) ? (zz) * T.P + ip0 + s_ * ipstride : C.n_rows - 1;                  \
-      nbb[PB_][s_] = MG_M3_EXP == 2 ? 1.0 : ((MG_M3_NT & 2) ? __builtin_nontemporal_load(a.b + r_) : a.b[r_]);               \
+      nbb[PB_][s_] = a.b[r_];                                                                                          \
       if (VAR) {                                                                                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < NV; ++k_)                                                              \
-          nvb[PB_][s_ % KV][k_] = MG_M3_EXP == 2 ? 1.0 : T.vband[(size_t)k_ * (size_t)T.vstride + (size_t)r_];        \
-        ndb[PB_][s_ % KV] = MG_M3_EXP == 2 ? 1.0 : a.d[r_];                                                            \
+          nvb[PB_][s_ % KV][k_] = T.vband[(size_t)k_ * (size_t)T.vstride + (size_t)r_];                                \
+        ndb[PB_][s_ % KV] = a.d[r_];                                                                                   \
       }                                                                                                                \
     }                                                                                                                  \
   } while (0)
@@ -2384,7 +2369,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
     }
     // As many stores as an iteration of the loop below issues, BEHIND the loads above: the compiler's wait for those loads
     // at the top of the loop is then s_waitcnt vmcnt(number of stores) on the entry path as well as on the back edge
-    if (MG_M3_EXP != 3) {
+    {
 #pragma unroll
       for (int i = 0; i < K1 * (((OUT >> 2) & 1) + ((OUT >> 1) & 1) + (OUT & 1)); ++i) sk[(size_t)i * 32 * NT] = 0.0;   // (distinct slots: distinct instructions)
     }
@@ -2510,15 +2495,14 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       // ---- the stores of this iteration: EVERY lane issues every store instruction (lanes / planes with nothing to store
       // write to their slot of the sink), so their number is fixed and the wait at the top of the next iteration can be
       // for the loads alone (s_waitcnt vmcnt(number of stores)): a store's acknowledgement is not on the critical path ------
-      if (MG_M3_EXP != 3) {
+      {
         const bool wt = s1 && z >= z0 && z < z1;        // (uniform) plane z belongs to this run: its t is stored
 #pragma unroll
         for (int s = 0; s < K1; ++s) {
           const int rowt = z * T.P + ip0 + s * ipstride, rowr = rowt - T.P;
           if (OUT & 4) {
             double* q_ = (wt && ((core >> s) & 1u)) ? a.t + rowt : sk;
-            if (MG_M3_NT & 1) __builtin_nontemporal_store(tc[s], q_);
-            else *q_ = tc[s];
+            *q_ = tc[s];
           }
           if (OUT & 1) {
             double* q_ = ((done2 >> s) & 1u) ? a.r + rowr : sk;
@@ -2634,9 +2618,6 @@ struct March4Dev {
   int oxl, oxh, oyl, oyh, ozl, ozh;
 };
 constexpr int RM4_G = 4;        // halo of the staged x (stage 1 runs on core + 3 rings)
-#ifndef MG_M4_EXP
-#define MG_M4_EXP 0   // attribution builds (make variant; scripts/march4_ab.py): 1 no accumulation chains, 2 no slab/operand loads, 3 no stores, 4 stages 3 and 4 skipped
-#endif
 
 template <int NT, int K1, int NPM, int PITCH>
 __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, March2Args a, March4Dev T) {
@@ -2766,8 +2747,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     off_ = (((pflag >> (4 * (m))) & 5u) == 5u) ? off_ : 4;                                                             \
     const int lo_ = pc_ == 0 ? 4 : 0;                                     /* (uniform: nothing in front of x) */       \
     off_ = off_ < lo_ ? lo_ : (off_ > lim_ ? lim_ : off_);                                                             \
-    if (MG_M4_EXP == 2) (dst) = d2_t{1.0, 1.0};                                                                        \
-    else (dst) = *reinterpret_cast<const d2_t*>(base_ + (unsigned)off_);                                               \
+    (dst) = *reinterpret_cast<const d2_t*>(base_ + (unsigned)off_);                                               \
   } while (0)
     // (n_cols odd: the last entry of x is the first of a pair whose second does not exist - the clamp above read the pair
     // one entry earlier; move it into place.  Only in the last plane.)
@@ -2811,7 +2791,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     const double* base_ = a.b + (long long)pc_ * T.P;                                                /* (uniform) */   \
     _Pragma("unroll") for (int s_ = 0; s_ < K1; ++s_) {                                                                \
       const int r_ = ((lv >> s_) & 1u) ? ip0 + s_ * T.n1 : 0;                                                          \
-      nbb[s_] = MG_M4_EXP == 2 ? 1.0 : base_[(unsigned)r_];                                                            \
+      nbb[s_] = base_[(unsigned)r_];                                                            \
     }                                                                                                                  \
   } while (0)
     M4_OPERANDS(zA);
@@ -2822,7 +2802,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
       if (zA - 1 >= 0 && ((lv >> s) & 1u)) xm[s] = a.x[(zA - 1) * T.P + ip0 + s * T.n1];
     }
 #pragma unroll
-    for (int i = 0; i < (MG_M4_EXP == 3 ? 0 : 2 * K1); ++i) sk[(size_t)i * 32 * NT] = 0.0;   // as many stores as an iteration issues, behind the loads (see march3)
+    for (int i = 0; i < 2 * K1; ++i) sk[(size_t)i * 32 * NT] = 0.0;   // as many stores as an iteration issues, behind the loads (see march3)
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < K1; ++s)   // own x of plane zA from its slab (slot 0) - every row of the strip: a row beyond the region is its neighbour's neighbour
@@ -2836,15 +2816,13 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
 #define M4_ACC(acc, lo_, up_, le_, ow_, ri_, dn_, hi_)                                                                 \
   do {                                                                                                                 \
     (acc) = 0.0;                                                                                                       \
-    if (MG_M4_EXP != 1) {                                                                                              \
-      (acc) = (acc) + rlo * (lo_);                                                                                     \
-      (acc) = (acc) + rv0 * (up_);                                                                                     \
-      (acc) = (acc) + rv1 * (le_);                                                                                     \
-      (acc) = (acc) + rv2 * (ow_);                                                                                     \
-      (acc) = (acc) + rv3 * (ri_);                                                                                     \
-      (acc) = (acc) + rv4 * (dn_);                                                                                     \
-      (acc) = (acc) + rhi * (hi_);                                                                                     \
-    }                                                                                                                  \
+    (acc) = (acc) + rlo * (lo_);                                                                                       \
+    (acc) = (acc) + rv0 * (up_);                                                                                       \
+    (acc) = (acc) + rv1 * (le_);                                                                                       \
+    (acc) = (acc) + rv2 * (ow_);                                                                                       \
+    (acc) = (acc) + rv3 * (ri_);                                                                                       \
+    (acc) = (acc) + rv4 * (dn_);                                                                                       \
+    (acc) = (acc) + rhi * (hi_);                                                                                       \
   } while (0)
     // the record of this pass's class in the z-class of the stage's plane (re-read only when it differs from the one held:
     // at the first / last planes, and in wavefronts that run more than one pass)
@@ -2862,10 +2840,8 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     const double dn_ = s == K1 - 1 ? M4_LDS(o8_ + P8) : (val)[s < K1 - 1 ? s + 1 : s];                                 \
     M4_ACC(acc, (lo_)[s], up_, le_, (val)[s], ri_, dn_, (hi_)[s]);                                                     \
   } while (0)
-#ifndef MG_M4_SCHED
-#define MG_M4_SCHED 1   // 1: the stages of an iteration are not interleaved by the scheduler (live ranges: 128 / 168 registers)
-#endif
-#define M4_SCHED do { if (MG_M4_SCHED) __builtin_amdgcn_sched_barrier(0); } while (0)
+// (the stages of an iteration are not interleaved by the scheduler: live ranges stay within 128 / 168 registers)
+#define M4_SCHED __builtin_amdgcn_sched_barrier(0)
     for (int z = zA; z <= zE; ++z) {
       d2_t cur[NPM];
       double b0[K1];
@@ -2894,8 +2870,8 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
       if (z + 1 <= zE) M4_OPERANDS(z + 1);
       const bool s1 = z < T.nplanes;                                            // (uniform; z >= zA >= 0)
       const bool s2 = z - 1 >= 0 && z - 1 < T.nplanes && z >= zs - 1;           // plane z-1 in [zs-2, ze+1]
-      const bool s3 = MG_M4_EXP != 4 && z - 2 >= 0 && z - 2 < T.nplanes && z >= zs + 1;   // plane z-2 in [zs-1, ze]
-      const bool s4 = MG_M4_EXP != 4 && z >= zs + 3;                                      // plane z-3 in [zs, ze)
+      const bool s3 = z - 2 >= 0 && z - 2 < T.nplanes && z >= zs + 1;   // plane z-2 in [zs-1, ze]
+      const bool s4 = z >= zs + 3;                                      // plane z-3 in [zs, ze)
       const int zc0 = s1 ? __builtin_amdgcn_readfirstlane((int)czL[z]) : zc1;   // (uniform)
       const bool cnt2 = z - 1 >= zs && z - 1 < ze && z - 1 >= T.ozl && z - 1 < T.ozh;   // (uniform) plane z-1 belongs to this segment (and to the owned box): its ||r||^2 counts
       const int xq8 = qz * XS8, xq18 = q1 * XS8;
@@ -2973,7 +2949,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
         }
       }
       // ---- the stores of this iteration (every lane issues every store instruction) ---------------------------------------
-      if (MG_M4_EXP != 3) {
+      {
         const bool w3 = s3 && z - 2 >= zs && z - 2 < ze;   // (uniform) t' of plane z-2 belongs to this segment
         double* bt_ = a.t + (long long)(z - 2) * T.P;      // (uniform bases; dereferenced for planes of the segment only)
         double* br_ = a.r + (long long)(z - 3) * T.P;
