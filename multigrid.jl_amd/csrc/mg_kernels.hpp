@@ -3591,6 +3591,25 @@ __global__ __launch_bounds__(BLK) void ghost_pack(const double* __restrict__ src
   const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
 }
+// two vectors of one level in one exchange (the restricted right-hand side and the first update d.*bc the restriction wrote beside it)
+__global__ __launch_bounds__(BLK) void ghost_pack2(const double* __restrict__ s1, const double* __restrict__ s2, const int* __restrict__ idx,
+                                                   double* __restrict__ d1, double* __restrict__ d2, long long n) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) {
+    const int j = idx[i];
+    d1[i] = s1[j];
+    d2[i] = s2[j];
+  }
+}
+__global__ __launch_bounds__(BLK) void ghost_unpack2(const double* __restrict__ s1, const double* __restrict__ s2, const int* __restrict__ idx,
+                                                     double* __restrict__ d1, double* __restrict__ d2, long long n) {
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) {
+    const int j = idx[i];
+    d1[j] = s1[i];
+    d2[j] = s2[i];
+  }
+}
 
 __global__ __launch_bounds__(BLK) void sum_partial(const double* __restrict__ x, long long n,
                                                    double* __restrict__ partial) {
