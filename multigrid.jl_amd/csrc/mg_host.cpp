@@ -109,8 +109,10 @@ inline std::size_t hash_slot(long long key, std::size_t mask) {
 }
 }  // namespace
 
-int mg_spgemm_count_INT64(long long n_rows, long long ncols_B, const long long* A_ptr, const long long* A_idx,
-                          const long long* B_ptr, const long long* B_idx, long long* C_ptr, long long nthreads) {
+extern "C++" {
+template <class I>
+static int spgemm_count_t(long long n_rows, long long ncols_B, const I* A_ptr, const I* A_idx, const I* B_ptr, const I* B_idx, long long* C_ptr,
+                          long long nthreads) {
   if (nthreads > 0) omp_set_num_threads((int)nthreads);
   C_ptr[0] = 0;
   if (ncols_B <= DENSE_MAX_COLS) {  // dense stamp array per thread: no per-row clearing
@@ -159,10 +161,9 @@ int mg_spgemm_count_INT64(long long n_rows, long long ncols_B, const long long* 
   return 0;
 }
 
-int mg_spgemm_fill_FP64_INT64(long long n_rows, long long ncols_B, const long long* A_ptr, const long long* A_idx,
-                              const double* A_val, const long long* B_ptr, const long long* B_idx,
-                              const double* B_val, const long long* C_ptr, long long* C_idx, double* C_val,
-                              long long nthreads) {
+template <class I>
+static int spgemm_fill_t(long long n_rows, long long ncols_B, const I* A_ptr, const I* A_idx, const double* A_val, const I* B_ptr, const I* B_idx,
+                         const double* B_val, const long long* C_ptr, I* C_idx, double* C_val, long long nthreads) {
   if (nthreads > 0) omp_set_num_threads((int)nthreads);
   if (ncols_B <= DENSE_MAX_COLS) {
 #pragma omp parallel
@@ -186,7 +187,7 @@ int mg_spgemm_fill_FP64_INT64(long long n_rows, long long ncols_B, const long lo
         }
         std::sort(touched.begin(), touched.end());
         for (long long j = 0; j < cnt; ++j) {
-          C_idx[out0 + j] = touched[(std::size_t)j];
+          C_idx[out0 + j] = (I)touched[(std::size_t)j];
           C_val[out0 + j] = acc[(std::size_t)touched[(std::size_t)j]];
         }
       }
@@ -222,7 +223,132 @@ int mg_spgemm_fill_FP64_INT64(long long n_rows, long long ncols_B, const long lo
       for (std::size_t s = 0; s < T; ++s)
         if (keys[s] != -1) row.emplace_back(keys[s], vals[s]);
       std::sort(row.begin(), row.end(), [](const std::pair<long long, double>& x, const std::pair<long long, double>& y) { return x.first < y.first; });
-      for (long long j = 0; j < cnt; ++j) { C_idx[out0 + j] = row[(std::size_t)j].first; C_val[out0 + j] = row[(std::size_t)j].second; }
+      for (long long j = 0; j < cnt; ++j) { C_idx[out0 + j] = (I)row[(std::size_t)j].first; C_val[out0 + j] = row[(std::size_t)j].second; }
+    }
+  }
+  return 0;
+}
+
+}  // extern "C++"
+
+int mg_spgemm_count_INT64(long long n_rows, long long ncols_B, const long long* A_ptr, const long long* A_idx,
+                          const long long* B_ptr, const long long* B_idx, long long* C_ptr, long long nthreads) {
+  return spgemm_count_t<long long>(n_rows, ncols_B, A_ptr, A_idx, B_ptr, B_idx, C_ptr, nthreads);
+}
+int mg_spgemm_fill_FP64_INT64(long long n_rows, long long ncols_B, const long long* A_ptr, const long long* A_idx,
+                              const double* A_val, const long long* B_ptr, const long long* B_idx,
+                              const double* B_val, const long long* C_ptr, long long* C_idx, double* C_val,
+                              long long nthreads) {
+  return spgemm_fill_t<long long>(n_rows, ncols_B, A_ptr, A_idx, A_val, B_ptr, B_idx, B_val, C_ptr, C_idx, C_val, nthreads);
+}
+// the same with 32-bit indices in and out (scipy's default below 2^31 entries: no widening copies of the operands - at C3's size
+// those copies were a quarter of the host setup); C_ptr stays 64-bit
+int mg_spgemm_count_INT32(long long n_rows, long long ncols_B, const int* A_ptr, const int* A_idx, const int* B_ptr, const int* B_idx,
+                          long long* C_ptr, long long nthreads) {
+  return spgemm_count_t<int>(n_rows, ncols_B, A_ptr, A_idx, B_ptr, B_idx, C_ptr, nthreads);
+}
+int mg_spgemm_fill_FP64_INT32(long long n_rows, long long ncols_B, const int* A_ptr, const int* A_idx, const double* A_val, const int* B_ptr,
+                              const int* B_idx, const double* B_val, const long long* C_ptr, int* C_idx, double* C_val, long long nthreads) {
+  return spgemm_fill_t<int>(n_rows, ncols_B, A_ptr, A_idx, A_val, B_ptr, B_idx, B_val, C_ptr, C_idx, C_val, nthreads);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Transposes of the setup (SA-AMG.jl:47 `R = P'`, l.115 `S + S'`): scipy's csc_tocsr is a serial scatter - 30 s of a 150 s setup
+// at 96^3 cells.  mg_csr_transpose: counting sort by column with per-column cursors, then every output row sorted by its
+// (distinct) column = input row index: the stored-order CSR of the transpose, whatever the thread count.
+// mg_csr_add_transpose_symm: out = S + S' for a STRUCTURALLY symmetric S with sorted rows (the strength matrix: A symmetric):
+// entry (i, j) looks (j, i) up by binary search in row j; returns 1 (nothing written is valid) if the pattern is not symmetric.
+// ------------------------------------------------------------------------------------------------
+int mg_csr_transpose_FP64_INT32(long long n_rows, long long n_cols, const int* ptr, const int* idx, const double* val, int* t_ptr, int* t_idx,
+                                double* t_val, long long nthreads) {
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+  const long long nnz = ptr[n_rows];
+  std::vector<int> cnt((std::size_t)n_cols + 1, 0);
+#pragma omp parallel for schedule(static)
+  for (long long k = 0; k < nnz; ++k) {
+#pragma omp atomic
+    ++cnt[(std::size_t)idx[k] + 1];
+  }
+  t_ptr[0] = 0;
+  for (long long j = 0; j < n_cols; ++j) t_ptr[j + 1] = t_ptr[j] + cnt[(std::size_t)j + 1];
+  std::vector<int> cur((std::size_t)n_cols, 0);
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (long long i = 0; i < n_rows; ++i)
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) {
+      int pos;
+#pragma omp atomic capture
+      pos = cur[(std::size_t)idx[k]]++;
+      const long long q = (long long)t_ptr[idx[k]] + pos;
+      t_idx[q] = (int)i;
+      t_val[q] = val[k];
+    }
+#pragma omp parallel
+  {
+    std::vector<std::pair<int, double>> row;
+#pragma omp for schedule(dynamic, 256)
+    for (long long j = 0; j < n_cols; ++j) {
+      const int a = t_ptr[j], b = t_ptr[j + 1];
+      bool sorted = true;
+      for (int k = a + 1; k < b && sorted; ++k) sorted = t_idx[k - 1] < t_idx[k];
+      if (sorted) continue;
+      row.clear();
+      for (int k = a; k < b; ++k) row.emplace_back(t_idx[k], t_val[k]);
+      std::sort(row.begin(), row.end(), [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+      for (int k = a; k < b; ++k) { t_idx[k] = row[(std::size_t)(k - a)].first; t_val[k] = row[(std::size_t)(k - a)].second; }
+    }
+  }
+  return 0;
+}
+int mg_csr_add_transpose_symm_FP64_INT32(long long n, const int* ptr, const int* idx, const double* val, double* out, long long nthreads) {
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+  int bad = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(| : bad)
+  for (long long i = 0; i < n; ++i)
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) {
+      const int j = idx[k];
+      const int* lo = idx + ptr[j];
+      const int* hi = idx + ptr[j + 1];
+      const int* f = std::lower_bound(lo, hi, (int)i);
+      if (f == hi || *f != (int)i) { bad = 1; out[k] = val[k]; continue; }
+      out[k] = val[k] + val[f - idx];
+    }
+  return bad;
+}
+
+// getStrengthMatrix before the symmetrisation (SA-AMG.jl:88-113), row-parallel: out = -val scaled per row by 1 / max(mm, largest
+// entry of the row of -A), mm = 1e-16 * (largest entry of -A); diagonal := 1; entries < theta := 0.  The same double operations
+// in the same order as the vectorised host code it replaces (negation, one reciprocal per row, one product per entry).
+int mg_sa_strength_FP64_INT32(long long n, const int* ptr, const int* idx, const double* val, double theta, double* out, long long nthreads) {
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+  const long long nnz = ptr[n];
+  double gmax = 0.0;
+  bool any = false;
+#pragma omp parallel
+  {
+    double m = 0.0;
+    bool have = false;
+#pragma omp for schedule(static) nowait
+    for (long long k = 0; k < nnz; ++k) {
+      const double v = -val[k];
+      if (!have || v > m) { m = v; have = true; }
+    }
+#pragma omp critical
+    if (have && (!any || m > gmax)) { gmax = m; any = true; }
+  }
+  const double mm = 1e-16 * gmax;
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (long long i = 0; i < n; ++i) {
+    const int a = ptr[i], b = ptr[i + 1];
+    if (b == a) continue;
+    double rmax = -val[a];
+    for (int k = a + 1; k < b; ++k) rmax = std::max(rmax, -val[k]);
+    rmax = std::max(mm, rmax);
+    const double sc = 1.0 / rmax;
+    for (int k = a; k < b; ++k) {
+      double v = (-val[k]) * sc;
+      if (idx[k] == (int)i) v = 1.0;
+      if (v < theta) v = 0.0;
+      out[k] = v;
     }
   }
   return 0;

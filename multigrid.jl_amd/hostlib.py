@@ -12,6 +12,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmgh
 _lib = None
 _i64p = C.POINTER(C.c_longlong)
 _f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int)
 
 
 def lib():
@@ -28,6 +29,17 @@ def lib():
         _lib.mg_spgemm_fill_FP64_INT64.argtypes = [C.c_longlong, C.c_longlong, _i64p, _i64p, _f64p, _i64p, _i64p, _f64p,
                                                    _i64p, _i64p, _f64p, C.c_longlong]
         _lib.mg_host_max_threads.restype = C.c_longlong
+        _lib.mg_spgemm_count_INT32.restype = C.c_int
+        _lib.mg_spgemm_count_INT32.argtypes = [C.c_longlong, C.c_longlong, _i32p, _i32p, _i32p, _i32p, _i64p, C.c_longlong]
+        _lib.mg_spgemm_fill_FP64_INT32.restype = C.c_int
+        _lib.mg_spgemm_fill_FP64_INT32.argtypes = [C.c_longlong, C.c_longlong, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _i64p, _i32p, _f64p,
+                                                   C.c_longlong]
+        _lib.mg_csr_transpose_FP64_INT32.restype = C.c_int
+        _lib.mg_csr_transpose_FP64_INT32.argtypes = [C.c_longlong, C.c_longlong, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, C.c_longlong]
+        _lib.mg_sa_strength_FP64_INT32.restype = C.c_int
+        _lib.mg_sa_strength_FP64_INT32.argtypes = [C.c_longlong, _i32p, _i32p, _f64p, C.c_double, _f64p, C.c_longlong]
+        _lib.mg_csr_add_transpose_symm_FP64_INT32.restype = C.c_int
+        _lib.mg_csr_add_transpose_symm_FP64_INT32.argtypes = [C.c_longlong, _i32p, _i32p, _f64p, _f64p, C.c_longlong]
     return _lib
 
 
@@ -39,24 +51,52 @@ def _pf(a):
     return a.ctypes.data_as(_f64p)
 
 
+def _threads(nthreads: int) -> int:
+    if nthreads <= 0:      # torchrun exports OMP_NUM_THREADS=1 to every rank: MG_HOST_THREADS overrides it here
+        nthreads = int(os.environ.get("MG_HOST_THREADS", "0") or 0)
+    return int(nthreads)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_i32p)
+
+
 def spgemm(A, B, nthreads: int = 0):
-    """C = A*B (CSR, sorted column indices, numerically cancelled entries kept), row-parallel on the host."""
+    """C = A*B (CSR, sorted column indices, numerically cancelled entries kept), row-parallel on the host.
+    Operands with 32-bit indices (scipy's default below 2^31 entries) are multiplied as they are - no widening copies."""
     A = sp.csr_matrix(A)
     B = sp.csr_matrix(B)
     if A.shape[1] != B.shape[0]:
         raise ValueError("dimension mismatch")
+    n = A.shape[0]
+    L = lib()
+    nthreads = _threads(nthreads)
+    Cp = np.zeros(n + 1, dtype=np.int64)
+    Av = np.ascontiguousarray(A.data, dtype=np.float64)
+    Bv = np.ascontiguousarray(B.data, dtype=np.float64)
+    if A.indices.dtype == np.int32 and B.indices.dtype == np.int32 and A.indptr.dtype == np.int32 and B.indptr.dtype == np.int32:
+        Ap, Ai, Bp, Bi = (np.ascontiguousarray(v) for v in (A.indptr, A.indices, B.indptr, B.indices))
+        rc = L.mg_spgemm_count_INT32(n, B.shape[1], _p32(Ap), _p32(Ai), _p32(Bp), _p32(Bi), _p64(Cp), nthreads)
+        if rc != 0:
+            raise RuntimeError(f"mg_spgemm_count_INT32 failed (status {rc})")
+        np.cumsum(Cp, out=Cp)
+        nnz = int(Cp[-1])
+        if max(nnz, B.shape[1]) < 2 ** 31 - 1:
+            Ci = np.empty(max(nnz, 1), dtype=np.int32)
+            Cv = np.empty(max(nnz, 1), dtype=np.float64)
+            rc = L.mg_spgemm_fill_FP64_INT32(n, B.shape[1], _p32(Ap), _p32(Ai), _pf(Av), _p32(Bp), _p32(Bi), _pf(Bv), _p64(Cp), _p32(Ci),
+                                             _pf(Cv), nthreads)
+            if rc != 0:
+                raise RuntimeError(f"mg_spgemm_fill_FP64_INT32 failed (status {rc})")
+            Cm = sp.csr_matrix((Cv[:nnz], Ci[:nnz], Cp.astype(np.int32)), shape=(n, B.shape[1]))
+            Cm.has_sorted_indices = True
+            return Cm
+        Cp[:] = 0                      # (the product needs 64-bit indices: the wide path below)
     Ap = np.ascontiguousarray(A.indptr, dtype=np.int64)
     Ai = np.ascontiguousarray(A.indices, dtype=np.int64)
-    Av = np.ascontiguousarray(A.data, dtype=np.float64)
     Bp = np.ascontiguousarray(B.indptr, dtype=np.int64)
     Bi = np.ascontiguousarray(B.indices, dtype=np.int64)
-    Bv = np.ascontiguousarray(B.data, dtype=np.float64)
-    n = A.shape[0]
-    Cp = np.zeros(n + 1, dtype=np.int64)
-    L = lib()
-    if nthreads <= 0:      # torchrun exports OMP_NUM_THREADS=1 to every rank: MG_HOST_THREADS overrides it here
-        nthreads = int(os.environ.get("MG_HOST_THREADS", "0") or 0)
-    rc = L.mg_spgemm_count_INT64(n, B.shape[1], _p64(Ap), _p64(Ai), _p64(Bp), _p64(Bi), _p64(Cp), int(nthreads))
+    rc = L.mg_spgemm_count_INT64(n, B.shape[1], _p64(Ap), _p64(Ai), _p64(Bp), _p64(Bi), _p64(Cp), nthreads)
     if rc != 0:
         raise RuntimeError(f"mg_spgemm_count_INT64 failed (status {rc})")
     np.cumsum(Cp, out=Cp)
@@ -64,10 +104,58 @@ def spgemm(A, B, nthreads: int = 0):
     Ci = np.empty(max(nnz, 1), dtype=np.int64)
     Cv = np.empty(max(nnz, 1), dtype=np.float64)
     rc = L.mg_spgemm_fill_FP64_INT64(n, B.shape[1], _p64(Ap), _p64(Ai), _pf(Av), _p64(Bp), _p64(Bi), _pf(Bv), _p64(Cp),
-                                     _p64(Ci), _pf(Cv), int(nthreads))
+                                     _p64(Ci), _pf(Cv), nthreads)
     if rc != 0:
         raise RuntimeError(f"mg_spgemm_fill_FP64_INT64 failed (status {rc})")
     idx_t = np.int32 if max(nnz, B.shape[1]) < 2 ** 31 - 1 else np.int64
     Cm = sp.csr_matrix((Cv[:nnz], Ci[:nnz].astype(idx_t), Cp.astype(idx_t)), shape=(n, B.shape[1]))
     Cm.has_sorted_indices = True
     return Cm
+
+
+def transpose_csr(M, nthreads: int = 0):
+    """M' as CSR with sorted column indices (the reference's `sparse(P')`, SA-AMG.jl:47), thread-parallel on the host."""
+    M = sp.csr_matrix(M)
+    if M.indices.dtype != np.int32 or M.indptr.dtype != np.int32 or M.nnz == 0:
+        T = sp.csr_matrix(M.T)
+        T.sort_indices()
+        return T
+    n, m = M.shape
+    ptr, idx, val = np.ascontiguousarray(M.indptr), np.ascontiguousarray(M.indices), np.ascontiguousarray(M.data, dtype=np.float64)
+    tp = np.empty(m + 1, dtype=np.int32)
+    ti = np.empty(M.nnz, dtype=np.int32)
+    tv = np.empty(M.nnz, dtype=np.float64)
+    rc = lib().mg_csr_transpose_FP64_INT32(n, m, _p32(ptr), _p32(idx), _pf(val), _p32(tp), _p32(ti), _pf(tv), _threads(nthreads))
+    if rc != 0:
+        raise RuntimeError("mg_csr_transpose_FP64_INT32 failed")
+    T = sp.csr_matrix((tv, ti, tp), shape=(m, n))
+    T.has_sorted_indices = True
+    return T
+
+
+def add_transpose(S, nthreads: int = 0):
+    """S + S' (SA-AMG.jl:115) with the pattern of S - a structurally symmetric S with sorted rows, thread-parallel; falls back to scipy otherwise."""
+    S = sp.csr_matrix(S)
+    if S.shape[0] == S.shape[1] and S.indices.dtype == np.int32 and S.indptr.dtype == np.int32 and S.has_sorted_indices and S.nnz > 0:
+        ptr, idx, val = np.ascontiguousarray(S.indptr), np.ascontiguousarray(S.indices), np.ascontiguousarray(S.data, dtype=np.float64)
+        out = np.empty(S.nnz, dtype=np.float64)
+        if lib().mg_csr_add_transpose_symm_FP64_INT32(S.shape[0], _p32(ptr), _p32(idx), _pf(val), _pf(out), _threads(nthreads)) == 0:
+            return sp.csr_matrix((out, idx.copy(), ptr.copy()), shape=S.shape)      # (own index arrays: the caller eliminates zeros in place)
+    return (S + S.T).tocsr()
+
+
+def sa_strength(A, theta: float, nthreads: int = 0):
+    """getStrengthMatrix up to (not including) the symmetrisation, row-parallel on the host: a CSR matrix with A's pattern, or None
+    when the operands do not fit the native path (64-bit indices)."""
+    A = sp.csr_matrix(A)
+    if A.indices.dtype != np.int32 or A.indptr.dtype != np.int32 or A.nnz == 0:
+        return None
+    if not A.has_sorted_indices:
+        A.sort_indices()
+    ptr, idx, val = np.ascontiguousarray(A.indptr), np.ascontiguousarray(A.indices), np.ascontiguousarray(A.data, dtype=np.float64)
+    out = np.empty(A.nnz, dtype=np.float64)
+    if lib().mg_sa_strength_FP64_INT32(A.shape[0], _p32(ptr), _p32(idx), _pf(val), float(theta), _pf(out), _threads(nthreads)) != 0:
+        return None
+    S = sp.csr_matrix((out, idx, ptr), shape=A.shape)
+    S.has_sorted_indices = True
+    return S

@@ -23,7 +23,7 @@ import scipy.sparse as sp
 from .mgdef import MGparam, _release_device
 from .mgsetup import _as_csr, adjustMemoryForNumRHS, defineCoarsestAinv, galerkin, getRelaxPrec
 
-from .hostlib import lib as _hostlib, spgemm
+from .hostlib import add_transpose, lib as _hostlib, sa_strength, spgemm, transpose_csr
 
 
 def getStrengthMatrix(A, strengthConnParam: float):
@@ -32,6 +32,12 @@ def getStrengthMatrix(A, strengthConnParam: float):
     pattern of the result is: pairs strong in at least one direction, plus the diagonal."""
     A = _as_csr(A)
     n = A.shape[0]
+    S = sa_strength(A, strengthConnParam)           # (row-parallel native form of the lines below: same operations, same order)
+    if S is not None:
+        S = add_transpose(S)
+        S.eliminate_zeros()
+        S.sort_indices()
+        return S
     S = (-A).tocsr()
     S.sort_indices()
     mm = 1e-16 * S.data.max()
@@ -42,7 +48,7 @@ def getStrengthMatrix(A, strengthConnParam: float):
     S.data = S.data * (1.0 / rowmax)[rows]          # scal_k = 1/maxVal_j; nzval *= scal_k (l.100-103)
     S.data[S.indices == rows] = 1.0
     S.data[S.data < strengthConnParam] = 0.0
-    S = (S + S.T).tocsr()
+    S = add_transpose(S)                            # S + S' (l.115): thread-parallel on the host for the symmetric pattern A gives S
     S.eliminate_zeros()
     S.sort_indices()
     return S
@@ -114,8 +120,7 @@ def SA_AMGsetup(A, param: MGparam, symm: bool = True, nrhs: int = 1, verbose: bo
         rho = min(float(abs(DA).sum()), float(abs(DA.data).max()))       # entry-wise norms (l.45)
         P = (P0 - (1.33 / rho) * spgemm(DA, P0)).tocsr()                 # l.46
         P.sort_indices()
-        R = sp.csr_matrix(P.T)                                           # l.47
-        R.sort_indices()
+        R = transpose_csr(P)                                             # l.47
         Ps.append(P)
         Rs.append(R)
         Ac = galerkin(R, Al, P)                                          # l.50
