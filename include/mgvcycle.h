@@ -231,7 +231,10 @@ int mg_spmv_FP64(mg_hierarchy* h, long long level, long long which, double alpha
 /* ---- the hot path, device-resident buffers -------------------------------------------------- */
 /* Same semantics with b/x already in HBM (hipMalloc'd or torch tensors' data_ptr).  Blocks with
  * nrhs>1 use the library's device layout: row-major [n][nrhs].  Work is enqueued on the library's
- * stream; the call returns after the stream has drained (synchronous from the host's view). */
+ * stream; the call returns after the stream has drained (synchronous from the host's view).
+ * The library's stream is non-blocking: it does NOT order against the caller's streams.  Whatever the caller still has in
+ * flight for these buffers (a fill, a copy, the kernel that produced b) must be complete on entry - synchronise the
+ * producing stream first (the Python binding does: device.py::_sync_torch), or hand the library that stream (mg_set_stream). */
 int mg_cycle_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n,
                       long long nrhs, long long x_is_zero);
 int mg_solve_dev_FP64(mg_hierarchy* h, const double* b_dev, double* x_dev, long long n,

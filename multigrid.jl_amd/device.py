@@ -210,6 +210,16 @@ def _ptr(t) -> int:
     raise TypeError("expected a torch CUDA tensor or an integer device address")
 
 
+def _sync_torch(*tensors):
+    """The library enqueues on its OWN non-blocking stream, which does not order against torch's: whatever torch still has in
+    flight for these tensors (a fill, a copy, the kernel that produced them) must have landed before the library touches them."""
+    for t in tensors:
+        if t is not None and hasattr(t, "is_cuda") and t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+            return
+
+
 DENSE_COARSE_MAX = 16384
 
 
@@ -470,6 +480,7 @@ class DeviceHierarchy:
         return z32
 
     def pcg_dev(self, b, x, tol: float, maxIter: int):
+        _sync_torch(b, x)
         iters, flag = C.c_longlong(0), C.c_longlong(0)
         resvec = np.zeros(max(int(maxIter), 1))
         _check(self.lib, self.lib.mg_pcg_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, float(tol), int(maxIter),
@@ -478,6 +489,7 @@ class DeviceHierarchy:
 
     def fgmres_dev(self, b, x, inner: int, tol: float, maxIter: int):
         """solveGMRES_MG on device tensors (one right-hand side); returns (flag, inner steps, resvec)."""
+        _sync_torch(b, x)
         iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
         resvec = np.zeros(max(int(inner) * int(maxIter), 1))
         _check(self.lib, self.lib.mg_fgmres_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, int(inner), float(tol), int(maxIter),
@@ -494,11 +506,13 @@ class DeviceHierarchy:
 
     # -- device-resident hot path (torch CUDA tensors, row-major [n][nrhs]) ---------------------
     def cycle_dev(self, b, x, x_is_zero: int = -1, nrhs: Optional[int] = None):
+        _sync_torch(b, x)
         nrhs = self.nrhs if nrhs is None else nrhs
         _check(self.lib, self.lib.mg_cycle_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, nrhs, int(x_is_zero)),
                "mg_cycle_dev")
 
     def solve_dev(self, b, x, tol: float, maxIter: int, nrhs: Optional[int] = None):
+        _sync_torch(b, x)
         nrhs = self.nrhs if nrhs is None else nrhs
         iters = C.c_longlong(0)
         resvec = np.zeros(int(maxIter) + 1)
@@ -507,17 +521,20 @@ class DeviceHierarchy:
         return int(iters.value), resvec[: iters.value + 1]
 
     def spmv_dev(self, level, which, alpha, x, beta, y, nrhs: Optional[int] = None):
+        _sync_torch(x, y)
         nrhs = self.nrhs if nrhs is None else nrhs
         _check(self.lib, self.lib.mg_spmv_dev_FP64(self.handle, level, which, float(alpha), _ptr(x), float(beta),
                                                    _ptr(y), nrhs), "mg_spmv_dev")
 
     def fused_dev(self, level, kernel, b, x, out, nrhs: Optional[int] = None):
+        _sync_torch(b, x, out)
         nrhs = self.nrhs if nrhs is None else nrhs
         _check(self.lib, self.lib.mg_fused_dev_FP64(self.handle, level, kernel, _ptr(b), _ptr(x), _ptr(out), nrhs),
                "mg_fused_dev")
 
     def sweep_residual_dev(self, level, b, x, t, r=None, xn=None, want_norm=False):
         """t = x + d.*(b - A x), r = b - A t [, xn = t + d.*r, ||r||] in one pass (two-stage marching kernel)."""
+        _sync_torch(b, x, t, r, xn)
         ss = C.c_double(0.0)
         _check(self.lib, self.lib.mg_sweep_residual_dev_FP64(
             self.handle, level, _ptr(b), _ptr(x), _ptr(t), _ptr(r) if r is not None else None,
@@ -527,6 +544,7 @@ class DeviceHierarchy:
     def four_stage_dev(self, level, b, x, tp, rp, want_norm=True):
         """The solve loop's two fine-level passes across the stopping test as one pass: t = x + d.*(b - A x), r = b - A t (||r||
         returned), xn = t + d.*r, tp = xn + d.*(b - A xn), rp = b - A tp (csr_rowclass_march4_spmv)."""
+        _sync_torch(b, x, tp, rp)
         ss = C.c_double(0.0)
         _check(self.lib, self.lib.mg_four_stage_dev_FP64(self.handle, level, _ptr(b), _ptr(x), _ptr(tp), _ptr(rp),
                                                          C.byref(ss) if want_norm else None), "mg_four_stage_dev")
