@@ -120,7 +120,17 @@ def free_port():
     return port
 
 
-def run_ranks(argv, n, extra_env=None, tag=""):
+def host_mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return float(line.split()[1]) / 1e6
+    except Exception:
+        pass
+    return 0.0
+
+
+def run_ranks(argv, n, extra_env=None, tag="", deadline_s=None):
     """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set - the fan-out the
     reference does with its worker map, DDParallel.jl:87-105,133-139), wait for all of them and return
     (exit code, parsed JSON line of rank 0 or None).  The parent never touches the GPU and never execs."""
@@ -142,7 +152,7 @@ def run_ranks(argv, n, extra_env=None, tag=""):
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
-    deadline = time.time() + float(os.environ.get("MG_BENCH_LAUNCH_TIMEOUT", "3600"))
+    deadline = time.time() + min(float(os.environ.get("MG_BENCH_LAUNCH_TIMEOUT", "3600")), deadline_s or 1e9)
     failed = None
     while True:
         rcs = [q.poll() for q in procs]
@@ -198,9 +208,16 @@ def strong_reference_run(args, n):
         rows *= c + 1
     if args.strong_reference != "on" and rows > 140_000_000:
         return None
+    # 512^3 on one GPU needs ~170 GB of host memory during its setup: 'auto' only where the host has it (else the failure would
+    # come after minutes of setup, inside the other ranks' rendezvous window)
+    need_gb = 1.3e-6 * rows
+    if args.strong_reference != "on" and host_mem_available_gb() < need_gb:
+        log(f"[launcher] strong reference skipped: {host_mem_available_gb():.0f} GB of host memory available, ~{need_gb:.0f} GB needed")
+        return None
     a1 = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-generic-pass",
           "--workload", "c2", "--cells", str(cells), "--global-cells", ",".join(str(c) for c in gcells)]
-    rc1, sref = run_ranks(a1, 1, {"MG_BENCH_N1_REFERENCE": "1"}, " n1-global")
+    # (under torchrun the other ranks wait in the rendezvous meanwhile: the child gets less than the process group's timeout)
+    rc1, sref = run_ranks(a1, 1, {"MG_BENCH_N1_REFERENCE": "1"}, " n1-global", deadline_s=PG_TIMEOUT.total_seconds() - 300.0)
     if rc1 != 0 or sref is None:
         log("[launcher] the N = 1 run of the global grid failed (memory?); strong_speedup_vs_n1 stays null")
         return None

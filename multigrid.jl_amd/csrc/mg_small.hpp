@@ -125,6 +125,68 @@ __global__ __launch_bounds__(256) void grid_small_prolong(SmallPDev T, const dou
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Band-27: 27-point grid operators whose COEFFICIENTS differ from row to row - the Galerkin levels of a div-sigma-grad hierarchy
+// (what jInv feeds the package: testGMG.jl:57-75; MGsetup.jl:226-270 exists because sigma changes every outer iteration).  No
+// two rows are equal, so there are no row classes; the pattern-coded CSR kernels moved 8 B per non-zero + descriptors through an LDS
+// phase.  Here the values live in 27 PLANAR arrays val[s][row] (s = (dz+1)*9 + (dy+1)*3 + (dx+1); 0 where a row has no such
+// entry), filled ON THE DEVICE from the CSR arrays (band27_fill: again after mg_replace_values / mg_rap), and a lane owns a row:
+// 27 coalesced value loads + 27 gathers of x issued at once, products added in (dz, dy, dx) = CSR order.  216 + 8..32 B per row.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct Band27Dev {
+  const double* val;   // [27][stride]
+  long long stride;
+  int n1, n2, n3, P, n;
+};
+// flag |= 1 if a row has an entry outside the 3 x 3 x 3 neighbourhood of its node or out of ascending order (the form is then dropped)
+__global__ __launch_bounds__(256) void band27_fill(CsrDev A, int n1, int n2, int n3, double* __restrict__ val, long long stride, int* __restrict__ flag) {
+  const int row = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (row >= A.n_rows) return;
+  const int P = n1 * n2;
+  const int z = row / P, rem = row - z * P, y = rem / n1, x = rem - y * n1;
+#pragma unroll
+  for (int s = 0; s < 27; ++s) val[(long long)s * stride + row] = 0.0;
+  int last = -1, bad = 0;
+  for (int k = A.rowptr[row]; k < A.rowptr[row + 1]; ++k) {
+    const int c = A.colidx[k];
+    const int cz = c / P, cr = c - cz * P, cy = cr / n1, cx = cr - cy * n1;
+    const int dz = cz - z, dy = cy - y, dx = cx - x;
+    if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) { bad = 1; continue; }
+    const int s = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+    if (s <= last) bad = 1;
+    last = s;
+    val[(long long)s * stride + row] = A.val[k];
+  }
+  if (bad) atomicOr(flag, 1);
+}
+// y = b - A x (RESID), y = x + d.*(b - A x) (SMOOTH), y = alpha A x + beta y (AXPBY)
+template <int MODE>
+__global__ __launch_bounds__(256) void grid27_band_spmv(Band27Dev T, VecArgs v) {
+  const int row = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (row >= T.n) return;
+  double rv[27], xv[27];
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int s = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+        int j = row + dz * T.P + dy * T.n1 + dx;
+        j = j < 0 ? 0 : (j >= T.n ? T.n - 1 : j);     // (an entry the row does not have: value 0 times some valid, finite x)
+        rv[s] = T.val[(long long)s * T.stride + row];
+        xv[s] = v.x[j];
+      }
+  double acc = 0.0;
+#pragma unroll
+  for (int s = 0; s < 27; ++s) acc = acc + rv[s] * xv[s];
+  double out;
+  if (MODE == AXPBY) out = v.alpha * acc + (v.beta != 0.0 ? v.beta * v.y[row] : 0.0);
+  else if (MODE == RESID) out = v.b[row] - acc;
+  else out = v.xs[row] + v.d_full[row] * (v.b[row] - acc);
+  v.y[row] = out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Long rows: one WAVEFRONT per row.  The Galerkin levels of an SA-AMG hierarchy on anisotropic diffusion carry rows of a few hundred
 // to several thousand entries (SA-AMG.jl:44-50: the smoothed prolongation widens every coarse stencil; BASELINE config C3: levels 3-5
 // hold 80 % of the hierarchy's 2.5 G non-zeros).  The LDS-staged segmented reduction of csr_stream_spmv serves them at 0.36-0.58 of

@@ -132,3 +132,70 @@ def test_long_row_kernel_vs_numpy(mg, built, n, m, avg):
             assert np.abs(out.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
     finally:
         op.close()
+
+
+def _divsiggrad(mg, cells, levels, seed=3):
+    import scipy.sparse as sp
+    mesh = mg.getRegularMesh([0.0, 1.0] * len(cells), cells)
+    sigma = np.exp(np.random.default_rng(seed).standard_normal(int(np.prod(cells))))
+    A = mg.getNodalDivSigGradMatrix(mesh, sigma)
+    A = (A + 1e-3 * abs(A).sum(axis=0).max() * sp.identity(A.shape[0], format="csr")).tocsr()
+    A.sort_indices()
+    p = mg.getMGparam(np.float64, np.int64, levels, 8, 6, 1e-10, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    mg.MGsetup(A, mesh, p)
+    return A, mesh, p
+
+
+@pytest.mark.parametrize("cells,levels", [([24, 16, 20], 3), ([16, 16, 16], 3), ([40, 24], 3)])
+def test_band27_variable_coefficient_levels(mg, built, cells, levels):
+    """Variable coefficients (div sigma grad: testGMG.jl:57-75): the 27-point (2-D: 9-point) Galerkin levels have no two equal rows;
+    they are held as 27 planar value arrays (grid27_band_spmv, kernel variant 9).  Products against numpy and against the
+    pattern-coded CSR kernels (no_band27), solve against the oracle, and the planar values follow replaceMatrixInHierarchy."""
+    import torch
+    from multigrid_jl_amd import device as D
+    A, mesh, p = _divsiggrad(mg, cells, levels)
+    h = D.DeviceHierarchy(p, 0, 1)
+    h0 = D.DeviceHierarchy(p, 0, 1, options={"no_band27": 1})
+    rng = np.random.default_rng(9)
+    try:
+        assert h.operator_kernel_variant(2, D.MG_OP_A) == 9 and h0.operator_kernel_variant(2, D.MG_OP_A) != 9
+        for l in range(2, len(p.As)):
+            Al, d = p.As[l - 1], np.asarray(p.relaxPrecs[l - 1])
+            n = Al.shape[0]
+            x, b = rng.standard_normal(n), rng.standard_normal(n)
+            xt, bt = torch.from_numpy(x).cuda(), torch.from_numpy(b).cuda()
+            for kern, ref in ((D.MG_K_RESIDUAL, b - Al @ x), (D.MG_K_SMOOTH, x + d * (b - Al @ x))):
+                out, out0 = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
+                h.fused_dev(l, kern, bt, xt, out)
+                h0.fused_dev(l, kern, bt, xt, out0)
+                assert np.abs(out.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+                assert np.abs(out.cpu().numpy() - out0.cpu().numpy()).max() <= 1e-13 * np.abs(ref).max()
+            y = torch.from_numpy(b.copy()).cuda()
+            h.spmv_dev(l, D.MG_OP_A, -0.5, xt, 2.0, y)
+            ref = -0.5 * (Al @ x) + 2.0 * b
+            assert np.abs(y.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+    finally:
+        h.close()
+        h0.close()
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    mg.solveMG(p, b, x)
+    hist = {}
+    xo = np.zeros_like(b)
+    orc.solveMG(p, b, xo, False, hist)
+    assert np.abs(p.resvec - hist["resvec"]).max() <= 1e-10 * hist["resvec"][0]
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    # new sigma, same pattern: the resident planar arrays are refilled (mg_rap_FP64)
+    A2, _, _ = _divsiggrad(mg, cells, levels, seed=4)
+    dev_before = p.device
+    mg.replaceMatrixInHierarchy(p, A2)
+    assert p.device is dev_before and p.device.operator_kernel_variant(2, D.MG_OP_A) == 9
+    b2 = mg.seeded_rhs(A2)
+    x = np.zeros_like(b2)
+    mg.solveMG(p, b2, x)
+    hist = {}
+    xo = np.zeros_like(b2)
+    orc.solveMG(p, b2, xo, False, hist)
+    assert np.abs(p.resvec - hist["resvec"]).max() <= 1e-10 * hist["resvec"][0]
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    mg.clear_(p)
