@@ -68,3 +68,30 @@ def test_block_solved_column_by_column(mg, built, monkeypatch, cells, levels, nr
         mg.solveMG(p1, np.ascontiguousarray(B[:, c]), xc)
         assert np.array_equal(xc, runs["columns"][0][:, c])
     mg.clear_(p1)
+
+
+@pytest.mark.gpu
+def test_block_cycle_and_column_solve_share_one_handle(mg, built, monkeypatch):
+    """the column-wise solve plays one vector at a time on the handle's OWN coarse buffers - the pointers a block cycle
+    (mg_cycle_dev with nrhs = k: the preconditioner call of a block Krylov method) keys its HIP graphs with.  A W-cycle on a grid
+    small enough that the graphs start at level 1: block cycle, column-wise solve, block cycle again on ONE handle - every result
+    must equal the oracle's (a graph captured for k columns replayed for one, or the reverse, would not)."""
+    _env(monkeypatch)
+    monkeypatch.setenv("MG_NO_COLUMNS", "0")
+    A, p, B = _setup(mg, [24, 20, 16], 3, 4, cyc="W", tol=0.0, maxIter=3)
+    h = mg.to_device(p)
+    assert h.four_stage_form(1)[0]
+    for rep in range(2):
+        Z = np.zeros_like(B)
+        mg.recursiveCycle(p, B, Z, 1)                          # block cycle (SpMM kernels, graphs keyed with nrhs = 4)
+        Zo = orc.recursiveCycle(p, B, np.zeros_like(B), 1, None, "W")
+        assert np.abs(Z - Zo).max() <= RES_TOL * np.abs(Zo).max(), rep
+        X = np.zeros_like(B)
+        mg.solveMG(p, B, X)                                    # column-wise solve (single-vector kernels, nrhs = 1 inside)
+        Xo = np.zeros_like(B)
+        hist = {}
+        orc.solveMG(p, B, Xo, False, hist)
+        assert np.abs(p.resvec - hist["resvec"]).max() / hist["resvec"][0] < RES_TOL, rep
+        assert np.abs(X - Xo).max() <= RES_TOL * np.abs(Xo).max(), rep
+    assert h.graph_launches()[1] >= 2          # (graphs of both kinds are cached side by side)
+    mg.clear_(p)
