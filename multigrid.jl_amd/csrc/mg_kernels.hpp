@@ -2841,7 +2841,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     M4_ACC(acc, (lo_)[s], up_, le_, (val)[s], ri_, dn_, (hi_)[s]);                                                     \
   } while (0)
 // (the stages of an iteration are not interleaved by the scheduler: live ranges stay within 128 / 168 registers)
-#define M4_SCHED __builtin_amdgcn_sched_barrier(0)
+#define M4_SCHED __builtin_amdgcn_sched_barrier(0)   /* (free scheduling of the 768- / 512-thread variants changes nothing: profiles/r05_march4_notes.md) */
     for (int z = zA; z <= zE; ++z) {
       d2_t cur[NPM];
       double b0[K1];
