@@ -103,6 +103,11 @@ def _worker(rank, world, port, case, cyc, mode, q, tol, maxit):
             H.cycle(bt, x2t, False)
             xc = x2t.cpu().numpy()
             extra["exchanges"], extra["sent"] = H.exchanges()
+            try:                # entry points whose sums would run over ghost rows are refused, not computed
+                H.dev.pcg_dev(bt, x2t.clone(), 1e-8, 2)
+                extra["pcg_refused"] = False
+            except mg.device.MGDeviceError as e:
+                extra["pcg_refused"] = "sharded" in str(e)
             extra["four_stage"] = H.dev.four_stage_form(1)[0]
             extra["comm_count"] = H.comm_count()
             H.close()
@@ -257,6 +262,7 @@ def test_ghost_form_early_stop_cpu(mg):
 def test_ghost_form_hip_plugin_vs_oracle(mg, world, case, cyc):
     """The library's schedule (mg_ghost_*) with `world` processes sharing the GPU through the host-staged transport."""
     extra = _check(mg, world, case, cyc, "plugin")
+    assert all(e["pcg_refused"] for e in extra)
     if world > 1:
         assert all(e["exchanges"] > 0 for e in extra)
 
