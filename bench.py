@@ -367,12 +367,21 @@ def main():
     # ---- host setup (CPU, as in the reference) ---------------------------------------------------
     t0 = time.perf_counter()
     if args.workload == "c3":
+        import threading
+        hb_stop = threading.Event()
+
+        def _heartbeat():      # (the SA setup at 256^3 takes minutes on the host: a line a minute says the run is alive)
+            t_hb = time.perf_counter()
+            while not hb_stop.wait(60.0):
+                print(f"[bench] host setup running, {time.perf_counter() - t_hb:.0f} s", file=sys.stderr, flush=True)
+        threading.Thread(target=_heartbeat, daemon=True).start()
         A, mesh = mg.anisotropic_divsiggrad([cells] * 3, weights=(1.0, 0.25, 0.0625))
         t_op = time.perf_counter() - t0
         p = mg.getMGparam(np.float64, np.int64, args.levels or 14, os.cpu_count() or 8, K, 0.0, "SPAI", 1.0, 1, 1, "V",
                           "Julia", 0.4, 0.0)
         t0 = time.perf_counter()
         mg.SA_AMGsetup(A, p, True, nrhs)
+        hb_stop.set()
         desc = (f"SA-AMG (theta=0.4, V(1,1) SPAI w=1) on anisotropic diffusion {cells}^3 cells, edge weights 16:4:1 x "
                 f"log-normal sigma, general CSR")
     else:

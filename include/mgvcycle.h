@@ -523,8 +523,11 @@ int mg_dist_destroy(mg_dist* h);
  * test) and ONE exchange per fused pass: the library tracks on how many ghost layers each level vector is still valid
  * (a product with A costs one) and refreshes all layers at once where the next operation needs more - on the fine level
  * right behind the four-stage pass, overlapped with the whole coarse cycle on a side stream.  Norms are sums over the
- * owned rows of all ranks.  One right-hand side, pointwise smoothers, V / W / F cycles, direct coarsest solve (anything
- * else: mg_dist_*).  Transport: RCCL (the 128-byte id of mg_dist_unique_id) or the host-staged plug-in (ops 0 and 1). */
+ * owned rows of all ranks.  Pointwise smoothers, V / W / F cycles, direct coarsest solve.  A block of 2-24 right-hand sides
+ * (mg_create / mg_set_nrhs before the attach; vectors [n_ext][nrhs] row-major) is SOLVED column by column - mg_solve_dev_FP64
+ * only, where the column-wise solve serves the fine level (four-stage pass, V(2,*)): every column plays the single-vector
+ * schedule with its own exchanges, one Frobenius stopping test over the owned rows of all ranks.  Anything else (a single
+ * block cycle, Jac-GMRES, the K-cycle, general CSR): mg_dist_*.  Transport: RCCL (the 128-byte id of mg_dist_unique_id) or the host-staged plug-in (ops 0 and 1). */
 int mg_ghost_attach(mg_hierarchy* h, long long rank, long long world, long long nlevels_sharded, const char* unique_id128);
 /* (RCCL transport, optional but recommended for world > 1) a SECOND communicator - another id of mg_dist_unique_id - for the
  * ghost-layer send / recv on the side stream: RCCL serialises the operations of one communicator in issue order whatever

@@ -360,7 +360,8 @@ class NativeGhostHierarchy:
         self.G = G
         self.D = D
         self.group = group
-        self.dev = D.DeviceHierarchy(G.param, device_id, 1, options=options)
+        self.nrhs = int(getattr(G.param, "nrhs", 1) or 1)      # (a block is solved column by column: mg_solve_dev_FP64, ghost-layer form)
+        self.dev = D.DeviceHierarchy(G.param, device_id, self.nrhs, options=options)
         self.lib = lib = self.dev.lib
         h = self.dev.handle
         rank, size = G.rank, G.size
@@ -433,8 +434,8 @@ class NativeGhostHierarchy:
         return self.G.levels[0].n
 
     def solve(self, b_ext, x_ext, tol: float, maxIter: int):
-        """solveMG on this rank's extended fine box (device tensors of n_ext doubles; the owned rows of b must be
-        valid, the library fills its ghost layers; x: in/out, owned rows valid on return)."""
+        """solveMG on this rank's extended fine box (device tensors of n_ext doubles - n_ext x nrhs, row-major, for a block; the
+        owned rows of b must be valid, the library fills its ghost layers; x: in/out, owned rows valid on return)."""
         return self.dev.solve_dev(b_ext, x_ext, tol, maxIter)
 
     def cycle(self, b_ext, x_ext, x_is_zero: bool):

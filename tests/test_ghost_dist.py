@@ -279,6 +279,100 @@ def test_ghost_form_hip_early_stop(mg):
     _check(mg, 2, "3d-a2", "V", "plugin", tol=1e-3, maxit=8)
 
 
+def _worker_block(rank, world, port, case, cyc, nrhs, q, tol, maxit, x_nonzero):
+    """A block of right-hand sides in the ghost-layer form: solved column by column on every rank's extended boxes."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        os.environ.update(MG_NO_SMALL="1", MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.05", MG_MARCH_MIN_WG="0",
+                          MG_MARCH_MAX_LEN="64", MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_WINP_MIN_ROWS="0", MG_MARCH27_MIN_ROWS="0",
+                          MG_MARCHR_MIN_ROWS="0", MG_MARCH4_TY_MAX="12")     # (33 lines: an odd count needs more than one tile row)
+        import multigrid_jl_amd as mg
+        from multigrid_jl_amd import ghost_dist as gd
+        from multigrid_jl_amd.structured_setup import poisson_operator
+        p, cells, rb = _param(mg, case, cyc)
+        G = gd.ghost_gmg(cells, _domains(world, len(cells), case), rank, world, p, poisson_operator(cells), replicate_below=rb, nrhs=nrhs)
+        A, mesh = mg.poisson_shifted(cells)
+        B = np.ascontiguousarray(mg.seeded_rhs(A, nrhs)[G.gid_fine])          # n_ext x nrhs, row-major: the device layout of a block
+        own = G.levels[0].own_mask()
+        H = gd.NativeGhostHierarchy(G, 0, transport="plugin" if world > 1 else "rccl")
+        assert H.nrhs == nrhs and H.dev.four_stage_form(1)[0]
+        bt = torch.from_numpy(B).cuda()
+        if x_nonzero:
+            X0 = np.random.default_rng(5).standard_normal((A.shape[0], nrhs))[G.gid_fine]
+            X0[~own] = np.nan                                                  # (only the owned rows of x are the caller's to give)
+            xt = torch.from_numpy(np.ascontiguousarray(X0)).cuda()
+        else:
+            xt = torch.zeros_like(bt)
+        e0 = H.exchanges()
+        it, resvec = H.solve(bt, xt, tol, maxit)
+        e1 = H.exchanges()
+        refused = False
+        try:                       # a single block CYCLE is not a ghost-form entry point
+            H.dev.cycle_dev(bt, xt.clone(), 0)
+        except mg.device.MGDeviceError:
+            refused = True
+        X = xt.cpu().numpy()
+        H.close()
+        out = [None] * world
+        dist.all_gather_object(out, (G.gid_fine[own], X[own], int(it), np.asarray(resvec), e1[0] - e0[0], refused))
+        if rank == 0:
+            Xg = np.zeros((A.shape[0], nrhs))
+            for gid, xl, *_ in out:
+                Xg[gid] = xl
+            q.put(("ok", [o[2] for o in out], [o[3] for o in out], Xg, [o[4] for o in out], [o[5] for o in out]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cyc,nrhs,tol,x_nonzero", [(2, "V", 3, 1e-30, False), (4, "W", 2, 3e-3, False), (2, "V", 2, 1e-30, True), (1, "V", 2, 1e-30, False)])
+def test_ghost_form_block_of_right_hand_sides(mg, world, cyc, nrhs, tol, x_nonzero):
+    """solveMG on an n x k block (SolveFuncs.jl:3-39, one Frobenius stopping test) with the grid cut over `world` ranks in the
+    ghost-layer form: every column plays the single-vector kernels on the rank's extended boxes, the norms are sums over the owned
+    rows of all ranks.  Against the oracle's block solve on the global hierarchy."""
+    from oracle import mg_oracle as orc
+    case, maxit = "3d-a2", 5
+    p, cells, _ = _param(mg, case, cyc)
+    A, mesh = mg.poisson_shifted(cells)
+    mg.MGsetup(A, mesh, p, nrhs)
+    B = mg.seeded_rhs(A, nrhs)
+    Xo = np.asfortranarray(np.random.default_rng(5).standard_normal(B.shape)) if x_nonzero else np.zeros_like(B)
+    p.maxOuterIter, p.relativeTol = maxit, tol
+    hist = {}
+    _, _, ito = orc.solveMG(p, B, Xo, False, hist)
+    res_ref = np.asarray(hist["resvec"])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_block, args=(r, world, port, case, cyc, nrhs, q, tol, maxit, x_nonzero)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    try:
+        res = q.get(timeout=600)
+    finally:
+        for pr in procs:
+            pr.join(timeout=60)
+            if pr.is_alive():
+                pr.kill()
+    assert res[0] == "ok", res[1]
+    _, its, resvecs, X, exch, refused = res
+    assert all(i == ito for i in its), (its, ito)
+    if tol == 3e-3:
+        assert 1 < ito < maxit                     # (meant to stop early)
+    for rv in resvecs:
+        assert np.abs(rv - res_ref).max() <= 1e-10 * res_ref[0]
+    assert np.abs(X - Xo).max() <= 1e-10 * np.abs(Xo).max()
+    assert all(refused)
+    if world > 1:
+        assert all(e > 0 for e in exch)
+
+
 def _worker_c4box(rank, world, port, cells, levels, q, steps):
     """One rank of the C4-sized run in the ghost-layer form: its 257^3 box + ghost layers, plug-in transport."""
     try:
