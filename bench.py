@@ -380,7 +380,9 @@ def main():
         p = mg.getMGparam(np.float64, np.int64, args.levels or 14, os.cpu_count() or 8, K, 0.0, "SPAI", 1.0, 1, 1, "V",
                           "Julia", 0.4, 0.0)
         t0 = time.perf_counter()
-        mg.SA_AMGsetup(A, p, True, nrhs)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):     # (per-level setup times go to stderr: stdout carries the one JSON line)
+            mg.SA_AMGsetup(A, p, True, nrhs, verbose=True)
         hb_stop.set()
         desc = (f"SA-AMG (theta=0.4, V(1,1) SPAI w=1) on anisotropic diffusion {cells}^3 cells, edge weights 16:4:1 x "
                 f"log-normal sigma, general CSR")

@@ -20,8 +20,11 @@ extern "C" {
 
 // aggr_out[k] (1-based root index of the aggregate of node k), length n.
 // Returns 0 on success.
-int mg_sa_aggregate_FP64_INT64(long long n, const long long* colptr, const long long* rowval,
-                               const double* nzval, long long* aggr) {
+// (I: index type; BASE: 1 for the reference's 1-based arrays, 0 for scipy's - CP / RV give the 1-based values either way)
+}  // extern "C"
+template <class I, int BASE>
+static int sa_aggregate_t(long long n, const I* colptr_, const I* rowval_, const double* nzval, long long* aggr) {
+  struct Ptr { const I* p; long long operator[](long long k) const { return (long long)p[k] + (1 - BASE); } } colptr{colptr_}, rowval{rowval_};
   const double tau = 3.0;  // l.121
   std::vector<double> aux((std::size_t)n + 1, 0.0);
   std::vector<long long> aux_count((std::size_t)n + 1, 0);
@@ -86,6 +89,14 @@ int mg_sa_aggregate_FP64_INT64(long long n, const long long* colptr, const long 
   for (long long k = 1; k <= n; ++k)  // l.205-209
     if (aggr[k - 1] < 0) aggr[k - 1] = -aggr[k - 1];
   return 0;
+}
+extern "C" {
+int mg_sa_aggregate_FP64_INT64(long long n, const long long* colptr, const long long* rowval, const double* nzval, long long* aggr) {
+  return sa_aggregate_t<long long, 1>(n, colptr, rowval, nzval, aggr);
+}
+// the same on scipy's 0-based 32-bit CSR arrays of the (symmetric) strength matrix as they are: no widened, shifted copies
+int mg_sa_aggregate_FP64_INT32_BASE0(long long n, const int* ptr, const int* idx, const double* nzval, long long* aggr) {
+  return sa_aggregate_t<int, 0>(n, ptr, idx, nzval, aggr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -253,6 +264,136 @@ int mg_spgemm_fill_FP64_INT32(long long n_rows, long long ncols_B, const int* A_
 }
 
 // ------------------------------------------------------------------------------------------------
+// SpGEMM in a symbolic and a numeric phase (round 5): the Galerkin products of the SA-AMG middle levels are 10^10 - 10^11 products
+// each, and the count + fill pair above walks them twice with a stamp test, a push and a sort in the inner loops.  Here the
+// SYMBOLIC phase finds every output row's sorted pattern once - a per-thread bitmap (set a bit per product, then scan the words
+// between the smallest and the largest column: sorted for free) where a row has many products, a stamped list + sort where it has
+// few - and keeps it in per-thread chunks; the NUMERIC phase zeroes the accumulator at the row's pattern, adds the products with
+// no test at all (same order as a serial Gustavson: same bits) and gathers.  int32 operands, at most DENSE_MAX_COLS columns.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct SpgemmPlan {
+  long long n_rows = 0, ncols = 0;
+  std::vector<std::vector<int>> chunk;          // per thread: the patterns of the rows it took, back to back
+  std::vector<int> owner;                        // [n_rows] thread that holds the row
+  std::vector<long long> where;                  // [n_rows] offset in that thread's chunk
+};
+}  // namespace
+
+void* mg_spgemm_symbolic_INT32(long long n_rows, long long ncols_B, const int* A_ptr, const int* A_idx, const int* B_ptr, const int* B_idx,
+                               long long* C_ptr, long long nthreads) {
+  if (ncols_B > DENSE_MAX_COLS || ncols_B <= 0 || n_rows < 0) return nullptr;
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+  SpgemmPlan* plan = new SpgemmPlan();
+  plan->n_rows = n_rows;
+  plan->ncols = ncols_B;
+  plan->owner.assign((std::size_t)n_rows, 0);
+  plan->where.assign((std::size_t)n_rows, 0);
+  plan->chunk.resize((std::size_t)omp_get_max_threads());
+  const long long nwords = (ncols_B + 63) / 64;
+  C_ptr[0] = 0;
+  bool failed = false;
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num();
+    std::vector<int>& out = plan->chunk[(std::size_t)t];
+    std::vector<unsigned long long> bits;
+    std::vector<int> stamp;
+    try {
+#pragma omp for schedule(dynamic, 16)
+      for (long long i = 0; i < n_rows; ++i) {
+        long long products = 0;
+        for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) products += B_ptr[A_idx[k] + 1] - B_ptr[A_idx[k]];
+        plan->owner[(std::size_t)i] = t;
+        plan->where[(std::size_t)i] = (long long)out.size();
+        if (products == 0) { C_ptr[i + 1] = 0; continue; }
+        const std::size_t at = out.size();
+        if (products * 4 >= nwords) {            // bitmap: the scan of at most nwords words is no more than the products it replaces a sort of
+          if (bits.empty()) bits.assign((std::size_t)nwords, 0ull);
+          int cmin = 0x7fffffff, cmax = -1;
+          for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) {
+            const int r = A_idx[k];
+            const int q0 = B_ptr[r], q1 = B_ptr[r + 1];
+            if (q1 > q0) {                       // (rows of B are sorted: their ends bound the columns)
+              cmin = std::min(cmin, B_idx[q0]);
+              cmax = std::max(cmax, B_idx[q1 - 1]);
+            }
+            // (a sorted row of B fills one word after the other: the word is built in a register and written once)
+            unsigned wcur = q1 > q0 ? (unsigned)B_idx[q0] >> 6 : 0u;
+            unsigned long long m = 0ull;
+            for (int q = q0; q < q1; ++q) {
+              const unsigned c = (unsigned)B_idx[q], wc = c >> 6;
+              if (wc != wcur) { bits[wcur] |= m; m = 0ull; wcur = wc; }
+              m |= 1ull << (c & 63u);
+            }
+            if (m) bits[wcur] |= m;
+          }
+          for (long long w = cmin >> 6; w <= (cmax >> 6); ++w) {
+            unsigned long long v = bits[(std::size_t)w];
+            if (!v) continue;
+            bits[(std::size_t)w] = 0ull;
+            while (v) {
+              out.push_back((int)(w * 64 + __builtin_ctzll(v)));
+              v &= v - 1;
+            }
+          }
+        } else {
+          if (stamp.empty()) stamp.assign((std::size_t)ncols_B, -1);
+          for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) {
+            const int r = A_idx[k];
+            for (int q = B_ptr[r]; q < B_ptr[r + 1]; ++q) {
+              const int c = B_idx[q];
+              if (stamp[(std::size_t)c] != (int)i) { stamp[(std::size_t)c] = (int)i; out.push_back(c); }
+            }
+          }
+          std::sort(out.begin() + (std::ptrdiff_t)at, out.end());
+        }
+        C_ptr[i + 1] = (long long)(out.size() - at);
+      }
+    } catch (...) {
+#pragma omp critical
+      failed = true;
+    }
+  }
+  if (failed) { delete plan; return nullptr; }
+  for (long long i = 0; i < n_rows; ++i) C_ptr[i + 1] += C_ptr[i];
+  return plan;
+}
+
+void mg_spgemm_plan_free(void* plan) { delete static_cast<SpgemmPlan*>(plan); }
+
+// C_ptr: the prefix sums the symbolic phase returned; C_idx / C_val: C_ptr[n_rows] entries.  Frees the plan.
+int mg_spgemm_numeric_FP64_INT32(void* plan_, const int* A_ptr, const int* A_idx, const double* A_val, const int* B_ptr, const int* B_idx,
+                                 const double* B_val, const long long* C_ptr, int* C_idx, double* C_val, long long nthreads) {
+  SpgemmPlan* plan = static_cast<SpgemmPlan*>(plan_);
+  if (!plan) return 1;
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+  const long long n_rows = plan->n_rows;
+#pragma omp parallel
+  {
+    std::vector<double> acc((std::size_t)plan->ncols, 0.0);
+#pragma omp for schedule(dynamic, 16)
+    for (long long i = 0; i < n_rows; ++i) {
+      const long long out0 = C_ptr[i], cnt = C_ptr[i + 1] - C_ptr[i];
+      if (cnt == 0) continue;
+      const int* pat = plan->chunk[(std::size_t)plan->owner[(std::size_t)i]].data() + plan->where[(std::size_t)i];
+      int* ci = C_idx + out0;
+      for (long long j = 0; j < cnt; ++j) { ci[j] = pat[j]; acc[(std::size_t)pat[j]] = 0.0; }
+      for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) {
+        const int r = A_idx[k];
+        const double a = A_val[k];
+        const int q1 = B_ptr[r + 1];
+        for (int q = B_ptr[r]; q < q1; ++q) acc[(std::size_t)B_idx[q]] += a * B_val[q];
+      }
+      double* cv = C_val + out0;
+      for (long long j = 0; j < cnt; ++j) cv[j] = acc[(std::size_t)ci[j]];
+    }
+  }
+  delete plan;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Transposes of the setup (SA-AMG.jl:47 `R = P'`, l.115 `S + S'`): scipy's csc_tocsr is a serial scatter - 30 s of a 150 s setup
 // at 96^3 cells.  mg_csr_transpose: counting sort by column with per-column cursors, then every output row sorted by its
 // (distinct) column = input row index: the stored-order CSR of the transpose, whatever the thread count.
@@ -313,6 +454,51 @@ int mg_csr_add_transpose_symm_FP64_INT32(long long n, const int* ptr, const int*
       out[k] = val[k] + val[f - idx];
     }
   return bad;
+}
+
+// Entries of a CSR matrix that are not zero, rows in place (scipy's eliminate_zeros into NEW arrays, thread-parallel):
+// new_ptr[n + 1]; out_idx / out_val sized for nnz entries, the first new_ptr[n] are written.
+int mg_csr_compact_nonzero_FP64_INT32(long long n, const int* ptr, const int* idx, const double* val, int* new_ptr, int* out_idx, double* out_val,
+                                      long long nthreads) {
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+  new_ptr[0] = 0;
+#pragma omp parallel for schedule(static)
+  for (long long i = 0; i < n; ++i) {
+    int c = 0;
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k) c += val[k] != 0.0;
+    new_ptr[i + 1] = c;
+  }
+  for (long long i = 0; i < n; ++i) new_ptr[i + 1] += new_ptr[i];
+#pragma omp parallel for schedule(static)
+  for (long long i = 0; i < n; ++i) {
+    int q = new_ptr[i];
+    for (int k = ptr[i]; k < ptr[i + 1]; ++k)
+      if (val[k] != 0.0) { out_idx[q] = idx[k]; out_val[q] = val[k]; ++q; }
+  }
+  return 0;
+}
+
+// s[j] = sum_i A[i,j]^2 (the column sums of squares getSPAIprec divides the diagonal by, MGsetup.jl:359-362).  Every thread owns a
+// contiguous range of COLUMNS and walks all rows (sorted: a binary search finds its part of a row), so every s[j] is summed in row
+// order - the bits of the serial scatter it replaces, whatever the thread count.
+int mg_csr_colsumsq_FP64_INT32(long long n_rows, long long n_cols, const int* ptr, const int* idx, const double* val, double* out, long long nthreads) {
+  if (nthreads > 0) omp_set_num_threads((int)nthreads);
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+    const int c0 = (int)(n_cols * t / nt), c1 = (int)(n_cols * (t + 1) / nt);
+    for (int j = c0; j < c1; ++j) out[j] = 0.0;
+    if (c1 > c0)
+      for (long long i = 0; i < n_rows; ++i) {
+        const int* lo = idx + ptr[i];
+        const int* hi = idx + ptr[i + 1];
+        for (const int* q = std::lower_bound(lo, hi, c0); q < hi && *q < c1; ++q) {
+          const double v = val[q - idx];
+          out[*q] += v * v;
+        }
+      }
+  }
+  return 0;
 }
 
 // getStrengthMatrix before the symmetrisation (SA-AMG.jl:88-113), row-parallel: out = -val scaled per row by 1 / max(mm, largest

@@ -34,12 +34,24 @@ def lib():
         _lib.mg_spgemm_fill_FP64_INT32.restype = C.c_int
         _lib.mg_spgemm_fill_FP64_INT32.argtypes = [C.c_longlong, C.c_longlong, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _i64p, _i32p, _f64p,
                                                    C.c_longlong]
+        _lib.mg_spgemm_symbolic_INT32.restype = C.c_void_p
+        _lib.mg_spgemm_symbolic_INT32.argtypes = [C.c_longlong, C.c_longlong, _i32p, _i32p, _i32p, _i32p, _i64p, C.c_longlong]
+        _lib.mg_spgemm_numeric_FP64_INT32.restype = C.c_int
+        _lib.mg_spgemm_numeric_FP64_INT32.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _i64p, _i32p, _f64p, C.c_longlong]
+        _lib.mg_spgemm_plan_free.restype = None
+        _lib.mg_spgemm_plan_free.argtypes = [C.c_void_p]
         _lib.mg_csr_transpose_FP64_INT32.restype = C.c_int
         _lib.mg_csr_transpose_FP64_INT32.argtypes = [C.c_longlong, C.c_longlong, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, C.c_longlong]
         _lib.mg_sa_strength_FP64_INT32.restype = C.c_int
         _lib.mg_sa_strength_FP64_INT32.argtypes = [C.c_longlong, _i32p, _i32p, _f64p, C.c_double, _f64p, C.c_longlong]
         _lib.mg_csr_add_transpose_symm_FP64_INT32.restype = C.c_int
         _lib.mg_csr_add_transpose_symm_FP64_INT32.argtypes = [C.c_longlong, _i32p, _i32p, _f64p, _f64p, C.c_longlong]
+        _lib.mg_csr_compact_nonzero_FP64_INT32.restype = C.c_int
+        _lib.mg_csr_compact_nonzero_FP64_INT32.argtypes = [C.c_longlong, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, C.c_longlong]
+        _lib.mg_csr_colsumsq_FP64_INT32.restype = C.c_int
+        _lib.mg_csr_colsumsq_FP64_INT32.argtypes = [C.c_longlong, C.c_longlong, _i32p, _i32p, _f64p, _f64p, C.c_longlong]
+        _lib.mg_sa_aggregate_FP64_INT32_BASE0.restype = C.c_int
+        _lib.mg_sa_aggregate_FP64_INT32_BASE0.argtypes = [C.c_longlong, _i32p, _i32p, _f64p, _i64p]
     return _lib
 
 
@@ -76,6 +88,22 @@ def spgemm(A, B, nthreads: int = 0):
     Bv = np.ascontiguousarray(B.data, dtype=np.float64)
     if A.indices.dtype == np.int32 and B.indices.dtype == np.int32 and A.indptr.dtype == np.int32 and B.indptr.dtype == np.int32:
         Ap, Ai, Bp, Bi = (np.ascontiguousarray(v) for v in (A.indptr, A.indices, B.indptr, B.indices))
+        if not os.environ.get("MG_HOST_SPGEMM_TWO_PASS") and B.has_sorted_indices:
+            # symbolic phase (sorted patterns, kept on the native side) + numeric phase: one walk over the products each, no sort / test in the second
+            plan = L.mg_spgemm_symbolic_INT32(n, B.shape[1], _p32(Ap), _p32(Ai), _p32(Bp), _p32(Bi), _p64(Cp), nthreads)
+            if plan:
+                nnz = int(Cp[-1])
+                if max(nnz, B.shape[1]) < 2 ** 31 - 1:
+                    Ci = np.empty(max(nnz, 1), dtype=np.int32)
+                    Cv = np.empty(max(nnz, 1), dtype=np.float64)
+                    rc = L.mg_spgemm_numeric_FP64_INT32(plan, _p32(Ap), _p32(Ai), _pf(Av), _p32(Bp), _p32(Bi), _pf(Bv), _p64(Cp), _p32(Ci), _pf(Cv), nthreads)
+                    if rc != 0:
+                        raise RuntimeError(f"mg_spgemm_numeric_FP64_INT32 failed (status {rc})")
+                    Cm = sp.csr_matrix((Cv[:nnz], Ci[:nnz], Cp.astype(np.int32)), shape=(n, B.shape[1]))
+                    Cm.has_sorted_indices = True
+                    return Cm
+                L.mg_spgemm_plan_free(plan)
+            Cp[:] = 0
         rc = L.mg_spgemm_count_INT32(n, B.shape[1], _p32(Ap), _p32(Ai), _p32(Bp), _p32(Bi), _p64(Cp), nthreads)
         if rc != 0:
             raise RuntimeError(f"mg_spgemm_count_INT32 failed (status {rc})")
@@ -134,14 +162,58 @@ def transpose_csr(M, nthreads: int = 0):
 
 
 def add_transpose(S, nthreads: int = 0):
-    """S + S' (SA-AMG.jl:115) with the pattern of S - a structurally symmetric S with sorted rows, thread-parallel; falls back to scipy otherwise."""
+    """S + S' (SA-AMG.jl:115) WITHOUT the entries that sum to zero (Julia's sparse `+` stores non-zero results only), rows sorted - for a
+    structurally symmetric S with sorted rows thread-parallel on the host, into arrays of its own; scipy otherwise."""
     S = sp.csr_matrix(S)
     if S.shape[0] == S.shape[1] and S.indices.dtype == np.int32 and S.indptr.dtype == np.int32 and S.has_sorted_indices and S.nnz > 0:
+        n = S.shape[0]
         ptr, idx, val = np.ascontiguousarray(S.indptr), np.ascontiguousarray(S.indices), np.ascontiguousarray(S.data, dtype=np.float64)
         out = np.empty(S.nnz, dtype=np.float64)
-        if lib().mg_csr_add_transpose_symm_FP64_INT32(S.shape[0], _p32(ptr), _p32(idx), _pf(val), _pf(out), _threads(nthreads)) == 0:
-            return sp.csr_matrix((out, idx.copy(), ptr.copy()), shape=S.shape)      # (own index arrays: the caller eliminates zeros in place)
-    return (S + S.T).tocsr()
+        if lib().mg_csr_add_transpose_symm_FP64_INT32(n, _p32(ptr), _p32(idx), _pf(val), _pf(out), _threads(nthreads)) == 0:
+            nptr = np.empty(n + 1, dtype=np.int32)
+            nidx = np.empty(S.nnz, dtype=np.int32)
+            nval = np.empty(S.nnz, dtype=np.float64)
+            if lib().mg_csr_compact_nonzero_FP64_INT32(n, _p32(ptr), _p32(idx), _pf(out), _p32(nptr), _p32(nidx), _pf(nval), _threads(nthreads)) == 0:
+                nnz = int(nptr[-1])
+                T = sp.csr_matrix((nval[:nnz], nidx[:nnz], nptr), shape=S.shape)
+                T.has_sorted_indices = True
+                return T
+    T = (S + S.T).tocsr()
+    T.eliminate_zeros()
+    T.sort_indices()
+    return T
+
+
+def col_sumsq(A, nthreads: int = 0):
+    """s[j] = sum_i A[i,j]^2 (getSPAIprec, MGsetup.jl:359-362), thread-parallel on the host; None when the operand does not fit the native path."""
+    if not sp.isspmatrix_csr(A) or A.indices.dtype != np.int32 or A.indptr.dtype != np.int32 or A.nnz == 0 or A.data.dtype != np.float64:
+        return None
+    ptr, idx, val = np.ascontiguousarray(A.indptr), np.ascontiguousarray(A.indices), np.ascontiguousarray(A.data)
+    out = np.empty(A.shape[1], dtype=np.float64)
+    if lib().mg_csr_colsumsq_FP64_INT32(A.shape[0], A.shape[1], _p32(ptr), _p32(idx), _pf(val), _pf(out), _threads(nthreads)) != 0:
+        return None
+    return out
+
+
+def sa_aggregate(S):
+    """neighborhoodAggregationNew (SA-AMG.jl:119-211) on the CSR arrays of the symmetric strength matrix (= its CSC arrays): aggr[k] = 1-based
+    root of node k's aggregate."""
+    S = sp.csr_matrix(S)
+    if not S.has_sorted_indices:
+        S.sort_indices()
+    n = S.shape[0]
+    aggr = np.zeros(n, dtype=np.int64)
+    val = np.ascontiguousarray(S.data, dtype=np.float64)
+    if S.indices.dtype == np.int32 and S.indptr.dtype == np.int32:
+        ptr, idx = np.ascontiguousarray(S.indptr), np.ascontiguousarray(S.indices)
+        rc = lib().mg_sa_aggregate_FP64_INT32_BASE0(n, _p32(ptr), _p32(idx), _pf(val), _p64(aggr))
+    else:
+        colptr = np.ascontiguousarray(S.indptr, dtype=np.int64) + 1
+        rowval = np.ascontiguousarray(S.indices, dtype=np.int64) + 1
+        rc = lib().mg_sa_aggregate_FP64_INT64(n, _p64(colptr), _p64(rowval), _pf(val), _p64(aggr))
+    if rc != 0:
+        raise RuntimeError("aggregation failed")
+    return aggr
 
 
 def sa_strength(A, theta: float, nthreads: int = 0):

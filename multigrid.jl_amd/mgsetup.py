@@ -48,7 +48,10 @@ def getSPAIprec(A):
     (equal to the row norm only for symmetric A).
     """
     A = _as_csr(A)
-    s = np.bincount(A.indices, weights=A.data * A.data, minlength=A.shape[1])
+    from .hostlib import col_sumsq
+    s = col_sumsq(A)                                # (thread-parallel on the host; the scipy / numpy line below otherwise)
+    if s is None:
+        s = np.bincount(A.indices, weights=A.data * A.data, minlength=A.shape[1])
     return A.diagonal() / s
 
 

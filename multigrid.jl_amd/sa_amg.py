@@ -23,7 +23,7 @@ import scipy.sparse as sp
 from .mgdef import MGparam, _release_device
 from .mgsetup import _as_csr, adjustMemoryForNumRHS, defineCoarsestAinv, galerkin, getRelaxPrec
 
-from .hostlib import add_transpose, lib as _hostlib, sa_strength, spgemm, transpose_csr
+from .hostlib import add_transpose, sa_aggregate, sa_strength, spgemm, transpose_csr
 
 
 def getStrengthMatrix(A, strengthConnParam: float):
@@ -34,10 +34,7 @@ def getStrengthMatrix(A, strengthConnParam: float):
     n = A.shape[0]
     S = sa_strength(A, strengthConnParam)           # (row-parallel native form of the lines below: same operations, same order)
     if S is not None:
-        S = add_transpose(S)
-        S.eliminate_zeros()
-        S.sort_indices()
-        return S
+        return add_transpose(S)                     # (S + S' without the entries that sum to zero, rows sorted)
     S = (-A).tocsr()
     S.sort_indices()
     mm = 1e-16 * S.data.max()
@@ -48,27 +45,12 @@ def getStrengthMatrix(A, strengthConnParam: float):
     S.data = S.data * (1.0 / rowmax)[rows]          # scal_k = 1/maxVal_j; nzval *= scal_k (l.100-103)
     S.data[S.indices == rows] = 1.0
     S.data[S.data < strengthConnParam] = 0.0
-    S = add_transpose(S)                            # S + S' (l.115): thread-parallel on the host for the symmetric pattern A gives S
-    S.eliminate_zeros()
-    S.sort_indices()
-    return S
+    return add_transpose(S)                         # S + S' (l.115): thread-parallel on the host for the symmetric pattern A gives S
 
 
 def neighborhoodAggregationNew(S):
     """Three-pass greedy aggregation (SA-AMG.jl:119-211), executed by the native helper."""
-    S = sp.csr_matrix(S)
-    S.sort_indices()
-    n = S.shape[0]
-    colptr = np.ascontiguousarray(S.indptr, dtype=np.int64) + 1       # S symmetric: CSR arrays == CSC arrays
-    rowval = np.ascontiguousarray(S.indices, dtype=np.int64) + 1
-    nzval = np.ascontiguousarray(S.data, dtype=np.float64)
-    aggr = np.zeros(n, dtype=np.int64)
-    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_longlong))
-    rc = _hostlib().mg_sa_aggregate_FP64_INT64(n, p64(colptr), p64(rowval), nzval.ctypes.data_as(C.POINTER(C.c_double)),
-                                               p64(aggr))
-    if rc != 0:
-        raise RuntimeError("aggregation failed")
-    return aggr
+    return sa_aggregate(S)                                            # (S symmetric: CSR arrays == CSC arrays)
 
 
 def aggrArray2P(aggr):
@@ -116,8 +98,10 @@ def SA_AMGsetup(A, param: MGparam, symm: bool = True, nrhs: int = 1, verbose: bo
             param.levels = l                                             # l.35-42: relaxPrecs[1:l-1]
             break
         relaxPrecs.append(d)
-        DA = sp.diags(d) @ Al                                            # (AT*diag(d))' (l.44)
-        rho = min(float(abs(DA).sum()), float(abs(DA.data).max()))       # entry-wise norms (l.45)
+        DA = sp.csr_matrix((Al.data * np.repeat(d, np.diff(Al.indptr)), Al.indices, Al.indptr), shape=Al.shape)   # (AT*diag(d))' (l.44): row i times d[i]
+        absDA = np.abs(DA.data)
+        rho = min(float(absDA.sum()), float(absDA.max()))                # entry-wise norms (l.45)
+        del absDA
         P = (P0 - (1.33 / rho) * spgemm(DA, P0)).tocsr()                 # l.46
         P.sort_indices()
         R = transpose_csr(P)                                             # l.47

@@ -59,7 +59,7 @@ MG_NO_LONGROW=1 python bench.py --workload c3 --cells 128 --steps 10 --warmup 2 
 echo "c3-128 done" >> $out/progress4.txt
 fi
 if [ "$part" = "5" ]; then
-python bench.py --workload c3 --steps 10 --warmup 2 --no-cpu-baseline > $out/c3_256_bench.json 2> $out/c3_256_bench.err
+OMP_NUM_THREADS=16 MG_HOST_THREADS=16 python bench.py --workload c3 --steps 10 --warmup 2 --no-cpu-baseline > $out/c3_256_bench.json 2> $out/c3_256_bench.err
 echo "c3-256 done" > $out/progress5.txt
 fi
 find $out -name "*.csv" -size +1M -delete
