@@ -361,6 +361,12 @@ int mg_op_bind_relax_dev_FP64(mg_operator* op, const double* d_dev, long long n)
  * geometry); geometry (optional, 12 entries, forms 3 and 4): tiles per line, tiles per column, TX, TY, rows per lane, workgroups, LDS bytes, estimated fill bytes per row x
  * 100, threads per workgroup, segments of the lockstep schedule (0: balanced), planes per segment, class-table entries. */
 int mg_sweep_residual_form(mg_hierarchy* h, long long level, long long* form, long long* geometry);
+/* Band form (form 4 above) of level `level`: info[0] = 1 when it is held; info[1] = 1 when the 7 value planes are in canonical
+ * slots (-z, -y, -x, diagonal, +x, +y, +z: every structure class a 7-point star); info[2] = 1 when the values are symmetric
+ * entry by entry (checked on the device whenever the values change: G' diag(sigma) G is) - the pass then reads the three lower
+ * entries of a row from the upper ones of its neighbours; info[3] = value planes streamed from HBM per pass (7, or 4).
+ * info[0] = 2: the level holds the band-27 form (27 planar arrays, kernel_variant 9); info[2] / info[3] likewise (27, or 14). */
+int mg_band_form(mg_hierarchy* h, long long level, long long* info);
 /* kernel variant serving the operator at nrhs == 1 (as mg_operator_rowclass_flags) and its exception rows */
 int mg_op_kernel_variant(mg_operator* op, long long* variant, long long* exception_rows);
 int mg_op_destroy(mg_operator* op);

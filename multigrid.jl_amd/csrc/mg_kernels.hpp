@@ -2095,6 +2095,10 @@ struct March3Dev {
   int n_cols, ncls;
   const double* vband;          // VAR (coefficients differ from row to row): 7 planar arrays of n_rows values, slot k at
   long long vstride;            // vband + k*vstride: k = 0 the z-1 entry, 1..5 the in-plane entries in stored order, 6 the z+1 entry
+  long long vsrc[RM3_NIP + 2];  // where slot k of row r is READ: vband[vsrc[k] + r].  k*vstride; for a symmetric operator in canonical slots
+                                // (build_band) the three lower entries come from the upper ones of the neighbour - slot 0 of row r = slot 6
+                                // of row r - P, slot 1 = slot 5 of row r - n1, slot 2 = slot 4 of row r - 1 (zeros in front of every slot) -
+                                // so that 4 of the 7 planes are streamed from HBM, the other three reads hit lines just fetched
   int has_exc;                  // box operator of a sharded level: the table holds 0xFFFF for rows that read the halo (neither
                                 // stage is computed here) and cmap continues with sx[n1] | sy[n2] | sz[nplanes]: stage 2 of
                                 // row (x, y, z) is left out where sx[x] | sy[y] | sz[z] (a neighbour is such a row)
@@ -2139,6 +2143,10 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       for (int i = tid; i < T.ncls; i += NT) dd[i] = C.cls_d[i];
     const int nm = (T.n1 + T.n2 + T.nplanes) * (T.has_exc ? 2 : 1) + T.ntab;
     for (int i = tid; i < nm; i += NT) cxL[i] = T.cmap[i];
+    // band form in canonical slots: a row without some neighbour still reads that neighbour's place (times the 0 in its slot) - the
+    // t slabs hold computed rows only, so every entry starts finite
+    if (VAR)
+      for (int i = tid; i < 2 * TS; i += NT) tw[i] = 0.0;
   }
   const int zstride = T.ncy * T.ncx;            // class = tabL[cz[z]*zstride + (cy[y]*ncx + cx[x])]
   // ---- the lane's place: column xx of the stage-1 region, lines j + s*SY ---------------------------------------------
@@ -2345,7 +2353,7 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march3_spmv(RowClassDev C, Ma
       nbb[PB_][s_] = a.b[r_];                                                                                          \
       if (VAR) {                                                                                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < NV; ++k_)                                                              \
-          nvb[PB_][s_ % KV][k_] = T.vband[(size_t)k_ * (size_t)T.vstride + (size_t)r_];                                \
+          nvb[PB_][s_ % KV][k_] = T.vband[T.vsrc[k_] + (long long)r_];                                                 \
         ndb[PB_][s_ % KV] = a.d[r_];                                                                                   \
       }                                                                                                                \
     }                                                                                                                  \
@@ -3011,6 +3019,16 @@ __global__ __launch_bounds__(BLK) void band_fill(const int* __restrict__ rowptr,
   if (i >= n) return;
   const int c = cls[i], k0 = rowptr[i], len = rowptr[i + 1] - k0;
   for (int e = 0; e < len && e < ns; ++e) vband[(size_t)slot[c * ns + e] * (size_t)vstride + (size_t)i] = val[k0 + e];
+}
+
+// Is a band in canonical slots (0: -z, 1: -y, 2: -x, 3: diagonal, 4: +x, 5: +y, 6: +z) symmetric entry by entry - A[r, r-s] == A[r-s, r]
+// for s = P, n1, 1?  bad += rows where it is not (the entries in front of a slot are zeros: a row without the neighbour must hold 0)
+__global__ __launch_bounds__(BLK) void band_sym_check(const double* __restrict__ vband, long long vstride, int n, int n1, int P, int* bad) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const double* s0 = vband;
+  const bool ok = s0[i] == s0[6 * vstride + i - P] && s0[vstride + i] == s0[5 * vstride + i - n1] && s0[2 * vstride + i] == s0[4 * vstride + i - 1];
+  if (!ok) atomicAdd(bad, 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -133,10 +133,28 @@ __global__ __launch_bounds__(256) void grid_small_prolong(SmallPDev T, const dou
 // 27 coalesced value loads + 27 gathers of x issued at once, products added in (dz, dy, dx) = CSR order.  216 + 8..32 B per row.
 // ------------------------------------------------------------------------------------------------------------------------------
 struct Band27Dev {
-  const double* val;   // [27][stride]
+  const double* val;   // [27][stride]; every slot is followed by zeros (stride >= n + P + n1 + 1)
   long long stride;
   int n1, n2, n3, P, n;
+  int sym;             // the values are symmetric entry by entry up to the rounding of the Galerkin product R*(A*P) that made them
+                       // (band27_sym_check: |A[i,j] - A[j,i]| <= 2^-50 |A[i,i]|; measured 1e-16 on div sigma grad): the 13 lower slots of row r are READ from the upper
+                       // slots of the neighbour - slot (dz,dy,dx) of row r = slot (-dz,-dy,-dx) of row r + dz*P + dy*n1 + dx - so that
+                       // 14 of the 27 planes are streamed from HBM; workgroups then take rows in XCD bands (the re-read lines sit in that L2)
 };
+// bad += rows whose lower entries differ from the neighbours' upper ones by more than the rounding of a Galerkin product (the two
+// are sums of the same terms in different orders); an entry one side has and the other lacks (a 0) counts unless it is that small
+__global__ __launch_bounds__(256) void band27_sym_check(Band27Dev T, int* __restrict__ bad) {
+  const int row = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (row >= T.n) return;
+  const double tol = 8.8817841970012523e-16 * fabs(T.val[13LL * T.stride + row]);   // 2^-50 |A[i,i]|
+  bool ok = true;
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    const int dz = s / 9 - 1, dy = (s / 3) % 3 - 1, dx = s % 3 - 1;
+    ok = ok && fabs(T.val[(long long)s * T.stride + row] - T.val[(long long)(26 - s) * T.stride + row + dz * T.P + dy * T.n1 + dx]) <= tol;
+  }
+  if (!ok) atomicAdd(bad, 1);
+}
 // flag |= 1 if a row has an entry outside the 3 x 3 x 3 neighbourhood of its node or out of ascending order (the form is then dropped)
 __global__ __launch_bounds__(256) void band27_fill(CsrDev A, int n1, int n2, int n3, double* __restrict__ val, long long stride, int* __restrict__ flag) {
   const int row = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -161,7 +179,7 @@ __global__ __launch_bounds__(256) void band27_fill(CsrDev A, int n1, int n2, int
 // y = b - A x (RESID), y = x + d.*(b - A x) (SMOOTH), y = alpha A x + beta y (AXPBY)
 template <int MODE>
 __global__ __launch_bounds__(256) void grid27_band_spmv(Band27Dev T, VecArgs v) {
-  const int row = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int row = (int)((T.sym ? xcd_band((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 256 + threadIdx.x);
   if (row >= T.n) return;
   double rv[27], xv[27];
 #pragma unroll
@@ -173,7 +191,8 @@ __global__ __launch_bounds__(256) void grid27_band_spmv(Band27Dev T, VecArgs v) 
         const int s = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
         int j = row + dz * T.P + dy * T.n1 + dx;
         j = j < 0 ? 0 : (j >= T.n ? T.n - 1 : j);     // (an entry the row does not have: value 0 times some valid, finite x)
-        rv[s] = T.val[(long long)s * T.stride + row];
+        const long long src = (s < 13 && T.sym) ? (long long)(26 - s) * T.stride + (dz * T.P + dy * T.n1 + dx) : (long long)s * T.stride;   // (uniform)
+        rv[s] = T.val[src + row];
         xv[s] = v.x[j];
       }
   double acc = 0.0;

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mg_set_coarse_gmres_FP64": (C.c_int, [_vp, _ll, _dp]),
     "mg_finalize": (C.c_int, [_vp]),
     "mg_set_nrhs": (C.c_int, [_vp, _ll]),
+    "mg_band_form": (C.c_int, [_vp, _ll, C.POINTER(C.c_longlong)]),
     "mg_replace_values_FP64": (C.c_int, [_vp, _ll, _ll, _dp, _ll]),
     "mg_rap_FP64": (C.c_int, [_vp, _dp, _ll, _ll, _dp, _lp]),
     "mg_get_values_FP64": (C.c_int, [_vp, _ll, _ll, _dp, _ll]),
@@ -647,6 +648,12 @@ class DeviceHierarchy:
         g = (C.c_longlong * 12)()
         _check(self.lib, self.lib.mg_sweep_residual_form(self.handle, level, C.byref(f), g), "mg_sweep_residual_form")
         return int(f.value), [int(v) for v in g]
+
+    def band_form(self, level: int):
+        """[held, canonical slots, symmetric reads, value planes streamed per pass] of the level's band form (mg_band_form)."""
+        g = (C.c_longlong * 4)()
+        _check(self.lib, self.lib.mg_band_form(self.handle, level, g), "mg_band_form")
+        return [int(v) for v in g]
 
     def operator_kernel_variant(self, level: int, which: int) -> int:
         """-1 streaming formats, 0 csr_rowclass_spmv, 1 csr_rowclass_window_spmv, 2 csr_rowclass_tile_spmv, 3 csr_rowclass_march_spmv,

@@ -894,12 +894,15 @@ def test_band_form_variable_coefficients(mg, built, monkeypatch, cells, k1, tile
     rng = np.random.default_rng(sum(cells) + 3)
     outs, runs = {}, {}
     xn_ = bn = None
-    for name, off in (("band", "0"), ("csr", "1")):
+    for name, off in (("band", "0"), ("band7", "0"), ("csr", "1")):
         monkeypatch.setenv("MG_NO_BAND", off)
+        monkeypatch.setenv("MG_NO_BAND_SYM", "1" if name == "band7" else "0")
         A, p, b = _setup_divsiggrad(mg, cells, 2, relax, 0.8 if relax == "Jac" else 1.0)
         h = mg.to_device(p)
         form, geo = h.sweep_residual_form(1)
         assert form == (4 if off == "0" else 0), (form, geo)
+        # G' diag(sigma) G is symmetric entry by entry: the pass reads the lower entries from the neighbours' upper ones (4 planes of 7)
+        assert h.band_form(1) == ([1, 1, 1, 4] if name == "band" else [1, 1, 0, 7] if name == "band7" else [0, 0, 0, 0])
         assert h.operator_rowclasses(1, D.MG_OP_A)[0] == 0          # really no row classes
         Al, dl = p.As[0], p.relaxPrecs[0]
         if xn_ is None:
@@ -946,9 +949,46 @@ def test_band_form_variable_coefficients(mg, built, monkeypatch, cells, k1, tile
             assert p.device is dev_before and p.device.sweep_residual_form(1)[0] == 4
             _compare_solve(mg, p, mg.seeded_rhs(A2, 1))
         mg.clear_(p)
+    for q in range(3):        # the symmetric reads substitute equal values: the same bits as the 7-plane reads
+        assert np.array_equal(runs["band"][q], runs["band7"][q])
     assert np.abs(runs["band"][0] - runs["csr"][0]).max() <= 1e-11 * np.abs(runs["csr"][0]).max()
     assert np.abs(runs["band"][1] - runs["csr"][1]).max() <= 1e-11 * runs["csr"][1][0]
     assert np.abs(runs["band"][2] - runs["csr"][2]).max() <= 1e-11 * np.abs(runs["csr"][2]).max()
+
+
+@pytest.mark.gpu
+def test_band_form_of_a_nonsymmetric_operator_reads_seven_planes(mg, built, monkeypatch):
+    """The symmetric reads of the band form are decided by a device check of the VALUES: rows of div sigma grad scaled by a random
+    diagonal keep the 7-point structure (canonical slots) but are no longer symmetric - the pass must stream all 7 planes, and
+    t, r, ||r|| must still agree with numpy; after the symmetric values are put back (replaceMatrixInHierarchy) it reads 4."""
+    import torch
+    import scipy.sparse as sp
+    monkeypatch.setenv("MG_BAND_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
+    cells = [33, 25, 9]
+    A, p, b = _setup_divsiggrad(mg, cells, 2)
+    rng = np.random.default_rng(8)
+    Ans = (sp.diags(np.exp(0.3 * rng.standard_normal(A.shape[0]))) @ A).tocsr()
+    Ans.sort_indices()
+    mesh = mg.getRegularMesh([0.0, 1.0] * 3, cells)
+    mg.MGsetup(Ans, mesh, p, 1)
+    h = mg.to_device(p)
+    assert h.sweep_residual_form(1)[0] == 4 and h.band_form(1) == [1, 1, 0, 7]
+    Al, dl = p.As[0], p.relaxPrecs[0]
+    xn_, bn = rng.standard_normal(Al.shape[0]), rng.standard_normal(Al.shape[0])
+    t_want = xn_ + dl * (bn - Al @ xn_)
+    r_want = bn - Al @ t_want
+    x, bb = torch.from_numpy(xn_).cuda(), torch.from_numpy(bn).cuda()
+    t, r = torch.zeros_like(x), torch.zeros_like(x)
+    nrm = h.sweep_residual_dev(1, bb, x, t, r, None, True)
+    assert np.abs(t.cpu().numpy() - t_want).max() / np.abs(t_want).max() < KERNEL_TOL
+    assert np.abs(r.cpu().numpy() - r_want).max() / np.abs(r_want).max() < 10 * KERNEL_TOL
+    assert abs(nrm - np.linalg.norm(r_want)) < 1e-12 * np.linalg.norm(r_want)
+    _compare_solve(mg, p, mg.seeded_rhs(Ans, 1))
+    mg.replaceMatrixInHierarchy(p, A)                       # symmetric values, same pattern: the check runs again
+    assert p.device.band_form(1) == [1, 1, 1, 4]
+    _compare_solve(mg, p, b)
+    mg.clear_(p)
 
 
 @pytest.mark.gpu

@@ -159,6 +159,11 @@ def test_band27_variable_coefficient_levels(mg, built, cells, levels):
     rng = np.random.default_rng(9)
     try:
         assert h.operator_kernel_variant(2, D.MG_OP_A) == 9 and h0.operator_kernel_variant(2, D.MG_OP_A) != 9
+        # a Galerkin operator of a symmetric fine one is symmetric up to the rounding of R*(A*P): 14 of the 27 planes are read
+        assert h.band_form(2) == [2, 1, 1, 14] and h0.band_form(2)[0] == 0
+        h7 = D.DeviceHierarchy(p, 0, 1, options={"no_band_sym": 1})
+        assert h7.band_form(2) == [2, 1, 0, 27]
+        h7.close()
         for l in range(2, len(p.As)):
             Al, d = p.As[l - 1], np.asarray(p.relaxPrecs[l - 1])
             n = Al.shape[0]
