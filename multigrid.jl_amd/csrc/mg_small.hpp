@@ -227,9 +227,10 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
     const double* __restrict__ xb = IDX16 ? v.x + __builtin_amdgcn_readfirstlane(rowbase[row]) : v.x;
 #define LR_COL(kk) (IDX16 ? (int)(NT ? __builtin_nontemporal_load(ci16 + (kk)) : ci16[(kk)]) : (NT ? __builtin_nontemporal_load(A.colidx + (kk)) : A.colidx[(kk)]))
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int k = k0 + lane;
+    int kb = k0;                                            // (uniform)
     // eight values + eight indices in flight per lane (6 KB per wavefront), the gathers behind them
-    for (; k + 448 < k1; k += 512) {
+    for (; kb + 512 <= k1; kb += 512) {
+      const int k = kb + lane;
       double vv[8];
       int cc[8];
 #pragma unroll
@@ -249,18 +250,32 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
       a2 = a2 + vv[6] * xx[6];
       a3 = a3 + vv[7] * xx[7];
     }
-    for (; k + 64 < k1; k += 128) {
-      const double v0 = NT ? __builtin_nontemporal_load(A.val + k) : A.val[k], v1 = NT ? __builtin_nontemporal_load(A.val + k + 64) : A.val[k + 64];
-      const int c0 = LR_COL(k), c1 = LR_COL(k + 64);
-      a0 = a0 + v0 * xb[c0];
-      a1 = a1 + v1 * xb[c1];
+    // the rest of the row (< 512 entries) in ONE masked shot: the same eight loads in flight per lane, entries beyond the row clamped
+    // to its last one and given the weight 0 (rows of a few hundred entries live here entirely)
+    if (kb < k1) {
+      const int k = kb + lane;
+      double vv[8];
+      int cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = k + 64 * u < k1 ? k + 64 * u : k1 - 1;
+        vv[u] = NT ? __builtin_nontemporal_load(A.val + kk) : A.val[kk];
+        cc[u] = LR_COL(kk);
+      }
+      double xx[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xx[u] = xb[cc[u]];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vv[u] = k + 64 * u < k1 ? vv[u] : 0.0;
+      a0 = a0 + vv[0] * xx[0];
+      a1 = a1 + vv[1] * xx[1];
+      a2 = a2 + vv[2] * xx[2];
+      a3 = a3 + vv[3] * xx[3];
+      a0 = a0 + vv[4] * xx[4];
+      a1 = a1 + vv[5] * xx[5];
+      a2 = a2 + vv[6] * xx[6];
+      a3 = a3 + vv[7] * xx[7];
     }
-    for (; k < k1; k += 64) {
-      const double vv = NT ? __builtin_nontemporal_load(A.val + k) : A.val[k];
-      const int cc = LR_COL(k);
-      a2 = a2 + vv * xb[cc];
-    }
-#undef LR_COL
     double acc = (a0 + a1) + (a2 + a3);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) {

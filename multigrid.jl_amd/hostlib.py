@@ -231,3 +231,73 @@ def sa_strength(A, theta: float, nthreads: int = 0):
     S = sp.csr_matrix((out, idx, ptr), shape=A.shape)
     S.has_sorted_indices = True
     return S
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Galerkin products of NEARLY DENSE levels on the GPU (setup time only; optional).  The SA-AMG hierarchy of anisotropic diffusion
+# (BASELINE config C3) ends in levels whose operators are 10-100 % dense - 56 698 rows x 13 705 entries at 256^3 cells: 2.7 x 10^12
+# products for R*(A*P) on the host, 300 of the setup's 540 s.  As dense fp64 GEMMs (rocBLAS through torch.matmul) the same product
+# is seconds.  The PATTERN is the structural one (an entry whose terms cancel is kept, as Julia's and scipy's sparse products keep
+# it): indicator matrices multiplied in fp32 (counts < 2^24: exact).  Values: the same terms summed in GEMM order instead of
+# Gustavson order (differences at rounding level).  MG_SETUP_GPU=0 keeps every product on the host.
+# ------------------------------------------------------------------------------------------------------------------------
+def galerkin_dense_gpu_ok(A, P) -> bool:
+    if os.environ.get("MG_SETUP_GPU", "1") == "0":
+        return False
+    n, nc = A.shape[0], P.shape[1]
+    if A.shape[0] != A.shape[1] or n < int(os.environ.get("MG_SETUP_GPU_MIN_ROWS", "3000")) or A.nnz < float(os.environ.get("MG_SETUP_GPU_MIN_DENSITY", "0.04")) * n * n:
+        return False
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return False
+        free, _ = torch.cuda.mem_get_info()
+    except Exception:
+        return False
+    need = 8.0 * (n * n + 2.0 * n * nc) + 4.0 * (n * n + 2.0 * n * nc) + 16.0 * A.nnz + 2.0e9
+    return need < 0.8 * free
+
+
+def _dense_on_gpu(M, torch, dev):
+    """(values, indicator) of a CSR matrix as dense fp64 / fp32 device tensors."""
+    M = sp.csr_matrix(M)
+    n, m = M.shape
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), torch.from_numpy(np.diff(M.indptr).astype(np.int64)).to(dev))
+    cols = torch.from_numpy(M.indices.astype(np.int64)).to(dev)
+    flat = rows * m + cols
+    del rows, cols
+    D = torch.zeros(n * m, dtype=torch.float64, device=dev)
+    D.index_put_((flat,), torch.from_numpy(np.ascontiguousarray(M.data, dtype=np.float64)).to(dev), accumulate=True)   # (duplicates, if any, add up)
+    S = torch.zeros(n * m, dtype=torch.float32, device=dev)
+    S.index_fill_(0, flat, 1.0)
+    return D.view(n, m), S.view(n, m)
+
+
+def galerkin_dense_gpu(R, A, P):
+    """A_c = R*(A*P) through dense GEMMs on the GPU; CSR (int32, sorted) with the structural pattern of the sparse product."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Ad, As_ = _dense_on_gpu(A, torch, dev)
+    Pd, Ps_ = _dense_on_gpu(P, torch, dev)
+    AP = Ad @ Pd
+    del Ad
+    APs = ((As_ @ Ps_) > 0.5).to(torch.float32)
+    del As_, Pd, Ps_
+    Rd, Rs_ = _dense_on_gpu(R, torch, dev)
+    Ac = Rd @ AP
+    del Rd, AP
+    pat = (Rs_ @ APs) > 0.5
+    del Rs_, APs
+    nc = Ac.shape[0]
+    counts = pat.sum(dim=1, dtype=torch.int64)
+    idx = pat.nonzero(as_tuple=False)                     # row-major: sorted rows, ascending columns
+    vals = Ac[pat]
+    ptr = np.zeros(nc + 1, dtype=np.int64)
+    np.cumsum(counts.cpu().numpy(), out=ptr[1:])
+    ci = idx[:, 1].to(torch.int32).cpu().numpy()
+    va = vals.cpu().numpy()
+    del Ac, pat, idx, vals
+    torch.cuda.empty_cache()
+    Cm = sp.csr_matrix((va, ci, ptr.astype(np.int32 if ptr[-1] < 2 ** 31 - 1 else np.int64)), shape=(nc, P.shape[1]))
+    Cm.has_sorted_indices = True
+    return Cm

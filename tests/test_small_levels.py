@@ -204,3 +204,35 @@ def test_band27_variable_coefficient_levels(mg, built, cells, levels):
     assert np.abs(p.resvec - hist["resvec"]).max() <= 1e-10 * hist["resvec"][0]
     assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
     mg.clear_(p)
+
+
+def test_galerkin_product_of_a_nearly_dense_level_on_the_gpu(mg, built, monkeypatch):
+    """Setup only: R*(A*P) of a nearly dense SA-AMG level as dense GEMMs on the GPU (hostlib.galerkin_dense_gpu) - the structural
+    pattern of the host's sparse product (explicit zeros and cancelling sums kept), values to rounding; and the switch that
+    hands such levels to it (size, density, MG_SETUP_GPU)."""
+    import scipy.sparse as sp
+    from multigrid_jl_amd import hostlib as H
+    rng = np.random.default_rng(12)
+    n, nc = 700, 90
+    A = sp.random(n, n, density=0.2, random_state=3, format="csr", dtype=np.float64)
+    A = (A + A.T + sp.identity(n) * 10.0).tocsr()
+    A.sort_indices()
+    A.data[5] = 0.0                                          # an explicit zero stays a structural entry
+    P = sp.random(n, nc, density=0.15, random_state=4, format="lil", dtype=np.float64)
+    P[0, 0] = 1.0
+    P[1, 0] = -1.0                                           # (sums that may cancel stay entries too)
+    P = sp.csr_matrix(P)
+    P.sort_indices()
+    R = H.transpose_csr(P)
+    want = H.spgemm(R, H.spgemm(A, P))
+    got = H.galerkin_dense_gpu(R, A, P)
+    assert got.shape == want.shape and np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    assert np.abs(got.data - want.data).max() <= 1e-13 * np.abs(want.data).max()
+    assert not H.galerkin_dense_gpu_ok(A, P)                 # (700 rows: below the size it pays from)
+    monkeypatch.setenv("MG_SETUP_GPU_MIN_ROWS", "500")
+    assert H.galerkin_dense_gpu_ok(A, P)
+    monkeypatch.setenv("MG_SETUP_GPU", "0")
+    assert not H.galerkin_dense_gpu_ok(A, P)
+    monkeypatch.setenv("MG_SETUP_GPU", "1")
+    thin = sp.random(4000, 4000, density=0.001, random_state=5, format="csr")
+    assert not H.galerkin_dense_gpu_ok(thin, sp.random(4000, 300, density=0.01, random_state=6, format="csr"))
