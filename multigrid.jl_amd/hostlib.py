@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import scipy.sparse as sp
@@ -300,4 +301,62 @@ def galerkin_dense_gpu(R, A, P):
     torch.cuda.empty_cache()
     Cm = sp.csr_matrix((va, ci, ptr.astype(np.int32 if ptr[-1] < 2 ** 31 - 1 else np.int64)), shape=(nc, P.shape[1]))
     Cm.has_sorted_indices = True
+    return Cm
+
+
+# Galerkin products too large for the host and too sparse for dense GEMMs: rocSPARSE's SpGEMM through torch.sparse.mm on CSR
+# operands (structural pattern, checked against the host product in tests; values to rounding).  Taken from MG_SETUP_GPU_MIN_PRODUCTS
+# estimated products on (the 241 k-row level of C3 at 256^3: 2.7 x 10^11); any failure (memory) falls back to the host product.
+def galerkin_sparse_gpu_ok(A, P) -> bool:
+    if os.environ.get("MG_SETUP_GPU", "1") == "0" or os.environ.get("MG_SETUP_GPU_SPARSE", "1") == "0":
+        return False
+    est = float(A.nnz) * float(P.nnz) / max(1, P.shape[0])
+    if est < float(os.environ.get("MG_SETUP_GPU_MIN_PRODUCTS", "5e9")):
+        return False
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return False
+        free, _ = torch.cuda.mem_get_info()
+    except Exception:
+        return False
+    return 16.0 * (A.nnz + 2 * P.nnz) * 8.0 < 0.8 * free      # (operands + a product several times their size)
+
+
+def _csr_to_gpu(M, torch, dev):
+    M = sp.csr_matrix(M)
+    return torch.sparse_csr_tensor(torch.from_numpy(M.indptr.astype(np.int64)).to(dev), torch.from_numpy(M.indices.astype(np.int64)).to(dev),
+                                   torch.from_numpy(np.ascontiguousarray(M.data, dtype=np.float64)).to(dev), size=M.shape)
+
+
+def galerkin_sparse_gpu(R, A, P):
+    """A_c = R*(A*P) through rocSPARSE's SpGEMM on the GPU; None when it does not go through (the caller then multiplies on the host)."""
+    import torch
+    import warnings
+    dev = torch.device("cuda", torch.cuda.current_device())
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            At = _csr_to_gpu(A, torch, dev)
+            Pt = _csr_to_gpu(P, torch, dev)
+            AP = torch.sparse.mm(At, Pt)
+            del At, Pt
+            Rt = _csr_to_gpu(R, torch, dev)
+            Ac = torch.sparse.mm(Rt, AP)
+            del Rt, AP
+            ptr = Ac.crow_indices().cpu().numpy()
+            idx = Ac.col_indices().cpu().numpy()
+            val = Ac.values().cpu().numpy()
+            del Ac
+    except Exception as e:                      # (out of memory, an unsupported size: the host product serves)
+        print(f"[multigrid.jl_amd] GPU SpGEMM not used ({type(e).__name__}: {str(e)[:120]}): host product", file=sys.stderr, flush=True)
+        try:
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+        return None
+    torch.cuda.empty_cache()
+    it = np.int32 if max(int(ptr[-1]), P.shape[1]) < 2 ** 31 - 1 else np.int64
+    Cm = sp.csr_matrix((val, idx.astype(it), ptr.astype(it)), shape=(R.shape[0], P.shape[1]))
+    Cm.sort_indices()
     return Cm

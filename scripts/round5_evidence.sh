@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 evidence on one MI355X box.  Output: gpurun_out/$1/   usage (through gpurun): bash scripts/round5_evidence.sh r05a <part>
-#  part 1  the driver's line (C2 + C5 leg + generic-CSR pass + div-sigma-grad leg + CPU baseline) and the A/B switches of the round
+#  part 1  the driver's line (C2 + C5 leg + generic-CSR pass + div-sigma-grad leg + CPU baseline), the A/B switches of the round, the bare default run
 #  part 2  rocprofv3 kernel stats / kernel-by-grid table of the same command, PMC traffic of the fine-level kernels, SQ counters of the four-stage pass
 #  part 3  sharded path: a world of one in both forms (+ the single-GPU path in the same job), dry ranks of 8 / 4 / 2, 512^3 on one GPU, strong ceiling
 #  part 4  C5 as its own workload, 400^3, C3 at 128^3
@@ -16,6 +16,8 @@ echo "c2 done" > $out/progress.txt
 MG_NO_SMALL=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass --no-divsiggrad --no-c5-leg > $out/c2_bench_no_small.json 2> /dev/null
 MG_SMALL_OVER_RC=300000 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass --no-divsiggrad --no-c5-leg > $out/c2_bench_small_on_level3.json 2> /dev/null
 MG_NO_MARCH4=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass --no-divsiggrad --no-c5-leg > $out/c2_bench_no_four_stage.json 2> /dev/null
+MG_NO_BAND_SYM=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-c5-leg > $out/c2_bench_no_band_sym.json 2> /dev/null
+python bench.py > $out/c2_bench_default_run.json 2> /dev/null
 echo "A/B done" >> $out/progress.txt
 fi
 if [ "$part" = "2" ]; then

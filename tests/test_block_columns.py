@@ -78,7 +78,7 @@ def test_block_cycle_and_column_solve_share_one_handle(mg, built, monkeypatch):
     must equal the oracle's (a graph captured for k columns replayed for one, or the reverse, would not)."""
     _env(monkeypatch)
     monkeypatch.setenv("MG_NO_COLUMNS", "0")
-    A, p, B = _setup(mg, [24, 20, 16], 3, 4, cyc="W", tol=0.0, maxIter=3)
+    A, p, B = _setup(mg, [24, 19, 16], 3, 4, cyc="W", tol=0.0, maxIter=3)      # (20 lines: an even count fits one tile row of the four-stage pass)
     h = mg.to_device(p)
     assert h.four_stage_form(1)[0]
     for rep in range(2):

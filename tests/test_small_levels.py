@@ -228,6 +228,10 @@ def test_galerkin_product_of_a_nearly_dense_level_on_the_gpu(mg, built, monkeypa
     got = H.galerkin_dense_gpu(R, A, P)
     assert got.shape == want.shape and np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
     assert np.abs(got.data - want.data).max() <= 1e-13 * np.abs(want.data).max()
+    got2 = H.galerkin_sparse_gpu(R, A, P)                    # rocSPARSE's SpGEMM (levels too large for dense blocks)
+    assert got2 is not None and np.array_equal(got2.indptr, want.indptr) and np.array_equal(got2.indices, want.indices)
+    assert np.abs(got2.data - want.data).max() <= 1e-13 * np.abs(want.data).max()
+    assert not H.galerkin_sparse_gpu_ok(A, P)                # (10^7 products: the host's)
     assert not H.galerkin_dense_gpu_ok(A, P)                 # (700 rows: below the size it pays from)
     monkeypatch.setenv("MG_SETUP_GPU_MIN_ROWS", "500")
     assert H.galerkin_dense_gpu_ok(A, P)
