@@ -499,7 +499,10 @@ def main():
                 "kernel": kname + " (" + kdesc + ")",
                 "achieved": round(mv_s / avg_s / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(mv_s / avg_s / 1e6 / HBM_PEAK_GBS, 4),
-                "traffic": None, "traffic_from_profile": traffic_prof,
+                # HBM bytes per launch of this kernel symbol from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, each counter in a
+                # run of its own: scripts/round5_evidence.sh part 2) - an offline figure of the same symbol on the same workload, never
+                # collected inside a timed run; null when the run uses another kernel
+                "traffic": (traffic_prof or {}).get("bytes_per_launch"), "traffic_from_profile": traffic_prof,
                 "bytes_per_launch": mv_s, "avg_launch_ms": round(avg_s, 5), "launches": cnt_s,
                 "device_format": fmt_name,
                 "definition": "achieved = bytes the kernel IN USE has to move for one launch (device format's matrix side "
@@ -662,7 +665,7 @@ def main():
             pair = launch_line(profg, movedg, (1, "smooth+residual"))
             pairn = launch_line(profg, movedg, (1, "smooth+residual+norm"))
             gen.update({"kernel": "mgk::csr_rowclass_march3_spmv<false, 5, 512, K1, 2, true>", "device_format": "band form (structure "
-                        "classes as a product map + 7 planar value arrays), fine level; pattern-coded CSR below", "sweep_residual_pair": pair,
+                        "classes as a product map + 7 planar value arrays, 4 of them read where the values are symmetric), fine level; band-27 / pattern-coded CSR below", "sweep_residual_pair": pair,
                         "sweep_residual_norm_pair": pairn})
             if pair:
                 gen.update({k: pair[k] for k in ("avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "achieved", "frac",
