@@ -222,20 +222,64 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int w = xcd_band((int)blockIdx.x, nwg);
   const int r0 = w * rows_per_wg, r1 = r0 + rows_per_wg < A.n_rows ? r0 + rows_per_wg : A.n_rows;
-  for (int row = r0 + wave; row < r1; row += 4) {
-    const int k0 = __builtin_amdgcn_readfirstlane(A.rowptr[row]), k1 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
-    const double* __restrict__ xb = IDX16 ? v.x + __builtin_amdgcn_readfirstlane(rowbase[row]) : v.x;
 #define LR_COL(kk) (IDX16 ? (int)(NT ? __builtin_nontemporal_load(ci16 + (kk)) : ci16[(kk)]) : (NT ? __builtin_nontemporal_load(A.colidx + (kk)) : A.colidx[(kk)]))
+#define LR_VAL(kk) (NT ? __builtin_nontemporal_load(A.val + (kk)) : A.val[(kk)])
+  // Software pipeline over the wavefront's rows: the FIRST 512 entries of the next row (values + indices, entries beyond the row clamped
+  // to its last one) are in flight while the current row gathers, multiplies and reduces; its row pointers one row further ahead.
+  int row = r0 + wave;
+  if (row >= r1) return;
+  int k0 = __builtin_amdgcn_readfirstlane(A.rowptr[row]), k1 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+  int nk0 = 0, nk1 = 0;
+  if (row + 4 < r1) { nk0 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 4]); nk1 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 5]); }
+  double pv[8];
+  int pc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int kk = k0 + lane + 64 * u < k1 ? k0 + lane + 64 * u : (k1 > k0 ? k1 - 1 : k0);
+    pv[u] = LR_VAL(kk);
+    pc[u] = LR_COL(kk);
+  }
+  for (; row < r1; row += 4) {
+    const double* __restrict__ xb = IDX16 ? v.x + __builtin_amdgcn_readfirstlane(rowbase[row]) : v.x;
+    // ---- the next row's first shot and the row pointers of the one after it ---------------------------------------------------
+    const bool have_next = row + 4 < r1;                     // (uniform)
+    int nnk0 = 0, nnk1 = 0;
+    if (row + 8 < r1) { nnk0 = A.rowptr[row + 8]; nnk1 = A.rowptr[row + 9]; }
+    double nv[8];
+    int nc[8];
+    if (have_next) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = nk0 + lane + 64 * u < nk1 ? nk0 + lane + 64 * u : (nk1 > nk0 ? nk1 - 1 : nk0);
+        nv[u] = LR_VAL(kk);
+        nc[u] = LR_COL(kk);
+      }
+    }
+    // ---- this row: the first shot from the registers, the rest (rows beyond 512 entries) chunk by chunk -------------------------
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int kb = k0;                                            // (uniform)
-    // eight values + eight indices in flight per lane (6 KB per wavefront), the gathers behind them
+    {
+      double xx[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xx[u] = xb[pc[u]];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pv[u] = k0 + lane + 64 * u < k1 ? pv[u] : 0.0;
+      a0 = a0 + pv[0] * xx[0];
+      a1 = a1 + pv[1] * xx[1];
+      a2 = a2 + pv[2] * xx[2];
+      a3 = a3 + pv[3] * xx[3];
+      a0 = a0 + pv[4] * xx[4];
+      a1 = a1 + pv[5] * xx[5];
+      a2 = a2 + pv[6] * xx[6];
+      a3 = a3 + pv[7] * xx[7];
+    }
+    int kb = k0 + 512;                                      // (uniform)
     for (; kb + 512 <= k1; kb += 512) {
       const int k = kb + lane;
       double vv[8];
       int cc[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        vv[u] = NT ? __builtin_nontemporal_load(A.val + k + 64 * u) : A.val[k + 64 * u];
+        vv[u] = LR_VAL(k + 64 * u);
         cc[u] = LR_COL(k + 64 * u);
       }
       double xx[8];
@@ -250,16 +294,14 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
       a2 = a2 + vv[6] * xx[6];
       a3 = a3 + vv[7] * xx[7];
     }
-    // the rest of the row (< 512 entries) in ONE masked shot: the same eight loads in flight per lane, entries beyond the row clamped
-    // to its last one and given the weight 0 (rows of a few hundred entries live here entirely)
-    if (kb < k1) {
+    if (kb < k1) {      // the rest of a long row in one masked shot
       const int k = kb + lane;
       double vv[8];
       int cc[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int kk = k + 64 * u < k1 ? k + 64 * u : k1 - 1;
-        vv[u] = NT ? __builtin_nontemporal_load(A.val + kk) : A.val[kk];
+        vv[u] = LR_VAL(kk);
         cc[u] = LR_COL(kk);
       }
       double xx[8];
@@ -290,7 +332,13 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
       }
       v.y[row] = out;
     }
+    // ---- rotate the pipeline --------------------------------------------------------------------------------------------------
+    k0 = nk0; k1 = nk1;
+    nk0 = __builtin_amdgcn_readfirstlane(nnk0); nk1 = __builtin_amdgcn_readfirstlane(nnk1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { pv[u] = nv[u]; pc[u] = nc[u]; }
   }
+#undef LR_VAL
 }
 
 }  // namespace mgk
