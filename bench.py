@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--ghost-dry", default="", help="R/N: timing aid - this ONE process is rank R of a world of N in the ghost-layer form, alone on "
                                                     "its GPU (exchanges pack and unpack, nothing travels): one GPU's compute share of the N-GPU step")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; the median is reported")
+    ap.add_argument("--c3-weights", default="1,0.25,0.0625", help="c3: edge weights of the three directions (SURVEY 8d states 1,1e-2,1e-4; "
+                    "the default 16:4:1 is what fits at 256^3 - profiles/HISTORY.md section 10)")
     ap.add_argument("--no-generic-pass", action="store_true", help="skip the second pass with the streaming formats forced")
     ap.add_argument("--no-c5-leg", action="store_true", help="skip the 16-right-hand-side leg (BASELINE configs[4]) on the same handle")
     ap.add_argument("--no-divsiggrad", action="store_true", help="skip the variable-coefficient (div sigma grad) leg")
@@ -375,7 +377,8 @@ def main():
             while not hb_stop.wait(60.0):
                 print(f"[bench] host setup running, {time.perf_counter() - t_hb:.0f} s", file=sys.stderr, flush=True)
         threading.Thread(target=_heartbeat, daemon=True).start()
-        A, mesh = mg.anisotropic_divsiggrad([cells] * 3, weights=(1.0, 0.25, 0.0625))
+        c3w = tuple(float(w) for w in args.c3_weights.split(","))
+        A, mesh = mg.anisotropic_divsiggrad([cells] * 3, weights=c3w)
         t_op = time.perf_counter() - t0
         p = mg.getMGparam(np.float64, np.int64, args.levels or 14, os.cpu_count() or 8, K, 0.0, "SPAI", 1.0, 1, 1, "V",
                           "Julia", 0.4, 0.0)
@@ -384,7 +387,7 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):     # (per-level setup times go to stderr: stdout carries the one JSON line)
             mg.SA_AMGsetup(A, p, True, nrhs, verbose=True)
         hb_stop.set()
-        desc = (f"SA-AMG (theta=0.4, V(1,1) SPAI w=1) on anisotropic diffusion {cells}^3 cells, edge weights 16:4:1 x "
+        desc = (f"SA-AMG (theta=0.4, V(1,1) SPAI w=1) on anisotropic diffusion {cells}^3 cells, edge weights {':'.join(f'{w:g}' for w in c3w)} x "
                 f"log-normal sigma, general CSR")
     else:
         gc = [int(c) for c in args.global_cells.split(",")] if args.global_cells else [cells] * 3
