@@ -200,3 +200,24 @@ def test_c3_128_sa_amg_matches_c_oracle(mg, built):
     assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
     assert abs(np.linalg.norm(b - A @ x) - p.resvec[-1]) <= 1e-10 * p.resvec[0]
     mg.clear_(p)
+
+
+def test_c3_survey_weights_64_sa_amg_matches_c_oracle(mg, built):
+    """The same at SURVEY 8d's STATED edge weights 1 : 1e-2 : 1e-4 (operator complexity ~45 at 64^3 cells: rows of thousands of entries
+    on the middle levels - the long-row kernel; the Galerkin products of the large / nearly dense levels run on the GPU in the setup):
+    three solveMG steps against the C/OpenMP oracle on the hierarchy the setup produced."""
+    A, mesh = mg.anisotropic_divsiggrad([64, 64, 64], weights=(1.0, 1e-2, 1e-4))
+    p = mg.getMGparam(np.float64, np.int64, 14, 8, 3, 0.0, "SPAI", 1.0, 1, 1, "V", "Julia", 0.4, 0.0)
+    mg.SA_AMGsetup(A, p, True, 1)
+    assert sum(a.nnz for a in p.As) > 20 * A.nnz
+    b = mg.seeded_rhs(A)
+    x = np.zeros_like(b)
+    mg.solveMG(p, b, x)
+    from multigrid_jl_amd import device as D
+    assert any(p.device.operator_kernel_variant(l, D.MG_OP_A) is not None for l in range(1, len(p.As)))
+    co = c_oracle.COracle(p, 1)
+    xo = np.zeros_like(b)
+    it, rv = co.solveMG(b, xo, 0.0, 3, c_oracle.max_threads())
+    assert it == 3 and np.abs(rv - p.resvec).max() / rv[0] < 1e-10
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    mg.clear_(p)
