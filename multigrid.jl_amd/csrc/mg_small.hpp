@@ -124,6 +124,43 @@ __global__ __launch_bounds__(256) void grid_small_prolong(SmallPDev T, const dou
   x[row] = 1.0 * acc + 1.0 * px;      // (the AXPBY epilogue with alpha = beta = 1: alpha*acc + beta*y)
 }
 
+// The same product with a lane per COARSE CELL: the up to 2 x 2 x 2 fine nodes (2i + dx, 2j + dy, 2k + dz) share the 8 coarse corners
+// of the cell, so a lane issues 8 coarse loads + 8 loads and 8 stores of x for 8 fine nodes - 3 memory instructions per fine node
+// where the lane-per-fine-row form above issues up to 10 (1-8 gathers + load + store) and the windowed form reads 4 bytes of
+// descriptors per row.  Consecutive lanes = consecutive coarse columns: every x access of a wavefront covers one contiguous stretch
+// of a fine line.  Per fine node the same products in the same order as above (the CSR row of P): same bits.
+__global__ __launch_bounds__(256) void grid_cell_prolong(SmallPDev T, const double* __restrict__ xc, double* __restrict__ x) {
+  const int c = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (c >= T.nc) return;
+  const int k = c / T.Pc, rem = c - k * T.Pc, j = rem / T.nc1, i = rem - j * T.nc1;
+  const bool hx = i + 1 < T.nc1, hy = j + 1 < T.nc2, hz = k + 1 < T.nc3;      // the cell has odd fine nodes in that direction
+  const int ox = hx ? 1 : 0, oy = hy ? T.nc1 : 0, oz = hz ? T.Pc : 0;
+  double cv[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) cv[s] = xc[c + ((s >> 2) & 1) * oz + ((s >> 1) & 1) * oy + (s & 1) * ox];
+  const long long f0 = (long long)(2 * k) * T.Pf + (long long)(2 * j) * T.nf1 + 2 * i;
+  double px[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {          // t = (dz, dy, dx) of the fine node inside the cell
+    const int dz = (t >> 2) & 1, dy = (t >> 1) & 1, dx = t & 1;
+    const bool on = (!dz || hz) && (!dy || hy) && (!dx || hx);
+    px[t] = on ? x[f0 + (long long)dz * T.Pf + dy * T.nf1 + dx] : 0.0;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int dz = (t >> 2) & 1, dy = (t >> 1) & 1, dx = t & 1;
+    const bool on = (!dz || hz) && (!dy || hy) && (!dx || hx);
+    const double w = (dz ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dx ? 0.5 : 1.0);
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {        // the corners this node takes: those not beyond it in any direction
+      const bool take = (((s >> 2) & 1) <= dz) && (((s >> 1) & 1) <= dy) && ((s & 1) <= dx);
+      acc = acc + (take ? w : 0.0) * cv[s];
+    }
+    if (on) x[f0 + (long long)dz * T.Pf + dy * T.nf1 + dx] = 1.0 * acc + 1.0 * px[t];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // Band-27: 27-point grid operators whose COEFFICIENTS differ from row to row - the Galerkin levels of a div-sigma-grad hierarchy
 // (what jInv feeds the package: testGMG.jl:57-75; MGsetup.jl:226-270 exists because sigma changes every outer iteration).  No

@@ -21,14 +21,17 @@ def test_small_level_kernels_vs_numpy_and_streaming_kernels(mg, built, cells, le
     from multigrid_jl_amd import device as D
     A, p = _hier(mg, cells, levels, relax, 1.0 if relax == "SPAI" else 0.8)
     h = D.DeviceHierarchy(p, 0, 1)
-    h0 = D.DeviceHierarchy(p, 0, 1, options={"no_small": 1})
+    h0 = D.DeviceHierarchy(p, 0, 1, options={"no_small": 1, "no_cell_prolong": 1})
+    h1 = D.DeviceHierarchy(p, 0, 1, options={"no_cell_prolong": 1})
     import torch
     rng = np.random.default_rng(5)
     try:
         nl = len(p.As)
         for l in range(1, nl):
             assert h.operator_kernel_variant(l, D.MG_OP_A) == 8, (l, h.operator_kernel_variant(l, D.MG_OP_A))
-            assert h.operator_kernel_variant(l, D.MG_OP_R) == 8 and h.operator_kernel_variant(l, D.MG_OP_P) == 8
+            # P: a lane per coarse cell (10; any size) in front of the lane-per-fine-row kernel (8)
+            assert h.operator_kernel_variant(l, D.MG_OP_R) == 8 and h.operator_kernel_variant(l, D.MG_OP_P) == 10
+            assert h1.operator_kernel_variant(l, D.MG_OP_P) == 8 and h0.operator_kernel_variant(l, D.MG_OP_P) not in (8, 10)
             assert h0.operator_kernel_variant(l, D.MG_OP_A) != 8
             Al, Pl, Rl, d = p.As[l - 1], p.Ps[l - 1], p.Rs[l - 1], np.asarray(p.relaxPrecs[l - 1])
             n, nc = Al.shape[0], Pl.shape[1]
@@ -52,11 +55,15 @@ def test_small_level_kernels_vs_numpy_and_streaming_kernels(mg, built, cells, le
             h.spmv_dev(l, D.MG_OP_P, 1.0, xct, 1.0, yf)
             yf0 = bt.clone()
             h0.spmv_dev(l, D.MG_OP_P, 1.0, xct, 1.0, yf0)
+            yf1 = bt.clone()
+            h1.spmv_dev(l, D.MG_OP_P, 1.0, xct, 1.0, yf1)
             assert np.abs(yf.cpu().numpy() - (b + Pl @ xc)).max() <= 1e-13 * np.abs(b + Pl @ xc).max()
             assert np.abs(yf.cpu().numpy() - yf0.cpu().numpy()).max() <= 1e-13 * np.abs(b + Pl @ xc).max()
+            assert torch.equal(yf, yf1)          # (the two arithmetic kernels add the same products in the same order)
     finally:
         h.close()
         h0.close()
+        h1.close()
 
 
 @pytest.mark.parametrize("cells,levels,cyc", [([32, 32, 32], 4, "V"), ([32, 16, 24], 3, "W"), ([64, 48], 4, "F")])
