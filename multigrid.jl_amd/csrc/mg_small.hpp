@@ -96,6 +96,64 @@ __global__ __launch_bounds__(256) void grid27_small_restrict(SmallRDev T, const 
   if (y2) y2[row] = pd * acc;
 }
 
+// bc = R r for the full-weighting restriction R = scale * P' of a vertex-centred grid pair (weights scale * 2^-(|dz|+|dy|+|dx|) for the
+// fine nodes (2i+dx, 2j+dy, 2k+dz) inside the grid: verified on the host), any size, with 9 memory instructions per coarse node instead
+// of 27 (+ 27 record loads in the kernel above): lanes 1..62 of a wavefront own consecutive coarse nodes (lanes 0 and 63 are halo lanes
+// that only load); per fine line (dz, dy) a lane loads ONE aligned 16-byte pair - (r[2i], r[2i+1]) where the line's first entry is even in
+// memory, (r[2i-1], r[2i]) where it is odd - and takes the third value from its neighbour lane by a wavefront shuffle.  Every fine entry
+// is loaded once per line it is used in, every load of a wavefront is one contiguous kilobyte.  Products added in ascending fine column
+// order = the CSR row of R: the bits of the kernels above.
+__device__ __forceinline__ d2_t wr_load_pair(const double* __restrict__ r, long long pb, long long nf) {
+  if (pb + 1 < nf) return *reinterpret_cast<const d2_t*>(r + pb);
+  d2_t v;
+  v.x = r[pb];
+  v.y = 0.0;
+  return v;
+}
+__global__ __launch_bounds__(256) void grid_wave_restrict(SmallRDev T, double scale, const double* __restrict__ r, double* __restrict__ bc,
+                                                          const double* __restrict__ d2, double* __restrict__ y2) {
+  const int lane = threadIdx.x & 63;
+  // (workgroups take the coarse nodes in XCD bands: the fine lines two neighbouring coarse lines / planes share are re-read from that L2)
+  const long long wv = (long long)xcd_band((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
+  const long long c = wv * 62 + lane - 1;
+  const bool own = lane >= 1 && lane <= 62 && c < T.nc;
+  const long long cc = c < 0 ? 0 : (c >= T.nc ? (long long)T.nc - 1 : c);     // (halo lanes beyond the ends: their values meet the weight 0)
+  const int k = (int)(cc / T.Pc), rem = (int)(cc - (long long)k * T.Pc), j = rem / T.nc1, i = rem - j * T.nc1;
+  const long long centre = (long long)(2 * k) * T.Pf + (long long)(2 * j) * T.nf1 + 2 * i;     // (even: an aligned pair starts there)
+  const double wxm = i > 0 ? 0.5 : 0.0, wxp = i < T.nc1 - 1 ? 0.5 : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const bool ez = dz == 0 || (dz < 0 ? k > 0 : k < T.nc3 - 1), ey = dy == 0 || (dy < 0 ? j > 0 : j < T.nc2 - 1);
+      const bool ex = ez && ey;
+      const double wl = ex ? scale * (dz ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) : 0.0;
+      const bool aligned = ((dz + dy) & 1) == 0;                                // (Pf and nf1 are odd)
+      // a line the node does not have: the centre line (aligned case) or the pair in front of the centre (its values meet the weight 0)
+      const long long f = ex ? centre + (long long)dz * T.Pf + (long long)dy * T.nf1 : (aligned ? centre : (centre > 0 ? centre - 1 : 1));
+      double vm, v0, vp;
+      if (aligned) {
+        const d2_t q = wr_load_pair(r, f, T.nf);
+        vm = __shfl_up(q.y, 1);
+        v0 = q.x;
+        vp = q.y;
+      } else {
+        const d2_t q = wr_load_pair(r, f - 1, T.nf);
+        vp = __shfl_down(q.x, 1);
+        vm = q.x;
+        v0 = q.y;
+      }
+      acc = acc + (wl * wxm) * vm;
+      acc = acc + wl * v0;
+      acc = acc + (wl * wxp) * vp;
+    }
+  if (own) {
+    bc[c] = acc;
+    if (y2) y2[c] = d2[c] * acc;
+  }
+}
+
 // x += P xc, P the full-weighting interpolation of a vertex-centred grid pair (fine = 2*coarse - 1 nodes per direction): weight 1
 // from the coincident coarse node, 1/2 from each of the two neighbours of an odd coordinate; the (up to 8) products are added in
 // ascending coarse column order, as the CSR row holds them.
@@ -130,7 +188,7 @@ __global__ __launch_bounds__(256) void grid_small_prolong(SmallPDev T, const dou
 // descriptors per row.  Consecutive lanes = consecutive coarse columns: every x access of a wavefront covers one contiguous stretch
 // of a fine line.  Per fine node the same products in the same order as above (the CSR row of P): same bits.
 __global__ __launch_bounds__(256) void grid_cell_prolong(SmallPDev T, const double* __restrict__ xc, double* __restrict__ x) {
-  const int c = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int c = (int)(xcd_band((int)blockIdx.x, (int)gridDim.x) * 256 + threadIdx.x);   // (XCD bands: the coarse corners neighbouring cells share)
   if (c >= T.nc) return;
   const int k = c / T.Pc, rem = c - k * T.Pc, j = rem / T.nc1, i = rem - j * T.nc1;
   const bool hx = i + 1 < T.nc1, hy = j + 1 < T.nc2, hz = k + 1 < T.nc3;      // the cell has odd fine nodes in that direction

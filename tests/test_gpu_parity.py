@@ -1037,6 +1037,7 @@ def test_prolongation_with_staged_coarse_windows(mg, built, monkeypatch, cells, 
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_WINP_MIN_ROWS", "0")
     monkeypatch.setenv("MG_NO_CELL_PROLONG", "1")    # (... and the lane-per-coarse-cell kernel, which takes x += P xc of odd-count grid pairs)
+    monkeypatch.setenv("MG_NO_WAVE_RESTRICT", "1")
     outs = {}
     for name, no in (("windows", "0"), ("lane", "1")):
         rng = np.random.default_rng(sum(cells) + 3)           # the same vectors for both runs

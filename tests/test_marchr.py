@@ -18,6 +18,7 @@ def _env(monkeypatch, segs=0, tx=0, ty=0):
     monkeypatch.setenv("MG_ROWCLASS_MIN_COVER", "0.05")
     monkeypatch.setenv("MG_MARCH_MIN_WG", "0")
     monkeypatch.setenv("MG_MARCHR_MIN_ROWS", "0")
+    monkeypatch.setenv("MG_NO_WAVE_RESTRICT", "1")   # (... and the wavefront form, which takes such grid pairs first)
     monkeypatch.setenv("MG_MARCHR_SEGS", str(segs))
     monkeypatch.setenv("MG_MARCHR_TX", str(tx))
     monkeypatch.setenv("MG_MARCHR_TY", str(ty))

@@ -21,8 +21,8 @@ def test_small_level_kernels_vs_numpy_and_streaming_kernels(mg, built, cells, le
     from multigrid_jl_amd import device as D
     A, p = _hier(mg, cells, levels, relax, 1.0 if relax == "SPAI" else 0.8)
     h = D.DeviceHierarchy(p, 0, 1)
-    h0 = D.DeviceHierarchy(p, 0, 1, options={"no_small": 1, "no_cell_prolong": 1})
-    h1 = D.DeviceHierarchy(p, 0, 1, options={"no_cell_prolong": 1})
+    h0 = D.DeviceHierarchy(p, 0, 1, options={"no_small": 1, "no_cell_prolong": 1, "no_wave_restrict": 1})
+    h1 = D.DeviceHierarchy(p, 0, 1, options={"no_cell_prolong": 1, "no_wave_restrict": 1})
     import torch
     rng = np.random.default_rng(5)
     try:
@@ -30,8 +30,10 @@ def test_small_level_kernels_vs_numpy_and_streaming_kernels(mg, built, cells, le
         for l in range(1, nl):
             assert h.operator_kernel_variant(l, D.MG_OP_A) == 8, (l, h.operator_kernel_variant(l, D.MG_OP_A))
             # P: a lane per coarse cell (10; any size) in front of the lane-per-fine-row kernel (8)
-            assert h.operator_kernel_variant(l, D.MG_OP_R) == 8 and h.operator_kernel_variant(l, D.MG_OP_P) == 10
+            # R: 62 coarse nodes per wavefront (11; any size) in front of the lane-per-coarse-row kernel with its records (8)
+            assert h.operator_kernel_variant(l, D.MG_OP_R) == 11 and h.operator_kernel_variant(l, D.MG_OP_P) == 10
             assert h1.operator_kernel_variant(l, D.MG_OP_P) == 8 and h0.operator_kernel_variant(l, D.MG_OP_P) not in (8, 10)
+            assert h1.operator_kernel_variant(l, D.MG_OP_R) == 8 and h0.operator_kernel_variant(l, D.MG_OP_R) not in (8, 11)
             assert h0.operator_kernel_variant(l, D.MG_OP_A) != 8
             Al, Pl, Rl, d = p.As[l - 1], p.Ps[l - 1], p.Rs[l - 1], np.asarray(p.relaxPrecs[l - 1])
             n, nc = Al.shape[0], Pl.shape[1]
@@ -51,6 +53,9 @@ def test_small_level_kernels_vs_numpy_and_streaming_kernels(mg, built, cells, le
             yc = torch.zeros(nc, dtype=torch.float64, device="cuda")
             h.spmv_dev(l, D.MG_OP_R, 1.0, xt, 0.0, yc)
             assert np.abs(yc.cpu().numpy() - Rl @ x).max() <= 1e-13 * np.abs(Rl @ x).max()
+            yc1 = torch.full((nc,), 7.0, dtype=torch.float64, device="cuda")
+            h1.spmv_dev(l, D.MG_OP_R, 1.0, xt, 0.0, yc1)
+            assert torch.equal(yc, yc1)          # (the wavefront form adds the same products in the same order as the record kernel)
             yf = bt.clone()
             h.spmv_dev(l, D.MG_OP_P, 1.0, xct, 1.0, yf)
             yf0 = bt.clone()
