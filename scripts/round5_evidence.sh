@@ -17,6 +17,7 @@ MG_NO_SMALL=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gener
 MG_SMALL_OVER_RC=300000 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass --no-divsiggrad --no-c5-leg > $out/c2_bench_small_on_level3.json 2> /dev/null
 MG_NO_MARCH4=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass --no-divsiggrad --no-c5-leg > $out/c2_bench_no_four_stage.json 2> /dev/null
 MG_NO_BAND_SYM=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-c5-leg > $out/c2_bench_no_band_sym.json 2> /dev/null
+MG_NO_CELL_PROLONG=1 MG_NO_WAVE_RESTRICT=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-generic-pass --no-divsiggrad --no-c5-leg > $out/c2_bench_old_transfers.json 2> /dev/null
 python bench.py > $out/c2_bench_default_run.json 2> /dev/null
 echo "A/B done" >> $out/progress.txt
 fi
