@@ -272,27 +272,39 @@ __global__ __launch_bounds__(256) void band27_fill(CsrDev A, int n1, int n2, int
   if (bad) atomicOr(flag, 1);
 }
 // y = b - A x (RESID), y = x + d.*(b - A x) (SMOOTH), y = alpha A x + beta y (AXPBY)
+// Lanes 1..62 of a wavefront own consecutive rows (0 and 63 are halo lanes): of the 27 entries of x a row reads, the 9 with dx = 0 are
+// loaded (one coalesced load per (dz, dy) line) and the 18 with dx = -1 / +1 come from the neighbour lanes by a wavefront shuffle - 9
+// memory instructions for x instead of 27 (where a line ends, the neighbour lane's value is not the row's neighbour: the band holds 0 there).
 template <int MODE>
 __global__ __launch_bounds__(256) void grid27_band_spmv(Band27Dev T, VecArgs v) {
-  const int row = (int)((T.sym ? xcd_band((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 256 + threadIdx.x);
-  if (row >= T.n) return;
+  const int lane = threadIdx.x & 63;
+  const long long wv = (long long)(T.sym ? xcd_band((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long long rr = wv * 62 + lane - 1;
+  const bool own = lane >= 1 && lane <= 62 && rr < T.n;
+  const int row = (int)(rr < 0 ? 0 : (rr >= T.n ? (long long)T.n - 1 : rr));
   double rv[27], xv[27];
 #pragma unroll
   for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+    for (int dy = -1; dy <= 1; ++dy) {
+      int j = row + dz * T.P + dy * T.n1;
+      j = j < 0 ? 0 : (j >= T.n ? T.n - 1 : j);       // (an entry the row does not have: value 0 times some valid, finite x)
+      const double xc = v.x[j];
+      const int s0 = (dz + 1) * 9 + (dy + 1) * 3;
+      xv[s0] = __shfl_up(xc, 1);
+      xv[s0 + 1] = xc;
+      xv[s0 + 2] = __shfl_down(xc, 1);
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx) {
-        const int s = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
-        int j = row + dz * T.P + dy * T.n1 + dx;
-        j = j < 0 ? 0 : (j >= T.n ? T.n - 1 : j);     // (an entry the row does not have: value 0 times some valid, finite x)
+        const int s = s0 + dx + 1;
         const long long src = (s < 13 && T.sym) ? (long long)(26 - s) * T.stride + (dz * T.P + dy * T.n1 + dx) : (long long)s * T.stride;   // (uniform)
         rv[s] = T.val[src + row];
-        xv[s] = v.x[j];
       }
+    }
   double acc = 0.0;
 #pragma unroll
   for (int s = 0; s < 27; ++s) acc = acc + rv[s] * xv[s];
+  if (!own) return;
   double out;
   if (MODE == AXPBY) out = v.alpha * acc + (v.beta != 0.0 ? v.beta * v.y[row] : 0.0);
   else if (MODE == RESID) out = v.b[row] - acc;
