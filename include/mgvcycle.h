@@ -309,7 +309,10 @@ int mg_operator_rowclasses(mg_hierarchy* h, long long level, long long which, lo
  * (x staged in LDS per workgroup of consecutive rows), 2 csr_rowclass_tile_spmv (plane tiles from the grid hint),
  * 3 csr_rowclass_march_spmv (z-marching ring of slabs from the grid hint), 4 csr_rowclass_lane_spmv (every lane
  * walks its own row's class, dictionary in LDS: the default for operators that are not staged), 7 csr_rowclass_marchr_spmv
- * (a restriction of a vertex-centred grid pair walking the fine planes: mg_marchr.hpp); with a block of
+ * (a restriction of a vertex-centred grid pair walking the fine planes: mg_marchr.hpp), 8 the one-trip kernels of the small grid
+ * levels (mg_small.hpp), 9 band-27 (planar values of a variable-coefficient 27-point grid operator), 10 grid_cell_prolong (the
+ * trilinear prolongation of a vertex-centred grid pair, a lane per coarse cell), 11 grid_wave_restrict (its restriction, 62 coarse
+ * nodes per wavefront) - 10 and 11 for grid pairs of any size whose P / R the upload verified entry by entry; with a block of
  * right-hand sides (current nrhs > 1): 5 csr_rowclass_lane_spmm (one column per lane), 6 csr_rowclass_lane_spmm2 (even
  * nrhs: two columns = 16 bytes per lane; its residual form also writes the ||r||^2 partials and x + d.*r), -1 the
  * CSR-stream SpMM;
