@@ -329,101 +329,66 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int w = xcd_band((int)blockIdx.x, nwg);
   const int r0 = w * rows_per_wg, r1 = r0 + rows_per_wg < A.n_rows ? r0 + rows_per_wg : A.n_rows;
-#define LR_COL(kk) (IDX16 ? (int)(NT ? __builtin_nontemporal_load(ci16 + (kk)) : ci16[(kk)]) : (NT ? __builtin_nontemporal_load(A.colidx + (kk)) : A.colidx[(kk)]))
-#define LR_VAL(kk) (NT ? __builtin_nontemporal_load(A.val + (kk)) : A.val[(kk)])
-  // Software pipeline over the wavefront's rows: the FIRST 512 entries of the next row (values + indices, entries beyond the row clamped
-  // to its last one) are in flight while the current row gathers, multiplies and reduces; its row pointers one row further ahead.
+  typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+  // A SHOT = 512 consecutive entries from an EVEN entry index sb: lane l takes the pairs sb + 2l + 128u, u = 0..3 - four 16-byte value
+  // loads and four index-pair loads (4 bytes with 16-bit offsets) per lane, 2 memory instructions per non-zero with the gathers where
+  // single entries took 3.  Entries outside the row [k0, k1) are loaded all the same (the arrays end in 512 spare entries) and
+  // replaced by (value 0, column 0) before they are used.
+#define LR_SHOT_LOAD(VV, C0, C1, sb)                                                                                   \
+  _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                                   \
+    const int p_ = (sb) + 2 * lane + 128 * u_;                                                                         \
+    (VV)[u_] = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(A.val + p_)) : *reinterpret_cast<const d2_t*>(A.val + p_); \
+    if (IDX16) {                                                                                                       \
+      const us2_t c_ = NT ? __builtin_nontemporal_load(reinterpret_cast<const us2_t*>(ci16 + p_)) : *reinterpret_cast<const us2_t*>(ci16 + p_); \
+      (C0)[u_] = (int)c_.x; (C1)[u_] = (int)c_.y;                                                                      \
+    } else {                                                                                                           \
+      const i2_t c_ = NT ? __builtin_nontemporal_load(reinterpret_cast<const i2_t*>(A.colidx + p_)) : *reinterpret_cast<const i2_t*>(A.colidx + p_); \
+      (C0)[u_] = c_.x; (C1)[u_] = c_.y;                                                                                \
+    }                                                                                                                  \
+  }
+#define LR_SHOT_USE(VV, C0, C1, sb, lo, hi)                                                                            \
+  do {                                                                                                                 \
+    double x0_[4], x1_[4];                                                                                             \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                                 \
+      const int p_ = (sb) + 2 * lane + 128 * u_;                                                                       \
+      const bool i0_ = p_ >= (lo) && p_ < (hi), i1_ = p_ + 1 >= (lo) && p_ + 1 < (hi);                                 \
+      x0_[u_] = xb[i0_ ? (C0)[u_] : 0];                                                                                \
+      x1_[u_] = xb[i1_ ? (C1)[u_] : 0];                                                                                \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                                 \
+      const int p_ = (sb) + 2 * lane + 128 * u_;                                                                       \
+      const bool i0_ = p_ >= (lo) && p_ < (hi), i1_ = p_ + 1 >= (lo) && p_ + 1 < (hi);                                 \
+      const double w0_ = i0_ ? (VV)[u_].x : 0.0, w1_ = i1_ ? (VV)[u_].y : 0.0;                                         \
+      if (u_ & 1) { a2 = a2 + w0_ * x0_[u_]; a3 = a3 + w1_ * x1_[u_]; }                                                \
+      else { a0 = a0 + w0_ * x0_[u_]; a1 = a1 + w1_ * x1_[u_]; }                                                       \
+    }                                                                                                                  \
+  } while (0)
+  // Software pipeline over the wavefront's rows: the FIRST shot of the next row is in flight while the current row gathers, multiplies
+  // and reduces; its row pointers one row further ahead.
   int row = r0 + wave;
   if (row >= r1) return;
   int k0 = __builtin_amdgcn_readfirstlane(A.rowptr[row]), k1 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
   int nk0 = 0, nk1 = 0;
   if (row + 4 < r1) { nk0 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 4]); nk1 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 5]); }
-  double pv[8];
-  int pc[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int kk = k0 + lane + 64 * u < k1 ? k0 + lane + 64 * u : (k1 > k0 ? k1 - 1 : k0);
-    pv[u] = LR_VAL(kk);
-    pc[u] = LR_COL(kk);
-  }
+  d2_t pv[4];
+  int pc0[4], pc1[4];
+  LR_SHOT_LOAD(pv, pc0, pc1, k0 & ~1);
   for (; row < r1; row += 4) {
     const double* __restrict__ xb = IDX16 ? v.x + __builtin_amdgcn_readfirstlane(rowbase[row]) : v.x;
-    // ---- the next row's first shot and the row pointers of the one after it ---------------------------------------------------
     const bool have_next = row + 4 < r1;                     // (uniform)
     int nnk0 = 0, nnk1 = 0;
     if (row + 8 < r1) { nnk0 = A.rowptr[row + 8]; nnk1 = A.rowptr[row + 9]; }
-    double nv[8];
-    int nc[8];
-    if (have_next) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int kk = nk0 + lane + 64 * u < nk1 ? nk0 + lane + 64 * u : (nk1 > nk0 ? nk1 - 1 : nk0);
-        nv[u] = LR_VAL(kk);
-        nc[u] = LR_COL(kk);
-      }
-    }
-    // ---- this row: the first shot from the registers, the rest (rows beyond 512 entries) chunk by chunk -------------------------
+    d2_t nv[4];
+    int nc0[4], nc1[4];
+    if (have_next) { LR_SHOT_LOAD(nv, nc0, nc1, nk0 & ~1); }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    {
-      double xx[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) xx[u] = xb[pc[u]];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pv[u] = k0 + lane + 64 * u < k1 ? pv[u] : 0.0;
-      a0 = a0 + pv[0] * xx[0];
-      a1 = a1 + pv[1] * xx[1];
-      a2 = a2 + pv[2] * xx[2];
-      a3 = a3 + pv[3] * xx[3];
-      a0 = a0 + pv[4] * xx[4];
-      a1 = a1 + pv[5] * xx[5];
-      a2 = a2 + pv[6] * xx[6];
-      a3 = a3 + pv[7] * xx[7];
-    }
-    int kb = k0 + 512;                                      // (uniform)
-    for (; kb + 512 <= k1; kb += 512) {
-      const int k = kb + lane;
-      double vv[8];
-      int cc[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        vv[u] = LR_VAL(k + 64 * u);
-        cc[u] = LR_COL(k + 64 * u);
-      }
-      double xx[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) xx[u] = xb[cc[u]];
-      a0 = a0 + vv[0] * xx[0];
-      a1 = a1 + vv[1] * xx[1];
-      a2 = a2 + vv[2] * xx[2];
-      a3 = a3 + vv[3] * xx[3];
-      a0 = a0 + vv[4] * xx[4];
-      a1 = a1 + vv[5] * xx[5];
-      a2 = a2 + vv[6] * xx[6];
-      a3 = a3 + vv[7] * xx[7];
-    }
-    if (kb < k1) {      // the rest of a long row in one masked shot
-      const int k = kb + lane;
-      double vv[8];
-      int cc[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int kk = k + 64 * u < k1 ? k + 64 * u : k1 - 1;
-        vv[u] = LR_VAL(kk);
-        cc[u] = LR_COL(kk);
-      }
-      double xx[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) xx[u] = xb[cc[u]];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) vv[u] = k + 64 * u < k1 ? vv[u] : 0.0;
-      a0 = a0 + vv[0] * xx[0];
-      a1 = a1 + vv[1] * xx[1];
-      a2 = a2 + vv[2] * xx[2];
-      a3 = a3 + vv[3] * xx[3];
-      a0 = a0 + vv[4] * xx[4];
-      a1 = a1 + vv[5] * xx[5];
-      a2 = a2 + vv[6] * xx[6];
-      a3 = a3 + vv[7] * xx[7];
+    int sb = k0 & ~1;                                        // (uniform)
+    LR_SHOT_USE(pv, pc0, pc1, sb, k0, k1);
+    for (sb += 512; sb < k1; sb += 512) {                    // rows beyond the first shot: shot by shot
+      d2_t vv[4];
+      int c0[4], c1[4];
+      LR_SHOT_LOAD(vv, c0, c1, sb);
+      LR_SHOT_USE(vv, c0, c1, sb, k0, k1);
     }
     double acc = (a0 + a1) + (a2 + a3);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -443,9 +408,10 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
     k0 = nk0; k1 = nk1;
     nk0 = __builtin_amdgcn_readfirstlane(nnk0); nk1 = __builtin_amdgcn_readfirstlane(nnk1);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { pv[u] = nv[u]; pc[u] = nc[u]; }
+    for (int u = 0; u < 4; ++u) { pv[u] = nv[u]; pc0[u] = nc0[u]; pc1[u] = nc1[u]; }
   }
-#undef LR_VAL
+#undef LR_SHOT_LOAD
+#undef LR_SHOT_USE
 }
 
 }  // namespace mgk
