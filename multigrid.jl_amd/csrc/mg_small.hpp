@@ -20,14 +20,19 @@ struct Small27Dev {
   const double* rec;   // [27 codes][28]: v[(dz+1)*9 + (dy+1)*3 + (dx+1)] (0 where the rows of that code have no entry), [27] = relaxPrec
   int n1, n2, n3, P, n;
 };
+// A grid pair may be EMBEDDED (round 6; the sharded cycle's extended boxes, ghost_dist.ghost_boxes): the fine grid nf = 2*m - 1 nodes
+// pairs with the SUB-BOX [o, o + m) of a larger coarse grid nc - coarse node (o1+i, o2+j, o3+k) coincides with fine node (2i, 2j, 2k);
+// R's rows outside the sub-box are empty, P reads no column outside it.  An ordinary pair has o = 0, m = nc.
 struct SmallRDev {
-  const double* rec;   // [27 codes of the COARSE position][27]: weights of the fine nodes (2i+dx, 2j+dy, 2k+dz)
+  const double* rec;   // [27 codes of the COARSE position][27]: weights of the fine nodes (2i+dx, 2j+dy, 2k+dz)  (ordinary pairs only)
   int nc1, nc2, nc3, Pc, nc;
   int nf1, nf2, nf3, Pf, nf;
+  int o1, o2, o3, m1, m2, m3;
 };
 struct SmallPDev {
   int nf1, nf2, nf3, Pf, nf;
   int nc1, nc2, nc3, Pc, nc;
+  int o1, o2, o3, m1, m2, m3;
 };
 
 __device__ __forceinline__ int small_code1(int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 2 : 1); }
@@ -118,16 +123,21 @@ __global__ __launch_bounds__(256) void grid_wave_restrict(SmallRDev T, double sc
   const long long c = wv * 62 + lane - 1;
   const bool own = lane >= 1 && lane <= 62 && c < T.nc;
   const long long cc = c < 0 ? 0 : (c >= T.nc ? (long long)T.nc - 1 : c);     // (halo lanes beyond the ends: their values meet the weight 0)
-  const int k = (int)(cc / T.Pc), rem = (int)(cc - (long long)k * T.Pc), j = rem / T.nc1, i = rem - j * T.nc1;
+  const int kk = (int)(cc / T.Pc), rem = (int)(cc - (long long)kk * T.Pc), jj = rem / T.nc1, ii = rem - jj * T.nc1;
+  // position inside the sub-box the fine grid pairs with (an ordinary pair: the whole coarse grid); a row outside it is empty: its
+  // lanes load from the nearest node of the sub-box and every weight is 0
+  const int k0 = kk - T.o3, j0 = jj - T.o2, i0 = ii - T.o1;
+  const bool inside = k0 >= 0 && k0 < T.m3 && j0 >= 0 && j0 < T.m2 && i0 >= 0 && i0 < T.m1;
+  const int k = k0 < 0 ? 0 : (k0 >= T.m3 ? T.m3 - 1 : k0), j = j0 < 0 ? 0 : (j0 >= T.m2 ? T.m2 - 1 : j0), i = i0 < 0 ? 0 : (i0 >= T.m1 ? T.m1 - 1 : i0);
   const long long centre = (long long)(2 * k) * T.Pf + (long long)(2 * j) * T.nf1 + 2 * i;     // (even: an aligned pair starts there)
-  const double wxm = i > 0 ? 0.5 : 0.0, wxp = i < T.nc1 - 1 ? 0.5 : 0.0;
+  const double wxm = (inside && i > 0) ? 0.5 : 0.0, wxp = (inside && i < T.m1 - 1) ? 0.5 : 0.0;
   double acc = 0.0;
 #pragma unroll
   for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
-      const bool ez = dz == 0 || (dz < 0 ? k > 0 : k < T.nc3 - 1), ey = dy == 0 || (dy < 0 ? j > 0 : j < T.nc2 - 1);
-      const bool ex = ez && ey;
+      const bool ez = dz == 0 || (dz < 0 ? k > 0 : k < T.m3 - 1), ey = dy == 0 || (dy < 0 ? j > 0 : j < T.m2 - 1);
+      const bool ex = inside && ez && ey;
       const double wl = ex ? scale * (dz ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) : 0.0;
       const bool aligned = ((dz + dy) & 1) == 0;                                // (Pf and nf1 are odd)
       // a line the node does not have: the centre line (aligned case) or the pair in front of the centre (its values meet the weight 0)
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256) void grid_small_prolong(SmallPDev T, const dou
   if (row >= T.nf) return;
   const int z = row / T.Pf, rem = row - z * T.Pf, yy = rem / T.nf1, xx = rem - yy * T.nf1;
   const int oz = z & 1, oy = yy & 1, ox = xx & 1;
-  const int c0 = (z >> 1) * T.Pc + (yy >> 1) * T.nc1 + (xx >> 1);
+  const int c0 = ((z >> 1) + T.o3) * T.Pc + ((yy >> 1) + T.o2) * T.nc1 + (xx >> 1) + T.o1;
   const double wz = oz ? 0.5 : 1.0, wy = oy ? 0.5 : 1.0, wx = ox ? 0.5 : 1.0;
   const double w = wz * wy * wx;      // (every entry of the row carries the same weight: 1/2 per odd coordinate)
   double xv[8];
@@ -188,10 +198,12 @@ __global__ __launch_bounds__(256) void grid_small_prolong(SmallPDev T, const dou
 // descriptors per row.  Consecutive lanes = consecutive coarse columns: every x access of a wavefront covers one contiguous stretch
 // of a fine line.  Per fine node the same products in the same order as above (the CSR row of P): same bits.
 __global__ __launch_bounds__(256) void grid_cell_prolong(SmallPDev T, const double* __restrict__ xc, double* __restrict__ x) {
-  const int c = (int)(xcd_band((int)blockIdx.x, (int)gridDim.x) * 256 + threadIdx.x);   // (XCD bands: the coarse corners neighbouring cells share)
-  if (c >= T.nc) return;
-  const int k = c / T.Pc, rem = c - k * T.Pc, j = rem / T.nc1, i = rem - j * T.nc1;
-  const bool hx = i + 1 < T.nc1, hy = j + 1 < T.nc2, hz = k + 1 < T.nc3;      // the cell has odd fine nodes in that direction
+  const int cs = (int)(xcd_band((int)blockIdx.x, (int)gridDim.x) * 256 + threadIdx.x);   // (XCD bands: the coarse corners neighbouring cells share)
+  const int Pm = T.m1 * T.m2;                                                  // cells of the sub-box the fine grid pairs with
+  if (cs >= Pm * T.m3) return;
+  const int k = cs / Pm, rem = cs - k * Pm, j = rem / T.m1, i = rem - j * T.m1;
+  const int c = (k + T.o3) * T.Pc + (j + T.o2) * T.nc1 + i + T.o1;
+  const bool hx = i + 1 < T.m1, hy = j + 1 < T.m2, hz = k + 1 < T.m3;         // the cell has odd fine nodes in that direction
   const int ox = hx ? 1 : 0, oy = hy ? T.nc1 : 0, oz = hz ? T.Pc : 0;
   double cv[8];
 #pragma unroll

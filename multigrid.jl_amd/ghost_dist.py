@@ -41,7 +41,8 @@ from .mgdef import MGparam, getMGparam
 from .mgsetup import MGsetup
 from .operators import getRegularMesh
 
-G_LAST = 3          # ghost layers of the last sharded level (see the module docstring)
+G_LAST = 3          # ghost layers of the coarser sharded levels (see the module docstring)
+G_FINE = 5          # ghost layers of the fine level: the four-stage pass (4 products) + the layer the restriction behind it reads
 FULL = 1 << 20      # validity depth of a vector whose every ghost layer is up to date
 
 
@@ -69,16 +70,45 @@ def _own_ranges(cells, nd, box, level):
     return out
 
 
-def ghost_boxes(cells, nd, box, a: int, g_last: int = G_LAST):
+def ghost_boxes(cells, nd, box, a: int, g_last: int = G_LAST, g_fine: int = G_FINE, nested: bool = False):
     """Owned and extended boxes of one rank on the sharded levels 0..a-1.
-    Returns a list (per level) of dicts: own (inclusive global ranges), ext (inclusive global ranges), gmin."""
+    Returns a list (per level) of dicts: own (inclusive global ranges), ext (inclusive global ranges), gmin.
+
+    Every level gets the ghost width ITS OWN passes consume (round 6): ``g_fine`` layers on the fine level (the four-stage pass
+    of the solve loop: four products + the layer the restriction behind it reads), ``g_last`` on every coarser sharded level
+    (x1 = d.*b, sweep, residual, restriction).  The extended box of a level ends on nodes of the next level (even coordinates)
+    and the next level's box holds at least the parents of all its nodes: the local P and R are then the grid transfer
+    operators between the fine box and a SUB-BOX of the coarse box (``grid_cell_prolong`` / ``grid_wave_restrict`` take the
+    sub-box's offset), the coarse rows outside that sub-box are ghost rows every exchange overwrites.
+    ``nested=True``: round 5's rule - ``g_last`` layers on the last sharded level, every finer box = 2 * coarse - 1 nodes
+    (ghost widths double per level: 11-12 fine layers for three sharded levels)."""
     dim = len(cells)
     lv = [dict(own=_own_ranges(cells, nd, box, l)) for l in range(a)]
-    last = lv[a - 1]
-    n_last = [(int(cells[k]) >> (a - 1)) + 1 for k in range(dim)]
-    last["ext"] = [(max(0, last["own"][k][0] - g_last), min(n_last[k] - 1, last["own"][k][1] + g_last)) for k in range(dim)]
-    for l in range(a - 2, -1, -1):
-        lv[l]["ext"] = [(2 * e[0], 2 * e[1]) for e in lv[l + 1]["ext"]]
+    if nested:
+        last = lv[a - 1]
+        n_last = [(int(cells[k]) >> (a - 1)) + 1 for k in range(dim)]
+        last["ext"] = [(max(0, last["own"][k][0] - g_last), min(n_last[k] - 1, last["own"][k][1] + g_last)) for k in range(dim)]
+        for l in range(a - 2, -1, -1):
+            lv[l]["ext"] = [(2 * e[0], 2 * e[1]) for e in lv[l + 1]["ext"]]
+    else:
+        prev = None
+        for l in range(a):
+            n_l = [(int(cells[k]) >> l) + 1 for k in range(dim)]
+            want = g_fine if l == 0 else g_last
+            ext = []
+            for k in range(dim):
+                olo, ohi = lv[l]["own"][k]
+                lo = max(0, olo - want) if olo > 0 else 0
+                hi = min(n_l[k] - 1, ohi + want) if ohi < n_l[k] - 1 else n_l[k] - 1
+                if prev is not None:                       # the parents of every node of the finer extended box
+                    lo, hi = min(lo, prev[k][0] // 2), max(hi, -(-prev[k][1] // 2))
+                if l + 1 < a:                              # the box ends on nodes of the next level
+                    lo, hi = lo - (lo & 1), min(n_l[k] - 1, hi + (hi & 1))
+                    if hi & 1:
+                        raise RuntimeError("ghost boxes: a sharded level with an even node count")
+                ext.append((int(lo), int(hi)))
+            lv[l]["ext"] = ext
+            prev = ext
     for l in range(a):
         n_l = [(int(cells[k]) >> l) + 1 for k in range(dim)]
         g = FULL
@@ -179,7 +209,8 @@ class GhostSetup:
 
 
 def ghost_gmg(global_cells, numDomains, rank: int, size: int, param: MGparam, operator, domain=None, nrhs: int = 1,
-              replicate_below: int = 300_000, gather_objects=None, g_last: int = G_LAST, dry_tail: bool = False) -> GhostSetup:
+              replicate_below: int = 300_000, gather_objects=None, g_last: int = G_LAST, dry_tail: bool = False,
+              g_fine: int = G_FINE, nested: bool = False) -> GhostSetup:
     """Build this rank's part of a FullWeighting / Galerkin GMG hierarchy in the ghost-layer form (no global matrix).
 
     ``operator(mesh_loc) -> csr`` generates the fine operator on a sub-mesh (rows next to an artificial cut may be
@@ -193,7 +224,7 @@ def ghost_gmg(global_cells, numDomains, rank: int, size: int, param: MGparam, op
     cells, nd, dim, nl, a = S["cells"], S["nd"], S["dim"], S["nl"], S["a"]
     As, Ps, Rs, ds, geoms = S["As"], S["Ps"], S["Rs"], S["ds"], S["geoms"]
     box = S["box"]
-    boxes = ghost_boxes(cells, nd, box, a, g_last)
+    boxes = ghost_boxes(cells, nd, box, a, g_last, g_fine, nested)
     G = GhostSetup()
     G.a, G.rank, G.size = a, rank, size
     # ---- sub-boxes of the setup boxes -------------------------------------------------------------------------------
@@ -221,7 +252,11 @@ def ghost_gmg(global_cells, numDomains, rank: int, size: int, param: MGparam, op
         A_loc.append(_submatrix(As[l], ids[l], luts[l], ids[l].size))
         d_loc.append(np.asarray(ds[l])[ids[l]])
         if l + 1 < a:
+            # the coarse box holds the parents of every fine node (ghost_boxes): P loses no entry; R's rows outside the sub-box
+            # of those parents are empty (the fine box ends on coarse nodes)
             P_loc.append(_submatrix(Ps[l], ids[l], luts[l + 1], ids[l + 1].size))
+            if P_loc[-1].nnz != sp.csr_matrix(Ps[l])[ids[l], :].nnz:
+                raise RuntimeError("ghost boxes: a fine node interpolates from a coarse node outside the coarse box")
             R_loc.append(_submatrix(Rs[l], ids[l + 1], luts[l], ids[l].size))
         else:
             # into / out of the first replicated level: P reads the replicated vector (global column ids); R has one row per
@@ -290,7 +325,7 @@ def ghost_gmg(global_cells, numDomains, rank: int, size: int, param: MGparam, op
     G.param = p
     G.n_tail = nt
     # ---- exchange plans: every rank can compute every other rank's boxes -----------------------------------------------
-    all_boxes = [ghost_boxes(cells, nd, default_box_of(q, nd), a, g_last) for q in range(size)]
+    all_boxes = [ghost_boxes(cells, nd, default_box_of(q, nd), a, g_last, g_fine, nested) for q in range(size)]
     for l in range(a):
         L = G.levels[l]
         me = boxes[l]

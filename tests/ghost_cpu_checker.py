@@ -39,7 +39,8 @@ class GhostCpuSequencer:
         if not self.active(l):
             return
         g = self.G.levels[l].gmin
-        d = FULL if d >= g else max(d, 0)
+        assert d >= 0, f"level {l}: an operation consumed more ghost layers than its input had (depth {d})"   # (gh_set: MG_ERR_STATE)
+        d = FULL if d >= g else d
         self.depth[l][id(v)] = d
         if self.poison and d < FULL:
             v[~self.G.levels[l].depth_mask(d)] = np.nan
@@ -213,7 +214,8 @@ class GhostCpuSequencer:
             res0 = self.norm_own(self.r[0])
         resvec = [res0]
         npre = max(1, int(p.relaxPre(1)))
-        can4 = fused4 and npre == 2
+        # (four_stage_serves: the pass consumes four ghost layers of x in one kernel - the fine level must have them)
+        can4 = fused4 and npre == 2 and (not self.active(0) or self.G.levels[0].gmin >= 4)
         pre_done, xnext, it = False, None, 0
         for count in range(1, maxIter + 1):
             cur = self.cycle_level(0, b, cur, x_zero, p.cycleType, r_valid=(count > 1 or not x_zero), xnext=xnext,

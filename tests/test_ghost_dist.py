@@ -36,6 +36,7 @@ CASES = {
     "3d-v11": ([32, 32, 32], 4, 1000, "SPAI", 1.0, 1, 1),
     "3d-v32": ([32, 32, 32], 4, 1000, "Jac", 0.8, 3, 2),
     "2d": ([64, 96], 4, 300, "Jac", 0.8, 2, 1),
+    "3d-a1": ([32, 32, 32], 4, 10000, "Jac", 0.8, 2, 1),        # ONE sharded level (the fine level's own ghost width must carry the four-stage pass)
 }
 
 
@@ -170,20 +171,33 @@ def mg():
     return m
 
 
-def test_ghost_boxes_are_nested_and_cover(mg):
+def test_ghost_boxes_cover_and_carry_their_own_widths(mg):
+    """Round 6: every sharded level has the ghost width its own passes consume (fine: 5 = four-stage pass + restriction, coarser: 3);
+    a level's box ends on nodes of the next level and the next level's box holds the parents of all its nodes."""
     from multigrid_jl_amd import ghost_dist as gd
     cells, nd, a = [64, 64, 128], [2, 2, 2], 3
     for rank in range(8):
         lv = gd.ghost_boxes(cells, nd, gd.default_box_of(rank, nd), a)
+        old = gd.ghost_boxes(cells, nd, gd.default_box_of(rank, nd), a, nested=True)
         for l in range(a):
             n_l = [(c >> l) + 1 for c in cells]
             for k in range(3):
                 (olo, ohi), (elo, ehi) = lv[l]["own"][k], lv[l]["ext"][k]
                 assert 0 <= elo <= olo <= ohi <= ehi <= n_l[k] - 1
+                assert old[l]["ext"][k][0] <= elo and ehi <= old[l]["ext"][k][1]                          # never larger than the nested boxes
+                want = gd.G_FINE if l == 0 else gd.G_LAST
+                assert olo == 0 or want <= olo - elo <= want + 1
+                assert ohi == n_l[k] - 1 or want <= ehi - ohi <= want + 1
                 if l + 1 < a:
-                    assert (elo, ehi) == (2 * lv[l + 1]["ext"][k][0], 2 * lv[l + 1]["ext"][k][1])     # nested: fine = 2*coarse - 1 nodes
+                    assert elo % 2 == 0 and ehi % 2 == 0                                                  # ends on nodes of the next level
+                    clo, chi = lv[l + 1]["ext"][k]
+                    assert clo <= elo // 2 and ehi // 2 <= chi                                            # the parents of every node
                     assert lv[l + 1]["own"][k] == (-(-olo // 2), ohi // 2)                               # owner of the coincident node
-        assert lv[a - 1]["gmin"] == gd.G_LAST and lv[0]["gmin"] >= 4 * gd.G_LAST - 3
+                    assert (old[l]["ext"][k][0], old[l]["ext"][k][1]) == (2 * old[l + 1]["ext"][k][0], 2 * old[l + 1]["ext"][k][1])
+        assert lv[0]["gmin"] >= gd.G_FINE and all(lv[l]["gmin"] >= gd.G_LAST for l in range(1, a))
+        assert old[a - 1]["gmin"] == gd.G_LAST and old[0]["gmin"] >= 4 * gd.G_LAST - 3
+    # one sharded level: the fine level's own width (ADVICE r5: 3 layers cannot carry the four-stage pass)
+    assert gd.ghost_boxes([32, 32, 32], [1, 1, 2], [0, 0, 1], 1)[0]["gmin"] >= 5
     # the owned boxes of a level tile the grid
     for l in range(a):
         seen = np.zeros([(c >> l) + 1 for c in cells][::-1], dtype=int)
@@ -245,7 +259,7 @@ def test_local_hierarchy_rows_equal_global(mg):
 
 
 @pytest.mark.parametrize("world,case,cyc", [(2, "3d-a2", "V"), (4, "3d-a2", "W"), (8, "3d-a2", "V"), (2, "3d-a3", "V"), (4, "3d-a3", "F"),
-                                            (2, "3d-v11", "V"), (4, "3d-v32", "V"), (2, "2d", "V"), (4, "2d", "W")])
+                                            (2, "3d-v11", "V"), (4, "3d-v32", "V"), (2, "2d", "V"), (4, "2d", "W"), (2, "3d-a1", "V"), (8, "3d-a1", "W")])
 def test_ghost_form_cpu_vs_oracle(mg, world, case, cyc):
     extra = _check(mg, world, case, cyc, "cpu")
     assert all(e["exchanges"] > 0 for e in extra)
@@ -415,7 +429,7 @@ def _worker_c4box(rank, world, port, cells, levels, q, steps):
 def test_c4_per_gpu_box_size_two_ranks_ghost_form_vs_c_oracle(mg):
     """BASELINE.json configs[3] (512^3 cells over 8 GPUs) puts a 257^3-node box on every GPU.  Two such boxes - 256 x 256 x 512
     cells, 33.9 M rows - on two ranks sharing this box's one GPU in the GHOST-LAYER form (host-staged transport): the fine level of
-    each rank runs the four-stage pass on 257 x 257 x 269 nodes, level 2 the 27-point marching form, the restriction the marching
+    each rank runs the four-stage pass on 257 x 257 x 261-263 nodes, level 2 the 27-point marching form, the restriction the marching
     form; four solveMG steps (from-zero step, two four-stage steps, last step) against the C/OpenMP oracle on the global hierarchy."""
     from oracle import c_oracle
     cells, levels, world, steps = [256, 256, 512], 6, 2, 4
@@ -438,7 +452,9 @@ def test_c4_per_gpu_box_size_two_ranks_ghost_form_vs_c_oracle(mg):
     assert res[0] == "ok", res[1]
     _, it, resvec, sums, info = res
     print("ghost form, C4 box size:", info)
-    assert info["four_stage"] == 1 and info["a"] == 3 and info["gmin"][0] >= 9, info
+    # round 6: every level carries its own ghost width - 5 fine layers (four-stage pass + restriction), 3 on the coarser levels
+    assert info["four_stage"] == 1 and info["a"] == 3 and info["gmin"] == [5, 3, 3], info
+    assert info["ext"][0][2] <= 257 + 6 and info["ext"][1][2] <= 129 + 4 and info["ext"][2][2] <= 65 + 3, info
     assert info["sweep_form"][0] == 3 and info["sweep_form"][1] == 5, info      # 2-D tile form on the fine level, 27-point marching form on level 2
     assert it == ito == steps
     assert np.abs(np.asarray(resvec) - rv).max() / rv[0] < 1e-10

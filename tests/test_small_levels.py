@@ -252,3 +252,49 @@ def test_galerkin_product_of_a_nearly_dense_level_on_the_gpu(mg, built, monkeypa
     monkeypatch.setenv("MG_SETUP_GPU", "1")
     thin = sp.random(4000, 4000, density=0.001, random_state=5, format="csr")
     assert not H.galerkin_dense_gpu_ok(thin, sp.random(4000, 300, density=0.01, random_state=6, format="csr"))
+
+
+@pytest.mark.parametrize("cells,nd,rank", [([32, 32, 64], [1, 1, 2], 1), ([32, 32, 64], [2, 2, 2], 0), ([32, 32, 64], [2, 2, 2], 7), ([64, 96], [2, 2], 3)])
+def test_embedded_grid_pair_transfers(mg, built, cells, nd, rank):
+    """Round 6: the extended boxes of the sharded cycle carry their own ghost widths, so a level's box pairs with a SUB-BOX of the
+    next level's box (ghost_dist.ghost_boxes).  grid_wave_restrict / grid_cell_prolong take that sub-box at its offset: R's rows
+    outside it are empty (written as 0), P reads no column outside it.  One rank's local operators against scipy."""
+    import torch
+    from multigrid_jl_amd import device as D, ghost_dist as gd
+    from multigrid_jl_amd.structured_setup import poisson_operator
+    world = int(np.prod(nd))
+    p = mg.getMGparam(np.float64, np.int64, 5 if len(cells) == 3 else 4, 8, 6, 1e-10, "Jac", 0.8, 2, 1, "V", "NoMUMPS", 0.5, 0.0)
+    G = gd.ghost_gmg(cells, nd, rank, world, p, poisson_operator(cells), replicate_below=1000 if len(cells) == 3 else 300, dry_tail=True)
+    assert G.a >= 2
+    h = D.DeviceHierarchy(G.param, 0, 1)
+    h0 = D.DeviceHierarchy(G.param, 0, 1, options={"no_small": 1, "no_cell_prolong": 1, "no_wave_restrict": 1})
+    rng = np.random.default_rng(11)
+    try:
+        embedded = 0
+        for l in range(1, G.a):
+            Pl, Rl = G.param.Ps[l - 1], G.param.Rs[l - 1]
+            nf, nc = Pl.shape
+            fine_n, coarse_n = G.levels[l - 1].ext_n, G.levels[l].ext_n
+            embedded += any(2 * c - 1 != f for f, c in zip(fine_n, coarse_n))
+            assert h.operator_kernel_variant(l, D.MG_OP_R) == 11 and h.operator_kernel_variant(l, D.MG_OP_P) == 10, (l, fine_n, coarse_n)
+            assert h0.operator_kernel_variant(l, D.MG_OP_R) not in (8, 11) and h0.operator_kernel_variant(l, D.MG_OP_P) not in (8, 10)
+            r, xc, x = rng.standard_normal(nf), rng.standard_normal(nc), rng.standard_normal(nf)
+            rt, xct = torch.from_numpy(r).cuda(), torch.from_numpy(xc).cuda()
+            ref = Rl @ r
+            for hh in (h, h0):
+                yc = torch.full((nc,), 7.0, dtype=torch.float64, device="cuda")
+                hh.spmv_dev(l, D.MG_OP_R, 1.0, rt, 0.0, yc)
+                assert np.abs(yc.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+            assert (yc.cpu().numpy()[np.diff(Rl.indptr) == 0] == 0.0).all()
+            ref = x + Pl @ xc
+            outs = []
+            for hh in (h, h0):
+                yf = torch.from_numpy(x).cuda()
+                hh.spmv_dev(l, D.MG_OP_P, 1.0, xct, 1.0, yf)
+                assert np.abs(yf.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+                outs.append(yf)
+            assert np.abs(outs[0].cpu().numpy() - outs[1].cpu().numpy()).max() <= 1e-13 * np.abs(ref).max()
+        assert embedded >= 1
+    finally:
+        h.close()
+        h0.close()
