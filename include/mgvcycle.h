@@ -558,6 +558,8 @@ int mg_ghost_set_dry(mg_hierarchy* h, long long on);
 /* exchanges started / doubles sent by this rank since mg_ghost_attach; ranks of the RCCL communicator (0: plug-in) */
 int mg_ghost_stats(mg_hierarchy* h, long long* exchanges, long long* doubles_sent);
 int mg_ghost_comm_count(mg_hierarchy* h, long long* count);
+/* all-reduces this rank entered since mg_ghost_attach (the scalars of norms / dots, the rows of the first replicated level) */
+int mg_ghost_allreduce_count(mg_hierarchy* h, long long* count);
 
 const char* mg_last_error(void);
 const char* mg_version(void);

@@ -3600,6 +3600,21 @@ __global__ __launch_bounds__(BLK) void sumsq_box_partial(const double* __restric
   const double s = block_sum(acc, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
+// x'y over the same sub-box (the dots of the sharded Krylov drivers count every global row once)
+__global__ __launch_bounds__(BLK) void dot_box_partial(const double* __restrict__ x, const double* __restrict__ y, BoxDev B, double* __restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * BLK) >> 6;
+  const int ly = B.hi[1] - B.lo[1], lz = B.hi[2] - B.lo[2];
+  double acc = 0.0;
+  for (long long q = wave; q < (long long)ly * lz; q += nwaves) {
+    const int z = (int)(q / ly) + B.lo[2], yy = (int)(q % ly) + B.lo[1];
+    const long long base = ((long long)z * B.n2 + yy) * B.n1;
+    for (int i = B.lo[0] + lane; i < B.hi[0]; i += 64) acc += x[base + i] * y[base + i];
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
 // ghost layers of a sharded level: dst[idx[i]] = src[i] (the received values into their places in the extended box)
 __global__ __launch_bounds__(BLK) void ghost_unpack(const double* __restrict__ src, const int* __restrict__ idx, double* __restrict__ dst, long long n) {
   const long long i = (long long)blockIdx.x * BLK + threadIdx.x;

@@ -145,6 +145,7 @@ SIGNATURES = {
     "mg_ghost_set_dry": (C.c_int, [_vp, _ll]),
     "mg_ghost_stats": (C.c_int, [_vp, _lp, _lp]),
     "mg_ghost_comm_count": (C.c_int, [_vp, _lp]),
+    "mg_ghost_allreduce_count": (C.c_int, [_vp, _lp]),
     "mg_last_error": (C.c_char_p, []),
     "mg_version": (C.c_char_p, []),
 }
@@ -487,6 +488,16 @@ class DeviceHierarchy:
         _check(self.lib, self.lib.mg_pcg_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, float(tol), int(maxIter),
                                                   C.byref(iters), C.byref(flag), _f64(resvec)), "mg_pcg_dev")
         return int(flag.value), int(iters.value), resvec[: iters.value]
+
+    def bicgstab_dev(self, b, x, tol: float, maxIter: int):
+        """solveBiCGSTAB_MG on device tensors (one right-hand side); returns (flag, iterations, resvec: the entry at the start, then
+        two per iteration)."""
+        _sync_torch(b, x)
+        iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        resvec = np.zeros(2 * max(int(maxIter), 1) + 1)
+        _check(self.lib, self.lib.mg_bicgstab_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, float(tol), int(maxIter),
+                                                       C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)), "mg_bicgstab_dev")
+        return int(flag.value), int(iters.value), resvec[: nres.value]
 
     def fgmres_dev(self, b, x, inner: int, tol: float, maxIter: int):
         """solveGMRES_MG on device tensors (one right-hand side); returns (flag, inner steps, resvec)."""

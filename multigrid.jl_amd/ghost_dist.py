@@ -483,6 +483,24 @@ class NativeGhostHierarchy:
         self.D._check(self.lib, self.lib.mg_ghost_stats(self.dev.handle, C.byref(a), C.byref(b)), "mg_ghost_stats")
         return int(a.value), int(b.value)
 
+    def allreduces(self) -> int:
+        """all-reduces this rank entered since attach (norms, dots, rows of the first replicated level)."""
+        import ctypes as C
+        c = C.c_longlong(0)
+        self.D._check(self.lib, self.lib.mg_ghost_allreduce_count(self.dev.handle, C.byref(c)), "mg_ghost_allreduce_count")
+        return int(c.value)
+
+    # -- MG-preconditioned Krylov on this rank's extended fine box (solveCG_MG / solveBiCGSTAB_MG / solveGMRES_MG, SolveFuncs.jl:74-133):
+    #    b, x device tensors of n_ext doubles, owned rows of b valid, owned rows of x valid on return; sums over the owned rows of all ranks
+    def pcg(self, b_ext, x_ext, tol: float, maxIter: int):
+        return self.dev.pcg_dev(b_ext, x_ext, tol, maxIter)
+
+    def bicgstab(self, b_ext, x_ext, tol: float, maxIter: int):
+        return self.dev.bicgstab_dev(b_ext, x_ext, tol, maxIter)
+
+    def fgmres(self, b_ext, x_ext, inner: int, tol: float, maxIter: int):
+        return self.dev.fgmres_dev(b_ext, x_ext, inner, tol, maxIter)
+
     def comm_count(self) -> int:
         import ctypes as C
         c = C.c_longlong(0)

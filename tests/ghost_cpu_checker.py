@@ -267,3 +267,153 @@ class GhostCpuSequencer:
             if res / res0 < tol:
                 break
         return it, np.array(resvec), cur
+
+
+# ---- sharded MG-preconditioned Krylov (mg_krylov.inc in the ghost-layer form): the oracle's drivers with the three sharded pieces -------
+class GhostKrylovCpu:
+    """KrylovMethods' cg / bicgstb / fgmres as oracle/mg_oracle.py restates them, on ONE rank's extended fine box the way the library
+    runs them on a ghost-attached handle: a dot is the sum over the owned rows of all ranks, a product with A follows one exchange
+    of its input's ghost layers, M is the sharded cycle from x = 0.  Counts exchanges (through the sequencer) and all-reduces."""
+
+    def __init__(self, S: GhostCpuSequencer):
+        self.S, self.G = S, S.G
+        self.own = self.G.levels[0].own_mask()
+        self.A = S.p.As[0]
+        self.allreduces = 0
+
+    def dot(self, x, y):
+        s = torch.tensor([float(np.dot(x[self.own], y[self.own]))], dtype=torch.float64)
+        if self.S.size > 1:
+            dist.all_reduce(s, group=self.S.group)
+        self.allreduces += 1
+        return float(s.item())
+
+    def norm(self, x):
+        return self.dot(x, x) ** 0.5
+
+    def Afun(self, v):
+        v = np.array(v, dtype=np.float64)
+        if self.S.active(0):
+            if self.S.poison:
+                v[~self.own] = np.nan               # (only the owned rows of a Krylov vector are meaningful)
+            self.S.depth[0][id(v)] = 0
+            self.S.need(0, v, 1)
+        return self.A @ v
+
+    def M(self, v):
+        return self.S.cycle(v, np.zeros_like(v), True)
+
+    def cg(self, b, x, tol, maxIter):
+        nr0 = self.norm(b)
+        r = b - self.Afun(x)
+        z = self.M(r)
+        p = z.copy()
+        resvec, flag, it = [], -1, 0
+        gamma = self.dot(r, z)
+        for it in range(1, maxIter + 1):
+            Ap = self.Afun(p)
+            alpha = gamma / self.dot(p, Ap)
+            if np.isinf(alpha) or alpha < 0:
+                flag = -2
+                break
+            x = x + alpha * p
+            r = r - alpha * Ap
+            rn = self.norm(r) / nr0
+            resvec.append(rn)
+            if rn <= tol:
+                flag = 0
+                break
+            z = self.M(r)
+            zr = self.dot(z, r)
+            beta, gamma = zr / gamma, zr
+            p = z + beta * p
+        return x, flag, it, np.array(resvec)
+
+    def bicgstb(self, b, x, tol, maxIter):
+        bn = self.norm(b)
+        r = b - self.Afun(x)
+        resvec = [self.norm(r) / bn]
+        rtld = r.copy()
+        omega, alpha, rho1, flag, it = 1.0, 0.0, 0.0, -1, 0
+        p = v = None
+        for it in range(1, maxIter + 1):
+            rho = self.dot(rtld, r)
+            if rho == 0:
+                flag = -2
+                break
+            p = r.copy() if it == 1 else r + ((rho / rho1) * (alpha / omega)) * (p - omega * v)
+            phat = self.M(p)
+            v = self.Afun(phat)
+            alpha = rho / self.dot(rtld, v)
+            s = r - alpha * v
+            sn = self.norm(s) / bn
+            resvec.append(sn)
+            if sn < tol:
+                x = x + alpha * phat
+                flag = -3
+                break
+            shat = self.M(s)
+            t = self.Afun(shat)
+            ts, tt = self.dot(t, s), self.dot(t, t)
+            self.allreduces -= 1                       # (the library sends the two scalars of omega in ONE all-reduce)
+            omega = ts / tt
+            x = x + alpha * phat + omega * shat
+            r = s - omega * t
+            err = self.norm(r) / bn
+            resvec.append(err)
+            if err <= tol:
+                flag = 0
+                break
+            if omega == 0:
+                flag = -2
+                break
+            rho1 = rho
+        return x, flag, it, np.array(resvec)
+
+    def fgmres(self, b, x, m, tol, maxIter):
+        n = b.size
+        bn = self.norm(b)
+        r = b - self.Afun(x)
+        rn = self.norm(r)
+        resvec, flag, total = [], -1, 0
+        for it in range(1, maxIter + 1):
+            V, Z, H = np.zeros((n, m + 1)), np.zeros((n, m)), np.zeros((m + 1, m))
+            cs, sn, s = np.zeros(m), np.zeros(m), np.zeros(m + 1)
+            V[:, 0] = r / rn
+            s[0] = rn
+            used = 0
+            for i in range(m):
+                Z[:, i] = self.M(V[:, i])
+                w = self.Afun(Z[:, i])
+                for k in range(i + 1):
+                    H[k, i] = self.dot(w, V[:, k])
+                    w = w - H[k, i] * V[:, k]
+                H[i + 1, i] = self.norm(w)
+                if H[i + 1, i] != 0:
+                    V[:, i + 1] = w / H[i + 1, i]
+                for k in range(i):
+                    t = cs[k] * H[k, i] + sn[k] * H[k + 1, i]
+                    H[k + 1, i] = -sn[k] * H[k, i] + cs[k] * H[k + 1, i]
+                    H[k, i] = t
+                rr = np.hypot(H[i, i], H[i + 1, i])
+                cs[i], sn[i] = (1.0, 0.0) if rr == 0 else (H[i, i] / rr, H[i + 1, i] / rr)
+                H[i, i], H[i + 1, i] = rr, 0.0
+                s[i + 1] = -sn[i] * s[i]
+                s[i] = cs[i] * s[i]
+                err = abs(s[i + 1]) / bn
+                resvec.append(err)
+                total += 1
+                used = i + 1
+                if err <= tol:
+                    flag = 0
+                    break
+            y = np.linalg.solve(np.triu(H[:used, :used]), s[:used])
+            x = x + Z[:, :used] @ y
+            if flag == 0:
+                break
+            r = b - self.Afun(x)
+            rn = self.norm(r)
+            if rn / bn <= tol:
+                flag = 0
+                break
+        return x, flag, total, np.array(resvec)

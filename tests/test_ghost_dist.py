@@ -104,8 +104,8 @@ def _worker(rank, world, port, case, cyc, mode, q, tol, maxit):
             H.cycle(bt, x2t, False)
             xc = x2t.cpu().numpy()
             extra["exchanges"], extra["sent"] = H.exchanges()
-            try:                # entry points whose sums would run over ghost rows are refused, not computed
-                H.dev.pcg_dev(bt, x2t.clone(), 1e-8, 2)
+            try:                # entry points whose sums would run over ghost rows (here: the host-pointer PCG) are refused, not computed
+                H.dev.pcg(b_ext, np.zeros_like(b_ext), 1e-8, 2)
                 extra["pcg_refused"] = False
             except mg.device.MGDeviceError as e:
                 extra["pcg_refused"] = "sharded" in str(e)
@@ -461,3 +461,135 @@ def test_c4_per_gpu_box_size_two_ranks_ghost_form_vs_c_oracle(mg):
     assert abs(sums[0] - xo.sum()) <= 1e-9 * np.abs(xo).sum() and abs(sums[1] - xo @ xo) <= 1e-10 * (xo @ xo)
     # communication the schedule issued: at most one fine-level exchange per step + two per coarser sharded level and step (+ b once)
     assert info["exchanges"] <= steps * (1 + 2 * (info["a"] - 1)) + 1, info
+
+
+# ---- sharded MG-preconditioned Krylov (round 6): solveCG_MG / solveBiCGSTAB_MG / solveGMRES_MG on ghost-attached handles ---------------
+def _worker_krylov(rank, world, port, case, cyc, mode, method, q, tol, maxit):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import multigrid_jl_amd as mg
+        from multigrid_jl_amd import ghost_dist as gd
+        from multigrid_jl_amd.structured_setup import poisson_operator
+        p, cells, rb = _param(mg, case, cyc)
+        G = gd.ghost_gmg(cells, _domains(world, len(cells), case), rank, world, p, poisson_operator(cells), replicate_below=rb)
+        A, mesh = mg.poisson_shifted(cells)
+        b = mg.seeded_rhs(A)
+        b_ext = b[G.gid_fine]
+        own = G.levels[0].own_mask()
+        x0 = np.zeros_like(b_ext)
+        if method == "bicgstab":            # (a non-zero start: the initial residual needs x's ghost layers)
+            x0 = (0.01 * np.random.default_rng(3).standard_normal(A.shape[0]))[G.gid_fine]
+        info = {}
+        if mode == "cpu":
+            from ghost_cpu_checker import GhostCpuSequencer, GhostKrylovCpu
+            S = GhostCpuSequencer(G)
+            K = GhostKrylovCpu(S)
+            if method == "pcg":
+                x, flag, it, resvec = K.cg(b_ext, x0, tol, maxit)
+            elif method == "bicgstab":
+                x, flag, it, resvec = K.bicgstb(b_ext, x0, tol, maxit)
+            else:
+                x, flag, it, resvec = K.fgmres(b_ext, x0, 3, tol, maxit)
+            info = dict(exchanges=S.exchanges, allreduces=K.allreduces)
+        else:
+            torch.cuda.set_device(0)
+            os.environ.update(MG_NO_SMALL="1", MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.3", MG_MARCH_MIN_WG="0",
+                              MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_WINP_MIN_ROWS="0", MG_MARCH27_MIN_ROWS="0", MG_MARCHR_MIN_ROWS="0")
+            H = gd.NativeGhostHierarchy(G, 0, transport="plugin" if world > 1 else "rccl")
+            bt = torch.from_numpy(b_ext).cuda()
+            # what ONE application of the preconditioner communicates (a cycle from x = 0)
+            e0, a0 = H.exchanges()[0], H.allreduces()
+            H.cycle(bt, torch.zeros_like(bt), True)
+            e_cyc, a_cyc = H.exchanges()[0] - e0, H.allreduces() - a0
+            x0n = x0.copy()
+            x0n[~own] = np.nan if method == "bicgstab" else 0.0      # (only the owned rows of x are the caller's to give)
+            xt = torch.from_numpy(x0n).cuda()
+            e0, a0 = H.exchanges()[0], H.allreduces()
+            if method == "pcg":
+                flag, it, resvec = H.pcg(bt, xt, tol, maxit)
+            elif method == "bicgstab":
+                flag, it, resvec = H.bicgstab(bt, xt, tol, maxit)
+            else:
+                flag, it, resvec = H.fgmres(bt, xt, 3, tol, maxit)
+            info = dict(exchanges=H.exchanges()[0] - e0, allreduces=H.allreduces() - a0, e_cyc=e_cyc, a_cyc=a_cyc)
+            x = xt.cpu().numpy()
+            H.close()
+        out = [None] * world
+        dist.all_gather_object(out, (G.gid_fine[own], x[own], int(flag), int(it), np.asarray(resvec), info))
+        if rank == 0:
+            xg = np.zeros_like(b)
+            for gid, xl, *_ in out:
+                xg[gid] = xl
+            q.put(("ok", [o[2] for o in out], [o[3] for o in out], [o[4] for o in out], xg, [o[5] for o in out]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+
+
+def _check_krylov(mg, world, case, cyc, mode, method, tol=1e-9, maxit=12):
+    from oracle import mg_oracle as orc
+    p, cells, _ = _param(mg, case, cyc)
+    A, mesh = mg.poisson_shifted(cells)
+    mg.MGsetup(A, mesh, p)
+    b = mg.seeded_rhs(A)
+    p.relativeTol, p.maxOuterIter = tol, maxit
+    if method == "pcg":
+        x_ref, flag_ref, it_ref, res_ref = orc.solveCG_MG(p, b, np.zeros_like(b))
+    elif method == "bicgstab":
+        x_ref, flag_ref, it_ref, res_ref = orc.solveBiCGSTAB_MG(p, b, 0.01 * np.random.default_rng(3).standard_normal(A.shape[0]))
+    else:
+        x_ref, flag_ref, it_ref, res_ref = orc.solveGMRES_MG(p, b, np.zeros_like(b), 3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_krylov, args=(r, world, port, case, cyc, mode, method, q, tol, maxit)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    try:
+        res = q.get(timeout=600)
+    finally:
+        for pr in procs:
+            pr.join(timeout=60)
+            if pr.is_alive():
+                pr.kill()
+    assert res[0] == "ok", res[1]
+    _, flags, its, resvecs, x, infos = res
+    assert all(f == flag_ref for f in flags) and all(i == it_ref for i in its), (flags, flag_ref, its, it_ref)
+    for rv in resvecs:                      # every rank holds the same, global, residual history
+        assert len(rv) == len(res_ref) and np.abs(rv - res_ref).max() <= 1e-10 * max(1.0, np.abs(res_ref).max()), (rv, res_ref)
+    assert np.abs(x - x_ref).max() <= 1e-10 * np.abs(x_ref).max()
+    return it_ref, infos
+
+
+@pytest.mark.parametrize("world,case,cyc,method", [(2, "3d-a2", "V", "pcg"), (4, "3d-a2", "V", "fgmres"), (8, "3d-a2", "V", "pcg"), (2, "3d-a3", "V", "bicgstab"),
+                                                   (4, "2d", "W", "pcg"), (2, "3d-a1", "V", "fgmres")])
+def test_ghost_form_krylov_cpu_vs_oracle(mg, world, case, cyc, method):
+    """The sharded drivers' three pieces - owned-row dots + all-reduce, one exchange in front of every product with A, the sharded cycle
+    as M - reproduce the oracle's iterates and iteration counts (numpy sequencer, NaN-poisoned ghost rows, gloo)."""
+    it, infos = _check_krylov(mg, world, case, cyc, "cpu", method)
+    assert it > 1 and all(i["exchanges"] > 0 for i in infos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case,cyc,method", [(1, "3d-a2", "V", "pcg"), (2, "3d-a2", "V", "pcg"), (4, "3d-a2", "V", "fgmres"), (2, "3d-a3", "V", "bicgstab"),
+                                                   (4, "3d-a2", "W", "pcg"), (2, "3d-a2", "V", "fgmres")])
+def test_ghost_form_krylov_hip_vs_oracle(mg, world, case, cyc, method):
+    """mg_pcg_dev / mg_bicgstab_dev / mg_fgmres_dev on ghost-attached handles (`world` processes sharing the GPU, host-staged transport;
+    RCCL at a world of one) against the oracle's solveCG_MG / solveBiCGSTAB_MG / solveGMRES_MG on the global hierarchy: same iterates,
+    same iteration counts; the communication per iteration is what the design says."""
+    k, infos = _check_krylov(mg, world, case, cyc, "plugin", method)
+    if world == 1:
+        return
+    for i in infos:
+        ec, ac = i["e_cyc"], i["a_cyc"]
+        assert ec > 0 and ac >= 1
+        if method == "pcg":        # k iterations, the k-th converged: products 1 + k (one exchange each), cycles k, scalars ||b||, r'z, k x (p'Ap, ||r||), (k-1) x z'r
+            assert i["exchanges"] == 1 + k + k * ec, (i, k)
+            assert i["allreduces"] == 1 + 3 * k + k * ac, (i, k)
+        elif method == "bicgstab":  # per iteration: 2 cycles, 2 products, scalars rho, r~'v, ||s||, (t's, t't) as ONE, ||r||
+            assert i["exchanges"] == 1 + k * (2 + 2 * ec), (i, k)
+            assert i["allreduces"] == 2 + k * (5 + 2 * ac), (i, k)
