@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no-generic-pass", action="store_true", help="skip the second pass with the streaming formats forced")
     ap.add_argument("--no-c5-leg", action="store_true", help="skip the 16-right-hand-side leg (BASELINE configs[4]) on the same handle")
     ap.add_argument("--no-divsiggrad", action="store_true", help="skip the variable-coefficient (div sigma grad) leg")
+    ap.add_argument("--no-c3-leg", action="store_true", help="skip the SA-AMG / general-CSR leg (BASELINE configs[2] at 128^3 cells) of the default line")
     ap.add_argument("--global-cells", default="", help="single-GPU path: a,b,c cells of a non-cubic grid with h = 1/--cells in every "
                                                        "direction (the GLOBAL grid of an N-GPU weak-scaling run, on one GPU)")
     ap.add_argument("--strong-reference", default="auto", choices=["auto", "on", "off"],
@@ -377,6 +378,7 @@ def main():
             while not hb_stop.wait(60.0):
                 print(f"[bench] host setup running, {time.perf_counter() - t_hb:.0f} s", file=sys.stderr, flush=True)
         threading.Thread(target=_heartbeat, daemon=True).start()
+        os.environ.setdefault("MG_SETUP_GPU", "1")     # (opt-in since round 6: the largest Galerkin products of this setup on the GPU; =0: host only)
         c3w = tuple(float(w) for w in args.c3_weights.split(","))
         A, mesh = mg.anisotropic_divsiggrad([cells] * 3, weights=c3w)
         t_op = time.perf_counter() - t0
@@ -387,8 +389,7 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):     # (per-level setup times go to stderr: stdout carries the one JSON line)
             mg.SA_AMGsetup(A, p, True, nrhs, verbose=True)
         hb_stop.set()
-        desc = (f"SA-AMG (theta=0.4, V(1,1) SPAI w=1) on anisotropic diffusion {cells}^3 cells, edge weights {':'.join(f'{w:g}' for w in c3w)} x "
-                f"log-normal sigma, general CSR")
+        desc = f"SA-AMG th=0.4 V(1,1) SPAI, anisotropic diffusion {cells}^3 cells, weights {':'.join(f'{w:g}' for w in c3w)} x lognormal, CSR"
     else:
         gc = [int(c) for c in args.global_cells.split(",")] if args.global_cells else [cells] * 3
         A, mesh = mg.poisson_shifted(gc, [v for g in gc for v in (0.0, g / float(cells))] if args.global_cells else None)
@@ -729,6 +730,26 @@ def main():
             "relres_after_steps": float(res2[-1] / res2[0]), "fine_level_form": {4: "band form (two-stage pass, values streamed once)",
                                                                                  0: "two launches (CSR kernels)"}.get(form2, str(form2)),
             "host_setup_s": round(t_set2, 1), "kernels": kt2}
+        # opt-in (mg_set_option band_sym_tol): symmetric reads on the 27-point Galerkin levels too, whose entries are symmetric only up to the
+        # rounding of R*(A*P) - the operator applied then differs from the stored one at rounding level (the default above is bit-faithful)
+        try:
+            h2t = mg.device.DeviceHierarchy(p2, device_id=local_rank, nrhs=1, options={"band_sym_tol": 1})
+            x2t = torch.zeros_like(b2)
+            h2t.solve_dev(b2, x2t, 0.0, max(1, W))
+            dtt = []
+            for _ in range(3):
+                x2t.zero_()
+                barrier()
+                t0 = time.perf_counter()
+                h2t.solve_dev(b2, x2t, 0.0, K)
+                barrier()
+                dtt.append(time.perf_counter() - t0)
+            roofline["divsiggrad"]["ms_per_step_with_band_sym_tol"] = round(sorted(dtt)[1] / K * 1e3, 4)
+            roofline["divsiggrad"]["band_form_L2"] = {"default": h2.band_form(2), "band_sym_tol": h2t.band_form(2)}
+            h2t.close()
+            del x2t
+        except Exception as e:
+            roofline["divsiggrad"]["ms_per_step_with_band_sym_tol"] = f"{type(e).__name__}: {e}"
         # 16 right-hand sides on this hierarchy: the matrix streams are real here (no row classes), so the block SpMM kernels - one pass
         # over A for all columns - are what runs (the column-wise path needs the four-stage pass of a constant-coefficient fine level)
         if not args.no_c5_leg:
@@ -759,6 +780,60 @@ def main():
         h2.close()
         del x2, b2, A2, p2
 
+    # ---- BASELINE configs[2] as a leg of the driver's line: SA-AMG on anisotropic diffusion, general CSR, at
+    # 128^3 cells (256^3 needs a minute of host setup: `--workload c3`).  Host setup as SA_AMGsetup does it, with its largest Galerkin
+    # products on the GPU (MG_SETUP_GPU=1, opt-in: same pattern, values to rounding - the leg times the CYCLE, not the setup). ---------
+    if args.workload == "c2" and nrhs == 1 and not args.no_c3_leg and not args.no_generic_pass and cells >= 128:
+        keep_env = os.environ.get("MG_SETUP_GPU")
+        try:
+            import contextlib
+            os.environ["MG_SETUP_GPU"] = "1"
+            c3c, K3 = 128, max(2, min(K, 5))
+            t0 = time.perf_counter()
+            A3, _ = mg.anisotropic_divsiggrad([c3c] * 3, weights=(1.0, 0.25, 0.0625))
+            p3 = mg.getMGparam(np.float64, np.int64, 14, os.cpu_count() or 8, K3, 0.0, "SPAI", 1.0, 1, 1, "V", "Julia", 0.4, 0.0)
+            with contextlib.redirect_stdout(sys.stderr):
+                mg.SA_AMGsetup(A3, p3, True, 1)
+            t_set3 = time.perf_counter() - t0
+            h3 = mg.device.DeviceHierarchy(p3, device_id=local_rank, nrhs=1)
+            n3 = A3.shape[0]
+            b3 = torch.from_numpy(np.ascontiguousarray(mg.seeded_rhs(A3, 1))).to(dev)
+            x3 = torch.zeros_like(b3)
+            h3.solve_dev(b3, x3, 0.0, 2)
+            d3 = []
+            for _ in range(3):
+                x3.zero_()
+                barrier()
+                t0 = time.perf_counter()
+                it3, res3 = h3.solve_dev(b3, x3, 0.0, K3)
+                barrier()
+                d3.append(time.perf_counter() - t0)
+            dt3 = sorted(d3)[1]
+            prof3, moved3, tot3 = profiled_pass(h3, b3, x3, K3, torch)
+            lev3 = {}
+            for (l, k), v in sorted(prof3.items()):
+                e = lev3.setdefault(l, [0.0, 0.0])
+                e[0] += v[0]
+                e[1] += moved3[(l, k)]
+            roofline["c3_leg"] = {
+                "workload": f"SA-AMG (theta 0.4, V(1,1) SPAI) on anisotropic diffusion {c3c}^3 cells, edge weights 16:4:1 x log-normal sigma, general CSR",
+                "ms_per_step": round(dt3 / K3 * 1e3, 4), "dof_updates_per_s": round(n3 * K3 / dt3, 1), "steps": K3, "N": int(n3),
+                "levels": int(p3.levels), "level_rows": [int(a.shape[0]) for a in p3.As], "level_nnz": [int(a.nnz) for a in p3.As],
+                "operator_complexity": round(sum(a.nnz for a in p3.As) / A3.nnz, 2), "relres_after_steps": float(res3[-1] / res3[0]),
+                "host_setup_s": round(t_set3, 1), "setup": "SA_AMGsetup on the host, its largest Galerkin products on the GPU (MG_SETUP_GPU=1)",
+                "per_level": {f"L{l}": {"ms_per_step": round(e[0] / K3, 4), "moved_MB_per_step": round(e[1] / K3 / 1e6, 1),
+                                        "frac": round(e[1] / e[0] / 1e6 / HBM_PEAK_GBS, 4) if e[0] > 0 else None} for l, e in sorted(lev3.items())},
+                "A_kernel_variant": [h3.operator_kernel_variant(l, mg.device.MG_OP_A) for l in range(1, int(p3.levels) + 1)]}
+            h3.close()
+            del b3, x3, A3, p3
+        except Exception as e:
+            roofline["c3_leg"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if keep_env is None:
+                os.environ.pop("MG_SETUP_GPU", None)
+            else:
+                os.environ["MG_SETUP_GPU"] = keep_env
+
     # ---- CPU baseline: the C/OpenMP oracle ("port") on a bounded sample of the same workload ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -770,8 +845,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64",   # (one GPU: neither weak nor strong)
             "data": "synthetic",
-            "config": {"workload": f"{desc} ({n} nodal DoF), {p.levels} levels, nrhs={nrhs}, fp64, "
-                                   f"one step = one cycle + residual + norm of solveMG",
+            "config": {"workload": f"{desc}, {p.levels} levels, nrhs={nrhs}, fp64"[:118],      # (kept under 120 characters: the driver's record cuts longer ones)
+                       "step": "one step = one cycle + the residual and norm of solveMG's stopping test (SolveFuncs.jl:24-37)",
                        "cells": cells, "levels": p.levels, "nrhs": nrhs, "N": n, "nnz": int(A.nnz),
                        "level_rows": [int(a.shape[0]) for a in p.As], "level_nnz": [int(a.nnz) for a in p.As],
                        "parallelism": "1 process per GPU"},
@@ -994,9 +1069,8 @@ def bench_weak(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
             "metric": "V-cycle DoF-updates/s", "value": round(n * K / dt, 1), "unit": "DoF-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"3D 7-pt Poisson, " + (f"{cells}^3 cells" if strong else f"{cells}^3 cells per GPU") + f" = {gcells} cells global ({n} nodal DoF), "
-                                   f"GMG V(2,1) damped-Jacobi w=0.8, {levels} levels, nrhs=1, fp64, "
-                                   f"solveMG step = cycle + residual + norm",
+            "config": {"workload": (f"3D 7-pt Poisson {gcells} cells" + ("" if strong else f" ({cells}^3 per GPU)") + f", GMG V(2,1) Jacobi w=0.8, {levels} levels, nrhs=1, fp64")[:118],
+                       "step": "one step = one cycle + the residual and norm of solveMG's stopping test",
                        "cells_per_gpu": cells, "global_cells": gcells, "levels": levels, "nrhs": 1, "N": n,
                        "parallelism": f"DomainDecomposition boxes {domains}, {len(Hpy.levels)} sharded levels, replicated "
                                       f"tail from {Hpy.n_tail} rows, " +
@@ -1150,8 +1224,8 @@ def bench_ghost(args, mg, torch, dist, cells, K, W, rank, world, local_rank):
             "n_gpus": 1 if dry else world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
             "timed_regions_ms_per_step": [round(v / K * 1e3, 4) for v in region],
             "higher_is_better": True, "scaling": (None if (world == 1) else args.scaling), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3D 7-pt Poisson, " + (f"{cells}^3 cells" if strong else f"{cells}^3 cells per GPU") + f" = {gcells} cells global ({n} nodal DoF), "
-                                   f"GMG V(2,1) damped-Jacobi w=0.8, {levels} levels, nrhs=1, fp64; one step = one cycle + residual + norm of solveMG",
+            "config": {"workload": (f"3D 7-pt Poisson {gcells} cells" + ("" if strong else f" ({cells}^3 per GPU)") + f", GMG V(2,1) Jacobi w=0.8, {levels} levels, nrhs=1, fp64")[:118],
+                       "step": "one step = one cycle + the residual and norm of solveMG's stopping test",
                        "cells_per_gpu": cells, "global_cells": gcells, "levels": levels, "nrhs": 1, "N": n,
                        "parallelism": f"DomainDecomposition boxes {domains} with ghost layers (the reference's overlap, DDIndices.jl:61-92): {G.a} sharded levels on "
                                       f"extended boxes, ghost widths {[L.gmin for L in G.levels]}, replicated levels from {G.n_tail} rows; every rank runs the "
@@ -1238,8 +1312,8 @@ def bench_distributed(args, mg, torch, dist, A, mesh, p, b_host, cells, nrhs, K,
             "metric": "V-cycle DoF-updates/s", "value": round(n * nrhs * K / dt, 1), "unit": "DoF-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"3D 7-pt Poisson {cells}^3 cells ({n} nodal DoF), GMG V(2,1) damped-Jacobi w=0.8, "
-                                   f"{p.levels} levels, nrhs={nrhs}, fp64, solveMG step = cycle + residual + norm",
+            "config": {"workload": f"3D 7-pt Poisson {cells}^3 cells, GMG V(2,1) Jacobi w=0.8, {p.levels} levels, nrhs={nrhs}, fp64"[:118],
+                       "step": "one step = one cycle + the residual and norm of solveMG's stopping test",
                        "cells": cells, "levels": p.levels, "nrhs": nrhs, "N": n, "nnz": int(A.nnz),
                        "parallelism": f"DomainDecomposition boxes {domains}, {len(H.levels)} sharded levels, "
                                       f"replicated tail from {H.n_tail} rows, all_to_all_single halo per SpMV (RCCL)"},

@@ -299,9 +299,15 @@ void* mg_spgemm_symbolic_INT32(long long n_rows, long long ncols_B, const int* A
     std::vector<int>& out = plan->chunk[(std::size_t)t];
     std::vector<unsigned long long> bits;
     std::vector<int> stamp;
-    try {
+    // (an exception must not leave the worksharing loop - OpenMP has no unwinding across it, the throwing thread would skip the
+    // loop's barrier: every iteration catches its own, raises the shared flag, and the remaining iterations do nothing)
 #pragma omp for schedule(dynamic, 16)
-      for (long long i = 0; i < n_rows; ++i) {
+    for (long long i = 0; i < n_rows; ++i) {
+      bool skip;
+#pragma omp atomic read
+      skip = failed;
+      if (skip) continue;
+      try {
         long long products = 0;
         for (long long k = A_ptr[i]; k < A_ptr[i + 1]; ++k) products += B_ptr[A_idx[k] + 1] - B_ptr[A_idx[k]];
         plan->owner[(std::size_t)i] = t;
@@ -349,10 +355,10 @@ void* mg_spgemm_symbolic_INT32(long long n_rows, long long ncols_B, const int* A
           std::sort(out.begin() + (std::ptrdiff_t)at, out.end());
         }
         C_ptr[i + 1] = (long long)(out.size() - at);
+      } catch (...) {
+#pragma omp atomic write
+        failed = true;
       }
-    } catch (...) {
-#pragma omp critical
-      failed = true;
     }
   }
   if (failed) { delete plan; return nullptr; }
@@ -369,11 +375,23 @@ int mg_spgemm_numeric_FP64_INT32(void* plan_, const int* A_ptr, const int* A_idx
   if (!plan) return 1;
   if (nthreads > 0) omp_set_num_threads((int)nthreads);
   const long long n_rows = plan->n_rows;
+  bool failed = false;
 #pragma omp parallel
   {
-    std::vector<double> acc((std::size_t)plan->ncols, 0.0);
+    std::vector<double> acc;
+    try {
+      acc.assign((std::size_t)plan->ncols, 0.0);
+    } catch (...) {          // (out of memory for a thread's accumulator: reported after the region, never std::terminate)
+#pragma omp atomic write
+      failed = true;
+    }
+#pragma omp barrier
 #pragma omp for schedule(dynamic, 16)
     for (long long i = 0; i < n_rows; ++i) {
+      bool skip;
+#pragma omp atomic read
+      skip = failed;
+      if (skip) continue;
       const long long out0 = C_ptr[i], cnt = C_ptr[i + 1] - C_ptr[i];
       if (cnt == 0) continue;
       const int* pat = plan->chunk[(std::size_t)plan->owner[(std::size_t)i]].data() + plan->where[(std::size_t)i];
@@ -390,7 +408,7 @@ int mg_spgemm_numeric_FP64_INT32(void* plan_, const int* A_ptr, const int* A_idx
     }
   }
   delete plan;
-  return 0;
+  return failed ? 2 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

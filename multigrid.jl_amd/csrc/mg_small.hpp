@@ -243,17 +243,20 @@ struct Band27Dev {
   const double* val;   // [27][stride]; every slot is followed by zeros (stride >= n + P + n1 + 1)
   long long stride;
   int n1, n2, n3, P, n;
-  int sym;             // the values are symmetric entry by entry up to the rounding of the Galerkin product R*(A*P) that made them
+  int sym;             // the values are symmetric entry by entry - BIT FOR BIT by default (round 6; then reading a lower entry from the neighbour's
+                       // upper one changes nothing), or, with the option band_sym_tol, up to the rounding of the Galerkin product R*(A*P) that made them
                        // (band27_sym_check: |A[i,j] - A[j,i]| <= 2^-50 |A[i,i]|; measured 1e-16 on div sigma grad): the 13 lower slots of row r are READ from the upper
                        // slots of the neighbour - slot (dz,dy,dx) of row r = slot (-dz,-dy,-dx) of row r + dz*P + dy*n1 + dx - so that
                        // 14 of the 27 planes are streamed from HBM; workgroups then take rows in XCD bands (the re-read lines sit in that L2)
 };
 // bad += rows whose lower entries differ from the neighbours' upper ones by more than the rounding of a Galerkin product (the two
 // are sums of the same terms in different orders); an entry one side has and the other lacks (a 0) counts unless it is that small
-__global__ __launch_bounds__(256) void band27_sym_check(Band27Dev T, int* __restrict__ bad) {
+// rtol = 0 (the default): bit for bit - the operator the kernel applies IS the stored one; rtol = 2^-50 (option band_sym_tol): up to the
+// rounding of the Galerkin product, |A[i,j] - A[j,i]| <= rtol |A[i,i]|
+__global__ __launch_bounds__(256) void band27_sym_check(Band27Dev T, double rtol, int* __restrict__ bad) {
   const int row = (int)(blockIdx.x * 256 + threadIdx.x);
   if (row >= T.n) return;
-  const double tol = 8.8817841970012523e-16 * fabs(T.val[13LL * T.stride + row]);   // 2^-50 |A[i,i]|
+  const double tol = rtol * fabs(T.val[13LL * T.stride + row]);
   bool ok = true;
 #pragma unroll
   for (int s = 0; s < 13; ++s) {

@@ -217,9 +217,8 @@ def ghost_gmg(global_cells, numDomains, rank: int, size: int, param: MGparam, op
     anything).  ``gather_objects(obj) -> list`` (one entry per rank) defaults to ``torch.distributed.all_gather_object``;
     it is called once, for the rows of the first replicated level."""
     from .structured_setup import setup_on_margin_box
-    if param.relaxType not in ("Jac", "SPAI") or param.cycleType not in ("V", "W", "F"):
-        raise NotImplementedError("the ghost-layer form runs the pointwise smoothers and the V / W / F cycles "
-                                  "(Jac-GMRES and the K-cycle: the halo form, distributed.NativeDistributedHierarchy)")
+    if param.relaxType not in ("Jac", "SPAI", "Jac-GMRES") or param.cycleType not in ("V", "W", "F", "K"):
+        raise NotImplementedError(f"the ghost-layer form does not know relaxType {param.relaxType!r} / cycleType {param.cycleType!r}")
     S = setup_on_margin_box(global_cells, numDomains, rank, size, param, operator, domain, replicate_below)
     cells, nd, dim, nl, a = S["cells"], S["nd"], S["dim"], S["nl"], S["a"]
     As, Ps, Rs, ds, geoms = S["As"], S["Ps"], S["Rs"], S["ds"], S["geoms"]
@@ -389,12 +388,15 @@ class NativeGhostHierarchy:
     transport="dry": timing aid - one rank of a larger world alone on its GPU, nothing travels (``ghost_gmg(dry_tail=True)``);
     a world of one rank needs none of them."""
 
-    def __init__(self, G: GhostSetup, device_id: int = 0, transport: str = "rccl", group=None, options=None):
+    def __init__(self, G: GhostSetup, device_id: int = 0, transport: str = "rccl", group=None, options=None, collectives=None):
         import ctypes as C
         from . import device as D
         self.G = G
         self.D = D
         self.group = group
+        # plug-in transport only: an object with all_to_all(send, send_splits, recv_splits) -> recv and all_reduce(values) -> sums on
+        # numpy arrays (default: torch.distributed on `group`); e.g. ranks that are THREADS of one process (tests/test_ghost_dist.py)
+        self.collectives = collectives
         self.nrhs = int(getattr(G.param, "nrhs", 1) or 1)      # (a block is solved column by column: mg_solve_dev_FP64, ghost-layer form)
         self.dev = D.DeviceHierarchy(G.param, device_id, self.nrhs, options=options)
         self.lib = lib = self.dev.lib
@@ -439,20 +441,29 @@ class NativeGhostHierarchy:
         dp, lp = C.POINTER(C.c_double), C.POINTER(C.c_longlong)
         FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_longlong, dp, lp, dp, lp, C.c_longlong)
 
+        class _TorchCollectives:
+            def all_to_all(self, send, ss, rs):
+                r_t = torch.zeros(sum(rs), dtype=torch.float64)
+                dist.all_to_all_single(r_t, torch.from_numpy(send), rs, ss, group=group)
+                return r_t.numpy()
+
+            def all_reduce(self, values):
+                t = torch.from_numpy(values)
+                dist.all_reduce(t, group=group)
+                return t.numpy()
+
+        coll = self.collectives if self.collectives is not None else _TorchCollectives()
+
         def cb(_user, op, send, send_splits, recv, recv_splits, count):
             try:
                 if op == 0:
                     ss = [int(send_splits[i]) for i in range(size)]
                     rs = [int(recv_splits[i]) for i in range(size)]
-                    s_t = torch.from_numpy(np.ctypeslib.as_array(send, shape=(max(sum(ss), 1),))[: sum(ss)].copy())
-                    r_t = torch.zeros(sum(rs), dtype=torch.float64)
-                    dist.all_to_all_single(r_t, s_t, rs, ss, group=group)
+                    out = coll.all_to_all(np.ctypeslib.as_array(send, shape=(max(sum(ss), 1),))[: sum(ss)].copy(), ss, rs)
                     if sum(rs):
-                        np.ctypeslib.as_array(recv, shape=(sum(rs),))[:] = r_t.numpy()
+                        np.ctypeslib.as_array(recv, shape=(sum(rs),))[:] = out
                 elif op == 1:
-                    t = torch.from_numpy(np.ctypeslib.as_array(send, shape=(int(count),)).copy())
-                    dist.all_reduce(t, group=group)
-                    np.ctypeslib.as_array(recv, shape=(int(count),))[:] = t.numpy()
+                    np.ctypeslib.as_array(recv, shape=(int(count),))[:] = coll.all_reduce(np.ctypeslib.as_array(send, shape=(int(count),)).copy())
                 else:
                     return 1
                 return 0

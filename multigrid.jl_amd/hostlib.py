@@ -240,10 +240,15 @@ def sa_strength(A, theta: float, nthreads: int = 0):
 # products for R*(A*P) on the host, 300 of the setup's 540 s.  As dense fp64 GEMMs (rocBLAS through torch.matmul) the same product
 # is seconds.  The PATTERN is the structural one (an entry whose terms cancel is kept, as Julia's and scipy's sparse products keep
 # it): indicator matrices multiplied in fp32 (counts < 2^24: exact).  Values: the same terms summed in GEMM order instead of
-# Gustavson order (differences at rounding level).  MG_SETUP_GPU=0 keeps every product on the host.
+# Gustavson order (differences at rounding level).  OPT-IN (round 6): MG_SETUP_GPU=1 - by default every product of the setup
+# stays on the host, as the reference's does, and the hierarchy does not depend on whether a GPU is present.
 # ------------------------------------------------------------------------------------------------------------------------
+def setup_on_gpu_enabled() -> bool:
+    return os.environ.get("MG_SETUP_GPU", "0") == "1"
+
+
 def galerkin_dense_gpu_ok(A, P) -> bool:
-    if os.environ.get("MG_SETUP_GPU", "1") == "0":
+    if not setup_on_gpu_enabled():
         return False
     n, nc = A.shape[0], P.shape[1]
     if A.shape[0] != A.shape[1] or n < int(os.environ.get("MG_SETUP_GPU_MIN_ROWS", "3000")) or A.nnz < float(os.environ.get("MG_SETUP_GPU_MIN_DENSITY", "0.04")) * n * n:
@@ -255,7 +260,9 @@ def galerkin_dense_gpu_ok(A, P) -> bool:
         free, _ = torch.cuda.mem_get_info()
     except Exception:
         return False
-    need = 8.0 * (n * n + 2.0 * n * nc) + 4.0 * (n * n + 2.0 * n * nc) + 16.0 * A.nnz + 2.0e9
+    # operands and products in fp64 + their indicators in fp32, the comparison / index temporaries of the pattern (1 B per entry of
+    # A*P and R*(A*P), 16 B per stored entry of the result, its values), the index lists of the scatter
+    need = 8.0 * (n * n + 2.0 * n * nc) + 4.0 * (n * n + 2.0 * n * nc) + 1.0 * (n * nc + nc * nc) + 28.0 * nc * nc + 16.0 * A.nnz + 2.0e9
     return need < 0.8 * free
 
 
@@ -275,8 +282,21 @@ def _dense_on_gpu(M, torch, dev):
 
 
 def galerkin_dense_gpu(R, A, P):
-    """A_c = R*(A*P) through dense GEMMs on the GPU; CSR (int32, sorted) with the structural pattern of the sparse product."""
+    """A_c = R*(A*P) through dense GEMMs on the GPU; CSR (int32, sorted) with the structural pattern of the sparse product.
+    None when it does not go through (out of memory, a rocBLAS error): the caller then multiplies on the host."""
     import torch
+    try:
+        return _galerkin_dense_gpu(R, A, P, torch)
+    except Exception as e:
+        print(f"[multigrid.jl_amd] dense GPU Galerkin product not used ({type(e).__name__}: {str(e)[:120]}): host product", file=sys.stderr, flush=True)
+        try:
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+        return None
+
+
+def _galerkin_dense_gpu(R, A, P, torch):
     dev = torch.device("cuda", torch.cuda.current_device())
     Ad, As_ = _dense_on_gpu(A, torch, dev)
     Pd, Ps_ = _dense_on_gpu(P, torch, dev)
@@ -308,7 +328,7 @@ def galerkin_dense_gpu(R, A, P):
 # operands (structural pattern, checked against the host product in tests; values to rounding).  Taken from MG_SETUP_GPU_MIN_PRODUCTS
 # estimated products on (the 241 k-row level of C3 at 256^3: 2.7 x 10^11); any failure (memory) falls back to the host product.
 def galerkin_sparse_gpu_ok(A, P) -> bool:
-    if os.environ.get("MG_SETUP_GPU", "1") == "0" or os.environ.get("MG_SETUP_GPU_SPARSE", "1") == "0":
+    if not setup_on_gpu_enabled() or os.environ.get("MG_SETUP_GPU_SPARSE", "1") == "0":
         return False
     est = float(A.nnz) * float(P.nnz) / max(1, P.shape[0])
     if est < float(os.environ.get("MG_SETUP_GPU_MIN_PRODUCTS", "5e9")):

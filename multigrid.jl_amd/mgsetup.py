@@ -75,9 +75,12 @@ def galerkin(R, A, P):
     The reference's serial Julia SpGEMM is the bulk of its setup time; here it is row-parallel on the host
     (csrc/mg_host.cpp) - still CPU, still before the device ever sees the hierarchy."""
     from .hostlib import galerkin_dense_gpu, galerkin_dense_gpu_ok, galerkin_sparse_gpu, galerkin_sparse_gpu_ok, spgemm
-    if galerkin_dense_gpu_ok(A, P):        # (nearly dense levels of an SA-AMG hierarchy, a GPU at hand: dense GEMMs - hostlib.py)
-        return galerkin_dense_gpu(R, A, P)
-    if galerkin_sparse_gpu_ok(A, P):       # (10^10 products and more: rocSPARSE's SpGEMM)
+    # (opt-in, MG_SETUP_GPU=1: the largest products of an SA-AMG setup on the GPU - same pattern, values to rounding; hostlib.py)
+    if galerkin_dense_gpu_ok(A, P):        # nearly dense levels: dense GEMMs
+        Ac = galerkin_dense_gpu(R, A, P)
+        if Ac is not None:
+            return Ac
+    if galerkin_sparse_gpu_ok(A, P):       # 10^10 products and more: rocSPARSE's SpGEMM
         Ac = galerkin_sparse_gpu(R, A, P)
         if Ac is not None:
             return Ac

@@ -166,11 +166,18 @@ class GhostCpuSequencer:
         xc = self.cycle_level(l + 1, bc, None, True, ctype)
         if l + 1 < len(p.As) - 1 and ctype in ("W", "F"):
             xc = self.cycle_level(l + 1, bc, xc, False, "W" if ctype == "W" else "V")
+        got = FULL
         if l + 1 < a and self.active(l + 1):
-            self.need(l + 1, xc, FULL)
+            # a correction valid on k >= 1 layers gives a fine vector valid on 2k - 1; it travels only where that falls short of
+            # what the post-smoothing (and the fused pass behind a deferred last sweep) consume
+            want = npost - (1 if defer_post else 0) + (5 if defer_post else 0)
+            reach = lambda: FULL if self.dep(l + 1, xc) >= FULL else 2 * self.dep(l + 1, xc) - 1
+            if reach() < min(want, self.G.levels[l].gmin):
+                self.need(l + 1, xc, FULL)
+            got = reach()
         dcur = self.dep(l, cur)
         cur = cur + p.Ps[l] @ xc
-        self.setd(l, cur, dcur)
+        self.setd(l, cur, min(dcur, got))
         nlast = npost - (1 if defer_post else 0)
         for _ in range(nlast):
             cur = self.sweep(l, b, cur)

@@ -210,8 +210,7 @@ def test_gloo_distributed_box_form(built, world, kind, cyc):
 
 # ---- GPU: the HIP kernels under the same schedule ---------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,nrhs,cyc", [(1, "gmg3d", 1, "V"), (2, "gmg3d", 1, "V"), (2, "gmg3d", 4, "W"),
-                                                 (2, "sa", 1, "V")])
+@pytest.mark.parametrize("world,kind,nrhs,cyc", [(2, "gmg3d", 4, "W"), (2, "sa", 1, "V")])
 def test_hip_distributed_solve_matches_oracle(built, world, kind, nrhs, cyc):
     _run(world, kind, nrhs, cyc, use_hip=True)
 
@@ -232,8 +231,7 @@ def test_hip_distributed_rowclass_with_exception_rows(built, world, monkeypatch)
 
 # ---- the native sequencer behind the C ABI (mg_dist_*) ----------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,cyc", [(1, "gmg3d", "V"), (2, "gmg3d", "V"), (2, "gmg3d", "W"), (4, "gmg3d", "F"),
-                                            (2, "gmg2d", "V"), (2, "sa", "V")])
+@pytest.mark.parametrize("world,kind,cyc", [(2, "gmg3d", "W"), (4, "gmg3d", "F"), (2, "sa", "V")])
 def test_native_sequencer_plugin_transport(built, world, kind, cyc):
     """mg_dist_* with the host-staged exchange plug-in (gloo underneath), `world` fresh processes sharing the one GPU:
     the C++ level schedule, pack kernels, interior/boundary split and replicated tail must reproduce the oracle."""
@@ -241,8 +239,7 @@ def test_native_sequencer_plugin_transport(built, world, kind, cyc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,nrhs,cyc", [(2, "gmg3d", 3, "V"), (2, "sa", 2, "V"), (4, "gmg3d", 4, "W"), (1, "gmg2d", 2, "F"),
-                                                 (2, "gmg3d", 16, "V")])
+@pytest.mark.parametrize("world,kind,nrhs,cyc", [(2, "sa", 2, "V"), (4, "gmg3d", 4, "W"), (2, "gmg3d", 16, "V")])
 def test_native_sequencer_blocks_of_right_hand_sides(built, world, kind, nrhs, cyc):
     """mg_dist_* with nrhs > 1 (MGdef.jl:163-176: the reference is block-capable everywhere; one Frobenius criterion for the
     block, SolveFuncs.jl:30): row-major [n][nrhs] blocks through the pack kernels, the halo exchange, the SpMM kernels, the
@@ -252,8 +249,7 @@ def test_native_sequencer_blocks_of_right_hand_sides(built, world, kind, nrhs, c
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,cyc,native", [(1, "gmg3d", "V", "plugin"), (2, "gmg3d", "V", "plugin"), (4, "gmg3d", "F", "plugin"),
-                                                   (2, "gmg3d", "W", None), (2, "gmg2d", "V", "plugin")])
+@pytest.mark.parametrize("world,kind,cyc,native", [(4, "gmg3d", "F", "plugin"), (2, "gmg3d", "W", None), (2, "gmg2d", "V", "plugin")])
 def test_box_form_local_operators_hip(built, world, kind, cyc, native):
     """Sharded levels in BOX form on the device: the local A is one square grid operator (z-marching / plane-tile kernels
     for the rows of the owned box that do not read the halo, csr_rows_spmv for those that do, after the exchange), driven
@@ -272,8 +268,7 @@ def test_native_box_form_default_thresholds(built, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,cyc,box", [(1, "gmg3d", "K", False), (2, "gmg3d", "K", False), (4, "gmg3d", "K", True),
-                                                (2, "gmg3d-jacgmres", "V", False), (2, "gmg3d-jacgmres", "K", True),
+@pytest.mark.parametrize("world,kind,cyc,box", [(2, "gmg3d", "K", False), (4, "gmg3d", "K", True), (2, "gmg3d-jacgmres", "K", True),
                                                 (4, "gmg3d-jacgmres", "W", False)])
 def test_native_sequencer_kcycle_and_jac_gmres(built, world, kind, cyc, box):
     """The K-cycle (2 FGMRES steps per level preconditioned by the next level's K-cycle, MGcycle.jl:72-76) and the Jac-GMRES
@@ -437,14 +432,16 @@ def _worker_c4box(rank, world, port, cells, levels, q):
 
 
 @pytest.mark.gpu
-def test_c4_per_gpu_box_size_two_ranks_vs_c_oracle(built):
-    """BASELINE.json configs[3] (512^3 cells over 8 GPUs) puts a 257^3-node box on every GPU.  Two such boxes - 256 x 256 x 512
-    cells, 33.9 M rows - on two ranks sharing this box's one GPU (host-staged plug-in transport): sharded host setup, box-form
-    levels, the fused sweep + residual pairs with their face-layer list kernels, replicated tail; two solveMG steps against the
-    C/OpenMP oracle on the global hierarchy (residual history to 1e-10, sum and norm of the iterate)."""
+def test_halo_form_large_boxes_two_ranks_vs_c_oracle(built):
+    """The HALO form (mg_dist_*: general CSR, block cycles, K-cycle, Jac-GMRES) on two 129^3-node boxes - 128 x 128 x 256 cells,
+    4.3 M rows - on two ranks sharing this box's one GPU (host-staged plug-in transport): sharded host setup, box-form levels, the
+    fused sweep + residual pairs with their face-layer list kernels, replicated tail; two solveMG steps against the C/OpenMP
+    oracle on the global hierarchy (residual history to 1e-10, sum and norm of the iterate).  BASELINE.json configs[3]'s per-GPU
+    box size (two 257^3 boxes) runs in the ghost-layer form, the default sharded path:
+    tests/test_ghost_dist.py::test_c4_per_gpu_box_size_two_ranks_ghost_form_vs_c_oracle (until round 5 it ran in both forms)."""
     from oracle import c_oracle
     import multigrid_jl_amd as mg
-    cells, levels, world = [256, 256, 512], 6, 2
+    cells, levels, world = [128, 128, 256], 5, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -463,7 +460,7 @@ def test_c4_per_gpu_box_size_two_ranks_vs_c_oracle(built):
         pr.join(timeout=300)
     assert res[0] == "ok", res[1]
     _, it, resvec, sums, info = res
-    assert info[0] and info[1] > 60000 and info[2] > 60000, info      # the two-stage pass with a real face layer on each rank
+    assert info[0] and info[1] > 15000 and info[2] > 15000, info      # the two-stage pass with a real face layer on each rank
     assert it == ito == 2
     assert np.abs(np.asarray(resvec) - rv).max() / rv[0] < 1e-10
     assert abs(sums[0] - xo.sum()) <= 1e-9 * np.abs(xo).sum() and abs(sums[1] - xo @ xo) <= 1e-10 * (xo @ xo)

@@ -29,6 +29,140 @@ def _free_port():
     return p
 
 
+class _ThreadWorld:
+    """`size` ranks that are THREADS of this process (one GPU context: the pool allows at most 6 GPU processes, C4 has 8 ranks).
+    The collectives of the plug-in transport over shared memory and a barrier; every rank enters every collective (the library's
+    schedule takes the same decisions on all ranks)."""
+
+    def __init__(self, size):
+        import threading
+        self.size = size
+        self.bar = threading.Barrier(size)
+        self.slot = [None] * size
+
+    def view(self, rank):
+        world = self
+
+        class _C:
+            def all_to_all(self, send, ss, rs):
+                world.slot[rank] = (send, ss)
+                world.bar.wait()
+                parts = []
+                for q in range(world.size):
+                    sq, ssq = world.slot[q]
+                    o = int(sum(ssq[:rank]))
+                    assert ssq[rank] == rs[q], "exchange plans of two ranks disagree"
+                    parts.append(sq[o:o + ssq[rank]])
+                out = np.concatenate(parts) if parts else np.zeros(0)
+                world.bar.wait()
+                return out
+
+            def all_reduce(self, values):
+                world.slot[rank] = values
+                world.bar.wait()
+                tot = np.sum([world.slot[q] for q in range(world.size)], axis=0)
+                world.bar.wait()
+                return tot
+
+        return _C()
+
+
+
+# format switches that make the tests' small grids take the kernels of the large ones (per handle: mg_set_option)
+TEST_OPTS = dict(no_small=1, rowclass_min_rows=0, rowclass_max_passes=64, rowclass_min_cover=0.3, march_min_wg=0, tile_min_wg=0, window_min_wg=0,
+                 winp_min_rows=0, march27_min_rows=0, marchr_min_rows=0)
+
+
+def _setup_all_ranks(mg, world, case, cyc, nrhs=1, nd=None):
+    """Host setup of EVERY rank in this process: what all_gather_object would deliver is captured in a first pass."""
+    from multigrid_jl_amd import ghost_dist as gd
+    from multigrid_jl_amd.structured_setup import poisson_operator
+    _, cells, rb = _param(mg, case, cyc)
+    nd = nd or _domains(world, len(cells), case)
+    pieces = {}
+    if world == 1:       # (nothing to gather)
+        return [gd.ghost_gmg(cells, nd, 0, 1, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, nrhs=nrhs)]
+
+    class _Captured(Exception):
+        pass
+
+    for r in range(world):
+        def capture(obj, _r=r):
+            pieces[_r] = obj
+            raise _Captured()
+        try:
+            gd.ghost_gmg(cells, nd, r, world, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, gather_objects=capture, nrhs=nrhs)
+        except _Captured:
+            pass
+    full = [pieces[r] for r in range(world)]
+    return [gd.ghost_gmg(cells, nd, r, world, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, gather_objects=lambda o: full, nrhs=nrhs)
+            for r in range(world)]
+
+
+def _thread_world_run(Gs, body, options=None):
+    """One thread per rank, one ghost-attached handle each (host-staged transport over shared memory): [body(rank, G, H)]."""
+    import threading
+    from multigrid_jl_amd import ghost_dist as gd
+    world = len(Gs)
+    W = _ThreadWorld(world)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            H = gd.NativeGhostHierarchy(Gs[r], 0, transport="plugin", collectives=W.view(r), options=dict(TEST_OPTS if options is None else options))
+            try:
+                out[r] = body(r, Gs[r], H)
+            finally:
+                H.close()
+        except Exception:   # pragma: no cover
+            import traceback
+            errs.append(f"rank {r}: {traceback.format_exc()}")
+            W.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errs, errs[0]
+    return out
+
+
+def _run_threads(mg, world, case, cyc, tol, maxit):
+    """What _run(..., "plugin") returns, with the ranks as threads of this process."""
+    Gs = _setup_all_ranks(mg, world, case, cyc)
+    _, cells, _ = _param(mg, case, cyc)
+    A, mesh = mg.poisson_shifted(cells)
+    b = mg.seeded_rhs(A)
+
+    def body(r, G, H):
+        b_ext = b[G.gid_fine]
+        own = G.levels[0].own_mask()
+        bt = torch.from_numpy(b_ext).cuda()
+        xt = torch.zeros_like(bt)
+        it, resvec = H.solve(bt, xt, tol, maxit)
+        x_ext = xt.cpu().numpy()
+        x2t = xt.clone()
+        H.cycle(bt, x2t, False)
+        extra = dict(zip(("exchanges", "sent"), H.exchanges()))
+        try:                # entry points whose sums would run over ghost rows (here: the host-pointer PCG) are refused, not computed
+            H.dev.pcg(b_ext, np.zeros_like(b_ext), 1e-8, 2)
+            extra["pcg_refused"] = False
+        except mg.device.MGDeviceError as e:
+            extra["pcg_refused"] = "sharded" in str(e)
+        extra["four_stage"] = H.dev.four_stage_form(1)[0]
+        extra["comm_count"] = H.comm_count()
+        return G.gid_fine[own], x_ext[own], x2t.cpu().numpy()[own], int(it), np.asarray(resvec), extra
+
+    out = _thread_world_run(Gs, body)
+    x, x2 = np.zeros_like(b), np.zeros_like(b)
+    for gid, xl, x2l, *_ in out:
+        x[gid] = xl
+        x2[gid] = x2l
+    return [o[3] for o in out], [o[4] for o in out], x, x2, [o[5] for o in out]
+
+
 CASES = {
     # name: (cells, levels, replicate_below, smoother, omega, npre, npost)
     "3d-a2": ([32, 32, 32], 4, 1000, "Jac", 0.8, 2, 1),
@@ -36,6 +170,8 @@ CASES = {
     "3d-v11": ([32, 32, 32], 4, 1000, "SPAI", 1.0, 1, 1),
     "3d-v32": ([32, 32, 32], 4, 1000, "Jac", 0.8, 3, 2),
     "2d": ([64, 96], 4, 300, "Jac", 0.8, 2, 1),
+    "3d-jg": ([32, 32, 32], 4, 1000, "Jac-GMRES", 0.75, 2, 2),  # Jac-GMRES smoother (FGMRES_relaxation, MGcycle.jl:48-50,96-98; FGMRES.jl:48-126)
+    "3d-a3-jg": ([32, 32, 64], 5, 1000, "Jac-GMRES", 0.75, 2, 1),
     "3d-a1": ([32, 32, 32], 4, 10000, "Jac", 0.8, 2, 1),        # ONE sharded level (the fine level's own ghost width must carry the four-stage pass)
 }
 
@@ -150,7 +286,10 @@ def _run(world, case, cyc, mode, tol=1e-8, maxit=6):
 def _check(mg, world, case, cyc, mode, tol=1e-8, maxit=6):
     from oracle import mg_oracle as orc
     A, b, x_ref, res_ref = _global_reference(mg, case, cyc, tol, maxit)
-    its, resvecs, x, x2, extra = _run(world, case, cyc, mode, tol, maxit)
+    if mode == "threads":      # the ranks are threads of this process (no spawn, no second GPU context: seconds instead of tens of seconds)
+        its, resvecs, x, x2, extra = _run_threads(mg, world, case, cyc, tol, maxit)
+    else:
+        its, resvecs, x, x2, extra = _run(world, case, cyc, mode, tol, maxit)
     assert all(i == len(res_ref) - 1 for i in its), (its, len(res_ref) - 1)
     for rv in resvecs:                      # every rank holds the same, global, residual history
         assert len(rv) == len(res_ref)
@@ -271,14 +410,27 @@ def test_ghost_form_early_stop_cpu(mg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,case,cyc", [(1, "3d-a2", "V"), (2, "3d-a2", "V"), (4, "3d-a2", "W"), (2, "3d-a3", "F"), (4, "3d-v32", "V"),
-                                            (2, "3d-v11", "V"), (2, "2d", "V")])
-def test_ghost_form_hip_plugin_vs_oracle(mg, world, case, cyc):
-    """The library's schedule (mg_ghost_*) with `world` processes sharing the GPU through the host-staged transport."""
-    extra = _check(mg, world, case, cyc, "plugin")
+@pytest.mark.parametrize("world,case,cyc,mode", [(1, "3d-a2", "V", "threads"), (2, "3d-a2", "V", "plugin"), (4, "3d-a2", "W", "threads"), (2, "3d-a3", "F", "threads"),
+                                                 (4, "3d-v32", "V", "threads"), (2, "3d-v11", "V", "threads"), (2, "2d", "V", "threads"), (2, "3d-a1", "V", "threads"),
+                                                 (8, "3d-a1", "W", "threads")])
+def test_ghost_form_hip_plugin_vs_oracle(mg, world, case, cyc, mode):
+    """The library's schedule (mg_ghost_*) with `world` ranks sharing the GPU through the host-staged transport: processes over
+    torch.distributed ("plugin": one case) or threads of this process over shared memory ("threads": same library path, no spawn)."""
+    extra = _check(mg, world, case, cyc, mode)
     assert all(e["pcg_refused"] for e in extra)
     if world > 1:
         assert all(e["exchanges"] > 0 for e in extra)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case,cyc", [(2, "3d-a2", "K"), (4, "3d-a3", "K"), (2, "3d-jg", "V"), (4, "3d-jg", "W"), (2, "3d-a3-jg", "K")])
+def test_ghost_form_kcycle_and_jac_gmres(mg, world, case, cyc):
+    """Round 6: the K-cycle (2 FGMRES steps per level preconditioned by the next level's K-cycle, MGcycle.jl:72-76) and
+    the Jac-GMRES smoother (FGMRES.jl:48-126) on ghost-attached handles: the FGMRES dots are sums over the owned rows of all ranks, every
+    product follows one exchange of its input's ghost layers, the data-dependent exits are identical on every rank.  Until round 5 these
+    ran in the halo form only (tests/test_distributed.py::test_native_sequencer_kcycle_and_jac_gmres)."""
+    extra = _check(mg, world, case, cyc, "threads", maxit=4)
+    assert all(e["exchanges"] > 0 for e in extra)
 
 
 @pytest.mark.gpu
@@ -290,58 +442,7 @@ def test_ghost_form_hip_rccl_world1(mg):
 
 @pytest.mark.gpu
 def test_ghost_form_hip_early_stop(mg):
-    _check(mg, 2, "3d-a2", "V", "plugin", tol=1e-3, maxit=8)
-
-
-def _worker_block(rank, world, port, case, cyc, nrhs, q, tol, maxit, x_nonzero):
-    """A block of right-hand sides in the ghost-layer form: solved column by column on every rank's extended boxes."""
-    try:
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        torch.cuda.set_device(0)
-        os.environ.update(MG_NO_SMALL="1", MG_ROWCLASS_MIN_ROWS="0", MG_ROWCLASS_MAX_PASSES="64", MG_ROWCLASS_MIN_COVER="0.05", MG_MARCH_MIN_WG="0",
-                          MG_MARCH_MAX_LEN="64", MG_TILE_MIN_WG="0", MG_WINDOW_MIN_WG="0", MG_WINP_MIN_ROWS="0", MG_MARCH27_MIN_ROWS="0",
-                          MG_MARCHR_MIN_ROWS="0", MG_MARCH4_TY_MAX="12")     # (33 lines: an odd count needs more than one tile row)
-        import multigrid_jl_amd as mg
-        from multigrid_jl_amd import ghost_dist as gd
-        from multigrid_jl_amd.structured_setup import poisson_operator
-        p, cells, rb = _param(mg, case, cyc)
-        G = gd.ghost_gmg(cells, _domains(world, len(cells), case), rank, world, p, poisson_operator(cells), replicate_below=rb, nrhs=nrhs)
-        A, mesh = mg.poisson_shifted(cells)
-        B = np.ascontiguousarray(mg.seeded_rhs(A, nrhs)[G.gid_fine])          # n_ext x nrhs, row-major: the device layout of a block
-        own = G.levels[0].own_mask()
-        H = gd.NativeGhostHierarchy(G, 0, transport="plugin" if world > 1 else "rccl")
-        assert H.nrhs == nrhs and H.dev.four_stage_form(1)[0]
-        bt = torch.from_numpy(B).cuda()
-        if x_nonzero:
-            X0 = np.random.default_rng(5).standard_normal((A.shape[0], nrhs))[G.gid_fine]
-            X0[~own] = np.nan                                                  # (only the owned rows of x are the caller's to give)
-            xt = torch.from_numpy(np.ascontiguousarray(X0)).cuda()
-        else:
-            xt = torch.zeros_like(bt)
-        e0 = H.exchanges()
-        it, resvec = H.solve(bt, xt, tol, maxit)
-        e1 = H.exchanges()
-        refused = False
-        try:                       # a single block CYCLE is not a ghost-form entry point
-            H.dev.cycle_dev(bt, xt.clone(), 0)
-        except mg.device.MGDeviceError:
-            refused = True
-        X = xt.cpu().numpy()
-        H.close()
-        out = [None] * world
-        dist.all_gather_object(out, (G.gid_fine[own], X[own], int(it), np.asarray(resvec), e1[0] - e0[0], refused))
-        if rank == 0:
-            Xg = np.zeros((A.shape[0], nrhs))
-            for gid, xl, *_ in out:
-                Xg[gid] = xl
-            q.put(("ok", [o[2] for o in out], [o[3] for o in out], Xg, [o[4] for o in out], [o[5] for o in out]))
-        dist.barrier()
-        dist.destroy_process_group()
-    except Exception as e:  # pragma: no cover
-        import traceback
-        q.put(("err", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+    _check(mg, 2, "3d-a2", "V", "threads", tol=1e-3, maxit=8)
 
 
 @pytest.mark.gpu
@@ -349,42 +450,52 @@ def _worker_block(rank, world, port, case, cyc, nrhs, q, tol, maxit, x_nonzero):
 def test_ghost_form_block_of_right_hand_sides(mg, world, cyc, nrhs, tol, x_nonzero):
     """solveMG on an n x k block (SolveFuncs.jl:3-39, one Frobenius stopping test) with the grid cut over `world` ranks in the
     ghost-layer form: every column plays the single-vector kernels on the rank's extended boxes, the norms are sums over the owned
-    rows of all ranks.  Against the oracle's block solve on the global hierarchy."""
+    rows of all ranks.  Against the oracle's block solve on the global hierarchy (ranks = threads of this process)."""
     from oracle import mg_oracle as orc
     case, maxit = "3d-a2", 5
     p, cells, _ = _param(mg, case, cyc)
     A, mesh = mg.poisson_shifted(cells)
     mg.MGsetup(A, mesh, p, nrhs)
     B = mg.seeded_rhs(A, nrhs)
-    Xo = np.asfortranarray(np.random.default_rng(5).standard_normal(B.shape)) if x_nonzero else np.zeros_like(B)
+    X0 = np.random.default_rng(5).standard_normal(B.shape)
+    Xo = np.asfortranarray(X0.copy()) if x_nonzero else np.zeros_like(B)
     p.maxOuterIter, p.relativeTol = maxit, tol
     hist = {}
     _, _, ito = orc.solveMG(p, B, Xo, False, hist)
     res_ref = np.asarray(hist["resvec"])
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_block, args=(r, world, port, case, cyc, nrhs, q, tol, maxit, x_nonzero)) for r in range(world)]
-    for pr in procs:
-        pr.start()
-    try:
-        res = q.get(timeout=600)
-    finally:
-        for pr in procs:
-            pr.join(timeout=60)
-            if pr.is_alive():
-                pr.kill()
-    assert res[0] == "ok", res[1]
-    _, its, resvecs, X, exch, refused = res
-    assert all(i == ito for i in its), (its, ito)
+    Gs = _setup_all_ranks(mg, world, case, cyc, nrhs=nrhs)
+    opts = dict(TEST_OPTS, rowclass_min_cover=0.05, march_max_len=64, march4_ty_max=12)     # (33 lines: an odd count needs more than one tile row)
+
+    def body(r, G, H):
+        own = G.levels[0].own_mask()
+        assert H.nrhs == nrhs and H.dev.four_stage_form(1)[0]
+        bt = torch.from_numpy(np.ascontiguousarray(B[G.gid_fine])).cuda()          # n_ext x nrhs, row-major: the device layout of a block
+        if x_nonzero:
+            Xl = X0[G.gid_fine].copy()
+            Xl[~own] = np.nan                                                      # (only the owned rows of x are the caller's to give)
+            xt = torch.from_numpy(np.ascontiguousarray(Xl)).cuda()
+        else:
+            xt = torch.zeros_like(bt)
+        e0 = H.exchanges()
+        it, resvec = H.solve(bt, xt, tol, maxit)
+        e1 = H.exchanges()
+        x2 = xt.clone()            # one more cycle on the block from the iterate (round 6: a block cycle = its columns' cycles)
+        H.dev.cycle_dev(bt, x2, 0)
+        return G.gid_fine[own], xt.cpu().numpy()[own], int(it), np.asarray(resvec), e1[0] - e0[0], x2.cpu().numpy()[own]
+
+    out = _thread_world_run(Gs, body, options=opts)
+    X, X2 = np.zeros((A.shape[0], nrhs)), np.zeros((A.shape[0], nrhs))
+    for gid, xl, it, rv, exch, x2l in out:
+        X[gid] = xl
+        X2[gid] = x2l
+        assert it == ito, (it, ito)
+        assert np.abs(rv - res_ref).max() <= 1e-10 * res_ref[0]
+        assert world == 1 or exch > 0
+    Xc = orc.recursiveCycle(p, B, np.asfortranarray(Xo.copy()), 1, None, cyc)
+    assert np.abs(X2 - Xc).max() <= 1e-10 * np.abs(Xc).max()
     if tol == 3e-3:
         assert 1 < ito < maxit                     # (meant to stop early)
-    for rv in resvecs:
-        assert np.abs(rv - res_ref).max() <= 1e-10 * res_ref[0]
     assert np.abs(X - Xo).max() <= 1e-10 * np.abs(Xo).max()
-    assert all(refused)
-    if world > 1:
-        assert all(e > 0 for e in exch)
 
 
 def _worker_c4box(rank, world, port, cells, levels, q, steps):
@@ -543,19 +654,22 @@ def _check_krylov(mg, world, case, cyc, mode, method, tol=1e-9, maxit=12):
         x_ref, flag_ref, it_ref, res_ref = orc.solveBiCGSTAB_MG(p, b, 0.01 * np.random.default_rng(3).standard_normal(A.shape[0]))
     else:
         x_ref, flag_ref, it_ref, res_ref = orc.solveGMRES_MG(p, b, np.zeros_like(b), 3)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_krylov, args=(r, world, port, case, cyc, mode, method, q, tol, maxit)) for r in range(world)]
-    for pr in procs:
-        pr.start()
-    try:
-        res = q.get(timeout=600)
-    finally:
+    if mode == "threads":
+        res = _krylov_threads(mg, world, case, cyc, method, tol, maxit)
+    else:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_krylov, args=(r, world, port, case, cyc, mode, method, q, tol, maxit)) for r in range(world)]
         for pr in procs:
-            pr.join(timeout=60)
-            if pr.is_alive():
-                pr.kill()
+            pr.start()
+        try:
+            res = q.get(timeout=600)
+        finally:
+            for pr in procs:
+                pr.join(timeout=60)
+                if pr.is_alive():
+                    pr.kill()
     assert res[0] == "ok", res[1]
     _, flags, its, resvecs, x, infos = res
     assert all(f == flag_ref for f in flags) and all(i == it_ref for i in its), (flags, flag_ref, its, it_ref)
@@ -574,14 +688,48 @@ def test_ghost_form_krylov_cpu_vs_oracle(mg, world, case, cyc, method):
     assert it > 1 and all(i["exchanges"] > 0 for i in infos)
 
 
+def _krylov_threads(mg, world, case, cyc, method, tol, maxit):
+    """The `plugin` mode of _worker_krylov with the ranks as threads of this process."""
+    Gs = _setup_all_ranks(mg, world, case, cyc)
+    _, cells, _ = _param(mg, case, cyc)
+    A, mesh = mg.poisson_shifted(cells)
+    b = mg.seeded_rhs(A)
+    x0g = 0.01 * np.random.default_rng(3).standard_normal(A.shape[0]) if method == "bicgstab" else np.zeros_like(b)
+
+    def body(r, G, H):
+        own = G.levels[0].own_mask()
+        bt = torch.from_numpy(b[G.gid_fine]).cuda()
+        e0, a0 = H.exchanges()[0], H.allreduces()
+        H.cycle(bt, torch.zeros_like(bt), True)          # what ONE application of the preconditioner communicates
+        e_cyc, a_cyc = H.exchanges()[0] - e0, H.allreduces() - a0
+        x0 = x0g[G.gid_fine].copy()
+        x0[~own] = np.nan if method == "bicgstab" else 0.0      # (only the owned rows of x are the caller's to give)
+        xt = torch.from_numpy(x0).cuda()
+        e0, a0 = H.exchanges()[0], H.allreduces()
+        if method == "pcg":
+            flag, it, resvec = H.pcg(bt, xt, tol, maxit)
+        elif method == "bicgstab":
+            flag, it, resvec = H.bicgstab(bt, xt, tol, maxit)
+        else:
+            flag, it, resvec = H.fgmres(bt, xt, 3, tol, maxit)
+        info = dict(exchanges=H.exchanges()[0] - e0, allreduces=H.allreduces() - a0, e_cyc=e_cyc, a_cyc=a_cyc)
+        return G.gid_fine[own], xt.cpu().numpy()[own], int(flag), int(it), np.asarray(resvec), info
+
+    out = _thread_world_run(Gs, body)
+    xg = np.zeros_like(b)
+    for gid, xl, *_ in out:
+        xg[gid] = xl
+    return "ok", [o[2] for o in out], [o[3] for o in out], [o[4] for o in out], xg, [o[5] for o in out]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,case,cyc,method", [(1, "3d-a2", "V", "pcg"), (2, "3d-a2", "V", "pcg"), (4, "3d-a2", "V", "fgmres"), (2, "3d-a3", "V", "bicgstab"),
-                                                   (4, "3d-a2", "W", "pcg"), (2, "3d-a2", "V", "fgmres")])
-def test_ghost_form_krylov_hip_vs_oracle(mg, world, case, cyc, method):
-    """mg_pcg_dev / mg_bicgstab_dev / mg_fgmres_dev on ghost-attached handles (`world` processes sharing the GPU, host-staged transport;
-    RCCL at a world of one) against the oracle's solveCG_MG / solveBiCGSTAB_MG / solveGMRES_MG on the global hierarchy: same iterates,
-    same iteration counts; the communication per iteration is what the design says."""
-    k, infos = _check_krylov(mg, world, case, cyc, "plugin", method)
+@pytest.mark.parametrize("world,case,cyc,method,mode", [(1, "3d-a2", "V", "pcg", "threads"), (2, "3d-a2", "V", "pcg", "plugin"), (4, "3d-a2", "V", "fgmres", "threads"),
+                                                        (2, "3d-a3", "V", "bicgstab", "threads"), (4, "3d-a2", "W", "pcg", "threads"), (2, "3d-a1", "V", "fgmres", "threads")])
+def test_ghost_form_krylov_hip_vs_oracle(mg, world, case, cyc, method, mode):
+    """mg_pcg_dev / mg_bicgstab_dev / mg_fgmres_dev on ghost-attached handles (`world` ranks sharing the GPU through the host-staged
+    transport: threads of this process, one case as processes over torch.distributed) against the oracle's solveCG_MG / solveBiCGSTAB_MG /
+    solveGMRES_MG on the global hierarchy: same iterates, same iteration counts; the communication per iteration is what the design says."""
+    k, infos = _check_krylov(mg, world, case, cyc, mode, method)
     if world == 1:
         return
     for i in infos:
@@ -593,3 +741,52 @@ def test_ghost_form_krylov_hip_vs_oracle(mg, world, case, cyc, method):
         elif method == "bicgstab":  # per iteration: 2 cycles, 2 products, scalars rho, r~'v, ||s||, (t's, t't) as ONE, ||r||
             assert i["exchanges"] == 1 + k * (2 + 2 * ec), (i, k)
             assert i["allreduces"] == 2 + k * (5 + 2 * ac), (i, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["solve", "pcg"])
+def test_c4_topology_eight_ranks_ghost_form_hip(mg, method):
+    """BASELINE.json configs[3] cuts the grid into numDomains = [2,2,2] (DDIndices.jl:41-47): every rank has 3 face, 3 edge and 1 corner
+    neighbour.  Eight ghost-attached handles on the one GPU of the box (ranks = threads of this process - the pool allows 6 GPU
+    processes - host-staged transport), three sharded levels with their own ghost widths: solveMG and the sharded PCG against the
+    oracle on the global hierarchy."""
+    from oracle import mg_oracle as orc
+    case, cyc, world, nd, tol, maxit = "3d-a3", "V", 8, [2, 2, 2], 1e-8, 6
+    p, cells, rb = _param(mg, case, cyc)
+    A, mesh = mg.poisson_shifted(cells)
+    mg.MGsetup(A, mesh, p)
+    b = mg.seeded_rhs(A)
+    p.maxOuterIter, p.relativeTol = maxit, tol
+    flag_ref = it_ref = None
+    if method == "solve":
+        hist = {}
+        x_ref = np.zeros_like(b)
+        orc.solveMG(p, b, x_ref, False, hist)
+        res_ref = np.asarray(hist["resvec"])
+    else:
+        x_ref, flag_ref, it_ref, res_ref = orc.solveCG_MG(p, b, np.zeros_like(b))
+    Gs = _setup_all_ranks(mg, world, case, cyc, nd=nd)
+    assert all(G.a == 3 for G in Gs)
+    for G in Gs:      # every rank exchanges with its 7 neighbours on the fine level: 3 faces, 3 edges, 1 corner
+        assert sum(1 for s in G.levels[0].send_splits if s > 0) == 7 and sum(1 for s in G.levels[0].recv_splits if s > 0) == 7
+
+    def body(r, G, H):
+        bt = torch.from_numpy(b[G.gid_fine]).cuda()
+        xt = torch.zeros_like(bt)
+        if method == "solve":
+            it, resvec = H.solve(bt, xt, tol, maxit)
+            flag = 0
+        else:
+            flag, it, resvec = H.pcg(bt, xt, tol, maxit)
+        own = G.levels[0].own_mask()
+        return G.gid_fine[own], xt.cpu().numpy()[own], int(it), np.asarray(resvec), int(flag), H.exchanges()
+
+    out = _thread_world_run(Gs, body)
+    x = np.zeros_like(b)
+    for gid, xl, it, rv, flag, exch in out:
+        x[gid] = xl
+        assert len(rv) == len(res_ref) and np.abs(rv - res_ref).max() <= 1e-10 * max(1.0, res_ref[0]), (rv, res_ref)
+        assert exch[0] > 0
+        if method == "pcg":
+            assert flag == flag_ref and it == it_ref
+    assert np.abs(x - x_ref).max() <= 1e-10 * np.abs(x_ref).max()

@@ -180,10 +180,11 @@ def test_c5_block_spmm_kernels_at_full_size_match_c_oracle(mg, c5):
 
 
 # ---- C3: SA-AMG on anisotropic diffusion, general CSR (BASELINE.json configs[2]) at 128^3 cells ----------------------
-def test_c3_128_sa_amg_matches_c_oracle(mg, built):
+def test_c3_128_sa_amg_matches_c_oracle(mg, built, monkeypatch):
     """The streaming formats (no repeated rows in any operator of this hierarchy) at 2.1 M rows: SA_AMGsetup on the host
     (theta 0.4, SPAI, V(1,1); edge weights 16:4:1 x log-normal sigma - DESIGN.md section 10 says why not SURVEY's
     1 : 1e-2 : 1e-4), two solveMG steps on the device against the C/OpenMP oracle."""
+    monkeypatch.setenv("MG_SETUP_GPU", "1")      # (opt-in: the setup's largest Galerkin products on the GPU; the test is about the cycle on the hierarchy it gets)
     A, mesh = mg.anisotropic_divsiggrad([128, 128, 128], weights=(1.0, 0.25, 0.0625))
     p = mg.getMGparam(np.float64, np.int64, 14, 8, 2, 0.0, "SPAI", 1.0, 1, 1, "V", "Julia", 0.4, 0.0)
     mg.SA_AMGsetup(A, p, True, 1)
@@ -202,10 +203,11 @@ def test_c3_128_sa_amg_matches_c_oracle(mg, built):
     mg.clear_(p)
 
 
-def test_c3_survey_weights_64_sa_amg_matches_c_oracle(mg, built):
+def test_c3_survey_weights_64_sa_amg_matches_c_oracle(mg, built, monkeypatch):
     """The same at SURVEY 8d's STATED edge weights 1 : 1e-2 : 1e-4 (operator complexity ~45 at 64^3 cells: rows of thousands of entries
     on the middle levels - the long-row kernel; the Galerkin products of the large / nearly dense levels run on the GPU in the setup):
     three solveMG steps against the C/OpenMP oracle on the hierarchy the setup produced."""
+    monkeypatch.setenv("MG_SETUP_GPU", "1")
     A, mesh = mg.anisotropic_divsiggrad([64, 64, 64], weights=(1.0, 1e-2, 1e-4))
     p = mg.getMGparam(np.float64, np.int64, 14, 8, 3, 0.0, "SPAI", 1.0, 1, 1, "V", "Julia", 0.4, 0.0)
     mg.SA_AMGsetup(A, p, True, 1)

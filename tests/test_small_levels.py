@@ -166,13 +166,19 @@ def test_band27_variable_coefficient_levels(mg, built, cells, levels):
     import torch
     from multigrid_jl_amd import device as D
     A, mesh, p = _divsiggrad(mg, cells, levels)
-    h = D.DeviceHierarchy(p, 0, 1)
+    h = D.DeviceHierarchy(p, 0, 1, options={"band_sym_tol": 1})
     h0 = D.DeviceHierarchy(p, 0, 1, options={"no_band27": 1})
     rng = np.random.default_rng(9)
     try:
         assert h.operator_kernel_variant(2, D.MG_OP_A) == 9 and h0.operator_kernel_variant(2, D.MG_OP_A) != 9
-        # a Galerkin operator of a symmetric fine one is symmetric up to the rounding of R*(A*P): 14 of the 27 planes are read
+        # a Galerkin operator of a symmetric fine one is symmetric up to the rounding of R*(A*P): with the option band_sym_tol 14 of the
+        # 27 planes are read; by DEFAULT (round 6) only bit-for-bit symmetry takes the symmetric reads - the device operator is the stored one
         assert h.band_form(2) == [2, 1, 1, 14] and h0.band_form(2)[0] == 0
+        hd = D.DeviceHierarchy(p, 0, 1)
+        A2 = p.As[1].tocsr()
+        exact = (A2 != A2.T).nnz == 0
+        assert hd.band_form(2) == ([2, 1, 1, 14] if exact else [2, 1, 0, 27])
+        hd.close()
         h7 = D.DeviceHierarchy(p, 0, 1, options={"no_band_sym": 1})
         assert h7.band_form(2) == [2, 1, 0, 27]
         h7.close()
@@ -243,13 +249,15 @@ def test_galerkin_product_of_a_nearly_dense_level_on_the_gpu(mg, built, monkeypa
     got2 = H.galerkin_sparse_gpu(R, A, P)                    # rocSPARSE's SpGEMM (levels too large for dense blocks)
     assert got2 is not None and np.array_equal(got2.indptr, want.indptr) and np.array_equal(got2.indices, want.indices)
     assert np.abs(got2.data - want.data).max() <= 1e-13 * np.abs(want.data).max()
+    monkeypatch.setenv("MG_SETUP_GPU_MIN_ROWS", "500")
+    monkeypatch.delenv("MG_SETUP_GPU", raising=False)
+    assert not H.galerkin_dense_gpu_ok(A, P)                 # OPT-IN: by default the setup stays on the host, as the reference's does
+    monkeypatch.setenv("MG_SETUP_GPU", "1")
+    assert H.galerkin_dense_gpu_ok(A, P)
     assert not H.galerkin_sparse_gpu_ok(A, P)                # (10^7 products: the host's)
+    monkeypatch.setenv("MG_SETUP_GPU_MIN_ROWS", "3000")
     assert not H.galerkin_dense_gpu_ok(A, P)                 # (700 rows: below the size it pays from)
     monkeypatch.setenv("MG_SETUP_GPU_MIN_ROWS", "500")
-    assert H.galerkin_dense_gpu_ok(A, P)
-    monkeypatch.setenv("MG_SETUP_GPU", "0")
-    assert not H.galerkin_dense_gpu_ok(A, P)
-    monkeypatch.setenv("MG_SETUP_GPU", "1")
     thin = sp.random(4000, 4000, density=0.001, random_state=5, format="csr")
     assert not H.galerkin_dense_gpu_ok(thin, sp.random(4000, 300, density=0.01, random_state=6, format="csr"))
 
