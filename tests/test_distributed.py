@@ -239,7 +239,7 @@ def test_native_sequencer_plugin_transport(built, world, kind, cyc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,nrhs,cyc", [(2, "sa", 2, "V"), (4, "gmg3d", 4, "W"), (2, "gmg3d", 16, "V")])
+@pytest.mark.parametrize("world,kind,nrhs,cyc", [(2, "sa", 2, "V"), (2, "gmg3d", 16, "V")])
 def test_native_sequencer_blocks_of_right_hand_sides(built, world, kind, nrhs, cyc):
     """mg_dist_* with nrhs > 1 (MGdef.jl:163-176: the reference is block-capable everywhere; one Frobenius criterion for the
     block, SolveFuncs.jl:30): row-major [n][nrhs] blocks through the pack kernels, the halo exchange, the SpMM kernels, the
@@ -268,8 +268,7 @@ def test_native_box_form_default_thresholds(built, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,cyc,box", [(2, "gmg3d", "K", False), (4, "gmg3d", "K", True), (2, "gmg3d-jacgmres", "K", True),
-                                                (4, "gmg3d-jacgmres", "W", False)])
+@pytest.mark.parametrize("world,kind,cyc,box", [(2, "gmg3d", "K", False), (4, "gmg3d-jacgmres", "W", False), (2, "gmg3d-jacgmres", "K", True)])
 def test_native_sequencer_kcycle_and_jac_gmres(built, world, kind, cyc, box):
     """The K-cycle (2 FGMRES steps per level preconditioned by the next level's K-cycle, MGcycle.jl:72-76) and the Jac-GMRES
     smoother (FGMRES.jl:48-126) in the native sharded sequencer: products with the halo exchanged, dots all-reduced, the
