@@ -814,7 +814,7 @@ def main():
             for (l, k), v in sorted(prof3.items()):
                 e = lev3.setdefault(l, [0.0, 0.0])
                 e[0] += v[0]
-                e[1] += moved3[(l, k)]
+                e[1] += moved3[(l, k)] * v[1]          # (bytes per launch x launches)
             roofline["c3_leg"] = {
                 "workload": f"SA-AMG (theta 0.4, V(1,1) SPAI) on anisotropic diffusion {c3c}^3 cells, edge weights 16:4:1 x log-normal sigma, general CSR",
                 "ms_per_step": round(dt3 / K3 * 1e3, 4), "dof_updates_per_s": round(n3 * K3 / dt3, 1), "steps": K3, "N": int(n3),
@@ -822,8 +822,7 @@ def main():
                 "operator_complexity": round(sum(a.nnz for a in p3.As) / A3.nnz, 2), "relres_after_steps": float(res3[-1] / res3[0]),
                 "host_setup_s": round(t_set3, 1), "setup": "SA_AMGsetup on the host, its largest Galerkin products on the GPU (MG_SETUP_GPU=1)",
                 "per_level": {f"L{l}": {"ms_per_step": round(e[0] / K3, 4), "moved_MB_per_step": round(e[1] / K3 / 1e6, 1),
-                                        "frac": round(e[1] / e[0] / 1e6 / HBM_PEAK_GBS, 4) if e[0] > 0 else None} for l, e in sorted(lev3.items())},
-                "A_kernel_variant": [h3.operator_kernel_variant(l, mg.device.MG_OP_A) for l in range(1, int(p3.levels) + 1)]}
+                                        "frac": round(e[1] / e[0] / 1e6 / HBM_PEAK_GBS, 4) if e[0] > 0 else None} for l, e in sorted(lev3.items())}}
             h3.close()
             del b3, x3, A3, p3
         except Exception as e:
