@@ -2666,6 +2666,9 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
   const bool twin = jt >= T.SY;
   const int j = twin ? T.SY - 1 : jt;
   const int own8 = ((K1 * j + 1) * pitch + xx + 1) * 8;   // byte offset of row 0's own entry inside a slab (every ring); row s: + s*P8
+#if defined(MG_M4_DPP)
+  const bool edge_l = xx == 0 || lane == 0, edge_r = xx == T.WX - 1 || lane == 63;   // lanes whose neighbour lane is not their neighbour column
+#endif
   // ---- the lane's 16-byte pairs of an x slab ---------------------------------------------------------------------------
   int pofs[NPM], pline[NPM];
   unsigned pflag = 0u;  // per m: bit 4m = the pair exists, bit 4m+1 = first pair of its line, bit 4m+2 = its line is inside the grid, bit 4m+3 = pg[m] is odd
@@ -2840,6 +2843,31 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     if (cq_ != rcls) M4_LOADRECS(cq_);                                                                                 \
   } while (0)
     // one row-stage: left / right from the slab, above / below from the strip's registers or (first / last row) the slab
+#if defined(MG_M4_DPP)
+    // Variant (make variant NAME=dpp DEFS=-DMG_M4_DPP; profiles/r06_march4_variants.md): the left / right neighbours of a row are the SAME
+    // row's values in the neighbour lanes (lane = column): taken by a wavefront shift (DPP wave_shr / wave_shl, no LDS bank touched);
+    // only the lanes at the ends of a line or of the wavefront read theirs from the slab (the same values: every lane's row values
+    // are what it wrote there).  Halves the slab reads of a row-stage.
+#define M4_DPP_F64(dst, src, ctrl)                                                                                     \
+  do {                                                                                                                 \
+    const unsigned long long u_ = (unsigned long long)__double_as_longlong(src);                                       \
+    const int lo32_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u_ & 0xffffffffull), (ctrl), 0xf, 0xf, false);    \
+    const int hi32_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u_ >> 32), (ctrl), 0xf, 0xf, false);              \
+    (dst) = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi32_ << 32) | (unsigned long long)(unsigned)lo32_)); \
+  } while (0)
+#define M4_ROWSTAGE(rB, val, lo_, hi_, acc)                                                                            \
+  do {                                                                                                                 \
+    const int o8_ = (rB) + own8 + s * P8;                                                                              \
+    double le_, ri_;                                                                                                   \
+    M4_DPP_F64(le_, (val)[s], 0x138);   /* wave_shr:1 - lane i takes lane i-1's */                                     \
+    M4_DPP_F64(ri_, (val)[s], 0x130);   /* wave_shl:1 - lane i takes lane i+1's */                                     \
+    if (edge_l) le_ = M4_LDS(o8_ - 8);                                                                                 \
+    if (edge_r) ri_ = M4_LDS(o8_ + 8);                                                                                 \
+    const double up_ = s == 0 ? M4_LDS(o8_ - P8) : (val)[s > 0 ? s - 1 : 0];                                           \
+    const double dn_ = s == K1 - 1 ? M4_LDS(o8_ + P8) : (val)[s < K1 - 1 ? s + 1 : s];                                 \
+    M4_ACC(acc, (lo_)[s], up_, le_, (val)[s], ri_, dn_, (hi_)[s]);                                                     \
+  } while (0)
+#else
 #define M4_ROWSTAGE(rB, val, lo_, hi_, acc)                                                                            \
   do {                                                                                                                 \
     const int o8_ = (rB) + own8 + s * P8;                                                                              \
@@ -2848,8 +2876,19 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
     const double dn_ = s == K1 - 1 ? M4_LDS(o8_ + P8) : (val)[s < K1 - 1 ? s + 1 : s];                                 \
     M4_ACC(acc, (lo_)[s], up_, le_, (val)[s], ri_, dn_, (hi_)[s]);                                                     \
   } while (0)
+#endif
 // (the stages of an iteration are not interleaved by the scheduler: live ranges stay within 128 / 168 registers)
+#if defined(MG_M4_NO_SCHED)      /* (make variant NAME=nosched DEFS=-DMG_M4_NO_SCHED: profiles/r06_march4_variants.md) */
+#define M4_SCHED
+#else
 #define M4_SCHED __builtin_amdgcn_sched_barrier(0)   /* (free scheduling of the 768- / 512-thread variants changes nothing: profiles/r05_march4_notes.md) */
+#endif
+#if defined(MG_M4_UNROLL)     /* (make variant NAME=unrollN DEFS=-DMG_M4_UNROLL=N: the plane loop unrolled by the compiler - the register rotations at its
+                                 end become renamings; profiles/r06_march4_variants.md) */
+#define M4_STR2(x) #x
+#define M4_STR(x) M4_STR2(x)
+    _Pragma(M4_STR(unroll MG_M4_UNROLL))
+#endif
     for (int z = zA; z <= zE; ++z) {
       d2_t cur[NPM];
       double b0[K1];
@@ -3007,6 +3046,9 @@ __global__ __launch_bounds__(NT) void csr_rowclass_march4_spmv(RowClassDev C, Ma
 #undef M4_ACC
 #undef M4_REC
 #undef M4_ROWSTAGE
+#if defined(MG_M4_DPP)
+#undef M4_DPP_F64
+#endif
 #undef M4_SCHED
 }
 
