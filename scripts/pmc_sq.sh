@@ -1,20 +1,23 @@
 #!/bin/bash
-# SQ-side PMC passes of the fused sweep + residual kernel (one variant).  usage: bash scripts/pmc_sq.sh <outdir> <variant>
+# SQ-side PMC passes of any kernel of a probe run.  usage: bash scripts/pmc_sq.sh <outdir under gpurun_out> <kernel name pattern> <probe.py> [args...]
+# e.g.  bash scripts/pmc_sq.sh r06/sq27 march27 scripts/pmc_probe.py 256          (level 2 of C2: the 27-point marching form)
+#       bash scripts/pmc_sq.sh r06/sqband march3 scripts/band_ab.py 3:0            (div-sigma-grad-like band form of the two-stage pass)
+# (counters in their own runs, --kernel-trace only beside --pmc: the pool refuses --pmc with the trace domains)
 set -u
-out=gpurun_out/${1:-sq}
-var=${2:-3:2:2:1024:0}
+out=gpurun_out/$1
+pat=$2
+shift 2
 mkdir -p $out
 export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
-           "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_WAVES SQ_ACTIVE_INST_FLAT" \
-           "TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCR_TCP_STALL_CYCLES TCP_READ_TAGCONFLICT_STALL_CYCLES" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+           "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_WAVES SQ_ACTIVE_INST_FLAT"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 scripts/march3_ab.py 256 $var > $out/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 "$@" > $out/p$i.log 2>&1
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python3 profiles/summarize_pmc.py $f | grep -E "march3" | grep -E "Lb0|false" | grep -E ", 5,|, 2," >> $out/sq.txt
+  [ -n "$f" ] && python3 profiles/summarize_pmc.py $f | grep -E "$pat" >> $out/sq.txt
+  echo "pass $i done" >> $out/progress.txt
 done
 find $out -type d -name "p[0-9]*" -prune -exec rm -rf {} \; 2>/dev/null
 cat $out/sq.txt
