@@ -60,8 +60,13 @@ __device__ __forceinline__ i2_t load_stream(const int* p) {
   return *reinterpret_cast<const i2_t*>(p);
 }
 
-struct CsrDev {
-  const int* rowptr;   // n_rows+1, 0-based
+// PTR: the type of the row pointers - int (12 B per non-zero + 4 B per row, SURVEY 8d's device widths) for operators of fewer than
+// 2^31 non-zeros, long long beyond (round 6: the reference is Int64 throughout, Multigrid.jl:19; the streaming kernels csr_stream_spmv and
+// csr_longrow_spmv are instantiated for both, every other format is built for int operators only)
+template <typename PTR>
+struct CsrDevT {
+  typedef PTR ptr_t;
+  const PTR* rowptr;   // n_rows+1, 0-based
   const int* colidx;   // nnz (+pad), 0-based
   const double* val;   // nnz (+pad)
   const int* blk_row;  // nblocks+1 row-block boundaries
@@ -70,6 +75,14 @@ struct CsrDev {
   int n_rows;
   int n_cols;
 };
+typedef CsrDevT<int> CsrDev;
+typedef CsrDevT<long long> CsrDev64;
+__device__ __forceinline__ int uniform_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uniform_first(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v & 0xffffffffull));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 
 struct VecArgs {
   double* sumsq;    // optional: per-row-block sum of squares of the output (fused ||r||^2, nrhs == 1)
@@ -106,8 +119,9 @@ __device__ __forceinline__ double epilogue(const VecArgs& v, int row, double acc
 // ------------------------------------------------------------------------------------------------
 // CSR-stream SpMV, one right-hand side.
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool NT>
-__global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
+template <int MODE, bool NT, typename AD = CsrDev>
+__global__ __launch_bounds__(BLK) void csr_stream_spmv(AD A, VecArgs v) {
+  typedef typename AD::ptr_t K;      // position in the non-zero stream: int, or long long for operators of >= 2^31 non-zeros
   __shared__ double prod[CHUNK];
   __shared__ int srow[MAXROWS + 1];
   __shared__ double red[BLK / 64];
@@ -118,13 +132,13 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
   const int r0 = A.blk_row[bid];
   const int r1 = A.blk_row[bid + 1];
   const int nrows = r1 - r0;
-  const int k0 = A.rowptr[r0];
-  const int k1 = A.rowptr[r1];
+  const K k0 = A.rowptr[r0];
+  const K k1 = A.rowptr[r1];
 
   if (nrows == 1 && (k1 - k0) > CHUNK - 2) {
     // One row longer than a chunk: the whole workgroup strides over it.
     double acc = 0.0;
-    for (int k = k0 + tid; k < k1; k += BLK) acc += A.val[k] * v.x[A.colidx[k]];
+    for (K k = k0 + tid; k < k1; k += BLK) acc += A.val[k] * v.x[A.colidx[k]];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
@@ -151,12 +165,12 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
   const bool owner = (lrow < nrows) && (sub == 0);
 
   // ---- issue every global load up front: matrix stream, row pointers, epilogue operands -------
-  const int base = k0 & ~1;  // 16-B aligned start of the value stream
+  const K base = k0 & ~(K)1;  // 16-B aligned start of the value stream
   d2_t va[PAIRS];
   i2_t ca[PAIRS];
 #pragma unroll
   for (int it = 0; it < PAIRS; ++it) {
-    const int idx = base + it * (2 * BLK) + 2 * tid;
+    const K idx = base + it * (2 * BLK) + 2 * tid;
     if (idx < k1) {
       va[it] = load_stream<NT>(A.val + idx);
       ca[it] = load_stream<NT>(A.colidx + idx);
@@ -165,8 +179,8 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
       ca[it] = i2_t{0, 0};
     }
   }
-  if (tid <= nrows) srow[tid] = A.rowptr[r0 + tid] - base;
-  if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = k1 - base;
+  if (tid <= nrows) srow[tid] = (int)(A.rowptr[r0 + tid] - base);
+  if (tid == 0 && nrows == MAXROWS) srow[MAXROWS] = (int)(k1 - base);
   double pb = 0.0, pd = 0.0, px = 0.0;
   if (owner) {
     const int row = r0 + lrow;
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(BLK) void csr_stream_spmv(CsrDev A, VecArgs v) {
   // ---- gather x and stage the products --------------------------------------------------------
 #pragma unroll
   for (int it = 0; it < PAIRS; ++it) {
-    const int idx = base + it * (2 * BLK) + 2 * tid;
+    const K idx = base + it * (2 * BLK) + 2 * tid;
     if (idx < k1) {
       d2_t p;
       p.x = va[it].x * v.x[ca[it].x];

@@ -338,9 +338,10 @@ __global__ __launch_bounds__(256) void grid27_band_spmv(Band27Dev T, VecArgs v) 
 // strided entries in stored order, then a fixed tree - deterministic, fp64 reassociation against the CSR row loop (<= 1e-13).
 // ------------------------------------------------------------------------------------------------------------------------------
 // IDX16: the column indices are 16-bit offsets from the row's first column (ci16 / rowbase: 10 instead of 12 bytes per non-zero)
-template <int MODE, bool NT, bool IDX16>
-__global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int nwg, int rows_per_wg, const unsigned short* __restrict__ ci16,
+template <int MODE, bool NT, bool IDX16, typename AD = CsrDev>
+__global__ __launch_bounds__(256) void csr_longrow_spmv(AD A, VecArgs v, int nwg, int rows_per_wg, const unsigned short* __restrict__ ci16,
                                                         const int* __restrict__ rowbase) {
+  typedef typename AD::ptr_t K;      // position in the non-zero stream (int; long long for operators of >= 2^31 non-zeros)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int w = xcd_band((int)blockIdx.x, nwg);
   const int r0 = w * rows_per_wg, r1 = r0 + rows_per_wg < A.n_rows ? r0 + rows_per_wg : A.n_rows;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
   // replaced by (value 0, column 0) before they are used.
 #define LR_SHOT_LOAD(VV, C0, C1, sb)                                                                                   \
   _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                                   \
-    const int p_ = (sb) + 2 * lane + 128 * u_;                                                                         \
+    const K p_ = (sb) + 2 * lane + 128 * u_;                                                                         \
     (VV)[u_] = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(A.val + p_)) : *reinterpret_cast<const d2_t*>(A.val + p_); \
     if (IDX16) {                                                                                                       \
       const us2_t c_ = NT ? __builtin_nontemporal_load(reinterpret_cast<const us2_t*>(ci16 + p_)) : *reinterpret_cast<const us2_t*>(ci16 + p_); \
@@ -365,13 +366,13 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
   do {                                                                                                                 \
     double x0_[4], x1_[4];                                                                                             \
     _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                                 \
-      const int p_ = (sb) + 2 * lane + 128 * u_;                                                                       \
+      const K p_ = (sb) + 2 * lane + 128 * u_;                                                                       \
       const bool i0_ = p_ >= (lo) && p_ < (hi), i1_ = p_ + 1 >= (lo) && p_ + 1 < (hi);                                 \
       x0_[u_] = xb[i0_ ? (C0)[u_] : 0];                                                                                \
       x1_[u_] = xb[i1_ ? (C1)[u_] : 0];                                                                                \
     }                                                                                                                  \
     _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                                 \
-      const int p_ = (sb) + 2 * lane + 128 * u_;                                                                       \
+      const K p_ = (sb) + 2 * lane + 128 * u_;                                                                       \
       const bool i0_ = p_ >= (lo) && p_ < (hi), i1_ = p_ + 1 >= (lo) && p_ + 1 < (hi);                                 \
       const double w0_ = i0_ ? (VV)[u_].x : 0.0, w1_ = i1_ ? (VV)[u_].y : 0.0;                                         \
       if (u_ & 1) { a2 = a2 + w0_ * x0_[u_]; a3 = a3 + w1_ * x1_[u_]; }                                                \
@@ -382,22 +383,22 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
   // and reduces; its row pointers one row further ahead.
   int row = r0 + wave;
   if (row >= r1) return;
-  int k0 = __builtin_amdgcn_readfirstlane(A.rowptr[row]), k1 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
-  int nk0 = 0, nk1 = 0;
-  if (row + 4 < r1) { nk0 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 4]); nk1 = __builtin_amdgcn_readfirstlane(A.rowptr[row + 5]); }
+  K k0 = uniform_first(A.rowptr[row]), k1 = uniform_first(A.rowptr[row + 1]);
+  K nk0 = 0, nk1 = 0;
+  if (row + 4 < r1) { nk0 = uniform_first(A.rowptr[row + 4]); nk1 = uniform_first(A.rowptr[row + 5]); }
   d2_t pv[4];
   int pc0[4], pc1[4];
-  LR_SHOT_LOAD(pv, pc0, pc1, k0 & ~1);
+  LR_SHOT_LOAD(pv, pc0, pc1, k0 & ~(K)1);
   for (; row < r1; row += 4) {
     const double* __restrict__ xb = IDX16 ? v.x + __builtin_amdgcn_readfirstlane(rowbase[row]) : v.x;
     const bool have_next = row + 4 < r1;                     // (uniform)
-    int nnk0 = 0, nnk1 = 0;
+    K nnk0 = 0, nnk1 = 0;
     if (row + 8 < r1) { nnk0 = A.rowptr[row + 8]; nnk1 = A.rowptr[row + 9]; }
     d2_t nv[4];
     int nc0[4], nc1[4];
-    if (have_next) { LR_SHOT_LOAD(nv, nc0, nc1, nk0 & ~1); }
+    if (have_next) { LR_SHOT_LOAD(nv, nc0, nc1, nk0 & ~(K)1); }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int sb = k0 & ~1;                                        // (uniform)
+    K sb = k0 & ~(K)1;                                       // (uniform)
     LR_SHOT_USE(pv, pc0, pc1, sb, k0, k1);
     for (sb += 512; sb < k1; sb += 512) {                    // rows beyond the first shot: shot by shot
       d2_t vv[4];
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256) void csr_longrow_spmv(CsrDev A, VecArgs v, int
     }
     // ---- rotate the pipeline --------------------------------------------------------------------------------------------------
     k0 = nk0; k1 = nk1;
-    nk0 = __builtin_amdgcn_readfirstlane(nnk0); nk1 = __builtin_amdgcn_readfirstlane(nnk1);
+    nk0 = uniform_first(nnk0); nk1 = uniform_first(nnk1);
 #pragma unroll
     for (int u = 0; u < 4; ++u) { pv[u] = nv[u]; pc0[u] = nc0[u]; pc1[u] = nc1[u]; }
   }
