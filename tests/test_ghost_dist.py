@@ -73,15 +73,16 @@ TEST_OPTS = dict(no_small=1, rowclass_min_rows=0, rowclass_max_passes=64, rowcla
                  winp_min_rows=0, march27_min_rows=0, marchr_min_rows=0)
 
 
-def _setup_all_ranks(mg, world, case, cyc, nrhs=1, nd=None):
+def _setup_all_ranks(mg, world, case, cyc, nrhs=1, nd=None, g_fine=None):
     """Host setup of EVERY rank in this process: what all_gather_object would deliver is captured in a first pass."""
     from multigrid_jl_amd import ghost_dist as gd
     from multigrid_jl_amd.structured_setup import poisson_operator
     _, cells, rb = _param(mg, case, cyc)
     nd = nd or _domains(world, len(cells), case)
+    kw = {} if g_fine is None else dict(g_fine=g_fine)
     pieces = {}
     if world == 1:       # (nothing to gather)
-        return [gd.ghost_gmg(cells, nd, 0, 1, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, nrhs=nrhs)]
+        return [gd.ghost_gmg(cells, nd, 0, 1, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, nrhs=nrhs, **kw)]
 
     class _Captured(Exception):
         pass
@@ -91,11 +92,11 @@ def _setup_all_ranks(mg, world, case, cyc, nrhs=1, nd=None):
             pieces[_r] = obj
             raise _Captured()
         try:
-            gd.ghost_gmg(cells, nd, r, world, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, gather_objects=capture, nrhs=nrhs)
+            gd.ghost_gmg(cells, nd, r, world, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, gather_objects=capture, nrhs=nrhs, **kw)
         except _Captured:
             pass
     full = [pieces[r] for r in range(world)]
-    return [gd.ghost_gmg(cells, nd, r, world, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, gather_objects=lambda o: full, nrhs=nrhs)
+    return [gd.ghost_gmg(cells, nd, r, world, _param(mg, case, cyc)[0], poisson_operator(cells), replicate_below=rb, gather_objects=lambda o: full, nrhs=nrhs, **kw)
             for r in range(world)]
 
 
@@ -129,9 +130,9 @@ def _thread_world_run(Gs, body, options=None):
     return out
 
 
-def _run_threads(mg, world, case, cyc, tol, maxit):
+def _run_threads(mg, world, case, cyc, tol, maxit, g_fine=None):
     """What _run(..., "plugin") returns, with the ranks as threads of this process."""
-    Gs = _setup_all_ranks(mg, world, case, cyc)
+    Gs = _setup_all_ranks(mg, world, case, cyc, g_fine=g_fine)
     _, cells, _ = _param(mg, case, cyc)
     A, mesh = mg.poisson_shifted(cells)
     b = mg.seeded_rhs(A)
@@ -211,7 +212,8 @@ def _worker(rank, world, port, case, cyc, mode, q, tol, maxit):
         from multigrid_jl_amd import ghost_dist as gd
         from multigrid_jl_amd.structured_setup import poisson_operator
         p, cells, rb = _param(mg, case, cyc)
-        G = gd.ghost_gmg(cells, _domains(world, len(cells), case), rank, world, p, poisson_operator(cells), replicate_below=rb)
+        kw = dict(g_fine=int(os.environ["MG_TEST_G_FINE"])) if os.environ.get("MG_TEST_G_FINE") else {}
+        G = gd.ghost_gmg(cells, _domains(world, len(cells), case), rank, world, p, poisson_operator(cells), replicate_below=rb, **kw)
         A, mesh = mg.poisson_shifted(cells)
         b = mg.seeded_rhs(A)
         b_ext = b[G.gid_fine]
@@ -404,6 +406,13 @@ def test_ghost_form_cpu_vs_oracle(mg, world, case, cyc):
     assert all(e["exchanges"] > 0 for e in extra)
 
 
+def test_ghost_form_three_fine_layers_cpu(mg, monkeypatch):
+    """The validity rules with a fine level of three ghost layers (what round 5 gave a single sharded level): the four-stage pass is not
+    taken (it consumes four), the NaN-poisoned sequencer finds no rule claiming too much, the history matches the oracle."""
+    monkeypatch.setenv("MG_TEST_G_FINE", "3")
+    _check(mg, 2, "3d-a1", "V", "cpu")
+
+
 def test_ghost_form_early_stop_cpu(mg):
     """The stopping test ends the loop in the middle: same step count and iterate as the oracle."""
     _check(mg, 2, "3d-a2", "V", "cpu", tol=1e-3, maxit=8)
@@ -431,6 +440,21 @@ def test_ghost_form_kcycle_and_jac_gmres(mg, world, case, cyc):
     ran in the halo form only (tests/test_distributed.py::test_native_sequencer_kcycle_and_jac_gmres)."""
     extra = _check(mg, world, case, cyc, "threads", maxit=4)
     assert all(e["exchanges"] > 0 for e in extra)
+
+
+@pytest.mark.gpu
+def test_ghost_form_three_fine_layers_take_the_two_stage_steps(mg):
+    """the four-stage pass consumes FOUR ghost layers of x in one kernel; a fine level that has only three (round 5: one
+    sharded level) silently produced a wrong restriction input.  With g_fine = 3 the pass must not be taken (two-stage steps instead), the
+    residual history still matches the oracle, and nothing is clamped: gh_set reports a negative depth as MG_ERR_STATE."""
+    from oracle import mg_oracle as orc
+    case, cyc, world, tol, maxit = "3d-a1", "V", 2, 1e-8, 6
+    A, b, x_ref, res_ref = _global_reference(mg, case, cyc, tol, maxit)
+    its, resvecs, x, x2, extra = _run_threads(mg, world, case, cyc, tol, maxit, g_fine=3)
+    assert all(i == len(res_ref) - 1 for i in its)
+    for rv in resvecs:
+        assert np.abs(rv - res_ref).max() <= 1e-10 * res_ref[0]
+    assert np.abs(x - x_ref).max() <= 1e-10 * np.abs(x_ref).max()
 
 
 @pytest.mark.gpu
