@@ -4250,6 +4250,53 @@ __global__ __launch_bounds__(BLK) void blk_gram_partial(const double* __restrict
     partial[((size_t)blockIdx.x * k + a) * k + threadIdx.x] = t;
   }
 }
+// the same over the rows of a sub-box of an x-fastest grid (the owned box inside a rank's extended box: the Gram matrices of the sharded
+// block Krylov drivers count every global row once)
+__global__ __launch_bounds__(BLK) void blk_gram_box_partial(const double* __restrict__ X, const double* __restrict__ Y, BoxDev B, int k,
+                                                            double* __restrict__ partial) {
+  __shared__ double red[BLK / 64][BLK_KMAX];
+  const int a = blockIdx.y;
+  double acc[BLK_KMAX];
+#pragma unroll
+  for (int b = 0; b < BLK_KMAX; ++b) acc[b] = 0.0;
+  const int lx = B.hi[0] - B.lo[0], ly = B.hi[1] - B.lo[1], lz = B.hi[2] - B.lo[2];
+  const long long nown = (long long)lx * ly * lz, stride = (long long)gridDim.x * BLK;
+  for (long long q = (long long)blockIdx.x * BLK + threadIdx.x; q < nown; q += stride) {
+    const int z = (int)(q / ((long long)lx * ly)), rem = (int)(q - (long long)z * lx * ly), y = rem / lx, x = rem - y * lx;
+    const long long i = ((long long)(z + B.lo[2]) * B.n2 + (y + B.lo[1])) * B.n1 + (x + B.lo[0]);
+    const double xa = X[i * k + a];
+#pragma unroll
+    for (int b = 0; b < BLK_KMAX; ++b)
+      if (b < k) acc[b] += xa * Y[i * k + b];
+  }
+#pragma unroll
+  for (int b = 0; b < BLK_KMAX; ++b) {
+    double t = acc[b];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][b] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < k) {
+    double t = 0.0;
+    for (int w = 0; w < BLK / 64; ++w) t += red[w][threadIdx.x];
+    partial[((size_t)blockIdx.x * k + a) * k + threadIdx.x] = t;
+  }
+}
+// ghost layers of a row-major block [n][k]: dst[i][:] = src[idx[i]][:] / dst[idx[i]][:] = src[i][:]
+__global__ __launch_bounds__(BLK) void ghost_pack_block(const double* __restrict__ src, const int* __restrict__ idx, double* __restrict__ dst, long long n, int k) {
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (t >= n * k) return;
+  const long long i = t / k;
+  const int c = (int)(t - i * k);
+  dst[t] = src[(long long)idx[i] * k + c];
+}
+__global__ __launch_bounds__(BLK) void ghost_unpack_block(const double* __restrict__ src, const int* __restrict__ idx, double* __restrict__ dst, long long n, int k) {
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (t >= n * k) return;
+  const long long i = t / k;
+  const int c = (int)(t - i * k);
+  dst[(long long)idx[i] * k + c] = src[t];
+}
 __global__ __launch_bounds__(BLK) void blk_gram_final(const double* __restrict__ partial, int nb, int k,
                                                       double* __restrict__ out) {
   const int e = threadIdx.x;   // entry a*k + b

@@ -489,6 +489,32 @@ class DeviceHierarchy:
                                                   C.byref(iters), C.byref(flag), _f64(resvec)), "mg_pcg_dev")
         return int(flag.value), int(iters.value), resvec[: iters.value]
 
+    # -- block Krylov drivers on device tensors (row-major [n][nrhs]); KrylovMethods.blockCG / blockBiCGSTB / blockFGMRES ----------
+    def block_pcg_dev(self, b, x, tol: float, maxIter: int):
+        """returns (flag, iterations, resmat[iterations][nrhs] of ||r_j|| / ||b_j||)"""
+        _sync_torch(b, x)
+        iters, flag = C.c_longlong(0), C.c_longlong(0)
+        resmat = np.zeros((max(int(maxIter), 1), self.nrhs))
+        _check(self.lib, self.lib.mg_block_pcg_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, self.nrhs, float(tol), int(maxIter),
+                                                        C.byref(iters), C.byref(flag), _f64(resmat)), "mg_block_pcg_dev")
+        return int(flag.value), int(iters.value), resmat[: iters.value]
+
+    def block_bicgstab_dev(self, b, x, tol: float, maxIter: int):
+        _sync_torch(b, x)
+        iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        resvec = np.zeros(2 * max(int(maxIter), 1) + 1)
+        _check(self.lib, self.lib.mg_block_bicgstab_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, self.nrhs, float(tol), int(maxIter),
+                                                             C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)), "mg_block_bicgstab_dev")
+        return int(flag.value), int(iters.value), resvec[: nres.value]
+
+    def block_fgmres_dev(self, b, x, inner: int, tol: float, maxIter: int):
+        _sync_torch(b, x)
+        iters, flag, nres = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        resvec = np.zeros(max(int(inner) * int(maxIter), 1))
+        _check(self.lib, self.lib.mg_block_fgmres_dev_FP64(self.handle, _ptr(b), _ptr(x), self.n, self.nrhs, int(inner), float(tol), int(maxIter),
+                                                           C.byref(iters), C.byref(flag), _f64(resvec), C.byref(nres)), "mg_block_fgmres_dev")
+        return int(flag.value), int(iters.value), resvec[: nres.value]
+
     def bicgstab_dev(self, b, x, tol: float, maxIter: int):
         """solveBiCGSTAB_MG on device tensors (one right-hand side); returns (flag, iterations, resvec: the entry at the start, then
         two per iteration)."""

@@ -503,14 +503,15 @@ class NativeGhostHierarchy:
 
     # -- MG-preconditioned Krylov on this rank's extended fine box (solveCG_MG / solveBiCGSTAB_MG / solveGMRES_MG, SolveFuncs.jl:74-133):
     #    b, x device tensors of n_ext doubles, owned rows of b valid, owned rows of x valid on return; sums over the owned rows of all ranks
+    #    (a block of nrhs > 1 columns, n_ext x nrhs row-major: KrylovMethods.blockCG / blockBiCGSTB / blockFGMRES, as the reference's wrappers call them)
     def pcg(self, b_ext, x_ext, tol: float, maxIter: int):
-        return self.dev.pcg_dev(b_ext, x_ext, tol, maxIter)
+        return self.dev.pcg_dev(b_ext, x_ext, tol, maxIter) if self.nrhs == 1 else self.dev.block_pcg_dev(b_ext, x_ext, tol, maxIter)
 
     def bicgstab(self, b_ext, x_ext, tol: float, maxIter: int):
-        return self.dev.bicgstab_dev(b_ext, x_ext, tol, maxIter)
+        return self.dev.bicgstab_dev(b_ext, x_ext, tol, maxIter) if self.nrhs == 1 else self.dev.block_bicgstab_dev(b_ext, x_ext, tol, maxIter)
 
     def fgmres(self, b_ext, x_ext, inner: int, tol: float, maxIter: int):
-        return self.dev.fgmres_dev(b_ext, x_ext, inner, tol, maxIter)
+        return self.dev.fgmres_dev(b_ext, x_ext, inner, tol, maxIter) if self.nrhs == 1 else self.dev.block_fgmres_dev(b_ext, x_ext, inner, tol, maxIter)
 
     def comm_count(self) -> int:
         import ctypes as C

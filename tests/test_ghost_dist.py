@@ -815,3 +815,52 @@ def test_c4_topology_eight_ranks_ghost_form_hip(mg, method):
         if method == "pcg":
             assert flag == flag_ref and it == it_ref
     assert np.abs(x - x_ref).max() <= 1e-10 * np.abs(x_ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,nrhs", [(2, 3), (4, 2)])
+def test_ghost_form_block_krylov_hip_vs_oracle(mg, world, nrhs):
+    """The BLOCK Krylov drivers on ghost-attached handles (round 6): blockCG / blockBiCGSTB / blockFGMRES as the reference's wrappers call
+    them for several right-hand sides (SolveFuncs.jl:95,113,130; MGWrapper.jl:67-78).  Blocks [n_ext][k] with their owned rows valid: a
+    Gram matrix is the box Gram over the owned rows + ONE all-reduce of k x k doubles, a product with A follows one exchange of the block's
+    ghost layers, the preconditioner is the block's columns through the sharded cycle.  Against the oracle on the global hierarchy."""
+    from oracle import mg_oracle as orc
+    case, cyc, tol, maxit = "3d-a2", "V", 1e-8, 12
+    p, cells, _ = _param(mg, case, cyc)
+    A, mesh = mg.poisson_shifted(cells)
+    mg.MGsetup(A, mesh, p, nrhs)
+    B = mg.seeded_rhs(A, nrhs)
+    p.relativeTol, p.maxOuterIter = tol, maxit
+    Af = lambda V: A @ V
+    M = orc.getMultigridPreconditioner(p, B)
+    Xcg, fcg, rcg, icg = orc.blockCG(Af, B, tol, maxit, M)
+    Xbi, fbi, ibi, rbi = orc.blockBiCGSTB(Af, B, tol, maxit, M)
+    Xgm, fgm, igm, rgm = orc.blockFGMRES(Af, B, 3, tol, maxit, M)
+    Gs = _setup_all_ranks(mg, world, case, cyc, nrhs=nrhs)
+    opts = dict(TEST_OPTS, rowclass_min_cover=0.05, march_max_len=64, march4_ty_max=12)
+
+    def body(r, G, H):
+        own = G.levels[0].own_mask()
+        bt = torch.from_numpy(np.ascontiguousarray(B[G.gid_fine])).cuda()
+        outs = []
+        for name in ("pcg", "bicgstab", "fgmres"):
+            xt = torch.zeros_like(bt)
+            if name == "pcg":
+                flag, it, res = H.pcg(bt, xt, tol, maxit)
+            elif name == "bicgstab":
+                flag, it, res = H.bicgstab(bt, xt, tol, maxit)
+            else:
+                flag, it, res = H.fgmres(bt, xt, 3, tol, maxit)
+            outs.append((xt.cpu().numpy()[own], int(flag), int(it), np.asarray(res)))
+        return G.gid_fine[own], outs
+
+    out = _thread_world_run(Gs, body, options=opts)
+    for j, (Xo, fo, io, ro) in enumerate(((Xcg, fcg, icg, rcg.max(axis=1)), (Xbi, fbi, ibi, rbi), (Xgm, fgm, igm, rgm))):
+        X = np.zeros_like(B)
+        for gid, outs in out:
+            xl, flag, it, res = outs[j]
+            X[gid] = xl
+            assert flag == fo and it == io, (j, flag, fo, it, io)
+            res = res.max(axis=1) if res.ndim == 2 else res
+            assert len(res) == len(ro) and np.abs(res - ro).max() <= 1e-8, (j, res, ro)
+        assert np.abs(X - Xo).max() <= 1e-8 * np.abs(Xo).max()
