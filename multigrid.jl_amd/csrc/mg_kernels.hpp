@@ -1369,10 +1369,8 @@ __global__ __launch_bounds__(CR, CR >= 1024 ? 8 : 4) void csr_rowclass_tile_spmv
 //  * the (chunk, plane) items are dealt to the workgroups as equal contiguous ranges of the chunk-major list, so a
 //    launch is exactly one balanced round of the resident workgroups (a range that runs off the end of a chunk
 //    continues at plane 0 of the next one).
-// Optional prologue (PRO): the staged vector is x + Pm*xc instead of x - the coarse-grid correction x += P*xc
-// (MGcycle.jl:90) is applied while the slab passes through registers, in the arithmetic of the stand-alone product
-// (entries in stored order, then 1.0*acc + x), so the post-smoothing sweep needs no prolongation launch and x is not
-// read-modified-written in HBM.
+// (Rounds 2-5 carried an optional prologue that staged x + P*xc instead of x - the coarse-grid correction fused into the first
+// post-smoothing sweep; measured slower than the prolongation kernel + sweep in every round, off by default since round 2, retired in round 6.)
 // The host selects this kernel only when EVERY dictionary entry of every class is a staged shift dz*P + rest with
 // |dz| <= 1, |rest| <= halo (true for grid operators; anything else keeps the plane-tile kernel and its global gathers).
 // ------------------------------------------------------------------------------------------------
@@ -1380,9 +1378,7 @@ constexpr int RM_C = 1024;    // rows of a plane per workgroup = threads per wor
 constexpr int RM_RING = 4;    // slabs in LDS: planes z-1, z, z+1 in use, z+2 being written
 constexpr int RM_DCAP = 512;  // dictionary entries of the operator
 constexpr int RM_NCLS = 128;  // classes of the operator
-constexpr int RM_PDCAP = 128; // dictionary entries / classes of the fused prolongation
-constexpr int RM_PNCLS = 64;
-constexpr int RM_DICT_BYTES = 16 * RM_DCAP + 8 * RM_NCLS + 4 * (RM_NCLS + 4) + 16 * RM_PDCAP + 4 * (RM_PNCLS + 4) + 4 * RM_PNCLS;
+constexpr int RM_DICT_BYTES = 16 * RM_DCAP + 8 * RM_NCLS + 4 * (RM_NCLS + 4);
 
 struct MarchDev {
   const int* lb;     // per dictionary entry: ((rest + halo) << 2) | (dz + 1)   (all >= 0: host check)
@@ -1396,17 +1392,9 @@ struct MarchDev {
   int maxlen;        // longest class
 };
 
-// The coarse-grid correction fused into the staging of csr_rowclass_march_spmv: Pm in row-class form (any variant
-// without exception rows; at most RM_PNCLS classes / RM_PDCAP entries; longest class maxlen).
-struct ProDev {
-  RowClassDev Pm;
-  const double* xc;
-  int ncls, nent, maxlen;
-};
-
 struct MarchEnt {   // one dictionary record in LDS
   double val;
-  int code;         // A: LDS index code ((rest + halo) << 2 | dz + 1); Pm: column offset from the row's first column
+  int code;         // LDS index code ((rest + halo) << 2 | dz + 1)
   int pad;
 };
 
@@ -1427,7 +1415,6 @@ __device__ __forceinline__ d2_t march_load_pair(const double* __restrict__ x, lo
   return r;
 }
 
-// class ids and first columns of the prolongation's rows e0, e0 + 1 (prefetched one plane ahead of their use)
 // The same pair with ONE 16-byte load in every lane, no branch and NO fix-up behind the load (a select on the loaded value
 // would be a wait right after the issue): the number of vector-memory instructions a lane issues is static (the loop-top
 // wait of the marching kernels counts them) and no load waits for an earlier one's destination registers - the two-path
@@ -1445,42 +1432,8 @@ __device__ __forceinline__ d2_t march_load_pair_raw(const double* __restrict__ x
 __device__ __forceinline__ void march_pair_fix(d2_t& v, long long e0, bool act, int n_cols) {
   if (march_pair_tail(e0, act, n_cols)) v.x = v.y;
 }
-struct ProRows {
-  int cls0, cls1, first0, first1;
-};
-__device__ __forceinline__ ProRows march_load_prorows(const RowClassDev& Pm, long long e0, bool act) {
-  ProRows r;
-  r.cls0 = r.cls1 = 0xFFFF;   // 0xFFFF: no contribution
-  r.first0 = r.first1 = 0;
-  if (act) {
-    if (e0 >= 0 && e0 + 1 < Pm.n_rows) {
-      const unsigned int cc = *reinterpret_cast<const unsigned int*>(Pm.cls + e0);   // e0 is even: 4-byte aligned
-      r.cls0 = (int)(cc & 0xFFFFu);
-      r.cls1 = (int)(cc >> 16);
-      if (Pm.firstcol) {
-        const i2_t f = *reinterpret_cast<const i2_t*>(Pm.firstcol + e0);
-        r.first0 = f.x;
-        r.first1 = f.y;
-      } else {
-        r.first0 = (int)e0;
-        r.first1 = (int)e0 + 1;
-      }
-    } else {
-      if (e0 >= 0 && e0 < Pm.n_rows) {
-        r.cls0 = Pm.cls[e0];
-        r.first0 = Pm.firstcol ? Pm.firstcol[e0] : (int)e0;
-      }
-      if (e0 + 1 >= 0 && e0 + 1 < Pm.n_rows) {
-        r.cls1 = Pm.cls[e0 + 1];
-        r.first1 = Pm.firstcol ? Pm.firstcol[e0 + 1] : (int)e0 + 1;
-      }
-    }
-  }
-  return r;
-}
-
-template <int MODE, bool EXC, bool PRO>
-__global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C, VecArgs v, MarchDev T, ProDev Q) {
+template <int MODE, bool EXC>
+__global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C, VecArgs v, MarchDev T) {
   extern __shared__ double win[];
   __shared__ double red[RM_C / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1492,9 +1445,6 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
   MarchEnt* dent = reinterpret_cast<MarchEnt*>(win + RM_RING * SLP);      // [RM_DCAP]
   double* dd = reinterpret_cast<double*>(dent + RM_DCAP);                 // [RM_NCLS] class relaxPrec
   int* dptr = reinterpret_cast<int*>(dd + RM_NCLS);                       // [RM_NCLS + 1] (+3 pad)
-  MarchEnt* pent = reinterpret_cast<MarchEnt*>(dptr + RM_NCLS + 4);       // [RM_PDCAP]
-  int* pptr = reinterpret_cast<int*>(pent + RM_PDCAP);                    // [RM_PNCLS + 1] (+3 pad)
-  int* pdelta = pptr + RM_PNCLS + 4;                                      // [RM_PNCLS]
   const bool class_d = (MODE == SMOOTH || (MODE == RESID && v.y2)) && !v.d;
   for (int i = tid; i < T.nent; i += RM_C) {
     MarchEnt e;
@@ -1505,17 +1455,6 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
   }
   for (int i = tid; i <= T.ncls; i += RM_C) dptr[i] = C.cls_ptr[i];
   for (int i = tid; i < T.ncls; i += RM_C) dd[i] = class_d ? C.cls_d[i] : 0.0;
-  if (PRO) {
-    for (int i = tid; i < Q.nent; i += RM_C) {
-      MarchEnt e;
-      e.val = Q.Pm.cls_val[i];
-      e.code = Q.Pm.cls_off[i];
-      e.pad = 0;
-      pent[i] = e;
-    }
-    for (int i = tid; i <= Q.ncls; i += RM_C) pptr[i] = Q.Pm.cls_ptr[i];
-    for (int i = tid; i < Q.ncls; i += RM_C) pdelta[i] = Q.Pm.firstcol ? 0 : Q.Pm.cls_delta[i];
-  }
   const long long tot = (long long)T.chunks * T.nplanes;
   long long it = tot * w / T.nblocks;
   const long long it_end = tot * (w + 1) / T.nblocks;
@@ -1525,45 +1464,10 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
   // slab of plane p of chunk c: global entries [a0, a0 + 2*npair), a0 = even floor of p*P + c*RM_C - halo
 #define MARCH_G0(c, p) ((long long)(p) * T.P + (long long)(c) * RM_C - T.halo)
 #define MARCH_E0(c, p) ((MARCH_G0(c, p) & ~1LL) + 2 * tid)
-  // (Pm*xc) for the pair's two rows: every lane walks the entries of its own rows' classes (dictionary in LDS), four
-  // entries of each row per trip - eight gathers of xc (global memory: L2) in flight, then the additions in stored
-  // order; rows without a class (cls 0xFFFF: outside the vector) contribute 0
-#define MARCH_PROLONG_PAIR(pr, out0_, out1_)                                                                           \
+  // pair -> LDS
+#define MARCH_STAGE(slot, val)                                                                                         \
   do {                                                                                                                 \
-    const bool ok0_ = (pr).cls0 != 0xFFFF, ok1_ = (pr).cls1 != 0xFFFF;                                                 \
-    const int c0_ = ok0_ ? (pr).cls0 : 0, c1_ = ok1_ ? (pr).cls1 : 0;                                                  \
-    const int s0_ = pptr[c0_], s1_ = pptr[c1_];                                                                        \
-    const int len0_ = ok0_ ? pptr[c0_ + 1] - s0_ : 0, len1_ = ok1_ ? pptr[c1_ + 1] - s1_ : 0;                          \
-    const double* xb0_ = Q.xc + ((pr).first0 + pdelta[c0_]);                                                           \
-    const double* xb1_ = Q.xc + ((pr).first1 + pdelta[c1_]);                                                           \
-    double a0_ = 0.0, a1_ = 0.0;                                                                                       \
-    for (int k_ = 0; k_ < Q.maxlen; k_ += 4) {                                                                         \
-      double g0_[4], g1_[4];                                                                                           \
-      const int m0_ = len0_ > 0 ? len0_ - 1 : 0, m1_ = len1_ > 0 ? len1_ - 1 : 0;                                      \
-      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                               \
-        g0_[u_] = (k_ + u_ < len0_) ? xb0_[pent[s0_ + min(k_ + u_, m0_)].code] : 0.0;                                  \
-        g1_[u_] = (k_ + u_ < len1_) ? xb1_[pent[s1_ + min(k_ + u_, m1_)].code] : 0.0;                                  \
-      }                                                                                                                \
-      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                               \
-        const double t0_ = a0_ + pent[s0_ + min(k_ + u_, m0_)].val * g0_[u_];                                          \
-        const double t1_ = a1_ + pent[s1_ + min(k_ + u_, m1_)].val * g1_[u_];                                          \
-        a0_ = (k_ + u_ < len0_) ? t0_ : a0_;                                                                           \
-        a1_ = (k_ + u_ < len1_) ? t1_ : a1_;                                                                           \
-      }                                                                                                                \
-    }                                                                                                                  \
-    (out0_) = a0_;                                                                                                     \
-    (out1_) = a1_;                                                                                                     \
-  } while (0)
-  // pair -> LDS; PRO: x + P*xc in the arithmetic of the stand-alone product (alpha = beta = 1: 1.0*acc + 1.0*x)
-#define MARCH_STAGE(slot, val, pr)                                                                                     \
-  do {                                                                                                                 \
-    d2_t sv_ = (val);                                                                                                  \
-    if (PRO) {                                                                                                         \
-      double acc0_, acc1_;                                                                                             \
-      MARCH_PROLONG_PAIR(pr, acc0_, acc1_);                                                                            \
-      sv_.x = 1.0 * acc0_ + 1.0 * sv_.x;                                                                               \
-      sv_.y = 1.0 * acc1_ + 1.0 * sv_.y;                                                                               \
-    }                                                                                                                  \
+    const d2_t sv_ = (val);                                                                                            \
     if (pact) {                                                                                                        \
       win[(slot) * SLP + 2 * tid] = sv_.x;                                                                             \
       win[(slot) * SLP + 2 * tid + 1] = sv_.y;                                                                         \
@@ -1580,24 +1484,15 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
     const bool rowlive = inplane < T.P;
     // ---- fill the ring: planes z0-1, z0, z0+1; plane z0+2 goes into registers -------------------------------------
     d2_t pre;
-    ProRows prow{};
-    if (PRO) {   // (one plane at a time: the fused prolongation needs the registers)
-#pragma unroll 1
-      for (int pp = 0; pp < 3; ++pp) {
-        const d2_t qq = march_load_pair(v.x, MARCH_E0(c, z0 - 1 + pp), pact, T.n_cols);
-        const ProRows rr = march_load_prorows(Q.Pm, MARCH_E0(c, z0 - 1 + pp), pact);
-        MARCH_STAGE(pp, qq, rr);
-      }
-    } else {
+    {
       const d2_t q0 = march_load_pair(v.x, MARCH_E0(c, z0 - 1), pact, T.n_cols);
       const d2_t q1 = march_load_pair(v.x, MARCH_E0(c, z0), pact, T.n_cols);
       const d2_t q2 = march_load_pair(v.x, MARCH_E0(c, z0 + 1), pact, T.n_cols);
-      MARCH_STAGE(0, q0, prow);
-      MARCH_STAGE(1, q1, prow);
-      MARCH_STAGE(2, q2, prow);
+      MARCH_STAGE(0, q0);
+      MARCH_STAGE(1, q1);
+      MARCH_STAGE(2, q2);
     }
     pre = march_load_pair(v.x, MARCH_E0(c, z0 + 2), pact, T.n_cols);
-    if (PRO) prow = march_load_prorows(Q.Pm, MARCH_E0(c, z0 + 2), pact);
     int ncls;
     double npb = 0.0, npd = 0.0;
     {
@@ -1620,13 +1515,11 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
     for (int z = z0; z < z1; ++z) {
       const int q = z - z0 + 1;                        // ring index of plane z (plane z0-1 is 0)
       d2_t cur = pre;
-      ProRows crow = prow;
       int cls = ncls;
       double pb = npb, pd = npd;
       asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cls), "+v"(pb), "+v"(pd));   // the wait of this iteration
-      if (PRO) asm volatile("" : "+v"(crow.cls0), "+v"(crow.cls1), "+v"(crow.first0), "+v"(crow.first1));
       // ---- plane z+2 into its slot (that of plane z-2, last read before the previous barrier) ----------------------
-      if (z + 2 <= z1) MARCH_STAGE((q + 2) & 3, cur, crow);   // (planes beyond z1 are not needed by this run)
+      if (z + 2 <= z1) MARCH_STAGE((q + 2) & 3, cur);   // (planes beyond z1 are not needed by this run)
       // ---- stores of plane z-1, then the loads of plane z+3 and of the row operands of plane z+1 ---------------------
       if (st_row >= 0) {
         if (MODE != RESID || v.y) v.y[st_row] = st_out;   // (the solve loop needs only ||r|| and x + d.*r: y may be null)
@@ -1634,7 +1527,6 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
       }
       if (z + 3 <= z1) {
         pre = march_load_pair(v.x, MARCH_E0(c, z + 3), pact, T.n_cols);
-        if (PRO) prow = march_load_prorows(Q.Pm, MARCH_E0(c, z + 3), pact);
       }
       if (z + 1 < z1) {
         const int row = (z + 1) * T.P + inplane;
@@ -1705,7 +1597,6 @@ __global__ __launch_bounds__(RM_C, 8) void csr_rowclass_march_spmv(RowClassDev C
 #undef MARCH_G0
 #undef MARCH_E0
 #undef MARCH_STAGE
-#undef MARCH_PROLONG_PAIR
 }
 
 // ------------------------------------------------------------------------------------------------

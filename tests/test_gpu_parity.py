@@ -655,10 +655,10 @@ def test_wrong_grid_hint_changes_nothing(mg, built, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cells,levels,cyc,pre,post", [([33, 25, 7], 2, "V", 2, 1), ([40, 30, 9], 3, "W", 1, 2), ([23, 23, 23], 3, "V", 2, 1),
                                                        ([70, 10, 12], 2, "F", 2, 2), ([64, 64, 20], 3, "V", 2, 1), ([31, 37], 3, "V", 2, 1)])
-def test_march_kernel_and_fused_prolongation(mg, built, monkeypatch, cells, levels, cyc, pre, post):
-    """csr_rowclass_march_spmv (z-marching ring of slabs) and the coarse-grid correction fused into the staging of the
-    first post-smoothing sweep: kernel-level products against scipy, the solve against the oracle, and bit-identical
-    iterates against the plane-tile kernel / the separate prolongation launch (same products, same order)."""
+def test_march_kernel_vs_plane_tiles(mg, built, monkeypatch, cells, levels, cyc, pre, post):
+    """csr_rowclass_march_spmv (z-marching ring of slabs): kernel-level products against scipy, the solve against the oracle, and
+    bit-identical iterates against the plane-tile kernel (same products, same order).  (Until round 5 this test also forced the
+    coarse-grid correction fused into the staging of the first post-smoothing sweep - measured slower in every round, retired in round 6.)"""
     import torch
     from multigrid_jl_amd import device as D
     monkeypatch.setenv("MG_ROWCLASS_MIN_ROWS", "0")
@@ -672,9 +672,8 @@ def test_march_kernel_and_fused_prolongation(mg, built, monkeypatch, cells, leve
     monkeypatch.setenv("MG_PAIR_MIN_ROWS", "0")
     rng = np.random.default_rng(sum(cells) + 1)
     runs = {}
-    for name, no_march, fuse in (("march+fused", "0", "1"), ("march", "0", "0"), ("tile", "1", "0")):
+    for name, no_march in (("march", "0"), ("tile", "1")):
         monkeypatch.setenv("MG_NO_MARCH", no_march)
-        monkeypatch.setenv("MG_FUSE_PROLONG", fuse)
         A, p, b = _setup(mg, cells, levels, "Jac", 0.8, pre, post, cyc, maxIter=5)
         h = mg.to_device(p)
         var = h.operator_kernel_variant(1, D.MG_OP_A)
@@ -704,10 +703,9 @@ def test_march_kernel_and_fused_prolongation(mg, built, monkeypatch, cells, leve
         assert np.abs(x1 - xo).max() <= RES_TOL * np.abs(xo).max()
         runs[name] = (x.copy(), np.asarray(p.resvec).copy(), x1.copy())
         mg.clear_(p)
-    for other in ("march", "tile"):
-        assert np.array_equal(runs["march+fused"][0], runs[other][0]), other          # same products, same order
-        assert np.array_equal(runs["march+fused"][2], runs[other][2]), other
-        assert np.abs(runs["march+fused"][1] - runs[other][1]).max() <= 1e-14 * runs[other][1][0]
+    assert np.array_equal(runs["march"][0], runs["tile"][0])          # same products, same order
+    assert np.array_equal(runs["march"][2], runs["tile"][2])
+    assert np.abs(runs["march"][1] - runs["tile"][1]).max() <= 1e-14 * runs["tile"][1][0]
 
 
 @pytest.mark.gpu
