@@ -522,21 +522,24 @@ int mg_dist_destroy(mg_dist* h);
 /* ---- sharded cycle with deep ghost layers (one process per GPU; csrc/mg_ghost.inc) -------------------------------------
  * The communication-avoiding form of the sharded cycle - the reference's `overlap` (getBoxWithOverlap,
  * src/DomainDecomposition/DDIndices.jl:61-92; box rule l.41-47; fan-out DDParallel.jl:87-105,133-139).  The host builds this
- * rank's part of the hierarchy on EXTENDED boxes - owned box + g ghost layers towards every neighbour, nested from level to
- * level (fine = 2 * coarse - 1 nodes) - and uploads it as an ORDINARY mg_hierarchy (mg_create ... mg_finalize): levels
- * 1..nlevels_sharded are extended-box grid operators, the levels below them are replicated on every rank; the restriction
- * into the first replicated level has one row per node of that level, non-empty for the nodes this rank owns.  These calls
- * attach geometry, exchange plans and transport; afterwards mg_cycle_dev_FP64 / mg_solve_dev_FP64 run the sharded cycle on
- * vectors of the extended fine box (b: owned rows valid on entry; x: owned rows valid on return), with every single-GPU
- * kernel form (four-stage pass, 27-point marching form, marching restriction, staged prolongation, pipelined stopping
- * test) and ONE exchange per fused pass: the library tracks on how many ghost layers each level vector is still valid
- * (a product with A costs one) and refreshes all layers at once where the next operation needs more - on the fine level
- * right behind the four-stage pass, overlapped with the whole coarse cycle on a side stream.  Norms are sums over the
- * owned rows of all ranks.  Pointwise smoothers, V / W / F cycles, direct coarsest solve.  A block of 2-24 right-hand sides
- * (mg_create / mg_set_nrhs before the attach; vectors [n_ext][nrhs] row-major) is SOLVED column by column - mg_solve_dev_FP64
- * only, where the column-wise solve serves the fine level (four-stage pass, V(2,*)): every column plays the single-vector
- * schedule with its own exchanges, one Frobenius stopping test over the owned rows of all ranks.  Anything else (a single
- * block cycle, Jac-GMRES, the K-cycle, general CSR): mg_dist_*.  Transport: RCCL (the 128-byte id of mg_dist_unique_id) or the host-staged plug-in (ops 0 and 1). */
+ * rank's part of the hierarchy on EXTENDED boxes - owned box + ghost layers towards every neighbour, every level with the width
+ * its own passes consume (round 6: 5 on the fine level = four-stage pass + restriction, 3 on the coarser ones; a level's box ends on
+ * nodes of the next level, whose box holds at least the parents of all its nodes - P and R then pair a box with a SUB-BOX of the next
+ * one, which the transfer kernels find in the uploaded operators) - and uploads it as an ORDINARY mg_hierarchy (mg_create ...
+ * mg_finalize): levels 1..nlevels_sharded are extended-box grid operators, the levels below them are replicated on every rank; the
+ * restriction into the first replicated level has one row per node of that level, non-empty for the nodes this rank owns.  These
+ * calls attach geometry, exchange plans and transport; afterwards the device-pointer entry points run SHARDED on vectors of the
+ * extended fine box (b: owned rows valid on entry; x: owned rows valid on return), with every single-GPU kernel form (four-stage pass,
+ * 27-point marching form, arithmetic transfers, pipelined stopping test): the library tracks on how many ghost layers each level
+ * vector is still valid (a product with A costs one) and refreshes all layers at once where the next operation needs more - on the
+ * fine level right behind the four-stage pass, overlapped with the whole coarse cycle on a side stream; exchanges awaited at once
+ * stay on the compute stream.  A pass that would consume more layers than its input has is MG_ERR_STATE, never a clamp.  Norms, dots
+ * and Gram matrices are sums over the owned rows of all ranks.  Served: mg_cycle_dev_FP64 / mg_solve_dev_FP64 (V / W / F / K cycles,
+ * Jac / SPAI / Jac-GMRES, direct coarsest solve; a block of 2-24 right-hand sides - mg_create / mg_set_nrhs before the attach, vectors
+ * [n_ext][nrhs] row-major - column by column where the column-wise solve serves the fine level: four-stage pass, V(2,*)), the
+ * MG-preconditioned Krylov drivers mg_pcg_dev_FP64 / mg_bicgstab_dev_FP64 / mg_fgmres_dev_FP64 (SolveFuncs.jl:74-133) and their block
+ * forms mg_block_*_dev_FP64.  Refused (MG_ERR_UNSUPPORTED): host-pointer entry points, coarseSolveType "GMRES", mg_rap_FP64; general
+ * CSR (SA-AMG) hierarchies take mg_dist_*.  Transport: RCCL (the 128-byte id of mg_dist_unique_id) or the host-staged plug-in (ops 0 and 1). */
 int mg_ghost_attach(mg_hierarchy* h, long long rank, long long world, long long nlevels_sharded, const char* unique_id128);
 /* (RCCL transport, optional but recommended for world > 1) a SECOND communicator - another id of mg_dist_unique_id - for the
  * ghost-layer send / recv on the side stream: RCCL serialises the operations of one communicator in issue order whatever
@@ -551,6 +554,9 @@ int mg_ghost_set_level_INT64(mg_hierarchy* h, long long level, const long long* 
                              const long long* own_hi, long long gmin, long long n_send, const long long* send_idx,
                              const long long* send_splits, long long n_recv, const long long* recv_idx,
                              const long long* recv_splits);
+/* COLLECTIVE over the ranks (one all-reduce): they agree on what every rank's kernels can do (four-stage pass, fused sweep + residual, its
+ * from-zero form, d.*bc out of the restriction) - the boxes of two ranks differ by a line or two, a format builder may serve one and not
+ * the other, and every rank must exchange at the same points.  A block handle whose ranks do not all have the four-stage pass fails here. */
 int mg_ghost_finalize(mg_hierarchy* h);
 /* Timing aid: rank R of a world of N alone on its GPU - exchanges run their pack / unpack kernels, nothing travels, sums stay
  * local (before mg_ghost_finalize; not with RCCL).  Results are meaningless, the step time is one GPU's compute share. */
