@@ -3,6 +3,10 @@
 //
 //   TWO:   t = x + d.*(b - A x)  (MGcycle.jl:129-131)   and   r = b - A t  (MGcycle.jl:58-60)   in one walk along z
 //   else:  ONE product per walk:  y = x + d.*(b - A x)  (MODE1 == SMOOTH)   or   y = b - A x  (MODE1 == RESID)
+//   FZ (with TWO; round 6): the level is entered with x = 0 (MGcycle.jl:29: `norm(x) > 0` fails, r = b), so the first update is
+//          x1 = d.*b and the walk is x1 = d.*b ; t = x1 + d.*(b - A x1) ; r = b - A t  - three stages, x is NOT read: the staging
+//          loads take b and every staged entry is multiplied by the relaxPrec of ITS row's class (two LDS look-ups per entry
+//          and plane); the restriction that produced b need not write x1.  Same products as the d.*b launch: same bits.
 //
 // Why another kernel (round 4): level 2 of C2 ran the plane-tile kernel (csr_rowclass_tile_spmv: six slabs staged per four
 // planes, then 27 x {16-byte record read, 4 operand reads} per lane) at 84 rows/ns - half of what the fine level's marching
@@ -43,8 +47,9 @@ struct March27Dev {
   int n_cols, ncls;
 };
 
-template <bool TWO, int MODE1, int NT, int NPM, int PITCH>
+template <bool TWO, int MODE1, int NT, int NPM, int PITCH, bool FZ = false>
 __global__ __launch_bounds__(NT, 4) void csr_rowclass_march27_spmv(March2Args a, March27Dev T) {
+  static_assert(!FZ || (TWO && MODE1 == SMOOTH), "the from-zero form is the pair's");
   extern __shared__ double win[];
   const int tid = threadIdx.x;
   const int w = xcd_band(blockIdx.x, T.nblocks);
@@ -73,6 +78,7 @@ __global__ __launch_bounds__(NT, 4) void csr_rowclass_march27_spmv(March2Args a,
   const int x0 = tx * T.TX, y0 = ty * T.TY;
   int pofs[NPM], pg[NPM];   // element index of the lane's pair inside a slab; in-plane index of its first element (before the even floor; may be negative)
   unsigned pflag = 0u;      // per m: bit 4m = the pair exists, bit 4m+1 = first pair of its line, bit 4m+2 = its line is inside the grid
+  int prp[FZ ? NPM : 1][3]; // FZ: cy*ncx + cx of the columns xb-1, xb, xb+1 of the pair's line (xb = its first column before the even floor), clamped into the grid
 #pragma unroll
   for (int m = 0; m < NPM; ++m) {
     const int pid = tid + m * NT;
@@ -80,6 +86,15 @@ __global__ __launch_bounds__(NT, 4) void csr_rowclass_march27_spmv(March2Args a,
     const int yl = y0 - GX + l;
     pofs[m] = l * PITCH + 2 * i;
     pg[m] = yl * T.n1 + x0 - GX + 2 * i;
+    if constexpr (FZ) {
+      const int yc = yl < 0 ? 0 : (yl >= T.n2 ? T.n2 - 1 : yl);
+      const int cyl = (int)cyG[yc] * T.ncx;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int xg = x0 - GX + 2 * i - 1 + k;
+        prp[m][k] = cyl + (int)cxG[xg < 0 ? 0 : (xg >= T.n1 ? T.n1 - 1 : xg)];
+      }
+    }
     if (pid < T.LY * T.NPL) pflag |= 1u << (4 * m);
     if (i == 0) pflag |= 2u << (4 * m);
     if (yl >= 0 && yl < T.n2) pflag |= 4u << (4 * m);
@@ -134,7 +149,18 @@ __global__ __launch_bounds__(NT, 4) void csr_rowclass_march27_spmv(March2Args a,
   do {                                                                                                                 \
     const bool act_ = ((pflag >> (4 * (m))) & 5u) == 5u && (p) >= 0 && (p) < T.nplanes;                                \
     const long long e0_ = ((long long)(p) * T.P + pg[m]) & ~1LL;                                                       \
-    (dst) = march_load_pair_raw(a.x, e0_, act_, T.n_cols);                                                             \
+    (dst) = march_load_pair_raw(FZ ? a.b : a.x, e0_, act_, T.n_cols);                                                  \
+  } while (0)
+  // FZ: the pair holds b of the entries (line, xb - par) and (line, xb - par + 1) of plane p: make it x1 = d.*b
+#define M27_SCALE(v, p, m)                                                                                             \
+  do {                                                                                                                 \
+    if constexpr (FZ) {                                                                                                \
+      const int par_ = M27_PAR(p, m);                                                                                  \
+      const int zb_ = M27_CZ(p) * zstride;                                                                             \
+      const int k0_ = par_ ? prp[m][0] : prp[m][1], k1_ = par_ ? prp[m][1] : prp[m][2];                                \
+      (v).x = dcl[(int)tabL[zb_ + k0_]].d * (v).x;                                                                     \
+      (v).y = dcl[(int)tabL[zb_ + k1_]].d * (v).y;                                                                     \
+    }                                                                                                                  \
   } while (0)
 #define M27_FIXPAIR(v, p, m)                                                                                           \
   do {                                                                                                                 \
@@ -195,9 +221,11 @@ __global__ __launch_bounds__(NT, 4) void csr_rowclass_march27_spmv(March2Args a,
       if (tid < nm) czL[tid] = creg;
       for (int i = tid + NT; i < nm; i += NT) czL[i] = czG[i];
     }
+    if (FZ) __syncthreads();                                      // (the first staged plane is scaled through the dictionaries)
 #pragma unroll
     for (int m = 0; m < NPM; ++m) {
       M27_FIXPAIR(q0[m], zA + 1, m);
+      M27_SCALE(q0[m], zA + 1, m);
       M27_STAGE((zA + 1) & 1, zA + 1, m, q0[m]);
     }
     const int rp = live1 ? cyv * T.ncx + cxv : 0;       // class of the row in plane z = tab[cz[z]*zstride + rp]
@@ -225,6 +253,7 @@ __global__ __launch_bounds__(NT, 4) void csr_rowclass_march27_spmv(March2Args a,
 #pragma unroll
         for (int m = 0; m < NPM; ++m) {
           M27_FIXPAIR(cur[m], z + 2, m);
+          M27_SCALE(cur[m], z + 2, m);
           M27_STAGE((z + 2) & 1, z + 2, m, cur[m]);
         }
       }
@@ -315,6 +344,7 @@ __global__ __launch_bounds__(NT, 4) void csr_rowclass_march27_spmv(March2Args a,
 #undef M27_PAR
 #undef M27_LOADPAIR
 #undef M27_FIXPAIR
+#undef M27_SCALE
 #undef M27_STAGE
 #undef M27_OPERANDS
 }

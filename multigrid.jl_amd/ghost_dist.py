@@ -32,6 +32,7 @@ by tests/test_ghost_dist.py) and the ctypes binding of the device side.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -414,7 +415,7 @@ class NativeGhostHierarchy:
                 dist.broadcast_object_list(box, src=0, group=group)
             uid, uid2 = C.create_string_buffer(box[0], 128), C.create_string_buffer(box[1], 128)
         D._check(lib, lib.mg_ghost_attach(h, rank, size, G.a, uid), "mg_ghost_attach")
-        if uid2 is not None:
+        if uid2 is not None and os.environ.get("MG_GHOST_ONE_COMM", "0") != "1":      # (=1: send / receive share the first communicator)
             D._check(lib, lib.mg_ghost_set_side_comm(h, uid2), "mg_ghost_set_side_comm")
         self._cb = None
         if transport == "dry":

@@ -96,3 +96,44 @@ def test_solve_with_27_point_marching_levels(mg, built, monkeypatch, cells, leve
         mg.clear_(p)
     assert np.array_equal(runs["m27"][0], runs["tile"][0])
     assert np.array_equal(runs["m27"][1], runs["tile"][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells,levels,cyc", [([32, 48, 32], 4, "V"), ([38, 70, 44], 3, "W")])
+def test_27_point_pair_from_zero(mg, built, monkeypatch, cells, levels, cyc):
+    """V(2,1): a 27-point level is entered with x = 0 (MGcycle.jl:29), so its first update is x1 = d.*b - formed INSIDE the pair's walk
+    (x1 = d.*b ; sweep ; residual: three stages, x not read; the restriction into the level writes no x1).  Same bits as the pair
+    reading the x1 the restriction wrote (MG_NO_MARCH27_ZERO=1) and as the plane tiles; history and iterate against the oracle; the
+    pair of level 2 moved one vector less per launch."""
+    _env(monkeypatch)
+    runs, moved = {}, {}
+    for name, env in (("zero", {}), ("x1", {"MG_NO_MARCH27_ZERO": "1"}), ("tile", {"MG_NO_MARCH27": "1"})):
+        for k in ("MG_NO_MARCH27_ZERO", "MG_NO_MARCH27"):
+            monkeypatch.setenv(k, env.get(k, "0"))
+        A, p, b = _setup(mg, cells, levels, cyc=cyc, pre=2, post=1, maxIter=5)
+        h = mg.to_device(p)
+        h.profile_enable(True)
+        x = np.zeros_like(b)
+        _, _, it = mg.solveMG(p, b, x)
+        prof, mv = h.profile(), h.profile_moved()
+        h.profile_enable(False)
+        if name != "tile":
+            assert h.sweep_residual_form(2)[0] == 5
+            moved[name] = mv[(2, "smooth+residual")]
+            assert (2, "dscale") not in prof
+        hist = {}
+        xo = np.zeros_like(b)
+        _, _, ito = orc.solveMG(p, b, xo, False, hist)
+        assert it == ito
+        assert np.abs(p.resvec - hist["resvec"]).max() / hist["resvec"][0] < RES_TOL
+        assert np.abs(x - xo).max() <= RES_TOL * np.abs(xo).max()
+        runs[name] = (x.copy(), np.asarray(p.resvec).copy())
+        n2 = p.As[1].shape[0]
+        mg.clear_(p)
+    for other in ("x1", "tile"):
+        assert np.array_equal(runs["zero"][0], runs[other][0])
+        assert np.array_equal(runs["zero"][1], runs[other][1])
+    if cyc == "V":      # every visit of level 2 starts from x = 0: each pair launch read b only
+        assert moved["x1"] - moved["zero"] == 8.0 * n2, (moved, n2)
+    else:               # (W: the second visit carries x)
+        assert 0.0 < moved["x1"] - moved["zero"] < 8.0 * n2, (moved, n2)
