@@ -328,6 +328,183 @@ __global__ __launch_bounds__(256) void grid27_band_spmv(Band27Dev T, VecArgs v) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Two launches of a small level as ONE (round 6).  The cycle of a level below ~300 000 rows is a chain of launches of 4.5-9 us each
+// for microseconds of work (levels 3-6 of C2: 20 % of the step for 1.9 % of the rows); two of its pairs have a consumer that reads
+// nothing but the producer's 3 x 3 x 3 neighbourhood, so a workgroup can make what it needs itself, in LDS:
+//   grid27_small_resid_restrict  r = b - A x (MGcycle.jl:58-60) on the 9^3 fine nodes around a 4 x 4 x 4 tile of coarse nodes, then
+//                                bc = R r (l.66) on the tile [and the coarse level's first update d.*bc]: r never reaches memory;
+//                                1.42 x the level's residuals are computed (the tiles' shared faces), from ONE staging of x
+//   grid27_small_prolong_smooth  x + P xc (l.90) on the 10 x 10 x 6 nodes around an 8 x 8 x 4 tile of fine nodes, then one sweep
+//                                y = (x + P xc) + d.*(b - A (x + P xc)) (l.92-102, 129-131) on the tile: the corrected x never reaches memory
+// Same expressions, same order of the products as grid27_small_spmv / grid_wave_restrict / grid_small_prolong: same bits (a node
+// outside the grid stages 0 where those kernels multiply a clamped neighbour by the value 0: a zero may change its sign).
+// Ordinary grid pairs only (fine = 2 * coarse - 1 nodes; not the embedded pairs of the sharded cycle).
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int SRR_CT = 4, SRR_XR = 2 * SRR_CT + 3, SRR_RR = 2 * SRR_CT + 1;     // coarse tile edge; edges of the staged x / r bricks
+constexpr int SRR_NX = SRR_XR * SRR_XR * SRR_XR, SRR_NR = SRR_RR * SRR_RR * SRR_RR;
+constexpr int SRR_XPL = (SRR_NX + 255) / 256, SRR_RPL = (SRR_NR + 255) / 256;   // entries of x / rows of r per lane
+// (every global load a phase needs is issued BEFORE the barrier in front of it: the phases themselves touch LDS and registers only)
+__global__ __launch_bounds__(256) void grid27_small_resid_restrict(Small27Dev A, SmallRDev R, double scale, const double* __restrict__ x,
+                                                                   const double* __restrict__ b, double* __restrict__ bc,
+                                                                   const double* __restrict__ d2, double* __restrict__ y2) {
+  __shared__ double xs[SRR_NX];
+  __shared__ double rs[SRR_NR];
+  __shared__ double recs[27 * 28];
+  const int tid = threadIdx.x;
+  const int tx_n = (R.nc1 + SRR_CT - 1) / SRR_CT, ty_n = (R.nc2 + SRR_CT - 1) / SRR_CT;
+  const int bz = (int)blockIdx.x / (tx_n * ty_n), brem = (int)blockIdx.x - bz * tx_n * ty_n, by = brem / tx_n, bx = brem - by * tx_n;
+  const int cx0 = bx * SRR_CT, cy0 = by * SRR_CT, cz0 = bz * SRR_CT;
+  const int fx0 = 2 * cx0 - 2, fy0 = 2 * cy0 - 2, fz0 = 2 * cz0 - 2;              // first node of the x brick
+  double xr[SRR_XPL], pb[SRR_RPL], rc[3];
+  int code[SRR_RPL];
+#pragma unroll
+  for (int u = 0; u < SRR_XPL; ++u) {
+    const int i = tid + u * 256;
+    const int uz = i / (SRR_XR * SRR_XR), ur = i - uz * SRR_XR * SRR_XR, uy = ur / SRR_XR, ux = ur - uy * SRR_XR;
+    const int fz = fz0 + uz, fy = fy0 + uy, fx = fx0 + ux;
+    const bool in = i < SRR_NX && fz >= 0 && fz < A.n3 && fy >= 0 && fy < A.n2 && fx >= 0 && fx < A.n1;
+    xr[u] = in ? x[fz * A.P + fy * A.n1 + fx] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < SRR_RPL; ++u) {
+    const int i = tid + u * 256;
+    const int tz = i / (SRR_RR * SRR_RR), tr = i - tz * SRR_RR * SRR_RR, ty = tr / SRR_RR, tx = tr - ty * SRR_RR;
+    const int fz = fz0 + 1 + tz, fy = fy0 + 1 + ty, fx = fx0 + 1 + tx;
+    const bool in = i < SRR_NR && fz >= 0 && fz < A.n3 && fy >= 0 && fy < A.n2 && fx >= 0 && fx < A.n1;
+    pb[u] = in ? b[fz * A.P + fy * A.n1 + fx] : 0.0;
+    code[u] = in ? (small_code1(fz, A.n3) * 3 + small_code1(fy, A.n2)) * 3 + small_code1(fx, A.n1) : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u) rc[u] = tid + u * 256 < 27 * 28 ? A.rec[tid + u * 256] : 0.0;
+  // the coarse node of the last phase (lanes 0 .. 63)
+  const int lz = (tid & 63) / (SRR_CT * SRR_CT), lr = (tid & 63) - lz * SRR_CT * SRR_CT, ly = lr / SRR_CT, lx = lr - ly * SRR_CT;
+  const int k = cz0 + lz, j = cy0 + ly, ii = cx0 + lx;
+  const bool cown = tid < SRR_CT * SRR_CT * SRR_CT && k < R.nc3 && j < R.nc2 && ii < R.nc1;
+  const int crow = cown ? k * R.Pc + j * R.nc1 + ii : 0;
+  const double pd = (cown && y2) ? d2[crow] : 0.0;
+#pragma unroll
+  for (int u = 0; u < SRR_XPL; ++u)
+    if (tid + u * 256 < SRR_NX) xs[tid + u * 256] = xr[u];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+    if (tid + u * 256 < 27 * 28) recs[tid + u * 256] = rc[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < SRR_RPL; ++u) {
+    const int i = tid + u * 256;
+    if (i >= SRR_NR) break;
+    const int tz = i / (SRR_RR * SRR_RR), tr = i - tz * SRR_RR * SRR_RR, ty = tr / SRR_RR, tx = tr - ty * SRR_RR;
+    double out = 0.0;
+    if (code[u] >= 0) {
+      const double* rec = recs + code[u] * 28;
+      double rv[27], xv[27];
+#pragma unroll
+      for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int s_ = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+            rv[s_] = rec[s_];
+            xv[s_] = xs[((tz + 1 + dz) * SRR_XR + (ty + 1 + dy)) * SRR_XR + (tx + 1 + dx)];
+          }
+      double acc = 0.0;
+#pragma unroll
+      for (int s_ = 0; s_ < 27; ++s_) acc = acc + rv[s_] * xv[s_];
+      out = pb[u] - acc;
+    }
+    rs[i] = out;
+  }
+  __syncthreads();
+  if (!cown) return;
+  const double wxm = ii > 0 ? 0.5 : 0.0, wxp = ii < R.nc1 - 1 ? 0.5 : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const bool ez = dz == 0 || (dz < 0 ? k > 0 : k < R.nc3 - 1), ey = dy == 0 || (dy < 0 ? j > 0 : j < R.nc2 - 1);
+      const double wl = (ez && ey) ? scale * (dz ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) : 0.0;
+      const double* q = rs + ((2 * lz + 1 + dz) * SRR_RR + (2 * ly + 1 + dy)) * SRR_RR + 2 * lx + 1;
+      acc = acc + (wl * wxm) * q[-1];
+      acc = acc + wl * q[0];
+      acc = acc + (wl * wxp) * q[1];
+    }
+  bc[crow] = acc;
+  if (y2) y2[crow] = pd * acc;
+}
+
+constexpr int SPS_TX = 8, SPS_TY = 8, SPS_TZ = 4, SPS_XX = SPS_TX + 2, SPS_XY = SPS_TY + 2, SPS_XZ = SPS_TZ + 2;
+constexpr int SPS_NX = SPS_XZ * SPS_XY * SPS_XX, SPS_XPL = (SPS_NX + 255) / 256;
+__global__ __launch_bounds__(256) void grid27_small_prolong_smooth(Small27Dev A, SmallPDev T, const double* __restrict__ xc, const double* __restrict__ x,
+                                                                   const double* __restrict__ b, double* __restrict__ y) {
+  __shared__ double xs[SPS_NX];
+  const int tid = threadIdx.x;
+  const int tx_n = (A.n1 + SPS_TX - 1) / SPS_TX, ty_n = (A.n2 + SPS_TY - 1) / SPS_TY;
+  const int bz = (int)blockIdx.x / (tx_n * ty_n), brem = (int)blockIdx.x - bz * tx_n * ty_n, by = brem / tx_n, bx = brem - by * tx_n;
+  const int x0 = bx * SPS_TX, y0 = by * SPS_TY, z0 = bz * SPS_TZ;
+  // the lane's own row and everything it needs from memory, in flight beside the staging loads
+  const int lz = tid / (SPS_TY * SPS_TX), lr = tid - lz * SPS_TY * SPS_TX, ly = lr / SPS_TX, lx = lr - ly * SPS_TX;
+  const int oz_ = z0 + lz, oy_ = y0 + ly, ox_ = x0 + lx;
+  const bool own = oz_ < A.n3 && oy_ < A.n2 && ox_ < A.n1;
+  const int orow = own ? oz_ * A.P + oy_ * A.n1 + ox_ : 0;
+  const int ocode = own ? (small_code1(oz_, A.n3) * 3 + small_code1(oy_, A.n2)) * 3 + small_code1(ox_, A.n1) : 13;
+  const double* __restrict__ rec = A.rec + ocode * 28;
+  double rv[27];
+#pragma unroll
+  for (int s_ = 0; s_ < 27; ++s_) rv[s_] = rec[s_];
+  const double pb = b[orow], pd = rec[27];
+  double st[SPS_XPL];
+#pragma unroll
+  for (int u = 0; u < SPS_XPL; ++u) {
+    const int i = tid + u * 256;
+    const int uz = i / (SPS_XY * SPS_XX), ur = i - uz * SPS_XY * SPS_XX, uy = ur / SPS_XX, ux = ur - uy * SPS_XX;
+    const int z = z0 - 1 + uz, yy = y0 - 1 + uy, xx = x0 - 1 + ux;
+    double out = 0.0;
+    if (i < SPS_NX && z >= 0 && z < A.n3 && yy >= 0 && yy < A.n2 && xx >= 0 && xx < A.n1) {      // (grid_small_prolong's row, kept in LDS)
+      const int row = z * T.Pf + yy * T.nf1 + xx;
+      const int oz = z & 1, oy = yy & 1, ox = xx & 1;
+      const int c0 = ((z >> 1) + T.o3) * T.Pc + ((yy >> 1) + T.o2) * T.nc1 + (xx >> 1) + T.o1;
+      const double wz = oz ? 0.5 : 1.0, wy = oy ? 0.5 : 1.0, wx = ox ? 0.5 : 1.0;
+      const double w = wz * wy * wx;
+      double xv[8];
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const bool on = (((s_ >> 2) & 1) <= oz) && (((s_ >> 1) & 1) <= oy) && ((s_ & 1) <= ox);
+        xv[s_] = 0.0;
+        if (on) xv[s_] = xc[c0 + ((s_ >> 2) & 1) * T.Pc + ((s_ >> 1) & 1) * T.nc1 + (s_ & 1)];
+      }
+      const double px = x[row];
+      double acc = 0.0;
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const bool on = (((s_ >> 2) & 1) <= oz) && (((s_ >> 1) & 1) <= oy) && ((s_ & 1) <= ox);
+        acc = acc + (on ? w : 0.0) * xv[s_];
+      }
+      out = 1.0 * acc + 1.0 * px;
+    }
+    st[u] = out;
+  }
+#pragma unroll
+  for (int u = 0; u < SPS_XPL; ++u)
+    if (tid + u * 256 < SPS_NX) xs[tid + u * 256] = st[u];
+  __syncthreads();
+  if (!own) return;
+  double xv[27];
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        xv[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] = xs[((lz + 1 + dz) * SPS_XY + (ly + 1 + dy)) * SPS_XX + (lx + 1 + dx)];
+  double acc = 0.0;
+#pragma unroll
+  for (int s_ = 0; s_ < 27; ++s_) acc = acc + rv[s_] * xv[s_];
+  y[orow] = xv[13] + pd * (pb - acc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Long rows: one WAVEFRONT per row.  The Galerkin levels of an SA-AMG hierarchy on anisotropic diffusion carry rows of a few hundred
 // to several thousand entries (SA-AMG.jl:44-50: the smoothed prolongation widens every coarse stencil; BASELINE config C3: levels 3-5
 // hold 80 % of the hierarchy's 2.5 G non-zeros).  The LDS-staged segmented reduction of csr_stream_spmv serves them at 0.36-0.58 of

@@ -87,6 +87,45 @@ def test_solves_with_small_level_kernels_match_the_oracle(mg, built, cells, leve
     mg.clear_(p)
 
 
+@pytest.mark.parametrize("cells,levels,cyc,pre,post", [([32, 32, 32], 4, "V", 2, 1), ([36, 20, 28], 3, "W", 1, 2), ([64, 48], 4, "F", 2, 2), ([24, 40, 16], 3, "K", 2, 1)])
+def test_two_launches_of_a_small_level_as_one(mg, built, monkeypatch, cells, levels, cyc, pre, post):
+    """grid27_small_resid_restrict (r = b - A x formed in LDS inside the restriction's launch, MGcycle.jl:58-66) and
+    grid27_small_prolong_smooth (x + P xc formed in LDS inside the first post-sweep's launch, MGcycle.jl:90-102): the same iterates
+    and residual history, bit for bit, as the launches they replace (MG_NO_SMALL_FUSE=1), and the oracle's to 1e-10; the profile
+    shows the fused launches and no residual launch on the levels they serve."""
+    runs = {}
+    for name, off in (("fused", "0"), ("plain", "1")):
+        monkeypatch.setenv("MG_NO_SMALL_FUSE", off)
+        A, mesh = mg.poisson_shifted(cells)
+        p = mg.getMGparam(np.float64, np.int64, levels, 8, 5, 1e-10, "Jac", 0.8, pre, post, cyc, "NoMUMPS", 0.5, 0.0)
+        mg.MGsetup(A, mesh, p)
+        b = mg.seeded_rhs(A)
+        h = mg.to_device(p)
+        h.profile_enable(True)
+        x = np.zeros_like(b)
+        _, _, it = mg.solveMG(p, b, x)
+        prof = h.profile()
+        h.profile_enable(False)
+        fused_levels = [l for (l, k) in prof if k == "smooth+prolong"]
+        if off == "0":
+            assert fused_levels, prof.keys()
+            if cyc != "K":
+                for l in fused_levels:      # (level 1's residual launches are the solve loop's own: the stopping test)
+                    assert ((l, "residual") not in prof or l == 1) and (l, "prolong") not in prof, (l, prof.keys())
+        else:
+            assert not fused_levels
+        hist = {}
+        xo = np.zeros_like(b)
+        _, _, ito = orc.solveMG(p, b, xo, False, hist)
+        assert it == ito
+        assert np.abs(p.resvec - hist["resvec"]).max() <= 1e-10 * hist["resvec"][0]
+        assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+        runs[name] = (x.copy(), np.asarray(p.resvec).copy())
+        mg.clear_(p)
+    assert np.array_equal(runs["fused"][0], runs["plain"][0])
+    assert np.array_equal(runs["fused"][1], runs["plain"][1])
+
+
 def test_small_levels_follow_new_values(mg, built):
     """replaceMatrixInHierarchy on the device (mg_rap_FP64): the position-code records are rebuilt from the new values."""
     A, p = _hier(mg, [16, 16, 16], 3)
