@@ -115,11 +115,32 @@ __device__ __forceinline__ d2_t wr_load_pair(const double* __restrict__ r, long 
   v.y = 0.0;
   return v;
 }
+// fs (optional; round 6): ONE more workgroup at the end of the grid adds up the np per-workgroup partial sums of the pass that ran in front
+// of this launch (sum_final_mirror's job: the solve loop's ||r||^2 of the four-stage pass - the fine restriction is the next launch of
+// every step, and a launch of its own for 245 numbers cost the step 4 us of kernel + 5 us of idle queue behind it)
+struct FinalSum {
+  const double* partial;
+  int np;
+  double* out;
+  double* host_mirror;
+};
 __global__ __launch_bounds__(256) void grid_wave_restrict(SmallRDev T, double scale, const double* __restrict__ r, double* __restrict__ bc,
-                                                          const double* __restrict__ d2, double* __restrict__ y2) {
+                                                          const double* __restrict__ d2, double* __restrict__ y2, FinalSum fs) {
   const int lane = threadIdx.x & 63;
+  const int nwg = (int)gridDim.x - (fs.partial ? 1 : 0);
+  if ((int)blockIdx.x == nwg) {      // (uniform: the extra workgroup; the same code as sum_final_mirror - same bits)
+    __shared__ double red[BLK / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < fs.np; i += BLK) acc += fs.partial[i];
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+      fs.out[0] = s;
+      fs.host_mirror[0] = s;
+    }
+    return;
+  }
   // (workgroups take the coarse nodes in XCD bands: the fine lines two neighbouring coarse lines / planes share are re-read from that L2)
-  const long long wv = (long long)xcd_band((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
+  const long long wv = (long long)xcd_band((int)blockIdx.x, nwg) * 4 + (threadIdx.x >> 6);
   const long long c = wv * 62 + lane - 1;
   const bool own = lane >= 1 && lane <= 62 && c < T.nc;
   const long long cc = c < 0 ? 0 : (c >= T.nc ? (long long)T.nc - 1 : c);     // (halo lanes beyond the ends: their values meet the weight 0)

@@ -134,3 +134,35 @@ def test_solve_with_the_four_stage_pass(mg, built, monkeypatch, cells, levels, c
     assert np.array_equal(runs["four"][2], runs["two"][2])
     assert np.abs(runs["four"][1] - runs["two"][1]).max() <= 1e-14 * runs["two"][1][0]
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tol", [0.0, 2e-3])
+def test_final_sum_inside_the_fine_restriction(mg, built, monkeypatch, tol):
+    """Default formats: the ||r||^2 partials of a four-stage pass are added up by one more workgroup of the launch behind it - the fine
+    restriction of the next cycle (grid_wave_restrict's FinalSum) - instead of a launch of their own: the same history bit for bit as with
+    MG_NO_DEFER_SUM=1, by count and when the stopping test ends the loop early, and the oracle's to 1e-10."""
+    runs = {}
+    monkeypatch.setenv("MG_MARCH_MIN_WG", "0")      # (the marching forms on a grid of 181 000 rows; everything else as shipped)
+    for name, off in (("inside", "0"), ("own", "1")):
+        monkeypatch.setenv("MG_NO_DEFER_SUM", off)
+        A, p, b = _setup(mg, [64, 48, 56], 4, tol=tol, maxIter=6, cyc="V")
+        h = mg.to_device(p)
+        from multigrid_jl_amd import device as D
+        assert h.four_stage_form(1)[0] and h.operator_kernel_variant(1, D.MG_OP_R) == 11      # (the wavefront restriction)
+        x = np.zeros_like(b)
+        _, _, it = mg.solveMG(p, b, x)
+        runs[name] = (x.copy(), np.asarray(p.resvec).copy(), it)
+        if name == "inside":
+            hist = {}
+            xo = np.zeros_like(b)
+            _, _, ito = orc.solveMG(p, b, xo, False, hist)
+            assert it == ito
+            assert np.abs(p.resvec - hist["resvec"]).max() / hist["resvec"][0] < RES_TOL
+            assert np.abs(x - xo).max() <= RES_TOL * np.abs(xo).max()
+        mg.clear_(p)
+    if tol > 0.0:
+        assert 1 < runs["inside"][2] < 6
+    assert runs["inside"][2] == runs["own"][2]
+    assert np.array_equal(runs["inside"][0], runs["own"][0])
+    assert np.array_equal(runs["inside"][1], runs["own"][1])
