@@ -58,7 +58,7 @@ typedef struct mg_hierarchy mg_hierarchy;
 #define MG_K_DSCALE 5   /* x = d.*b (first sweep from x=0) (MGcycle.jl:134)            */
 #define MG_K_COARSE 6   /* xc = LU \ bc                    (MGcycle.jl:177)            */
 #define MG_K_NORM 7     /* ||r||^2                         (SolveFuncs.jl:30)          */
-#define MG_K_SMOOTH_PROLONG 8 /* RETIRED in round 6 (the prolongation fused into the first post-sweep: slower than its two launches in every round); the slot keeps its number */
+#define MG_K_SMOOTH_PROLONG 8 /* small levels (round 6): x + P*xc formed in LDS inside the first post-smoothing sweep's launch (grid27_small_prolong_smooth; MGcycle.jl:90-102); profile slot only.  (The fine-level form of rounds 2-5 - the prolongation inside the marching sweep's staging - was slower in every round and is retired.)  A small level's residual + restriction as one launch (grid27_small_resid_restrict) is counted under MG_K_RESTRICT */
 #define MG_K_SMOOTH_RESIDUAL 9 /* t = x + d.*(b - A*x) and r = b - A*t in one pass (MGcycle.jl:129-131 + 58-60 / SolveFuncs.jl:26-27) */
 #define MG_K_SMOOTH_RESIDUAL_NORM 10 /* the same pass in the solve loop: last post-smoothing sweep + the stopping test's residual: ||r||^2 and t + d.*r out (SolveFuncs.jl:26-30); profile slot only */
 #define MG_K_FOUR_STAGE 11 /* solve loop, fine level: the last post-smoothing sweep + stopping-test residual of step k AND the second pre-smoothing sweep + residual of step k+1 in one pass (SolveFuncs.jl:24-37 around MGcycle.jl:26-31,54-60): x, b in; t', r' and ||r||^2 out; profile slot only */
