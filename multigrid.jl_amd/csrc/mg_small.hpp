@@ -108,12 +108,18 @@ __global__ __launch_bounds__(256) void grid27_small_restrict(SmallRDev T, const 
 // memory, (r[2i-1], r[2i]) where it is odd - and takes the third value from its neighbour lane by a wavefront shuffle.  Every fine entry
 // is loaded once per line it is used in, every load of a wavefront is one contiguous kilobyte.  Products added in ascending fine column
 // order = the CSR row of R: the bits of the kernels above.
-__device__ __forceinline__ d2_t wr_load_pair(const double* __restrict__ r, long long pb, long long nf) {
-  if (pb + 1 < nf) return *reinterpret_cast<const d2_t*>(r + pb);
-  d2_t v;
-  v.x = r[pb];
-  v.y = 0.0;
-  return v;
+// One 16-byte pair (r[pb], r[pb + 1]), no branch, no bounds test (round 6: a test per load cost every wavefront ~8 instructions x 9 in a kernel
+// whose 450 instructions per wavefront, not its bytes, set its time).  The only pair without a second entry starts at the LAST fine node,
+// pb = nf - 1: nf is odd (2m - 1 nodes per direction), so with a 16-byte aligned vector that pair lies inside one aligned 16-byte granule
+// - the 8 bytes behind the vector are in the same page, whoever owns them; the caller never USES that entry (wr_neighbour / the weight test).
+__device__ __forceinline__ d2_t wr_load_pair(const double* __restrict__ r, long long pb) { return *reinterpret_cast<const d2_t*>(r + pb); }
+// the neighbour lane's value by a wavefront shift on the vector pipe (DPP wave_shr:1 / wave_shl:1; lanes 0 / 63 keep 0: halo lanes)
+template <int CTRL>
+__device__ __forceinline__ double wr_neighbour(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
 }
 // fs (optional; round 6): ONE more workgroup at the end of the grid adds up the np per-workgroup partial sums of the pass that ran in front
 // of this launch (sum_final_mirror's job: the solve loop's ||r||^2 of the four-stage pass - the fine restriction is the next launch of
@@ -140,11 +146,27 @@ __global__ __launch_bounds__(256) void grid_wave_restrict(SmallRDev T, double sc
     return;
   }
   // (workgroups take the coarse nodes in XCD bands: the fine lines two neighbouring coarse lines / planes share are re-read from that L2)
-  const long long wv = (long long)xcd_band((int)blockIdx.x, nwg) * 4 + (threadIdx.x >> 6);
-  const long long c = wv * 62 + lane - 1;
+  const int wv = __builtin_amdgcn_readfirstlane(xcd_band((int)blockIdx.x, nwg) * 4 + (int)(threadIdx.x >> 6));
+  const int c = wv * 62 + lane - 1;
   const bool own = lane >= 1 && lane <= 62 && c < T.nc;
-  const long long cc = c < 0 ? 0 : (c >= T.nc ? (long long)T.nc - 1 : c);     // (halo lanes beyond the ends: their values meet the weight 0)
-  const int kk = (int)(cc / T.Pc), rem = (int)(cc - (long long)kk * T.Pc), jj = rem / T.nc1, ii = rem - jj * T.nc1;
+  const int cc = c < 0 ? 0 : (c >= T.nc ? T.nc - 1 : c);     // (halo lanes beyond the ends: their values meet the weight 0)
+  // (k, j, i) of the node: the two divisions once per WAVEFRONT on the scalar unit (its first node), the lanes step from there - a line
+  // of >= 64 coarse nodes is left at most once inside a wavefront
+  int kk, jj, ii;
+  if (T.nc1 >= 64) {
+    const int cb = wv * 62 - 1 < 0 ? 0 : (wv * 62 - 1 >= T.nc ? T.nc - 1 : wv * 62 - 1);   // (uniform)
+    const int kb = cb / T.Pc, rb = cb - kb * T.Pc, jb = rb / T.nc1, ib = rb - jb * T.nc1;
+    ii = ib + (cc - cb);
+    jj = jb;
+    kk = kb;
+    if (ii >= T.nc1) { ii -= T.nc1; ++jj; }
+    if (jj >= T.nc2) { jj -= T.nc2; ++kk; }
+  } else {
+    kk = cc / T.Pc;
+    const int rem = cc - kk * T.Pc;
+    jj = rem / T.nc1;
+    ii = rem - jj * T.nc1;
+  }
   // position inside the sub-box the fine grid pairs with (an ordinary pair: the whole coarse grid); a row outside it is empty: its
   // lanes load from the nearest node of the sub-box and every weight is 0
   const int k0 = kk - T.o3, j0 = jj - T.o2, i0 = ii - T.o1;
@@ -152,6 +174,7 @@ __global__ __launch_bounds__(256) void grid_wave_restrict(SmallRDev T, double sc
   const int k = k0 < 0 ? 0 : (k0 >= T.m3 ? T.m3 - 1 : k0), j = j0 < 0 ? 0 : (j0 >= T.m2 ? T.m2 - 1 : j0), i = i0 < 0 ? 0 : (i0 >= T.m1 ? T.m1 - 1 : i0);
   const long long centre = (long long)(2 * k) * T.Pf + (long long)(2 * j) * T.nf1 + 2 * i;     // (even: an aligned pair starts there)
   const double wxm = (inside && i > 0) ? 0.5 : 0.0, wxp = (inside && i < T.m1 - 1) ? 0.5 : 0.0;
+  const bool lastnode = centre + 1 >= T.nf;      // (its aligned pairs have no second entry: never used, see wr_load_pair)
   double acc = 0.0;
 #pragma unroll
   for (int dz = -1; dz <= 1; ++dz)
@@ -165,13 +188,13 @@ __global__ __launch_bounds__(256) void grid_wave_restrict(SmallRDev T, double sc
       const long long f = ex ? centre + (long long)dz * T.Pf + (long long)dy * T.nf1 : (aligned ? centre : (centre > 0 ? centre - 1 : 1));
       double vm, v0, vp;
       if (aligned) {
-        const d2_t q = wr_load_pair(r, f, T.nf);
-        vm = __shfl_up(q.y, 1);
+        const d2_t q = wr_load_pair(r, f);
+        vm = wr_neighbour<0x138>(q.y);           // lane - 1's second entry
         v0 = q.x;
-        vp = q.y;
+        vp = lastnode ? 0.0 : q.y;
       } else {
-        const d2_t q = wr_load_pair(r, f - 1, T.nf);
-        vp = __shfl_down(q.x, 1);
+        const d2_t q = wr_load_pair(r, f - 1);
+        vp = wr_neighbour<0x130>(q.x);           // lane + 1's first entry
         vm = q.x;
         v0 = q.y;
       }
@@ -222,7 +245,23 @@ __global__ __launch_bounds__(256) void grid_cell_prolong(SmallPDev T, const doub
   const int cs = (int)(xcd_band((int)blockIdx.x, (int)gridDim.x) * 256 + threadIdx.x);   // (XCD bands: the coarse corners neighbouring cells share)
   const int Pm = T.m1 * T.m2;                                                  // cells of the sub-box the fine grid pairs with
   if (cs >= Pm * T.m3) return;
-  const int k = cs / Pm, rem = cs - k * Pm, j = rem / T.m1, i = rem - j * T.m1;
+  // (k, j, i) of the cell: the two divisions once per WAVEFRONT on the scalar unit, the lanes step from its first cell (a line of >= 64 cells
+  // is left at most once inside a wavefront)
+  int k, j, i;
+  if (T.m1 >= 64) {
+    const int cb = __builtin_amdgcn_readfirstlane(cs);
+    const int kb = cb / Pm, rb = cb - kb * Pm, jb = rb / T.m1, ib = rb - jb * T.m1;
+    i = ib + (cs - cb);
+    j = jb;
+    k = kb;
+    if (i >= T.m1) { i -= T.m1; ++j; }
+    if (j >= T.m2) { j -= T.m2; ++k; }
+  } else {
+    k = cs / Pm;
+    const int rem = cs - k * Pm;
+    j = rem / T.m1;
+    i = rem - j * T.m1;
+  }
   const int c = (k + T.o3) * T.Pc + (j + T.o2) * T.nc1 + i + T.o1;
   const bool hx = i + 1 < T.m1, hy = j + 1 < T.m2, hz = k + 1 < T.m3;         // the cell has odd fine nodes in that direction
   const int ox = hx ? 1 : 0, oy = hy ? T.nc1 : 0, oz = hz ? T.Pc : 0;
@@ -230,25 +269,40 @@ __global__ __launch_bounds__(256) void grid_cell_prolong(SmallPDev T, const doub
 #pragma unroll
   for (int s = 0; s < 8; ++s) cv[s] = xc[c + ((s >> 2) & 1) * oz + ((s >> 1) & 1) * oy + (s & 1) * ox];
   const long long f0 = (long long)(2 * k) * T.Pf + (long long)(2 * j) * T.nf1 + 2 * i;
+  // the cell's two fine nodes of a line (dx = 0, 1) travel as ONE 16-byte access (round 6; 8 loads + 8 stores of 8 bytes before): the lines
+  // with dz + dy odd start at an odd index - a 16-byte access at an 8-byte aligned address, which the hardware takes (march_load_pair_raw)
   double px[8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {          // u = (dz, dy)
+    const int dz = u >> 1, dy = u & 1;
+    const bool on0 = (!dz || hz) && (!dy || hy);
+    const long long f = on0 ? f0 + (long long)dz * T.Pf + dy * T.nf1 : f0;
+    const d2_t v = wr_load_pair(x, f);            // (the last cell of a line: its second entry is the next line's first node - loaded, not used)
+    px[2 * u] = v.x;
+    px[2 * u + 1] = v.y;
+  }
+  double out[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {          // t = (dz, dy, dx) of the fine node inside the cell
     const int dz = (t >> 2) & 1, dy = (t >> 1) & 1, dx = t & 1;
-    const bool on = (!dz || hz) && (!dy || hy) && (!dx || hx);
-    px[t] = on ? x[f0 + (long long)dz * T.Pf + dy * T.nf1 + dx] : 0.0;
-  }
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int dz = (t >> 2) & 1, dy = (t >> 1) & 1, dx = t & 1;
-    const bool on = (!dz || hz) && (!dy || hy) && (!dx || hx);
     const double w = (dz ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dx ? 0.5 : 1.0);
     double acc = 0.0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {        // the corners this node takes: those not beyond it in any direction
-      const bool take = (((s >> 2) & 1) <= dz) && (((s >> 1) & 1) <= dy) && ((s & 1) <= dx);
-      acc = acc + (take ? w : 0.0) * cv[s];
+    for (int s = 0; s < 8; ++s) {        // the corners this node takes: those not beyond it in any direction (the others carried the weight 0:
+      const bool take = (((s >> 2) & 1) <= dz) && (((s >> 1) & 1) <= dy) && ((s & 1) <= dx);   // 37 of the 64 products of a cell - dropped)
+      if (take) acc = acc + w * cv[s];
     }
-    if (on) x[f0 + (long long)dz * T.Pf + dy * T.nf1 + dx] = 1.0 * acc + 1.0 * px[t];
+    out[t] = 1.0 * acc + 1.0 * px[t];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int dz = u >> 1, dy = u & 1;
+    const bool on0 = (!dz || hz) && (!dy || hy);
+    const long long f = f0 + (long long)dz * T.Pf + dy * T.nf1;
+    if (on0) {
+      if (hx) *reinterpret_cast<d2_t*>(x + f) = d2_t{out[2 * u], out[2 * u + 1]};
+      else x[f] = out[2 * u];
+    }
   }
 }
 
