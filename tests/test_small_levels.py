@@ -126,6 +126,45 @@ def test_two_launches_of_a_small_level_as_one(mg, built, monkeypatch, cells, lev
     assert np.array_equal(runs["fused"][1], runs["plain"][1])
 
 
+def test_transfer_kernels_take_unaligned_vectors_through_another_form(mg, built):
+    """grid_wave_restrict / grid_cell_prolong read the fine vector in 16-byte pairs (the pair at the last entry of an odd-length vector stays
+    inside one aligned granule ONLY for a 16-byte aligned base): a vector at an 8-byte aligned address takes another kernel, same result."""
+    import torch
+    from multigrid_jl_amd import device as D
+    A, p = _hier(mg, [24, 16, 32], 3)
+    h = D.DeviceHierarchy(p, 0, 1)
+    try:
+        rng = np.random.default_rng(11)
+        Pl, Rl = p.Ps[0], p.Rs[0]
+        n, nc = Pl.shape
+        x, xc = rng.standard_normal(n), rng.standard_normal(nc)
+        big = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        xa = torch.from_numpy(x).cuda()
+        xu = big[1:]
+        xu.copy_(xa)
+        assert xa.data_ptr() % 16 == 0 and xu.data_ptr() % 16 == 8
+        ya, yu = torch.zeros(nc, dtype=torch.float64, device="cuda"), torch.zeros(nc, dtype=torch.float64, device="cuda")
+        h.spmv_dev(1, D.MG_OP_R, 1.0, xa, 0.0, ya)
+        h.spmv_dev(1, D.MG_OP_R, 1.0, xu, 0.0, yu)
+        ref = Rl @ x
+        assert np.abs(ya.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert np.abs(yu.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+        xct = torch.from_numpy(xc).cuda()
+        fa = xa.clone()
+        big2 = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        fu = big2[1:]
+        fu.copy_(xa)
+        h.spmv_dev(1, D.MG_OP_P, 1.0, xct, 1.0, fa)
+        h.spmv_dev(1, D.MG_OP_P, 1.0, xct, 1.0, fu)
+        ref = x + Pl @ xc
+        assert np.abs(fa.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert np.abs(fu.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert big2[0].item() == 0.0
+    finally:
+        h.close()
+    mg.clear_(p)
+
+
 def test_small_levels_follow_new_values(mg, built):
     """replaceMatrixInHierarchy on the device (mg_rap_FP64): the position-code records are rebuilt from the new values."""
     A, p = _hier(mg, [16, 16, 16], 3)
